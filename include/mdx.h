@@ -1,0 +1,218 @@
+/*
+ * mdx.h — C ABI of the MI355X-native MD force engine that sits behind Molchanica's `src/md`
+ * step loop.
+ *
+ * Every entry point below replaces one use of the (external, absent) `dynamics` crate that the
+ * reference makes; the reference call site is cited as  [ref: file:line]  relative to
+ * /root/reference.  The Rust host binds these with a plain `extern "C"` block (see
+ * INTEGRATION.md); no library-allocated memory crosses the ABI, all outputs are caller-allocated.
+ *
+ * Units (from the reference UI, src/ui/popup/ff_params.rs:343-344,392-393,465-467; md_viewer.rs:201-256):
+ *   length Å, time ps, mass Da, energy kcal/mol, charge e, angles rad, bond k kcal/mol/Å²,
+ *   angle k kcal/mol/rad².  Engine state is f32 (src/md/mod.rs:848-852, dt: f32 at :699).
+ *
+ * Threading: a handle is NOT thread-safe (the reference holds `&mut MdState`, src/md/mod.rs:748);
+ * any one thread at a time may call into it.  The library uses its own non-default HIP stream.
+ */
+#ifndef MDX_H
+#define MDX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (ParamError{descrip} analogue, src/md/mod.rs:967) ------------------------- */
+#define MDX_OK       0
+#define MDX_EPARAM  (-1) /* bad system / config (the reference's ParamError)                      */
+#define MDX_EDEVICE (-2) /* no usable GPU / HIP error; host falls back like src/util.rs:1072-1119 */
+#define MDX_ENAN    (-3) /* non-finite state detected (blow-up; cf. sol_shrinking_box.rs:776-789) */
+#define MDX_EOOM    (-4) /* device or host allocation failed                                     */
+
+/* ---- MdOverrides switches  [ref: src/md/mod.rs:671-682; src/mol_editor/mod.rs:869-875] ------ */
+#define MDX_OVR_BONDED_DISABLED           0x1u
+#define MDX_OVR_COULOMB_DISABLED          0x2u
+#define MDX_OVR_LJ_DISABLED               0x4u
+#define MDX_OVR_LONG_RANGE_RECIP_DISABLED 0x8u /* always effectively set: cutoff Coulomb only   */
+
+/* ---- per-atom flags  [ref: AtomDynamics.static_/bonded_only, src/docking/mod.rs:260-262] ---- */
+#define MDX_ATOM_STATIC      0x1u /* never integrated (infinite mass)                             */
+#define MDX_ATOM_BONDED_ONLY 0x2u /* takes part in bonded terms only (no LJ / Coulomb)            */
+#define MDX_ATOM_GHOST       0x4u /* multi-GPU halo copy: position is imposed each step, never
+                                     integrated, its force is not reported                       */
+
+/* ---- Coulomb treatment inside the cutoff ----------------------------------------------------- */
+#define MDX_COULOMB_SHIFTED   0 /* E = k q q (1/r - 1/rc), F = k q q / r^2          (default)     */
+#define MDX_COULOMB_REACTION  1 /* reaction field eps_rf = inf: F = k q q (1/r^2 - r/rc^3)        */
+#define MDX_COULOMB_EWALD     2 /* SPME real-space part: E = k q q erfc(a r)/r                    */
+
+#define MDX_COMBINE_LORENTZ_BERTHELOT 0 /* sigma_ij=(si+sj)/2, eps_ij=sqrt(ei ej)   (default)     */
+#define MDX_COMBINE_GEOMETRIC         1 /* sigma_ij=sqrt(si sj), eps_ij=sqrt(ei ej)               */
+
+/* which array mdx_download / mdx_upload moves  [ref: md.atoms[i].posit/.force,
+ * src/mol_alignment.rs:349-352; src/properties/sol_shrinking_box.rs:777-786] */
+#define MDX_POS   0
+#define MDX_VEL   1
+#define MDX_FORCE 2
+
+/* Flat SoA system description: what `MdState::new(dev,&cfg,&mols,param_set)` receives after the
+ * host has parameterised its molecules  [ref: src/md/mod.rs:689, 1110-1151].  All pointers are
+ * host memory; the handle copies everything, the caller may free immediately. */
+typedef struct mdx_system {
+    uint32_t n_atoms;
+    const float*    pos;       /* [3N] Å, xyz interleaved                                         */
+    const float*    vel;       /* [3N] Å/ps or NULL (zero)   [ref: atom_init_velocities, :1146]   */
+    const float*    mass;      /* [N]  Da                                                         */
+    const float*    charge;    /* [N]  e                                                          */
+    const uint32_t* lj_type;   /* [N]  index into lj_sigma/lj_eps                                 */
+    uint32_t        n_lj_types;
+    const float*    lj_sigma;  /* [T]  Å          [ref: ff_params.rs:564-576 lennard_jones{sigma,eps}] */
+    const float*    lj_eps;    /* [T]  kcal/mol                                                   */
+    const uint8_t*  flags;     /* [N]  MDX_ATOM_* or NULL                                         */
+
+    uint32_t        n_bonds;       /* E = k (r - r0)^2          [ref: ff_params.rs:352-372]       */
+    const uint32_t* bond_idx;      /* [2*n_bonds]                                                 */
+    const float*    bond_k;
+    const float*    bond_r0;
+
+    uint32_t        n_angles;      /* E = k (theta - theta0)^2  [ref: ff_params.rs:401-421]       */
+    const uint32_t* angle_idx;     /* [3*n_angles]  i-j-k, j is the apex                          */
+    const float*    angle_k;
+    const float*    angle_theta0;  /* rad                                                         */
+
+    uint32_t        n_dihedrals;   /* E = v [1 + cos(n phi - phase)], v = barrier_height/divider  */
+    const uint32_t* dihedral_idx;  /* [4*n_dihedrals]  proper i-j-k-l; improper as listed          */
+    const float*    dihedral_v;    /*                           [ref: ff_params.rs:474-511]       */
+    const float*    dihedral_phase;/* rad                                                         */
+    const int32_t*  dihedral_n;    /* periodicity                                                 */
+
+    const uint32_t* excl_offsets;  /* [N+1] CSR of fully excluded partners (1-2, 1-3), symmetric  */
+    const uint32_t* excl_idx;
+    uint32_t        n_pairs14;     /* 1-4 pairs: excluded from the pair loop, evaluated scaled    */
+    const uint32_t* pairs14_idx;   /* [2*n_pairs14]                                               */
+
+    uint32_t        n_mols;        /* [ref: md.mol_start_indices, src/md/mod.rs:809-947]          */
+    const uint32_t* mol_start;     /* [n_mols] first atom of each molecule, or NULL               */
+
+    int32_t periodic;              /* 1: orthorhombic PBC in box_lo..box_hi; 0: vacuum            */
+    float   box_lo[3];             /* [ref: SimBox{bounds_low,bounds_high}, sol_shrinking_box.rs:600-603] */
+    float   box_hi[3];
+} mdx_system;
+
+/* The subset of MdConfig the force/integrate path reads  [ref: src/ui/panels/md.rs:252-261,
+ * 291-305; src/md/mod.rs:671-686].  Fill with mdx_config_default() first. */
+typedef struct mdx_config {
+    float    lj_cutoff;        /* Å; <=0 or inf: no cutoff (vacuum only)       [ref: md.rs:252-261] */
+    float    coulomb_cutoff;   /* Å                                                               */
+    float    skin;             /* Å Verlet buffer; lists rebuilt when max displacement > skin/2   */
+    float    coulomb_k;        /* 332.0637 kcal·Å/(mol·e²)                                        */
+    float    scale14_lj;       /* 0.5     (Amber 1/2.0)                                           */
+    float    scale14_coulomb;  /* 0.8333… (Amber 1/1.2)                                           */
+    int32_t  coulomb_mode;     /* MDX_COULOMB_*                                                   */
+    float    ewald_alpha;      /* 1/Å, MDX_COULOMB_EWALD only                                     */
+    int32_t  combining_rule;   /* MDX_COMBINE_*                                                   */
+    uint32_t overrides;        /* MDX_OVR_* bit set                                               */
+    float    softening_sq;     /* Å², added to r² in the Coulomb force (src/cuda/util.cu:9 uses 1e-6); default 0 */
+    uint32_t chunk_steps;      /* steps enqueued between host checks of the rebuild flag (default 16) */
+    uint32_t nb_variant;       /* 0 = library default; kernel selection knob for A/B measurement  */
+    uint32_t reserved[7];
+} mdx_config;
+
+/* Superset of SnapshotEnergyData  [ref: src/ui/panels/md_viewer.rs:195-257; src/md/mod.rs:1241-1245] */
+typedef struct mdx_energies {
+    double kinetic;             /* kcal/mol */
+    double potential;           /* = potential_nonbonded + potential_bonded */
+    double potential_nonbonded; /* lj + coulomb + lj14 + coulomb14 */
+    double potential_bonded;    /* bond + angle + dihedral */
+    double lj, coulomb, lj14, coulomb14;
+    double bond, angle, dihedral;
+    double temperature;         /* K, 2 KE / (dof kB), dof = 3 N_mobile - 3 (>=1) */
+    double volume;              /* Å³ (0 in vacuum) */
+    double density;             /* amu/Å³ (0 in vacuum) */
+    double virial;              /* sum r_ij·f_ij over non-bonded pairs (reserved, 0 for now) */
+    double max_force;           /* max |F| kcal/mol/Å — blow-up detector (sol_shrinking_box.rs:776-789) */
+} mdx_energies;
+
+/* Counters and timers (md.computation_time() analogue, src/md/mod.rs:740-743). */
+typedef struct mdx_stats {
+    uint64_t step_count;        /* [ref: md.step_count, src/md/mod.rs:738] */
+    uint64_t rebuild_count;
+    uint32_t n_atoms, n_slots, n_tiles, n_clusters;
+    uint64_t n_list_entries;    /* (tile, j-cluster) entries in the current pair list */
+    uint64_t n_masked_entries;
+    /* HIP-event timing of the kernels, filled only while mdx_profile(h,1) is on */
+    double   nb_ms_sum;    uint64_t nb_launches;
+    double   bonded_ms_sum; uint64_t bonded_launches;
+    double   integ_ms_sum;  uint64_t integ_launches;
+    double   rebuild_ms_sum;
+    double   wall_ms_sum;       /* host wall time inside mdx_step */
+} mdx_stats;
+
+typedef struct mdx_handle mdx_handle;
+
+/* Number of usable gfx950 devices; 0 lets the host keep its CPU path
+ * [ref: get_computation_device, src/util.rs:1072-1119]. */
+int mdx_device_count(void);
+
+/* Thread-local description of the last failure  [ref: ParamError.descrip]. */
+const char* mdx_last_error(void);
+
+void mdx_config_default(mdx_config* cfg);
+
+/* MdState::new  [ref: src/md/mod.rs:689; src/docking/mod.rs:235; src/mol_editor/mod.rs:901]. */
+int mdx_create(const mdx_system* sys, const mdx_config* cfg, int device, mdx_handle** out);
+void mdx_destroy(mdx_handle* h);
+
+/* MdState::step(&dev, dt, Option<Vec<Vec3F32>>) repeated n_steps times on the device
+ * [ref: src/md/mod.rs:716,748 (10-step GUI burst :737); src/mol_alignment.rs:346 (ext forces)].
+ * ext_forces: [3N] kcal/mol/Å in caller atom order, held constant over the burst, or NULL. */
+int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32_t n_steps);
+
+/* Forces + per-term energies of the current state without stepping (the per-snapshot
+ * energy_data, src/md/viewer.rs:378-394). */
+int mdx_energy(mdx_handle* h, mdx_energies* out);
+
+/* dynamics::compute_energy_snapshot  [ref: src/md/mod.rs:1036]: stateless single-point scorer.
+ * forces_or_null: [3N]. */
+int mdx_single_point(const mdx_system* sys, const mdx_config* cfg, int device,
+                     mdx_energies* out, float* forces_or_null);
+
+/* State read-back / host-side mutation  [ref: md.atoms[i].posit/.force public fields]. */
+int mdx_download(mdx_handle* h, int which, float* dst /* [3N] */);
+int mdx_upload(mdx_handle* h, int which, const float* src /* [3N] */);
+
+/* md.cell = SimBox::new(lo,hi) followed by md.rebuild_spatial_caches()
+ * [ref: src/properties/sol_shrinking_box.rs:600-603, 632]. */
+int mdx_set_box(mdx_handle* h, const float lo[3], const float hi[3]);
+int mdx_rebuild_spatial_caches(mdx_handle* h);
+
+uint64_t mdx_step_count(const mdx_handle* h);
+
+/* Verlet neighbour list of the current spatial caches, in caller atom order: all j != i with
+ * canonical fp32 minimum-image distance r2 < (max cutoff + skin)^2 at the positions of the last
+ * rebuild, each row sorted ascending.  Call with idx == NULL to get offsets[N+1] only
+ * (offsets[N] = total), then again with idx sized offsets[N]. */
+int mdx_neighbor_list(mdx_handle* h, uint32_t* offsets /* [N+1] */, uint32_t* idx /* or NULL */);
+
+/* Kernel timing with HIP events on the library's stream; mdx_get_stats reads the sums. */
+int mdx_profile(mdx_handle* h, int enable);
+int mdx_get_stats(mdx_handle* h, mdx_stats* out);
+
+/* ---- multi-GPU spatial decomposition support (no reference counterpart) ----------
+ * Ghost atoms (MDX_ATOM_GHOST) are part of the system passed to mdx_create.  Their positions are
+ * overwritten from a DEVICE buffer each step (the RCCL receive buffer), and owned positions are
+ * packed into a DEVICE send buffer by index list; both run on the library's stream, which the
+ * host obtains to order its collectives. */
+int   mdx_step_begin(mdx_handle* h, float dt, int first);  /* kick + drift of owned atoms       */
+int   mdx_pack_positions(mdx_handle* h, const uint32_t* d_atom_idx, uint32_t n, float* d_out4);
+int   mdx_unpack_positions(mdx_handle* h, const uint32_t* d_atom_idx, uint32_t n, const float* d_in4);
+int   mdx_step_end(mdx_handle* h, float dt, int last);     /* forces (+ closing half kick)       */
+int   mdx_needs_rebuild(mdx_handle* h, int* out);          /* max displacement > skin/2 ?        */
+void* mdx_stream(mdx_handle* h);                           /* hipStream_t                        */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDX_H */

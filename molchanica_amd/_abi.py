@@ -1,0 +1,220 @@
+"""ctypes mirror of include/mdx.h (struct layouts and constants).
+
+Kept free of any library loading so that the oracle wrapper and the CPU-only tests can use the
+same struct definitions without a GPU build being present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+MDX_OK, MDX_EPARAM, MDX_EDEVICE, MDX_ENAN, MDX_EOOM = 0, -1, -2, -3, -4
+
+OVR_BONDED_DISABLED = 0x1
+OVR_COULOMB_DISABLED = 0x2
+OVR_LJ_DISABLED = 0x4
+OVR_LONG_RANGE_RECIP_DISABLED = 0x8
+
+ATOM_STATIC, ATOM_BONDED_ONLY, ATOM_GHOST = 0x1, 0x2, 0x4
+
+COULOMB_SHIFTED, COULOMB_REACTION, COULOMB_EWALD = 0, 1, 2
+COMBINE_LORENTZ_BERTHELOT, COMBINE_GEOMETRIC = 0, 1
+
+POS, VEL, FORCE = 0, 1, 2
+
+_fp = C.POINTER(C.c_float)
+_u32p = C.POINTER(C.c_uint32)
+_i32p = C.POINTER(C.c_int32)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class CSystem(C.Structure):
+    _fields_ = [
+        ("n_atoms", C.c_uint32),
+        ("pos", _fp), ("vel", _fp), ("mass", _fp), ("charge", _fp),
+        ("lj_type", _u32p), ("n_lj_types", C.c_uint32),
+        ("lj_sigma", _fp), ("lj_eps", _fp), ("flags", _u8p),
+        ("n_bonds", C.c_uint32), ("bond_idx", _u32p), ("bond_k", _fp), ("bond_r0", _fp),
+        ("n_angles", C.c_uint32), ("angle_idx", _u32p), ("angle_k", _fp), ("angle_theta0", _fp),
+        ("n_dihedrals", C.c_uint32), ("dihedral_idx", _u32p), ("dihedral_v", _fp),
+        ("dihedral_phase", _fp), ("dihedral_n", _i32p),
+        ("excl_offsets", _u32p), ("excl_idx", _u32p),
+        ("n_pairs14", C.c_uint32), ("pairs14_idx", _u32p),
+        ("n_mols", C.c_uint32), ("mol_start", _u32p),
+        ("periodic", C.c_int32), ("box_lo", C.c_float * 3), ("box_hi", C.c_float * 3),
+    ]
+
+
+class CConfig(C.Structure):
+    _fields_ = [
+        ("lj_cutoff", C.c_float), ("coulomb_cutoff", C.c_float), ("skin", C.c_float),
+        ("coulomb_k", C.c_float), ("scale14_lj", C.c_float), ("scale14_coulomb", C.c_float),
+        ("coulomb_mode", C.c_int32), ("ewald_alpha", C.c_float), ("combining_rule", C.c_int32),
+        ("overrides", C.c_uint32), ("softening_sq", C.c_float), ("chunk_steps", C.c_uint32),
+        ("nb_variant", C.c_uint32), ("reserved", C.c_uint32 * 7),
+    ]
+
+
+class CEnergies(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "kinetic", "potential", "potential_nonbonded", "potential_bonded",
+        "lj", "coulomb", "lj14", "coulomb14", "bond", "angle", "dihedral",
+        "temperature", "volume", "density", "virial", "max_force")]
+
+    def as_dict(self) -> dict:
+        return {n: float(getattr(self, n)) for n, _ in self._fields_}
+
+
+class CStats(C.Structure):
+    _fields_ = [
+        ("step_count", C.c_uint64), ("rebuild_count", C.c_uint64),
+        ("n_atoms", C.c_uint32), ("n_slots", C.c_uint32), ("n_tiles", C.c_uint32),
+        ("n_clusters", C.c_uint32),
+        ("n_list_entries", C.c_uint64), ("n_masked_entries", C.c_uint64),
+        ("nb_ms_sum", C.c_double), ("nb_launches", C.c_uint64),
+        ("bonded_ms_sum", C.c_double), ("bonded_launches", C.c_uint64),
+        ("integ_ms_sum", C.c_double), ("integ_launches", C.c_uint64),
+        ("rebuild_ms_sum", C.c_double), ("wall_ms_sum", C.c_double),
+    ]
+
+    def as_dict(self) -> dict:
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+@dataclass
+class MdConfig:
+    """The force/integrate subset of the reference's `MdConfig`
+    (src/ui/panels/md.rs:252-261, 291-305; overrides src/md/mod.rs:671-686)."""
+    lj_cutoff: float = 10.0
+    coulomb_cutoff: float = 10.0
+    skin: float = 2.0
+    coulomb_k: float = 332.0637
+    scale14_lj: float = 0.5
+    scale14_coulomb: float = 1.0 / 1.2
+    coulomb_mode: int = COULOMB_SHIFTED
+    ewald_alpha: float = 0.0
+    combining_rule: int = COMBINE_LORENTZ_BERTHELOT
+    overrides: int = OVR_LONG_RANGE_RECIP_DISABLED
+    softening_sq: float = 0.0
+    chunk_steps: int = 16
+    nb_variant: int = 0
+
+    def to_c(self) -> CConfig:
+        c = CConfig()
+        for k in ("lj_cutoff", "coulomb_cutoff", "skin", "coulomb_k", "scale14_lj",
+                  "scale14_coulomb", "coulomb_mode", "ewald_alpha", "combining_rule",
+                  "overrides", "softening_sq", "chunk_steps", "nb_variant"):
+            setattr(c, k, getattr(self, k))
+        return c
+
+
+def _arr(a, dtype, shape=None):
+    a = np.ascontiguousarray(np.asarray(a, dtype=dtype))
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+@dataclass
+class MdSystem:
+    """Flat SoA system: the shape `setup_mols_dyn` hands to `MdState::new`
+    (src/md/mod.rs:1076-1157: atoms, atom_posits, atom_init_velocities, bonds, static_,
+    bonded_only), after parameterisation."""
+    pos: np.ndarray                       # [N,3] f32
+    mass: np.ndarray                      # [N]
+    charge: np.ndarray                    # [N]
+    lj_type: np.ndarray                   # [N] u32
+    lj_sigma: np.ndarray                  # [T]
+    lj_eps: np.ndarray                    # [T]
+    vel: np.ndarray | None = None         # [N,3]
+    flags: np.ndarray | None = None       # [N] u8
+    bond_idx: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.uint32))
+    bond_k: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))
+    bond_r0: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))
+    angle_idx: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.uint32))
+    angle_k: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))
+    angle_theta0: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))
+    dihedral_idx: np.ndarray = field(default_factory=lambda: np.zeros((0, 4), np.uint32))
+    dihedral_v: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))
+    dihedral_phase: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))
+    dihedral_n: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    excl_offsets: np.ndarray | None = None  # [N+1]
+    excl_idx: np.ndarray | None = None
+    pairs14_idx: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.uint32))
+    mol_start: np.ndarray | None = None
+    periodic: bool = False
+    box_lo: tuple = (0.0, 0.0, 0.0)
+    box_hi: tuple = (0.0, 0.0, 0.0)
+    name: str = ""
+
+    @property
+    def n_atoms(self) -> int:
+        return int(self.pos.shape[0])
+
+    def normalise(self) -> "MdSystem":
+        n = self.n_atoms
+        self.pos = _arr(self.pos, np.float32, (n, 3))
+        self.mass = _arr(self.mass, np.float32, (n,))
+        self.charge = _arr(self.charge, np.float32, (n,))
+        self.lj_type = _arr(self.lj_type, np.uint32, (n,))
+        self.lj_sigma = _arr(self.lj_sigma, np.float32)
+        self.lj_eps = _arr(self.lj_eps, np.float32)
+        if self.vel is not None:
+            self.vel = _arr(self.vel, np.float32, (n, 3))
+        if self.flags is not None:
+            self.flags = _arr(self.flags, np.uint8, (n,))
+        self.bond_idx = _arr(self.bond_idx, np.uint32, (-1, 2))
+        self.bond_k = _arr(self.bond_k, np.float32)
+        self.bond_r0 = _arr(self.bond_r0, np.float32)
+        self.angle_idx = _arr(self.angle_idx, np.uint32, (-1, 3))
+        self.angle_k = _arr(self.angle_k, np.float32)
+        self.angle_theta0 = _arr(self.angle_theta0, np.float32)
+        self.dihedral_idx = _arr(self.dihedral_idx, np.uint32, (-1, 4))
+        self.dihedral_v = _arr(self.dihedral_v, np.float32)
+        self.dihedral_phase = _arr(self.dihedral_phase, np.float32)
+        self.dihedral_n = _arr(self.dihedral_n, np.int32)
+        if self.excl_offsets is None:
+            self.excl_offsets = np.zeros(n + 1, np.uint32)
+            self.excl_idx = np.zeros(0, np.uint32)
+        self.excl_offsets = _arr(self.excl_offsets, np.uint32, (n + 1,))
+        self.excl_idx = _arr(self.excl_idx, np.uint32)
+        self.pairs14_idx = _arr(self.pairs14_idx, np.uint32, (-1, 2))
+        if self.mol_start is not None:
+            self.mol_start = _arr(self.mol_start, np.uint32)
+        return self
+
+    def to_c(self) -> CSystem:
+        """Returns a CSystem whose pointers alias this object's arrays (keep `self` alive)."""
+        self.normalise()
+        s = CSystem()
+
+        def p(a, t):
+            if a is None or a.size == 0:
+                return C.cast(None, t)
+            return a.ctypes.data_as(t)
+
+        s.n_atoms = self.n_atoms
+        s.pos, s.vel = p(self.pos, _fp), p(self.vel, _fp)
+        s.mass, s.charge = p(self.mass, _fp), p(self.charge, _fp)
+        s.lj_type, s.n_lj_types = p(self.lj_type, _u32p), int(self.lj_sigma.size)
+        s.lj_sigma, s.lj_eps = p(self.lj_sigma, _fp), p(self.lj_eps, _fp)
+        s.flags = p(self.flags, _u8p)
+        s.n_bonds = int(self.bond_idx.shape[0])
+        s.bond_idx, s.bond_k, s.bond_r0 = p(self.bond_idx, _u32p), p(self.bond_k, _fp), p(self.bond_r0, _fp)
+        s.n_angles = int(self.angle_idx.shape[0])
+        s.angle_idx, s.angle_k, s.angle_theta0 = (p(self.angle_idx, _u32p), p(self.angle_k, _fp),
+                                                  p(self.angle_theta0, _fp))
+        s.n_dihedrals = int(self.dihedral_idx.shape[0])
+        s.dihedral_idx, s.dihedral_v = p(self.dihedral_idx, _u32p), p(self.dihedral_v, _fp)
+        s.dihedral_phase, s.dihedral_n = p(self.dihedral_phase, _fp), p(self.dihedral_n, _i32p)
+        s.excl_offsets = self.excl_offsets.ctypes.data_as(_u32p)
+        s.excl_idx = p(self.excl_idx, _u32p)
+        s.n_pairs14, s.pairs14_idx = int(self.pairs14_idx.shape[0]), p(self.pairs14_idx, _u32p)
+        s.n_mols = 0 if self.mol_start is None else int(self.mol_start.size)
+        s.mol_start = p(self.mol_start, _u32p)
+        s.periodic = 1 if self.periodic else 0
+        s.box_lo = (C.c_float * 3)(*[float(v) for v in self.box_lo])
+        s.box_hi = (C.c_float * 3)(*[float(v) for v in self.box_hi])
+        return s

@@ -1,0 +1,632 @@
+// mdx_api.hip — handle life-cycle and the C ABI of include/mdx.h.
+//
+// Mirrors the surface of the (absent) `dynamics` crate that Molchanica consumes:
+//   MdState::new -> mdx_create            [ref: /root/reference src/md/mod.rs:689]
+//   MdState::step -> mdx_step             [ref: src/md/mod.rs:716,748; src/mol_alignment.rs:346]
+//   compute_energy_snapshot -> mdx_single_point / mdx_energy   [ref: src/md/mod.rs:1036]
+//   md.atoms[i].posit/.force -> mdx_download/mdx_upload        [ref: src/mol_alignment.rs:349-352]
+//   md.cell + rebuild_spatial_caches -> mdx_set_box / mdx_rebuild_spatial_caches
+//                                                   [ref: src/properties/sol_shrinking_box.rs:600-632]
+// There is no CPU fallback in this library: without a gfx950 device every entry point fails with
+// MDX_EDEVICE and the host keeps its own CPU path (src/util.rs:1072-1119 semantics).
+#include "mdx_internal.h"
+#include <algorithm>
+#include <chrono>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+static thread_local std::string g_last_error;
+void mdx_set_error(const std::string& s) { g_last_error = s; }
+
+static inline unsigned div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
+static bool cut_on(float rc) { return rc > 0.f && std::isfinite(rc); }
+static uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+static float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+#define FAIL(code, msg) do { mdx_set_error(msg); return (code); } while (0)
+
+template <typename T>
+static int upload_vec(T** dptr, const std::vector<T>& v, hipStream_t st) {
+    if (*dptr) { (void)hipFree(*dptr); *dptr = nullptr; }
+    HIP_TRY(hipMalloc((void**)dptr, std::max<size_t>(sizeof(T) * v.size(), 16)));
+    if (!v.empty()) HIP_TRY(hipMemcpyAsync(*dptr, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, st));
+    return MDX_OK;
+}
+template <typename T>
+static int alloc_n(T** dptr, size_t n) {
+    if (*dptr) { (void)hipFree(*dptr); *dptr = nullptr; }
+    HIP_TRY(hipMalloc((void**)dptr, std::max<size_t>(sizeof(T) * n, 16)));
+    return MDX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int mdx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char* mdx_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" void mdx_config_default(mdx_config* c) {
+    std::memset(c, 0, sizeof(*c));
+    c->lj_cutoff = 10.0f; c->coulomb_cutoff = 10.0f; c->skin = 2.0f;
+    c->coulomb_k = 332.0637f; c->scale14_lj = 0.5f; c->scale14_coulomb = 1.0f / 1.2f;
+    c->coulomb_mode = MDX_COULOMB_SHIFTED; c->combining_rule = MDX_COMBINE_LORENTZ_BERTHELOT;
+    c->overrides = MDX_OVR_LONG_RANGE_RECIP_DISABLED;
+    c->chunk_steps = 16;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int validate(const mdx_system* s, const mdx_config* c) {
+    if (!s || !c) FAIL(MDX_EPARAM, "null system or config");
+    const uint32_t N = s->n_atoms;
+    if (N == 0) FAIL(MDX_EPARAM, "system has no atoms");
+    if (N > (1u << 30)) FAIL(MDX_EPARAM, "too many atoms");
+    if (!s->pos || !s->mass || !s->charge || !s->lj_type || !s->lj_sigma || !s->lj_eps)
+        FAIL(MDX_EPARAM, "missing per-atom array (pos/mass/charge/lj_type/lj_sigma/lj_eps)");
+    if (s->n_lj_types == 0) FAIL(MDX_EPARAM, "no LJ types");
+    for (uint32_t i = 0; i < N; ++i) {
+        if (s->lj_type[i] >= s->n_lj_types) FAIL(MDX_EPARAM, "lj_type index out of range");
+        const bool fixed = s->flags && (s->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST));
+        if (!fixed && !(s->mass[i] > 0.f && std::isfinite(s->mass[i]))) FAIL(MDX_EPARAM, "non-positive mass");
+        if (!std::isfinite(s->charge[i])) FAIL(MDX_EPARAM, "non-finite charge");
+        for (int d = 0; d < 3; ++d)
+            if (!std::isfinite(s->pos[3 * i + d])) FAIL(MDX_EPARAM, "non-finite position");
+    }
+    for (uint32_t t = 0; t < s->n_lj_types; ++t)
+        if (!(s->lj_sigma[t] >= 0.f) || !(s->lj_eps[t] >= 0.f) || !std::isfinite(s->lj_sigma[t]) ||
+            !std::isfinite(s->lj_eps[t]))
+            FAIL(MDX_EPARAM, "LJ sigma/eps must be finite and non-negative");
+    auto chk = [&](const uint32_t* idx, uint32_t n, int w, const char* what) -> int {
+        if (n && !idx) FAIL(MDX_EPARAM, std::string("missing index array: ") + what);
+        for (size_t k = 0; k < (size_t)n * w; ++k)
+            if (idx[k] >= N) FAIL(MDX_EPARAM, std::string("atom index out of range in ") + what);
+        return MDX_OK;
+    };
+    MDX_TRY(chk(s->bond_idx, s->n_bonds, 2, "bonds"));
+    MDX_TRY(chk(s->angle_idx, s->n_angles, 3, "angles"));
+    MDX_TRY(chk(s->dihedral_idx, s->n_dihedrals, 4, "dihedrals"));
+    MDX_TRY(chk(s->pairs14_idx, s->n_pairs14, 2, "pairs14"));
+    if (s->n_bonds && (!s->bond_k || !s->bond_r0)) FAIL(MDX_EPARAM, "missing bond parameters");
+    if (s->n_angles && (!s->angle_k || !s->angle_theta0)) FAIL(MDX_EPARAM, "missing angle parameters");
+    if (s->n_dihedrals && (!s->dihedral_v || !s->dihedral_phase || !s->dihedral_n))
+        FAIL(MDX_EPARAM, "missing dihedral parameters");
+    if (s->excl_offsets) {
+        if (s->excl_offsets[0] != 0) FAIL(MDX_EPARAM, "excl_offsets[0] must be 0");
+        for (uint32_t i = 0; i < N; ++i)
+            if (s->excl_offsets[i + 1] < s->excl_offsets[i]) FAIL(MDX_EPARAM, "excl_offsets not monotone");
+        if (s->excl_offsets[N] && !s->excl_idx) FAIL(MDX_EPARAM, "missing excl_idx");
+        for (uint32_t k = 0; k < s->excl_offsets[N]; ++k)
+            if (s->excl_idx[k] >= N) FAIL(MDX_EPARAM, "exclusion index out of range");
+    }
+    if (!(c->skin >= 0.f) || !std::isfinite(c->skin)) FAIL(MDX_EPARAM, "skin must be finite and >= 0");
+    if (!(c->coulomb_k >= 0.f)) FAIL(MDX_EPARAM, "coulomb_k must be >= 0");
+    if (c->coulomb_mode < 0 || c->coulomb_mode > 2) FAIL(MDX_EPARAM, "unknown coulomb_mode");
+    if (c->combining_rule < 0 || c->combining_rule > 1) FAIL(MDX_EPARAM, "unknown combining_rule");
+    if (c->coulomb_mode == MDX_COULOMB_EWALD && !(c->ewald_alpha > 0.f))
+        FAIL(MDX_EPARAM, "ewald_alpha must be > 0 for MDX_COULOMB_EWALD");
+    return MDX_OK;
+}
+
+static int check_box(bool periodic, const float* lo, const float* hi, const mdx_config* c) {
+    if (!periodic) return MDX_OK;
+    if (!cut_on(c->lj_cutoff) || !cut_on(c->coulomb_cutoff))
+        FAIL(MDX_EPARAM, "a periodic system needs finite LJ and Coulomb cut-offs");
+    const float rl = std::max(c->lj_cutoff, c->coulomb_cutoff) + c->skin;
+    for (int d = 0; d < 3; ++d) {
+        const float L = hi[d] - lo[d];
+        if (!(L > 0.f) || !std::isfinite(L)) FAIL(MDX_EPARAM, "box extent must be positive");
+        if (L < 2.0f * rl)
+            FAIL(MDX_EPARAM, "box edge shorter than 2*(cutoff+skin): minimum image is not unique");
+    }
+    return MDX_OK;
+}
+
+static void free_device(mdx_handle* h) {
+    DeviceState& d = h->d;
+    void* ptrs[] = {d.o_qs, d.o_lj, d.o_invm, d.o_mass, d.o_q, d.o_lj_raw, d.excl_off, d.excl_idx, d.pos_orig,
+                    d.vel_orig, d.ext_orig, d.posq, d.lj, d.vel, d.force, d.ref, d.orig_of, d.slot_of, d.cell_of,
+                    d.cell_count, d.cell_start, d.cell_cursor, d.sorted_orig, d.col_tiles, d.tile_start,
+                    d.tile_col, d.scan_tmp, d.cl_lo, d.cl_hi, d.list_counts, d.entry_cnt, d.entry_off,
+                    d.mchunk_cnt, d.mchunk_off, d.entries, d.masks, d.bond_o, d.bond_s, d.bond_p, d.angle_o,
+                    d.angle_s, d.angle_p, d.dih_o, d.dih_s, d.dih_p, d.p14_o, d.p14_s, d.p14_p, d.ctl, d.energy,
+                    d.flags_dev, d.bbox_red};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    d = DeviceState{};
+}
+
+extern "C" void mdx_destroy(mdx_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& e : h->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& e : h->ev_pool) (void)hipEventDestroy(e);
+    free_device(h);
+    if (h->h_ctl) (void)hipHostFree(h->h_ctl);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx_handle* h) {
+    const uint32_t N = s->n_atoms;
+    h->N = N; h->cfg = *c; h->device = device;
+    if (h->cfg.chunk_steps == 0) h->cfg.chunk_steps = 16;
+    if (h->cfg.chunk_steps > MDX_MAX_CHUNK) h->cfg.chunk_steps = MDX_MAX_CHUNK;
+    h->periodic = s->periodic != 0;
+    for (int d = 0; d < 3; ++d) { h->box_lo[d] = s->box_lo[d]; h->box_hi[d] = s->box_hi[d]; }
+    MDX_TRY(check_box(h->periodic, h->box_lo, h->box_hi, c));
+    const bool all_cut = cut_on(c->lj_cutoff) && cut_on(c->coulomb_cutoff);
+    h->r_list = all_cut ? std::max(c->lj_cutoff, c->coulomb_cutoff) + c->skin : INFINITY;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) FAIL(MDX_EDEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) FAIL(MDX_EDEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    hipStream_t st = h->stream;
+    DeviceState& d = h->d;
+
+    // ---- static per-atom data ----
+    const bool lj_off = (c->overrides & MDX_OVR_LJ_DISABLED) != 0;
+    const bool coul_off = (c->overrides & MDX_OVR_COULOMB_DISABLED) != 0;
+    const bool geom = c->combining_rule == MDX_COMBINE_GEOMETRIC;
+    const float sqrt_ke = std::sqrt(c->coulomb_k);
+    std::vector<float> qs(N), invm(N), mass(N), q(N);
+    std::vector<float2> lj(N), ljraw(N);
+    h->flags.assign(N, 0);
+    h->n_mobile = 0; h->total_mass = 0.0;
+    for (uint32_t i = 0; i < N; ++i) {
+        const uint8_t fl = s->flags ? s->flags[i] : 0;
+        h->flags[i] = fl;
+        const bool nb_off = (fl & MDX_ATOM_BONDED_ONLY) != 0;
+        const bool fixed = (fl & (MDX_ATOM_STATIC | MDX_ATOM_GHOST)) != 0;
+        const float sg = s->lj_sigma[s->lj_type[i]], ep = s->lj_eps[s->lj_type[i]];
+        q[i] = (nb_off || coul_off) ? 0.f : s->charge[i];
+        qs[i] = q[i] * sqrt_ke;
+        const float ep_eff = (nb_off || lj_off) ? 0.f : ep;
+        lj[i] = make_float2(geom ? std::sqrt(sg) : 0.5f * sg, std::sqrt(24.0f * ep_eff));
+        ljraw[i] = make_float2(sg, ep_eff);
+        mass[i] = s->mass[i];
+        invm[i] = fixed ? 0.f : MDX_ACC_CONV / s->mass[i];
+        if (!fixed) { h->n_mobile++; }
+        if (!(fl & MDX_ATOM_GHOST)) h->total_mass += s->mass[i];
+    }
+    MDX_TRY(upload_vec(&d.o_qs, qs, st)); MDX_TRY(upload_vec(&d.o_lj, lj, st));
+    MDX_TRY(upload_vec(&d.o_invm, invm, st)); MDX_TRY(upload_vec(&d.o_mass, mass, st));
+    MDX_TRY(upload_vec(&d.o_q, q, st)); MDX_TRY(upload_vec(&d.o_lj_raw, ljraw, st));
+
+    // ---- merged exclusion CSR (1-2, 1-3 and 1-4), symmetric, sorted, unique ----
+    {
+        std::vector<std::vector<uint32_t>> ex(N);
+        if (s->excl_offsets)
+            for (uint32_t i = 0; i < N; ++i)
+                for (uint32_t k = s->excl_offsets[i]; k < s->excl_offsets[i + 1]; ++k) {
+                    const uint32_t j = s->excl_idx[k];
+                    if (j == i) continue;
+                    ex[i].push_back(j); ex[j].push_back(i);
+                }
+        for (uint32_t p = 0; p < s->n_pairs14; ++p) {
+            const uint32_t a = s->pairs14_idx[2 * p], b = s->pairs14_idx[2 * p + 1];
+            if (a == b) FAIL(MDX_EPARAM, "1-4 pair of an atom with itself");
+            ex[a].push_back(b); ex[b].push_back(a);
+        }
+        std::vector<uint32_t> off(N + 1, 0), idx;
+        for (uint32_t i = 0; i < N; ++i) {
+            std::sort(ex[i].begin(), ex[i].end());
+            ex[i].erase(std::unique(ex[i].begin(), ex[i].end()), ex[i].end());
+            if (ex[i].size() > 255) FAIL(MDX_EPARAM, "more than 255 exclusions on one atom");
+            off[i + 1] = off[i] + (uint32_t)ex[i].size();
+            idx.insert(idx.end(), ex[i].begin(), ex[i].end());
+        }
+        MDX_TRY(upload_vec(&d.excl_off, off, st)); MDX_TRY(upload_vec(&d.excl_idx, idx, st));
+    }
+
+    // ---- bonded terms ----
+    h->n_bonds = s->n_bonds; h->n_angles = s->n_angles; h->n_dih = s->n_dihedrals; h->n_p14 = s->n_pairs14;
+    {
+        std::vector<uint32_t> bi(s->bond_idx, s->bond_idx + 2 * (size_t)s->n_bonds);
+        std::vector<float2> bp(s->n_bonds);
+        for (uint32_t k = 0; k < s->n_bonds; ++k) bp[k] = make_float2(s->bond_k[k], s->bond_r0[k]);
+        MDX_TRY(upload_vec(&d.bond_o, bi, st)); MDX_TRY(upload_vec(&d.bond_p, bp, st));
+        MDX_TRY(alloc_n(&d.bond_s, bi.size()));
+        std::vector<uint32_t> ai(s->angle_idx, s->angle_idx + 3 * (size_t)s->n_angles);
+        std::vector<float2> ap(s->n_angles);
+        for (uint32_t k = 0; k < s->n_angles; ++k) ap[k] = make_float2(s->angle_k[k], s->angle_theta0[k]);
+        MDX_TRY(upload_vec(&d.angle_o, ai, st)); MDX_TRY(upload_vec(&d.angle_p, ap, st));
+        MDX_TRY(alloc_n(&d.angle_s, ai.size()));
+        std::vector<uint32_t> di(s->dihedral_idx, s->dihedral_idx + 4 * (size_t)s->n_dihedrals);
+        std::vector<float4> dp(s->n_dihedrals);
+        for (uint32_t k = 0; k < s->n_dihedrals; ++k)
+            dp[k] = make_float4(s->dihedral_v[k], s->dihedral_phase[k], (float)s->dihedral_n[k], 0.f);
+        MDX_TRY(upload_vec(&d.dih_o, di, st)); MDX_TRY(upload_vec(&d.dih_p, dp, st));
+        MDX_TRY(alloc_n(&d.dih_s, di.size()));
+        std::vector<uint32_t> pi(s->pairs14_idx, s->pairs14_idx + 2 * (size_t)s->n_pairs14);
+        std::vector<float4> pp(s->n_pairs14);
+        for (uint32_t k = 0; k < s->n_pairs14; ++k) {
+            const uint32_t a = pi[2 * k], b = pi[2 * k + 1];
+            const float sa = ljraw[a].x, sb = ljraw[b].x;
+            const float sig = geom ? std::sqrt(sa * sb) : 0.5f * (sa + sb);
+            const float eps = std::sqrt(ljraw[a].y * ljraw[b].y);
+            pp[k] = make_float4(sig, 4.0f * c->scale14_lj * eps, c->scale14_coulomb * c->coulomb_k * q[a] * q[b], 0.f);
+        }
+        MDX_TRY(upload_vec(&d.p14_o, pi, st)); MDX_TRY(upload_vec(&d.p14_p, pp, st));
+        MDX_TRY(alloc_n(&d.p14_s, pi.size()));
+    }
+
+    // ---- dynamic state staging ----
+    {
+        std::vector<float4> p4(N), v4(N);
+        for (uint32_t i = 0; i < N; ++i) {
+            p4[i] = make_float4(s->pos[3 * i], s->pos[3 * i + 1], s->pos[3 * i + 2], 0.f);
+            v4[i] = s->vel ? make_float4(s->vel[3 * i], s->vel[3 * i + 1], s->vel[3 * i + 2], 0.f)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (invm[i] == 0.f) v4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        MDX_TRY(upload_vec(&d.pos_orig, p4, st)); MDX_TRY(upload_vec(&d.vel_orig, v4, st));
+        MDX_TRY(alloc_n(&d.ext_orig, N));
+    }
+    MDX_TRY(alloc_n(&d.slot_of, N)); MDX_TRY(alloc_n(&d.cell_of, N)); MDX_TRY(alloc_n(&d.sorted_orig, N));
+    MDX_TRY(alloc_n(&d.ctl, 1)); MDX_TRY(alloc_n(&d.energy, EN_COUNT + 2)); MDX_TRY(alloc_n(&d.flags_dev, 4));
+    HIP_TRY(hipMemsetAsync(d.ctl, 0, sizeof(StepCtl), st));
+    HIP_TRY(hipMemsetAsync(d.energy, 0, sizeof(double) * (EN_COUNT + 2), st));
+    HIP_TRY(hipHostMalloc((void**)&h->h_ctl, sizeof(StepCtl), hipHostMallocDefault));
+    HIP_TRY(hipStreamSynchronize(st));  // host vectors go out of scope
+    h->in_slot_space = false; h->list_valid = false; h->forces_valid = false;
+    MDX_TRY(mdx_rebuild(h));
+    return MDX_OK;
+}
+
+extern "C" int mdx_create(const mdx_system* sys, const mdx_config* cfg, int device, mdx_handle** out) {
+    if (!out) FAIL(MDX_EPARAM, "null out pointer");
+    *out = nullptr;
+    MDX_TRY(validate(sys, cfg));
+    mdx_handle* h = new (std::nothrow) mdx_handle();
+    if (!h) FAIL(MDX_EOOM, "host allocation failed");
+    int rc = create_impl(sys, cfg, device, h);
+    if (rc != MDX_OK) { std::string keep = g_last_error; mdx_destroy(h); g_last_error = keep; return rc; }
+    *out = h;
+    return MDX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+static uint32_t stale_threshold_bits(const mdx_handle* h) {
+    if (std::isinf(h->r_list)) return f2u(1.0e29f);  // all pairs listed: never stale (NaN still trips)
+    const float half = 0.5f * h->cfg.skin;
+    return f2u(half * half);
+}
+
+static int compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint32_t thr) {
+    MDX_TRY(mdx_launch_nonbonded(h, energy, gate, thr));
+    MDX_TRY(mdx_launch_bonded(h, energy, gate, thr));
+    MDX_TRY(mdx_launch_add_ext(h, gate, thr));
+    return MDX_OK;
+}
+
+static int ensure_ready(mdx_handle* h) {
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->list_valid) MDX_TRY(mdx_rebuild(h));
+    if (!h->forces_valid) {
+        MDX_TRY(compute_forces(h, false, nullptr, 0));
+        h->forces_valid = true;
+    }
+    return MDX_OK;
+}
+
+// ---- profiling -------------------------------------------------------------------------------
+void mdx_prof_begin(mdx_handle* h, int kind) {
+    if (!h->profile) return;
+    mdx_handle::EvPair p{};
+    p.kind = kind;
+    hipEvent_t* ev[2] = {&p.a, &p.b};
+    for (auto e : ev) {
+        if (!h->ev_pool.empty()) { *e = h->ev_pool.back(); h->ev_pool.pop_back(); }
+        else (void)hipEventCreate(e);
+    }
+    (void)hipEventRecord(p.a, h->stream);
+    h->ev_pending.push_back(p);
+}
+void mdx_prof_end(mdx_handle* h) {
+    if (!h->profile || h->ev_pending.empty()) return;
+    (void)hipEventRecord(h->ev_pending.back().b, h->stream);
+}
+void mdx_prof_collect(mdx_handle* h) {
+    for (auto& p : h->ev_pending) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(p.b);
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            if (p.kind == 0) { h->stats.nb_ms_sum += ms; h->stats.nb_launches++; }
+            else if (p.kind == 1) { h->stats.bonded_ms_sum += ms; h->stats.bonded_launches++; }
+            else { h->stats.integ_ms_sum += ms; h->stats.integ_launches++; }
+        }
+        h->ev_pool.push_back(p.a); h->ev_pool.push_back(p.b);
+    }
+    h->ev_pending.clear();
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32_t n_steps) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    if (!std::isfinite(dt)) FAIL(MDX_EPARAM, "non-finite dt");
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    DeviceState& d = h->d;
+    // external forces (held constant over the burst)  [ref: src/mol_alignment.rs:318-346]
+    const bool had_ext = h->have_ext;
+    if (ext_forces) {
+        std::vector<float4> e4(h->N);
+        for (uint32_t i = 0; i < h->N; ++i)
+            e4[i] = make_float4(ext_forces[3 * i], ext_forces[3 * i + 1], ext_forces[3 * i + 2], 0.f);
+        HIP_TRY(hipMemcpyAsync(d.ext_orig, e4.data(), sizeof(float4) * h->N, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        h->have_ext = true; h->forces_valid = false;
+    } else if (had_ext) {
+        h->have_ext = false; h->forces_valid = false;
+    }
+    if (n_steps == 0) return MDX_OK;
+    MDX_TRY(ensure_ready(h));
+    const uint32_t thr = stale_threshold_bits(h);
+    uint32_t remaining = n_steps;
+    while (remaining) {
+        const uint32_t chunk = std::min(remaining, h->cfg.chunk_steps);
+        HIP_TRY(hipMemsetAsync(d.ctl, 0, sizeof(StepCtl), st));
+        for (uint32_t s = 0; s < chunk; ++s) {
+            MDX_TRY(mdx_launch_integrate(h, s == 0 ? 0 : 1, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr));
+            MDX_TRY(compute_forces(h, false, &d.ctl->disp2[s + 1], thr));
+        }
+        MDX_TRY(mdx_launch_integrate(h, 2, dt, &d.ctl->disp2[chunk], nullptr, thr));
+        HIP_TRY(hipMemcpyAsync(h->h_ctl, d.ctl, sizeof(StepCtl), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h->profile) mdx_prof_collect(h);
+        uint32_t done = chunk;
+        for (uint32_t s = 0; s < chunk; ++s) {
+            if (h->h_ctl->disp2[s + 1] > thr) {
+                if (u2f(h->h_ctl->disp2[s + 1]) > 1.0e29f) {
+                    h->forces_valid = false; h->list_valid = false;
+                    h->step_count += s;
+                    FAIL(MDX_ENAN, "non-finite or runaway coordinates during mdx_step");
+                }
+                // the drift of step s happened, its forces did not: rebuild, finish the step
+                h->list_valid = false;
+                MDX_TRY(mdx_rebuild(h));
+                MDX_TRY(compute_forces(h, false, nullptr, 0));
+                MDX_TRY(mdx_launch_integrate(h, 2, dt, nullptr, nullptr, thr));
+                done = s + 1;
+                break;
+            }
+        }
+        h->forces_valid = true;
+        h->step_count += done;
+        remaining -= done;
+    }
+    h->stats.wall_ms_sum +=
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MDX_OK;
+}
+
+extern "C" uint64_t mdx_step_count(const mdx_handle* h) { return h ? h->step_count : 0; }
+
+extern "C" int mdx_energy(mdx_handle* h, mdx_energies* out) {
+    if (!h || !out) FAIL(MDX_EPARAM, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->list_valid) MDX_TRY(mdx_rebuild(h));
+    hipStream_t st = h->stream;
+    HIP_TRY(hipMemsetAsync(h->d.energy, 0, sizeof(double) * (EN_COUNT + 2), st));
+    MDX_TRY(compute_forces(h, true, nullptr, 0));
+    h->forces_valid = true;
+    MDX_TRY(mdx_launch_kinetic(h));
+    double e[EN_COUNT + 2];
+    HIP_TRY(hipMemcpyAsync(e, h->d.energy, sizeof(e), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h->profile) mdx_prof_collect(h);
+    std::memset(out, 0, sizeof(*out));
+    out->bond = e[EN_BOND]; out->angle = e[EN_ANGLE]; out->dihedral = e[EN_DIHEDRAL];
+    out->lj = e[EN_LJ]; out->coulomb = e[EN_COUL]; out->lj14 = e[EN_LJ14]; out->coulomb14 = e[EN_COUL14];
+    out->kinetic = e[EN_KIN];
+    out->potential_bonded = out->bond + out->angle + out->dihedral;
+    out->potential_nonbonded = out->lj + out->coulomb + out->lj14 + out->coulomb14;
+    out->potential = out->potential_bonded + out->potential_nonbonded;
+    const double dof = std::max(1.0, 3.0 * (double)h->n_mobile - 3.0);
+    out->temperature = 2.0 * out->kinetic / (dof * MDX_KB);
+    if (h->periodic) {
+        out->volume = (double)(h->box_hi[0] - h->box_lo[0]) * (h->box_hi[1] - h->box_lo[1]) *
+                      (h->box_hi[2] - h->box_lo[2]);
+        out->density = h->total_mass / out->volume;
+    }
+    uint32_t mf2; std::memcpy(&mf2, &e[EN_COUNT], 4);
+    out->max_force = std::sqrt((double)u2f(mf2));
+    const double tot = out->potential + out->kinetic;
+    if (!std::isfinite(tot)) FAIL(MDX_ENAN, "non-finite energy");
+    return MDX_OK;
+}
+
+extern "C" int mdx_single_point(const mdx_system* sys, const mdx_config* cfg, int device, mdx_energies* out,
+                                float* forces_or_null) {
+    mdx_handle* h = nullptr;
+    MDX_TRY(mdx_create(sys, cfg, device, &h));
+    int rc = out ? mdx_energy(h, out) : MDX_OK;
+    if (rc == MDX_OK && forces_or_null) rc = mdx_download(h, MDX_FORCE, forces_or_null);
+    std::string keep = g_last_error;
+    mdx_destroy(h);
+    g_last_error = keep;
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int mdx_download(mdx_handle* h, int which, float* dst) {
+    if (!h || !dst) FAIL(MDX_EPARAM, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const uint32_t N = h->N;
+    const float4* src = nullptr;
+    if (which == MDX_POS || which == MDX_VEL) {
+        if (h->in_slot_space)
+            MDX_TRY(mdx_gather_to_orig(h, which == MDX_POS ? h->d.posq : h->d.vel,
+                                       which == MDX_POS ? h->d.pos_orig : h->d.vel_orig));
+        src = which == MDX_POS ? h->d.pos_orig : h->d.vel_orig;
+    } else if (which == MDX_FORCE) {
+        MDX_TRY(ensure_ready(h));
+        // cell_of/sorted_orig are rebuild scratch; borrow pos-sized scratch via a temporary buffer
+        float4* tmp = nullptr;
+        HIP_TRY(hipMalloc((void**)&tmp, sizeof(float4) * N));
+        int rc = mdx_gather_to_orig(h, h->d.force, tmp);
+        std::vector<float4> hf(N);
+        if (rc == MDX_OK) {
+            hipError_t e = hipMemcpyAsync(hf.data(), tmp, sizeof(float4) * N, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { (void)hipFree(tmp); FAIL(MDX_EDEVICE, hipGetErrorString(e)); }
+        }
+        (void)hipFree(tmp);
+        MDX_TRY(rc);
+        for (uint32_t i = 0; i < N; ++i) {
+            const bool ghost = (h->flags[i] & MDX_ATOM_GHOST) != 0;
+            dst[3 * i] = ghost ? 0.f : hf[i].x; dst[3 * i + 1] = ghost ? 0.f : hf[i].y;
+            dst[3 * i + 2] = ghost ? 0.f : hf[i].z;
+        }
+        return MDX_OK;
+    } else FAIL(MDX_EPARAM, "unknown array selector");
+    std::vector<float4> hb(N);
+    HIP_TRY(hipMemcpyAsync(hb.data(), src, sizeof(float4) * N, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (uint32_t i = 0; i < N; ++i) { dst[3 * i] = hb[i].x; dst[3 * i + 1] = hb[i].y; dst[3 * i + 2] = hb[i].z; }
+    return MDX_OK;
+}
+
+extern "C" int mdx_upload(mdx_handle* h, int which, const float* src) {
+    if (!h || !src) FAIL(MDX_EPARAM, "null argument");
+    if (which != MDX_POS && which != MDX_VEL) FAIL(MDX_EPARAM, "only MDX_POS and MDX_VEL can be uploaded");
+    HIP_TRY(hipSetDevice(h->device));
+    const uint32_t N = h->N;
+    for (size_t k = 0; k < 3 * (size_t)N; ++k)
+        if (!std::isfinite(src[k])) FAIL(MDX_EPARAM, "non-finite value in upload");
+    MDX_TRY(mdx_unsort_state(h));  // keep the other array: both now live in caller-order staging
+    std::vector<float4> b(N);
+    for (uint32_t i = 0; i < N; ++i) {
+        b[i] = make_float4(src[3 * i], src[3 * i + 1], src[3 * i + 2], 0.f);
+        if (which == MDX_VEL && (h->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST))) b[i] = make_float4(0, 0, 0, 0);
+    }
+    HIP_TRY(hipMemcpyAsync(which == MDX_POS ? h->d.pos_orig : h->d.vel_orig, b.data(), sizeof(float4) * N,
+                           hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->list_valid = false; h->forces_valid = false;
+    return MDX_OK;
+}
+
+extern "C" int mdx_set_box(mdx_handle* h, const float lo[3], const float hi[3]) {
+    if (!h || !lo || !hi) FAIL(MDX_EPARAM, "null argument");
+    if (!h->periodic) FAIL(MDX_EPARAM, "mdx_set_box on a non-periodic system");
+    MDX_TRY(check_box(true, lo, hi, &h->cfg));
+    HIP_TRY(hipSetDevice(h->device));
+    MDX_TRY(mdx_unsort_state(h));
+    for (int d = 0; d < 3; ++d) { h->box_lo[d] = lo[d]; h->box_hi[d] = hi[d]; }
+    h->list_valid = false; h->forces_valid = false;
+    return MDX_OK;
+}
+
+extern "C" int mdx_rebuild_spatial_caches(mdx_handle* h) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    h->list_valid = false;
+    MDX_TRY(mdx_rebuild(h));
+    return MDX_OK;
+}
+
+extern "C" int mdx_neighbor_list(mdx_handle* h, uint32_t* offsets, uint32_t* idx) {
+    if (!h || !offsets) FAIL(MDX_EPARAM, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->list_valid) MDX_TRY(mdx_rebuild(h));
+    return mdx_extract_neighbors(h, offsets, idx);
+}
+
+extern "C" int mdx_profile(mdx_handle* h, int enable) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    mdx_prof_collect(h);
+    h->profile = enable != 0;
+    if (enable) {
+        h->stats.nb_ms_sum = h->stats.bonded_ms_sum = h->stats.integ_ms_sum = 0.0;
+        h->stats.rebuild_ms_sum = h->stats.wall_ms_sum = 0.0;
+        h->stats.nb_launches = h->stats.bonded_launches = h->stats.integ_launches = 0;
+    }
+    return MDX_OK;
+}
+
+extern "C" int mdx_get_stats(mdx_handle* h, mdx_stats* out) {
+    if (!h || !out) FAIL(MDX_EPARAM, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    mdx_prof_collect(h);
+    h->stats.step_count = h->step_count; h->stats.rebuild_count = h->rebuild_count;
+    *out = h->stats;
+    return MDX_OK;
+}
+
+// ---- multi-GPU support: split step + halo pack/unpack -------------------------------------------
+__global__ void pack_pos_kernel(uint32_t n, const uint32_t* __restrict__ atom_idx, const uint32_t* __restrict__ slot_of,
+                                const float4* __restrict__ posq, float4* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = posq[slot_of[atom_idx[i]]];
+}
+__global__ void unpack_pos_kernel(uint32_t n, const uint32_t* __restrict__ atom_idx, const uint32_t* __restrict__ slot_of,
+                                  float4* __restrict__ posq, const float4* __restrict__ in) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = slot_of[atom_idx[i]];
+    const float4 v = in[i];
+    float4 p = posq[s];
+    p.x = v.x; p.y = v.y; p.z = v.z;
+    posq[s] = p;
+}
+
+extern "C" int mdx_step_begin(mdx_handle* h, float dt, int first) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    MDX_TRY(ensure_ready(h));
+    HIP_TRY(hipMemsetAsync(h->d.ctl, 0, sizeof(StepCtl), h->stream));
+    MDX_TRY(mdx_launch_integrate(h, first ? 0 : 1, dt, nullptr, &h->d.ctl->disp2[1], stale_threshold_bits(h)));
+    h->forces_valid = false;
+    return MDX_OK;
+}
+
+extern "C" int mdx_pack_positions(mdx_handle* h, const uint32_t* d_atom_idx, uint32_t n, float* d_out4) {
+    if (!h || (n && (!d_atom_idx || !d_out4))) FAIL(MDX_EPARAM, "null argument");
+    if (!h->in_slot_space) FAIL(MDX_EPARAM, "spatial caches not built");
+    if (n) hipLaunchKernelGGL(pack_pos_kernel, dim3(div_up(n, 256)), dim3(256), 0, h->stream, n, d_atom_idx,
+                              h->d.slot_of, h->d.posq, (float4*)d_out4);
+    HIP_TRY(hipGetLastError());
+    return MDX_OK;
+}
+
+extern "C" int mdx_unpack_positions(mdx_handle* h, const uint32_t* d_atom_idx, uint32_t n, const float* d_in4) {
+    if (!h || (n && (!d_atom_idx || !d_in4))) FAIL(MDX_EPARAM, "null argument");
+    if (!h->in_slot_space) FAIL(MDX_EPARAM, "spatial caches not built");
+    if (n) hipLaunchKernelGGL(unpack_pos_kernel, dim3(div_up(n, 256)), dim3(256), 0, h->stream, n, d_atom_idx,
+                              h->d.slot_of, h->d.posq, (const float4*)d_in4);
+    HIP_TRY(hipGetLastError());
+    h->forces_valid = false;
+    return MDX_OK;
+}
+
+extern "C" int mdx_step_end(mdx_handle* h, float dt, int last) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    MDX_TRY(compute_forces(h, false, nullptr, 0));
+    h->forces_valid = true;
+    if (last) MDX_TRY(mdx_launch_integrate(h, 2, dt, nullptr, nullptr, stale_threshold_bits(h)));
+    h->step_count += 1;
+    return MDX_OK;
+}
+
+extern "C" int mdx_needs_rebuild(mdx_handle* h, int* out) {
+    if (!h || !out) FAIL(MDX_EPARAM, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    uint32_t v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, &h->d.ctl->disp2[1], sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *out = v > stale_threshold_bits(h);
+    return MDX_OK;
+}
+
+extern "C" void* mdx_stream(mdx_handle* h) { return h ? (void*)h->stream : nullptr; }

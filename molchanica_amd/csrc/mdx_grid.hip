@@ -1,0 +1,825 @@
+// mdx_grid.hip — spatial caches: column grid, counting sort, tile/cluster formation, cluster
+// bounding boxes and the tile pair list with exclusion masks.  Hand-written HIP for gfx950.
+//
+// Replaces what `MdState::new` / `md.rebuild_spatial_caches()` do inside the absent `dynamics`
+// crate  [ref: /root/reference src/md/mod.rs:689; src/properties/sol_shrinking_box.rs:632].
+// Everything here is integer / bounding-box work and HBM-bound; it runs once per ~40-80 steps.
+//
+// Pipeline (all on the handle's stream):
+//   bin      atom -> (column, z-bin) cell id, wrap into the box, histogram       (1 thread/atom)
+//   scan     exclusive prefix over cells; per-column tile counts and prefix
+//   scatter  counting-sort scatter (arbitrary order inside a cell) ...
+//   cellsort ... made deterministic: each cell's handful of atoms sorted by (z, atom id)
+//   assign   one wavefront per tile: 64 z-consecutive atoms of a column, bitonic sub-sort by
+//            y | x | z so that each run of 8 lanes (a cluster) is a compact brick
+//   gather   slot-space arrays (posq, lj, vel, ref) from caller-order data; dummies parked far away
+//   bbox     per-cluster bounding boxes
+//   list     per tile: all (j-cluster, image) within r_list of the tile, with the per-i-cluster
+//            mask, exclusion-bearing entries first + their 64-bit per-lane interaction masks
+//   remap    bonded index lists caller order -> slot order
+#include "mdx_internal.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+#define WAVE_LDS_SYNC()                                      \
+    do {                                                     \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); \
+        __builtin_amdgcn_wave_barrier();                     \
+    } while (0)
+
+static inline unsigned div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+// ================================================================================================
+// exclusive scan of u32 (n elements; callers append a trailing 0 so out[n-1] is the total)
+// ================================================================================================
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* s_wave, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+        uint32_t x = s_wave[w];
+        if (w < wave) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tile_kernel(const uint32_t* __restrict__ in,
+                                                                 uint32_t* __restrict__ out,
+                                                                 uint32_t* __restrict__ tile_sums, uint32_t n) {
+    __shared__ uint32_t s_wave[SCAN_THREADS / 64];
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS], sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0u;
+        sum += v[k];
+    }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan_256(sum, s_wave, &total);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) out[base + k] = ex;
+        ex += v[k];
+    }
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_sums_kernel(uint32_t* __restrict__ sums, uint32_t nb) {
+    __shared__ uint32_t s_wave[SCAN_THREADS / 64];
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < nb; b0 += SCAN_THREADS) {
+        uint32_t i = b0 + threadIdx.x;
+        uint32_t v = (i < nb) ? sums[i] : 0u, total;
+        uint32_t ex = block_exclusive_scan_256(v, s_wave, &total);
+        if (i < nb) sums[i] = carry + ex;
+        carry += total;
+    }
+}
+
+__global__ void scan_add_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ sums, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += sums[i / SCAN_TILE];
+}
+
+int mdx_exclusive_scan_u32(mdx_handle* h, const uint32_t* in, uint32_t* out, uint32_t n) {
+    if (n == 0) return MDX_OK;
+    uint32_t nb = div_up(n, SCAN_TILE);
+    uint32_t* sums = h->d.scan_tmp;
+    hipLaunchKernelGGL(scan_tile_kernel, dim3(nb), dim3(SCAN_THREADS), 0, h->stream, in, out, sums, n);
+    if (nb > 1) {
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, h->stream, sums, nb);
+        hipLaunchKernelGGL(scan_add_kernel, dim3(div_up(n, 256)), dim3(256), 0, h->stream, out, sums, n);
+    }
+    HIP_TRY(hipGetLastError());
+    return MDX_OK;
+}
+
+// ================================================================================================
+// binning
+// ================================================================================================
+__device__ __forceinline__ float wrap1(float x, float lo, float L) {
+    float t = x - floorf((x - lo) / L) * L;
+    if (t < lo) t += L;
+    if (t >= lo + L) t -= L;
+    return t;
+}
+
+__global__ void bin_atoms_kernel(float4* __restrict__ pos_orig, uint32_t N, GridParams g,
+                                 uint32_t* __restrict__ cell_of, uint32_t* __restrict__ cell_count,
+                                 uint32_t* __restrict__ nonfinite) {
+    uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= N) return;
+    float4 p = pos_orig[o];
+    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {
+        atomicOr(nonfinite, 1u);
+        p.x = g.lo[0]; p.y = g.lo[1]; p.z = g.lo[2];
+    }
+    if (g.periodic) {
+        p.x = wrap1(p.x, g.lo[0], g.len[0]);
+        p.y = wrap1(p.y, g.lo[1], g.len[1]);
+        p.z = wrap1(p.z, g.lo[2], g.len[2]);
+    }
+    pos_orig[o] = p;
+    int cx = min(g.ncx - 1, max(0, (int)((p.x - g.lo[0]) * g.inv_col[0])));
+    int cy = min(g.ncy - 1, max(0, (int)((p.y - g.lo[1]) * g.inv_col[1])));
+    int zb = min(g.nzb - 1, max(0, (int)((p.z - g.lo[2]) * g.inv_zbin)));
+    uint32_t cell = (uint32_t)((cx * g.ncy + cy) * g.nzb + zb);
+    cell_of[o] = cell;
+    atomicAdd(&cell_count[cell], 1u);
+}
+
+__global__ void column_tiles_kernel(const uint32_t* __restrict__ cell_start, uint32_t ncol, int nzb,
+                                    uint32_t* __restrict__ col_tiles) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > ncol) return;
+    if (c == ncol) { col_tiles[c] = 0; return; }
+    uint32_t cnt = cell_start[(size_t)(c + 1) * nzb] - cell_start[(size_t)c * nzb];
+    col_tiles[c] = (cnt + MDX_TILE - 1) / MDX_TILE;
+}
+
+__global__ void tile_col_kernel(const uint32_t* __restrict__ tile_start, uint32_t ncol,
+                                uint32_t* __restrict__ tile_col) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    for (uint32_t t = tile_start[c]; t < tile_start[c + 1]; ++t) tile_col[t] = c;
+}
+
+__global__ void scatter_kernel(const uint32_t* __restrict__ cell_of, const uint32_t* __restrict__ cell_start,
+                               uint32_t* __restrict__ cell_cursor, uint32_t* __restrict__ sorted_orig, uint32_t N) {
+    uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= N) return;
+    uint32_t c = cell_of[o];
+    uint32_t k = atomicAdd(&cell_cursor[c], 1u);
+    sorted_orig[cell_start[c] + k] = o;
+}
+
+// Insertion sort of every cell's members by (z, atom id): removes the arbitrary order the atomic
+// scatter left, so the whole build is deterministic.  Cells hold a handful of atoms.
+__global__ void cell_sort_kernel(const uint32_t* __restrict__ cell_start, uint32_t ncells,
+                                 const float4* __restrict__ pos_orig, uint32_t* __restrict__ sorted_orig) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncells) return;
+    uint32_t b = cell_start[c], e = cell_start[c + 1];
+    for (uint32_t i = b + 1; i < e; ++i) {
+        uint32_t oi = sorted_orig[i];
+        float zi = pos_orig[oi].z;
+        uint32_t j = i;
+        while (j > b) {
+            uint32_t oj = sorted_orig[j - 1];
+            float zj = pos_orig[oj].z;
+            if (zj < zi || (zj == zi && oj < oi)) break;
+            sorted_orig[j] = oj;
+            --j;
+        }
+        sorted_orig[j] = oi;
+    }
+}
+
+// ================================================================================================
+// tile assignment + in-tile sub-sort (one wavefront per tile)
+// ================================================================================================
+struct SortItem { float k; float a, b; uint32_t o; };
+
+template <int GROUP>
+__device__ __forceinline__ void bitonic_group(float& key, float& p1, float& p2, uint32_t& o, int lane) {
+#pragma unroll
+    for (int k = 2; k <= GROUP; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            float ok = __shfl_xor(key, j), o1 = __shfl_xor(p1, j), o2 = __shfl_xor(p2, j);
+            uint32_t oo = __shfl_xor(o, j);
+            bool asc = ((lane & k) == 0) || (k == GROUP);
+            bool lower = (lane & j) == 0;
+            bool mine_gt = (key > ok) || (key == ok && o > oo);
+            bool mine_lt = (key < ok) || (key == ok && o < oo);
+            bool take = (lower == asc) ? mine_gt : mine_lt;
+            if (take) { key = ok; p1 = o1; p2 = o2; o = oo; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void assign_tiles_kernel(
+    uint32_t T, int nzb, const uint32_t* __restrict__ tile_col, const uint32_t* __restrict__ tile_start,
+    const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ sorted_orig,
+    const float4* __restrict__ pos_orig, uint32_t* __restrict__ orig_of, uint32_t* __restrict__ slot_of) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (t > T) return;
+    if (t == T) {  // the null tile: all dummies
+        orig_of[(size_t)t * MDX_TILE + lane] = MDX_INVALID;
+        return;
+    }
+    const uint32_t c = tile_col[t];
+    const uint32_t a0 = cell_start[(size_t)c * nzb] + (t - tile_start[c]) * MDX_TILE;
+    const uint32_t aend = cell_start[(size_t)(c + 1) * nzb];
+    const uint32_t p = a0 + lane;
+    const bool valid = p < aend;
+    uint32_t o = valid ? sorted_orig[p] : MDX_INVALID;
+    float x = FLT_MAX, y = FLT_MAX, z = FLT_MAX;
+    if (valid) { float4 q = pos_orig[o]; x = q.x; y = q.y; z = q.z; }
+    // halves by y, quarters by x, eighths (clusters) by z
+    bitonic_group<64>(y, x, z, o, lane);
+    bitonic_group<32>(x, y, z, o, lane);
+    bitonic_group<16>(z, x, y, o, lane);
+    const uint32_t slot = t * MDX_TILE + lane;
+    orig_of[slot] = o;
+    if (o != MDX_INVALID) slot_of[o] = slot;
+}
+
+__global__ void gather_slots_kernel(uint32_t S, const uint32_t* __restrict__ orig_of,
+                                    const float4* __restrict__ pos_orig, const float4* __restrict__ vel_orig,
+                                    const float* __restrict__ o_qs, const float2* __restrict__ o_lj,
+                                    const float* __restrict__ o_invm, float4* __restrict__ posq,
+                                    float2* __restrict__ lj, float4* __restrict__ vel, float4* __restrict__ ref,
+                                    float4* __restrict__ force) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    uint32_t o = orig_of[s];
+    float4 p, v; float2 l;
+    if (o != MDX_INVALID) {
+        float4 q = pos_orig[o], w = vel_orig[o];
+        p = make_float4(q.x, q.y, q.z, o_qs[o]);
+        v = make_float4(w.x, w.y, w.z, o_invm[o]);
+        l = o_lj[o];
+    } else {
+        // dummy: far away, every dummy at its own coordinate so no two coincide
+        float d = MDX_DUMMY_BASE + MDX_DUMMY_STEP * (float)(s & 0xFFFFF);
+        p = make_float4(d, d + 17.0f * (float)(s >> 20), d, 0.f);
+        v = make_float4(0.f, 0.f, 0.f, 0.f);
+        l = make_float2(0.f, 0.f);
+    }
+    posq[s] = p; vel[s] = v; lj[s] = l; ref[s] = p;
+    force[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ void cluster_bbox_kernel(uint32_t NC, const uint32_t* __restrict__ orig_of,
+                                    const float4* __restrict__ posq, float4* __restrict__ cl_lo,
+                                    float4* __restrict__ cl_hi) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= NC) return;
+    float3 lo = make_float3(3.0e38f, 3.0e38f, 3.0e38f), hi = make_float3(-3.0e38f, -3.0e38f, -3.0e38f);
+    int n = 0;
+    for (int k = 0; k < MDX_CLUSTER; ++k) {
+        uint32_t s = c * MDX_CLUSTER + k;
+        if (orig_of[s] == MDX_INVALID) continue;
+        float4 p = posq[s];
+        lo.x = fminf(lo.x, p.x); lo.y = fminf(lo.y, p.y); lo.z = fminf(lo.z, p.z);
+        hi.x = fmaxf(hi.x, p.x); hi.y = fmaxf(hi.y, p.y); hi.z = fmaxf(hi.z, p.z);
+        ++n;
+    }
+    cl_lo[c] = make_float4(lo.x, lo.y, lo.z, (float)n);
+    cl_hi[c] = make_float4(hi.x, hi.y, hi.z, 0.f);
+}
+
+__global__ void unsort_kernel(uint32_t N, const uint32_t* __restrict__ slot_of, const float4* __restrict__ posq,
+                              const float4* __restrict__ vel, float4* __restrict__ pos_orig,
+                              float4* __restrict__ vel_orig) {
+    uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= N) return;
+    uint32_t s = slot_of[o];
+    pos_orig[o] = posq[s];
+    vel_orig[o] = vel[s];
+}
+
+__global__ void gather_orig_kernel(uint32_t N, const uint32_t* __restrict__ slot_of,
+                                   const float4* __restrict__ slot_arr, float4* __restrict__ orig_arr) {
+    uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= N) return;
+    orig_arr[o] = slot_arr[slot_of[o]];
+}
+
+__global__ void remap_kernel(uint32_t n, const uint32_t* __restrict__ idx_o, const uint32_t* __restrict__ slot_of,
+                             uint32_t* __restrict__ idx_s) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) idx_s[i] = slot_of[idx_o[i]];
+}
+
+// ================================================================================================
+// tile pair list
+// ================================================================================================
+constexpr int LB_WAVES = 4;
+constexpr int LB_HASH = 1024;
+constexpr int LB_MAXFLAG = 512;
+
+__device__ __forceinline__ uint32_t hash_u32(uint32_t k) { return (k * 2654435761u) >> 22; }  // 10 bits
+
+__device__ __forceinline__ bool hash_insert(uint32_t* tab, uint32_t key) {
+    uint32_t hpos = hash_u32(key);
+    for (int probe = 0; probe < LB_HASH; ++probe) {
+        uint32_t prev = atomicCAS(&tab[hpos], MDX_INVALID, key);
+        if (prev == MDX_INVALID || prev == key) return true;
+        hpos = (hpos + 1) & (LB_HASH - 1);
+    }
+    return false;
+}
+
+__device__ __forceinline__ bool hash_contains(const uint32_t* tab, uint32_t key) {
+    uint32_t hpos = hash_u32(key);
+    for (int probe = 0; probe < LB_HASH; ++probe) {
+        uint32_t v = tab[hpos];
+        if (v == key) return true;
+        if (v == MDX_INVALID) return false;
+        hpos = (hpos + 1) & (LB_HASH - 1);
+    }
+    return false;
+}
+
+__device__ __forceinline__ float gap(float lo_a, float hi_a, float lo_b, float hi_b) {
+    return fmaxf(0.f, fmaxf(lo_a - hi_b, lo_b - hi_a));
+}
+
+__device__ __forceinline__ int floor_div(int a, int b) {
+    int q = a / b, r = a % b;
+    return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q;
+}
+
+struct ListArgs {
+    uint32_t T;
+    GridParams g;
+    float r_build;  // slightly inflated list radius for the bounding-box tests
+    const uint32_t* tile_col; const uint32_t* tile_start;
+    const float4* cl_lo; const float4* cl_hi;
+    const uint32_t* orig_of; const uint32_t* slot_of;
+    const uint32_t* excl_off; const uint32_t* excl_idx;
+    // count pass out
+    ListCounts* counts; uint32_t* entry_cnt; uint32_t* mchunk_cnt;
+    // fill pass in/out
+    const uint32_t* entry_off; const uint32_t* mchunk_off;
+    uint2* entries; unsigned long long* masks;
+    uint32_t* err;
+    uint32_t null_cluster;
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
+    __shared__ uint32_t s_hash[LB_WAVES][LB_HASH];
+    __shared__ uint32_t s_fl[LB_WAVES][LB_MAXFLAG];
+    __shared__ float s_ibb[LB_WAVES][MDX_CL_PER_TILE][6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t t = blockIdx.x * LB_WAVES + wave;
+    if (t >= a.T) return;
+    uint32_t* hash = s_hash[wave];
+    uint32_t* fl = s_fl[wave];
+    const GridParams& g = a.g;
+
+    for (int k = lane; k < LB_HASH; k += 64) hash[k] = MDX_INVALID;
+    // i-cluster boxes and the tile box
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    if (lane < MDX_CL_PER_TILE) {
+        float4 l4 = a.cl_lo[t * MDX_CL_PER_TILE + lane], h4 = a.cl_hi[t * MDX_CL_PER_TILE + lane];
+        lo[0] = l4.x; lo[1] = l4.y; lo[2] = l4.z; hi[0] = h4.x; hi[1] = h4.y; hi[2] = h4.z;
+        for (int d = 0; d < 3; ++d) { s_ibb[wave][lane][d] = lo[d]; s_ibb[wave][lane][3 + d] = hi[d]; }
+    }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1)
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], m));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], m));
+        }
+    for (int d = 0; d < 3; ++d) { lo[d] = __shfl(lo[d], 0); hi[d] = __shfl(hi[d], 0); }
+    WAVE_LDS_SYNC();
+
+    // exclusion-bearing clusters: our own 8 and those holding an excluded partner of any lane
+    const uint32_t myslot = t * MDX_TILE + lane;
+    const uint32_t myo = a.orig_of[myslot];
+    bool ok_ins = true;
+    if (lane < MDX_CL_PER_TILE) ok_ins &= hash_insert(hash, t * MDX_CL_PER_TILE + lane);
+    uint32_t eb = 0, ee = 0;
+    if (myo != MDX_INVALID) { eb = a.excl_off[myo]; ee = a.excl_off[myo + 1]; }
+    for (uint32_t k = eb; k < ee; ++k) ok_ins &= hash_insert(hash, a.slot_of[a.excl_idx[k]] >> 3);
+    if (!ok_ins) atomicOr(a.err, 1u);
+    WAVE_LDS_SYNC();
+
+    const float r = a.r_build, r2 = r * r;
+    uint32_t nm = 0, np = 0;
+    uint32_t ebase = 0, nm_pad_total = 0;
+    if (FILL) { ebase = a.entry_off[t]; nm_pad_total = a.counts[t].n_masked; }
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    int ix0, ix1, iy0, iy1, kz0 = 0, kz1 = 0;
+    if (isinf(r) || r > 1.0e30f) {
+        ix0 = 0; ix1 = g.ncx - 1; iy0 = 0; iy1 = g.ncy - 1;
+    } else {
+        ix0 = (int)floorf((lo[0] - r - g.lo[0]) * g.inv_col[0]);
+        ix1 = (int)floorf((hi[0] + r - g.lo[0]) * g.inv_col[0]);
+        iy0 = (int)floorf((lo[1] - r - g.lo[1]) * g.inv_col[1]);
+        iy1 = (int)floorf((hi[1] + r - g.lo[1]) * g.inv_col[1]);
+        if (!g.periodic) {
+            ix0 = max(ix0, 0); ix1 = min(ix1, g.ncx - 1);
+            iy0 = max(iy0, 0); iy1 = min(iy1, g.ncy - 1);
+        } else {
+            ix0 = max(ix0, -g.ncx); ix1 = min(ix1, 2 * g.ncx - 1);
+            iy0 = max(iy0, -g.ncy); iy1 = min(iy1, 2 * g.ncy - 1);
+            if (lo[2] - r < g.lo[2]) kz0 = -1;
+            if (hi[2] + r >= g.lo[2] + g.len[2]) kz1 = 1;
+        }
+    }
+    const float colw_x = 1.0f / g.inv_col[0], colw_y = 1.0f / g.inv_col[1];
+
+    for (int ix = ix0; ix <= ix1; ++ix) {
+        const int kx = g.periodic ? floor_div(ix, g.ncx) : 0;
+        const int wx = ix - kx * g.ncx;
+        const float sx = (float)kx * g.len[0];
+        // column slab distance in x (column interval, slightly widened)
+        const float cxlo = g.lo[0] + (float)wx * colw_x + sx - 1e-3f, cxhi = cxlo + colw_x + 2e-3f;
+        const float gx = (wx == 0 || wx == g.ncx - 1) ? 0.f : gap(cxlo, cxhi, lo[0], hi[0]);
+        for (int iy = iy0; iy <= iy1; ++iy) {
+            const int ky = g.periodic ? floor_div(iy, g.ncy) : 0;
+            const int wy = iy - ky * g.ncy;
+            const float sy = (float)ky * g.len[1];
+            const float cylo = g.lo[1] + (float)wy * colw_y + sy - 1e-3f, cyhi = cylo + colw_y + 2e-3f;
+            const float gy = (wy == 0 || wy == g.ncy - 1) ? 0.f : gap(cylo, cyhi, lo[1], hi[1]);
+            if (gx * gx + gy * gy >= r2) continue;
+            const uint32_t c2 = (uint32_t)(wx * g.ncy + wy);
+            const uint32_t cl0 = a.tile_start[c2] * MDX_CL_PER_TILE, cl1 = a.tile_start[c2 + 1] * MDX_CL_PER_TILE;
+            for (int kz = kz0; kz <= kz1; ++kz) {
+                const float sz = (float)kz * g.len[2];
+                const uint32_t code = (uint32_t)((kx + 1) + 3 * (ky + 1) + 9 * (kz + 1));
+                for (uint32_t base = cl0; base < cl1; base += 64) {
+                    const uint32_t jc = base + lane;
+                    bool pass = false;
+                    uint32_t imask = 0;
+                    if (jc < cl1) {
+                        float4 jl = a.cl_lo[jc], jh = a.cl_hi[jc];
+                        jl.x += sx; jh.x += sx; jl.y += sy; jh.y += sy; jl.z += sz; jh.z += sz;
+                        float dx = gap(jl.x, jh.x, lo[0], hi[0]);
+                        float dy = gap(jl.y, jh.y, lo[1], hi[1]);
+                        float dz = gap(jl.z, jh.z, lo[2], hi[2]);
+                        if (jl.w > 0.f && dx * dx + dy * dy + dz * dz < r2) {
+#pragma unroll
+                            for (int ci = 0; ci < MDX_CL_PER_TILE; ++ci) {
+                                const float* b = s_ibb[wave][ci];
+                                float ex = gap(jl.x, jh.x, b[0], b[3]);
+                                float ey = gap(jl.y, jh.y, b[1], b[4]);
+                                float ez = gap(jl.z, jh.z, b[2], b[5]);
+                                if (ex * ex + ey * ey + ez * ez < r2) imask |= 1u << ci;
+                            }
+                            pass = imask != 0;
+                        }
+                    }
+                    const bool flagged = pass && hash_contains(hash, jc);
+                    const unsigned long long bm = __ballot(flagged), bp = __ballot(pass && !flagged);
+                    if (FILL) {
+                        const uint2 ent = make_uint2(jc, code | (imask << 8));
+                        if (flagged) {
+                            uint32_t k = nm + __popcll(bm & lt_mask);
+                            a.entries[ebase + k] = ent;
+                            if (k < LB_MAXFLAG) fl[k] = jc;
+                        } else if (pass) {
+                            uint32_t k = np + __popcll(bp & lt_mask);
+                            a.entries[ebase + nm_pad_total + k] = ent;
+                        }
+                    }
+                    nm += __popcll(bm);
+                    np += __popcll(bp);
+                }
+            }
+        }
+    }
+    const uint32_t nm_pad = (nm + 7) & ~7u, np_pad = (np + 7) & ~7u;
+    if (nm > LB_MAXFLAG) atomicOr(a.err, 2u);
+    if (!FILL) {
+        if (lane == 0) {
+            a.counts[t].n_masked = nm_pad;
+            a.counts[t].n_plain = np_pad;
+            a.entry_cnt[t] = nm_pad + np_pad;
+            a.mchunk_cnt[t] = nm_pad >> 3;
+        }
+        return;
+    }
+    // pad both runs with null entries
+    const uint2 null_ent = make_uint2(a.null_cluster, 13u);
+    if (lane < (int)(nm_pad - nm)) a.entries[ebase + nm + lane] = null_ent;
+    if (lane < (int)(np_pad - np)) a.entries[ebase + nm_pad_total + np + lane] = null_ent;
+    WAVE_LDS_SYNC();
+
+    // interaction masks of the masked run: bit (8*e + jj) of lane i <=> i interacts with atom jj
+    // of the chunk's e-th entry.
+    const uint32_t nmc = min(nm, (uint32_t)LB_MAXFLAG);
+    const uint32_t mbase = a.mchunk_off[t];
+    for (uint32_t c = 0; c < (nm_pad >> 3); ++c) {
+        unsigned long long m = 0ull;
+        uint32_t jcs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            uint32_t idx = c * 8 + e;
+            jcs[e] = (idx < nmc) ? fl[idx] : MDX_INVALID;
+            if (idx < nmc) m |= 0xFFull << (8 * e);
+        }
+        if (myo == MDX_INVALID) {
+            m = 0ull;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (jcs[e] == (myslot >> 3)) m &= ~(1ull << (8 * e + (myslot & 7)));
+            for (uint32_t k = eb; k < ee; ++k) {
+                uint32_t sp = a.slot_of[a.excl_idx[k]];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (jcs[e] == (sp >> 3)) m &= ~(1ull << (8 * e + (sp & 7)));
+            }
+        }
+        a.masks[(size_t)(mbase + c) * 64 + lane] = m;
+    }
+}
+
+// ================================================================================================
+// neighbour-list extraction (parity / debugging API): canonical fp32 distances
+// ================================================================================================
+__device__ __forceinline__ float r2_canonical(float4 pi, float4 pj, const float* L, int periodic) {
+    float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+    if (periodic) {
+        dx = dx - rintf(dx / L[0]) * L[0];
+        dy = dy - rintf(dy / L[1]) * L[1];
+        dz = dz - rintf(dz / L[2]) * L[2];
+    }
+    return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void extract_neighbors_kernel(
+    uint32_t T, GridParams g, float rl2, const uint32_t* __restrict__ entry_off, const uint2* __restrict__ entries,
+    const uint32_t* __restrict__ orig_of, const float4* __restrict__ ref, uint32_t* __restrict__ cnt,
+    const uint32_t* __restrict__ off, uint32_t* __restrict__ idx) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const uint32_t slot = t * MDX_TILE + lane;
+    const uint32_t oi = orig_of[slot];
+    const float4 pi = ref[slot];
+    uint32_t k = 0;
+    uint32_t* row = (FILL && oi != MDX_INVALID) ? idx + off[oi] : nullptr;
+    for (uint32_t e = entry_off[t]; e < entry_off[t + 1]; ++e) {
+        const uint32_t jc = entries[e].x;
+        for (int jj = 0; jj < MDX_CLUSTER; ++jj) {
+            const uint32_t js = jc * MDX_CLUSTER + jj;
+            const uint32_t oj = orig_of[js];
+            if (oj == MDX_INVALID || oi == MDX_INVALID || oj == oi) continue;
+            if (r2_canonical(pi, ref[js], g.len, g.periodic) < rl2) {
+                if (FILL) row[k] = oj;
+                ++k;
+            }
+        }
+    }
+    if (!FILL && oi != MDX_INVALID) cnt[oi] = k;
+}
+
+// ================================================================================================
+// host orchestration
+// ================================================================================================
+static int alloc_dev(void** p, size_t bytes) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
+    return MDX_OK;
+}
+#define ALLOC(ptr, count) MDX_TRY(alloc_dev((void**)&(ptr), sizeof(*(ptr)) * (size_t)(count)))
+
+static int setup_grid(mdx_handle* h) {
+    GridParams& g = h->grid;
+    const uint32_t N = h->N;
+    g.periodic = h->periodic ? 1 : 0;
+    if (h->periodic) {
+        for (int d = 0; d < 3; ++d) { g.lo[d] = h->box_lo[d]; g.len[d] = h->box_hi[d] - h->box_lo[d]; }
+    } else {
+        // bounding box of the current caller-order positions (vacuum systems are small)
+        std::vector<float4> hp(N);
+        HIP_TRY(hipMemcpyAsync(hp.data(), h->d.pos_orig, sizeof(float4) * N, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (uint32_t i = 0; i < N; ++i) {
+            const float v[3] = {hp[i].x, hp[i].y, hp[i].z};
+            for (int d = 0; d < 3; ++d) {
+                if (!std::isfinite(v[d])) { mdx_set_error("non-finite position"); return MDX_ENAN; }
+                lo[d] = std::min(lo[d], v[d]); hi[d] = std::max(hi[d], v[d]);
+            }
+        }
+        for (int d = 0; d < 3; ++d) { g.lo[d] = lo[d] - 0.01f; g.len[d] = std::max(hi[d] - lo[d] + 0.02f, 1.0f); }
+    }
+    const double vol = (double)g.len[0] * g.len[1] * g.len[2];
+    const double rho = std::max((double)N / vol, 1e-4);
+    double s = std::cbrt(64.0 / rho);            // cubic 64-atom bricks at the mean density
+    s = std::min(std::max(s, 3.0), 24.0);
+    g.ncx = std::max(1, (int)std::floor(g.len[0] / s));
+    g.ncy = std::max(1, (int)std::floor(g.len[1] / s));
+    while ((double)g.ncx * g.ncy > 4.0e6) { g.ncx = std::max(1, g.ncx / 2); g.ncy = std::max(1, g.ncy / 2); }
+    g.inv_col[0] = (float)(g.ncx / (double)g.len[0]);
+    g.inv_col[1] = (float)(g.ncy / (double)g.len[1]);
+    const double col_area = ((double)g.len[0] / g.ncx) * ((double)g.len[1] / g.ncy);
+    double zh = 6.0 / (rho * col_area);          // ~6 atoms per fine cell
+    zh = std::min(std::max(zh, 0.25), (double)g.len[2]);
+    long nzb = std::max(1L, (long)std::ceil(g.len[2] / zh));
+    const long ncol = (long)g.ncx * g.ncy;
+    while (ncol * nzb > 48L * 1000 * 1000) nzb = (nzb + 1) / 2;
+    g.nzb = (int)nzb;
+    g.inv_zbin = (float)(g.nzb / (double)g.len[2]);
+    const uint32_t new_ncol = (uint32_t)ncol, new_ncells = (uint32_t)(ncol * nzb);
+    DeviceState& d = h->d;
+    if (new_ncells > h->ncells || !d.cell_count) {
+        ALLOC(d.cell_count, (size_t)new_ncells + 1);
+        ALLOC(d.cell_start, (size_t)new_ncells + 1);
+        ALLOC(d.cell_cursor, (size_t)new_ncells + 1);
+        ALLOC(d.scan_tmp, (size_t)new_ncells / SCAN_TILE + (size_t)h->N / SCAN_TILE + 4096);
+    }
+    if (new_ncol > h->ncol || !d.col_tiles) {
+        ALLOC(d.col_tiles, (size_t)new_ncol + 1);
+        ALLOC(d.tile_start, (size_t)new_ncol + 1);
+    }
+    h->ncol = new_ncol; h->ncells = new_ncells;
+    // capacity in tiles: sum ceil(cnt/64) <= N/64 + ncol, + the null tile
+    const uint32_t need_tiles = N / MDX_TILE + new_ncol + 2;
+    if (need_tiles > h->cap_tiles) {
+        h->cap_tiles = need_tiles;
+        const size_t S = (size_t)need_tiles * MDX_TILE, NC = (size_t)need_tiles * MDX_CL_PER_TILE;
+        ALLOC(d.posq, S); ALLOC(d.lj, S); ALLOC(d.vel, S); ALLOC(d.force, S); ALLOC(d.ref, S);
+        ALLOC(d.orig_of, S);
+        ALLOC(d.tile_col, need_tiles);
+        ALLOC(d.cl_lo, NC); ALLOC(d.cl_hi, NC);
+        ALLOC(d.list_counts, need_tiles);
+        ALLOC(d.entry_cnt, (size_t)need_tiles + 1); ALLOC(d.entry_off, (size_t)need_tiles + 1);
+        ALLOC(d.mchunk_cnt, (size_t)need_tiles + 1); ALLOC(d.mchunk_off, (size_t)need_tiles + 1);
+    }
+    return MDX_OK;
+}
+
+int mdx_unsort_state(mdx_handle* h) {
+    if (!h->in_slot_space) return MDX_OK;
+    hipLaunchKernelGGL(unsort_kernel, dim3(div_up(h->N, 256)), dim3(256), 0, h->stream, h->N, h->d.slot_of,
+                       h->d.posq, h->d.vel, h->d.pos_orig, h->d.vel_orig);
+    HIP_TRY(hipGetLastError());
+    h->in_slot_space = false;
+    return MDX_OK;
+}
+
+int mdx_gather_to_orig(mdx_handle* h, const float4* slot_arr, float4* orig_arr) {
+    hipLaunchKernelGGL(gather_orig_kernel, dim3(div_up(h->N, 256)), dim3(256), 0, h->stream, h->N,
+                       h->d.slot_of, slot_arr, orig_arr);
+    HIP_TRY(hipGetLastError());
+    return MDX_OK;
+}
+
+int mdx_rebuild(mdx_handle* h) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->profile) {
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, h->stream));
+    }
+    MDX_TRY(mdx_unsort_state(h));  // dynamic state -> caller-order staging
+    MDX_TRY(setup_grid(h));
+    DeviceState& d = h->d;
+    const uint32_t N = h->N;
+    const GridParams g = h->grid;
+    hipStream_t st = h->stream;
+
+    HIP_TRY(hipMemsetAsync(d.cell_count, 0, sizeof(uint32_t) * ((size_t)h->ncells + 1), st));
+    HIP_TRY(hipMemsetAsync(d.cell_cursor, 0, sizeof(uint32_t) * ((size_t)h->ncells + 1), st));
+    HIP_TRY(hipMemsetAsync(d.flags_dev, 0, sizeof(uint32_t) * 4, st));
+    hipLaunchKernelGGL(bin_atoms_kernel, dim3(div_up(N, 256)), dim3(256), 0, st, d.pos_orig, N, g, d.cell_of,
+                       d.cell_count, d.flags_dev + 1);
+    MDX_TRY(mdx_exclusive_scan_u32(h, d.cell_count, d.cell_start, h->ncells + 1));
+    hipLaunchKernelGGL(column_tiles_kernel, dim3(div_up(h->ncol + 1, 256)), dim3(256), 0, st, d.cell_start,
+                       h->ncol, g.nzb, d.col_tiles);
+    MDX_TRY(mdx_exclusive_scan_u32(h, d.col_tiles, d.tile_start, h->ncol + 1));
+    hipLaunchKernelGGL(scatter_kernel, dim3(div_up(N, 256)), dim3(256), 0, st, d.cell_of, d.cell_start,
+                       d.cell_cursor, d.sorted_orig, N);
+    hipLaunchKernelGGL(cell_sort_kernel, dim3(div_up(h->ncells, 256)), dim3(256), 0, st, d.cell_start,
+                       h->ncells, d.pos_orig, d.sorted_orig);
+    uint32_t T = 0, flags[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(&T, d.tile_start + h->ncol, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(flags, d.flags_dev, sizeof(flags), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (flags[1]) { mdx_set_error("non-finite position at neighbour rebuild"); return MDX_ENAN; }
+    if (T + 1 > h->cap_tiles) { mdx_set_error("internal: tile capacity exceeded"); return MDX_EDEVICE; }
+    h->T = T;
+    h->S = (T + 1) * MDX_TILE;
+    const uint32_t S = h->S, NC = (T + 1) * MDX_CL_PER_TILE;
+
+    hipLaunchKernelGGL(tile_col_kernel, dim3(div_up(h->ncol, 256)), dim3(256), 0, st, d.tile_start, h->ncol,
+                       d.tile_col);
+    hipLaunchKernelGGL(assign_tiles_kernel, dim3(div_up(T + 1, 4)), dim3(256), 0, st, T, g.nzb, d.tile_col,
+                       d.tile_start, d.cell_start, d.sorted_orig, d.pos_orig, d.orig_of, d.slot_of);
+    hipLaunchKernelGGL(gather_slots_kernel, dim3(div_up(S, 256)), dim3(256), 0, st, S, d.orig_of, d.pos_orig,
+                       d.vel_orig, d.o_qs, d.o_lj, d.o_invm, d.posq, d.lj, d.vel, d.ref, d.force);
+    hipLaunchKernelGGL(cluster_bbox_kernel, dim3(div_up(NC, 256)), dim3(256), 0, st, NC, d.orig_of, d.posq,
+                       d.cl_lo, d.cl_hi);
+    h->in_slot_space = true;
+
+    // ---- pair list: count, scan, fill ----
+    ListArgs a{};
+    a.T = T; a.g = g;
+    a.r_build = std::isinf(h->r_list) ? h->r_list : h->r_list * (1.0f + 1e-5f) + 1e-4f;
+    a.tile_col = d.tile_col; a.tile_start = d.tile_start; a.cl_lo = d.cl_lo; a.cl_hi = d.cl_hi;
+    a.orig_of = d.orig_of; a.slot_of = d.slot_of; a.excl_off = d.excl_off; a.excl_idx = d.excl_idx;
+    a.counts = d.list_counts; a.entry_cnt = d.entry_cnt; a.mchunk_cnt = d.mchunk_cnt;
+    a.entry_off = d.entry_off; a.mchunk_off = d.mchunk_off; a.entries = d.entries; a.masks = d.masks;
+    a.err = d.flags_dev; a.null_cluster = T * MDX_CL_PER_TILE;
+    HIP_TRY(hipMemsetAsync(d.entry_cnt + T, 0, sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(d.mchunk_cnt + T, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(build_list_kernel<false>, dim3(div_up(T, LB_WAVES)), dim3(LB_WAVES * 64), 0, st, a);
+    MDX_TRY(mdx_exclusive_scan_u32(h, d.entry_cnt, d.entry_off, T + 1));
+    MDX_TRY(mdx_exclusive_scan_u32(h, d.mchunk_cnt, d.mchunk_off, T + 1));
+    uint32_t E = 0, MC = 0;
+    HIP_TRY(hipMemcpyAsync(&E, d.entry_off + T, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&MC, d.mchunk_off + T, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(flags, d.flags_dev, sizeof(flags), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (flags[0]) { mdx_set_error("exclusion table overflow while building the pair list"); return MDX_EPARAM; }
+    if (E > h->cap_entries || !d.entries) {
+        h->cap_entries = (uint64_t)(E * 1.25) + 1024;
+        ALLOC(d.entries, h->cap_entries);
+        a.entries = d.entries;
+    }
+    if (MC > h->cap_mchunks || !d.masks) {
+        h->cap_mchunks = (uint32_t)(MC * 1.25) + 64;
+        ALLOC(d.masks, (size_t)h->cap_mchunks * 64);
+        a.masks = d.masks;
+    }
+    h->E = E; h->MC = MC;
+    hipLaunchKernelGGL(build_list_kernel<true>, dim3(div_up(T, LB_WAVES)), dim3(LB_WAVES * 64), 0, st, a);
+
+    // ---- bonded index lists into slot space ----
+    if (h->n_bonds) hipLaunchKernelGGL(remap_kernel, dim3(div_up(2 * h->n_bonds, 256)), dim3(256), 0, st,
+                                       2 * h->n_bonds, d.bond_o, d.slot_of, d.bond_s);
+    if (h->n_angles) hipLaunchKernelGGL(remap_kernel, dim3(div_up(3 * h->n_angles, 256)), dim3(256), 0, st,
+                                        3 * h->n_angles, d.angle_o, d.slot_of, d.angle_s);
+    if (h->n_dih) hipLaunchKernelGGL(remap_kernel, dim3(div_up(4 * h->n_dih, 256)), dim3(256), 0, st,
+                                     4 * h->n_dih, d.dih_o, d.slot_of, d.dih_s);
+    if (h->n_p14) hipLaunchKernelGGL(remap_kernel, dim3(div_up(2 * h->n_p14, 256)), dim3(256), 0, st,
+                                     2 * h->n_p14, d.p14_o, d.slot_of, d.p14_s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(flags, d.flags_dev, sizeof(flags), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (flags[0]) { mdx_set_error("exclusion table overflow while building the pair list"); return MDX_EPARAM; }
+
+    h->list_valid = true;
+    h->forces_valid = false;
+    h->rebuild_count++;
+    uint64_t nmask = (uint64_t)MC * 8;
+    h->stats.n_atoms = N; h->stats.n_slots = S; h->stats.n_tiles = T; h->stats.n_clusters = NC;
+    h->stats.n_list_entries = E; h->stats.n_masked_entries = nmask;
+    if (h->profile) {
+        float ms = 0.f;
+        HIP_TRY(hipEventRecord(e1, st)); HIP_TRY(hipEventSynchronize(e1));
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        h->stats.rebuild_ms_sum += ms;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    return MDX_OK;
+}
+
+int mdx_extract_neighbors(mdx_handle* h, uint32_t* offsets, uint32_t* idx) {
+    DeviceState& d = h->d;
+    const uint32_t N = h->N, T = h->T;
+    hipStream_t st = h->stream;
+    const float rl2 = h->r_list * h->r_list;
+    uint32_t *d_cnt = nullptr, *d_off = nullptr, *d_idx = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_cnt, sizeof(uint32_t) * ((size_t)N + 1)));
+    HIP_TRY(hipMalloc((void**)&d_off, sizeof(uint32_t) * ((size_t)N + 1)));
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * ((size_t)N + 1), st));
+    hipLaunchKernelGGL(extract_neighbors_kernel<false>, dim3(div_up(T, 4)), dim3(256), 0, st, T, h->grid, rl2,
+                       d.entry_off, d.entries, d.orig_of, d.ref, d_cnt, d_off, d_idx);
+    int rc = mdx_exclusive_scan_u32(h, d_cnt, d_off, N + 1);
+    if (rc != MDX_OK) { (void)hipFree(d_cnt); (void)hipFree(d_off); return rc; }
+    std::vector<uint32_t> off(N + 1);
+    HIP_TRY(hipMemcpyAsync(off.data(), d_off, sizeof(uint32_t) * ((size_t)N + 1), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint32_t total = off[N];
+    std::vector<uint32_t> raw(total ? total : 1);
+    HIP_TRY(hipMalloc((void**)&d_idx, sizeof(uint32_t) * (total ? total : 1)));
+    hipLaunchKernelGGL(extract_neighbors_kernel<true>, dim3(div_up(T, 4)), dim3(256), 0, st, T, h->grid, rl2,
+                       d.entry_off, d.entries, d.orig_of, d.ref, d_cnt, d_off, d_idx);
+    HIP_TRY(hipMemcpyAsync(raw.data(), d_idx, sizeof(uint32_t) * total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_idx);
+    // rows: sort, drop duplicates (a cluster may be listed under two images in a small box)
+    uint32_t w = 0;
+    std::vector<uint32_t> new_off(N + 1);
+    for (uint32_t i = 0; i < N; ++i) {
+        new_off[i] = w;
+        uint32_t* b = raw.data() + off[i];
+        uint32_t* e = raw.data() + off[i + 1];
+        std::sort(b, e);
+        e = std::unique(b, e);
+        const uint32_t n = (uint32_t)(e - b);
+        if (idx) std::copy(b, e, idx + w);
+        w += n;
+    }
+    new_off[N] = w;
+    std::copy(new_off.begin(), new_off.end(), offsets);
+    return MDX_OK;
+}

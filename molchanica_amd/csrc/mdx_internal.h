@@ -1,0 +1,200 @@
+// mdx_internal.h — shared declarations of the gfx950 MD engine (not part of the public ABI).
+//
+// Data layout in HBM ("slot space"):
+//   Atoms are re-ordered at every neighbour rebuild into TILES of 64 consecutive slots (one
+//   wavefront = one tile, one atom per lane); a tile is 8 CLUSTERS of 8 slots.  Tiles are bricks
+//   of an x-y column grid, z-sorted inside a column, and sub-sorted so every cluster is compact.
+//   Unused slots hold dummy atoms (charge 0, eps 0, infinite mass) parked far away at distinct
+//   coordinates.  All per-step kernels work on slot-space float4 arrays (16 B per lane: the
+//   widest coalesced access):
+//     posq [S] x,y,z, q*sqrt(k_e)          lj   [S] (sigma/2 | sqrt(sigma), sqrt(24 eps))
+//     vel  [S] vx,vy,vz, 418.4/mass (0 = never integrated)
+//     force[S] fx,fy,fz,-                  ref  [S] position at the last rebuild
+//   The pair list is per tile: a run of (j-cluster, image shift, i-cluster mask) entries, the
+//   ones that need exclusion masks first, each run padded to a multiple of 8 entries (= one
+//   64-atom chunk staged through LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/mdx.h"
+
+#define MDX_TILE 64
+#define MDX_CLUSTER 8
+#define MDX_CL_PER_TILE 8
+#define MDX_ACC_CONV 418.4f
+#define MDX_KB 0.0019872041
+#define MDX_INVALID 0xFFFFFFFFu
+#define MDX_DUMMY_BASE 1.0e6f
+#define MDX_DUMMY_STEP 64.0f
+#define MDX_MAX_CHUNK 64
+
+enum { EN_BOND = 0, EN_ANGLE, EN_DIHEDRAL, EN_LJ, EN_COUL, EN_LJ14, EN_COUL14, EN_KIN, EN_COUNT };
+
+struct GridParams {
+    float lo[3];       // origin of the column grid (box_lo, or bounding box in vacuum)
+    float len[3];      // box edge (periodic) or bounding extent
+    float inv_col[2];  // 1 / column edge in x, y
+    float inv_zbin;    // 1 / fine z-bin height
+    int ncx, ncy, nzb; // columns in x, y; z-bins per column
+    int periodic;
+};
+
+struct NbParams {
+    float rc2_lj, rc2_coul;  // squared cut-offs (FLT_MAX = none)
+    float shift[3];          // box edges for image shifts (0 in vacuum)
+    float coul_shift;        // 1/rc  (shifted potential), or c_rf (reaction field)
+    float k_rf2;             // 2*k_rf (reaction field force term)
+    float k_rf;
+    float alpha;             // Ewald real-space
+    float soft2;
+    int coul_mode;
+    int geometric;           // combining rule
+    int lj_on, coul_on;
+};
+
+struct BondedParams {
+    float box[3];  // edges, 0 when not periodic
+    float inv_box[3];
+    float scale14_lj, scale14_coul;
+    int geometric, lj_on, coul_on;
+};
+
+// Control block in device memory: the rebuild trigger.  disp2[s] holds, as the bit pattern of a
+// non-negative float, the largest squared displacement (w.r.t. the positions of the last rebuild)
+// seen after the drift of chunk-step s-1; every kernel of chunk-step s first tests
+// disp2[s] > thr and turns into a no-op when the list has gone stale, so the host may enqueue a
+// whole chunk of steps without synchronising.
+struct StepCtl {
+    uint32_t disp2[MDX_MAX_CHUNK + 2];
+    uint32_t nonfinite;
+    uint32_t pad;
+};
+
+struct ListCounts {  // per tile
+    uint32_t n_masked;  // entries in the masked run (multiple of 8)
+    uint32_t n_plain;   // entries in the plain run (multiple of 8)
+};
+
+// ---- device buffers owned by a handle -----------------------------------------------------------
+struct DeviceState {
+    // static per-atom data, caller ("orig") order
+    float*    o_qs = nullptr;      // q*sqrt(ke) (0 for bonded_only)
+    float2*   o_lj = nullptr;
+    float*    o_invm = nullptr;    // ACC_CONV/mass or 0
+    float*    o_mass = nullptr;
+    float*    o_q = nullptr;       // raw charge (1-4 pairs)
+    float2*   o_lj_raw = nullptr;  // (sigma, eps) raw (1-4 pairs)
+    uint32_t* excl_off = nullptr;  // merged exclusions + 1-4 CSR, orig order
+    uint32_t* excl_idx = nullptr;
+    // staging in orig order
+    float4* pos_orig = nullptr;
+    float4* vel_orig = nullptr;
+    float4* ext_orig = nullptr;
+    // slot space
+    float4* posq = nullptr; float2* lj = nullptr; float4* vel = nullptr; float4* force = nullptr;
+    float4* ref = nullptr;
+    uint32_t* orig_of = nullptr;  // [S]
+    uint32_t* slot_of = nullptr;  // [N]
+    // grid build scratch
+    uint32_t* cell_of = nullptr;      // [N]
+    uint32_t* cell_count = nullptr;   // [ncells+1]
+    uint32_t* cell_start = nullptr;   // [ncells+1]
+    uint32_t* cell_cursor = nullptr;  // [ncells]
+    uint32_t* sorted_orig = nullptr;  // [N]
+    uint32_t* col_tiles = nullptr;    // [ncol+1]
+    uint32_t* tile_start = nullptr;   // [ncol+1]
+    uint32_t* tile_col = nullptr;     // [T]
+    uint32_t* scan_tmp = nullptr;
+    // cluster bounding boxes
+    float4* cl_lo = nullptr; float4* cl_hi = nullptr;  // [NC]
+    // pair list
+    ListCounts* list_counts = nullptr;  // [T]
+    uint32_t* entry_cnt = nullptr;      // [T+1] entries per tile (masked+plain), then scanned
+    uint32_t* entry_off = nullptr;      // [T+1]
+    uint32_t* mchunk_cnt = nullptr;     // [T+1]
+    uint32_t* mchunk_off = nullptr;     // [T+1]
+    uint2*    entries = nullptr;        // [E]
+    unsigned long long* masks = nullptr; // [MC*64]
+    // bonded terms: orig-order indices + slot-order copies
+    uint32_t *bond_o = nullptr, *bond_s = nullptr; float2* bond_p = nullptr;
+    uint32_t *angle_o = nullptr, *angle_s = nullptr; float2* angle_p = nullptr;
+    uint32_t *dih_o = nullptr, *dih_s = nullptr; float4* dih_p = nullptr;  // v, phase, n, -
+    uint32_t *p14_o = nullptr, *p14_s = nullptr; float4* p14_p = nullptr;  // sig, eps, kqq, -
+    // control / reductions
+    StepCtl* ctl = nullptr;
+    double*  energy = nullptr;     // [EN_COUNT + 2]
+    uint32_t* flags_dev = nullptr; // misc error flags
+    float*   bbox_red = nullptr;   // [6] min/max reduction (vacuum grid)
+};
+
+struct mdx_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t N = 0;
+    mdx_config cfg{};
+    // host copies of the system (needed to rebuild after set_box etc.)
+    bool periodic = false;
+    float box_lo[3]{}, box_hi[3]{};
+    uint32_t n_bonds = 0, n_angles = 0, n_dih = 0, n_p14 = 0;
+    uint32_t n_mobile = 0;
+    double total_mass = 0.0;
+    std::vector<uint8_t> flags;
+    // grid
+    GridParams grid{};
+    uint32_t ncol = 0, ncells = 0;
+    uint32_t T = 0;          // real tiles (the null tile is tile T)
+    uint32_t S = 0;          // slots = (T+1)*64
+    uint32_t cap_tiles = 0;  // allocation capacity in tiles (incl. null)
+    uint64_t E = 0, cap_entries = 0;
+    uint32_t MC = 0, cap_mchunks = 0;
+    float r_list = 0.f;
+    // state flags
+    bool list_valid = false;    // spatial caches match the slot-space state
+    bool forces_valid = false;
+    bool in_slot_space = false; // dynamic state lives in slot arrays (else in *_orig staging)
+    bool have_ext = false;
+    uint64_t step_count = 0, rebuild_count = 0;
+    // profiling
+    bool profile = false;
+    struct EvPair { hipEvent_t a, b; int kind; };
+    std::vector<EvPair> ev_pending;
+    std::vector<hipEvent_t> ev_pool;
+    mdx_stats stats{};
+    DeviceState d;
+    StepCtl* h_ctl = nullptr;  // pinned
+};
+
+// ---- error plumbing ------------------------------------------------------------------------------
+void mdx_set_error(const std::string& s);
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            mdx_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));              \
+            return (_e == hipErrorOutOfMemory) ? MDX_EOOM : MDX_EDEVICE;                   \
+        }                                                                                  \
+    } while (0)
+#define MDX_TRY(expr) do { int _r = (expr); if (_r != MDX_OK) return _r; } while (0)
+
+// ---- kernel launchers (each .hip file) -------------------------------------------------------------
+// grid / list build (mdx_grid.hip)
+int mdx_rebuild(mdx_handle* h);
+int mdx_unsort_state(mdx_handle* h);  // slot space -> pos_orig / vel_orig
+int mdx_gather_to_orig(mdx_handle* h, const float4* slot_arr, float4* orig_arr);
+int mdx_extract_neighbors(mdx_handle* h, uint32_t* offsets, uint32_t* idx);
+// forces
+int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr_bits);
+int mdx_launch_bonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr_bits);
+int mdx_launch_add_ext(mdx_handle* h, const uint32_t* d_gate, uint32_t thr_bits);
+// integration (mode: 0 = half kick + drift, 1 = full kick + drift, 2 = closing half kick)
+int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_gate_in,
+                         uint32_t* d_disp_out, uint32_t thr_bits);
+int mdx_launch_kinetic(mdx_handle* h);  // energy[EN_KIN], energy[EN_COUNT] = max |F|^2
+int mdx_exclusive_scan_u32(mdx_handle* h, const uint32_t* in, uint32_t* out, uint32_t n);
+
+// profiling helpers
+void mdx_prof_begin(mdx_handle* h, int kind);
+void mdx_prof_end(mdx_handle* h);
+void mdx_prof_collect(mdx_handle* h);

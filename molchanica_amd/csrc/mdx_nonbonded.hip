@@ -1,0 +1,232 @@
+// mdx_nonbonded.hip — the Lennard-Jones + Coulomb pair loop (the dominant kernel of the path).
+//
+// Replaces the pair-force part of `MdState::step` in the absent `dynamics` crate; the formulas
+// follow the only in-tree statement of them, /root/reference src/cuda/util.cu:53-63 (Coulomb,
+// dir = tgt - src) and :92-140 (LJ 12-6: F = dir*24 eps (2 s^12 - s^6)/r, E = 4 eps (s^12 - s^6)).
+// The reference's own (unused) kernels are one target per thread with a serial loop over ALL
+// sources (src/cuda/cuda.cu:10-37, 73-102); this kernel keeps "one atom per lane" and replaces the
+// O(N) inner loop by the tile pair list, with the neighbour atoms staged through LDS.
+//
+// Mapping (gfx950, wave64):
+//   * one wavefront = one i-tile: lane l owns slot tile*64+l, its force accumulates in registers
+//     and is written once with a coalesced 16-B store.  No atomics, no Newton-3 write-back: every
+//     pair is evaluated from both sides, which makes forces bitwise reproducible run to run.
+//   * the tile's list is consumed in chunks of 8 entries = 64 j-atoms: lane l fetches j-atom l of
+//     the chunk (8 x 128-B contiguous cluster records of posq + 8 x 64 B of lj: coalesced), adds
+//     the periodic image shift once, and parks it in the wave's private LDS strip; the next
+//     chunk's global loads are issued before the current chunk is computed (register prefetch).
+//   * the inner loop reads each j record as one broadcast ds_read_b128 + ds_read_b64 (all lanes
+//     the same address: conflict-free) and runs ~25 VALU ops per pair.
+//   * exclusions/self pairs: only the first n_masked entries of a tile can contain them; those
+//     chunks carry a 64-bit per-lane interaction mask, the (vast) rest runs mask-free.
+//   * workgroup = 4 waves = 4 consecutive tiles of a column (shared neighbourhood -> L1/L2 hits);
+//     blockIdx is remapped so that each XCD walks one contiguous eighth of the tile range and its
+//     private L2 sees a compact spatial region.
+// No MFMA: this is pairwise scalar work.  Roofline: fp32 VALU bound.
+#include "mdx_internal.h"
+#include <cfloat>
+
+#define WAVE_LDS_SYNC()                                        \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); \
+        __builtin_amdgcn_wave_barrier();                       \
+    } while (0)
+
+constexpr int NB_WAVES = 4;
+
+struct NbArgs {
+    uint32_t T;
+    const float4* posq; const float2* lj;
+    const ListCounts* counts; const uint32_t* entry_off; const uint32_t* mchunk_off;
+    const uint2* entries; const unsigned long long* masks;
+    float4* force; double* energy;
+    NbParams p;
+    const uint32_t* gate; uint32_t thr_bits;
+};
+
+enum { CM_SHIFTED = 0, CM_RF = 1, CM_EWALD = 2, CM_SOFT = 3 };
+
+template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, bool MASKED>
+__device__ __forceinline__ void chunk_pairs(const float4* __restrict__ sx, const float2* __restrict__ sl,
+                                            unsigned long long mask, float xi, float yi, float zi, float qi,
+                                            float sgi, float epi, const NbParams& p, float& fx, float& fy,
+                                            float& fz, double& elj, double& ecoul) {
+#pragma unroll 8
+    for (int jj = 0; jj < 64; ++jj) {
+        const float4 pj = sx[jj];
+        const float2 lj = sl[jj];
+        const float dx = xi - pj.x, dy = yi - pj.y, dz = zi - pj.z;
+        const float r2 = dx * dx + dy * dy + dz * dz;
+        bool in_lj = r2 < p.rc2_lj;
+        bool in_c = SAMECUT ? in_lj : (r2 < p.rc2_coul);
+        if (MASKED) {
+            const bool m = (mask >> jj) & 1ull;
+            in_lj = in_lj && m;
+            in_c = in_c && m;
+        }
+        const float rinv = __builtin_amdgcn_rsqf(r2);
+        const float rinv2 = rinv * rinv;
+        const float sig = GEOM ? sgi * lj.x : sgi + lj.x;
+        const float eps = epi * lj.y;                   // 24 eps_ij
+        const float s2 = sig * sig * rinv2;
+        const float s6 = s2 * s2 * s2;
+        const float es6 = eps * s6;
+        float flj = es6 * (2.0f * s6 - 1.0f) * rinv2;   // 24 eps (2 s12 - s6) / r^2
+        const float qq = qi * pj.w;                     // k_e q_i q_j
+        float fc;
+        if (COUL == CM_SHIFTED) fc = qq * rinv * rinv2;
+        else if (COUL == CM_SOFT) fc = qq * rinv * __frcp_rn(r2 + p.soft2);
+        else if (COUL == CM_RF) fc = qq * (rinv * rinv2 - p.k_rf2);
+        else {
+            const float r = r2 * rinv, ar = p.alpha * r;
+            fc = qq * (erfcf(ar) * rinv + 1.1283791671f * p.alpha * __expf(-ar * ar)) * rinv2;
+        }
+        float fs;
+        if (SAMECUT) fs = in_lj ? (flj + fc) : 0.0f;
+        else fs = (in_lj ? flj : 0.0f) + (in_c ? fc : 0.0f);
+        fx += fs * dx; fy += fs * dy; fz += fs * dz;
+        if (ENERGY) {
+            float e_l = es6 * (s6 - 1.0f) * (1.0f / 6.0f);  // 4 eps (s12 - s6)
+            float e_c;
+            if (COUL == CM_SHIFTED || COUL == CM_SOFT) e_c = qq * (rinv - p.coul_shift);
+            else if (COUL == CM_RF) e_c = qq * (rinv + p.k_rf * r2 - p.coul_shift);
+            else e_c = qq * erfcf(p.alpha * r2 * rinv) * rinv;
+            elj += in_lj ? (double)e_l : 0.0;
+            ecoul += in_c ? (double)e_c : 0.0;
+        }
+    }
+}
+
+template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT>
+__global__ __launch_bounds__(NB_WAVES * 64) void nb_tile_kernel(NbArgs a) {
+    if (a.gate && *a.gate > a.thr_bits) return;
+    __shared__ float4 s_xyzq[NB_WAVES][64];
+    __shared__ float2 s_lj[NB_WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // XCD-aware remap: block b is dispatched to XCD b%8; give each XCD a contiguous tile range
+    const uint32_t nblocks = (a.T + NB_WAVES - 1) / NB_WAVES;
+    const uint32_t per_xcd = (nblocks + 7) >> 3;
+    const uint32_t blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (blk >= nblocks) return;
+    const uint32_t t = blk * NB_WAVES + wave;
+    if (t >= a.T) return;
+
+    const uint32_t islot = t * MDX_TILE + lane;
+    const float4 pi = a.posq[islot];
+    const float2 li = a.lj[islot];
+    const ListCounts cnt = a.counts[t];
+    const uint32_t e0 = a.entry_off[t];
+    const uint32_t nmc = cnt.n_masked >> 3, nchunks = (cnt.n_masked + cnt.n_plain) >> 3;
+    const uint32_t mbase = a.mchunk_off[t];
+    float4* sx = s_xyzq[wave];
+    float2* sl = s_lj[wave];
+
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    double elj = 0.0, ecoul = 0.0;
+
+    // prefetch chunk 0
+    float4 nj = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 nl = make_float2(0.f, 0.f);
+    uint32_t ncode = 13;
+    if (nchunks) {
+        const uint2 ent = a.entries[e0 + (lane >> 3)];
+        const uint32_t js = ent.x * MDX_CLUSTER + (lane & 7);
+        nj = a.posq[js]; nl = a.lj[js]; ncode = ent.y & 31u;
+    }
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        {   // image shift, then park in LDS
+            const int kx = (int)(ncode % 3u) - 1, ky = (int)((ncode / 3u) % 3u) - 1, kz = (int)(ncode / 9u) - 1;
+            nj.x += (float)kx * a.p.shift[0];
+            nj.y += (float)ky * a.p.shift[1];
+            nj.z += (float)kz * a.p.shift[2];
+            sx[lane] = nj;
+            sl[lane] = nl;
+        }
+        WAVE_LDS_SYNC();
+        if (c + 1 < nchunks) {
+            const uint2 ent = a.entries[e0 + (c + 1) * 8 + (lane >> 3)];
+            const uint32_t js = ent.x * MDX_CLUSTER + (lane & 7);
+            nj = a.posq[js]; nl = a.lj[js]; ncode = ent.y & 31u;
+        }
+        if (c < nmc) {
+            const unsigned long long m = a.masks[(size_t)(mbase + c) * 64 + lane];
+            chunk_pairs<ENERGY, COUL, GEOM, SAMECUT, true>(sx, sl, m, pi.x, pi.y, pi.z, pi.w, li.x, li.y, a.p,
+                                                           fx, fy, fz, elj, ecoul);
+        } else {
+            chunk_pairs<ENERGY, COUL, GEOM, SAMECUT, false>(sx, sl, ~0ull, pi.x, pi.y, pi.z, pi.w, li.x, li.y,
+                                                            a.p, fx, fy, fz, elj, ecoul);
+        }
+        WAVE_LDS_SYNC();
+    }
+    a.force[islot] = make_float4(fx, fy, fz, 0.f);
+    if (ENERGY) {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) {
+            elj += __shfl_xor(elj, m);
+            ecoul += __shfl_xor(ecoul, m);
+        }
+        if (lane == 0) {   // every pair is seen from both sides
+            atomicAdd(&a.energy[EN_LJ], 0.5 * elj);
+            atomicAdd(&a.energy[EN_COUL], 0.5 * ecoul);
+        }
+    }
+}
+
+template <bool ENERGY, int COUL>
+static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samecut) {
+    const uint32_t nblocks = (a.T + NB_WAVES - 1) / NB_WAVES;
+    const uint32_t grid = ((nblocks + 7) / 8) * 8;
+    dim3 g(grid), b(NB_WAVES * 64);
+    if (geom) {
+        if (samecut) hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, true, true>), g, b, 0, h->stream, a);
+        else hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, true, false>), g, b, 0, h->stream, a);
+    } else {
+        if (samecut) hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, false, true>), g, b, 0, h->stream, a);
+        else hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, false, false>), g, b, 0, h->stream, a);
+    }
+}
+
+static bool cut_on(float rc) { return rc > 0.f && std::isfinite(rc); }
+
+int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr_bits) {
+    const mdx_config& c = h->cfg;
+    NbArgs a{};
+    a.T = h->T;
+    a.posq = h->d.posq; a.lj = h->d.lj; a.counts = h->d.list_counts; a.entry_off = h->d.entry_off;
+    a.mchunk_off = h->d.mchunk_off; a.entries = h->d.entries; a.masks = h->d.masks;
+    a.force = h->d.force; a.energy = h->d.energy; a.gate = d_gate; a.thr_bits = thr_bits;
+    NbParams& p = a.p;
+    p.rc2_lj = cut_on(c.lj_cutoff) ? c.lj_cutoff * c.lj_cutoff : FLT_MAX;
+    p.rc2_coul = cut_on(c.coulomb_cutoff) ? c.coulomb_cutoff * c.coulomb_cutoff : FLT_MAX;
+    for (int d = 0; d < 3; ++d) p.shift[d] = h->periodic ? (h->box_hi[d] - h->box_lo[d]) : 0.f;
+    const bool ccut = cut_on(c.coulomb_cutoff);
+    const float rc = c.coulomb_cutoff;
+    p.alpha = c.ewald_alpha; p.soft2 = c.softening_sq;
+    p.k_rf = 0.f; p.k_rf2 = 0.f; p.coul_shift = 0.f;
+    int mode = CM_SHIFTED;
+    switch (c.coulomb_mode) {
+    case MDX_COULOMB_REACTION:
+        mode = CM_RF;
+        if (ccut) { p.k_rf = 1.0f / (2.0f * rc * rc * rc); p.k_rf2 = 2.0f * p.k_rf; p.coul_shift = 1.5f / rc; }
+        break;
+    case MDX_COULOMB_EWALD: mode = CM_EWALD; break;
+    default:
+        mode = (c.softening_sq != 0.f) ? CM_SOFT : CM_SHIFTED;
+        if (ccut) p.coul_shift = 1.0f / rc;
+    }
+    const bool geom = c.combining_rule == MDX_COMBINE_GEOMETRIC;
+    const bool samecut = p.rc2_lj == p.rc2_coul;
+    mdx_prof_begin(h, 0);
+#define NB_DISPATCH(E)                                                              \
+    switch (mode) {                                                                 \
+    case CM_SHIFTED: launch_variant<E, CM_SHIFTED>(h, a, geom, samecut); break;     \
+    case CM_SOFT: launch_variant<E, CM_SOFT>(h, a, geom, samecut); break;           \
+    case CM_RF: launch_variant<E, CM_RF>(h, a, geom, samecut); break;               \
+    default: launch_variant<E, CM_EWALD>(h, a, geom, samecut); break;               \
+    }
+    if (energy) { NB_DISPATCH(true) } else { NB_DISPATCH(false) }
+#undef NB_DISPATCH
+    mdx_prof_end(h);
+    HIP_TRY(hipGetLastError());
+    return MDX_OK;
+}

@@ -1,0 +1,253 @@
+"""Host-side mirror of the `dynamics` crate surface Molchanica calls, over the C ABI (libmdx.so).
+
+Names, argument meaning and error behaviour follow the reference call sites
+(/root/reference, `dynamics = "0.2.2"` is external):
+  MdState::new(dev, &cfg, &mols, param_set) -> Result<(MdState, ..), ParamError>   src/md/mod.rs:689
+  md.step(&dev, dt, Option<Vec<Vec3F32>>)                                           src/md/mod.rs:748
+  run_dynamics_blocking(md, dev, dt, n_steps)                                       src/md/mod.rs:696-724
+  compute_energy_snapshot(dev, &mols, param_set) -> Result<Snapshot, ParamError>    src/md/mod.rs:1036
+  md.atoms[i].posit / .force, md.step_count, md.cell, md.rebuild_spatial_caches()   src/mol_alignment.rs:349-352,
+                                                                 src/properties/sol_shrinking_box.rs:600-632
+There is no CPU fallback here: if libmdx.so is missing or no GPU is usable this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._abi import (CConfig, CEnergies, CStats, CSystem, FORCE, MDX_EDEVICE, MDX_ENAN, MDX_EOOM,
+                   MDX_EPARAM, MDX_OK, POS, VEL, MdConfig, MdSystem)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmdx.so")
+
+
+class ParamError(ValueError):
+    """The reference's `ParamError { descrip }` (src/md/mod.rs:967)."""
+
+
+class DeviceError(RuntimeError):
+    """HIP/device failure (MDX_EDEVICE / MDX_EOOM); the reference degrades to its CPU path here
+    (src/util.rs:1072-1119) — this library has none and says so loudly."""
+
+
+class BlowUpError(FloatingPointError):
+    """Non-finite state (MDX_ENAN); cf. the stop criteria at sol_shrinking_box.rs:776-789."""
+
+
+_lib = None
+_fp = C.POINTER(C.c_float)
+_u32p = C.POINTER(C.c_uint32)
+
+
+def load_library():
+    """Loads libmdx.so (built in-tree by __graft_entry__.build()).  Fails loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists).")
+    lib = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    lib.mdx_device_count.restype = C.c_int
+    lib.mdx_last_error.restype = C.c_char_p
+    lib.mdx_config_default.argtypes = [C.POINTER(CConfig)]
+    lib.mdx_create.argtypes = [C.POINTER(CSystem), C.POINTER(CConfig), C.c_int, C.POINTER(H)]
+    lib.mdx_destroy.argtypes = [H]
+    lib.mdx_destroy.restype = None
+    lib.mdx_step.argtypes = [H, C.c_float, _fp, C.c_uint32]
+    lib.mdx_energy.argtypes = [H, C.POINTER(CEnergies)]
+    lib.mdx_single_point.argtypes = [C.POINTER(CSystem), C.POINTER(CConfig), C.c_int,
+                                     C.POINTER(CEnergies), _fp]
+    lib.mdx_download.argtypes = [H, C.c_int, _fp]
+    lib.mdx_upload.argtypes = [H, C.c_int, _fp]
+    lib.mdx_set_box.argtypes = [H, C.c_float * 3, C.c_float * 3]
+    lib.mdx_rebuild_spatial_caches.argtypes = [H]
+    lib.mdx_step_count.argtypes = [H]
+    lib.mdx_step_count.restype = C.c_uint64
+    lib.mdx_neighbor_list.argtypes = [H, _u32p, _u32p]
+    lib.mdx_profile.argtypes = [H, C.c_int]
+    lib.mdx_get_stats.argtypes = [H, C.POINTER(CStats)]
+    lib.mdx_step_begin.argtypes = [H, C.c_float, C.c_int]
+    lib.mdx_step_end.argtypes = [H, C.c_float, C.c_int]
+    lib.mdx_pack_positions.argtypes = [H, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.mdx_unpack_positions.argtypes = [H, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.mdx_needs_rebuild.argtypes = [H, C.POINTER(C.c_int)]
+    lib.mdx_stream.argtypes = [H]
+    lib.mdx_stream.restype = C.c_void_p
+    _lib = lib
+    return lib
+
+
+def _check(rc: int):
+    if rc == MDX_OK:
+        return
+    msg = load_library().mdx_last_error().decode("utf-8", "replace")
+    if rc == MDX_EPARAM:
+        raise ParamError(msg)
+    if rc == MDX_ENAN:
+        raise BlowUpError(msg)
+    if rc in (MDX_EDEVICE, MDX_EOOM):
+        raise DeviceError(msg)
+    raise RuntimeError(f"mdx error {rc}: {msg}")
+
+
+def device_count() -> int:
+    """`get_computation_device` probe (src/util.rs:1072-1119): 0 means "stay on the CPU path"."""
+    return int(load_library().mdx_device_count())
+
+
+class MdState:
+    """`dynamics::MdState` as Molchanica uses it."""
+
+    def __init__(self, system: MdSystem, cfg: MdConfig | None = None, device: int = 0):
+        lib = load_library()
+        self.cfg = cfg or MdConfig()
+        self.system = system.normalise()
+        self._h = C.c_void_p()
+        cs, cc = self.system.to_c(), self.cfg.to_c()
+        _check(lib.mdx_create(C.byref(cs), C.byref(cc), int(device), C.byref(self._h)))
+        self.n_atoms = system.n_atoms
+
+    # `MdState::new` spelling of the reference
+    @classmethod
+    def new(cls, system: MdSystem, cfg: MdConfig | None = None, device: int = 0) -> "MdState":
+        return cls(system, cfg, device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            load_library().mdx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- stepping --------------------------------------------------------------------------
+    def step(self, dt: float, external_forces=None, n_steps: int = 1):
+        """`md.step(&dev, dt, ext)`; n_steps > 1 keeps the GUI's 10-step burst
+        (src/md/mod.rs:737) or a blocking run on the device."""
+        ext = None
+        if external_forces is not None:
+            ext = np.ascontiguousarray(external_forces, dtype=np.float32).reshape(self.n_atoms, 3)
+        _check(load_library().mdx_step(self._h, float(dt),
+                                       None if ext is None else ext.ctypes.data_as(_fp), int(n_steps)))
+
+    @property
+    def step_count(self) -> int:
+        return int(load_library().mdx_step_count(self._h))
+
+    # -- energies / forces -------------------------------------------------------------------
+    def energy(self) -> dict:
+        """Per-snapshot `SnapshotEnergyData` superset (src/ui/panels/md_viewer.rs:195-257)."""
+        e = CEnergies()
+        _check(load_library().mdx_energy(self._h, C.byref(e)))
+        return e.as_dict()
+
+    def _download(self, which: int) -> np.ndarray:
+        out = np.empty((self.n_atoms, 3), dtype=np.float32)
+        _check(load_library().mdx_download(self._h, which, out.ctypes.data_as(_fp)))
+        return out
+
+    def positions(self) -> np.ndarray:
+        return self._download(POS)
+
+    def velocities(self) -> np.ndarray:
+        return self._download(VEL)
+
+    def forces(self) -> np.ndarray:
+        return self._download(FORCE)
+
+    def set_positions(self, pos):
+        a = np.ascontiguousarray(pos, dtype=np.float32).reshape(self.n_atoms, 3)
+        _check(load_library().mdx_upload(self._h, POS, a.ctypes.data_as(_fp)))
+
+    def set_velocities(self, vel):
+        a = np.ascontiguousarray(vel, dtype=np.float32).reshape(self.n_atoms, 3)
+        _check(load_library().mdx_upload(self._h, VEL, a.ctypes.data_as(_fp)))
+
+    # -- cell / spatial caches -----------------------------------------------------------------
+    def set_cell(self, lo, hi):
+        """`md.cell = SimBox::new(lo, hi)` (sol_shrinking_box.rs:600-603)."""
+        _check(load_library().mdx_set_box(self._h, (C.c_float * 3)(*map(float, lo)),
+                                          (C.c_float * 3)(*map(float, hi))))
+
+    def rebuild_spatial_caches(self):
+        _check(load_library().mdx_rebuild_spatial_caches(self._h))
+
+    def neighbor_list(self):
+        """-> (offsets [N+1], idx) of the Verlet list at the last rebuild, caller atom order."""
+        lib = load_library()
+        off = np.zeros(self.n_atoms + 1, dtype=np.uint32)
+        _check(lib.mdx_neighbor_list(self._h, off.ctypes.data_as(_u32p), None))
+        idx = np.zeros(max(int(off[-1]), 1), dtype=np.uint32)
+        _check(lib.mdx_neighbor_list(self._h, off.ctypes.data_as(_u32p), idx.ctypes.data_as(_u32p)))
+        return off, idx[: int(off[-1])]
+
+    # -- profiling ---------------------------------------------------------------------------
+    def profile(self, enable: bool = True):
+        _check(load_library().mdx_profile(self._h, 1 if enable else 0))
+
+    def stats(self) -> dict:
+        s = CStats()
+        _check(load_library().mdx_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def computation_time(self) -> float:
+        """`md.computation_time()` (src/md/mod.rs:740-743): ms spent inside step calls."""
+        return float(self.stats()["wall_ms_sum"])
+
+    # -- multi-GPU plumbing (raw device pointers; used by molchanica_amd.decomp) -----------------
+    def step_begin(self, dt: float, first: bool):
+        _check(load_library().mdx_step_begin(self._h, float(dt), int(first)))
+
+    def step_end(self, dt: float, last: bool):
+        _check(load_library().mdx_step_end(self._h, float(dt), int(last)))
+
+    def pack_positions(self, d_idx_ptr: int, n: int, d_out_ptr: int):
+        _check(load_library().mdx_pack_positions(self._h, C.c_void_p(d_idx_ptr), int(n), C.c_void_p(d_out_ptr)))
+
+    def unpack_positions(self, d_idx_ptr: int, n: int, d_in_ptr: int):
+        _check(load_library().mdx_unpack_positions(self._h, C.c_void_p(d_idx_ptr), int(n), C.c_void_p(d_in_ptr)))
+
+    def needs_rebuild(self) -> bool:
+        v = C.c_int(0)
+        _check(load_library().mdx_needs_rebuild(self._h, C.byref(v)))
+        return bool(v.value)
+
+    def stream_ptr(self) -> int:
+        return int(load_library().mdx_stream(self._h) or 0)
+
+
+def run_dynamics_blocking(md: MdState, dt: float, n_steps: int):
+    """`run_dynamics_blocking` (src/md/mod.rs:696-724): n plain steps, no early exit."""
+    if n_steps == 0:
+        return
+    md.step(dt, None, n_steps)
+
+
+def compute_energy_snapshot(system: MdSystem, cfg: MdConfig | None = None, device: int = 0,
+                            with_forces: bool = False):
+    """`dynamics::compute_energy_snapshot` (src/md/mod.rs:1036): stateless single-point scorer.
+    Returns the energy dict (and forces [N,3] when asked)."""
+    lib = load_library()
+    cfg = cfg or MdConfig()
+    system.normalise()
+    cs, cc = system.to_c(), cfg.to_c()
+    e = CEnergies()
+    f = np.zeros((system.n_atoms, 3), dtype=np.float32) if with_forces else None
+    _check(lib.mdx_single_point(C.byref(cs), C.byref(cc), int(device), C.byref(e),
+                                None if f is None else f.ctypes.data_as(_fp)))
+    return (e.as_dict(), f) if with_forces else e.as_dict()

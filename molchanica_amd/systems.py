@@ -1,0 +1,367 @@
+"""Seeded synthetic inputs S0–S4 for the MD hot path.
+
+The reference commits no structures or parameter files (/root/reference .gitignore:15-34), so
+every configuration of BASELINE.json is generated here from a seed: flexible 3-site TIP3P water
+(standard Amber values, not from the reference tree), GAFF-like ligands and bonded chains.
+Pure numpy host code, setup-time only.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from ._abi import MdSystem
+from . import topology as topo
+
+KB = 0.0019872041          # kcal/mol/K
+ACC_CONV = 418.4           # kcal/mol/Å/Da -> Å/ps²
+
+# flexible TIP3P
+TIP3P = dict(o_sigma=3.15061, o_eps=0.1521, q_o=-0.834, q_h=0.417, r_oh=0.9572, k_b=553.0,
+             theta=math.radians(104.52), k_theta=100.0, m_o=15.9994, m_h=1.008)
+
+# GAFF-like LJ table for the synthetic solutes: (sigma Å, eps kcal/mol)
+SOLUTE_TYPES = [(3.39967, 0.0860), (3.25000, 0.1700), (2.95992, 0.2100), (2.0, 0.0157)]
+SOLUTE_MASS = [12.011, 14.007, 15.999, 1.008]
+
+
+def maxwell_boltzmann(mass: np.ndarray, temp: float, rng: np.random.Generator) -> np.ndarray:
+    sig = np.sqrt(KB * temp * ACC_CONV / mass)[:, None]
+    v = rng.normal(size=(mass.size, 3)) * sig
+    p = (v * mass[:, None]).sum(0) / mass.sum()
+    return (v - p).astype(np.float32)
+
+
+def _random_rotations(n: int, rng: np.random.Generator) -> np.ndarray:
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q.T
+    r = np.empty((n, 3, 3))
+    r[:, 0, 0] = 1 - 2 * (y * y + z * z); r[:, 0, 1] = 2 * (x * y - z * w); r[:, 0, 2] = 2 * (x * z + y * w)
+    r[:, 1, 0] = 2 * (x * y + z * w); r[:, 1, 1] = 1 - 2 * (x * x + z * z); r[:, 1, 2] = 2 * (y * z - x * w)
+    r[:, 2, 0] = 2 * (x * z - y * w); r[:, 2, 1] = 2 * (y * z + x * w); r[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    return r
+
+
+def _water_atoms(sites: np.ndarray, rng: np.random.Generator, jitter: float):
+    """sites [W,3] -> pos [3W,3] (O,H,H per water), randomly oriented."""
+    w = sites.shape[0]
+    t = TIP3P
+    h = np.array([[t["r_oh"] * math.sin(t["theta"] / 2), t["r_oh"] * math.cos(t["theta"] / 2), 0.0],
+                  [-t["r_oh"] * math.sin(t["theta"] / 2), t["r_oh"] * math.cos(t["theta"] / 2), 0.0]])
+    rot = _random_rotations(w, rng)
+    pos = np.empty((w, 3, 3))
+    pos[:, 0] = sites
+    pos[:, 1] = sites + rot @ h[0]
+    pos[:, 2] = sites + rot @ h[1]
+    pos = pos.reshape(-1, 3)
+    if jitter > 0:
+        pos = pos + rng.normal(scale=jitter, size=pos.shape)
+    return pos
+
+
+def _water_topology(first_atom: int, w: int, type_o: int, type_h: int):
+    t = TIP3P
+    o = first_atom + 3 * np.arange(w, dtype=np.int64)
+    bonds = np.stack([np.stack([o, o + 1], 1), np.stack([o, o + 2], 1)], 1).reshape(-1, 2)
+    angles = np.stack([o + 1, o, o + 2], 1)
+    excl_pairs = np.concatenate([bonds, np.stack([o + 1, o + 2], 1)], 0)
+    return dict(
+        bonds=bonds, bond_k=np.full(2 * w, t["k_b"]), bond_r0=np.full(2 * w, t["r_oh"]),
+        angles=angles, angle_k=np.full(w, t["k_theta"]), angle_t0=np.full(w, t["theta"]),
+        excl_pairs=excl_pairs,
+        mass=np.tile([t["m_o"], t["m_h"], t["m_h"]], w),
+        charge=np.tile([t["q_o"], t["q_h"], t["q_h"]], w),
+        lj_type=np.tile([type_o, type_h, type_h], w),
+    )
+
+
+def water_box(n_side: int = 6, seed: int = 5, spacing: float = 3.1034, jitter: float = 0.05,
+              temp: float = 300.0, name: str | None = None) -> MdSystem:
+    """n_side³ flexible TIP3P waters on a jittered lattice.  n_side=70 is S4/C5 `water1M`
+    (1,029,000 atoms, 217.24 Å cube)."""
+    rng = np.random.default_rng(seed)
+    w = n_side ** 3
+    box = n_side * spacing
+    g = (np.arange(n_side) + 0.5) * spacing
+    sites = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    pos = _water_atoms(sites, rng, jitter)
+    tp = _water_topology(0, w, 0, 1)
+    off, idx = topo.csr_from_pairs(3 * w, tp["excl_pairs"])
+    mass = tp["mass"].astype(np.float32)
+    return MdSystem(
+        pos=pos, mass=mass, charge=tp["charge"], lj_type=tp["lj_type"],
+        lj_sigma=[TIP3P["o_sigma"], 0.0], lj_eps=[TIP3P["o_eps"], 0.0],
+        vel=maxwell_boltzmann(mass, temp, np.random.default_rng(seed + 100)),
+        bond_idx=tp["bonds"], bond_k=tp["bond_k"], bond_r0=tp["bond_r0"],
+        angle_idx=tp["angles"], angle_k=tp["angle_k"], angle_theta0=tp["angle_t0"],
+        excl_offsets=off, excl_idx=idx, mol_start=3 * np.arange(w),
+        periodic=True, box_lo=(0, 0, 0), box_hi=(box, box, box),
+        name=name or f"water{3 * w}",
+    ).normalise()
+
+
+# ---------------------------------------------------------------------------------------------
+def _solute_from_geometry(pos: np.ndarray, bonds: np.ndarray, types: np.ndarray,
+                          rng: np.random.Generator, charge_sigma: float = 0.3):
+    """Parameterise a bonded solute around its generated geometry (equilibrium values are the
+    actual geometry perturbed by 2 %, so every bonded term carries a non-zero force)."""
+    n = pos.shape[0]
+    adj = topo.adjacency(n, bonds)
+    angles = topo.angles_from_bonds(adj)
+    dihedrals = topo.dihedrals_from_bonds(adj)
+    off, idx, p14 = topo.exclusions_and_pairs14(n, adj)
+    b = np.asarray(bonds, dtype=np.int64)
+    r = np.linalg.norm(pos[b[:, 0]] - pos[b[:, 1]], axis=1)
+    bond_r0 = r * (1 + rng.normal(scale=0.02, size=r.size))
+    bond_k = rng.uniform(250.0, 450.0, size=r.size)
+    if angles.shape[0]:
+        a = angles.astype(np.int64)
+        v1 = pos[a[:, 0]] - pos[a[:, 1]]
+        v2 = pos[a[:, 2]] - pos[a[:, 1]]
+        cs = (v1 * v2).sum(1) / (np.linalg.norm(v1, axis=1) * np.linalg.norm(v2, axis=1))
+        th = np.arccos(np.clip(cs, -1, 1))
+        angle_t0 = np.clip(th * (1 + rng.normal(scale=0.02, size=th.size)), 0.3, math.pi - 0.05)
+        angle_k = rng.uniform(40.0, 90.0, size=th.size)
+    else:
+        angle_t0 = angle_k = np.zeros(0)
+    nd = dihedrals.shape[0]
+    dih_v = rng.uniform(0.1, 2.0, size=nd)
+    dih_n = rng.integers(1, 4, size=nd)
+    dih_phase = rng.integers(0, 2, size=nd) * math.pi
+    q = rng.normal(scale=charge_sigma, size=n)
+    q -= q.mean()
+    return dict(angles=angles, dihedrals=dihedrals, excl_off=off, excl_idx=idx, p14=p14,
+                bond_k=bond_k, bond_r0=bond_r0, angle_k=angle_k, angle_t0=angle_t0,
+                dih_v=dih_v, dih_n=dih_n, dih_phase=dih_phase, charge=q,
+                mass=np.asarray(SOLUTE_MASS)[types])
+
+
+def lig50(seed: int = 1, n_atoms: int = 50) -> MdSystem:
+    """S0/C1: random bonded tree (degree <= 4), vacuum, no cutoff — the editor's ~50-atom ligand
+    (/root/reference src/mol_editor/mod.rs:826-912)."""
+    rng = np.random.default_rng(seed)
+    pos = np.zeros((n_atoms, 3))
+    deg = np.zeros(n_atoms, dtype=int)
+    bonds = []
+    k = 1
+    while k < n_atoms:
+        parent = int(rng.integers(0, k))
+        if deg[parent] >= (3 if parent else 4):
+            continue
+        for _ in range(200):
+            d = rng.normal(size=3)
+            d /= np.linalg.norm(d)
+            cand = pos[parent] + 1.5 * d
+            dist = np.linalg.norm(pos[:k] - cand, axis=1)
+            dist[parent] = 9.0
+            if dist.min() >= 2.1:
+                break
+        else:
+            continue
+        pos[k] = cand
+        bonds.append((parent, k))
+        deg[parent] += 1
+        deg[k] += 1
+        k += 1
+    bonds = np.asarray(bonds)
+    types = rng.integers(0, 4, size=n_atoms)
+    sp = _solute_from_geometry(pos, bonds, types, rng)
+    sig = rng.uniform(2.5, 3.4, size=n_atoms)
+    eps = rng.uniform(0.015, 0.21, size=n_atoms)
+    return MdSystem(
+        pos=pos, mass=sp["mass"], charge=sp["charge"], lj_type=np.arange(n_atoms),
+        lj_sigma=sig, lj_eps=eps, vel=maxwell_boltzmann(sp["mass"], 300.0, np.random.default_rng(seed + 100)),
+        bond_idx=bonds, bond_k=sp["bond_k"], bond_r0=sp["bond_r0"],
+        angle_idx=sp["angles"], angle_k=sp["angle_k"], angle_theta0=sp["angle_t0"],
+        dihedral_idx=sp["dihedrals"], dihedral_v=sp["dih_v"], dihedral_phase=sp["dih_phase"],
+        dihedral_n=sp["dih_n"], excl_offsets=sp["excl_off"], excl_idx=sp["excl_idx"],
+        pairs14_idx=sp["p14"], mol_start=[0], periodic=False, name=f"lig{n_atoms}",
+    ).normalise()
+
+
+def _serpentine_chain(n_atoms: int, centre: np.ndarray, row_len: float, rng: np.random.Generator,
+                      row_gap: float = 4.6, layer_gap: float = 5.2, rows_per_layer: int = 8):
+    """Compact bonded chain: zig-zag backbone along a serpentine centre line, every second
+    backbone atom carries one H-like side atom.  Returns pos, bonds, types."""
+    step = 1.27
+    n_back = int(math.ceil(n_atoms * 2 / 3))
+    # centre-line polyline
+    pts = []
+    row = 0
+    while True:
+        layer, r = divmod(row, rows_per_layer)
+        yy = r if layer % 2 == 0 else rows_per_layer - 1 - r
+        y = yy * row_gap
+        z = layer * layer_gap
+        xs = (0.0, row_len) if row % 2 == 0 else (row_len, 0.0)
+        pts.append((xs[0], y, z))
+        pts.append((xs[1], y, z))
+        row += 1
+        seg = np.diff(np.asarray(pts), axis=0)
+        if np.linalg.norm(seg, axis=1).sum() > (n_back + 2) * step:
+            break
+    pts = np.asarray(pts)
+    seg = np.diff(pts, axis=0)
+    seglen = np.linalg.norm(seg, axis=1)
+    cum = np.concatenate([[0.0], np.cumsum(seglen)])
+    s = (np.arange(n_back) + 0.5) * step
+    k = np.clip(np.searchsorted(cum, s, side="right") - 1, 0, len(seg) - 1)
+    back = pts[k] + seg[k] * ((s - cum[k]) / seglen[k])[:, None]
+    zig = np.where(np.arange(n_back) % 2 == 0, 0.36, -0.36)
+    back[:, 2] += zig
+    pos = [back]
+    bonds = [np.stack([np.arange(n_back - 1), np.arange(1, n_back)], 1)]
+    n_side = n_atoms - n_back
+    owners = (np.arange(n_side) * 2) % n_back if n_side * 2 <= n_back else np.arange(n_side) % n_back
+    side = back[owners].copy()
+    side[:, 2] += np.sign(zig[owners]) * 1.09
+    pos.append(side)
+    bonds.append(np.stack([owners, n_back + np.arange(n_side)], 1))
+    pos = np.concatenate(pos) + rng.normal(scale=0.03, size=(n_atoms, 3))
+    pos += centre - pos.mean(0)
+    types = np.concatenate([rng.integers(0, 3, size=n_back), np.full(n_side, 3)])
+    return pos, np.concatenate(bonds), types
+
+
+def _helix(n_atoms: int, axis_origin: np.ndarray, phase: float, rng: np.random.Generator):
+    """One helical strand (radius 9 Å, rise 1.0 Å per backbone atom) with side atoms pointing in."""
+    n_back = int(math.ceil(n_atoms * 2 / 3))
+    t = np.arange(n_back)
+    ang = phase + t * 0.14
+    back = np.stack([9.0 * np.cos(ang), 9.0 * np.sin(ang), t * 0.34 * 3.0], 1)
+    n_side = n_atoms - n_back
+    owners = (np.arange(n_side) * 2) % n_back
+    side = back[owners].copy()
+    side[:, 0] *= (9.0 - 1.09) / 9.0
+    side[:, 1] *= (9.0 - 1.09) / 9.0
+    pos = np.concatenate([back, side]) + rng.normal(scale=0.03, size=(n_atoms, 3))
+    pos += axis_origin
+    bonds = np.concatenate([np.stack([t[:-1], t[1:]], 1), np.stack([owners, n_back + np.arange(n_side)], 1)])
+    types = np.concatenate([rng.integers(0, 3, size=n_back), np.full(n_side, 3)])
+    return pos, bonds, types
+
+
+def _solvate(solutes: list, box: float, n_total: int | None, seed: int, name: str,
+             clearance: float = 2.9) -> MdSystem:
+    """Merge bonded solutes (pos, bonds, types, params) with lattice water up to n_total atoms."""
+    from scipy.spatial import cKDTree
+
+    rng = np.random.default_rng(seed + 7)
+    n_side = int(round(box / 3.1034))
+    sp = box / n_side
+    g = (np.arange(n_side) + 0.5) * sp
+    sites = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    sol_pos = np.concatenate([s["pos"] for s in solutes]) if solutes else np.zeros((0, 3))
+    n_sol = sol_pos.shape[0]
+    if n_sol:
+        tree = cKDTree(np.mod(sol_pos, box), boxsize=box)
+        d, _ = tree.query(sites, k=1)
+        sites = sites[d > clearance + 0.8]
+    if n_total is not None:
+        w = (n_total - n_sol) // 3
+        if w > sites.shape[0]:
+            raise ValueError(f"{name}: only {sites.shape[0]} water sites for {w} waters")
+        keep = np.sort(rng.choice(sites.shape[0], size=w, replace=False))
+        sites = sites[keep]
+    w = sites.shape[0]
+    wpos = _water_atoms(sites, rng, 0.05)
+    n_types = len(SOLUTE_TYPES)
+    tp = _water_topology(n_sol, w, n_types, n_types + 1)
+
+    pos = np.concatenate([sol_pos, wpos])
+    n = pos.shape[0]
+    mass = np.concatenate([s["mass"] for s in solutes] + [tp["mass"]])
+    charge = np.concatenate([s["charge"] for s in solutes] + [tp["charge"]])
+    lj_type = np.concatenate([s["types"] for s in solutes] + [tp["lj_type"]])
+    bonds, bk, br0, angles, ak, at0 = [], [], [], [], [], []
+    dih, dv, dp, dn, p14, excl_pairs, mol_start = [], [], [], [], [], [], []
+    base = 0
+    for s in solutes:
+        mol_start.append(base)
+        bonds.append(s["bonds"] + base); bk.append(s["bond_k"]); br0.append(s["bond_r0"])
+        angles.append(s["angles"].astype(np.int64) + base); ak.append(s["angle_k"]); at0.append(s["angle_t0"])
+        dih.append(s["dihedrals"].astype(np.int64) + base); dv.append(s["dih_v"]); dp.append(s["dih_phase"]); dn.append(s["dih_n"])
+        p14.append(s["p14"].astype(np.int64) + base)
+        eo, ei = s["excl_off"].astype(np.int64), s["excl_idx"].astype(np.int64)
+        ii = np.repeat(np.arange(s["pos"].shape[0]), np.diff(eo))
+        m = ii < ei
+        excl_pairs.append(np.stack([ii[m], ei[m]], 1) + base)
+        base += s["pos"].shape[0]
+    bonds.append(tp["bonds"]); bk.append(tp["bond_k"]); br0.append(tp["bond_r0"])
+    angles.append(tp["angles"]); ak.append(tp["angle_k"]); at0.append(tp["angle_t0"])
+    excl_pairs.append(tp["excl_pairs"])
+    mol_start = np.concatenate([np.asarray(mol_start, dtype=np.int64), n_sol + 3 * np.arange(w)])
+    off, idx = topo.csr_from_pairs(n, np.concatenate(excl_pairs))
+    cat = lambda xs, shape: (np.concatenate(xs) if xs else np.zeros(shape))
+    mass = mass.astype(np.float32)
+    return MdSystem(
+        pos=pos, mass=mass, charge=charge, lj_type=lj_type,
+        lj_sigma=[t[0] for t in SOLUTE_TYPES] + [TIP3P["o_sigma"], 0.0],
+        lj_eps=[t[1] for t in SOLUTE_TYPES] + [TIP3P["o_eps"], 0.0],
+        vel=maxwell_boltzmann(mass, 300.0, np.random.default_rng(seed + 100)),
+        bond_idx=np.concatenate(bonds), bond_k=np.concatenate(bk), bond_r0=np.concatenate(br0),
+        angle_idx=np.concatenate(angles), angle_k=np.concatenate(ak), angle_theta0=np.concatenate(at0),
+        dihedral_idx=cat(dih, (0, 4)), dihedral_v=cat(dv, 0), dihedral_phase=cat(dp, 0),
+        dihedral_n=cat(dn, 0), excl_offsets=off, excl_idx=idx, pairs14_idx=cat(p14, (0, 2)),
+        mol_start=mol_start, periodic=True, box_lo=(0, 0, 0), box_hi=(box, box, box), name=name,
+    ).normalise()
+
+
+def _solute_dict(pos, bonds, types, rng):
+    sp = _solute_from_geometry(pos, bonds, types, rng)
+    sp.update(pos=pos, bonds=np.asarray(bonds, dtype=np.int64), types=types)
+    return sp
+
+
+def dhfr23k(seed: int = 2, n_chain: int = 2489, n_total: int = 23558, box: float = 62.23) -> MdSystem:
+    """S1/C2: DHFR/JAC-sized system — 2,489-atom bonded chain + 7,023 waters, 62.23 Å cube."""
+    rng = np.random.default_rng(seed)
+    pos, bonds, types = _serpentine_chain(n_chain, np.full(3, box / 2), 38.0, rng)
+    return _solvate([_solute_dict(pos, bonds, types, rng)], box, n_total, seed, "dhfr23k")
+
+
+def small_solvated(seed: int = 11, n_chain: int = 120, box: float = 26.0,
+                   n_total: int | None = None) -> MdSystem:
+    """A few-thousand-atom chain-in-water system for fast parity tests."""
+    rng = np.random.default_rng(seed)
+    pos, bonds, types = _serpentine_chain(n_chain, np.full(3, box / 2), 14.0, rng, rows_per_layer=3)
+    return _solvate([_solute_dict(pos, bonds, types, rng)], box, n_total, seed, f"solv{n_chain}")
+
+
+def complex50k(seed: int = 3, box: float = 80.0, n_total: int = 51200) -> MdSystem:
+    """S2/C3: 5,000-atom chain + the 50-atom ligand placed ~8 Å from the chain centroid surface
+    (cf. /root/reference src/docking/mod.rs:98-105) + water."""
+    rng = np.random.default_rng(seed)
+    pos, bonds, types = _serpentine_chain(5000, np.full(3, box / 2), 46.0, rng)
+    chain = _solute_dict(pos, bonds, types, rng)
+    lig = lig50(seed=1)
+    lp = lig.pos.astype(np.float64)
+    lp = lp - lp.mean(0)
+    top = pos[:, 2].max()
+    lp += np.array([box / 2, box / 2, top + 8.0 + (lp[:, 2].max() - lp[:, 2].min()) / 2])
+    ltypes = rng.integers(0, 3, size=lp.shape[0])
+    ligd = _solute_dict(lp, lig.bond_idx.astype(np.int64), ltypes, rng)
+    return _solvate([chain, ligd], box, n_total, seed, "complex50k")
+
+
+def dna100k(seed: int = 4, box: float = 100.0, n_total: int = 100000) -> MdSystem:
+    """S3/C4: two ~800-atom helical strands + water, 100 Å cube."""
+    rng = np.random.default_rng(seed)
+    o = np.array([box / 2, box / 2, box / 2 - 0.5 * 534 * 0.34 * 3.0 * 0.5])
+    a = _helix(800, o, 0.0, rng)
+    b = _helix(800, o, math.pi, rng)
+    return _solvate([_solute_dict(*a, rng), _solute_dict(*b, rng)], box, n_total - (n_total - 1600) % 3,
+                    seed, "dna100k")
+
+
+def water1m(seed: int = 5) -> MdSystem:
+    """S4/C5: 70³ waters = 1,029,000 atoms, 217.24 Å cube."""
+    return water_box(70, seed=seed, name="water1M")
+
+
+BY_NAME = {
+    "lig50": lig50, "dhfr23k": dhfr23k, "complex50k": complex50k, "dna100k": dna100k,
+    "water1M": water1m,
+}

@@ -1,0 +1,560 @@
+/*
+ * mdx_oracle.c — CPU restatement (plain C, fp64) of the MD force / integrate path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (molchanica_amd/, libmdx.so) links,
+ * imports or executes this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may.  PARITY UNPINNED: the reference's arithmetic lives in the third-party
+ * crate `dynamics = "0.2.2"` (Cargo.toml:25; + ewald 0.1.15, lin_alg 1.4.3, bio_files 0.5.3)
+ * which is absent from /root/reference and cannot be built here (no Rust toolchain), and the
+ * reference holds no test or golden vector on this path (src/tests.rs:3-4 is empty).  This
+ * restatement is therefore pinned by analytic known-answer tests and self-consistency checks
+ * (tests/test_oracle_*.py), not by the reference binary.
+ *
+ * What it follows in the reference tree (paths relative to /root/reference):
+ *   - LJ 12-6 force/energy form and the `tgt - src` direction convention: src/cuda/util.cu:92-140
+ *   - Coulomb form dir*q_s*q_t/(r^2 + soft):                           src/cuda/util.cu:53-63
+ *   - minimum image d - rint(d/L)*L per axis, guard extent>0:          src/cuda/util.cu:65-71,
+ *                                                                       src/md/mod.rs:278-296
+ *   - parameter record shapes/units (bond k_b,r_0; angle k,theta_0; dihedral
+ *     barrier_height/divider, phase, periodicity; LJ sigma,eps; mass):  src/ui/popup/ff_params.rs:322-580
+ *   - per-term disable switches:                                        src/md/mod.rs:671-682
+ *   - energy outputs and their units:                                   src/ui/panels/md_viewer.rs:195-257
+ *   - velocity-Verlet integrator named at                               README.md:236-240
+ * Conventions the absent crate fixes silently are explicit mdx_config fields (include/mdx.h).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "../include/mdx.h"
+
+#define ACC_CONV 418.4          /* kcal/mol/Å/Da -> Å/ps² */
+#define KB_KCAL  0.0019872041   /* kcal/mol/K */
+
+enum { E_BOND, E_ANGLE, E_DIHEDRAL, E_LJ, E_COUL, E_LJ14, E_COUL14, E_KIN, E_N };
+
+int orc_num_energies(void) { return E_N; }
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+static int cutoff_on(float rc) { return rc > 0.0f && isfinite(rc); }
+
+/* src/cuda/util.cu:65-71 / src/md/mod.rs:278-296 */
+static inline void min_image(const mdx_system* s, double d[3]) {
+    if (!s->periodic) return;
+    for (int a = 0; a < 3; ++a) {
+        double L = (double)s->box_hi[a] - (double)s->box_lo[a];
+        if (L > 0.0) d[a] -= rint(d[a] / L) * L;
+    }
+}
+
+/* Canonical fp32 pair distance: the same IEEE operations, in the same order, that the GPU's
+ * neighbour-list extraction kernel performs (no FMA contraction: this file is built with
+ * -ffp-contract=off and the fused steps are spelled fmaf). */
+static inline float r2_canonical(const mdx_system* s, const float* pi, const float* pj) {
+    float d[3];
+    for (int a = 0; a < 3; ++a) {
+        d[a] = pi[a] - pj[a];
+        if (s->periodic) {
+            float L = s->box_hi[a] - s->box_lo[a];
+            d[a] = d[a] - rintf(d[a] / L) * L;
+        }
+    }
+    return fmaf(d[2], d[2], fmaf(d[1], d[1], d[0] * d[0]));
+}
+
+/* Position wrap into [lo, lo+L): identical fp32 sequence to the GPU binning kernel. */
+void orc_wrap_f32(const mdx_system* s, float* pos, uint32_t n) {
+    if (!s->periodic) return;
+    for (uint32_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) {
+            float lo = s->box_lo[a], L = s->box_hi[a] - s->box_lo[a];
+            float x = pos[3 * i + a];
+            float t = x - floorf((x - lo) / L) * L;
+            if (t < lo) t += L;
+            if (t >= lo + L) t -= L;
+            pos[3 * i + a] = t;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* exclusion lookup: merged (excl CSR + pairs14) per-atom sorted lists                          */
+typedef struct { uint32_t* off; uint32_t* idx; } excl_t;
+
+static int cmp_u32(const void* a, const void* b) {
+    uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
+    return (x > y) - (x < y);
+}
+
+static excl_t build_excl(const mdx_system* s) {
+    uint32_t n = s->n_atoms;
+    excl_t e;
+    e.off = (uint32_t*)calloc((size_t)n + 1, sizeof(uint32_t));
+    for (uint32_t i = 0; i < n; ++i)
+        e.off[i + 1] = s->excl_offsets ? s->excl_offsets[i + 1] - s->excl_offsets[i] : 0;
+    for (uint32_t p = 0; p < s->n_pairs14; ++p) {
+        e.off[s->pairs14_idx[2 * p] + 1]++;
+        e.off[s->pairs14_idx[2 * p + 1] + 1]++;
+    }
+    for (uint32_t i = 0; i < n; ++i) e.off[i + 1] += e.off[i];
+    e.idx = (uint32_t*)malloc(sizeof(uint32_t) * (e.off[n] ? e.off[n] : 1));
+    uint32_t* cur = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
+    memcpy(cur, e.off, sizeof(uint32_t) * ((size_t)n + 1));
+    if (s->excl_offsets)
+        for (uint32_t i = 0; i < n; ++i)
+            for (uint32_t k = s->excl_offsets[i]; k < s->excl_offsets[i + 1]; ++k)
+                e.idx[cur[i]++] = s->excl_idx[k];
+    for (uint32_t p = 0; p < s->n_pairs14; ++p) {
+        uint32_t a = s->pairs14_idx[2 * p], b = s->pairs14_idx[2 * p + 1];
+        e.idx[cur[a]++] = b;
+        e.idx[cur[b]++] = a;
+    }
+    for (uint32_t i = 0; i < n; ++i)
+        qsort(e.idx + e.off[i], e.off[i + 1] - e.off[i], sizeof(uint32_t), cmp_u32);
+    free(cur);
+    return e;
+}
+
+static inline int is_excluded(const excl_t* e, uint32_t i, uint32_t j) {
+    uint32_t lo = e->off[i], hi = e->off[i + 1];
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (e->idx[mid] < j) lo = mid + 1; else hi = mid;
+    }
+    return lo < e->off[i + 1] && e->idx[lo] == j;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* pair parameters                                                                              */
+static inline void lj_pair(const mdx_system* s, const mdx_config* c, uint32_t i, uint32_t j,
+                           double* sig, double* eps) {
+    double si = s->lj_sigma[s->lj_type[i]], sj = s->lj_sigma[s->lj_type[j]];
+    double ei = s->lj_eps[s->lj_type[i]], ej = s->lj_eps[s->lj_type[j]];
+    *sig = (c->combining_rule == MDX_COMBINE_GEOMETRIC) ? sqrt(si * sj) : 0.5 * (si + sj);
+    *eps = sqrt(ei * ej);
+}
+
+static inline int nb_active(const mdx_system* s, uint32_t i) {
+    return !(s->flags && (s->flags[i] & MDX_ATOM_BONDED_ONLY));
+}
+
+/* One non-bonded pair.  d = r_i - r_j (tgt - src, src/cuda/util.cu:118-140), r2 = |d|^2 (fp64).
+ * Inclusion (r < rc) is decided by the caller from the canonical fp32 r2. Adds force on i
+ * (caller adds the opposite on j) and energies. */
+static inline void pair_terms(const mdx_config* c, double sig, double eps, double qq,
+                              double r2, int in_lj, int in_coul, double* fs_out,
+                              double* e_lj, double* e_coul) {
+    double fs = 0.0; /* force on i = fs * d */
+    double r = sqrt(r2), inv_r = 1.0 / r;
+    if (in_lj && !(c->overrides & MDX_OVR_LJ_DISABLED) && eps != 0.0) {
+        /* src/cuda/util.cu:92-115 */
+        double sr = sig * inv_r, sr2 = sr * sr, sr6 = sr2 * sr2 * sr2, sr12 = sr6 * sr6;
+        fs += 24.0 * eps * (2.0 * sr12 - sr6) * inv_r * inv_r;
+        *e_lj += 4.0 * eps * (sr12 - sr6);
+    }
+    if (in_coul && !(c->overrides & MDX_OVR_COULOMB_DISABLED) && qq != 0.0) {
+        double kqq = (double)c->coulomb_k * qq;
+        double rc = (double)c->coulomb_cutoff;
+        int cut = cutoff_on(c->coulomb_cutoff);
+        switch (c->coulomb_mode) {
+        case MDX_COULOMB_REACTION: {
+            double krf = cut ? 1.0 / (2.0 * rc * rc * rc) : 0.0;
+            double crf = cut ? 1.5 / rc : 0.0;
+            fs += kqq * (inv_r * inv_r * inv_r - 2.0 * krf);
+            *e_coul += kqq * (inv_r + krf * r2 - crf);
+        } break;
+        case MDX_COULOMB_EWALD: {
+            double a = (double)c->ewald_alpha, ar = a * r;
+            double erfc_ar = erfc(ar);
+            fs += kqq * (erfc_ar * inv_r + 1.1283791670955126 * a * exp(-ar * ar)) * inv_r * inv_r;
+            *e_coul += kqq * erfc_ar * inv_r;
+        } break;
+        default: /* MDX_COULOMB_SHIFTED; src/cuda/util.cu:53-63 with the softening as a parameter */
+            fs += kqq * inv_r / (r2 + (double)c->softening_sq);
+            *e_coul += kqq * (inv_r - (cut ? 1.0 / rc : 0.0));
+        }
+    }
+    *fs_out = fs;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* bonded terms (Amber forms; ff_params.rs:352-372, 401-421, 474-511)                           */
+static void bonded_forces(const mdx_system* s, const mdx_config* c, const double* x, double* f,
+                          double* en) {
+    if (c->overrides & MDX_OVR_BONDED_DISABLED) return;
+    for (uint32_t b = 0; b < s->n_bonds; ++b) {
+        uint32_t i = s->bond_idx[2 * b], j = s->bond_idx[2 * b + 1];
+        double d[3] = { x[3*i] - x[3*j], x[3*i+1] - x[3*j+1], x[3*i+2] - x[3*j+2] };
+        min_image(s, d);
+        double r = sqrt(d[0]*d[0] + d[1]*d[1] + d[2]*d[2]);
+        double dr = r - (double)s->bond_r0[b], k = s->bond_k[b];
+        en[E_BOND] += k * dr * dr;
+        double fs = -2.0 * k * dr / r;
+        for (int a = 0; a < 3; ++a) { f[3*i+a] += fs * d[a]; f[3*j+a] -= fs * d[a]; }
+    }
+    for (uint32_t t = 0; t < s->n_angles; ++t) {
+        uint32_t i = s->angle_idx[3*t], j = s->angle_idx[3*t+1], k = s->angle_idx[3*t+2];
+        double a1[3] = { x[3*i]-x[3*j], x[3*i+1]-x[3*j+1], x[3*i+2]-x[3*j+2] };
+        double a2[3] = { x[3*k]-x[3*j], x[3*k+1]-x[3*j+1], x[3*k+2]-x[3*j+2] };
+        min_image(s, a1); min_image(s, a2);
+        double r1 = sqrt(a1[0]*a1[0]+a1[1]*a1[1]+a1[2]*a1[2]);
+        double r2 = sqrt(a2[0]*a2[0]+a2[1]*a2[1]+a2[2]*a2[2]);
+        double cs = (a1[0]*a2[0]+a1[1]*a2[1]+a1[2]*a2[2]) / (r1 * r2);
+        if (cs > 1.0) cs = 1.0; if (cs < -1.0) cs = -1.0;
+        double th = acos(cs), dth = th - (double)s->angle_theta0[t], kk = s->angle_k[t];
+        en[E_ANGLE] += kk * dth * dth;
+        double sn = sqrt(1.0 - cs * cs); if (sn < 1e-8) sn = 1e-8;
+        double dEdth = 2.0 * kk * dth;
+        /* dtheta/dr_i = -(a2/|a2| - cos * a1/|a1|) / (|a1| sin) */
+        for (int a = 0; a < 3; ++a) {
+            double gi = -(a2[a] / r2 - cs * a1[a] / r1) / (r1 * sn);
+            double gk = -(a1[a] / r1 - cs * a2[a] / r2) / (r2 * sn);
+            f[3*i+a] -= dEdth * gi;
+            f[3*k+a] -= dEdth * gk;
+            f[3*j+a] += dEdth * (gi + gk);
+        }
+    }
+    for (uint32_t t = 0; t < s->n_dihedrals; ++t) {
+        uint32_t i = s->dihedral_idx[4*t], j = s->dihedral_idx[4*t+1],
+                 k = s->dihedral_idx[4*t+2], l = s->dihedral_idx[4*t+3];
+        /* Blondel & Karplus: F = ri-rj, G = rj-rk, H = rl-rk, A = F x G, B = H x G */
+        double F[3] = { x[3*i]-x[3*j], x[3*i+1]-x[3*j+1], x[3*i+2]-x[3*j+2] };
+        double G[3] = { x[3*j]-x[3*k], x[3*j+1]-x[3*k+1], x[3*j+2]-x[3*k+2] };
+        double H[3] = { x[3*l]-x[3*k], x[3*l+1]-x[3*k+1], x[3*l+2]-x[3*k+2] };
+        min_image(s, F); min_image(s, G); min_image(s, H);
+        double A[3] = { F[1]*G[2]-F[2]*G[1], F[2]*G[0]-F[0]*G[2], F[0]*G[1]-F[1]*G[0] };
+        double B[3] = { H[1]*G[2]-H[2]*G[1], H[2]*G[0]-H[0]*G[2], H[0]*G[1]-H[1]*G[0] };
+        double A2 = A[0]*A[0]+A[1]*A[1]+A[2]*A[2], B2 = B[0]*B[0]+B[1]*B[1]+B[2]*B[2];
+        double Gn = sqrt(G[0]*G[0]+G[1]*G[1]+G[2]*G[2]);
+        if (A2 < 1e-24 || B2 < 1e-24 || Gn < 1e-12) continue;
+        double cosphi = (A[0]*B[0]+A[1]*B[1]+A[2]*B[2]);
+        /* sin(phi) |A||B| = (B x A) . G / |G| */
+        double BxA[3] = { B[1]*A[2]-B[2]*A[1], B[2]*A[0]-B[0]*A[2], B[0]*A[1]-B[1]*A[0] };
+        double sinphi = (BxA[0]*G[0]+BxA[1]*G[1]+BxA[2]*G[2]) / Gn;
+        double phi = atan2(sinphi, cosphi);
+        double n = (double)s->dihedral_n[t], v = s->dihedral_v[t], ph = s->dihedral_phase[t];
+        en[E_DIHEDRAL] += v * (1.0 + cos(n * phi - ph));
+        double dEdphi = -v * n * sin(n * phi - ph);
+        double FG = F[0]*G[0]+F[1]*G[1]+F[2]*G[2], HG = H[0]*G[0]+H[1]*G[1]+H[2]*G[2];
+        for (int a = 0; a < 3; ++a) {
+            double dpi = -Gn / A2 * A[a];
+            double dpl =  Gn / B2 * B[a];
+            double dpj =  Gn / A2 * A[a] + FG / (A2 * Gn) * A[a] - HG / (B2 * Gn) * B[a];
+            double dpk = -Gn / B2 * B[a] - FG / (A2 * Gn) * A[a] + HG / (B2 * Gn) * B[a];
+            f[3*i+a] -= dEdphi * dpi;
+            f[3*j+a] -= dEdphi * dpj;
+            f[3*k+a] -= dEdphi * dpk;
+            f[3*l+a] -= dEdphi * dpl;
+        }
+    }
+    /* scaled 1-4 pairs: no cutoff, no potential shift */
+    for (uint32_t p = 0; p < s->n_pairs14; ++p) {
+        uint32_t i = s->pairs14_idx[2*p], j = s->pairs14_idx[2*p+1];
+        if (!nb_active(s, i) || !nb_active(s, j)) continue;
+        double d[3] = { x[3*i]-x[3*j], x[3*i+1]-x[3*j+1], x[3*i+2]-x[3*j+2] };
+        min_image(s, d);
+        double r2 = d[0]*d[0]+d[1]*d[1]+d[2]*d[2], r = sqrt(r2), inv_r = 1.0 / r;
+        double sig, eps; lj_pair(s, c, i, j, &sig, &eps);
+        double fs = 0.0;
+        if (!(c->overrides & MDX_OVR_LJ_DISABLED)) {
+            double sr = sig * inv_r, sr2 = sr*sr, sr6 = sr2*sr2*sr2, sr12 = sr6*sr6;
+            fs += (double)c->scale14_lj * 24.0 * eps * (2.0 * sr12 - sr6) * inv_r * inv_r;
+            en[E_LJ14] += (double)c->scale14_lj * 4.0 * eps * (sr12 - sr6);
+        }
+        if (!(c->overrides & MDX_OVR_COULOMB_DISABLED)) {
+            double kqq = (double)c->scale14_coulomb * (double)c->coulomb_k *
+                         (double)s->charge[i] * (double)s->charge[j];
+            fs += kqq * inv_r * inv_r * inv_r;
+            en[E_COUL14] += kqq * inv_r;
+        }
+        for (int a = 0; a < 3; ++a) { f[3*i+a] += fs * d[a]; f[3*j+a] -= fs * d[a]; }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* cell grid for O(N) pair search (periodic or not)                                             */
+typedef struct {
+    int n[3]; double lo[3], w[3]; uint32_t* start; uint32_t* items; int periodic;
+} grid_t;
+
+static grid_t build_grid(const mdx_system* s, const double* x, double rmin) {
+    grid_t g; uint32_t N = s->n_atoms;
+    g.periodic = s->periodic;
+    double lo[3], hi[3];
+    if (s->periodic) for (int a = 0; a < 3; ++a) { lo[a] = s->box_lo[a]; hi[a] = s->box_hi[a]; }
+    else {
+        for (int a = 0; a < 3; ++a) { lo[a] = 1e300; hi[a] = -1e300; }
+        for (uint32_t i = 0; i < N; ++i) for (int a = 0; a < 3; ++a) {
+            if (x[3*i+a] < lo[a]) lo[a] = x[3*i+a];
+            if (x[3*i+a] > hi[a]) hi[a] = x[3*i+a];
+        }
+        for (int a = 0; a < 3; ++a) hi[a] += 1e-6;
+    }
+    size_t tot = 1;
+    for (int a = 0; a < 3; ++a) {
+        double L = hi[a] - lo[a];
+        int n = (int)floor(L / rmin); if (n < 1) n = 1; if (n > 256) n = 256;
+        g.n[a] = n; g.lo[a] = lo[a]; g.w[a] = L / n; tot *= (size_t)n;
+    }
+    g.start = (uint32_t*)calloc(tot + 1, sizeof(uint32_t));
+    g.items = (uint32_t*)malloc(sizeof(uint32_t) * (N ? N : 1));
+    uint32_t* cell = (uint32_t*)malloc(sizeof(uint32_t) * (N ? N : 1));
+    for (uint32_t i = 0; i < N; ++i) {
+        int c[3];
+        for (int a = 0; a < 3; ++a) {
+            double L = g.w[a] * g.n[a], t = x[3*i+a] - g.lo[a];
+            if (s->periodic) t -= floor(t / L) * L;
+            int k = (int)floor(t / g.w[a]);
+            if (k < 0) k = 0; if (k >= g.n[a]) k = g.n[a] - 1;
+            c[a] = k;
+        }
+        cell[i] = (uint32_t)((c[2] * g.n[1] + c[1]) * g.n[0] + c[0]);
+        g.start[cell[i] + 1]++;
+    }
+    for (size_t k = 0; k < tot; ++k) g.start[k + 1] += g.start[k];
+    uint32_t* cur = (uint32_t*)malloc(sizeof(uint32_t) * (tot + 1));
+    memcpy(cur, g.start, sizeof(uint32_t) * (tot + 1));
+    for (uint32_t i = 0; i < N; ++i) g.items[cur[cell[i]]++] = i;
+    free(cur); free(cell);
+    return g;
+}
+static void free_grid(grid_t* g) { free(g->start); free(g->items); }
+
+/* Enumerate the distinct neighbour cells of cell (cx,cy,cz) (27-stencil, deduplicated when a
+ * dimension has < 3 cells). Returns count, fills ids. */
+static int neighbour_cells(const grid_t* g, int cx, int cy, int cz, uint32_t* ids) {
+    int cnt = 0;
+    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+        int c[3] = { cx + dx, cy + dy, cz + dz }, ok = 1;
+        for (int a = 0; a < 3; ++a) {
+            if (g->periodic) c[a] = ((c[a] % g->n[a]) + g->n[a]) % g->n[a];
+            else if (c[a] < 0 || c[a] >= g->n[a]) ok = 0;
+        }
+        if (!ok) continue;
+        uint32_t id = (uint32_t)((c[2] * g->n[1] + c[1]) * g->n[0] + c[0]);
+        int dup = 0;
+        for (int k = 0; k < cnt; ++k) if (ids[k] == id) { dup = 1; break; }
+        if (!dup) ids[cnt++] = id;
+    }
+    return cnt;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Forces + energies.  x: fp64 positions [3N] (NULL -> s->pos).  f: [3N] out.  en: [E_N] out.
+ * use_cells: 0 = O(N^2) brute force, 1 = cell list (needs a cutoff).  Pair inclusion uses the
+ * canonical fp32 r2 of the positions rounded to f32.  ext: optional external forces [3N]. */
+int orc_forces(const mdx_system* s, const mdx_config* c, const double* x_in, const double* ext,
+               double* f, double* en, int use_cells) {
+    uint32_t N = s->n_atoms;
+    double* x = (double*)malloc(sizeof(double) * 3 * (N ? N : 1));
+    float* xf = (float*)malloc(sizeof(float) * 3 * (N ? N : 1));
+    for (uint32_t i = 0; i < 3 * N; ++i) {
+        x[i] = x_in ? x_in[i] : (double)s->pos[i];
+        xf[i] = (float)x[i];
+    }
+    memset(f, 0, sizeof(double) * 3 * N);
+    for (int k = 0; k < E_N; ++k) en[k] = 0.0;
+    excl_t ex = build_excl(s);
+    int cut_lj = cutoff_on(c->lj_cutoff), cut_c = cutoff_on(c->coulomb_cutoff);
+    float rc2_lj = c->lj_cutoff * c->lj_cutoff, rc2_c = c->coulomb_cutoff * c->coulomb_cutoff;
+    double rmax = fmax(cut_lj ? c->lj_cutoff : 0.0, cut_c ? c->coulomb_cutoff : 0.0);
+    if (use_cells && !(cut_lj && cut_c)) use_cells = 0;
+
+    grid_t g; if (use_cells) g = build_grid(s, x, rmax);
+    double e_lj = 0.0, e_c = 0.0;
+
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : e_lj, e_c)
+    for (uint32_t i = 0; i < N; ++i) {
+        if (!nb_active(s, i)) continue;
+        double fi[3] = { 0, 0, 0 };
+        /* full-list evaluation: each i sums over all j (every pair visited twice, energies halved);
+         * keeps the loop race-free under OpenMP */
+        uint32_t ids[27]; int ncell = 1; uint32_t jbeg = 0, jend = N;
+        if (use_cells) {
+            int cc[3];
+            for (int a = 0; a < 3; ++a) {
+                double L = g.w[a] * g.n[a], t = x[3*i+a] - g.lo[a];
+                if (s->periodic) t -= floor(t / L) * L;
+                int k = (int)floor(t / g.w[a]);
+                if (k < 0) k = 0; if (k >= g.n[a]) k = g.n[a] - 1;
+                cc[a] = k;
+            }
+            ncell = neighbour_cells(&g, cc[0], cc[1], cc[2], ids);
+        }
+        for (int ci = 0; ci < ncell; ++ci) {
+            if (use_cells) { jbeg = g.start[ids[ci]]; jend = g.start[ids[ci] + 1]; }
+            for (uint32_t jj = jbeg; jj < jend; ++jj) {
+                uint32_t j = use_cells ? g.items[jj] : jj;
+                if (j == i || !nb_active(s, j)) continue;
+                float r2f = r2_canonical(s, xf + 3 * i, xf + 3 * j);
+                int in_lj = !cut_lj || r2f < rc2_lj, in_c = !cut_c || r2f < rc2_c;
+                if (!in_lj && !in_c) continue;
+                if (is_excluded(&ex, i, j)) continue;
+                double d[3] = { x[3*i]-x[3*j], x[3*i+1]-x[3*j+1], x[3*i+2]-x[3*j+2] };
+                min_image(s, d);
+                double r2 = d[0]*d[0]+d[1]*d[1]+d[2]*d[2];
+                double sig, eps; lj_pair(s, c, i, j, &sig, &eps);
+                double qq = (double)s->charge[i] * (double)s->charge[j];
+                double fs, el = 0.0, ec = 0.0;
+                pair_terms(c, sig, eps, qq, r2, in_lj, in_c, &fs, &el, &ec);
+                fi[0] += fs * d[0]; fi[1] += fs * d[1]; fi[2] += fs * d[2];
+                e_lj += 0.5 * el; e_c += 0.5 * ec;
+            }
+        }
+        f[3*i] = fi[0]; f[3*i+1] = fi[1]; f[3*i+2] = fi[2];
+    }
+    en[E_LJ] = e_lj; en[E_COUL] = e_c;
+    bonded_forces(s, c, x, f, en);
+    if (ext) for (uint32_t i = 0; i < 3 * N; ++i) f[i] += ext[i];
+    if (use_cells) free_grid(&g);
+    free(ex.off); free(ex.idx); free(x); free(xf);
+    return 0;
+}
+
+/* Kinetic energy (kcal/mol) of fp64 velocities. */
+double orc_kinetic(const mdx_system* s, const double* v) {
+    double ke = 0.0;
+    for (uint32_t i = 0; i < s->n_atoms; ++i) {
+        if (s->flags && (s->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST))) continue;
+        ke += 0.5 * (double)s->mass[i] * (v[3*i]*v[3*i] + v[3*i+1]*v[3*i+1] + v[3*i+2]*v[3*i+2]);
+    }
+    return ke / ACC_CONV;
+}
+
+/* Velocity Verlet (README.md:236-240), fp64 state.  x, v updated in place.  en (E_N) receives the
+ * energies of the final state.  Returns 0. */
+int orc_step(const mdx_system* s, const mdx_config* c, double* x, double* v, double dt,
+             uint32_t n_steps, const double* ext, double* en, int use_cells) {
+    uint32_t N = s->n_atoms;
+    double* f = (double*)malloc(sizeof(double) * 3 * (N ? N : 1));
+    orc_forces(s, c, x, ext, f, en, use_cells);
+    for (uint32_t st = 0; st < n_steps; ++st) {
+        for (uint32_t i = 0; i < N; ++i) {
+            int fixed = s->flags && (s->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST));
+            double im = fixed ? 0.0 : ACC_CONV / (double)s->mass[i];
+            for (int a = 0; a < 3; ++a) {
+                v[3*i+a] += 0.5 * dt * f[3*i+a] * im;
+                x[3*i+a] += fixed ? 0.0 : dt * v[3*i+a];
+            }
+        }
+        orc_forces(s, c, x, ext, f, en, use_cells);
+        for (uint32_t i = 0; i < N; ++i) {
+            int fixed = s->flags && (s->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST));
+            double im = fixed ? 0.0 : ACC_CONV / (double)s->mass[i];
+            for (int a = 0; a < 3; ++a) v[3*i+a] += 0.5 * dt * f[3*i+a] * im;
+        }
+    }
+    en[E_KIN] = orc_kinetic(s, v);
+    free(f);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Verlet neighbour list (caller atom order, rows ascending): all j != i with canonical fp32
+ * r2 < rlist^2.  Two-call protocol like mdx_neighbor_list. pos: f32 [3N]. */
+int orc_neighbor_list(const mdx_system* s, const float* pos, float rlist, uint32_t* offsets,
+                      uint32_t* idx, int use_cells) {
+    uint32_t N = s->n_atoms; float rl2 = rlist * rlist;
+    grid_t g; double* xd = NULL;
+    if (use_cells) {
+        xd = (double*)malloc(sizeof(double) * 3 * (N ? N : 1));
+        for (uint32_t i = 0; i < 3 * N; ++i) xd[i] = pos[i];
+        g = build_grid(s, xd, (double)rlist * 1.0001);
+    }
+    uint32_t* cnt = (uint32_t*)calloc((size_t)N + 1, sizeof(uint32_t));
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && !idx) break;
+#pragma omp parallel for schedule(dynamic, 64)
+        for (uint32_t i = 0; i < N; ++i) {
+            uint32_t ids[27]; int ncell = 1; uint32_t jbeg = 0, jend = N, k = 0;
+            uint32_t* row = (pass == 1) ? idx + offsets[i] : NULL;
+            if (use_cells) {
+                int cc[3];
+                for (int a = 0; a < 3; ++a) {
+                    double L = g.w[a] * g.n[a], t = xd[3*i+a] - g.lo[a];
+                    if (s->periodic) t -= floor(t / L) * L;
+                    int q = (int)floor(t / g.w[a]);
+                    if (q < 0) q = 0; if (q >= g.n[a]) q = g.n[a] - 1;
+                    cc[a] = q;
+                }
+                ncell = neighbour_cells(&g, cc[0], cc[1], cc[2], ids);
+            }
+            for (int ci = 0; ci < ncell; ++ci) {
+                if (use_cells) { jbeg = g.start[ids[ci]]; jend = g.start[ids[ci] + 1]; }
+                for (uint32_t jj = jbeg; jj < jend; ++jj) {
+                    uint32_t j = use_cells ? g.items[jj] : jj;
+                    if (j == i) continue;
+                    if (r2_canonical(s, pos + 3 * i, pos + 3 * j) < rl2) {
+                        if (row) row[k] = j;
+                        ++k;
+                    }
+                }
+            }
+            if (pass == 0) cnt[i] = k;
+            else qsort(row, k, sizeof(uint32_t), cmp_u32);
+        }
+        if (pass == 0) {
+            offsets[0] = 0;
+            for (uint32_t i = 0; i < N; ++i) offsets[i + 1] = offsets[i] + cnt[i];
+        }
+    }
+    free(cnt);
+    if (use_cells) { free_grid(&g); free(xd); }
+    return 0;
+}
+
+/* Atoms that have at least one non-excluded pair whose canonical r2 lies within a relative band
+ * `rel` of a cutoff: a one-ulp difference in the distance arithmetic may flip such a pair in or
+ * out.  slack[i] receives the summed magnitude of the pair forces at stake (kcal/mol/Å).  The GPU
+ * parity tests widen the per-atom tolerance by exactly this amount. */
+int orc_cutoff_slack(const mdx_system* s, const mdx_config* c, const float* pos, double rel,
+                     double* slack) {
+    uint32_t N = s->n_atoms;
+    memset(slack, 0, sizeof(double) * N);
+    int cut_lj = cutoff_on(c->lj_cutoff), cut_c = cutoff_on(c->coulomb_cutoff);
+    if (!cut_lj && !cut_c) return 0;
+    double rmax = fmax(cut_lj ? c->lj_cutoff : 0.0, cut_c ? c->coulomb_cutoff : 0.0);
+    double* xd = (double*)malloc(sizeof(double) * 3 * (N ? N : 1));
+    for (uint32_t i = 0; i < 3 * N; ++i) xd[i] = pos[i];
+    grid_t g = build_grid(s, xd, rmax * (1.0 + 2.0 * rel));
+    excl_t ex = build_excl(s);
+    double rl2 = (double)c->lj_cutoff * c->lj_cutoff, rcc2 = (double)c->coulomb_cutoff * c->coulomb_cutoff;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (uint32_t i = 0; i < N; ++i) {
+        if (!nb_active(s, i)) continue;
+        int cc[3]; uint32_t ids[27];
+        for (int a = 0; a < 3; ++a) {
+            double L = g.w[a] * g.n[a], t = xd[3*i+a] - g.lo[a];
+            if (s->periodic) t -= floor(t / L) * L;
+            int q = (int)floor(t / g.w[a]);
+            if (q < 0) q = 0; if (q >= g.n[a]) q = g.n[a] - 1;
+            cc[a] = q;
+        }
+        int ncell = neighbour_cells(&g, cc[0], cc[1], cc[2], ids);
+        for (int ci = 0; ci < ncell; ++ci)
+            for (uint32_t jj = g.start[ids[ci]]; jj < g.start[ids[ci] + 1]; ++jj) {
+                uint32_t j = g.items[jj];
+                if (j == i || !nb_active(s, j)) continue;
+                double r2 = (double)r2_canonical(s, pos + 3 * i, pos + 3 * j);
+                int near_lj = cut_lj && fabs(r2 - rl2) <= rel * rl2;
+                int near_c = cut_c && fabs(r2 - rcc2) <= rel * rcc2;
+                if (!near_lj && !near_c) continue;
+                if (is_excluded(&ex, i, j)) continue;
+                double sig, eps; lj_pair(s, c, i, j, &sig, &eps);
+                double qq = (double)s->charge[i] * (double)s->charge[j];
+                double fs, el = 0, ec = 0;
+                pair_terms(c, sig, eps, qq, r2, near_lj, near_c, &fs, &el, &ec);
+                slack[i] += fabs(fs) * sqrt(r2);
+            }
+    }
+    free_grid(&g); free(ex.off); free(ex.idx); free(xd);
+    return 0;
+}

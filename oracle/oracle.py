@@ -1,0 +1,137 @@
+"""ctypes front-end of oracle/liborc.so (CPU restatement; TEST INFRASTRUCTURE ONLY — see the
+header of mdx_oracle.c.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+import this module; the product package molchanica_amd never does)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from molchanica_amd._abi import CConfig, CSystem, MdConfig, MdSystem
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ENERGY_NAMES = ("bond", "angle", "dihedral", "lj", "coulomb", "lj14", "coulomb14", "kinetic")
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_u32p = C.POINTER(C.c_uint32)
+
+
+def build(extra: str = "", target: str = "liborc.so") -> str:
+    path = os.path.join(_HERE, target)
+    src = os.path.join(_HERE, "mdx_oracle.c")
+    if (not os.path.exists(path)) or os.path.getmtime(path) < os.path.getmtime(src):
+        if target == "liborc.so" and not extra:
+            subprocess.check_call(["make", "-C", _HERE, "liborc.so"], stdout=subprocess.DEVNULL)
+        else:
+            subprocess.check_call(
+                f"gcc -O3 {extra} -fPIC -shared -fopenmp -ffp-contract=off -std=c11 "
+                f"{src} -o {path} -lm", shell=True)
+    return path
+
+
+_lib = None
+
+
+def lib(path: str | None = None):
+    global _lib
+    if _lib is None or path is not None:
+        l = C.CDLL(path or build())
+        l.orc_forces.argtypes = [C.POINTER(CSystem), C.POINTER(CConfig), _dp, _dp, _dp, _dp, C.c_int]
+        l.orc_step.argtypes = [C.POINTER(CSystem), C.POINTER(CConfig), _dp, _dp, C.c_double,
+                               C.c_uint32, _dp, _dp, C.c_int]
+        l.orc_neighbor_list.argtypes = [C.POINTER(CSystem), _fp, C.c_float, _u32p, _u32p, C.c_int]
+        l.orc_cutoff_slack.argtypes = [C.POINTER(CSystem), C.POINTER(CConfig), _fp, C.c_double, _dp]
+        l.orc_kinetic.argtypes = [C.POINTER(CSystem), _dp]
+        l.orc_kinetic.restype = C.c_double
+        l.orc_wrap_f32.argtypes = [C.POINTER(CSystem), _fp, C.c_uint32]
+        if path is not None:
+            return l
+        _lib = l
+    return _lib
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def forces(sys: MdSystem, cfg: MdConfig, pos=None, ext=None, use_cells=False, _lib_override=None):
+    """-> (forces [N,3] f64, energies dict).  pos: optional fp64 [N,3] override."""
+    l = _lib_override or lib()
+    cs, cc = sys.to_c(), cfg.to_c()
+    n = sys.n_atoms
+    x = None if pos is None else np.ascontiguousarray(pos, dtype=np.float64).reshape(n, 3)
+    e = None if ext is None else np.ascontiguousarray(ext, dtype=np.float64).reshape(n, 3)
+    f = np.zeros((n, 3), dtype=np.float64)
+    en = np.zeros(len(ENERGY_NAMES), dtype=np.float64)
+    rc = l.orc_forces(C.byref(cs), C.byref(cc), _d(x), _d(e), _d(f), _d(en), int(use_cells))
+    assert rc == 0
+    return f, _energies(en)
+
+
+def _energies(en):
+    d = dict(zip(ENERGY_NAMES, (float(v) for v in en)))
+    d["potential_bonded"] = d["bond"] + d["angle"] + d["dihedral"]
+    d["potential_nonbonded"] = d["lj"] + d["coulomb"] + d["lj14"] + d["coulomb14"]
+    d["potential"] = d["potential_bonded"] + d["potential_nonbonded"]
+    return d
+
+
+def step(sys: MdSystem, cfg: MdConfig, dt: float, n_steps: int, pos=None, vel=None, ext=None,
+         use_cells=False):
+    """Velocity Verlet in fp64.  -> (pos, vel, energies-of-final-state)."""
+    l = lib()
+    cs, cc = sys.to_c(), cfg.to_c()
+    n = sys.n_atoms
+    x = np.array(sys.pos if pos is None else pos, dtype=np.float64).reshape(n, 3).copy()
+    if vel is None:
+        vel = sys.vel if sys.vel is not None else np.zeros((n, 3))
+    v = np.array(vel, dtype=np.float64).reshape(n, 3).copy()
+    e = None if ext is None else np.ascontiguousarray(ext, dtype=np.float64).reshape(n, 3)
+    en = np.zeros(len(ENERGY_NAMES), dtype=np.float64)
+    rc = l.orc_step(C.byref(cs), C.byref(cc), _d(x), _d(v), float(dt), int(n_steps), _d(e), _d(en),
+                    int(use_cells))
+    assert rc == 0
+    return x, v, _energies(en)
+
+
+def neighbor_list(sys: MdSystem, rlist: float, pos=None, use_cells=False):
+    """-> (offsets [N+1] u32, idx u32): canonical-fp32 Verlet list, rows ascending."""
+    l = lib()
+    cs = sys.to_c()
+    n = sys.n_atoms
+    p = np.ascontiguousarray(sys.pos if pos is None else pos, dtype=np.float32).reshape(n, 3)
+    off = np.zeros(n + 1, dtype=np.uint32)
+    l.orc_neighbor_list(C.byref(cs), p.ctypes.data_as(_fp), float(rlist), off.ctypes.data_as(_u32p),
+                        None, int(use_cells))
+    idx = np.zeros(max(int(off[-1]), 1), dtype=np.uint32)
+    l.orc_neighbor_list(C.byref(cs), p.ctypes.data_as(_fp), float(rlist), off.ctypes.data_as(_u32p),
+                        idx.ctypes.data_as(_u32p), int(use_cells))
+    return off, idx[: int(off[-1])]
+
+
+def cutoff_slack(sys: MdSystem, cfg: MdConfig, pos=None, rel: float = 1e-5):
+    l = lib()
+    cs, cc = sys.to_c(), cfg.to_c()
+    n = sys.n_atoms
+    p = np.ascontiguousarray(sys.pos if pos is None else pos, dtype=np.float32).reshape(n, 3)
+    out = np.zeros(n, dtype=np.float64)
+    l.orc_cutoff_slack(C.byref(cs), C.byref(cc), p.ctypes.data_as(_fp), float(rel), _d(out))
+    return out
+
+
+def wrap(sys: MdSystem, pos):
+    l = lib()
+    cs = sys.to_c()
+    p = np.array(pos, dtype=np.float32).reshape(-1, 3).copy()
+    l.orc_wrap_f32(C.byref(cs), p.ctypes.data_as(_fp), p.shape[0])
+    return p
+
+
+def kinetic(sys: MdSystem, vel):
+    l = lib()
+    cs = sys.to_c()
+    v = np.ascontiguousarray(vel, dtype=np.float64).reshape(-1, 3)
+    return float(l.orc_kinetic(C.byref(cs), _d(v)))
