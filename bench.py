@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — MD steps/s and atom-updates/s of the hot path on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path (velocity-Verlet kick/drift, LJ+Coulomb tile kernel, bonded
+terms, rebuild trigger; neighbour rebuilds included at their natural cadence) over the synthetic
+1,029,000-atom TIP3P box (BASELINE.json configs[4], "water1M"), which fits one GPU, with all
+state resident in HBM before the timed region.  For N > 1 the SAME box is spatially decomposed
+across the ranks (strong scaling) with ghost-atom halo exchange over RCCL.
+
+Prints ONE JSON line on rank 0: the contract keys plus
+  roofline     — dominant kernel (nb_tile_kernel): algorithmic bytes (32 B per atom)
+                 x atoms per launch / mean launch duration from HIP events on the library's stream
+  cpu_baseline — the CPU oracle (C, OpenMP, all host cores) on a bounded sample of the same box
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3
+B_ALG_NONBONDED = 32.0         # R x(12)+q(4)+type(4), W f(12)  per atom per launch
+B_ALG_STEP_WATER = 170.0       # whole step, water box
+FLOP_PER_PAIR = 45.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--workload", default="water1M", choices=["water1M", "dhfr23k", "complex50k", "dna100k"])
+    ap.add_argument("--dt", type=float, default=0.0005)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--nb-variant", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(system, cfg, dt, n_steps):
+    """Times the oracle (kind "port": this repo's C restatement — the reference's Rust engine
+    cannot be built) on all host cores, on a bounded sample: n_steps velocity-Verlet steps of the
+    same system (n_steps+1 force evaluations)."""
+    from oracle import oracle
+    try:
+        path = oracle.build(extra="-march=native", target="liborc_native.so")
+        lib = oracle.lib(path)
+    except Exception:
+        lib = oracle.lib()
+    import ctypes as C
+    cs, cc = system.to_c(), cfg.to_c()
+    n = system.n_atoms
+    x = system.pos.astype(np.float64).copy()
+    v = system.vel.astype(np.float64).copy()
+    en = np.zeros(8)
+    dp = C.POINTER(C.c_double)
+    t0 = time.perf_counter()
+    lib.orc_step(C.byref(cs), C.byref(cc), x.ctypes.data_as(dp), v.ctypes.data_as(dp), float(dt), int(n_steps),
+                 None, en.ctypes.data_as(dp), 1)
+    el = time.perf_counter() - t0
+    lib.orc_max_threads.restype = C.c_int
+    return {
+        "value": n * n_steps / el, "unit": "atom-updates/s", "steps_per_s": n_steps / el,
+        "cores": int(lib.orc_max_threads()), "kind": "port",
+        "sample": f"{n_steps} velocity-Verlet steps ({n_steps + 1} force evaluations) of the same {n}-atom box, "
+                  f"fp64 cell-list oracle, OpenMP over all host cores, {el:.1f} s",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from molchanica_amd import MdConfig, systems
+    from molchanica_amd.md_state import MdState
+
+    system = systems.BY_NAME[args.workload]()
+    cfg = MdConfig(nb_variant=args.nb_variant)  # rc 10 Å (LJ & Coulomb), skin 2 Å, shifted cutoff Coulomb
+    n_atoms = system.n_atoms
+
+    if world == 1:
+        md = MdState(system, cfg, device=local_rank)
+        stepper = lambda k: md.step(args.dt, None, k)
+        stats = md.stats
+        prof = md.profile
+        parallelism = "single"
+    else:
+        from molchanica_amd.decomp import DecomposedMd
+        md = DecomposedMd(system, cfg, rank=rank, world=world, device=local_rank)
+        stepper = lambda k: md.step(args.dt, k)
+        stats = md.stats
+        prof = md.profile
+        parallelism = md.describe()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    stepper(args.warmup)
+    prof(True)
+    rebuilds0 = stats()["rebuild_count"]
+    sync()
+    t0 = time.perf_counter()
+    stepper(args.steps)
+    sync()
+    el = time.perf_counter() - t0
+    st = stats()
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    steps_per_s = args.steps / el
+    value = n_atoms * steps_per_s
+    nb_ms = st["nb_ms_sum"] / max(st["nb_launches"], 1)
+    atoms_per_launch = st["n_atoms"]
+    achieved = B_ALG_NONBONDED * atoms_per_launch / (nb_ms * 1e-3) / 1e9 if nb_ms > 0 else 0.0
+    pair_evals = float(st["n_cluster_pairs"]) * 64   # (i-cluster, j-cluster) pairs x 8 x 8 lanes
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "nb_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            if tj.get("workload") == args.workload and world == 1:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+    out = {
+        "metric": "MD atom-updates/sec (and steps/sec), 1M-atom solvated box",
+        "value": value, "unit": "atom-updates/s", "steps_per_s": steps_per_s,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+        "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.workload, "n_atoms": n_atoms, "lj_cutoff": cfg.lj_cutoff,
+                   "coulomb_cutoff": cfg.coulomb_cutoff, "skin": cfg.skin, "dt_ps": args.dt,
+                   "coulomb": "shifted cutoff", "parallelism": parallelism,
+                   "rebuilds_in_timed_region": int(st["rebuild_count"] - rebuilds0)},
+        "roofline": {"kernel": "nb_tile_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "launch_ms": nb_ms, "launches": st["nb_launches"],
+                     "algorithmic_bytes_per_launch": B_ALG_NONBONDED * atoms_per_launch,
+                     "note": "pair loop is fp32-VALU bound, see valu_frac; HBM fraction is low by physics"},
+        "valu": {"pair_evals_per_launch": pair_evals,
+                 "pair_evals_per_s": pair_evals / (nb_ms * 1e-3) if nb_ms > 0 else 0.0,
+                 "algorithmic_tflops": FLOP_PER_PAIR * 209.4 * atoms_per_launch / (nb_ms * 1e-3) / 1e12 if nb_ms > 0 else 0.0,
+                 "peak_tflops": FP32_PEAK_TFLOPS},
+        "step_hbm_frac": B_ALG_STEP_WATER * value / (world * HBM_PEAK_GBS * 1e9),
+        "kernel_ms": {"nonbonded": nb_ms, "bonded": st["bonded_ms_sum"] / max(st["bonded_launches"], 1),
+                      "integrate": st["integ_ms_sum"] / max(st["integ_launches"], 1),
+                      "rebuild_total": st["rebuild_ms_sum"]},
+    }
+    out["valu"]["frac"] = out["valu"]["algorithmic_tflops"] / FP32_PEAK_TFLOPS
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(system, cfg, args.dt, args.cpu_steps)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,7 +116,7 @@ typedef struct mdx_config {
     uint32_t overrides;        /* MDX_OVR_* bit set                                               */
     float    softening_sq;     /* Å², added to r² in the Coulomb force (src/cuda/util.cu:9 uses 1e-6); default 0 */
     uint32_t chunk_steps;      /* steps enqueued between host checks of the rebuild flag (default 16) */
-    uint32_t nb_variant;       /* 0 = library default; kernel selection knob for A/B measurement  */
+    uint32_t nb_variant;       /* pair kernel: 0 = library default, 1 = whole-tile, 2 = cluster-masked (A/B knob) */
     uint32_t reserved[7];
 } mdx_config;
 
@@ -142,6 +142,7 @@ typedef struct mdx_stats {
     uint32_t n_atoms, n_slots, n_tiles, n_clusters;
     uint64_t n_list_entries;    /* (tile, j-cluster) entries in the current pair list */
     uint64_t n_masked_entries;
+    uint64_t n_cluster_pairs;   /* (i-cluster, j-cluster) pairs within the list radius; x64 = pair evaluations per force call */
     /* HIP-event timing of the kernels, filled only while mdx_profile(h,1) is on */
     double   nb_ms_sum;    uint64_t nb_launches;
     double   bonded_ms_sum; uint64_t bonded_launches;

@@ -1,7 +1,7 @@
 """ctypes mirror of include/mdx.h (struct layouts and constants).
 
-Kept free of any library loading so that the oracle wrapper and the CPU-only tests can use the
-same struct definitions without a GPU build being present.
+Kept free of any library loading so that CPU-only tooling and tests can use the same struct
+definitions without a GPU build being present.
 """
 from __future__ import annotations
 
@@ -73,6 +73,7 @@ class CStats(C.Structure):
         ("n_atoms", C.c_uint32), ("n_slots", C.c_uint32), ("n_tiles", C.c_uint32),
         ("n_clusters", C.c_uint32),
         ("n_list_entries", C.c_uint64), ("n_masked_entries", C.c_uint64),
+        ("n_cluster_pairs", C.c_uint64),
         ("nb_ms_sum", C.c_double), ("nb_launches", C.c_uint64),
         ("bonded_ms_sum", C.c_double), ("bonded_launches", C.c_uint64),
         ("integ_ms_sum", C.c_double), ("integ_launches", C.c_uint64),
@@ -151,7 +152,7 @@ class MdSystem:
 
     @property
     def n_atoms(self) -> int:
-        return int(self.pos.shape[0])
+        return int(np.asarray(self.pos).reshape(-1, 3).shape[0])
 
     def normalise(self) -> "MdSystem":
         n = self.n_atoms

@@ -130,9 +130,9 @@ static void free_device(mdx_handle* h) {
                     d.vel_orig, d.ext_orig, d.posq, d.lj, d.vel, d.force, d.ref, d.orig_of, d.slot_of, d.cell_of,
                     d.cell_count, d.cell_start, d.cell_cursor, d.sorted_orig, d.col_tiles, d.tile_start,
                     d.tile_col, d.scan_tmp, d.cl_lo, d.cl_hi, d.list_counts, d.entry_cnt, d.entry_off,
-                    d.mchunk_cnt, d.mchunk_off, d.entries, d.masks, d.bond_o, d.bond_s, d.bond_p, d.angle_o,
-                    d.angle_s, d.angle_p, d.dih_o, d.dih_s, d.dih_p, d.p14_o, d.p14_s, d.p14_p, d.ctl, d.energy,
-                    d.flags_dev, d.bbox_red};
+                    d.mchunk_cnt, d.mchunk_off, d.entries, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
+                    d.role_off_s, d.role_rec_s, d.ctl, d.energy,
+                    d.flags_dev, d.bbox_red, d.pair_count};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = DeviceState{};
 }
@@ -223,36 +223,50 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
         MDX_TRY(upload_vec(&d.excl_off, off, st)); MDX_TRY(upload_vec(&d.excl_idx, idx, st));
     }
 
-    // ---- bonded terms ----
+    // ---- bonded terms -> per-atom role lists (caller order) ----
     h->n_bonds = s->n_bonds; h->n_angles = s->n_angles; h->n_dih = s->n_dihedrals; h->n_p14 = s->n_pairs14;
     {
-        std::vector<uint32_t> bi(s->bond_idx, s->bond_idx + 2 * (size_t)s->n_bonds);
-        std::vector<float2> bp(s->n_bonds);
-        for (uint32_t k = 0; k < s->n_bonds; ++k) bp[k] = make_float2(s->bond_k[k], s->bond_r0[k]);
-        MDX_TRY(upload_vec(&d.bond_o, bi, st)); MDX_TRY(upload_vec(&d.bond_p, bp, st));
-        MDX_TRY(alloc_n(&d.bond_s, bi.size()));
-        std::vector<uint32_t> ai(s->angle_idx, s->angle_idx + 3 * (size_t)s->n_angles);
-        std::vector<float2> ap(s->n_angles);
-        for (uint32_t k = 0; k < s->n_angles; ++k) ap[k] = make_float2(s->angle_k[k], s->angle_theta0[k]);
-        MDX_TRY(upload_vec(&d.angle_o, ai, st)); MDX_TRY(upload_vec(&d.angle_p, ap, st));
-        MDX_TRY(alloc_n(&d.angle_s, ai.size()));
-        std::vector<uint32_t> di(s->dihedral_idx, s->dihedral_idx + 4 * (size_t)s->n_dihedrals);
-        std::vector<float4> dp(s->n_dihedrals);
+        std::vector<uint32_t> cnt(N + 1, 0);
+        auto count_term = [&](const uint32_t* idx, uint32_t n, int w) {
+            for (size_t k = 0; k < (size_t)n * w; ++k) cnt[idx[k] + 1]++;
+        };
+        count_term(s->bond_idx, s->n_bonds, 2); count_term(s->angle_idx, s->n_angles, 3);
+        count_term(s->dihedral_idx, s->n_dihedrals, 4); count_term(s->pairs14_idx, s->n_pairs14, 2);
+        for (uint32_t i = 0; i < N; ++i) cnt[i + 1] += cnt[i];
+        const uint32_t R = cnt[N];
+        std::vector<RoleRec> recs(R);
+        std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
+        auto add_term = [&](const uint32_t* at, int w, uint32_t kind, float p0, float p1, float p2) {
+            for (int r = 0; r < w; ++r) {
+                RoleRec rec{};
+                int q = 0;
+                for (int k = 0; k < w; ++k) if (k != r) rec.p[q++] = at[k];
+                rec.meta = kind | ((uint32_t)r << 4);
+                rec.prm[0] = p0; rec.prm[1] = p1; rec.prm[2] = p2; rec.prm[3] = 0.f;
+                recs[cur[at[r]]++] = rec;
+            }
+        };
+        for (uint32_t k = 0; k < s->n_bonds; ++k) {
+            if (s->bond_idx[2 * k] == s->bond_idx[2 * k + 1]) FAIL(MDX_EPARAM, "bond of an atom with itself");
+            add_term(s->bond_idx + 2 * k, 2, ROLE_BOND, s->bond_k[k], s->bond_r0[k], 0.f);
+        }
+        for (uint32_t k = 0; k < s->n_angles; ++k)
+            add_term(s->angle_idx + 3 * k, 3, ROLE_ANGLE, s->angle_k[k], s->angle_theta0[k], 0.f);
         for (uint32_t k = 0; k < s->n_dihedrals; ++k)
-            dp[k] = make_float4(s->dihedral_v[k], s->dihedral_phase[k], (float)s->dihedral_n[k], 0.f);
-        MDX_TRY(upload_vec(&d.dih_o, di, st)); MDX_TRY(upload_vec(&d.dih_p, dp, st));
-        MDX_TRY(alloc_n(&d.dih_s, di.size()));
-        std::vector<uint32_t> pi(s->pairs14_idx, s->pairs14_idx + 2 * (size_t)s->n_pairs14);
-        std::vector<float4> pp(s->n_pairs14);
+            add_term(s->dihedral_idx + 4 * k, 4, ROLE_DIHEDRAL, s->dihedral_v[k], s->dihedral_phase[k],
+                     (float)s->dihedral_n[k]);
         for (uint32_t k = 0; k < s->n_pairs14; ++k) {
-            const uint32_t a = pi[2 * k], b = pi[2 * k + 1];
+            const uint32_t a = s->pairs14_idx[2 * k], b = s->pairs14_idx[2 * k + 1];
             const float sa = ljraw[a].x, sb = ljraw[b].x;
             const float sig = geom ? std::sqrt(sa * sb) : 0.5f * (sa + sb);
             const float eps = std::sqrt(ljraw[a].y * ljraw[b].y);
-            pp[k] = make_float4(sig, 4.0f * c->scale14_lj * eps, c->scale14_coulomb * c->coulomb_k * q[a] * q[b], 0.f);
+            add_term(s->pairs14_idx + 2 * k, 2, ROLE_PAIR14, sig, 4.0f * c->scale14_lj * eps,
+                     c->scale14_coulomb * c->coulomb_k * q[a] * q[b]);
         }
-        MDX_TRY(upload_vec(&d.p14_o, pi, st)); MDX_TRY(upload_vec(&d.p14_p, pp, st));
-        MDX_TRY(alloc_n(&d.p14_s, pi.size()));
+        h->n_roles = R;
+        MDX_TRY(upload_vec(&d.role_off_o, cnt, st)); MDX_TRY(upload_vec(&d.role_rec_o, recs, st));
+        MDX_TRY(alloc_n(&d.role_rec_s, R));
+        HIP_TRY(hipStreamSynchronize(st));
     }
 
     // ---- dynamic state staging ----
@@ -318,7 +332,7 @@ static int ensure_ready(mdx_handle* h) {
 void mdx_prof_begin(mdx_handle* h, int kind) {
     if (!h->profile) return;
     mdx_handle::EvPair p{};
-    p.kind = kind;
+    p.kind = kind; p.tag = h->prof_tag;
     hipEvent_t* ev[2] = {&p.a, &p.b};
     for (auto e : ev) {
         if (!h->ev_pool.empty()) { *e = h->ev_pool.back(); h->ev_pool.pop_back(); }
@@ -331,11 +345,14 @@ void mdx_prof_end(mdx_handle* h) {
     if (!h->profile || h->ev_pending.empty()) return;
     (void)hipEventRecord(h->ev_pending.back().b, h->stream);
 }
-void mdx_prof_collect(mdx_handle* h) {
+void mdx_prof_collect(mdx_handle* h, int first_stale_step) {
     for (auto& p : h->ev_pending) {
         float ms = 0.f;
         (void)hipEventSynchronize(p.b);
-        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+        // launches enqueued behind a stale list were no-ops: the integrate pass of the stale step
+        // itself still ran (it detected it), force kernels of that step and everything later did not
+        const bool ran = p.tag < 0 || (p.kind == 2 ? p.tag <= first_stale_step : p.tag < first_stale_step);
+        if (ran && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             if (p.kind == 0) { h->stats.nb_ms_sum += ms; h->stats.nb_launches++; }
             else if (p.kind == 1) { h->stats.bonded_ms_sum += ms; h->stats.bonded_launches++; }
             else { h->stats.integ_ms_sum += ms; h->stats.integ_launches++; }
@@ -373,14 +390,20 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         const uint32_t chunk = std::min(remaining, h->cfg.chunk_steps);
         HIP_TRY(hipMemsetAsync(d.ctl, 0, sizeof(StepCtl), st));
         for (uint32_t s = 0; s < chunk; ++s) {
+            h->prof_tag = (int)s;
             MDX_TRY(mdx_launch_integrate(h, s == 0 ? 0 : 1, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr));
             MDX_TRY(compute_forces(h, false, &d.ctl->disp2[s + 1], thr));
         }
+        h->prof_tag = (int)chunk;
         MDX_TRY(mdx_launch_integrate(h, 2, dt, &d.ctl->disp2[chunk], nullptr, thr));
+        h->prof_tag = -1;
         HIP_TRY(hipMemcpyAsync(h->h_ctl, d.ctl, sizeof(StepCtl), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (h->profile) mdx_prof_collect(h);
         uint32_t done = chunk;
+        int first_stale = 1 << 30;
+        for (uint32_t s = 0; s < chunk; ++s)
+            if (h->h_ctl->disp2[s + 1] > thr) { first_stale = (int)s; break; }
+        if (h->profile) mdx_prof_collect(h, first_stale);
         for (uint32_t s = 0; s < chunk; ++s) {
             if (h->h_ctl->disp2[s + 1] > thr) {
                 if (u2f(h->h_ctl->disp2[s + 1]) > 1.0e29f) {

@@ -304,10 +304,34 @@ __global__ void gather_orig_kernel(uint32_t N, const uint32_t* __restrict__ slot
     orig_arr[o] = slot_arr[slot_of[o]];
 }
 
-__global__ void remap_kernel(uint32_t n, const uint32_t* __restrict__ idx_o, const uint32_t* __restrict__ slot_of,
-                             uint32_t* __restrict__ idx_s) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) idx_s[i] = slot_of[idx_o[i]];
+// Role lists into slot space: count per slot, (scan), then copy with the partners re-indexed.
+__global__ void role_count_kernel(uint32_t S, const uint32_t* __restrict__ orig_of,
+                                  const uint32_t* __restrict__ role_off_o, uint32_t* __restrict__ cnt) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > S) return;
+    uint32_t n = 0;
+    if (s < S) {
+        const uint32_t o = orig_of[s];
+        if (o != MDX_INVALID) n = role_off_o[o + 1] - role_off_o[o];
+    }
+    cnt[s] = n;
+}
+
+__global__ void role_fill_kernel(uint32_t S, const uint32_t* __restrict__ orig_of, const uint32_t* __restrict__ slot_of,
+                                 const uint32_t* __restrict__ role_off_o, const RoleRec* __restrict__ rec_o,
+                                 const uint32_t* __restrict__ role_off_s, RoleRec* __restrict__ rec_s) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const uint32_t o = orig_of[s];
+    if (o == MDX_INVALID) return;
+    const uint32_t b = role_off_o[o], n = role_off_o[o + 1] - b, w = role_off_s[s];
+    for (uint32_t k = 0; k < n; ++k) {
+        RoleRec r = rec_o[b + k];
+        const uint32_t kind = r.meta & 0xFu;
+        const int np = kind == ROLE_DIHEDRAL ? 3 : (kind == ROLE_ANGLE ? 2 : 1);
+        for (int q = 0; q < np; ++q) r.p[q] = slot_of[r.p[q]];
+        rec_s[w + k] = r;
+    }
 }
 
 // ================================================================================================
@@ -364,6 +388,8 @@ struct ListArgs {
     uint2* entries; unsigned long long* masks;
     uint32_t* err;
     uint32_t null_cluster;
+    int mask_layout;                 // 1: bit (8e+jj) of lane i-atom; 2: bit (8e+ci) of lane (ii, jj)
+    unsigned long long* pair_count;  // statistics: sum of popcount(imask)
 };
 
 template <bool FILL>
@@ -407,7 +433,7 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     WAVE_LDS_SYNC();
 
     const float r = a.r_build, r2 = r * r;
-    uint32_t nm = 0, np = 0;
+    uint32_t nm = 0, np = 0, npairs = 0;
     uint32_t ebase = 0, nm_pad_total = 0;
     if (FILL) { ebase = a.entry_off[t]; nm_pad_total = a.counts[t].n_masked; }
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -488,6 +514,7 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
                     }
                     nm += __popcll(bm);
                     np += __popcll(bp);
+                    if (!FILL && pass) npairs += __popc(imask);
                 }
             }
         }
@@ -495,7 +522,10 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     const uint32_t nm_pad = (nm + 7) & ~7u, np_pad = (np + 7) & ~7u;
     if (nm > LB_MAXFLAG) atomicOr(a.err, 2u);
     if (!FILL) {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) npairs += __shfl_xor(npairs, m);
         if (lane == 0) {
+            atomicAdd(a.pair_count, (unsigned long long)npairs);
             a.counts[t].n_masked = nm_pad;
             a.counts[t].n_plain = np_pad;
             a.entry_cnt[t] = nm_pad + np_pad;
@@ -534,6 +564,19 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
                 for (int e = 0; e < 8; ++e)
                     if (jcs[e] == (sp >> 3)) m &= ~(1ull << (8 * e + (sp & 7)));
             }
+        }
+        if (a.mask_layout == 2) {
+            // cluster-masked kernel: lane (ii = lane&7, jj = lane>>3) needs, for entry e and
+            // i-cluster ci, the bit "i-atom ci*8+ii interacts with j-atom jj of entry e"
+            const int ii = lane & 7, jj = lane >> 3;
+            unsigned long long mq = 0ull;
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci) {
+                const unsigned long long mp = __shfl(m, ci * 8 + ii);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) mq |= ((mp >> (8 * e + jj)) & 1ull) << (8 * e + ci);
+            }
+            m = mq;
         }
         a.masks[(size_t)(mbase + c) * 64 + lane] = m;
     }
@@ -634,13 +677,17 @@ static int setup_grid(mdx_handle* h) {
         ALLOC(d.cell_count, (size_t)new_ncells + 1);
         ALLOC(d.cell_start, (size_t)new_ncells + 1);
         ALLOC(d.cell_cursor, (size_t)new_ncells + 1);
-        ALLOC(d.scan_tmp, (size_t)new_ncells / SCAN_TILE + (size_t)h->N / SCAN_TILE + 4096);
     }
     if (new_ncol > h->ncol || !d.col_tiles) {
         ALLOC(d.col_tiles, (size_t)new_ncol + 1);
         ALLOC(d.tile_start, (size_t)new_ncol + 1);
     }
     h->ncol = new_ncol; h->ncells = new_ncells;
+    {   // scratch of the exclusive scans: one partial per 2048 elements of the longest scanned array
+        const size_t longest = std::max<size_t>((size_t)new_ncells + 1, (size_t)N + 64 * (size_t)new_ncol + 256);
+        const size_t need = longest / SCAN_TILE + 64;
+        if (need > h->cap_scan) { h->cap_scan = need; ALLOC(d.scan_tmp, need); }
+    }
     // capacity in tiles: sum ceil(cnt/64) <= N/64 + ncol, + the null tile
     const uint32_t need_tiles = N / MDX_TILE + new_ncol + 2;
     if (need_tiles > h->cap_tiles) {
@@ -648,6 +695,7 @@ static int setup_grid(mdx_handle* h) {
         const size_t S = (size_t)need_tiles * MDX_TILE, NC = (size_t)need_tiles * MDX_CL_PER_TILE;
         ALLOC(d.posq, S); ALLOC(d.lj, S); ALLOC(d.vel, S); ALLOC(d.force, S); ALLOC(d.ref, S);
         ALLOC(d.orig_of, S);
+        ALLOC(d.role_cnt_s, S + 1); ALLOC(d.role_off_s, S + 1);
         ALLOC(d.tile_col, need_tiles);
         ALLOC(d.cl_lo, NC); ALLOC(d.cl_hi, NC);
         ALLOC(d.list_counts, need_tiles);
@@ -728,12 +776,18 @@ int mdx_rebuild(mdx_handle* h) {
     a.counts = d.list_counts; a.entry_cnt = d.entry_cnt; a.mchunk_cnt = d.mchunk_cnt;
     a.entry_off = d.entry_off; a.mchunk_off = d.mchunk_off; a.entries = d.entries; a.masks = d.masks;
     a.err = d.flags_dev; a.null_cluster = T * MDX_CL_PER_TILE;
+    a.mask_layout = mdx_nb_variant(h);
+    if (!d.pair_count) ALLOC(d.pair_count, 2);
+    a.pair_count = d.pair_count;
+    HIP_TRY(hipMemsetAsync(d.pair_count, 0, sizeof(unsigned long long) * 2, st));
     HIP_TRY(hipMemsetAsync(d.entry_cnt + T, 0, sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(d.mchunk_cnt + T, 0, sizeof(uint32_t), st));
     hipLaunchKernelGGL(build_list_kernel<false>, dim3(div_up(T, LB_WAVES)), dim3(LB_WAVES * 64), 0, st, a);
     MDX_TRY(mdx_exclusive_scan_u32(h, d.entry_cnt, d.entry_off, T + 1));
     MDX_TRY(mdx_exclusive_scan_u32(h, d.mchunk_cnt, d.mchunk_off, T + 1));
     uint32_t E = 0, MC = 0;
+    unsigned long long npairs = 0;
+    HIP_TRY(hipMemcpyAsync(&npairs, d.pair_count, sizeof(npairs), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&E, d.entry_off + T, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&MC, d.mchunk_off + T, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(flags, d.flags_dev, sizeof(flags), hipMemcpyDeviceToHost, st));
@@ -752,15 +806,14 @@ int mdx_rebuild(mdx_handle* h) {
     h->E = E; h->MC = MC;
     hipLaunchKernelGGL(build_list_kernel<true>, dim3(div_up(T, LB_WAVES)), dim3(LB_WAVES * 64), 0, st, a);
 
-    // ---- bonded index lists into slot space ----
-    if (h->n_bonds) hipLaunchKernelGGL(remap_kernel, dim3(div_up(2 * h->n_bonds, 256)), dim3(256), 0, st,
-                                       2 * h->n_bonds, d.bond_o, d.slot_of, d.bond_s);
-    if (h->n_angles) hipLaunchKernelGGL(remap_kernel, dim3(div_up(3 * h->n_angles, 256)), dim3(256), 0, st,
-                                        3 * h->n_angles, d.angle_o, d.slot_of, d.angle_s);
-    if (h->n_dih) hipLaunchKernelGGL(remap_kernel, dim3(div_up(4 * h->n_dih, 256)), dim3(256), 0, st,
-                                     4 * h->n_dih, d.dih_o, d.slot_of, d.dih_s);
-    if (h->n_p14) hipLaunchKernelGGL(remap_kernel, dim3(div_up(2 * h->n_p14, 256)), dim3(256), 0, st,
-                                     2 * h->n_p14, d.p14_o, d.slot_of, d.p14_s);
+    // ---- bonded role lists into slot space ----
+    if (h->n_roles) {
+        hipLaunchKernelGGL(role_count_kernel, dim3(div_up(S + 1, 256)), dim3(256), 0, st, S, d.orig_of,
+                           d.role_off_o, d.role_cnt_s);
+        MDX_TRY(mdx_exclusive_scan_u32(h, d.role_cnt_s, d.role_off_s, S + 1));
+        hipLaunchKernelGGL(role_fill_kernel, dim3(div_up(S, 256)), dim3(256), 0, st, S, d.orig_of, d.slot_of,
+                           d.role_off_o, d.role_rec_o, d.role_off_s, d.role_rec_s);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(flags, d.flags_dev, sizeof(flags), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -772,6 +825,7 @@ int mdx_rebuild(mdx_handle* h) {
     uint64_t nmask = (uint64_t)MC * 8;
     h->stats.n_atoms = N; h->stats.n_slots = S; h->stats.n_tiles = T; h->stats.n_clusters = NC;
     h->stats.n_list_entries = E; h->stats.n_masked_entries = nmask;
+    h->stats.n_cluster_pairs = (mdx_nb_variant(h) == 2) ? npairs : (uint64_t)E * 8;
     if (h->profile) {
         float ms = 0.f;
         HIP_TRY(hipEventRecord(e1, st)); HIP_TRY(hipEventSynchronize(e1));

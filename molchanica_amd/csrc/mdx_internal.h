@@ -72,6 +72,14 @@ struct StepCtl {
     uint32_t pad;
 };
 
+// One (term, atom-of-that-term) record of the atom-owned bonded gather (mdx_bonded.hip).
+enum { ROLE_BOND = 0, ROLE_ANGLE = 1, ROLE_DIHEDRAL = 2, ROLE_PAIR14 = 3 };
+struct __attribute__((aligned(16))) RoleRec {
+    uint32_t p[3];   // the term's other atoms, in term order (caller index in *_o, slot in *_s)
+    uint32_t meta;   // kind | role << 4  (role = this atom's position in the term)
+    float prm[4];    // bond: k, r0 | angle: k, theta0 | dihedral: v, phase, n | 1-4: sigma, 4 s eps, s ke qq
+};
+
 struct ListCounts {  // per tile
     uint32_t n_masked;  // entries in the masked run (multiple of 8)
     uint32_t n_plain;   // entries in the plain run (multiple of 8)
@@ -117,15 +125,15 @@ struct DeviceState {
     uint32_t* mchunk_off = nullptr;     // [T+1]
     uint2*    entries = nullptr;        // [E]
     unsigned long long* masks = nullptr; // [MC*64]
-    // bonded terms: orig-order indices + slot-order copies
-    uint32_t *bond_o = nullptr, *bond_s = nullptr; float2* bond_p = nullptr;
-    uint32_t *angle_o = nullptr, *angle_s = nullptr; float2* angle_p = nullptr;
-    uint32_t *dih_o = nullptr, *dih_s = nullptr; float4* dih_p = nullptr;  // v, phase, n, -
-    uint32_t *p14_o = nullptr, *p14_s = nullptr; float4* p14_p = nullptr;  // sig, eps, kqq, -
+    // bonded terms as per-atom role lists: caller order (static) and slot order (per rebuild)
+    uint32_t* role_off_o = nullptr; RoleRec* role_rec_o = nullptr;   // [N+1], [R]
+    uint32_t* role_cnt_s = nullptr; uint32_t* role_off_s = nullptr;  // [S+1]
+    RoleRec*  role_rec_s = nullptr;                                  // [R]
     // control / reductions
     StepCtl* ctl = nullptr;
     double*  energy = nullptr;     // [EN_COUNT + 2]
     uint32_t* flags_dev = nullptr; // misc error flags
+    unsigned long long* pair_count = nullptr;  // cluster pairs in the list (statistics)
     float*   bbox_red = nullptr;   // [6] min/max reduction (vacuum grid)
 };
 
@@ -138,6 +146,7 @@ struct mdx_handle {
     bool periodic = false;
     float box_lo[3]{}, box_hi[3]{};
     uint32_t n_bonds = 0, n_angles = 0, n_dih = 0, n_p14 = 0;
+    uint32_t n_roles = 0;
     uint32_t n_mobile = 0;
     double total_mass = 0.0;
     std::vector<uint8_t> flags;
@@ -147,6 +156,7 @@ struct mdx_handle {
     uint32_t T = 0;          // real tiles (the null tile is tile T)
     uint32_t S = 0;          // slots = (T+1)*64
     uint32_t cap_tiles = 0;  // allocation capacity in tiles (incl. null)
+    size_t cap_scan = 0;
     uint64_t E = 0, cap_entries = 0;
     uint32_t MC = 0, cap_mchunks = 0;
     float r_list = 0.f;
@@ -158,7 +168,8 @@ struct mdx_handle {
     uint64_t step_count = 0, rebuild_count = 0;
     // profiling
     bool profile = false;
-    struct EvPair { hipEvent_t a, b; int kind; };
+    struct EvPair { hipEvent_t a, b; int kind; int tag; };
+    int prof_tag = -1;       // chunk step of the launches being enqueued (-1: ungated)
     std::vector<EvPair> ev_pending;
     std::vector<hipEvent_t> ev_pool;
     mdx_stats stats{};
@@ -194,7 +205,14 @@ int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_ga
 int mdx_launch_kinetic(mdx_handle* h);  // energy[EN_KIN], energy[EN_COUNT] = max |F|^2
 int mdx_exclusive_scan_u32(mdx_handle* h, const uint32_t* in, uint32_t* out, uint32_t n);
 
+// pair-kernel variant actually used: 1 = whole-tile kernel, 2 = cluster-masked kernel
+#define MDX_NB_DEFAULT_VARIANT 2
+static inline int mdx_nb_variant(const mdx_handle* h) {
+    const uint32_t v = h->cfg.nb_variant;
+    return (v == 1 || v == 2) ? (int)v : MDX_NB_DEFAULT_VARIANT;
+}
+
 // profiling helpers
 void mdx_prof_begin(mdx_handle* h, int kind);
 void mdx_prof_end(mdx_handle* h);
-void mdx_prof_collect(mdx_handle* h);
+void mdx_prof_collect(mdx_handle* h, int first_stale_step = 1 << 30);

@@ -46,6 +46,47 @@ struct NbArgs {
 
 enum { CM_SHIFTED = 0, CM_RF = 1, CM_EWALD = 2, CM_SOFT = 3 };
 
+// One pair, seen from atom i: adds the force on i.  `allowed` carries the exclusion mask bit.
+template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT>
+__device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi, float sgi, float epi,
+                                          const float4 pj, const float2 lj, bool allowed, const NbParams& p,
+                                          float& fx, float& fy, float& fz, double& elj, double& ecoul) {
+    const float dx = xi - pj.x, dy = yi - pj.y, dz = zi - pj.z;   // tgt - src (src/cuda/util.cu:118-140)
+    const float r2 = dx * dx + dy * dy + dz * dz;
+    const bool in_lj = (r2 < p.rc2_lj) && allowed;
+    const bool in_c = SAMECUT ? in_lj : ((r2 < p.rc2_coul) && allowed);
+    const float rinv = __builtin_amdgcn_rsqf(r2);
+    const float rinv2 = rinv * rinv;
+    const float sig = GEOM ? sgi * lj.x : sgi + lj.x;
+    const float eps = epi * lj.y;                   // 24 eps_ij
+    const float s2 = sig * sig * rinv2;
+    const float s6 = s2 * s2 * s2;
+    const float es6 = eps * s6;
+    const float flj_r2 = es6 * (2.0f * s6 - 1.0f);  // 24 eps (2 s12 - s6)      [force * r^2]
+    const float qq = qi * pj.w;                     // k_e q_i q_j
+    float fc_r2;                                    // Coulomb force * r^2
+    if (COUL == CM_SHIFTED) fc_r2 = qq * rinv;
+    else if (COUL == CM_SOFT) fc_r2 = qq * rinv * r2 * __frcp_rn(r2 + p.soft2);
+    else if (COUL == CM_RF) fc_r2 = qq * (rinv - p.k_rf2 * r2);
+    else {
+        const float r = r2 * rinv, ar = p.alpha * r;
+        fc_r2 = qq * (erfcf(ar) * rinv + 1.1283791671f * p.alpha * __expf(-ar * ar));
+    }
+    float fs;
+    if (SAMECUT) fs = in_lj ? (flj_r2 + fc_r2) * rinv2 : 0.0f;
+    else fs = (in_lj || in_c) ? ((in_lj ? flj_r2 : 0.0f) + (in_c ? fc_r2 : 0.0f)) * rinv2 : 0.0f;
+    fx += fs * dx; fy += fs * dy; fz += fs * dz;
+    if (ENERGY) {
+        const float e_l = es6 * (s6 - 1.0f) * (1.0f / 6.0f);  // 4 eps (s12 - s6)
+        float e_c;
+        if (COUL == CM_SHIFTED || COUL == CM_SOFT) e_c = qq * (rinv - p.coul_shift);
+        else if (COUL == CM_RF) e_c = qq * (rinv + p.k_rf * r2 - p.coul_shift);
+        else e_c = qq * erfcf(p.alpha * r2 * rinv) * rinv;
+        elj += in_lj ? (double)e_l : 0.0;
+        ecoul += in_c ? (double)e_c : 0.0;
+    }
+}
+
 template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, bool MASKED>
 __device__ __forceinline__ void chunk_pairs(const float4* __restrict__ sx, const float2* __restrict__ sl,
                                             unsigned long long mask, float xi, float yi, float zi, float qi,
@@ -53,47 +94,9 @@ __device__ __forceinline__ void chunk_pairs(const float4* __restrict__ sx, const
                                             float& fz, double& elj, double& ecoul) {
 #pragma unroll 8
     for (int jj = 0; jj < 64; ++jj) {
-        const float4 pj = sx[jj];
-        const float2 lj = sl[jj];
-        const float dx = xi - pj.x, dy = yi - pj.y, dz = zi - pj.z;
-        const float r2 = dx * dx + dy * dy + dz * dz;
-        bool in_lj = r2 < p.rc2_lj;
-        bool in_c = SAMECUT ? in_lj : (r2 < p.rc2_coul);
-        if (MASKED) {
-            const bool m = (mask >> jj) & 1ull;
-            in_lj = in_lj && m;
-            in_c = in_c && m;
-        }
-        const float rinv = __builtin_amdgcn_rsqf(r2);
-        const float rinv2 = rinv * rinv;
-        const float sig = GEOM ? sgi * lj.x : sgi + lj.x;
-        const float eps = epi * lj.y;                   // 24 eps_ij
-        const float s2 = sig * sig * rinv2;
-        const float s6 = s2 * s2 * s2;
-        const float es6 = eps * s6;
-        float flj = es6 * (2.0f * s6 - 1.0f) * rinv2;   // 24 eps (2 s12 - s6) / r^2
-        const float qq = qi * pj.w;                     // k_e q_i q_j
-        float fc;
-        if (COUL == CM_SHIFTED) fc = qq * rinv * rinv2;
-        else if (COUL == CM_SOFT) fc = qq * rinv * __frcp_rn(r2 + p.soft2);
-        else if (COUL == CM_RF) fc = qq * (rinv * rinv2 - p.k_rf2);
-        else {
-            const float r = r2 * rinv, ar = p.alpha * r;
-            fc = qq * (erfcf(ar) * rinv + 1.1283791671f * p.alpha * __expf(-ar * ar)) * rinv2;
-        }
-        float fs;
-        if (SAMECUT) fs = in_lj ? (flj + fc) : 0.0f;
-        else fs = (in_lj ? flj : 0.0f) + (in_c ? fc : 0.0f);
-        fx += fs * dx; fy += fs * dy; fz += fs * dz;
-        if (ENERGY) {
-            float e_l = es6 * (s6 - 1.0f) * (1.0f / 6.0f);  // 4 eps (s12 - s6)
-            float e_c;
-            if (COUL == CM_SHIFTED || COUL == CM_SOFT) e_c = qq * (rinv - p.coul_shift);
-            else if (COUL == CM_RF) e_c = qq * (rinv + p.k_rf * r2 - p.coul_shift);
-            else e_c = qq * erfcf(p.alpha * r2 * rinv) * rinv;
-            elj += in_lj ? (double)e_l : 0.0;
-            ecoul += in_c ? (double)e_c : 0.0;
-        }
+        const bool allowed = MASKED ? (bool)((mask >> jj) & 1ull) : true;
+        pair_eval<ENERGY, COUL, GEOM, SAMECUT>(xi, yi, zi, qi, sgi, epi, sx[jj], sl[jj], allowed, p, fx, fy, fz,
+                                               elj, ecoul);
     }
 }
 
@@ -172,18 +175,129 @@ __global__ __launch_bounds__(NB_WAVES * 64) void nb_tile_kernel(NbArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Variant 2: cluster-masked tile kernel.  Same list, same LDS staging, but a lane is the pair
+// (i-atom ii = lane&7 of every i-cluster, j-atom jj = lane>>3 of the current entry): the eight
+// i-clusters of the tile sit in registers, and an entry is evaluated only against the i-clusters
+// whose bounding box is within the list radius of the j-cluster (the entry's 8-bit imask, a
+// wave-uniform branch).  That removes the corner (i-cluster, j-cluster) pairs a whole-tile test
+// lets through - about 40 % of the pair evaluations at rc 10 + skin 2 - at the price of one
+// cross-lane reduction per tile.  Still one owner per i-atom, no atomics, deterministic.
+template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT>
+__global__ __launch_bounds__(NB_WAVES * 64) void nb_cluster_kernel(NbArgs a) {
+    if (a.gate && *a.gate > a.thr_bits) return;
+    __shared__ float4 s_xyzq[NB_WAVES][64];
+    __shared__ float2 s_lj[NB_WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nblocks = (a.T + NB_WAVES - 1) / NB_WAVES;
+    const uint32_t per_xcd = (nblocks + 7) >> 3;
+    const uint32_t blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (blk >= nblocks) return;
+    const uint32_t t = blk * NB_WAVES + wave;
+    if (t >= a.T) return;
+    const int ii = lane & 7, jj = lane >> 3;
+
+    float xi[8], yi[8], zi[8], qi[8], sgi[8], epi[8], fx[8], fy[8], fz[8];
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) {
+        const uint32_t s = t * MDX_TILE + ci * MDX_CLUSTER + ii;
+        const float4 pi = a.posq[s];
+        const float2 li = a.lj[s];
+        xi[ci] = pi.x; yi[ci] = pi.y; zi[ci] = pi.z; qi[ci] = pi.w; sgi[ci] = li.x; epi[ci] = li.y;
+        fx[ci] = 0.f; fy[ci] = 0.f; fz[ci] = 0.f;
+    }
+    const ListCounts cnt = a.counts[t];
+    const uint32_t e0 = a.entry_off[t];
+    const uint32_t nmc = cnt.n_masked >> 3, nchunks = (cnt.n_masked + cnt.n_plain) >> 3;
+    const uint32_t mbase = a.mchunk_off[t];
+    float4* sx = s_xyzq[wave];
+    float2* sl = s_lj[wave];
+    double elj = 0.0, ecoul = 0.0;
+
+    float4 nj = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 nl = make_float2(0.f, 0.f);
+    uint32_t ny = 13;
+    if (nchunks) {
+        const uint2 ent = a.entries[e0 + (lane >> 3)];
+        const uint32_t js = ent.x * MDX_CLUSTER + (lane & 7);
+        nj = a.posq[js]; nl = a.lj[js]; ny = ent.y;
+    }
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        const uint32_t cur_y = ny;
+        {
+            const uint32_t code = ny & 31u;
+            const int kx = (int)(code % 3u) - 1, ky = (int)((code / 3u) % 3u) - 1, kz = (int)(code / 9u) - 1;
+            nj.x += (float)kx * a.p.shift[0];
+            nj.y += (float)ky * a.p.shift[1];
+            nj.z += (float)kz * a.p.shift[2];
+            sx[lane] = nj;
+            sl[lane] = nl;
+        }
+        WAVE_LDS_SYNC();
+        if (c + 1 < nchunks) {
+            const uint2 ent = a.entries[e0 + (c + 1) * 8 + (lane >> 3)];
+            const uint32_t js = ent.x * MDX_CLUSTER + (lane & 7);
+            nj = a.posq[js]; nl = a.lj[js]; ny = ent.y;
+        }
+        const bool masked = c < nmc;
+        const unsigned long long mq = masked ? a.masks[(size_t)(mbase + c) * 64 + lane] : ~0ull;
+#pragma unroll 1
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t im = (__builtin_amdgcn_readlane(cur_y, e * 8) >> 8) & 0xFFu;  // wave-uniform
+            if (im == 0) continue;
+            const float4 pj = sx[e * 8 + jj];
+            const float2 lj = sl[e * 8 + jj];
+            const uint32_t m8 = (uint32_t)(mq >> (8 * e)) & 0xFFu;
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci) {
+                if (im & (1u << ci)) {
+                    pair_eval<ENERGY, COUL, GEOM, SAMECUT>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci], pj, lj,
+                                                           (m8 >> ci) & 1u, a.p, fx[ci], fy[ci], fz[ci], elj, ecoul);
+                }
+            }
+        }
+        WAVE_LDS_SYNC();
+    }
+    // sum the eight j-lanes of every i-atom (lanes ii, ii+8, ..., ii+56), then lane (ii, jj) keeps
+    // i-cluster ci == jj: slot tile*64 + jj*8 + ii == tile*64 + lane, a coalesced store.
+    float ox = 0.f, oy = 0.f, oz = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) {
+        float x = fx[ci], y = fy[ci], z = fz[ci];
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) {
+            x += __shfl_xor(x, m); y += __shfl_xor(y, m); z += __shfl_xor(z, m);
+        }
+        if (jj == ci) { ox = x; oy = y; oz = z; }
+    }
+    a.force[t * MDX_TILE + lane] = make_float4(ox, oy, oz, 0.f);
+    if (ENERGY) {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) {
+            elj += __shfl_xor(elj, m);
+            ecoul += __shfl_xor(ecoul, m);
+        }
+        if (lane == 0) {
+            atomicAdd(&a.energy[EN_LJ], 0.5 * elj);
+            atomicAdd(&a.energy[EN_COUL], 0.5 * ecoul);
+        }
+    }
+}
+
 template <bool ENERGY, int COUL>
 static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samecut) {
     const uint32_t nblocks = (a.T + NB_WAVES - 1) / NB_WAVES;
     const uint32_t grid = ((nblocks + 7) / 8) * 8;
     dim3 g(grid), b(NB_WAVES * 64);
-    if (geom) {
-        if (samecut) hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, true, true>), g, b, 0, h->stream, a);
-        else hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, true, false>), g, b, 0, h->stream, a);
-    } else {
-        if (samecut) hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, false, true>), g, b, 0, h->stream, a);
-        else hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, false, false>), g, b, 0, h->stream, a);
-    }
+    const bool cl = mdx_nb_variant(h) == 2;
+#define NB_LAUNCH(G, S)                                                                                    \
+    do {                                                                                                   \
+        if (cl) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S>), g, b, 0, h->stream, a);        \
+        else hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, G, S>), g, b, 0, h->stream, a);              \
+    } while (0)
+    if (geom) { if (samecut) NB_LAUNCH(true, true); else NB_LAUNCH(true, false); }
+    else      { if (samecut) NB_LAUNCH(false, true); else NB_LAUNCH(false, false); }
+#undef NB_LAUNCH
 }
 
 static bool cut_on(float rc) { return rc > 0.f && std::isfinite(rc); }

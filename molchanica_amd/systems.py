@@ -183,25 +183,36 @@ def lig50(seed: int = 1, n_atoms: int = 50) -> MdSystem:
 
 def _serpentine_chain(n_atoms: int, centre: np.ndarray, row_len: float, rng: np.random.Generator,
                       row_gap: float = 4.6, layer_gap: float = 5.2, rows_per_layer: int = 8):
-    """Compact bonded chain: zig-zag backbone along a serpentine centre line, every second
+    """Compact bonded chain: zig-zag backbone along a serpentine centre line (straight rows joined
+    by semicircular U-turns, so no two non-bonded atoms come closer than ~3 Å), every second
     backbone atom carries one H-like side atom.  Returns pos, bonds, types."""
     step = 1.27
     n_back = int(math.ceil(n_atoms * 2 / 3))
-    # centre-line polyline
-    pts = []
-    row = 0
-    while True:
+    need = (n_back + 2) * step
+
+    def arc(c, u, w, rad, n=12):   # half circle from c - rad*u to c + rad*u, bulging towards +w
+        a = np.linspace(0.0, math.pi, n + 1)[1:]
+        return [c - rad * math.cos(t) * u + rad * math.sin(t) * w for t in a]
+
+    ex, ey, ez = np.eye(3)
+    pts = [np.zeros(3)]
+    total, row = 0.0, 0
+    while total < need:
         layer, r = divmod(row, rows_per_layer)
-        yy = r if layer % 2 == 0 else rows_per_layer - 1 - r
-        y = yy * row_gap
-        z = layer * layer_gap
-        xs = (0.0, row_len) if row % 2 == 0 else (row_len, 0.0)
-        pts.append((xs[0], y, z))
-        pts.append((xs[1], y, z))
+        xdir = 1.0 if row % 2 == 0 else -1.0
+        end = pts[-1] + xdir * row_len * ex
+        pts.append(end)
+        total += row_len
+        last_in_layer = r == rows_per_layer - 1
+        if last_in_layer:      # climb to the next layer: half circle in the x-z plane
+            new = arc(end + 0.5 * layer_gap * ez, ez, xdir * ex, 0.5 * layer_gap)
+            total += math.pi * 0.5 * layer_gap
+        else:                  # next row of the same layer: half circle in the x-y plane
+            ydir = 1.0 if layer % 2 == 0 else -1.0
+            new = arc(end + 0.5 * row_gap * ydir * ey, ydir * ey, xdir * ex, 0.5 * row_gap)
+            total += math.pi * 0.5 * row_gap
+        pts.extend(new)
         row += 1
-        seg = np.diff(np.asarray(pts), axis=0)
-        if np.linalg.norm(seg, axis=1).sum() > (n_back + 2) * step:
-            break
     pts = np.asarray(pts)
     seg = np.diff(pts, axis=0)
     seglen = np.linalg.norm(seg, axis=1)
@@ -209,17 +220,22 @@ def _serpentine_chain(n_atoms: int, centre: np.ndarray, row_len: float, rng: np.
     s = (np.arange(n_back) + 0.5) * step
     k = np.clip(np.searchsorted(cum, s, side="right") - 1, 0, len(seg) - 1)
     back = pts[k] + seg[k] * ((s - cum[k]) / seglen[k])[:, None]
+    tang = seg[k] / seglen[k][:, None]
+    # zig-zag along the normal closest to z (y where the path itself runs along z)
+    nrm = ez - (tang @ ez)[:, None] * tang
+    bad = np.linalg.norm(nrm, axis=1) < 0.3
+    nrm[bad] = ey - (tang[bad] @ ey)[:, None] * tang[bad]
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
     zig = np.where(np.arange(n_back) % 2 == 0, 0.36, -0.36)
-    back[:, 2] += zig
+    back = back + zig[:, None] * nrm
     pos = [back]
     bonds = [np.stack([np.arange(n_back - 1), np.arange(1, n_back)], 1)]
     n_side = n_atoms - n_back
     owners = (np.arange(n_side) * 2) % n_back if n_side * 2 <= n_back else np.arange(n_side) % n_back
-    side = back[owners].copy()
-    side[:, 2] += np.sign(zig[owners]) * 1.09
+    side = back[owners] + (np.sign(zig[owners]) * 1.09)[:, None] * nrm[owners]
     pos.append(side)
     bonds.append(np.stack([owners, n_back + np.arange(n_side)], 1))
-    pos = np.concatenate(pos) + rng.normal(scale=0.03, size=(n_atoms, 3))
+    pos = np.concatenate(pos) + rng.normal(scale=0.02, size=(n_atoms, 3))
     pos += centre - pos.mean(0)
     types = np.concatenate([rng.integers(0, 3, size=n_back), np.full(n_side, 3)])
     return pos, np.concatenate(bonds), types
@@ -249,20 +265,24 @@ def _solvate(solutes: list, box: float, n_total: int | None, seed: int, name: st
     from scipy.spatial import cKDTree
 
     rng = np.random.default_rng(seed + 7)
-    n_side = int(round(box / 3.1034))
-    sp = box / n_side
-    g = (np.arange(n_side) + 0.5) * sp
-    sites = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
     sol_pos = np.concatenate([s["pos"] for s in solutes]) if solutes else np.zeros((0, 3))
     n_sol = sol_pos.shape[0]
-    if n_sol:
-        tree = cKDTree(np.mod(sol_pos, box), boxsize=box)
-        d, _ = tree.query(sites, k=1)
-        sites = sites[d > clearance + 0.8]
+    tree = cKDTree(np.mod(sol_pos, box), boxsize=box) if n_sol else None
+    n_side = int(round(box / 3.1034))
+    while True:   # refine the water lattice until enough sites clear the solute
+        sp = box / n_side
+        g = (np.arange(n_side) + 0.5) * sp
+        sites = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+        if tree is not None:
+            d, _ = tree.query(sites, k=1)
+            sites = sites[d > clearance]
+        if n_total is None or (n_total - n_sol) // 3 <= sites.shape[0]:
+            break
+        n_side += 1
+        if sp < 2.7:
+            raise ValueError(f"{name}: cannot place {(n_total - n_sol) // 3} waters")
     if n_total is not None:
         w = (n_total - n_sol) // 3
-        if w > sites.shape[0]:
-            raise ValueError(f"{name}: only {sites.shape[0]} water sites for {w} waters")
         keep = np.sort(rng.choice(sites.shape[0], size=w, replace=False))
         sites = sites[keep]
     w = sites.shape[0]
