@@ -776,7 +776,7 @@ int mdx_rebuild(mdx_handle* h) {
     a.counts = d.list_counts; a.entry_cnt = d.entry_cnt; a.mchunk_cnt = d.mchunk_cnt;
     a.entry_off = d.entry_off; a.mchunk_off = d.mchunk_off; a.entries = d.entries; a.masks = d.masks;
     a.err = d.flags_dev; a.null_cluster = T * MDX_CL_PER_TILE;
-    a.mask_layout = mdx_nb_variant(h);
+    a.mask_layout = mdx_nb_variant(h) >= 2 ? 2 : 1;
     if (!d.pair_count) ALLOC(d.pair_count, 2);
     a.pair_count = d.pair_count;
     HIP_TRY(hipMemsetAsync(d.pair_count, 0, sizeof(unsigned long long) * 2, st));
@@ -825,7 +825,7 @@ int mdx_rebuild(mdx_handle* h) {
     uint64_t nmask = (uint64_t)MC * 8;
     h->stats.n_atoms = N; h->stats.n_slots = S; h->stats.n_tiles = T; h->stats.n_clusters = NC;
     h->stats.n_list_entries = E; h->stats.n_masked_entries = nmask;
-    h->stats.n_cluster_pairs = (mdx_nb_variant(h) == 2) ? npairs : (uint64_t)E * 8;
+    h->stats.n_cluster_pairs = (mdx_nb_variant(h) >= 2) ? npairs : (uint64_t)E * 8;
     if (h->profile) {
         float ms = 0.f;
         HIP_TRY(hipEventRecord(e1, st)); HIP_TRY(hipEventSynchronize(e1));

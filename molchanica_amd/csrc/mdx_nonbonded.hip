@@ -47,7 +47,12 @@ struct NbArgs {
 enum { CM_SHIFTED = 0, CM_RF = 1, CM_EWALD = 2, CM_SOFT = 3 };
 
 // One pair, seen from atom i: adds the force on i.  `allowed` carries the exclusion mask bit.
-template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT>
+// BRANCHY = true wraps everything behind the cutoff test in a divergent `if`: hipcc emits an
+// exec-masked region with an s_cbranch_execz early-out, so a cluster pair with no lane inside the
+// cutoff costs 7 VALU ops instead of 25 (the cluster kernel: ~40 % of its cluster pairs).  The
+// whole-tile kernel keeps the straight-line select form, which the compiler can software-pipeline
+// across its unrolled j loop.
+template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, bool BRANCHY>
 __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi, float sgi, float epi,
                                           const float4 pj, const float2 lj, bool allowed, const NbParams& p,
                                           float& fx, float& fy, float& fz, double& elj, double& ecoul) {
@@ -55,6 +60,7 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
     const float r2 = dx * dx + dy * dy + dz * dz;
     const bool in_lj = (r2 < p.rc2_lj) && allowed;
     const bool in_c = SAMECUT ? in_lj : ((r2 < p.rc2_coul) && allowed);
+    if (BRANCHY && !(in_lj || in_c)) return;
     const float rinv = __builtin_amdgcn_rsqf(r2);
     const float rinv2 = rinv * rinv;
     const float sig = GEOM ? sgi * lj.x : sgi + lj.x;
@@ -73,7 +79,7 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
         fc_r2 = qq * (erfcf(ar) * rinv + 1.1283791671f * p.alpha * __expf(-ar * ar));
     }
     float fs;
-    if (SAMECUT) fs = in_lj ? (flj_r2 + fc_r2) * rinv2 : 0.0f;
+    if (SAMECUT) fs = (BRANCHY || in_lj) ? (flj_r2 + fc_r2) * rinv2 : 0.0f;
     else fs = (in_lj || in_c) ? ((in_lj ? flj_r2 : 0.0f) + (in_c ? fc_r2 : 0.0f)) * rinv2 : 0.0f;
     fx += fs * dx; fy += fs * dy; fz += fs * dz;
     if (ENERGY) {
@@ -95,7 +101,7 @@ __device__ __forceinline__ void chunk_pairs(const float4* __restrict__ sx, const
 #pragma unroll 8
     for (int jj = 0; jj < 64; ++jj) {
         const bool allowed = MASKED ? (bool)((mask >> jj) & 1ull) : true;
-        pair_eval<ENERGY, COUL, GEOM, SAMECUT>(xi, yi, zi, qi, sgi, epi, sx[jj], sl[jj], allowed, p, fx, fy, fz,
+        pair_eval<ENERGY, COUL, GEOM, SAMECUT, false>(xi, yi, zi, qi, sgi, epi, sx[jj], sl[jj], allowed, p, fx, fy, fz,
                                                elj, ecoul);
     }
 }
@@ -183,8 +189,8 @@ __global__ __launch_bounds__(NB_WAVES * 64) void nb_tile_kernel(NbArgs a) {
 // wave-uniform branch).  That removes the corner (i-cluster, j-cluster) pairs a whole-tile test
 // lets through - about 40 % of the pair evaluations at rc 10 + skin 2 - at the price of one
 // cross-lane reduction per tile.  Still one owner per i-atom, no atomics, deterministic.
-template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT>
-__global__ __launch_bounds__(NB_WAVES * 64) void nb_cluster_kernel(NbArgs a) {
+template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int GROUP, bool ILDS>
+__global__ __launch_bounds__(NB_WAVES * 64, ILDS ? 6 : 4) void nb_cluster_kernel(NbArgs a) {
     if (a.gate && *a.gate > a.thr_bits) return;
     __shared__ float4 s_xyzq[NB_WAVES][64];
     __shared__ float2 s_lj[NB_WAVES][64];
@@ -197,13 +203,21 @@ __global__ __launch_bounds__(NB_WAVES * 64) void nb_cluster_kernel(NbArgs a) {
     if (t >= a.T) return;
     const int ii = lane & 7, jj = lane >> 3;
 
+    __shared__ float4 s_ixyzq[ILDS ? NB_WAVES : 1][64];
+    __shared__ float2 s_ilj[ILDS ? NB_WAVES : 1][64];
     float xi[8], yi[8], zi[8], qi[8], sgi[8], epi[8], fx[8], fy[8], fz[8];
+    if (ILDS) {   // i-tile parked in LDS: ~48 VGPRs less, two more waves per SIMD
+        s_ixyzq[wave][lane] = a.posq[t * MDX_TILE + lane];
+        s_ilj[wave][lane] = a.lj[t * MDX_TILE + lane];
+    }
 #pragma unroll
     for (int ci = 0; ci < 8; ++ci) {
-        const uint32_t s = t * MDX_TILE + ci * MDX_CLUSTER + ii;
-        const float4 pi = a.posq[s];
-        const float2 li = a.lj[s];
-        xi[ci] = pi.x; yi[ci] = pi.y; zi[ci] = pi.z; qi[ci] = pi.w; sgi[ci] = li.x; epi[ci] = li.y;
+        if (!ILDS) {
+            const uint32_t s = t * MDX_TILE + ci * MDX_CLUSTER + ii;
+            const float4 pi = a.posq[s];
+            const float2 li = a.lj[s];
+            xi[ci] = pi.x; yi[ci] = pi.y; zi[ci] = pi.z; qi[ci] = pi.w; sgi[ci] = li.x; epi[ci] = li.y;
+        }
         fx[ci] = 0.f; fy[ci] = 0.f; fz[ci] = 0.f;
     }
     const ListCounts cnt = a.counts[t];
@@ -214,11 +228,15 @@ __global__ __launch_bounds__(NB_WAVES * 64) void nb_cluster_kernel(NbArgs a) {
     float2* sl = s_lj[wave];
     double elj = 0.0, ecoul = 0.0;
 
+    // two-deep software pipeline: entries of chunk c+2 and atoms of chunk c+1 are in flight while
+    // chunk c is evaluated, so the dependent (entry -> posq) load never stalls the wave
     float4 nj = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 nl = make_float2(0.f, 0.f);
     uint32_t ny = 13;
+    uint2 ent_n = make_uint2(0u, 13u);
     if (nchunks) {
         const uint2 ent = a.entries[e0 + (lane >> 3)];
+        if (nchunks > 1) ent_n = a.entries[e0 + 8 + (lane >> 3)];
         const uint32_t js = ent.x * MDX_CLUSTER + (lane & 7);
         nj = a.posq[js]; nl = a.lj[js]; ny = ent.y;
     }
@@ -235,24 +253,63 @@ __global__ __launch_bounds__(NB_WAVES * 64) void nb_cluster_kernel(NbArgs a) {
         }
         WAVE_LDS_SYNC();
         if (c + 1 < nchunks) {
-            const uint2 ent = a.entries[e0 + (c + 1) * 8 + (lane >> 3)];
-            const uint32_t js = ent.x * MDX_CLUSTER + (lane & 7);
-            nj = a.posq[js]; nl = a.lj[js]; ny = ent.y;
+            const uint32_t js = ent_n.x * MDX_CLUSTER + (lane & 7);
+            nj = a.posq[js]; nl = a.lj[js]; ny = ent_n.y;
+            if (c + 2 < nchunks) ent_n = a.entries[e0 + (c + 2) * 8 + (lane >> 3)];
         }
         const bool masked = c < nmc;
         const unsigned long long mq = masked ? a.masks[(size_t)(mbase + c) * 64 + lane] : ~0ull;
+        // entry loop: the next entry's j record is fetched from LDS before the current one is
+        // evaluated; i-clusters are taken in z-adjacent pairs (2k, 2k+1) so that each uniform
+        // branch guards two independent dependency chains (ILP 2) - the partner of a lone set
+        // bit is evaluated masked-off.
+        float4 pj_n = sx[jj];
+        float2 lj_n = sl[jj];
 #pragma unroll 1
         for (int e = 0; e < 8; ++e) {
+            const float4 pj = pj_n;
+            const float2 lj = lj_n;
+            if (e < 7) { pj_n = sx[(e + 1) * 8 + jj]; lj_n = sl[(e + 1) * 8 + jj]; }
             const uint32_t im = (__builtin_amdgcn_readlane(cur_y, e * 8) >> 8) & 0xFFu;  // wave-uniform
             if (im == 0) continue;
-            const float4 pj = sx[e * 8 + jj];
-            const float2 lj = sl[e * 8 + jj];
-            const uint32_t m8 = (uint32_t)(mq >> (8 * e)) & 0xFFu;
+            if (masked) {
+                const uint32_t m8 = (uint32_t)(mq >> (8 * e)) & im;
 #pragma unroll
-            for (int ci = 0; ci < 8; ++ci) {
-                if (im & (1u << ci)) {
-                    pair_eval<ENERGY, COUL, GEOM, SAMECUT>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci], pj, lj,
-                                                           (m8 >> ci) & 1u, a.p, fx[ci], fy[ci], fz[ci], elj, ecoul);
+                for (int cp = 0; cp < 8 / GROUP; ++cp) {
+                    if (im & (((1u << GROUP) - 1u) << (GROUP * cp))) {
+#pragma unroll
+                        for (int ci = GROUP * cp; ci < GROUP * cp + GROUP; ++ci) {
+                            if (ILDS) {
+                                const float4 pi = s_ixyzq[wave][ci * 8 + ii];
+                                const float2 li = s_ilj[wave][ci * 8 + ii];
+                                pair_eval<ENERGY, COUL, GEOM, SAMECUT, true>(pi.x, pi.y, pi.z, pi.w, li.x, li.y, pj, lj,
+                                                                       (m8 >> ci) & 1u, a.p, fx[ci], fy[ci], fz[ci],
+                                                                       elj, ecoul);
+                            } else
+                            pair_eval<ENERGY, COUL, GEOM, SAMECUT, true>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci], pj,
+                                                                   lj, (m8 >> ci) & 1u, a.p, fx[ci], fy[ci], fz[ci],
+                                                                   elj, ecoul);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int cp = 0; cp < 8 / GROUP; ++cp) {
+                    if (im & (((1u << GROUP) - 1u) << (GROUP * cp))) {
+#pragma unroll
+                        for (int ci = GROUP * cp; ci < GROUP * cp + GROUP; ++ci) {
+                            if (ILDS) {
+                                const float4 pi = s_ixyzq[wave][ci * 8 + ii];
+                                const float2 li = s_ilj[wave][ci * 8 + ii];
+                                pair_eval<ENERGY, COUL, GEOM, SAMECUT, true>(pi.x, pi.y, pi.z, pi.w, li.x, li.y, pj, lj,
+                                                                       (im >> ci) & 1u, a.p, fx[ci], fy[ci], fz[ci],
+                                                                       elj, ecoul);
+                            } else
+                            pair_eval<ENERGY, COUL, GEOM, SAMECUT, true>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci], pj,
+                                                                   lj, (im >> ci) & 1u, a.p, fx[ci], fy[ci], fz[ci],
+                                                                   elj, ecoul);
+                        }
+                    }
                 }
             }
         }
@@ -289,10 +346,11 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
     const uint32_t nblocks = (a.T + NB_WAVES - 1) / NB_WAVES;
     const uint32_t grid = ((nblocks + 7) / 8) * 8;
     dim3 g(grid), b(NB_WAVES * 64);
-    const bool cl = mdx_nb_variant(h) == 2;
+    const int var = mdx_nb_variant(h);
 #define NB_LAUNCH(G, S)                                                                                    \
     do {                                                                                                   \
-        if (cl) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S>), g, b, 0, h->stream, a);        \
+        if (var == 2) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 1, false>), g, b, 0, h->stream, a); \
+        else if (var == 3) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 1, true>), g, b, 0, h->stream, a); \
         else hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, G, S>), g, b, 0, h->stream, a);              \
     } while (0)
     if (geom) { if (samecut) NB_LAUNCH(true, true); else NB_LAUNCH(true, false); }
