@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--nb-variant", type=int, default=0)
+    ap.add_argument("--decomposed", action="store_true", help="drive the decomposed path even on one GPU")
     return ap.parse_args()
 
 
@@ -101,7 +102,7 @@ def main():
     cfg = MdConfig(nb_variant=args.nb_variant)  # rc 10 Å (LJ & Coulomb), skin 2 Å, shifted cutoff Coulomb
     n_atoms = system.n_atoms
 
-    if world == 1:
+    if world == 1 and not args.decomposed:
         md = MdState(system, cfg, device=local_rank)
         stepper = lambda k: md.step(args.dt, None, k)
         stats = md.stats

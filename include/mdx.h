@@ -201,16 +201,40 @@ int mdx_neighbor_list(mdx_handle* h, uint32_t* offsets /* [N+1] */, uint32_t* id
 int mdx_profile(mdx_handle* h, int enable);
 int mdx_get_stats(mdx_handle* h, mdx_stats* out);
 
-/* ---- multi-GPU spatial decomposition support (no reference counterpart) ----------
- * Ghost atoms (MDX_ATOM_GHOST) are part of the system passed to mdx_create.  Their positions are
- * overwritten from a DEVICE buffer each step (the RCCL receive buffer), and owned positions are
- * packed into a DEVICE send buffer by index list; both run on the library's stream, which the
- * host obtains to order its collectives. */
-int   mdx_step_begin(mdx_handle* h, float dt, int first);  /* kick + drift of owned atoms       */
-int   mdx_pack_positions(mdx_handle* h, const uint32_t* d_atom_idx, uint32_t n, float* d_out4);
-int   mdx_unpack_positions(mdx_handle* h, const uint32_t* d_atom_idx, uint32_t n, const float* d_in4);
-int   mdx_step_end(mdx_handle* h, float dt, int last);     /* forces (+ closing half kick)       */
-int   mdx_needs_rebuild(mdx_handle* h, int* out);          /* max displacement > skin/2 ?        */
+/* ---- multi-GPU spatial decomposition support (the reference is single-device,
+ * src/util.rs:1086, so this is new capability, not parity) -------------------------------------
+ * One handle per GPU/rank, created from the GLOBAL system (static per-atom data and topology are
+ * replicated: 288 GB of HBM per GPU make that free), then told which atoms it simulates:
+ * its owned atoms plus ghost copies of every atom within cutoff+skin of its brick.  In a
+ * decomposed dimension the local region is not periodic: ghosts arrive already shifted into the
+ * rank's frame.  All d_* pointers are DEVICE memory; everything runs on mdx_stream(h). */
+#define MDX_PERIODIC_NONE 0
+#define MDX_PERIODIC_XYZ  1
+#define MDX_PERIODIC_DIMS(x, y, z) (0x10 | ((x) ? 1 : 0) | ((y) ? 2 : 0) | ((z) ? 4 : 0))
+
+int mdx_set_local_atoms(mdx_handle* h, uint32_t n_local, const uint32_t* d_gid /* [n] global ids */,
+                        const uint8_t* d_ghost /* [n] 1 = halo copy */, const float* d_pos4 /* [4n] */,
+                        const float* d_vel4 /* [4n] */, const float lo[3], const float hi[3] /* local extent */,
+                        int32_t periodic /* MDX_PERIODIC_* of the LOCAL region */);
+int mdx_local_state(mdx_handle* h, float* d_pos4, float* d_vel4);   /* local order, 4 floats per atom */
+
+/* A chunk of steps without host synchronisation.  flag word s+1 is raised by the drift of step s
+ * when an owned atom moved more than skin/2 since the last rebuild; the host all-reduces (max) that
+ * word across ranks on the same stream, and every later kernel of the chunk gates on it. */
+int      mdx_chunk_begin(mdx_handle* h);                                  /* zero the flag words   */
+int      mdx_chunk_integrate(mdx_handle* h, int mode, float dt, uint32_t s); /* mode 0: half kick+drift,
+                                                 1: full kick+drift, 2: closing half kick; gated on flag[s] */
+int      mdx_chunk_forces(mdx_handle* h, int32_t s);                      /* gated on flag[s+1]; s<0: ungated */
+int      mdx_chunk_end(mdx_handle* h, uint32_t n_words, uint32_t* flags_out); /* sync, copy flag words  */
+void*    mdx_flag_words(mdx_handle* h);          /* device uint32[66]: the words the host all-reduces   */
+uint32_t mdx_stale_threshold(const mdx_handle* h); /* a word above this (as uint) means "list is stale"  */
+int      mdx_add_steps(mdx_handle* h, uint32_t n);
+
+/* Halo traffic: gather owned positions by global id into a send buffer / scatter received ghost
+ * positions (plus a per-ghost image shift) back.  4 floats per atom. */
+int   mdx_pack_positions(mdx_handle* h, const uint32_t* d_gid, uint32_t n, float* d_out4);
+int   mdx_unpack_positions(mdx_handle* h, const uint32_t* d_gid, uint32_t n, const float* d_in4,
+                           const float* d_shift4_or_null);
 void* mdx_stream(mdx_handle* h);                           /* hipStream_t                        */
 
 #ifdef __cplusplus

@@ -110,12 +110,18 @@ static int validate(const mdx_system* s, const mdx_config* c) {
     return MDX_OK;
 }
 
-static int check_box(bool periodic, const float* lo, const float* hi, const mdx_config* c) {
-    if (!periodic) return MDX_OK;
+static void decode_periodic(int32_t v, int per[3]) {
+    if (v & 0x10) { per[0] = v & 1; per[1] = (v >> 1) & 1; per[2] = (v >> 2) & 1; }
+    else per[0] = per[1] = per[2] = (v != 0);
+}
+
+static int check_box(const int per[3], const float* lo, const float* hi, const mdx_config* c) {
+    if (!(per[0] || per[1] || per[2])) return MDX_OK;
     if (!cut_on(c->lj_cutoff) || !cut_on(c->coulomb_cutoff))
         FAIL(MDX_EPARAM, "a periodic system needs finite LJ and Coulomb cut-offs");
     const float rl = std::max(c->lj_cutoff, c->coulomb_cutoff) + c->skin;
     for (int d = 0; d < 3; ++d) {
+        if (!per[d]) continue;
         const float L = hi[d] - lo[d];
         if (!(L > 0.f) || !std::isfinite(L)) FAIL(MDX_EPARAM, "box extent must be positive");
         if (L < 2.0f * rl)
@@ -127,7 +133,8 @@ static int check_box(bool periodic, const float* lo, const float* hi, const mdx_
 static void free_device(mdx_handle* h) {
     DeviceState& d = h->d;
     void* ptrs[] = {d.o_qs, d.o_lj, d.o_invm, d.o_mass, d.o_q, d.o_lj_raw, d.excl_off, d.excl_idx, d.pos_orig,
-                    d.vel_orig, d.ext_orig, d.posq, d.lj, d.vel, d.force, d.ref, d.orig_of, d.slot_of, d.cell_of,
+                    d.vel_orig, d.ext_orig, d.posq, d.lj, d.vel, d.force, d.ref, d.orig_of, d.slot_of, d.gid, d.lflag,
+                    d.slot_flags, d.cell_of,
                     d.cell_count, d.cell_start, d.cell_cursor, d.sorted_orig, d.col_tiles, d.tile_start,
                     d.tile_col, d.scan_tmp, d.cl_lo, d.cl_hi, d.list_counts, d.entry_cnt, d.entry_off,
                     d.mchunk_cnt, d.mchunk_off, d.entries, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
@@ -154,9 +161,11 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
     h->N = N; h->cfg = *c; h->device = device;
     if (h->cfg.chunk_steps == 0) h->cfg.chunk_steps = 16;
     if (h->cfg.chunk_steps > MDX_MAX_CHUNK) h->cfg.chunk_steps = MDX_MAX_CHUNK;
-    h->periodic = s->periodic != 0;
+    decode_periodic(s->periodic, h->per);
+    h->periodic = h->per[0] || h->per[1] || h->per[2];
     for (int d = 0; d < 3; ++d) { h->box_lo[d] = s->box_lo[d]; h->box_hi[d] = s->box_hi[d]; }
-    MDX_TRY(check_box(h->periodic, h->box_lo, h->box_hi, c));
+    MDX_TRY(check_box(h->per, h->box_lo, h->box_hi, c));
+    h->n_local = N; h->cap_local = N;
     const bool all_cut = cut_on(c->lj_cutoff) && cut_on(c->coulomb_cutoff);
     h->r_list = all_cut ? std::max(c->lj_cutoff, c->coulomb_cutoff) + c->skin : INFINITY;
 
@@ -280,6 +289,11 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
         }
         MDX_TRY(upload_vec(&d.pos_orig, p4, st)); MDX_TRY(upload_vec(&d.vel_orig, v4, st));
         MDX_TRY(alloc_n(&d.ext_orig, N));
+        std::vector<uint32_t> gid(N);
+        std::vector<uint8_t> lf(N);
+        for (uint32_t i = 0; i < N; ++i) { gid[i] = i; lf[i] = (h->flags[i] & MDX_ATOM_GHOST) ? 1 : 0; }
+        MDX_TRY(upload_vec(&d.gid, gid, st)); MDX_TRY(upload_vec(&d.lflag, lf, st));
+        HIP_TRY(hipStreamSynchronize(st));
     }
     MDX_TRY(alloc_n(&d.slot_of, N)); MDX_TRY(alloc_n(&d.cell_of, N)); MDX_TRY(alloc_n(&d.sorted_orig, N));
     MDX_TRY(alloc_n(&d.ctl, 1)); MDX_TRY(alloc_n(&d.energy, EN_COUNT + 2)); MDX_TRY(alloc_n(&d.flags_dev, 4));
@@ -373,6 +387,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
     // external forces (held constant over the burst)  [ref: src/mol_alignment.rs:318-346]
     const bool had_ext = h->have_ext;
     if (ext_forces) {
+        if (h->n_local != h->N) FAIL(MDX_EPARAM, "external forces are not supported on a decomposed handle");
         std::vector<float4> e4(h->N);
         for (uint32_t i = 0; i < h->N; ++i)
             e4[i] = make_float4(ext_forces[3 * i], ext_forces[3 * i + 1], ext_forces[3 * i + 2], 0.f);
@@ -482,7 +497,7 @@ extern "C" int mdx_download(mdx_handle* h, int which, float* dst) {
     if (!h || !dst) FAIL(MDX_EPARAM, "null argument");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = h->stream;
-    const uint32_t N = h->N;
+    const uint32_t N = h->n_local;   // == n_atoms unless mdx_set_local_atoms narrowed the set
     const float4* src = nullptr;
     if (which == MDX_POS || which == MDX_VEL) {
         if (h->in_slot_space)
@@ -504,7 +519,7 @@ extern "C" int mdx_download(mdx_handle* h, int which, float* dst) {
         (void)hipFree(tmp);
         MDX_TRY(rc);
         for (uint32_t i = 0; i < N; ++i) {
-            const bool ghost = (h->flags[i] & MDX_ATOM_GHOST) != 0;
+            const bool ghost = h->n_local == h->N && (h->flags[i] & MDX_ATOM_GHOST) != 0;
             dst[3 * i] = ghost ? 0.f : hf[i].x; dst[3 * i + 1] = ghost ? 0.f : hf[i].y;
             dst[3 * i + 2] = ghost ? 0.f : hf[i].z;
         }
@@ -521,6 +536,7 @@ extern "C" int mdx_upload(mdx_handle* h, int which, const float* src) {
     if (!h || !src) FAIL(MDX_EPARAM, "null argument");
     if (which != MDX_POS && which != MDX_VEL) FAIL(MDX_EPARAM, "only MDX_POS and MDX_VEL can be uploaded");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->n_local != h->N) FAIL(MDX_EPARAM, "mdx_upload on a decomposed handle: use mdx_set_local_atoms");
     const uint32_t N = h->N;
     for (size_t k = 0; k < 3 * (size_t)N; ++k)
         if (!std::isfinite(src[k])) FAIL(MDX_EPARAM, "non-finite value in upload");
@@ -540,7 +556,7 @@ extern "C" int mdx_upload(mdx_handle* h, int which, const float* src) {
 extern "C" int mdx_set_box(mdx_handle* h, const float lo[3], const float hi[3]) {
     if (!h || !lo || !hi) FAIL(MDX_EPARAM, "null argument");
     if (!h->periodic) FAIL(MDX_EPARAM, "mdx_set_box on a non-periodic system");
-    MDX_TRY(check_box(true, lo, hi, &h->cfg));
+    MDX_TRY(check_box(h->per, lo, hi, &h->cfg));
     HIP_TRY(hipSetDevice(h->device));
     MDX_TRY(mdx_unsort_state(h));
     for (int d = 0; d < 3; ++d) { h->box_lo[d] = lo[d]; h->box_hi[d] = hi[d]; }
@@ -591,64 +607,125 @@ extern "C" int mdx_get_stats(mdx_handle* h, mdx_stats* out) {
 __global__ void pack_pos_kernel(uint32_t n, const uint32_t* __restrict__ atom_idx, const uint32_t* __restrict__ slot_of,
                                 const float4* __restrict__ posq, float4* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = posq[slot_of[atom_idx[i]]];
+    if (i < n) { const uint32_t s = slot_of[atom_idx[i]]; out[i] = (s == MDX_INVALID) ? make_float4(0.f, 0.f, 0.f, 0.f) : posq[s]; }
 }
 __global__ void unpack_pos_kernel(uint32_t n, const uint32_t* __restrict__ atom_idx, const uint32_t* __restrict__ slot_of,
-                                  float4* __restrict__ posq, const float4* __restrict__ in) {
+                                  float4* __restrict__ posq, const float4* __restrict__ in,
+                                  const float4* __restrict__ shift) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t s = slot_of[atom_idx[i]];
-    const float4 v = in[i];
+    if (s == MDX_INVALID) return;
+    float4 v = in[i];
+    if (shift) { const float4 sh = shift[i]; v.x += sh.x; v.y += sh.y; v.z += sh.z; }
     float4 p = posq[s];
     p.x = v.x; p.y = v.y; p.z = v.z;
     posq[s] = p;
 }
 
-extern "C" int mdx_step_begin(mdx_handle* h, float dt, int first) {
-    if (!h) FAIL(MDX_EPARAM, "null handle");
-    MDX_TRY(ensure_ready(h));
-    HIP_TRY(hipMemsetAsync(h->d.ctl, 0, sizeof(StepCtl), h->stream));
-    MDX_TRY(mdx_launch_integrate(h, first ? 0 : 1, dt, nullptr, &h->d.ctl->disp2[1], stale_threshold_bits(h)));
-    h->forces_valid = false;
+extern "C" int mdx_set_local_atoms(mdx_handle* h, uint32_t n_local, const uint32_t* d_gid, const uint8_t* d_ghost,
+                                   const float* d_pos4, const float* d_vel4, const float lo[3], const float hi[3],
+                                   int32_t periodic) {
+    if (!h || !d_gid || !d_ghost || !d_pos4 || !d_vel4 || !lo || !hi) FAIL(MDX_EPARAM, "null argument");
+    if (n_local == 0 || n_local > h->N) FAIL(MDX_EPARAM, "n_local must be in 1..n_atoms (each atom at most once)");
+    HIP_TRY(hipSetDevice(h->device));
+    int per[3];
+    decode_periodic(periodic, per);
+    MDX_TRY(check_box(per, h->box_lo, h->box_hi, &h->cfg));
+    hipStream_t st = h->stream;
+    DeviceState& d = h->d;
+    HIP_TRY(hipMemcpyAsync(d.gid, d_gid, sizeof(uint32_t) * n_local, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d.lflag, d_ghost, sizeof(uint8_t) * n_local, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d.pos_orig, d_pos4, sizeof(float4) * n_local, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d.vel_orig, d_vel4, sizeof(float4) * n_local, hipMemcpyDeviceToDevice, st));
+    h->n_local = n_local;
+    for (int k = 0; k < 3; ++k) { h->per[k] = per[k]; h->local_lo[k] = lo[k]; h->local_hi[k] = hi[k]; }
+    h->periodic = per[0] || per[1] || per[2];
+    h->have_local_bounds = true;
+    h->in_slot_space = false; h->list_valid = false; h->forces_valid = false;
     return MDX_OK;
 }
 
-extern "C" int mdx_pack_positions(mdx_handle* h, const uint32_t* d_atom_idx, uint32_t n, float* d_out4) {
-    if (!h || (n && (!d_atom_idx || !d_out4))) FAIL(MDX_EPARAM, "null argument");
+extern "C" int mdx_local_state(mdx_handle* h, float* d_pos4, float* d_vel4) {
+    if (!h || !d_pos4 || !d_vel4) FAIL(MDX_EPARAM, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->in_slot_space) {
+        MDX_TRY(mdx_gather_to_orig(h, h->d.posq, (float4*)d_pos4));
+        MDX_TRY(mdx_gather_to_orig(h, h->d.vel, (float4*)d_vel4));
+    } else {
+        HIP_TRY(hipMemcpyAsync(d_pos4, h->d.pos_orig, sizeof(float4) * h->n_local, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(d_vel4, h->d.vel_orig, sizeof(float4) * h->n_local, hipMemcpyDeviceToDevice, h->stream));
+    }
+    return MDX_OK;
+}
+
+extern "C" int mdx_chunk_begin(mdx_handle* h) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->list_valid) MDX_TRY(mdx_rebuild(h));
+    HIP_TRY(hipMemsetAsync(h->d.ctl, 0, sizeof(StepCtl), h->stream));
+    return MDX_OK;
+}
+
+extern "C" int mdx_chunk_integrate(mdx_handle* h, int mode, float dt, uint32_t s) {
+    if (!h || s > MDX_MAX_CHUNK || mode < 0 || mode > 2) FAIL(MDX_EPARAM, "bad argument");
+    h->prof_tag = (int)s;
+    int rc = mdx_launch_integrate(h, mode, dt, &h->d.ctl->disp2[s], mode == 2 ? nullptr : &h->d.ctl->disp2[s + 1],
+                                  stale_threshold_bits(h));
+    h->prof_tag = -1;
+    return rc;
+}
+
+extern "C" int mdx_chunk_forces(mdx_handle* h, int32_t s) {
+    if (!h || s > (int32_t)MDX_MAX_CHUNK) FAIL(MDX_EPARAM, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->list_valid) MDX_TRY(mdx_rebuild(h));
+    h->prof_tag = s;
+    int rc = compute_forces(h, false, s < 0 ? nullptr : &h->d.ctl->disp2[s + 1], stale_threshold_bits(h));
+    h->prof_tag = -1;
+    if (rc == MDX_OK) h->forces_valid = true;
+    return rc;
+}
+
+extern "C" int mdx_chunk_end(mdx_handle* h, uint32_t n_words, uint32_t* flags_out) {
+    if (!h || !flags_out || n_words > MDX_MAX_CHUNK + 2) FAIL(MDX_EPARAM, "bad argument");
+    HIP_TRY(hipMemcpyAsync(h->h_ctl, h->d.ctl, sizeof(StepCtl), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const uint32_t thr = stale_threshold_bits(h);
+    int first_stale = 1 << 30;
+    for (uint32_t k = 0; k < n_words; ++k) {
+        flags_out[k] = h->h_ctl->disp2[k];
+        if (k > 0 && first_stale == (1 << 30) && flags_out[k] > thr) first_stale = (int)k - 1;
+    }
+    if (h->profile) mdx_prof_collect(h, first_stale);
+    return MDX_OK;
+}
+
+extern "C" void* mdx_flag_words(mdx_handle* h) { return h ? (void*)h->d.ctl->disp2 : nullptr; }
+extern "C" uint32_t mdx_stale_threshold(const mdx_handle* h) { return h ? stale_threshold_bits(h) : 0u; }
+extern "C" int mdx_add_steps(mdx_handle* h, uint32_t n) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    h->step_count += n;
+    return MDX_OK;
+}
+
+extern "C" int mdx_pack_positions(mdx_handle* h, const uint32_t* d_gid, uint32_t n, float* d_out4) {
+    if (!h || (n && (!d_gid || !d_out4))) FAIL(MDX_EPARAM, "null argument");
     if (!h->in_slot_space) FAIL(MDX_EPARAM, "spatial caches not built");
-    if (n) hipLaunchKernelGGL(pack_pos_kernel, dim3(div_up(n, 256)), dim3(256), 0, h->stream, n, d_atom_idx,
+    if (n) hipLaunchKernelGGL(pack_pos_kernel, dim3(div_up(n, 256)), dim3(256), 0, h->stream, n, d_gid,
                               h->d.slot_of, h->d.posq, (float4*)d_out4);
     HIP_TRY(hipGetLastError());
     return MDX_OK;
 }
 
-extern "C" int mdx_unpack_positions(mdx_handle* h, const uint32_t* d_atom_idx, uint32_t n, const float* d_in4) {
-    if (!h || (n && (!d_atom_idx || !d_in4))) FAIL(MDX_EPARAM, "null argument");
+extern "C" int mdx_unpack_positions(mdx_handle* h, const uint32_t* d_gid, uint32_t n, const float* d_in4,
+                                    const float* d_shift4) {
+    if (!h || (n && (!d_gid || !d_in4))) FAIL(MDX_EPARAM, "null argument");
     if (!h->in_slot_space) FAIL(MDX_EPARAM, "spatial caches not built");
-    if (n) hipLaunchKernelGGL(unpack_pos_kernel, dim3(div_up(n, 256)), dim3(256), 0, h->stream, n, d_atom_idx,
-                              h->d.slot_of, h->d.posq, (const float4*)d_in4);
+    if (n) hipLaunchKernelGGL(unpack_pos_kernel, dim3(div_up(n, 256)), dim3(256), 0, h->stream, n, d_gid,
+                              h->d.slot_of, h->d.posq, (const float4*)d_in4, (const float4*)d_shift4);
     HIP_TRY(hipGetLastError());
     h->forces_valid = false;
-    return MDX_OK;
-}
-
-extern "C" int mdx_step_end(mdx_handle* h, float dt, int last) {
-    if (!h) FAIL(MDX_EPARAM, "null handle");
-    HIP_TRY(hipSetDevice(h->device));
-    MDX_TRY(compute_forces(h, false, nullptr, 0));
-    h->forces_valid = true;
-    if (last) MDX_TRY(mdx_launch_integrate(h, 2, dt, nullptr, nullptr, stale_threshold_bits(h)));
-    h->step_count += 1;
-    return MDX_OK;
-}
-
-extern "C" int mdx_needs_rebuild(mdx_handle* h, int* out) {
-    if (!h || !out) FAIL(MDX_EPARAM, "null argument");
-    HIP_TRY(hipSetDevice(h->device));
-    uint32_t v = 0;
-    HIP_TRY(hipMemcpyAsync(&v, &h->d.ctl->disp2[1], sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    *out = v > stale_threshold_bits(h);
     return MDX_OK;
 }
 

@@ -165,8 +165,8 @@ int mdx_launch_bonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32
     a.S = h->S; a.role_off = h->d.role_off_s; a.roles = h->d.role_rec_s;
     a.posq = h->d.posq; a.force = h->d.force; a.energy = h->d.energy; a.gate = d_gate; a.thr_bits = thr_bits;
     for (int d = 0; d < 3; ++d) {
-        a.p.box[d] = h->periodic ? (h->box_hi[d] - h->box_lo[d]) : 0.f;
-        a.p.inv_box[d] = h->periodic ? 1.0f / a.p.box[d] : 0.f;
+        a.p.box[d] = h->per[d] ? (h->box_hi[d] - h->box_lo[d]) : 0.f;
+        a.p.inv_box[d] = h->per[d] ? 1.0f / a.p.box[d] : 0.f;
     }
     mdx_prof_begin(h, 1);
     const dim3 g((h->S + 255) / 256), b(256);

@@ -130,11 +130,9 @@ __global__ void bin_atoms_kernel(float4* __restrict__ pos_orig, uint32_t N, Grid
         atomicOr(nonfinite, 1u);
         p.x = g.lo[0]; p.y = g.lo[1]; p.z = g.lo[2];
     }
-    if (g.periodic) {
-        p.x = wrap1(p.x, g.lo[0], g.len[0]);
-        p.y = wrap1(p.y, g.lo[1], g.len[1]);
-        p.z = wrap1(p.z, g.lo[2], g.len[2]);
-    }
+    if (g.per[0]) p.x = wrap1(p.x, g.lo[0], g.len[0]);
+    if (g.per[1]) p.y = wrap1(p.y, g.lo[1], g.len[1]);
+    if (g.per[2]) p.z = wrap1(p.z, g.lo[2], g.len[2]);
     pos_orig[o] = p;
     int cx = min(g.ncx - 1, max(0, (int)((p.x - g.lo[0]) * g.inv_col[0])));
     int cy = min(g.ncy - 1, max(0, (int)((p.y - g.lo[1]) * g.inv_col[1])));
@@ -217,7 +215,8 @@ __device__ __forceinline__ void bitonic_group(float& key, float& p1, float& p2, 
 __global__ __launch_bounds__(256) void assign_tiles_kernel(
     uint32_t T, int nzb, const uint32_t* __restrict__ tile_col, const uint32_t* __restrict__ tile_start,
     const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ sorted_orig,
-    const float4* __restrict__ pos_orig, uint32_t* __restrict__ orig_of, uint32_t* __restrict__ slot_of) {
+    const float4* __restrict__ pos_orig, const uint32_t* __restrict__ gid, uint32_t* __restrict__ orig_of,
+    uint32_t* __restrict__ slot_of) {
     const int lane = threadIdx.x & 63;
     const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (t > T) return;
@@ -239,24 +238,29 @@ __global__ __launch_bounds__(256) void assign_tiles_kernel(
     bitonic_group<16>(z, x, y, o, lane);
     const uint32_t slot = t * MDX_TILE + lane;
     orig_of[slot] = o;
-    if (o != MDX_INVALID) slot_of[o] = slot;
+    if (o != MDX_INVALID) slot_of[gid[o]] = slot;
 }
 
 __global__ void gather_slots_kernel(uint32_t S, const uint32_t* __restrict__ orig_of,
+                                    const uint32_t* __restrict__ gid, const uint8_t* __restrict__ lflag,
                                     const float4* __restrict__ pos_orig, const float4* __restrict__ vel_orig,
                                     const float* __restrict__ o_qs, const float2* __restrict__ o_lj,
                                     const float* __restrict__ o_invm, float4* __restrict__ posq,
                                     float2* __restrict__ lj, float4* __restrict__ vel, float4* __restrict__ ref,
-                                    float4* __restrict__ force) {
+                                    float4* __restrict__ force, uint8_t* __restrict__ slot_flags) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
     uint32_t o = orig_of[s];
     float4 p, v; float2 l;
+    uint8_t fl = 0;
     if (o != MDX_INVALID) {
+        const uint32_t g = gid[o];
+        const bool ghost = (lflag[o] & 1u) != 0;
         float4 q = pos_orig[o], w = vel_orig[o];
-        p = make_float4(q.x, q.y, q.z, o_qs[o]);
-        v = make_float4(w.x, w.y, w.z, o_invm[o]);
-        l = o_lj[o];
+        p = make_float4(q.x, q.y, q.z, o_qs[g]);
+        v = ghost ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(w.x, w.y, w.z, o_invm[g]);
+        l = o_lj[g];
+        fl = ghost ? 1 : 3;
     } else {
         // dummy: far away, every dummy at its own coordinate so no two coincide
         float d = MDX_DUMMY_BASE + MDX_DUMMY_STEP * (float)(s & 0xFFFFF);
@@ -266,6 +270,7 @@ __global__ void gather_slots_kernel(uint32_t S, const uint32_t* __restrict__ ori
     }
     posq[s] = p; vel[s] = v; lj[s] = l; ref[s] = p;
     force[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    slot_flags[s] = fl;
 }
 
 __global__ void cluster_bbox_kernel(uint32_t NC, const uint32_t* __restrict__ orig_of,
@@ -287,49 +292,60 @@ __global__ void cluster_bbox_kernel(uint32_t NC, const uint32_t* __restrict__ or
     cl_hi[c] = make_float4(hi.x, hi.y, hi.z, 0.f);
 }
 
-__global__ void unsort_kernel(uint32_t N, const uint32_t* __restrict__ slot_of, const float4* __restrict__ posq,
-                              const float4* __restrict__ vel, float4* __restrict__ pos_orig,
-                              float4* __restrict__ vel_orig) {
+__global__ void unsort_kernel(uint32_t N, const uint32_t* __restrict__ gid, const uint32_t* __restrict__ slot_of,
+                              const float4* __restrict__ posq, const float4* __restrict__ vel,
+                              float4* __restrict__ pos_orig, float4* __restrict__ vel_orig) {
     uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= N) return;
-    uint32_t s = slot_of[o];
+    uint32_t s = slot_of[gid[o]];
     pos_orig[o] = posq[s];
     vel_orig[o] = vel[s];
 }
 
-__global__ void gather_orig_kernel(uint32_t N, const uint32_t* __restrict__ slot_of,
+__global__ void gather_orig_kernel(uint32_t N, const uint32_t* __restrict__ gid, const uint32_t* __restrict__ slot_of,
                                    const float4* __restrict__ slot_arr, float4* __restrict__ orig_arr) {
     uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= N) return;
-    orig_arr[o] = slot_arr[slot_of[o]];
+    orig_arr[o] = slot_arr[slot_of[gid[o]]];
 }
 
 // Role lists into slot space: count per slot, (scan), then copy with the partners re-indexed.
-__global__ void role_count_kernel(uint32_t S, const uint32_t* __restrict__ orig_of,
-                                  const uint32_t* __restrict__ role_off_o, uint32_t* __restrict__ cnt) {
+__global__ void role_count_kernel(uint32_t S, const uint32_t* __restrict__ orig_of, const uint32_t* __restrict__ gid,
+                                  const uint8_t* __restrict__ lflag, const uint32_t* __restrict__ role_off_o,
+                                  uint32_t* __restrict__ cnt) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s > S) return;
     uint32_t n = 0;
     if (s < S) {
         const uint32_t o = orig_of[s];
-        if (o != MDX_INVALID) n = role_off_o[o + 1] - role_off_o[o];
+        if (o != MDX_INVALID && !(lflag[o] & 1u)) {   // ghosts carry no bonded work: their owner does it
+            const uint32_t g = gid[o];
+            n = role_off_o[g + 1] - role_off_o[g];
+        }
     }
     cnt[s] = n;
 }
 
-__global__ void role_fill_kernel(uint32_t S, const uint32_t* __restrict__ orig_of, const uint32_t* __restrict__ slot_of,
+__global__ void role_fill_kernel(uint32_t S, const uint32_t* __restrict__ orig_of, const uint32_t* __restrict__ gid,
+                                 const uint8_t* __restrict__ lflag, const uint32_t* __restrict__ slot_of,
                                  const uint32_t* __restrict__ role_off_o, const RoleRec* __restrict__ rec_o,
-                                 const uint32_t* __restrict__ role_off_s, RoleRec* __restrict__ rec_s) {
+                                 const uint32_t* __restrict__ role_off_s, RoleRec* __restrict__ rec_s,
+                                 uint32_t* __restrict__ err) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
     const uint32_t o = orig_of[s];
-    if (o == MDX_INVALID) return;
-    const uint32_t b = role_off_o[o], n = role_off_o[o + 1] - b, w = role_off_s[s];
+    if (o == MDX_INVALID || (lflag[o] & 1u)) return;
+    const uint32_t g = gid[o];
+    const uint32_t b = role_off_o[g], n = role_off_o[g + 1] - b, w = role_off_s[s];
     for (uint32_t k = 0; k < n; ++k) {
         RoleRec r = rec_o[b + k];
         const uint32_t kind = r.meta & 0xFu;
         const int np = kind == ROLE_DIHEDRAL ? 3 : (kind == ROLE_ANGLE ? 2 : 1);
-        for (int q = 0; q < np; ++q) r.p[q] = slot_of[r.p[q]];
+        for (int q = 0; q < np; ++q) {
+            const uint32_t sp = slot_of[r.p[q]];
+            if (sp == MDX_INVALID) { atomicOr(err, 4u); r.p[q] = s; }   // bonded partner outside the halo
+            else r.p[q] = sp;
+        }
         rec_s[w + k] = r;
     }
 }
@@ -379,7 +395,7 @@ struct ListArgs {
     float r_build;  // slightly inflated list radius for the bounding-box tests
     const uint32_t* tile_col; const uint32_t* tile_start;
     const float4* cl_lo; const float4* cl_hi;
-    const uint32_t* orig_of; const uint32_t* slot_of;
+    const uint32_t* orig_of; const uint32_t* slot_of; const uint32_t* gid; const uint8_t* slot_flags;
     const uint32_t* excl_off; const uint32_t* excl_idx;
     // count pass out
     ListCounts* counts; uint32_t* entry_cnt; uint32_t* mchunk_cnt;
@@ -403,6 +419,13 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     uint32_t* hash = s_hash[wave];
     uint32_t* fl = s_fl[wave];
     const GridParams& g = a.g;
+    // a tile that holds no owned atom (halo copies / padding only) is never an i-tile
+    if (!__any((a.slot_flags[t * MDX_TILE + lane] & 2u) != 0)) {
+        if (!FILL && lane == 0) {
+            a.counts[t].n_masked = 0; a.counts[t].n_plain = 0; a.entry_cnt[t] = 0; a.mchunk_cnt[t] = 0;
+        }
+        return;
+    }
 
     for (int k = lane; k < LB_HASH; k += 64) hash[k] = MDX_INVALID;
     // i-cluster boxes and the tile box
@@ -427,8 +450,11 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     bool ok_ins = true;
     if (lane < MDX_CL_PER_TILE) ok_ins &= hash_insert(hash, t * MDX_CL_PER_TILE + lane);
     uint32_t eb = 0, ee = 0;
-    if (myo != MDX_INVALID) { eb = a.excl_off[myo]; ee = a.excl_off[myo + 1]; }
-    for (uint32_t k = eb; k < ee; ++k) ok_ins &= hash_insert(hash, a.slot_of[a.excl_idx[k]] >> 3);
+    if (myo != MDX_INVALID) { const uint32_t mg = a.gid[myo]; eb = a.excl_off[mg]; ee = a.excl_off[mg + 1]; }
+    for (uint32_t k = eb; k < ee; ++k) {
+        const uint32_t sp = a.slot_of[a.excl_idx[k]];
+        if (sp != MDX_INVALID) ok_ins &= hash_insert(hash, sp >> 3);   // absent partner: beyond the halo, out of range
+    }
     if (!ok_ins) atomicOr(a.err, 1u);
     WAVE_LDS_SYNC();
 
@@ -446,12 +472,11 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
         ix1 = (int)floorf((hi[0] + r - g.lo[0]) * g.inv_col[0]);
         iy0 = (int)floorf((lo[1] - r - g.lo[1]) * g.inv_col[1]);
         iy1 = (int)floorf((hi[1] + r - g.lo[1]) * g.inv_col[1]);
-        if (!g.periodic) {
-            ix0 = max(ix0, 0); ix1 = min(ix1, g.ncx - 1);
-            iy0 = max(iy0, 0); iy1 = min(iy1, g.ncy - 1);
-        } else {
-            ix0 = max(ix0, -g.ncx); ix1 = min(ix1, 2 * g.ncx - 1);
-            iy0 = max(iy0, -g.ncy); iy1 = min(iy1, 2 * g.ncy - 1);
+        if (!g.per[0]) { ix0 = max(ix0, 0); ix1 = min(ix1, g.ncx - 1); }
+        else { ix0 = max(ix0, -g.ncx); ix1 = min(ix1, 2 * g.ncx - 1); }
+        if (!g.per[1]) { iy0 = max(iy0, 0); iy1 = min(iy1, g.ncy - 1); }
+        else { iy0 = max(iy0, -g.ncy); iy1 = min(iy1, 2 * g.ncy - 1); }
+        if (g.per[2]) {
             if (lo[2] - r < g.lo[2]) kz0 = -1;
             if (hi[2] + r >= g.lo[2] + g.len[2]) kz1 = 1;
         }
@@ -459,14 +484,14 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     const float colw_x = 1.0f / g.inv_col[0], colw_y = 1.0f / g.inv_col[1];
 
     for (int ix = ix0; ix <= ix1; ++ix) {
-        const int kx = g.periodic ? floor_div(ix, g.ncx) : 0;
+        const int kx = g.per[0] ? floor_div(ix, g.ncx) : 0;
         const int wx = ix - kx * g.ncx;
         const float sx = (float)kx * g.len[0];
         // column slab distance in x (column interval, slightly widened)
         const float cxlo = g.lo[0] + (float)wx * colw_x + sx - 1e-3f, cxhi = cxlo + colw_x + 2e-3f;
         const float gx = (wx == 0 || wx == g.ncx - 1) ? 0.f : gap(cxlo, cxhi, lo[0], hi[0]);
         for (int iy = iy0; iy <= iy1; ++iy) {
-            const int ky = g.periodic ? floor_div(iy, g.ncy) : 0;
+            const int ky = g.per[1] ? floor_div(iy, g.ncy) : 0;
             const int wy = iy - ky * g.ncy;
             const float sy = (float)ky * g.len[1];
             const float cylo = g.lo[1] + (float)wy * colw_y + sy - 1e-3f, cyhi = cylo + colw_y + 2e-3f;
@@ -560,6 +585,7 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
                 if (jcs[e] == (myslot >> 3)) m &= ~(1ull << (8 * e + (myslot & 7)));
             for (uint32_t k = eb; k < ee; ++k) {
                 uint32_t sp = a.slot_of[a.excl_idx[k]];
+                if (sp == MDX_INVALID) continue;
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (jcs[e] == (sp >> 3)) m &= ~(1ull << (8 * e + (sp & 7)));
@@ -585,13 +611,11 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
 // ================================================================================================
 // neighbour-list extraction (parity / debugging API): canonical fp32 distances
 // ================================================================================================
-__device__ __forceinline__ float r2_canonical(float4 pi, float4 pj, const float* L, int periodic) {
+__device__ __forceinline__ float r2_canonical(float4 pi, float4 pj, const float* L, const int* per) {
     float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-    if (periodic) {
-        dx = dx - rintf(dx / L[0]) * L[0];
-        dy = dy - rintf(dy / L[1]) * L[1];
-        dz = dz - rintf(dz / L[2]) * L[2];
-    }
+    if (per[0]) dx = dx - rintf(dx / L[0]) * L[0];
+    if (per[1]) dy = dy - rintf(dy / L[1]) * L[1];
+    if (per[2]) dz = dz - rintf(dz / L[2]) * L[2];
     return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
 }
 
@@ -614,7 +638,7 @@ __global__ __launch_bounds__(256) void extract_neighbors_kernel(
             const uint32_t js = jc * MDX_CLUSTER + jj;
             const uint32_t oj = orig_of[js];
             if (oj == MDX_INVALID || oi == MDX_INVALID || oj == oi) continue;
-            if (r2_canonical(pi, ref[js], g.len, g.periodic) < rl2) {
+            if (r2_canonical(pi, ref[js], g.len, g.per) < rl2) {
                 if (FILL) row[k] = oj;
                 ++k;
             }
@@ -635,11 +659,15 @@ static int alloc_dev(void** p, size_t bytes) {
 
 static int setup_grid(mdx_handle* h) {
     GridParams& g = h->grid;
-    const uint32_t N = h->N;
-    g.periodic = h->periodic ? 1 : 0;
-    if (h->periodic) {
-        for (int d = 0; d < 3; ++d) { g.lo[d] = h->box_lo[d]; g.len[d] = h->box_hi[d] - h->box_lo[d]; }
-    } else {
+    const uint32_t N = h->n_local;
+    bool need_bbox = false;
+    for (int d = 0; d < 3; ++d) {
+        g.per[d] = h->per[d];
+        if (h->per[d]) { g.lo[d] = h->box_lo[d]; g.len[d] = h->box_hi[d] - h->box_lo[d]; }
+        else if (h->have_local_bounds) { g.lo[d] = h->local_lo[d]; g.len[d] = std::max(h->local_hi[d] - h->local_lo[d], 1.0f); }
+        else need_bbox = true;
+    }
+    if (need_bbox) {
         // bounding box of the current caller-order positions (vacuum systems are small)
         std::vector<float4> hp(N);
         HIP_TRY(hipMemcpyAsync(hp.data(), h->d.pos_orig, sizeof(float4) * N, hipMemcpyDeviceToHost, h->stream));
@@ -652,7 +680,8 @@ static int setup_grid(mdx_handle* h) {
                 lo[d] = std::min(lo[d], v[d]); hi[d] = std::max(hi[d], v[d]);
             }
         }
-        for (int d = 0; d < 3; ++d) { g.lo[d] = lo[d] - 0.01f; g.len[d] = std::max(hi[d] - lo[d] + 0.02f, 1.0f); }
+        for (int d = 0; d < 3; ++d)
+            if (!h->per[d]) { g.lo[d] = lo[d] - 0.01f; g.len[d] = std::max(hi[d] - lo[d] + 0.02f, 1.0f); }
     }
     const double vol = (double)g.len[0] * g.len[1] * g.len[2];
     const double rho = std::max((double)N / vol, 1e-4);
@@ -694,7 +723,7 @@ static int setup_grid(mdx_handle* h) {
         h->cap_tiles = need_tiles;
         const size_t S = (size_t)need_tiles * MDX_TILE, NC = (size_t)need_tiles * MDX_CL_PER_TILE;
         ALLOC(d.posq, S); ALLOC(d.lj, S); ALLOC(d.vel, S); ALLOC(d.force, S); ALLOC(d.ref, S);
-        ALLOC(d.orig_of, S);
+        ALLOC(d.orig_of, S); ALLOC(d.slot_flags, S);
         ALLOC(d.role_cnt_s, S + 1); ALLOC(d.role_off_s, S + 1);
         ALLOC(d.tile_col, need_tiles);
         ALLOC(d.cl_lo, NC); ALLOC(d.cl_hi, NC);
@@ -707,16 +736,16 @@ static int setup_grid(mdx_handle* h) {
 
 int mdx_unsort_state(mdx_handle* h) {
     if (!h->in_slot_space) return MDX_OK;
-    hipLaunchKernelGGL(unsort_kernel, dim3(div_up(h->N, 256)), dim3(256), 0, h->stream, h->N, h->d.slot_of,
-                       h->d.posq, h->d.vel, h->d.pos_orig, h->d.vel_orig);
+    hipLaunchKernelGGL(unsort_kernel, dim3(div_up(h->n_local, 256)), dim3(256), 0, h->stream, h->n_local, h->d.gid,
+                       h->d.slot_of, h->d.posq, h->d.vel, h->d.pos_orig, h->d.vel_orig);
     HIP_TRY(hipGetLastError());
     h->in_slot_space = false;
     return MDX_OK;
 }
 
 int mdx_gather_to_orig(mdx_handle* h, const float4* slot_arr, float4* orig_arr) {
-    hipLaunchKernelGGL(gather_orig_kernel, dim3(div_up(h->N, 256)), dim3(256), 0, h->stream, h->N,
-                       h->d.slot_of, slot_arr, orig_arr);
+    hipLaunchKernelGGL(gather_orig_kernel, dim3(div_up(h->n_local, 256)), dim3(256), 0, h->stream, h->n_local,
+                       h->d.gid, h->d.slot_of, slot_arr, orig_arr);
     HIP_TRY(hipGetLastError());
     return MDX_OK;
 }
@@ -730,10 +759,11 @@ int mdx_rebuild(mdx_handle* h) {
     MDX_TRY(mdx_unsort_state(h));  // dynamic state -> caller-order staging
     MDX_TRY(setup_grid(h));
     DeviceState& d = h->d;
-    const uint32_t N = h->N;
+    const uint32_t N = h->n_local;   // atoms simulated here (all of them on a single GPU)
     const GridParams g = h->grid;
     hipStream_t st = h->stream;
 
+    HIP_TRY(hipMemsetAsync(d.slot_of, 0xFF, sizeof(uint32_t) * (size_t)h->N, st));
     HIP_TRY(hipMemsetAsync(d.cell_count, 0, sizeof(uint32_t) * ((size_t)h->ncells + 1), st));
     HIP_TRY(hipMemsetAsync(d.cell_cursor, 0, sizeof(uint32_t) * ((size_t)h->ncells + 1), st));
     HIP_TRY(hipMemsetAsync(d.flags_dev, 0, sizeof(uint32_t) * 4, st));
@@ -760,9 +790,10 @@ int mdx_rebuild(mdx_handle* h) {
     hipLaunchKernelGGL(tile_col_kernel, dim3(div_up(h->ncol, 256)), dim3(256), 0, st, d.tile_start, h->ncol,
                        d.tile_col);
     hipLaunchKernelGGL(assign_tiles_kernel, dim3(div_up(T + 1, 4)), dim3(256), 0, st, T, g.nzb, d.tile_col,
-                       d.tile_start, d.cell_start, d.sorted_orig, d.pos_orig, d.orig_of, d.slot_of);
-    hipLaunchKernelGGL(gather_slots_kernel, dim3(div_up(S, 256)), dim3(256), 0, st, S, d.orig_of, d.pos_orig,
-                       d.vel_orig, d.o_qs, d.o_lj, d.o_invm, d.posq, d.lj, d.vel, d.ref, d.force);
+                       d.tile_start, d.cell_start, d.sorted_orig, d.pos_orig, d.gid, d.orig_of, d.slot_of);
+    hipLaunchKernelGGL(gather_slots_kernel, dim3(div_up(S, 256)), dim3(256), 0, st, S, d.orig_of, d.gid, d.lflag,
+                       d.pos_orig, d.vel_orig, d.o_qs, d.o_lj, d.o_invm, d.posq, d.lj, d.vel, d.ref, d.force,
+                       d.slot_flags);
     hipLaunchKernelGGL(cluster_bbox_kernel, dim3(div_up(NC, 256)), dim3(256), 0, st, NC, d.orig_of, d.posq,
                        d.cl_lo, d.cl_hi);
     h->in_slot_space = true;
@@ -772,7 +803,8 @@ int mdx_rebuild(mdx_handle* h) {
     a.T = T; a.g = g;
     a.r_build = std::isinf(h->r_list) ? h->r_list : h->r_list * (1.0f + 1e-5f) + 1e-4f;
     a.tile_col = d.tile_col; a.tile_start = d.tile_start; a.cl_lo = d.cl_lo; a.cl_hi = d.cl_hi;
-    a.orig_of = d.orig_of; a.slot_of = d.slot_of; a.excl_off = d.excl_off; a.excl_idx = d.excl_idx;
+    a.orig_of = d.orig_of; a.slot_of = d.slot_of; a.gid = d.gid; a.slot_flags = d.slot_flags;
+    a.excl_off = d.excl_off; a.excl_idx = d.excl_idx;
     a.counts = d.list_counts; a.entry_cnt = d.entry_cnt; a.mchunk_cnt = d.mchunk_cnt;
     a.entry_off = d.entry_off; a.mchunk_off = d.mchunk_off; a.entries = d.entries; a.masks = d.masks;
     a.err = d.flags_dev; a.null_cluster = T * MDX_CL_PER_TILE;
@@ -808,16 +840,20 @@ int mdx_rebuild(mdx_handle* h) {
 
     // ---- bonded role lists into slot space ----
     if (h->n_roles) {
-        hipLaunchKernelGGL(role_count_kernel, dim3(div_up(S + 1, 256)), dim3(256), 0, st, S, d.orig_of,
-                           d.role_off_o, d.role_cnt_s);
+        hipLaunchKernelGGL(role_count_kernel, dim3(div_up(S + 1, 256)), dim3(256), 0, st, S, d.orig_of, d.gid,
+                           d.lflag, d.role_off_o, d.role_cnt_s);
         MDX_TRY(mdx_exclusive_scan_u32(h, d.role_cnt_s, d.role_off_s, S + 1));
-        hipLaunchKernelGGL(role_fill_kernel, dim3(div_up(S, 256)), dim3(256), 0, st, S, d.orig_of, d.slot_of,
-                           d.role_off_o, d.role_rec_o, d.role_off_s, d.role_rec_s);
+        hipLaunchKernelGGL(role_fill_kernel, dim3(div_up(S, 256)), dim3(256), 0, st, S, d.orig_of, d.gid, d.lflag,
+                           d.slot_of, d.role_off_o, d.role_rec_o, d.role_off_s, d.role_rec_s, d.flags_dev);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(flags, d.flags_dev, sizeof(flags), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (flags[0]) { mdx_set_error("exclusion table overflow while building the pair list"); return MDX_EPARAM; }
+    if (flags[0] & 3u) { mdx_set_error("exclusion table overflow while building the pair list"); return MDX_EPARAM; }
+    if (flags[0] & 4u) {
+        mdx_set_error("a bonded partner of an owned atom is missing from the local atom set (halo too thin)");
+        return MDX_EPARAM;
+    }
 
     h->list_valid = true;
     h->forces_valid = false;
@@ -838,7 +874,7 @@ int mdx_rebuild(mdx_handle* h) {
 
 int mdx_extract_neighbors(mdx_handle* h, uint32_t* offsets, uint32_t* idx) {
     DeviceState& d = h->d;
-    const uint32_t N = h->N, T = h->T;
+    const uint32_t N = h->n_local, T = h->T;
     hipStream_t st = h->stream;
     const float rl2 = h->r_list * h->r_list;
     uint32_t *d_cnt = nullptr, *d_off = nullptr, *d_idx = nullptr;

@@ -38,7 +38,7 @@ struct GridParams {
     float inv_col[2];  // 1 / column edge in x, y
     float inv_zbin;    // 1 / fine z-bin height
     int ncx, ncy, nzb; // columns in x, y; z-bins per column
-    int periodic;
+    int per[3];        // periodic per dimension (a decomposed dimension is not periodic locally)
 };
 
 struct NbParams {
@@ -103,8 +103,11 @@ struct DeviceState {
     // slot space
     float4* posq = nullptr; float2* lj = nullptr; float4* vel = nullptr; float4* force = nullptr;
     float4* ref = nullptr;
-    uint32_t* orig_of = nullptr;  // [S]
-    uint32_t* slot_of = nullptr;  // [N]
+    uint32_t* orig_of = nullptr;  // [S]  slot -> local atom index (MDX_INVALID for dummies)
+    uint32_t* slot_of = nullptr;  // [N]  GLOBAL atom id -> slot (MDX_INVALID when not simulated here)
+    uint32_t* gid = nullptr;      // [cap_local] local atom index -> global atom id
+    uint8_t*  lflag = nullptr;    // [cap_local] bit0: ghost (halo copy owned by another rank)
+    uint8_t*  slot_flags = nullptr; // [S] bit0: real atom, bit1: owned (not a ghost)
     // grid build scratch
     uint32_t* cell_of = nullptr;      // [N]
     uint32_t* cell_count = nullptr;   // [ncells+1]
@@ -143,7 +146,11 @@ struct mdx_handle {
     uint32_t N = 0;
     mdx_config cfg{};
     // host copies of the system (needed to rebuild after set_box etc.)
-    bool periodic = false;
+    bool periodic = false;      // any dimension periodic
+    int per[3] = {0, 0, 0};     // per-dimension periodicity
+    uint32_t n_local = 0, cap_local = 0;  // atoms simulated by this handle (== N on a single GPU)
+    float local_lo[3]{}, local_hi[3]{};   // extent of the local region in non-periodic dimensions (decomposed runs)
+    bool have_local_bounds = false;
     float box_lo[3]{}, box_hi[3]{};
     uint32_t n_bonds = 0, n_angles = 0, n_dih = 0, n_p14 = 0;
     uint32_t n_roles = 0;

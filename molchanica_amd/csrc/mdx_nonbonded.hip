@@ -40,6 +40,7 @@ struct NbArgs {
     const ListCounts* counts; const uint32_t* entry_off; const uint32_t* mchunk_off;
     const uint2* entries; const unsigned long long* masks;
     float4* force; double* energy;
+    const uint8_t* slot_flags;   // bit1: owned (energy of a ghost i-atom belongs to its owner's rank)
     NbParams p;
     const uint32_t* gate; uint32_t thr_bits;
 };
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(NB_WAVES * 64) void nb_tile_kernel(NbArgs a) {
     }
     a.force[islot] = make_float4(fx, fy, fz, 0.f);
     if (ENERGY) {
+        if (!(a.slot_flags[islot] & 2u)) { elj = 0.0; ecoul = 0.0; }
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) {
             elj += __shfl_xor(elj, m);
@@ -227,6 +229,13 @@ __global__ __launch_bounds__(NB_WAVES * 64, ILDS ? 6 : 4) void nb_cluster_kernel
     float4* sx = s_xyzq[wave];
     float2* sl = s_lj[wave];
     double elj = 0.0, ecoul = 0.0;
+    uint32_t own_bits = 0xFFu;   // ENERGY only: bit ci set <=> i-atom (ci, ii) is owned by this rank
+    if (ENERGY) {
+        own_bits = 0;
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci)
+            own_bits |= ((a.slot_flags[t * MDX_TILE + ci * MDX_CLUSTER + ii] >> 1) & 1u) << ci;
+    }
 
     // two-deep software pipeline: entries of chunk c+2 and atoms of chunk c+1 are in flight while
     // chunk c is evaluated, so the dependent (entry -> posq) load never stalls the wave
@@ -279,16 +288,18 @@ __global__ __launch_bounds__(NB_WAVES * 64, ILDS ? 6 : 4) void nb_cluster_kernel
                     if (im & (((1u << GROUP) - 1u) << (GROUP * cp))) {
 #pragma unroll
                         for (int ci = GROUP * cp; ci < GROUP * cp + GROUP; ++ci) {
+                            double e1 = 0.0, e2 = 0.0;
                             if (ILDS) {
                                 const float4 pi = s_ixyzq[wave][ci * 8 + ii];
                                 const float2 li = s_ilj[wave][ci * 8 + ii];
                                 pair_eval<ENERGY, COUL, GEOM, SAMECUT, true>(pi.x, pi.y, pi.z, pi.w, li.x, li.y, pj, lj,
                                                                        (m8 >> ci) & 1u, a.p, fx[ci], fy[ci], fz[ci],
-                                                                       elj, ecoul);
+                                                                       e1, e2);
                             } else
                             pair_eval<ENERGY, COUL, GEOM, SAMECUT, true>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci], pj,
                                                                    lj, (m8 >> ci) & 1u, a.p, fx[ci], fy[ci], fz[ci],
-                                                                   elj, ecoul);
+                                                                   e1, e2);
+                            if (ENERGY && ((own_bits >> ci) & 1u)) { elj += e1; ecoul += e2; }
                         }
                     }
                 }
@@ -298,16 +309,18 @@ __global__ __launch_bounds__(NB_WAVES * 64, ILDS ? 6 : 4) void nb_cluster_kernel
                     if (im & (((1u << GROUP) - 1u) << (GROUP * cp))) {
 #pragma unroll
                         for (int ci = GROUP * cp; ci < GROUP * cp + GROUP; ++ci) {
+                            double e1 = 0.0, e2 = 0.0;
                             if (ILDS) {
                                 const float4 pi = s_ixyzq[wave][ci * 8 + ii];
                                 const float2 li = s_ilj[wave][ci * 8 + ii];
                                 pair_eval<ENERGY, COUL, GEOM, SAMECUT, true>(pi.x, pi.y, pi.z, pi.w, li.x, li.y, pj, lj,
                                                                        (im >> ci) & 1u, a.p, fx[ci], fy[ci], fz[ci],
-                                                                       elj, ecoul);
+                                                                       e1, e2);
                             } else
                             pair_eval<ENERGY, COUL, GEOM, SAMECUT, true>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci], pj,
                                                                    lj, (im >> ci) & 1u, a.p, fx[ci], fy[ci], fz[ci],
-                                                                   elj, ecoul);
+                                                                   e1, e2);
+                            if (ENERGY && ((own_bits >> ci) & 1u)) { elj += e1; ecoul += e2; }
                         }
                     }
                 }
@@ -366,11 +379,11 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
     a.T = h->T;
     a.posq = h->d.posq; a.lj = h->d.lj; a.counts = h->d.list_counts; a.entry_off = h->d.entry_off;
     a.mchunk_off = h->d.mchunk_off; a.entries = h->d.entries; a.masks = h->d.masks;
-    a.force = h->d.force; a.energy = h->d.energy; a.gate = d_gate; a.thr_bits = thr_bits;
+    a.force = h->d.force; a.energy = h->d.energy; a.slot_flags = h->d.slot_flags; a.gate = d_gate; a.thr_bits = thr_bits;
     NbParams& p = a.p;
     p.rc2_lj = cut_on(c.lj_cutoff) ? c.lj_cutoff * c.lj_cutoff : FLT_MAX;
     p.rc2_coul = cut_on(c.coulomb_cutoff) ? c.coulomb_cutoff * c.coulomb_cutoff : FLT_MAX;
-    for (int d = 0; d < 3; ++d) p.shift[d] = h->periodic ? (h->box_hi[d] - h->box_lo[d]) : 0.f;
+    for (int d = 0; d < 3; ++d) p.shift[d] = h->per[d] ? (h->box_hi[d] - h->box_lo[d]) : 0.f;
     const bool ccut = cut_on(c.coulomb_cutoff);
     const float rc = c.coulomb_cutoff;
     p.alpha = c.ewald_alpha; p.soft2 = c.softening_sq;

@@ -51,6 +51,15 @@ def load_library():
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run "
             f"`python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists).")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 (+ HSA runtime).  If
+    # libmdx.so were loaded first it would pull the system copy by RUNPATH and a later torch.cuda
+    # initialisation then finds "No HIP GPUs" — and device pointers could not be shared with
+    # torch.distributed buffers.  Importing torch first makes the dynamic linker resolve libmdx's
+    # libamdhip64.so.7 dependency to the copy torch already mapped (same SONAME).
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # a host without PyTorch (e.g. the Rust application) simply uses the system runtime
+        pass
     lib = C.CDLL(LIB_PATH)
     H = C.c_void_p
     lib.mdx_device_count.restype = C.c_int
@@ -72,11 +81,20 @@ def load_library():
     lib.mdx_neighbor_list.argtypes = [H, _u32p, _u32p]
     lib.mdx_profile.argtypes = [H, C.c_int]
     lib.mdx_get_stats.argtypes = [H, C.POINTER(CStats)]
-    lib.mdx_step_begin.argtypes = [H, C.c_float, C.c_int]
-    lib.mdx_step_end.argtypes = [H, C.c_float, C.c_int]
+    lib.mdx_set_local_atoms.argtypes = [H, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_float * 3, C.c_float * 3, C.c_int32]
+    lib.mdx_local_state.argtypes = [H, C.c_void_p, C.c_void_p]
+    lib.mdx_chunk_begin.argtypes = [H]
+    lib.mdx_chunk_integrate.argtypes = [H, C.c_int, C.c_float, C.c_uint32]
+    lib.mdx_chunk_forces.argtypes = [H, C.c_int32]
+    lib.mdx_chunk_end.argtypes = [H, C.c_uint32, _u32p]
+    lib.mdx_flag_words.argtypes = [H]
+    lib.mdx_flag_words.restype = C.c_void_p
+    lib.mdx_stale_threshold.argtypes = [H]
+    lib.mdx_stale_threshold.restype = C.c_uint32
+    lib.mdx_add_steps.argtypes = [H, C.c_uint32]
     lib.mdx_pack_positions.argtypes = [H, C.c_void_p, C.c_uint32, C.c_void_p]
-    lib.mdx_unpack_positions.argtypes = [H, C.c_void_p, C.c_uint32, C.c_void_p]
-    lib.mdx_needs_rebuild.argtypes = [H, C.POINTER(C.c_int)]
+    lib.mdx_unpack_positions.argtypes = [H, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     lib.mdx_stream.argtypes = [H]
     lib.mdx_stream.restype = C.c_void_p
     _lib = lib
@@ -209,23 +227,44 @@ class MdState:
         """`md.computation_time()` (src/md/mod.rs:740-743): ms spent inside step calls."""
         return float(self.stats()["wall_ms_sum"])
 
-    # -- multi-GPU plumbing (raw device pointers; used by molchanica_amd.decomp) -----------------
-    def step_begin(self, dt: float, first: bool):
-        _check(load_library().mdx_step_begin(self._h, float(dt), int(first)))
+    # -- multi-GPU plumbing (raw device pointers; used by molchanica_amd.decomp) -------------------
+    def set_local_atoms(self, n_local, d_gid, d_ghost, d_pos4, d_vel4, lo, hi, periodic_mask: int):
+        _check(load_library().mdx_set_local_atoms(
+            self._h, int(n_local), C.c_void_p(d_gid), C.c_void_p(d_ghost), C.c_void_p(d_pos4), C.c_void_p(d_vel4),
+            (C.c_float * 3)(*map(float, lo)), (C.c_float * 3)(*map(float, hi)), int(periodic_mask)))
 
-    def step_end(self, dt: float, last: bool):
-        _check(load_library().mdx_step_end(self._h, float(dt), int(last)))
+    def local_state(self, d_pos4, d_vel4):
+        _check(load_library().mdx_local_state(self._h, C.c_void_p(d_pos4), C.c_void_p(d_vel4)))
 
-    def pack_positions(self, d_idx_ptr: int, n: int, d_out_ptr: int):
-        _check(load_library().mdx_pack_positions(self._h, C.c_void_p(d_idx_ptr), int(n), C.c_void_p(d_out_ptr)))
+    def chunk_begin(self):
+        _check(load_library().mdx_chunk_begin(self._h))
 
-    def unpack_positions(self, d_idx_ptr: int, n: int, d_in_ptr: int):
-        _check(load_library().mdx_unpack_positions(self._h, C.c_void_p(d_idx_ptr), int(n), C.c_void_p(d_in_ptr)))
+    def chunk_integrate(self, mode: int, dt: float, s: int):
+        _check(load_library().mdx_chunk_integrate(self._h, int(mode), float(dt), int(s)))
 
-    def needs_rebuild(self) -> bool:
-        v = C.c_int(0)
-        _check(load_library().mdx_needs_rebuild(self._h, C.byref(v)))
-        return bool(v.value)
+    def chunk_forces(self, s: int):
+        _check(load_library().mdx_chunk_forces(self._h, int(s)))
+
+    def chunk_end(self, n_words: int) -> np.ndarray:
+        out = np.zeros(n_words, dtype=np.uint32)
+        _check(load_library().mdx_chunk_end(self._h, int(n_words), out.ctypes.data_as(_u32p)))
+        return out
+
+    def flag_words_ptr(self) -> int:
+        return int(load_library().mdx_flag_words(self._h) or 0)
+
+    def stale_threshold(self) -> int:
+        return int(load_library().mdx_stale_threshold(self._h))
+
+    def add_steps(self, n: int):
+        _check(load_library().mdx_add_steps(self._h, int(n)))
+
+    def pack_positions(self, d_gid: int, n: int, d_out4: int):
+        _check(load_library().mdx_pack_positions(self._h, C.c_void_p(d_gid), int(n), C.c_void_p(d_out4)))
+
+    def unpack_positions(self, d_gid: int, n: int, d_in4: int, d_shift4: int = 0):
+        _check(load_library().mdx_unpack_positions(self._h, C.c_void_p(d_gid), int(n), C.c_void_p(d_in4),
+                                                   C.c_void_p(d_shift4) if d_shift4 else None))
 
     def stream_ptr(self) -> int:
         return int(load_library().mdx_stream(self._h) or 0)
