@@ -216,7 +216,7 @@ int mdx_exclusive_scan_u32(mdx_handle* h, const uint32_t* in, uint32_t* out, uin
 #define MDX_NB_DEFAULT_VARIANT 2
 static inline int mdx_nb_variant(const mdx_handle* h) {
     const uint32_t v = h->cfg.nb_variant;
-    return (v >= 1 && v <= 3) ? (int)v : MDX_NB_DEFAULT_VARIANT;   // 3: cluster kernel, i-clusters in pairs
+    return (v >= 1 && v <= 4) ? (int)v : MDX_NB_DEFAULT_VARIANT;   // 3/4: cluster kernel, 1/4 waves per tile forced
 }
 
 // profiling helpers

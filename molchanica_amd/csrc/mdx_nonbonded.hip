@@ -24,6 +24,7 @@
 //     private L2 sees a compact spatial region.
 // No MFMA: this is pairwise scalar work.  Roofline: fp32 VALU bound.
 #include "mdx_internal.h"
+#include <algorithm>
 #include <cfloat>
 
 #define WAVE_LDS_SYNC()                                        \
@@ -184,42 +185,45 @@ __global__ __launch_bounds__(NB_WAVES * 64) void nb_tile_kernel(NbArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Variant 2: cluster-masked tile kernel.  Same list, same LDS staging, but a lane is the pair
-// (i-atom ii = lane&7 of every i-cluster, j-atom jj = lane>>3 of the current entry): the eight
-// i-clusters of the tile sit in registers, and an entry is evaluated only against the i-clusters
-// whose bounding box is within the list radius of the j-cluster (the entry's 8-bit imask, a
-// wave-uniform branch).  That removes the corner (i-cluster, j-cluster) pairs a whole-tile test
-// lets through - about 40 % of the pair evaluations at rc 10 + skin 2 - at the price of one
-// cross-lane reduction per tile.  Still one owner per i-atom, no atomics, deterministic.
-template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int GROUP, bool ILDS>
-__global__ __launch_bounds__(NB_WAVES * 64, ILDS ? 6 : 4) void nb_cluster_kernel(NbArgs a) {
+// Variant 2 (default): cluster-masked tile kernel.  Same list, same LDS staging, but a lane is the
+// pair (i-atom ii = lane&7 of every i-cluster, j-atom jj = lane>>3 of the current entry): the
+// eight i-clusters of the tile sit in registers, and an entry is evaluated only against the
+// i-clusters whose bounding box is within the list radius of the j-cluster (the entry's 8-bit
+// imask, a wave-uniform branch).  That removes the corner (i-cluster, j-cluster) pairs a
+// whole-tile test lets through - about 40 % of the pair evaluations at rc 10 + skin 2 - at the
+// price of one cross-lane reduction per tile.  Still one owner per i-atom, no atomics,
+// deterministic.
+//
+// WPT = waves per tile.  WPT = 1: a workgroup is 4 tiles.  WPT = 4: the 4 waves of a workgroup
+// share ONE tile, wave w takes chunks w, w+4, ... of its list and the partial forces are summed
+// through LDS in a fixed order.  A tile's list is a ~270 us dependency chain for one wave, so a
+// launch with fewer tiles than the chip has wave slots (strong scaling: 1/8 of the box per GPU,
+// or any system below ~250 k atoms) is latency-bound; splitting the list 4 ways fills the SIMDs.
+template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT>
+__global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, 4) void nb_cluster_kernel(NbArgs a) {
     if (a.gate && *a.gate > a.thr_bits) return;
-    __shared__ float4 s_xyzq[NB_WAVES][64];
-    __shared__ float2 s_lj[NB_WAVES][64];
+    constexpr int BW = WPT > NB_WAVES ? WPT : NB_WAVES;       // waves per workgroup
+    __shared__ float4 s_xyzq[BW][64];
+    __shared__ float2 s_lj[BW][64];
+    __shared__ float s_red[WPT > 1 ? BW : 1][3][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t nblocks = (a.T + NB_WAVES - 1) / NB_WAVES;
+    constexpr int TPB = BW / WPT;                             // tiles per workgroup
+    const uint32_t nblocks = (a.T + TPB - 1) / TPB;
     const uint32_t per_xcd = (nblocks + 7) >> 3;
     const uint32_t blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if (blk >= nblocks) return;
-    const uint32_t t = blk * NB_WAVES + wave;
-    if (t >= a.T) return;
+    if (blk >= nblocks) return;                               // whole workgroup
+    const uint32_t t = blk * TPB + (WPT == 1 ? wave : 0);
+    const int part = WPT == 1 ? 0 : wave;                     // which share of the tile's chunks
+    if (WPT == 1 && t >= a.T) return;
     const int ii = lane & 7, jj = lane >> 3;
 
-    __shared__ float4 s_ixyzq[ILDS ? NB_WAVES : 1][64];
-    __shared__ float2 s_ilj[ILDS ? NB_WAVES : 1][64];
     float xi[8], yi[8], zi[8], qi[8], sgi[8], epi[8], fx[8], fy[8], fz[8];
-    if (ILDS) {   // i-tile parked in LDS: ~48 VGPRs less, two more waves per SIMD
-        s_ixyzq[wave][lane] = a.posq[t * MDX_TILE + lane];
-        s_ilj[wave][lane] = a.lj[t * MDX_TILE + lane];
-    }
 #pragma unroll
     for (int ci = 0; ci < 8; ++ci) {
-        if (!ILDS) {
-            const uint32_t s = t * MDX_TILE + ci * MDX_CLUSTER + ii;
-            const float4 pi = a.posq[s];
-            const float2 li = a.lj[s];
-            xi[ci] = pi.x; yi[ci] = pi.y; zi[ci] = pi.z; qi[ci] = pi.w; sgi[ci] = li.x; epi[ci] = li.y;
-        }
+        const uint32_t s = t * MDX_TILE + ci * MDX_CLUSTER + ii;
+        const float4 pi = a.posq[s];
+        const float2 li = a.lj[s];
+        xi[ci] = pi.x; yi[ci] = pi.y; zi[ci] = pi.z; qi[ci] = pi.w; sgi[ci] = li.x; epi[ci] = li.y;
         fx[ci] = 0.f; fy[ci] = 0.f; fz[ci] = 0.f;
     }
     const ListCounts cnt = a.counts[t];
@@ -237,21 +241,22 @@ __global__ __launch_bounds__(NB_WAVES * 64, ILDS ? 6 : 4) void nb_cluster_kernel
             own_bits |= ((a.slot_flags[t * MDX_TILE + ci * MDX_CLUSTER + ii] >> 1) & 1u) << ci;
     }
 
-    // two-deep software pipeline: entries of chunk c+2 and atoms of chunk c+1 are in flight while
-    // chunk c is evaluated, so the dependent (entry -> posq) load never stalls the wave
+    // two-deep software pipeline: entries of the wave's next-but-one chunk and atoms of its next
+    // chunk are in flight while the current chunk is evaluated, so the dependent (entry -> posq)
+    // load never stalls the wave
     float4 nj = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 nl = make_float2(0.f, 0.f);
     uint32_t ny = 13;
     uint2 ent_n = make_uint2(0u, 13u);
-    if (nchunks) {
-        const uint2 ent = a.entries[e0 + (lane >> 3)];
-        if (nchunks > 1) ent_n = a.entries[e0 + 8 + (lane >> 3)];
+    if ((uint32_t)part < nchunks) {
+        const uint2 ent = a.entries[e0 + part * 8 + (lane >> 3)];
+        if ((uint32_t)part + WPT < nchunks) ent_n = a.entries[e0 + (part + WPT) * 8 + (lane >> 3)];
         const uint32_t js = ent.x * MDX_CLUSTER + (lane & 7);
         nj = a.posq[js]; nl = a.lj[js]; ny = ent.y;
     }
-    for (uint32_t c = 0; c < nchunks; ++c) {
+    for (uint32_t c = part; c < nchunks; c += WPT) {
         const uint32_t cur_y = ny;
-        {
+        {   // image shift, then park in LDS
             const uint32_t code = ny & 31u;
             const int kx = (int)(code % 3u) - 1, ky = (int)((code / 3u) % 3u) - 1, kz = (int)(code / 9u) - 1;
             nj.x += (float)kx * a.p.shift[0];
@@ -261,17 +266,14 @@ __global__ __launch_bounds__(NB_WAVES * 64, ILDS ? 6 : 4) void nb_cluster_kernel
             sl[lane] = nl;
         }
         WAVE_LDS_SYNC();
-        if (c + 1 < nchunks) {
+        if (c + WPT < nchunks) {
             const uint32_t js = ent_n.x * MDX_CLUSTER + (lane & 7);
             nj = a.posq[js]; nl = a.lj[js]; ny = ent_n.y;
-            if (c + 2 < nchunks) ent_n = a.entries[e0 + (c + 2) * 8 + (lane >> 3)];
+            if (c + 2 * WPT < nchunks) ent_n = a.entries[e0 + (c + 2 * WPT) * 8 + (lane >> 3)];
         }
         const bool masked = c < nmc;
         const unsigned long long mq = masked ? a.masks[(size_t)(mbase + c) * 64 + lane] : ~0ull;
-        // entry loop: the next entry's j record is fetched from LDS before the current one is
-        // evaluated; i-clusters are taken in z-adjacent pairs (2k, 2k+1) so that each uniform
-        // branch guards two independent dependency chains (ILP 2) - the partner of a lone set
-        // bit is evaluated masked-off.
+        // entry loop: the next entry's j record is fetched from LDS before the current one is evaluated
         float4 pj_n = sx[jj];
         float2 lj_n = sl[jj];
 #pragma unroll 1
@@ -281,48 +283,15 @@ __global__ __launch_bounds__(NB_WAVES * 64, ILDS ? 6 : 4) void nb_cluster_kernel
             if (e < 7) { pj_n = sx[(e + 1) * 8 + jj]; lj_n = sl[(e + 1) * 8 + jj]; }
             const uint32_t im = (__builtin_amdgcn_readlane(cur_y, e * 8) >> 8) & 0xFFu;  // wave-uniform
             if (im == 0) continue;
-            if (masked) {
-                const uint32_t m8 = (uint32_t)(mq >> (8 * e)) & im;
+            // exclusion bits only exist in masked chunks; elsewhere the (uniform) imask bit suffices
+            const uint32_t m8 = masked ? ((uint32_t)(mq >> (8 * e)) & im) : im;
 #pragma unroll
-                for (int cp = 0; cp < 8 / GROUP; ++cp) {
-                    if (im & (((1u << GROUP) - 1u) << (GROUP * cp))) {
-#pragma unroll
-                        for (int ci = GROUP * cp; ci < GROUP * cp + GROUP; ++ci) {
-                            double e1 = 0.0, e2 = 0.0;
-                            if (ILDS) {
-                                const float4 pi = s_ixyzq[wave][ci * 8 + ii];
-                                const float2 li = s_ilj[wave][ci * 8 + ii];
-                                pair_eval<ENERGY, COUL, GEOM, SAMECUT, true>(pi.x, pi.y, pi.z, pi.w, li.x, li.y, pj, lj,
-                                                                       (m8 >> ci) & 1u, a.p, fx[ci], fy[ci], fz[ci],
-                                                                       e1, e2);
-                            } else
-                            pair_eval<ENERGY, COUL, GEOM, SAMECUT, true>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci], pj,
-                                                                   lj, (m8 >> ci) & 1u, a.p, fx[ci], fy[ci], fz[ci],
-                                                                   e1, e2);
-                            if (ENERGY && ((own_bits >> ci) & 1u)) { elj += e1; ecoul += e2; }
-                        }
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int cp = 0; cp < 8 / GROUP; ++cp) {
-                    if (im & (((1u << GROUP) - 1u) << (GROUP * cp))) {
-#pragma unroll
-                        for (int ci = GROUP * cp; ci < GROUP * cp + GROUP; ++ci) {
-                            double e1 = 0.0, e2 = 0.0;
-                            if (ILDS) {
-                                const float4 pi = s_ixyzq[wave][ci * 8 + ii];
-                                const float2 li = s_ilj[wave][ci * 8 + ii];
-                                pair_eval<ENERGY, COUL, GEOM, SAMECUT, true>(pi.x, pi.y, pi.z, pi.w, li.x, li.y, pj, lj,
-                                                                       (im >> ci) & 1u, a.p, fx[ci], fy[ci], fz[ci],
-                                                                       e1, e2);
-                            } else
-                            pair_eval<ENERGY, COUL, GEOM, SAMECUT, true>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci], pj,
-                                                                   lj, (im >> ci) & 1u, a.p, fx[ci], fy[ci], fz[ci],
-                                                                   e1, e2);
-                            if (ENERGY && ((own_bits >> ci) & 1u)) { elj += e1; ecoul += e2; }
-                        }
-                    }
+            for (int ci = 0; ci < 8; ++ci) {
+                if (im & (1u << ci)) {
+                    double e1 = 0.0, e2 = 0.0;
+                    pair_eval<ENERGY, COUL, GEOM, SAMECUT, true>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci], pj, lj,
+                                                                 (m8 >> ci) & 1u, a.p, fx[ci], fy[ci], fz[ci], e1, e2);
+                    if (ENERGY && ((own_bits >> ci) & 1u)) { elj += e1; ecoul += e2; }
                 }
             }
         }
@@ -340,7 +309,18 @@ __global__ __launch_bounds__(NB_WAVES * 64, ILDS ? 6 : 4) void nb_cluster_kernel
         }
         if (jj == ci) { ox = x; oy = y; oz = z; }
     }
-    a.force[t * MDX_TILE + lane] = make_float4(ox, oy, oz, 0.f);
+    if (WPT > 1) {   // fixed-order sum of the waves' partial forces
+        s_red[wave][0][lane] = ox; s_red[wave][1][lane] = oy; s_red[wave][2][lane] = oz;
+        __syncthreads();
+        if (wave == 0) {
+            ox = s_red[0][0][lane]; oy = s_red[0][1][lane]; oz = s_red[0][2][lane];
+#pragma unroll
+            for (int w = 1; w < WPT; ++w) { ox += s_red[w][0][lane]; oy += s_red[w][1][lane]; oz += s_red[w][2][lane]; }
+            a.force[t * MDX_TILE + lane] = make_float4(ox, oy, oz, 0.f);
+        }
+    } else {
+        a.force[t * MDX_TILE + lane] = make_float4(ox, oy, oz, 0.f);
+    }
     if (ENERGY) {
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) {
@@ -356,15 +336,23 @@ __global__ __launch_bounds__(NB_WAVES * 64, ILDS ? 6 : 4) void nb_cluster_kernel
 
 template <bool ENERGY, int COUL>
 static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samecut) {
-    const uint32_t nblocks = (a.T + NB_WAVES - 1) / NB_WAVES;
-    const uint32_t grid = ((nblocks + 7) / 8) * 8;
-    dim3 g(grid), b(NB_WAVES * 64);
     const int var = mdx_nb_variant(h);
+    // waves per tile: split a tile's list over the 4 waves of its workgroup when the launch has
+    // fewer tiles than ~3 per SIMD (the chip holds 4 waves/SIMD of this kernel on 1024 SIMDs)
+    int wpt = 1;
+    if (var == 2) wpt = (a.T < 4096u) ? 8 : 4;     // measured: 4 beats 1 at every size, 8 below ~200 k atoms
+    else if (var == 4) wpt = 4;
+    const uint32_t bw = std::max(wpt, NB_WAVES);
+    const uint32_t tpb = (var == 1) ? NB_WAVES : bw / wpt;
+    const uint32_t nblocks = (a.T + tpb - 1) / tpb;
+    const uint32_t grid = ((nblocks + 7) / 8) * 8;
+    dim3 g(grid), b(bw * 64);
 #define NB_LAUNCH(G, S)                                                                                    \
     do {                                                                                                   \
-        if (var == 2) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 1, false>), g, b, 0, h->stream, a); \
-        else if (var == 3) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 1, true>), g, b, 0, h->stream, a); \
-        else hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, G, S>), g, b, 0, h->stream, a);              \
+        if (var == 1) hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, G, S>), g, b, 0, h->stream, a);     \
+        else if (wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8>), g, b, 0, h->stream, a); \
+        else if (wpt == 4) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4>), g, b, 0, h->stream, a); \
+        else hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 1>), g, b, 0, h->stream, a);        \
     } while (0)
     if (geom) { if (samecut) NB_LAUNCH(true, true); else NB_LAUNCH(true, false); }
     else      { if (samecut) NB_LAUNCH(false, true); else NB_LAUNCH(false, false); }

@@ -130,8 +130,16 @@ def _solute_from_geometry(pos: np.ndarray, bonds: np.ndarray, types: np.ndarray,
     dih_v = rng.uniform(0.1, 2.0, size=nd)
     dih_n = rng.integers(1, 4, size=nd)
     dih_phase = rng.integers(0, 2, size=nd) * math.pi
+    # H-like side atoms (type 3) carry a small positive charge like real hydrogens: a negative
+    # one would pull TIP3P hydrogens (which have no LJ term) into a Coulomb singularity
     q = rng.normal(scale=charge_sigma, size=n)
-    q -= q.mean()
+    h_like = np.asarray(types) == 3
+    q[h_like] = rng.uniform(0.03, 0.15, size=int(h_like.sum()))
+    heavy = ~h_like
+    if heavy.any():
+        q[heavy] -= q.sum() / heavy.sum()
+    else:
+        q -= q.mean()
     return dict(angles=angles, dihedrals=dihedrals, excl_off=off, excl_idx=idx, p14=p14,
                 bond_k=bond_k, bond_r0=bond_r0, angle_k=angle_k, angle_t0=angle_t0,
                 dih_v=dih_v, dih_n=dih_n, dih_phase=dih_phase, charge=q,

@@ -9,7 +9,7 @@ sizes = [int(x) for x in sys.argv[1:]] or [40, 70]
 for n in sizes:
     s3 = systems.water_box(n)
     f_ref = None
-    for variant in (2, 3, 2, 3):
+    for variant in (4, 2, 4, 2):
         md3 = MdState(s3, MdConfig(nb_variant=variant))
         f = md3.forces()
         if f_ref is None: f_ref = f
