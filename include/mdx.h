@@ -231,10 +231,14 @@ uint32_t mdx_stale_threshold(const mdx_handle* h); /* a word above this (as uint
 int      mdx_add_steps(mdx_handle* h, uint32_t n);
 
 /* Halo traffic: gather owned positions by global id into a send buffer / scatter received ghost
- * positions (plus a per-ghost image shift) back.  4 floats per atom. */
-int   mdx_pack_positions(mdx_handle* h, const uint32_t* d_gid, uint32_t n, float* d_out4);
+ * positions (plus a per-ghost image shift) back.  4 floats per row.  A row whose id is 0xFFFFFFFF
+ * is a FLAG row: pack writes the bit pattern of flag word `flag_word` into it, unpack merges (max)
+ * a received one into the local word — when every rank is every other rank's peer (2, 4, 8 GPUs)
+ * the stale-list decision thus rides on the halo message and needs no separate all-reduce.
+ * flag_word < 0 disables that. */
+int   mdx_pack_positions(mdx_handle* h, const uint32_t* d_gid, uint32_t n, float* d_out4, int32_t flag_word);
 int   mdx_unpack_positions(mdx_handle* h, const uint32_t* d_gid, uint32_t n, const float* d_in4,
-                           const float* d_shift4_or_null);
+                           const float* d_shift4_or_null, int32_t flag_word);
 void* mdx_stream(mdx_handle* h);                           /* hipStream_t                        */
 
 #ifdef __cplusplus

@@ -604,17 +604,32 @@ extern "C" int mdx_get_stats(mdx_handle* h, mdx_stats* out) {
 }
 
 // ---- multi-GPU support: split step + halo pack/unpack -------------------------------------------
+// A row whose id is MDX_INVALID is a FLAG row: it carries this rank's rebuild-flag word to the peer
+// (bit pattern in .x), so the global "list went stale" decision rides on the halo message itself.
 __global__ void pack_pos_kernel(uint32_t n, const uint32_t* __restrict__ atom_idx, const uint32_t* __restrict__ slot_of,
-                                const float4* __restrict__ posq, float4* __restrict__ out) {
+                                const float4* __restrict__ posq, float4* __restrict__ out,
+                                const uint32_t* __restrict__ flag_word) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const uint32_t s = slot_of[atom_idx[i]]; out[i] = (s == MDX_INVALID) ? make_float4(0.f, 0.f, 0.f, 0.f) : posq[s]; }
+    if (i >= n) return;
+    const uint32_t g = atom_idx[i];
+    if (g == MDX_INVALID) {
+        out[i] = make_float4(flag_word ? __uint_as_float(*flag_word) : 0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const uint32_t s = slot_of[g];
+    out[i] = (s == MDX_INVALID) ? make_float4(0.f, 0.f, 0.f, 0.f) : posq[s];
 }
 __global__ void unpack_pos_kernel(uint32_t n, const uint32_t* __restrict__ atom_idx, const uint32_t* __restrict__ slot_of,
                                   float4* __restrict__ posq, const float4* __restrict__ in,
-                                  const float4* __restrict__ shift) {
+                                  const float4* __restrict__ shift, uint32_t* __restrict__ flag_word) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t s = slot_of[atom_idx[i]];
+    const uint32_t g = atom_idx[i];
+    if (g == MDX_INVALID) {   // a peer's flag word: merge (max) into ours
+        if (flag_word) atomicMax(flag_word, __float_as_uint(in[i].x));
+        return;
+    }
+    const uint32_t s = slot_of[g];
     if (s == MDX_INVALID) return;
     float4 v = in[i];
     if (shift) { const float4 sh = shift[i]; v.x += sh.x; v.y += sh.y; v.z += sh.z; }
@@ -709,21 +724,23 @@ extern "C" int mdx_add_steps(mdx_handle* h, uint32_t n) {
     return MDX_OK;
 }
 
-extern "C" int mdx_pack_positions(mdx_handle* h, const uint32_t* d_gid, uint32_t n, float* d_out4) {
-    if (!h || (n && (!d_gid || !d_out4))) FAIL(MDX_EPARAM, "null argument");
+extern "C" int mdx_pack_positions(mdx_handle* h, const uint32_t* d_gid, uint32_t n, float* d_out4, int32_t flag_word) {
+    if (!h || (n && (!d_gid || !d_out4)) || flag_word > (int32_t)MDX_MAX_CHUNK + 1) FAIL(MDX_EPARAM, "bad argument");
     if (!h->in_slot_space) FAIL(MDX_EPARAM, "spatial caches not built");
     if (n) hipLaunchKernelGGL(pack_pos_kernel, dim3(div_up(n, 256)), dim3(256), 0, h->stream, n, d_gid,
-                              h->d.slot_of, h->d.posq, (float4*)d_out4);
+                              h->d.slot_of, h->d.posq, (float4*)d_out4,
+                              flag_word >= 0 ? &h->d.ctl->disp2[flag_word] : nullptr);
     HIP_TRY(hipGetLastError());
     return MDX_OK;
 }
 
 extern "C" int mdx_unpack_positions(mdx_handle* h, const uint32_t* d_gid, uint32_t n, const float* d_in4,
-                                    const float* d_shift4) {
-    if (!h || (n && (!d_gid || !d_in4))) FAIL(MDX_EPARAM, "null argument");
+                                    const float* d_shift4, int32_t flag_word) {
+    if (!h || (n && (!d_gid || !d_in4)) || flag_word > (int32_t)MDX_MAX_CHUNK + 1) FAIL(MDX_EPARAM, "bad argument");
     if (!h->in_slot_space) FAIL(MDX_EPARAM, "spatial caches not built");
     if (n) hipLaunchKernelGGL(unpack_pos_kernel, dim3(div_up(n, 256)), dim3(256), 0, h->stream, n, d_gid,
-                              h->d.slot_of, h->d.posq, (const float4*)d_in4, (const float4*)d_shift4);
+                              h->d.slot_of, h->d.posq, (const float4*)d_in4, (const float4*)d_shift4,
+                              flag_word >= 0 ? &h->d.ctl->disp2[flag_word] : nullptr);
     HIP_TRY(hipGetLastError());
     h->forces_valid = false;
     return MDX_OK;

@@ -239,10 +239,11 @@ class HipEngine:
     def chunk_end(self, n): return self.md.chunk_end(n)
     def add_steps(self, n): self.md.add_steps(n)
 
-    def pack(self, gid, out4): self.md.pack_positions(gid.data_ptr(), int(gid.numel()), out4.data_ptr())
+    def pack(self, gid, out4, flag_word=-1):
+        self.md.pack_positions(gid.data_ptr(), int(gid.numel()), out4.data_ptr(), flag_word)
 
-    def unpack(self, gid, in4, shift4):
-        self.md.unpack_positions(gid.data_ptr(), int(gid.numel()), in4.data_ptr(), shift4.data_ptr())
+    def unpack(self, gid, in4, shift4, flag_word=-1):
+        self.md.unpack_positions(gid.data_ptr(), int(gid.numel()), in4.data_ptr(), shift4.data_ptr(), flag_word)
 
     def energy(self): return self.md.energy()
     def stats(self): return self.md.stats()
@@ -307,23 +308,37 @@ class DecomposedMd:
                                     lo, hi, part.periodic_mask())
         self.owned_gid = torch.nonzero(owned, as_tuple=False).flatten()
         self.n_owned = int(self.owned_gid.numel())
-        # halo lists, derived identically on every rank: what rank q needs from rank p
-        self.send, self.recv = [], []          # (peer, gid int32 tensor, buffer [n,4]) / (+ shift4)
+        # halo lists, derived identically on every rank: what rank q needs from rank p.  All peers'
+        # rows live in ONE send and ONE receive buffer (one pack and one unpack launch per step); a
+        # peer's segment ends with a flag row (id -1) that carries the rebuild-flag word.
+        INV = -1
+        s_ids, r_ids, r_shift, self.send, self.recv = [], [], [], [], []   # (peer, row0, row1)
+        s0 = r0 = 0
         for q in range(self.world):
             if q == r:
                 continue
             mq, _ = part.local_mask_and_shift(q, posw)
-            s_idx = torch.nonzero(mq & owned, as_tuple=False).flatten()       # mine, ghost on q
+            s_idx = torch.nonzero(mq & owned, as_tuple=False).flatten()              # mine, ghost on q
+            r_idx = torch.nonzero(mask & (owner == q), as_tuple=False).flatten()     # q's, ghost here
             if s_idx.numel():
-                self.send.append((q, s_idx.to(torch.int32).contiguous(),
-                                  torch.empty((s_idx.numel(), 4), dtype=torch.float32, device=self.dev)))
-            r_idx = torch.nonzero(mask & (owner == q), as_tuple=False).flatten()  # q's, ghost here
+                s_ids += [s_idx.to(torch.int32), torch.full((1,), INV, dtype=torch.int32, device=self.dev)]
+                self.send.append((q, s0, s0 + s_idx.numel() + 1))
+                s0 += s_idx.numel() + 1
             if r_idx.numel():
-                sh4 = torch.zeros((r_idx.numel(), 4), dtype=torch.float32, device=self.dev)
-                sh4[:, :3] = shift[r_idx]
-                self.recv.append((q, r_idx.to(torch.int32).contiguous(),
-                                  torch.empty((r_idx.numel(), 4), dtype=torch.float32, device=self.dev),
-                                  sh4.contiguous()))
+                r_ids += [r_idx.to(torch.int32), torch.full((1,), INV, dtype=torch.int32, device=self.dev)]
+                sh = torch.zeros((r_idx.numel() + 1, 4), dtype=torch.float32, device=self.dev)
+                sh[:-1, :3] = shift[r_idx]
+                r_shift.append(sh)
+                self.recv.append((q, r0, r0 + r_idx.numel() + 1))
+                r0 += r_idx.numel() + 1
+        mk = lambda xs, shape, dt: (torch.cat(xs).contiguous() if xs else torch.zeros(shape, dtype=dt, device=self.dev))
+        self.send_ids = mk(s_ids, (0,), torch.int32)
+        self.recv_ids = mk(r_ids, (0,), torch.int32)
+        self.recv_shift = mk(r_shift, (0, 4), torch.float32)
+        self.send_buf = torch.zeros((s0, 4), dtype=torch.float32, device=self.dev)
+        self.recv_buf = torch.zeros((r0, 4), dtype=torch.float32, device=self.dev)
+        # the flag can ride on the halo only if every other rank is a peer in both directions
+        self.flag_on_halo = (len(self.send) == self.world - 1 and len(self.recv) == self.world - 1)
         self.repartitions += 1
 
     def _gather_global(self):
@@ -339,14 +354,16 @@ class DecomposedMd:
             self.comm.all_reduce(state, "sum")
         return state[:, :3].contiguous(), state[:, 3:].contiguous()
 
-    def _halo_exchange(self):
+    def _halo_exchange(self, flag_word: int):
         if self.world == 1:
             return
-        for q, gid, buf in self.send:
-            self.engine.pack(gid, buf)
-        self.comm.exchange([(q, buf) for q, gid, buf in self.send], [(q, buf) for q, gid, buf, sh4 in self.recv])
-        for q, gid, buf, sh4 in self.recv:
-            self.engine.unpack(gid, buf, sh4)
+        fw = flag_word if self.flag_on_halo else -1
+        if self.send_ids.numel():
+            self.engine.pack(self.send_ids, self.send_buf, fw)
+        self.comm.exchange([(q, self.send_buf[a:b]) for q, a, b in self.send],
+                           [(q, self.recv_buf[a:b]) for q, a, b in self.recv])
+        if self.recv_ids.numel():
+            self.engine.unpack(self.recv_ids, self.recv_buf, self.recv_shift, fw)
 
     # ------------------------------------------------------------------------------------------
     def step(self, dt: float, n_steps: int):
@@ -360,13 +377,13 @@ class DecomposedMd:
                 flags = eng.flag_tensor()
                 for s in range(chunk):
                     eng.chunk_integrate(0 if s == 0 else 1, dt, s)
-                    if self.world > 1:
+                    if self.world > 1 and not self.flag_on_halo:
                         # reduce through a torch-owned word: the flag array itself lives in the
                         # engine's allocation, which the NCCL process group does not know about
                         self._flag_tmp.copy_(flags[s + 1:s + 2])
                         self.comm.all_reduce(self._flag_tmp, "max")
                         flags[s + 1:s + 2].copy_(self._flag_tmp)
-                    self._halo_exchange()
+                    self._halo_exchange(s + 1)
                     eng.chunk_forces(s)
                 eng.chunk_integrate(2, dt, chunk)
                 words = eng.chunk_end(chunk + 1)

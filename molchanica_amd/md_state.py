@@ -93,8 +93,8 @@ def load_library():
     lib.mdx_stale_threshold.argtypes = [H]
     lib.mdx_stale_threshold.restype = C.c_uint32
     lib.mdx_add_steps.argtypes = [H, C.c_uint32]
-    lib.mdx_pack_positions.argtypes = [H, C.c_void_p, C.c_uint32, C.c_void_p]
-    lib.mdx_unpack_positions.argtypes = [H, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    lib.mdx_pack_positions.argtypes = [H, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int32]
+    lib.mdx_unpack_positions.argtypes = [H, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int32]
     lib.mdx_stream.argtypes = [H]
     lib.mdx_stream.restype = C.c_void_p
     _lib = lib
@@ -259,12 +259,12 @@ class MdState:
     def add_steps(self, n: int):
         _check(load_library().mdx_add_steps(self._h, int(n)))
 
-    def pack_positions(self, d_gid: int, n: int, d_out4: int):
-        _check(load_library().mdx_pack_positions(self._h, C.c_void_p(d_gid), int(n), C.c_void_p(d_out4)))
+    def pack_positions(self, d_gid: int, n: int, d_out4: int, flag_word: int = -1):
+        _check(load_library().mdx_pack_positions(self._h, C.c_void_p(d_gid), int(n), C.c_void_p(d_out4), int(flag_word)))
 
-    def unpack_positions(self, d_gid: int, n: int, d_in4: int, d_shift4: int = 0):
+    def unpack_positions(self, d_gid: int, n: int, d_in4: int, d_shift4: int = 0, flag_word: int = -1):
         _check(load_library().mdx_unpack_positions(self._h, C.c_void_p(d_gid), int(n), C.c_void_p(d_in4),
-                                                   C.c_void_p(d_shift4) if d_shift4 else None))
+                                                   C.c_void_p(d_shift4) if d_shift4 else None, int(flag_word)))
 
     def stream_ptr(self) -> int:
         return int(load_library().mdx_stream(self._h) or 0)

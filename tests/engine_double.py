@@ -113,15 +113,25 @@ class NumpyEngine:
     def add_steps(self, n):
         self.steps += n
 
-    def pack(self, gid, out4):
-        rows = self.row[gid.numpy().astype(np.int64)]
+    def pack(self, gid, out4, flag_word=-1):
+        g = gid.numpy().astype(np.int64)
+        atoms = g >= 0
+        rows = self.row[g[atoms]]
         assert (rows >= 0).all()
-        out4[:, :3] = torch.from_numpy(self.x[rows].astype(np.float32))
+        o = out4.numpy()
+        o[atoms, :3] = self.x[rows].astype(np.float32)
+        if flag_word >= 0:   # flag rows carry the bit pattern of the local flag word
+            o[~atoms, 0] = np.int32(int(self.flags[flag_word])).view(np.float32)
 
-    def unpack(self, gid, in4, shift4):
-        rows = self.row[gid.numpy().astype(np.int64)]
+    def unpack(self, gid, in4, shift4, flag_word=-1):
+        g = gid.numpy().astype(np.int64)
+        atoms = g >= 0
+        rows = self.row[g[atoms]]
         assert (rows >= 0).all()
-        self.x[rows] = (in4[:, :3] + shift4[:, :3]).numpy().astype(np.float64)
+        self.x[rows] = (in4[atoms, :3] + shift4[atoms, :3]).numpy().astype(np.float64)
+        if flag_word >= 0 and (~atoms).any():
+            got = int(in4.numpy()[~atoms, 0].copy().view(np.int32).max())
+            self.flags[flag_word] = max(int(self.flags[flag_word]), got)
 
     def energy(self):
         return {k: 0.0 for k in ("kinetic", "lj", "coulomb", "lj14", "coulomb14", "bond", "angle", "dihedral")}
