@@ -245,6 +245,7 @@ class HipEngine:
     def unpack(self, gid, in4, shift4, flag_word=-1):
         self.md.unpack_positions(gid.data_ptr(), int(gid.numel()), in4.data_ptr(), shift4.data_ptr(), flag_word)
 
+    def rebuild(self): self.md.rebuild_spatial_caches()
     def energy(self): return self.md.energy()
     def stats(self): return self.md.stats()
     def profile(self, on): self.md.profile(on)
@@ -254,12 +255,24 @@ class DecomposedMd:
     """`MdState`-like stepping of ONE box decomposed over `world` ranks (one process per GPU)."""
 
     def __init__(self, system: MdSystem, cfg: MdConfig, rank: int, world: int, device: int = 0,
-                 engine=None, halo_margin: float = 0.0, comm=None):
+                 engine=None, halo_margin: float = 4.4, comm=None):
         if not system.periodic:
             raise ValueError("spatial decomposition needs a periodic box")
         self.system, self.cfg, self.rank, self.world = system.normalise(), cfg, rank, world
         self.n_atoms = system.n_atoms
-        self.halo = max(cfg.lj_cutoff, cfg.coulomb_cutoff) + cfg.skin + halo_margin
+        # Ghosts are kept out to r_list + margin.  Atoms may then drift margin/2 from where they
+        # were at the last repartition before any rank can miss a neighbour, so that many local
+        # list rebuilds (each triggered by skin/2 of drift, on the current owned+ghost set, no host
+        # work, no ownership change) are allowed between two repartitions.
+        r_list = max(cfg.lj_cutoff, cfg.coulomb_cutoff) + cfg.skin
+        grid = process_grid(world)
+        room = min([(float(system.box_hi[d]) - float(system.box_lo[d])) * (1.0 - 1.0 / grid[d]) / 2.0 - r_list - 0.01
+                    for d in range(3) if grid[d] > 1] or [halo_margin])
+        self.halo_margin = max(0.0, min(float(halo_margin), room))
+        self.halo = r_list + self.halo_margin
+        per_rebuild = 0.5 * cfg.skin + 0.15          # drift that triggers a rebuild + one step of overshoot
+        self.local_rebuilds_allowed = int((0.5 * self.halo_margin) // per_rebuild) if world > 1 else 0
+        self.local_rebuilds = 0
         self.part = Partition(system.box_lo, system.box_hi, world, self.halo)
         self.engine = engine if engine is not None else HipEngine(system, cfg, device)
         self.comm = comm if comm is not None else DistComm(rank, world)
@@ -268,6 +281,7 @@ class DecomposedMd:
         self._flag_tmp = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.step_count = 0
         self.repartitions = 0
+        self.repartition_s = 0.0
         pos = torch.as_tensor(self.system.pos, dtype=torch.float32).to(self.dev)
         vel = torch.as_tensor(self.system.vel if self.system.vel is not None
                               else np.zeros_like(self.system.pos), dtype=torch.float32).to(self.dev)
@@ -283,7 +297,8 @@ class DecomposedMd:
 
     def describe(self) -> str:
         g = self.part.grid
-        return f"spatial {g[0]}x{g[1]}x{g[2]} bricks, ghost halo {self.halo:.1f} A, RCCL send/recv per peer"
+        return (f"spatial {g[0]}x{g[1]}x{g[2]} bricks, ghost halo {self.halo:.1f} A, RCCL send/recv per peer, "
+                f"{self.local_rebuilds_allowed} local rebuilds per repartition")
 
     def _repartition_from(self, pos_all: torch.Tensor, vel_all: torch.Tensor):
         """pos_all/vel_all: [N,3] global state, identical on every rank."""
@@ -293,6 +308,8 @@ class DecomposedMd:
         mask, shift = part.local_mask_and_shift(r, posw)
         owned = owner == r
         assert bool((mask | ~owned).all()), "an owned atom fell outside its own halo region"
+        self.owned_gid = torch.nonzero(owned, as_tuple=False).flatten()
+        self.n_owned = int(self.owned_gid.numel())
         gid_local = torch.nonzero(mask, as_tuple=False).flatten()            # ascending global ids
         ghost = (~owned[gid_local]).to(torch.uint8)
         self.own_rows = owned[gid_local]
@@ -306,20 +323,23 @@ class DecomposedMd:
         self.gid_local = gid_local.to(torch.int32).contiguous()
         self.engine.set_local_atoms(self.gid_local, ghost.contiguous(), pos4.contiguous(), vel4.contiguous(),
                                     lo, hi, part.periodic_mask())
-        self.owned_gid = torch.nonzero(owned, as_tuple=False).flatten()
-        self.n_owned = int(self.owned_gid.numel())
         # halo lists, derived identically on every rank: what rank q needs from rank p.  All peers'
         # rows live in ONE send and ONE receive buffer (one pack and one unpack launch per step); a
         # peer's segment ends with a flag row (id -1) that carries the rebuild-flag word.
         INV = -1
         s_ids, r_ids, r_shift, self.send, self.recv = [], [], [], [], []   # (peer, row0, row1)
         s0 = r0 = 0
+        own_idx = self.owned_gid                      # my atoms: candidates for every peer's halo
+        pos_own = posw[own_idx]
+        owner_loc = owner[gid_local]                  # owners of everything simulated here
+        shift_loc = shift[gid_local]
         for q in range(self.world):
             if q == r:
                 continue
-            mq, _ = part.local_mask_and_shift(q, posw)
-            s_idx = torch.nonzero(mq & owned, as_tuple=False).flatten()              # mine, ghost on q
-            r_idx = torch.nonzero(mask & (owner == q), as_tuple=False).flatten()     # q's, ghost here
+            mq, _ = part.local_mask_and_shift(q, pos_own)                # O(N/world) per peer
+            s_idx = own_idx[mq]                                          # mine, ghost on q (ascending ids)
+            sel = owner_loc == q
+            r_idx = gid_local[sel]                                       # q's, ghost here (ascending ids)
             if s_idx.numel():
                 s_ids += [s_idx.to(torch.int32), torch.full((1,), INV, dtype=torch.int32, device=self.dev)]
                 self.send.append((q, s0, s0 + s_idx.numel() + 1))
@@ -327,7 +347,7 @@ class DecomposedMd:
             if r_idx.numel():
                 r_ids += [r_idx.to(torch.int32), torch.full((1,), INV, dtype=torch.int32, device=self.dev)]
                 sh = torch.zeros((r_idx.numel() + 1, 4), dtype=torch.float32, device=self.dev)
-                sh[:-1, :3] = shift[r_idx]
+                sh[:-1, :3] = shift_loc[sel]
                 r_shift.append(sh)
                 self.recv.append((q, r0, r0 + r_idx.numel() + 1))
                 r0 += r_idx.numel() + 1
@@ -393,8 +413,18 @@ class DecomposedMd:
                         if np.uint32(words[s + 1]).view(np.float32) > 1.0e29:
                             raise FloatingPointError("non-finite or runaway coordinates during decomposed step")
                         # the drift of step s happened everywhere, its forces nowhere: repartition, finish it
-                        pos, vel = self._gather_global()
-                        self._repartition_from(pos, vel)
+                        if self.local_rebuilds < self.local_rebuilds_allowed:
+                            self.local_rebuilds += 1          # same decision on every rank: the flag is global
+                            eng.rebuild()
+                        else:
+                            import time as _t
+                            t0 = _t.perf_counter()
+                            pos, vel = self._gather_global()
+                            self._repartition_from(pos, vel)
+                            if self.dev.type == "cuda":
+                                torch.cuda.current_stream(self.dev).synchronize()
+                            self.repartition_s += _t.perf_counter() - t0
+                            self.local_rebuilds = 0
                         eng.chunk_begin()
                         eng.chunk_forces(-1)
                         eng.chunk_integrate(2, dt, 0)
@@ -429,6 +459,7 @@ class DecomposedMd:
     def stats(self) -> dict:
         st = self.engine.stats()
         st["repartitions"] = self.repartitions
+        st["repartition_ms_sum"] = 1e3 * self.repartition_s
         st["n_owned"] = self.n_owned
         st["n_ghost"] = int(self.gid_local.numel()) - self.n_owned
         return st

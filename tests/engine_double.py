@@ -107,6 +107,9 @@ class NumpyEngine:
             f[i] = (fs[:, None] * d[m]).sum(0)
         self.f = f
 
+    def rebuild(self):
+        self.list_valid = False
+
     def chunk_end(self, n):
         return self.flags[:n].numpy().astype(np.uint32).copy()
 

@@ -96,9 +96,9 @@ def test_partition_rejects_thin_boxes():
         Partition((0, 0, 0), (30, 30, 30), 2, 9.0)
 
 
-def _reference_trajectory(n_steps):
+def _reference_trajectory(n_steps, box=30.0):
     from tests.engine_double import NumpyEngine
-    s = charged_fluid()
+    s = charged_fluid(n=int(360 * (box / 30.0) ** 3), box=box)
     md = DecomposedMd(s, CFG, rank=0, world=1, engine=NumpyEngine(s, CFG))
     md.step(0.002, n_steps)
     return md.positions(), md.velocities(), md.repartitions
@@ -110,15 +110,15 @@ def _free_port():
         return so.getsockname()[1]
 
 
-def _worker(rank, world, port, n_steps, out_dir):
+def _worker(rank, world, port, n_steps, out_dir, margin, box):
     from tests.engine_double import NumpyEngine
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        s = charged_fluid()
+        s = charged_fluid(n=int(360 * (box / 30.0) ** 3), box=box)
         eng = NumpyEngine(s, CFG)
-        md = DecomposedMd(s, CFG, rank=rank, world=world, engine=eng, comm=DistComm(rank, world))
+        md = DecomposedMd(s, CFG, rank=rank, world=world, engine=eng, comm=DistComm(rank, world), halo_margin=margin)
         assert md.n_owned + md.stats()["n_ghost"] == eng.n_local
         md.step(0.002, n_steps)
         pos, vel = md.positions(), md.velocities()
@@ -128,24 +128,27 @@ def _worker(rank, world, port, n_steps, out_dir):
         assert np.array_equal(t.numpy(), pos)
         if rank == 0:
             np.savez(os.path.join(out_dir, "out.npz"), pos=pos, vel=vel, rep=md.repartitions,
-                     owned=md.n_owned, local=eng.n_local)
+                     owned=md.n_owned, local=eng.n_local, allowed=md.local_rebuilds_allowed)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_gloo_ranks_reproduce_single_domain(world, tmp_path):
-    n_steps = 23
-    ref_pos, ref_vel, ref_rep = _reference_trajectory(n_steps)
-    mp.spawn(_worker, args=(world, _free_port(), n_steps, str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("world,margin", [(2, 0.0), (4, 0.0), (2, 1.4)])
+def test_gloo_ranks_reproduce_single_domain(world, margin, tmp_path):
+    """margin 0: every stale list repartitions; margin 1.4 Å: one local rebuild between repartitions."""
+    n_steps = 23 if margin == 0.0 else 40
+    box = 30.0 if margin == 0.0 else 36.0
+    ref_pos, ref_vel, ref_rep = _reference_trajectory(n_steps, box)
+    mp.spawn(_worker, args=(world, _free_port(), n_steps, str(tmp_path), margin, box), nprocs=world, join=True)
     out = np.load(tmp_path / "out.npz")
-    L = 30.0
+    L = box
     d = out["pos"] - ref_pos
     d -= np.round(d / L) * L
     assert np.abs(d).max() < 2e-4, np.abs(d).max()          # f32 hand-over at repartition, fp64 inside
     assert np.abs(out["vel"] - ref_vel).max() < 2e-3
     assert int(out["rep"]) >= 2, "no repartition happened: the test would not cover migration"
-    assert int(out["owned"]) < 360 and int(out["local"]) > int(out["owned"])
+    assert int(out["allowed"]) == (0 if margin == 0.0 else 1)
+    assert int(out["owned"]) < ref_pos.shape[0] and int(out["local"]) > int(out["owned"])
 
 
 def test_thread_comm_matches_single_domain():
@@ -160,7 +163,8 @@ def test_thread_comm_matches_single_domain():
     def run(rank):
         try:
             s = charged_fluid()
-            md = DecomposedMd(s, CFG, rank=rank, world=world, engine=NumpyEngine(s, CFG), comm=ThreadComm(rank, shared))
+            md = DecomposedMd(s, CFG, rank=rank, world=world, engine=NumpyEngine(s, CFG), comm=ThreadComm(rank, shared),
+                              halo_margin=0.0)
             md.step(0.002, n_steps)
             res[rank] = md.positions()
         except Exception as e:   # pragma: no cover

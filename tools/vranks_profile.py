@@ -29,6 +29,6 @@ th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
 if errs: raise errs[0]
 for r in sorted(res):
     st, el = res[r]
-    print("rank %d: owned %d ghost %d tiles %d entries %d | nb %.3f ms bonded %.3f integ %.3f | repartitions %d rebuild_ms %.2f | wall %.2fs" % (
+    print("rank %d: owned %d ghost %d tiles %d entries %d | nb %.3f ms bonded %.3f integ %.3f | repartitions %d (%.2f ms each, host wall) rebuild_ms %.2f | wall %.2fs" % (
         r, st["n_owned"], st["n_ghost"], st["n_tiles"], st["n_list_entries"], st["nb_ms_sum"]/max(st["nb_launches"],1),
-        st["bonded_ms_sum"]/max(st["bonded_launches"],1), st["integ_ms_sum"]/max(st["integ_launches"],1), st["repartitions"], st["rebuild_ms_sum"], el))
+        st["bonded_ms_sum"]/max(st["bonded_launches"],1), st["integ_ms_sum"]/max(st["integ_launches"],1), st["repartitions"], st["repartition_ms_sum"]/max(st["repartitions"]-1,1), st["rebuild_ms_sum"], el))
