@@ -96,3 +96,23 @@ def test_chain_solute_across_brick_faces(reference):
     d = res[0]["pos"].astype(np.float64) - p_ref
     d -= np.round(d / L) * L
     assert math.sqrt((d ** 2).sum(1).mean()) < 2e-3
+
+
+def test_local_rebuilds_between_repartitions():
+    """A box large enough for a halo margin: stale lists are first rebuilt locally (owned + ghost
+    set unchanged, no host work), ownership migrates only every other time."""
+    from molchanica_amd.md_state import MdState
+    s = systems.water_box(18, seed=8)            # 17,496 atoms, 55.9 Å box
+    cfg = MdConfig(**CFG)
+    with MdState(s, cfg) as md:
+        md.step(0.0005, None, 45)
+        p_ref = md.positions().astype(np.float64)
+        rebuilds_ref = md.stats()["rebuild_count"]
+    res = run_ranks(s, cfg, 2, 45)
+    st = res[0]["stats"]
+    assert st["rebuild_count"] - 1 > st["repartitions"] - 1 >= 1, (st["rebuild_count"], st["repartitions"])
+    L = np.array(s.box_hi, dtype=np.float64)
+    d = res[0]["pos"].astype(np.float64) - p_ref
+    d -= np.round(d / L) * L
+    assert math.sqrt((d ** 2).sum(1).mean()) < 3e-3
+    assert rebuilds_ref >= 3
