@@ -11,7 +11,7 @@ state resident in HBM before the timed region.  For N > 1 the SAME box is spatia
 across the ranks (strong scaling) with ghost-atom halo exchange over RCCL.
 
 Prints ONE JSON line on rank 0: the contract keys plus
-  roofline     — dominant kernel (nb_tile_kernel): algorithmic bytes (32 B per atom)
+  roofline     — dominant kernel (nb_cluster_kernel): algorithmic bytes (32 B per atom)
                  x atoms per launch / mean launch duration from HIP events on the library's stream
   cpu_baseline — the CPU oracle (C, OpenMP, all host cores) on a bounded sample of the same box
 """
@@ -160,7 +160,7 @@ def main():
                    "coulomb_cutoff": cfg.coulomb_cutoff, "skin": cfg.skin, "dt_ps": args.dt,
                    "coulomb": "shifted cutoff", "parallelism": parallelism,
                    "rebuilds_in_timed_region": int(st["rebuild_count"] - rebuilds0)},
-        "roofline": {"kernel": "nb_tile_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": "nb_cluster_kernel" if args.nb_variant in (0, 2, 3, 4) else "nb_tile_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "launch_ms": nb_ms, "launches": st["nb_launches"],
                      "algorithmic_bytes_per_launch": B_ALG_NONBONDED * atoms_per_launch,
