@@ -201,6 +201,39 @@ int mdx_neighbor_list(mdx_handle* h, uint32_t* offsets /* [N+1] */, uint32_t* id
 int mdx_profile(mdx_handle* h, int enable);
 int mdx_get_stats(mdx_handle* h, mdx_stats* out);
 
+/* ---- callers either side of `step` -----------------------------------------------
+ * The reference reaches these through the same MdState: `md.minimize_energy(dev, iters, ext)`
+ * (src/ui/mol_editor.rs:375; src/mol_alignment.rs:356; sol_shrinking_box.rs:962),
+ * `md.initialize_velocities(TEMP, zero_com_drift)` (sol_shrinking_box.rs:965),
+ * `Integrator::VerletVelocity{thermostat: Some(tau)}` + `temp_target` (src/ui/panels/md.rs:296-305;
+ * CSVR per README.md:237-238), `zero_com_drift` (water_sol.rs:144), `snapshot_handlers.memory:
+ * Some(every_n)` (water_sol.rs:185-189), `md.flush_snapshot_queues()` + `md.snapshots`
+ * (src/md/mod.rs:118-122).  Their algorithms live in the absent crate; the ones implemented here
+ * are stated in DESIGN.md §8 and restated by the oracle. */
+#define MDX_THERMOSTAT_NONE      0
+#define MDX_THERMOSTAT_BERENDSEN 1 /* lambda^2 = 1 + (Dt/tau)(T0/T - 1)                              */
+#define MDX_THERMOSTAT_CSVR      2 /* Bussi-Donadio-Parrinello stochastic velocity rescaling         */
+
+/* Steepest descent with an adaptive maximum displacement (start 0.01 Å; x += h F/|F|max; accepted
+ * when the potential energy drops: h *= 1.2, else the move is undone and h *= 0.5); stops after
+ * max_iters force evaluations or when max |F| < f_tol.  Velocities are left untouched. */
+int mdx_minimize_energy(mdx_handle* h, uint32_t max_iters, const float* ext_forces_or_null, float f_tol,
+                        mdx_energies* final_or_null, uint32_t* iters_done_or_null);
+/* Maxwell-Boltzmann velocities from a counter-based generator (splitmix64 + Box-Muller, three
+ * normals per atom in caller order) so that a given seed means the same velocities everywhere. */
+int mdx_initialize_velocities(mdx_handle* h, float temperature, int zero_com_drift, uint64_t seed);
+/* Velocity rescaling applied every `every_n_steps` steps (coupling interval Dt = every_n_steps*dt). */
+int mdx_set_thermostat(mdx_handle* h, int kind, float temp_target, float tau_ps, uint32_t every_n_steps,
+                       uint64_t seed);
+int mdx_set_zero_com_drift(mdx_handle* h, int enable);   /* removed at the thermostat cadence (or every 100 steps) */
+/* In-memory snapshots every `every_n` steps: time, step, energies, positions (and velocities). */
+int      mdx_set_snapshot_cadence(mdx_handle* h, uint32_t every_n, int with_velocities);
+uint32_t mdx_snapshot_count(const mdx_handle* h);
+int      mdx_snapshot_read(mdx_handle* h, uint32_t k, double* time_ps, uint64_t* step, mdx_energies* e,
+                           float* pos /* [3N] */, float* vel_or_null /* [3N] */);
+int      mdx_flush_snapshot_queues(mdx_handle* h);       /* drop the stored snapshots (after the host cloned them) */
+double   mdx_time_ps(const mdx_handle* h);
+
 /* ---- multi-GPU spatial decomposition support (the reference is single-device,
  * src/util.rs:1086, so this is new capability, not parity) -------------------------------------
  * One handle per GPU/rank, created from the GLOBAL system (static per-atom data and topology are

@@ -202,6 +202,7 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
         if (!fixed) { h->n_mobile++; }
         if (!(fl & MDX_ATOM_GHOST)) h->total_mass += s->mass[i];
     }
+    h->h_mass = mass;
     MDX_TRY(upload_vec(&d.o_qs, qs, st)); MDX_TRY(upload_vec(&d.o_lj, lj, st));
     MDX_TRY(upload_vec(&d.o_invm, invm, st)); MDX_TRY(upload_vec(&d.o_mass, mass, st));
     MDX_TRY(upload_vec(&d.o_q, q, st)); MDX_TRY(upload_vec(&d.o_lj_raw, ljraw, st));
@@ -296,9 +297,9 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
         HIP_TRY(hipStreamSynchronize(st));
     }
     MDX_TRY(alloc_n(&d.slot_of, N)); MDX_TRY(alloc_n(&d.cell_of, N)); MDX_TRY(alloc_n(&d.sorted_orig, N));
-    MDX_TRY(alloc_n(&d.ctl, 1)); MDX_TRY(alloc_n(&d.energy, EN_COUNT + 2)); MDX_TRY(alloc_n(&d.flags_dev, 4));
+    MDX_TRY(alloc_n(&d.ctl, 1)); MDX_TRY(alloc_n(&d.energy, EN_COUNT + 8)); MDX_TRY(alloc_n(&d.flags_dev, 4));
     HIP_TRY(hipMemsetAsync(d.ctl, 0, sizeof(StepCtl), st));
-    HIP_TRY(hipMemsetAsync(d.energy, 0, sizeof(double) * (EN_COUNT + 2), st));
+    HIP_TRY(hipMemsetAsync(d.energy, 0, sizeof(double) * (EN_COUNT + 8), st));
     HIP_TRY(hipHostMalloc((void**)&h->h_ctl, sizeof(StepCtl), hipHostMallocDefault));
     HIP_TRY(hipStreamSynchronize(st));  // host vectors go out of scope
     h->in_slot_space = false; h->list_valid = false; h->forces_valid = false;
@@ -331,6 +332,13 @@ static int compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint
     MDX_TRY(mdx_launch_add_ext(h, gate, thr));
     return MDX_OK;
 }
+
+int mdx_compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint32_t thr) {
+    return compute_forces(h, energy, gate, thr);
+}
+
+static int ensure_ready(mdx_handle* h);
+int mdx_ensure_ready(mdx_handle* h) { return ensure_ready(h); }
 
 static int ensure_ready(mdx_handle* h) {
     HIP_TRY(hipSetDevice(h->device));
@@ -402,7 +410,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
     const uint32_t thr = stale_threshold_bits(h);
     uint32_t remaining = n_steps;
     while (remaining) {
-        const uint32_t chunk = std::min(remaining, h->cfg.chunk_steps);
+        const uint32_t chunk = std::min(std::min(remaining, h->cfg.chunk_steps), mdx_steps_to_next_event(h));
         HIP_TRY(hipMemsetAsync(d.ctl, 0, sizeof(StepCtl), st));
         for (uint32_t s = 0; s < chunk; ++s) {
             h->prof_tag = (int)s;
@@ -437,7 +445,9 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         }
         h->forces_valid = true;
         h->step_count += done;
+        h->time_ps += (double)dt * done;
         remaining -= done;
+        MDX_TRY(mdx_after_steps(h, dt, done));
     }
     h->stats.wall_ms_sum +=
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -446,12 +456,14 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
 
 extern "C" uint64_t mdx_step_count(const mdx_handle* h) { return h ? h->step_count : 0; }
 
-extern "C" int mdx_energy(mdx_handle* h, mdx_energies* out) {
+extern "C" int mdx_energy(mdx_handle* h, mdx_energies* out) { return mdx_energy_impl(h, out); }
+
+int mdx_energy_impl(mdx_handle* h, mdx_energies* out) {
     if (!h || !out) FAIL(MDX_EPARAM, "null argument");
     HIP_TRY(hipSetDevice(h->device));
     if (!h->list_valid) MDX_TRY(mdx_rebuild(h));
     hipStream_t st = h->stream;
-    HIP_TRY(hipMemsetAsync(h->d.energy, 0, sizeof(double) * (EN_COUNT + 2), st));
+    HIP_TRY(hipMemsetAsync(h->d.energy, 0, sizeof(double) * (EN_COUNT + 8), st));
     MDX_TRY(compute_forces(h, true, nullptr, 0));
     h->forces_valid = true;
     MDX_TRY(mdx_launch_kinetic(h));

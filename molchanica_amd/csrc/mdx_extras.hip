@@ -1,0 +1,319 @@
+// mdx_extras.hip — the callers either side of `step`: energy minimiser,
+// velocity initialisation, thermostats, centre-of-mass drift removal and in-memory snapshots.
+//
+// Reference call sites (the algorithms themselves live in the absent `dynamics` crate):
+//   md.minimize_energy(dev, iters, ext)          src/ui/mol_editor.rs:375, src/mol_alignment.rs:356,
+//                                                src/properties/sol_shrinking_box.rs:962
+//   md.initialize_velocities(TEMP, zero_com)     src/properties/sol_shrinking_box.rs:965
+//   VerletVelocity{thermostat: Some(tau)}        src/ui/panels/md.rs:296-305 (CSVR per README.md:237-238)
+//   zero_com_drift                               src/properties/water_sol.rs:144
+//   snapshot_handlers.memory / md.snapshots /
+//   md.flush_snapshot_queues()                   src/properties/water_sol.rs:185-189, src/md/mod.rs:118-122
+// All of these reuse the force path; their own kernels are streaming passes (HBM-bound).
+#include "mdx_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#define FAIL(code, msg) do { mdx_set_error(msg); return (code); } while (0)
+static inline unsigned div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+// ---- RNG (bit-for-bit the oracle's) -------------------------------------------------------------
+static double rng_u01(uint64_t* s) { return ((double)(mdx_splitmix64(s) >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+static double rng_gauss(uint64_t* s) {
+#pragma clang fp contract(off)
+    const double u1 = rng_u01(s), u2 = rng_u01(s);
+    return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+}
+static double rng_gamma_int(uint64_t* s, long ia) {   // shape ia >= 1, scale 1 (Marsaglia & Tsang)
+    const double d = (double)ia - 1.0 / 3.0, c = 1.0 / std::sqrt(9.0 * d);
+    for (;;) {
+        const double x = rng_gauss(s), t = 1.0 + c * x;
+        if (t <= 0.0) continue;
+        const double v = t * t * t, u = rng_u01(s);
+        if (std::log(u) < 0.5 * x * x + d - d * v + d * std::log(v)) return d * v;
+    }
+}
+static double rng_sum_noises(uint64_t* s, long nn) {  // sum of nn squared normals
+    if (nn <= 0) return 0.0;
+    if (nn == 1) { const double g = rng_gauss(s); return g * g; }
+    if (nn % 2 == 0) return 2.0 * rng_gamma_int(s, nn / 2);
+    const double g = rng_gauss(s);
+    return 2.0 * rng_gamma_int(s, (nn - 1) / 2) + g * g;
+}
+
+// ---- kernels --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scale_vel_kernel(uint32_t S, float4* __restrict__ vel, float lambda, float cx,
+                                                        float cy, float cz) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    float4 v = vel[s];
+    if (v.w == 0.f) return;
+    v.x = (v.x - cx) * lambda; v.y = (v.y - cy) * lambda; v.z = (v.z - cz) * lambda;
+    vel[s] = v;
+}
+
+__global__ __launch_bounds__(256) void momentum_kernel(uint32_t S, const float4* __restrict__ vel, double* out) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    double px = 0, py = 0, pz = 0, m = 0;
+    if (s < S) {
+        const float4 v = vel[s];
+        if (v.w != 0.f) {
+            m = (double)MDX_ACC_CONV / (double)v.w;
+            px = m * v.x; py = m * v.y; pz = m * v.z;
+        }
+    }
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) {
+        px += __shfl_xor(px, k); py += __shfl_xor(py, k); pz += __shfl_xor(pz, k); m += __shfl_xor(m, k);
+    }
+    if ((threadIdx.x & 63) == 0 && m != 0.0) {
+        atomicAdd(&out[0], px); atomicAdd(&out[1], py); atomicAdd(&out[2], pz); atomicAdd(&out[3], m);
+    }
+}
+
+// x += scale * F for mobile atoms; raises the stale flag like the drift pass
+__global__ __launch_bounds__(256) void min_move_kernel(uint32_t S, float4* __restrict__ posq, const float4* __restrict__ force,
+                                                       const float4* __restrict__ vel, const float4* __restrict__ ref,
+                                                       float scale, uint32_t* flag, uint32_t thr_bits) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    float d2 = 0.f;
+    if (s < S && vel[s].w != 0.f) {
+        float4 p = posq[s];
+        const float4 f = force[s], r = ref[s];
+        p.x += scale * f.x; p.y += scale * f.y; p.z += scale * f.z;
+        posq[s] = p;
+        const float dx = p.x - r.x, dy = p.y - r.y, dz = p.z - r.z;
+        d2 = dx * dx + dy * dy + dz * dz;
+        if (!(d2 < 1.0e30f)) d2 = 3.0e38f;
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, m));
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(d2) > thr_bits) atomicMax(flag, __float_as_uint(d2));
+}
+
+int mdx_launch_scale_velocities(mdx_handle* h, float lambda, const double* com) {
+    hipLaunchKernelGGL(scale_vel_kernel, dim3(div_up(h->S, 256)), dim3(256), 0, h->stream, h->S, h->d.vel, lambda,
+                       com ? (float)com[0] : 0.f, com ? (float)com[1] : 0.f, com ? (float)com[2] : 0.f);
+    HIP_TRY(hipGetLastError());
+    return MDX_OK;
+}
+
+int mdx_launch_momentum(mdx_handle* h) {
+    HIP_TRY(hipMemsetAsync(h->d.energy + EN_COUNT + 1, 0, sizeof(double) * 4, h->stream));
+    hipLaunchKernelGGL(momentum_kernel, dim3(div_up(h->S, 256)), dim3(256), 0, h->stream, h->S, h->d.vel,
+                       h->d.energy + EN_COUNT + 1);
+    HIP_TRY(hipGetLastError());
+    return MDX_OK;
+}
+
+// ---- thermostat / COM / snapshots at their cadence ----------------------------------------------------
+static double dof(const mdx_handle* h) { return std::max(1.0, 3.0 * (double)h->n_mobile - 3.0); }
+
+static int kinetic_energy(mdx_handle* h, double* ke) {
+    HIP_TRY(hipMemsetAsync(h->d.energy + EN_KIN, 0, sizeof(double), h->stream));
+    MDX_TRY(mdx_launch_kinetic(h));
+    HIP_TRY(hipMemcpyAsync(ke, h->d.energy + EN_KIN, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MDX_OK;
+}
+
+static int remove_com(mdx_handle* h) {
+    double p[4];
+    MDX_TRY(mdx_launch_momentum(h));
+    HIP_TRY(hipMemcpyAsync(p, h->d.energy + EN_COUNT + 1, sizeof(p), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (p[3] <= 0.0) return MDX_OK;
+    const double com[3] = {p[0] / p[3], p[1] / p[3], p[2] / p[3]};
+    return mdx_launch_scale_velocities(h, 1.0f, com);
+}
+
+static int apply_thermostat(mdx_handle* h, double dt_couple) {
+    double ke = 0.0;
+    MDX_TRY(kinetic_energy(h, &ke));
+    if (!(ke > 0.0) || !std::isfinite(ke)) return MDX_OK;
+    const double nf = dof(h), k0 = 0.5 * nf * MDX_KB * (double)h->tstat_temp;
+    double lambda = 1.0;
+    if (h->tstat_kind == MDX_THERMOSTAT_BERENDSEN) {
+        const double t = 2.0 * ke / (nf * MDX_KB);
+        lambda = std::sqrt(std::max(0.0, 1.0 + dt_couple / (double)h->tstat_tau * ((double)h->tstat_temp / t - 1.0)));
+    } else if (h->tstat_kind == MDX_THERMOSTAT_CSVR) {
+        // Bussi, Donadio, Parrinello, J. Chem. Phys. 126, 014101 (2007), eq. (A7)
+        const double c = h->tstat_tau > 0.f ? std::exp(-dt_couple / (double)h->tstat_tau) : 0.0;
+        const double r1 = rng_gauss(&h->rng_state);
+        const double s = rng_sum_noises(&h->rng_state, (long)nf - 1);
+        const double f = (1.0 - c) * k0 / (nf * ke);
+        const double a2 = c + f * (r1 * r1 + s) + 2.0 * r1 * std::sqrt(c * f);
+        lambda = std::sqrt(std::max(0.0, a2));
+    }
+    return mdx_launch_scale_velocities(h, (float)lambda, nullptr);
+}
+
+static int take_snapshot(mdx_handle* h) {
+    mdx_handle::Snapshot sn;
+    sn.time = h->time_ps; sn.step = h->step_count;
+    MDX_TRY(mdx_energy_impl(h, &sn.e));
+    sn.pos.resize(3 * (size_t)h->n_local);
+    MDX_TRY(mdx_download(h, MDX_POS, sn.pos.data()));
+    if (h->snap_vel) {
+        sn.vel.resize(3 * (size_t)h->n_local);
+        MDX_TRY(mdx_download(h, MDX_VEL, sn.vel.data()));
+    }
+    h->snapshots.push_back(std::move(sn));
+    return MDX_OK;
+}
+
+uint32_t mdx_steps_to_next_event(const mdx_handle* h) {
+    uint32_t n = 0xFFFFFFFFu;
+    auto upd = [&](uint32_t every) { if (every) n = std::min<uint32_t>(n, every - (uint32_t)(h->step_count % every)); };
+    if (h->tstat_kind) upd(h->tstat_every);
+    if (h->zero_com) upd(h->tstat_kind ? h->tstat_every : 100u);
+    upd(h->snap_every);
+    return n;
+}
+
+int mdx_after_steps(mdx_handle* h, float dt, uint32_t done) {
+    if (!done) return MDX_OK;
+    const uint64_t sc = h->step_count;
+    if (h->zero_com && sc % (h->tstat_kind ? h->tstat_every : 100u) == 0) MDX_TRY(remove_com(h));
+    if (h->tstat_kind && sc % h->tstat_every == 0) MDX_TRY(apply_thermostat(h, (double)dt * h->tstat_every));
+    if (h->snap_every && sc % h->snap_every == 0) MDX_TRY(take_snapshot(h));
+    return MDX_OK;
+}
+
+// ---- C ABI ------------------------------------------------------------------------------------------
+extern "C" int mdx_set_thermostat(mdx_handle* h, int kind, float temp_target, float tau_ps, uint32_t every_n_steps,
+                                  uint64_t seed) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    if (kind < 0 || kind > 2) FAIL(MDX_EPARAM, "unknown thermostat kind");
+    if (kind && (!(temp_target >= 0.f) || !(tau_ps > 0.f) || every_n_steps == 0))
+        FAIL(MDX_EPARAM, "thermostat needs temp_target >= 0, tau > 0 and a coupling interval >= 1 step");
+    h->tstat_kind = kind; h->tstat_temp = temp_target; h->tstat_tau = tau_ps;
+    h->tstat_every = every_n_steps ? every_n_steps : 10; h->rng_state = seed;
+    return MDX_OK;
+}
+
+extern "C" int mdx_set_zero_com_drift(mdx_handle* h, int enable) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    h->zero_com = enable != 0;
+    return MDX_OK;
+}
+
+extern "C" int mdx_set_snapshot_cadence(mdx_handle* h, uint32_t every_n, int with_velocities) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    h->snap_every = every_n; h->snap_vel = with_velocities != 0;
+    return MDX_OK;
+}
+
+extern "C" uint32_t mdx_snapshot_count(const mdx_handle* h) { return h ? (uint32_t)h->snapshots.size() : 0u; }
+extern "C" double mdx_time_ps(const mdx_handle* h) { return h ? h->time_ps : 0.0; }
+
+extern "C" int mdx_snapshot_read(mdx_handle* h, uint32_t k, double* time_ps, uint64_t* step, mdx_energies* e, float* pos,
+                                 float* vel) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    if (k >= h->snapshots.size()) FAIL(MDX_EPARAM, "snapshot index out of range");
+    const auto& sn = h->snapshots[k];
+    if (time_ps) *time_ps = sn.time;
+    if (step) *step = sn.step;
+    if (e) *e = sn.e;
+    if (pos) std::memcpy(pos, sn.pos.data(), sizeof(float) * sn.pos.size());
+    if (vel) {
+        if (sn.vel.empty()) FAIL(MDX_EPARAM, "snapshot was taken without velocities");
+        std::memcpy(vel, sn.vel.data(), sizeof(float) * sn.vel.size());
+    }
+    return MDX_OK;
+}
+
+extern "C" int mdx_flush_snapshot_queues(mdx_handle* h) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    h->snapshots.clear();
+    h->snapshots.shrink_to_fit();
+    return MDX_OK;
+}
+
+extern "C" int mdx_initialize_velocities(mdx_handle* h, float temperature, int zero_com_drift, uint64_t seed) {
+#pragma clang fp contract(off)   // no FMA contraction: the oracle (built -ffp-contract=off) must get the same bits
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    if (!(temperature >= 0.f) || !std::isfinite(temperature)) FAIL(MDX_EPARAM, "temperature must be >= 0");
+    if (h->n_local != h->N) FAIL(MDX_EPARAM, "initialize_velocities on a decomposed handle");
+    const uint32_t N = h->N;
+    std::vector<float> v(3 * (size_t)N);
+    std::vector<double> vd(3 * (size_t)N);
+    uint64_t st = seed;
+    double p[3] = {0, 0, 0}, mt = 0;
+    for (uint32_t i = 0; i < N; ++i) {
+        const bool fixed = (h->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST)) != 0;
+        const double sig = std::sqrt(MDX_KB * (double)temperature * 418.4 / (double)h->h_mass[i]);
+        for (int d = 0; d < 3; ++d) {
+            const double g = rng_gauss(&st);          // drawn for every atom: the stream does not depend on flags
+            vd[3 * i + d] = fixed ? 0.0 : g * sig;
+            if (!fixed) p[d] += (double)h->h_mass[i] * vd[3 * i + d];
+        }
+        if (!fixed) mt += h->h_mass[i];
+    }
+    for (uint32_t i = 0; i < N; ++i) {
+        const bool fixed = (h->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST)) != 0;
+        for (int d = 0; d < 3; ++d)
+            v[3 * i + d] = (float)((fixed || !zero_com_drift || mt <= 0) ? vd[3 * i + d] : vd[3 * i + d] - p[d] / mt);
+    }
+    return mdx_upload(h, MDX_VEL, v.data());
+}
+
+extern "C" int mdx_minimize_energy(mdx_handle* h, uint32_t max_iters, const float* ext_forces, float f_tol,
+                                   mdx_energies* final_e, uint32_t* iters_done) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    if (h->n_local != h->N) FAIL(MDX_EPARAM, "minimize_energy on a decomposed handle");
+    HIP_TRY(hipSetDevice(h->device));
+    MDX_TRY(mdx_step(h, 0.f, ext_forces, 0));      // installs / clears the external forces
+    hipStream_t st = h->stream;
+    float4* backup = nullptr;                          // accepted positions, caller order
+    HIP_TRY(hipMalloc((void**)&backup, sizeof(float4) * (size_t)h->N));
+    auto done = [&](int rc) { (void)hipFree(backup); return rc; };
+
+    mdx_energies cur{};
+    int rc = mdx_energy_impl(h, &cur);
+    if (rc != MDX_OK) return done(rc);
+    rc = mdx_gather_to_orig(h, h->d.posq, backup);
+    if (rc != MDX_OK) return done(rc);
+    double hstep = 0.01;
+    uint32_t it = 0;
+    const float half = 0.5f * h->cfg.skin;
+    uint32_t thr; { float t = std::isinf(h->r_list) ? 1.0e29f : half * half; std::memcpy(&thr, &t, 4); }
+    while (it < max_iters && cur.max_force >= (double)f_tol && cur.max_force > 0.0) {
+        const float scale = (float)(hstep / cur.max_force);
+        if (hipMemsetAsync(&h->d.ctl->disp2[1], 0, sizeof(uint32_t), st) != hipSuccess) return done(MDX_EDEVICE);
+        hipLaunchKernelGGL(min_move_kernel, dim3(div_up(h->S, 256)), dim3(256), 0, st, h->S, h->d.posq, h->d.force,
+                           h->d.vel, h->d.ref, scale, &h->d.ctl->disp2[1], thr);
+        uint32_t flag = 0;
+        if (hipMemcpyAsync(&flag, &h->d.ctl->disp2[1], sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { mdx_set_error("HIP error in minimiser"); return done(MDX_EDEVICE); }
+        if (flag > thr) h->list_valid = false;     // moved more than skin/2 since the last rebuild
+        h->forces_valid = false;
+        mdx_energies trial{};
+        rc = mdx_energy_impl(h, &trial);
+        ++it;
+        if (rc == MDX_ENAN) { trial.potential = INFINITY; rc = MDX_OK; }
+        if (rc != MDX_OK) return done(rc);
+        if (trial.potential < cur.potential) {
+            cur = trial;
+            hstep *= 1.2;
+            rc = mdx_gather_to_orig(h, h->d.posq, backup);
+            if (rc != MDX_OK) return done(rc);
+        } else {
+            hstep *= 0.5;
+            // undo: accepted positions back into the caller-order staging, velocities kept
+            rc = mdx_unsort_state(h);
+            if (rc != MDX_OK) return done(rc);
+            if (hipMemcpyAsync(h->d.pos_orig, backup, sizeof(float4) * (size_t)h->N, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return done(MDX_EDEVICE);
+            h->list_valid = false; h->forces_valid = false;
+            mdx_energies again{};
+            rc = mdx_energy_impl(h, &again);          // forces at the accepted point (the sort order changed)
+            if (rc != MDX_OK) return done(rc);
+            cur.max_force = again.max_force;
+        }
+    }
+    if (final_e) *final_e = cur;
+    if (iters_done) *iters_done = it;
+    return done(MDX_OK);
+}

@@ -134,7 +134,7 @@ struct DeviceState {
     RoleRec*  role_rec_s = nullptr;                                  // [R]
     // control / reductions
     StepCtl* ctl = nullptr;
-    double*  energy = nullptr;     // [EN_COUNT + 2]
+    double*  energy = nullptr;     // [EN_COUNT + 8]: energies, max|F|^2 bits, momentum (px,py,pz,mass)
     uint32_t* flags_dev = nullptr; // misc error flags
     unsigned long long* pair_count = nullptr;  // cluster pairs in the list (statistics)
     float*   bbox_red = nullptr;   // [6] min/max reduction (vacuum grid)
@@ -157,6 +157,7 @@ struct mdx_handle {
     uint32_t n_mobile = 0;
     double total_mass = 0.0;
     std::vector<uint8_t> flags;
+    std::vector<float> h_mass;
     // grid
     GridParams grid{};
     uint32_t ncol = 0, ncells = 0;
@@ -180,6 +181,14 @@ struct mdx_handle {
     std::vector<EvPair> ev_pending;
     std::vector<hipEvent_t> ev_pool;
     mdx_stats stats{};
+    // thermostat / COM / snapshots
+    int tstat_kind = 0; float tstat_temp = 300.f, tstat_tau = 1.f; uint32_t tstat_every = 10;
+    uint64_t rng_state = 0;
+    bool zero_com = false;
+    uint32_t snap_every = 0; bool snap_vel = false;
+    double time_ps = 0.0;
+    struct Snapshot { double time; uint64_t step; mdx_energies e; std::vector<float> pos, vel; };
+    std::vector<Snapshot> snapshots;
     DeviceState d;
     StepCtl* h_ctl = nullptr;  // pinned
 };
@@ -217,6 +226,23 @@ int mdx_exclusive_scan_u32(mdx_handle* h, const uint32_t* in, uint32_t* out, uin
 static inline int mdx_nb_variant(const mdx_handle* h) {
     const uint32_t v = h->cfg.nb_variant;
     return (v >= 1 && v <= 4) ? (int)v : MDX_NB_DEFAULT_VARIANT;   // 3/4: cluster kernel, 1/4 waves per tile forced
+}
+
+// shared between mdx_api.hip and mdx_extras.hip
+int mdx_compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint32_t thr);
+int mdx_ensure_ready(mdx_handle* h);
+int mdx_energy_impl(mdx_handle* h, mdx_energies* out);
+int mdx_after_steps(mdx_handle* h, float dt, uint32_t done);      // thermostat / COM / snapshots at their cadence
+uint32_t mdx_steps_to_next_event(const mdx_handle* h);            // chunk lengths stop at these boundaries
+int mdx_launch_scale_velocities(mdx_handle* h, float lambda, const double* com_v_or_null);
+int mdx_launch_momentum(mdx_handle* h);                           // energy[EN_COUNT+1..] <- sum m v (3 doubles) + mass
+
+// counter-based RNG shared (bit for bit) with the oracle
+static inline uint64_t mdx_splitmix64(uint64_t* s) {
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
 }
 
 // profiling helpers

@@ -81,6 +81,18 @@ def load_library():
     lib.mdx_neighbor_list.argtypes = [H, _u32p, _u32p]
     lib.mdx_profile.argtypes = [H, C.c_int]
     lib.mdx_get_stats.argtypes = [H, C.POINTER(CStats)]
+    lib.mdx_minimize_energy.argtypes = [H, C.c_uint32, _fp, C.c_float, C.POINTER(CEnergies), _u32p]
+    lib.mdx_initialize_velocities.argtypes = [H, C.c_float, C.c_int, C.c_uint64]
+    lib.mdx_set_thermostat.argtypes = [H, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_uint64]
+    lib.mdx_set_zero_com_drift.argtypes = [H, C.c_int]
+    lib.mdx_set_snapshot_cadence.argtypes = [H, C.c_uint32, C.c_int]
+    lib.mdx_snapshot_count.argtypes = [H]
+    lib.mdx_snapshot_count.restype = C.c_uint32
+    lib.mdx_snapshot_read.argtypes = [H, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
+                                      C.POINTER(CEnergies), _fp, _fp]
+    lib.mdx_flush_snapshot_queues.argtypes = [H]
+    lib.mdx_time_ps.argtypes = [H]
+    lib.mdx_time_ps.restype = C.c_double
     lib.mdx_set_local_atoms.argtypes = [H, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_float * 3, C.c_float * 3, C.c_int32]
     lib.mdx_local_state.argtypes = [H, C.c_void_p, C.c_void_p]
@@ -213,6 +225,58 @@ class MdState:
         idx = np.zeros(max(int(off[-1]), 1), dtype=np.uint32)
         _check(lib.mdx_neighbor_list(self._h, off.ctypes.data_as(_u32p), idx.ctypes.data_as(_u32p)))
         return off, idx[: int(off[-1])]
+
+    # -- callers either side of step -------------------------------------------------
+    def minimize_energy(self, max_iters: int, external_forces=None, f_tol: float = 0.0):
+        """`md.minimize_energy(dev, iters, ext)` (src/ui/mol_editor.rs:375).  -> (energies, iterations)."""
+        ext = None
+        if external_forces is not None:
+            ext = np.ascontiguousarray(external_forces, dtype=np.float32).reshape(self.n_atoms, 3)
+        e, it = CEnergies(), C.c_uint32(0)
+        _check(load_library().mdx_minimize_energy(self._h, int(max_iters), None if ext is None else ext.ctypes.data_as(_fp),
+                                                  float(f_tol), C.byref(e), C.byref(it)))
+        return e.as_dict(), int(it.value)
+
+    def initialize_velocities(self, temperature: float, zero_com_drift: bool = True, seed: int = 0):
+        """`md.initialize_velocities(TEMP, zero_com_drift)` (sol_shrinking_box.rs:965)."""
+        _check(load_library().mdx_initialize_velocities(self._h, float(temperature), int(zero_com_drift), int(seed)))
+
+    def set_thermostat(self, kind: int, temp_target: float, tau_ps: float, every_n_steps: int = 10, seed: int = 0):
+        """`Integrator::VerletVelocity{thermostat: Some(tau)}` + `temp_target`; kind 1 Berendsen, 2 CSVR."""
+        _check(load_library().mdx_set_thermostat(self._h, int(kind), float(temp_target), float(tau_ps),
+                                                 int(every_n_steps), int(seed)))
+
+    def set_zero_com_drift(self, enable: bool = True):
+        _check(load_library().mdx_set_zero_com_drift(self._h, int(enable)))
+
+    def set_snapshot_cadence(self, every_n: int, with_velocities: bool = False):
+        """`snapshot_handlers.memory: Some(every_n)` (water_sol.rs:185-189)."""
+        _check(load_library().mdx_set_snapshot_cadence(self._h, int(every_n), int(with_velocities)))
+
+    @property
+    def snapshots(self) -> list:
+        """`md.snapshots` (src/md/mod.rs:121-122): list of dicts time/step/energy_data/atom_posits[/velocities]."""
+        lib = load_library()
+        out = []
+        for k in range(int(lib.mdx_snapshot_count(self._h))):
+            t, st, e = C.c_double(), C.c_uint64(), CEnergies()
+            pos = np.empty((self.n_atoms, 3), dtype=np.float32)
+            vel = np.empty((self.n_atoms, 3), dtype=np.float32)
+            rc = lib.mdx_snapshot_read(self._h, k, C.byref(t), C.byref(st), C.byref(e), pos.ctypes.data_as(_fp),
+                                       vel.ctypes.data_as(_fp))
+            if rc != MDX_OK:   # taken without velocities
+                _check(lib.mdx_snapshot_read(self._h, k, C.byref(t), C.byref(st), C.byref(e), pos.ctypes.data_as(_fp), None))
+                vel = None
+            out.append(dict(time=float(t.value), step=int(st.value), energy_data=e.as_dict(), atom_posits=pos,
+                            atom_velocities=vel))
+        return out
+
+    def flush_snapshot_queues(self):
+        _check(load_library().mdx_flush_snapshot_queues(self._h))
+
+    @property
+    def time_ps(self) -> float:
+        return float(load_library().mdx_time_ps(self._h))
 
     # -- profiling ---------------------------------------------------------------------------
     def profile(self, enable: bool = True):

@@ -558,3 +558,162 @@ int orc_cutoff_slack(const mdx_system* s, const mdx_config* c, const float* pos,
     free_grid(&g); free(ex.off); free(ex.idx); free(xd);
     return 0;
 }
+
+/* =============================================================================================
+ * Callers either side of `step`: minimiser, velocity initialisation, thermostats.
+ * The reference reaches these through MdState (src/ui/mol_editor.rs:375, src/mol_alignment.rs:356,
+ * src/properties/sol_shrinking_box.rs:962-965, src/ui/panels/md.rs:296-305); their algorithms live
+ * in the absent crate, so the ones restated here are the build's documented choice.
+ * ============================================================================================= */
+static uint64_t splitmix64(uint64_t* s) {
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static double rng_u01(uint64_t* s) { return ((double)(splitmix64(s) >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+static double rng_gauss(uint64_t* s) {
+    double u1 = rng_u01(s), u2 = rng_u01(s);
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+static double rng_gamma_int(uint64_t* s, long ia) {
+    double d = (double)ia - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (;;) {
+        double x = rng_gauss(s), t = 1.0 + c * x;
+        if (t <= 0.0) continue;
+        double v = t * t * t, u = rng_u01(s);
+        if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) return d * v;
+    }
+}
+static double rng_sum_noises(uint64_t* s, long nn) {
+    if (nn <= 0) return 0.0;
+    if (nn == 1) { double g = rng_gauss(s); return g * g; }
+    if (nn % 2 == 0) return 2.0 * rng_gamma_int(s, nn / 2);
+    double g = rng_gauss(s);
+    return 2.0 * rng_gamma_int(s, (nn - 1) / 2) + g * g;
+}
+
+static uint32_t n_mobile(const mdx_system* s) {
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < s->n_atoms; ++i)
+        if (!(s->flags && (s->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST)))) ++n;
+    return n;
+}
+double orc_dof(const mdx_system* s) { double d = 3.0 * n_mobile(s) - 3.0; return d < 1.0 ? 1.0 : d; }
+
+/* Maxwell-Boltzmann velocities: three normals per atom in caller order from splitmix64 + Box-Muller. */
+void orc_init_velocities(const mdx_system* s, double temperature, int zero_com, uint64_t seed, double* v) {
+    uint64_t st = seed;
+    double p[3] = { 0, 0, 0 }, mt = 0;
+    for (uint32_t i = 0; i < s->n_atoms; ++i) {
+        int fixed = s->flags && (s->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST));
+        double sig = sqrt(KB_KCAL * temperature * ACC_CONV / (double)s->mass[i]);
+        for (int a = 0; a < 3; ++a) {
+            double g = rng_gauss(&st);
+            v[3 * i + a] = fixed ? 0.0 : g * sig;
+            if (!fixed) p[a] += (double)s->mass[i] * v[3 * i + a];
+        }
+        if (!fixed) mt += s->mass[i];
+    }
+    if (zero_com && mt > 0)
+        for (uint32_t i = 0; i < s->n_atoms; ++i) {
+            int fixed = s->flags && (s->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST));
+            if (!fixed) for (int a = 0; a < 3; ++a) v[3 * i + a] -= p[a] / mt;
+        }
+}
+
+/* Velocity scaling factor of one thermostat application.  kind 1: Berendsen, 2: CSVR
+ * (Bussi, Donadio, Parrinello 2007, eq. A7).  ke in kcal/mol, dt_couple in ps. */
+double orc_thermostat_lambda(int kind, double ke, double nf, double temp_target, double tau, double dt_couple,
+                             uint64_t* rng) {
+    if (!(ke > 0.0)) return 1.0;
+    double k0 = 0.5 * nf * KB_KCAL * temp_target;
+    if (kind == 1) {
+        double t = 2.0 * ke / (nf * KB_KCAL);
+        double l2 = 1.0 + dt_couple / tau * (temp_target / t - 1.0);
+        return sqrt(l2 > 0 ? l2 : 0);
+    } else if (kind == 2) {
+        double c = tau > 0 ? exp(-dt_couple / tau) : 0.0;
+        double r1 = rng_gauss(rng);
+        double sn = rng_sum_noises(rng, (long)nf - 1);
+        double f = (1.0 - c) * k0 / (nf * ke);
+        double a2 = c + f * (r1 * r1 + sn) + 2.0 * r1 * sqrt(c * f);
+        return sqrt(a2 > 0 ? a2 : 0);
+    }
+    return 1.0;
+}
+
+/* Velocity Verlet with a thermostat applied every `every` steps (and optional COM drift removal at
+ * the same cadence, before the rescale), mirroring mdx_step + mdx_after_steps. */
+int orc_step_thermo(const mdx_system* s, const mdx_config* c, double* x, double* v, double dt, uint32_t n_steps,
+                    int kind, double temp_target, double tau, uint32_t every, uint64_t seed, int zero_com,
+                    double* temps_out /* [n_steps/every] or NULL */, int use_cells) {
+    double en[E_N];
+    uint64_t rng = seed;
+    double nf = orc_dof(s);
+    uint32_t k = 0;
+    for (uint32_t st = 0; st < n_steps; st += every) {
+        uint32_t n = every < n_steps - st ? every : n_steps - st;
+        orc_step(s, c, x, v, dt, n, NULL, en, use_cells);
+        if (n < every) break;
+        if (zero_com) {
+            double p[3] = { 0, 0, 0 }, mt = 0;
+            for (uint32_t i = 0; i < s->n_atoms; ++i) {
+                if (s->flags && (s->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST))) continue;
+                for (int a = 0; a < 3; ++a) p[a] += (double)s->mass[i] * v[3 * i + a];
+                mt += s->mass[i];
+            }
+            for (uint32_t i = 0; i < s->n_atoms; ++i) {
+                if (s->flags && (s->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST))) continue;
+                for (int a = 0; a < 3; ++a) v[3 * i + a] -= p[a] / mt;
+            }
+        }
+        double ke = orc_kinetic(s, v);
+        double lam = orc_thermostat_lambda(kind, ke, nf, temp_target, tau, dt * every, &rng);
+        for (uint32_t i = 0; i < 3 * s->n_atoms; ++i) v[i] *= lam;
+        if (temps_out) temps_out[k++] = 2.0 * orc_kinetic(s, v) / (nf * KB_KCAL);
+    }
+    return 0;
+}
+
+/* Steepest descent with adaptive maximum displacement (same rule as mdx_minimize_energy).
+ * x updated in place; returns the number of trial evaluations; e_out[E_N] = energies at the result. */
+int orc_minimize(const mdx_system* s, const mdx_config* c, double* x, uint32_t max_iters, const double* ext,
+                 double f_tol, double* e_out, int use_cells) {
+    uint32_t N = s->n_atoms;
+    double* f = (double*)malloc(sizeof(double) * 3 * N);
+    double* ft = (double*)malloc(sizeof(double) * 3 * N);
+    double* xt = (double*)malloc(sizeof(double) * 3 * N);
+    double en[E_N], ent[E_N];
+    orc_forces(s, c, x, ext, f, en, use_cells);
+    double h = 0.01;
+    uint32_t it = 0;
+    for (;;) {
+        double fmax = 0.0;
+        for (uint32_t i = 0; i < N; ++i) {
+            if (s->flags && (s->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST))) continue;
+            double m = sqrt(f[3*i]*f[3*i] + f[3*i+1]*f[3*i+1] + f[3*i+2]*f[3*i+2]);
+            if (m > fmax) fmax = m;
+        }
+        if (it >= max_iters || fmax < f_tol || fmax <= 0.0) break;
+        double scale = h / fmax;
+        for (uint32_t i = 0; i < N; ++i) {
+            int fixed = s->flags && (s->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST));
+            for (int a = 0; a < 3; ++a) xt[3*i+a] = x[3*i+a] + (fixed ? 0.0 : scale * f[3*i+a]);
+        }
+        orc_forces(s, c, xt, ext, ft, ent, use_cells);
+        ++it;
+        double ep = 0, ept = 0;
+        for (int k = 0; k < E_KIN; ++k) { ep += en[k]; ept += ent[k]; }
+        if (ept < ep) {
+            memcpy(x, xt, sizeof(double) * 3 * N); memcpy(f, ft, sizeof(double) * 3 * N);
+            memcpy(en, ent, sizeof(en));
+            h *= 1.2;
+        } else {
+            h *= 0.5;
+        }
+    }
+    memcpy(e_out, en, sizeof(en));
+    free(f); free(ft); free(xt);
+    return (int)it;
+}

@@ -47,6 +47,16 @@ def lib(path: str | None = None):
         l.orc_kinetic.argtypes = [C.POINTER(CSystem), _dp]
         l.orc_kinetic.restype = C.c_double
         l.orc_wrap_f32.argtypes = [C.POINTER(CSystem), _fp, C.c_uint32]
+        l.orc_dof.argtypes = [C.POINTER(CSystem)]
+        l.orc_dof.restype = C.c_double
+        l.orc_init_velocities.argtypes = [C.POINTER(CSystem), C.c_double, C.c_int, C.c_uint64, _dp]
+        l.orc_init_velocities.restype = None
+        l.orc_thermostat_lambda.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                            C.POINTER(C.c_uint64)]
+        l.orc_thermostat_lambda.restype = C.c_double
+        l.orc_step_thermo.argtypes = [C.POINTER(CSystem), C.POINTER(CConfig), _dp, _dp, C.c_double, C.c_uint32,
+                                      C.c_int, C.c_double, C.c_double, C.c_uint32, C.c_uint64, C.c_int, _dp, C.c_int]
+        l.orc_minimize.argtypes = [C.POINTER(CSystem), C.POINTER(CConfig), _dp, C.c_uint32, _dp, C.c_double, _dp, C.c_int]
         if path is not None:
             return l
         _lib = l
@@ -135,3 +145,41 @@ def kinetic(sys: MdSystem, vel):
     cs = sys.to_c()
     v = np.ascontiguousarray(vel, dtype=np.float64).reshape(-1, 3)
     return float(l.orc_kinetic(C.byref(cs), _d(v)))
+
+
+def dof(sys: MdSystem) -> float:
+    cs = sys.to_c()
+    return float(lib().orc_dof(C.byref(cs)))
+
+
+def init_velocities(sys: MdSystem, temperature: float, zero_com: bool, seed: int):
+    cs = sys.to_c()
+    v = np.zeros((sys.n_atoms, 3), dtype=np.float64)
+    lib().orc_init_velocities(C.byref(cs), float(temperature), int(zero_com), int(seed), _d(v))
+    return v
+
+
+def step_thermo(sys: MdSystem, cfg: MdConfig, dt, n_steps, kind, temp_target, tau, every, seed, zero_com=False,
+                pos=None, vel=None, use_cells=False):
+    """-> (pos, vel, temperatures after each coupling)."""
+    cs, cc = sys.to_c(), cfg.to_c()
+    n = sys.n_atoms
+    x = np.array(sys.pos if pos is None else pos, dtype=np.float64).reshape(n, 3).copy()
+    v = np.array(sys.vel if vel is None else vel, dtype=np.float64).reshape(n, 3).copy()
+    temps = np.zeros(max(n_steps // every, 1), dtype=np.float64)
+    lib().orc_step_thermo(C.byref(cs), C.byref(cc), _d(x), _d(v), float(dt), int(n_steps), int(kind),
+                          float(temp_target), float(tau), int(every), int(seed), int(zero_com), _d(temps),
+                          int(use_cells))
+    return x, v, temps[: n_steps // every]
+
+
+def minimize(sys: MdSystem, cfg: MdConfig, max_iters, f_tol=0.0, pos=None, ext=None, use_cells=False):
+    """-> (pos, energies, trial evaluations)."""
+    cs, cc = sys.to_c(), cfg.to_c()
+    n = sys.n_atoms
+    x = np.array(sys.pos if pos is None else pos, dtype=np.float64).reshape(n, 3).copy()
+    e = None if ext is None else np.ascontiguousarray(ext, dtype=np.float64).reshape(n, 3)
+    en = np.zeros(len(ENERGY_NAMES), dtype=np.float64)
+    it = lib().orc_minimize(C.byref(cs), C.byref(cc), _d(x), int(max_iters), _d(e), float(f_tol), _d(en),
+                            int(use_cells))
+    return x, _energies(en), int(it)

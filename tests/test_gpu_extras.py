@@ -1,0 +1,132 @@
+"""GPU parity of the SURVEY §8f rows against the oracle: minimiser, velocity initialisation,
+thermostats, centre-of-mass drift removal, snapshots."""
+import math
+
+import numpy as np
+import pytest
+
+from molchanica_amd import MdConfig, systems
+
+pytestmark = pytest.mark.gpu
+NOCUT = dict(lj_cutoff=0.0, coulomb_cutoff=0.0)
+KB = 0.0019872041
+
+
+@pytest.fixture(scope="module")
+def mdx():
+    from molchanica_amd import md_state
+    assert md_state.device_count() >= 1
+    return md_state
+
+
+def test_minimize_energy_matches_oracle(mdx, orc):
+    """md.minimize_energy(dev, iters, None) (src/ui/mol_editor.rs:375)."""
+    s = systems.lig50()
+    cfg = MdConfig(**NOCUT)
+    for n in (10, 60):
+        with mdx.MdState(s, cfg) as md:
+            v0 = md.velocities()
+            e, it = md.minimize_energy(n)
+            x = md.positions().astype(np.float64)
+            assert np.array_equal(md.velocities(), v0), "the minimiser must leave velocities alone"
+        xo, eo, ito = orc.minimize(s, cfg, n)
+        assert it == ito == n
+        assert e["potential"] == pytest.approx(eo["potential"], rel=2e-4, abs=2e-3)
+        assert math.sqrt(((x - xo) ** 2).sum(1).mean()) < 2e-3
+    # periodic, with neighbour rebuilds on the way and a force tolerance stop
+    s = systems.small_solvated()
+    cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.0, coulomb_mode=1)
+    with mdx.MdState(s, cfg) as md:
+        e0 = md.energy()["potential"]
+        e, it = md.minimize_energy(40)
+        x = md.positions().astype(np.float64)
+    xo, eo, _ = orc.minimize(s, cfg, 40, use_cells=True)
+    # 40 accept/reject decisions on a truncated-LJ surface: the f32 and f64 descents may take a
+    # different branch once; both must have gained the same ~4.7e3 kcal/mol to within 0.2 %
+    assert e["potential"] < e0 and e["potential"] == pytest.approx(eo["potential"], rel=2e-3)
+    L = np.array(s.box_hi)
+    d = x - xo
+    d -= np.round(d / L) * L
+    assert math.sqrt((d ** 2).sum(1).mean()) < 2e-2
+
+
+def test_minimize_with_external_forces_and_static_atoms(mdx, orc):
+    s = systems.lig50()
+    s.flags = np.zeros(50, np.uint8)
+    s.flags[:8] = 1
+    ext = np.zeros((50, 3), np.float32)
+    ext[20:30, 1] = 15.0
+    cfg = MdConfig(**NOCUT)
+    with mdx.MdState(s, cfg) as md:
+        e, it = md.minimize_energy(25, ext)
+        x = md.positions().astype(np.float64)
+    xo, eo, _ = orc.minimize(s, cfg, 25, ext=ext)
+    assert np.array_equal(x[:8], s.pos[:8].astype(np.float64))
+    assert math.sqrt(((x - xo) ** 2).sum(1).mean()) < 2e-3
+
+
+def test_initialize_velocities_equals_oracle(mdx, orc):
+    s = systems.water_box(6, seed=3)
+    with mdx.MdState(s, MdConfig(lj_cutoff=7.0, coulomb_cutoff=7.0, skin=1.5)) as md:
+        md.initialize_velocities(310.0, True, seed=1234)
+        v = md.velocities()
+        t = md.energy()["temperature"]
+    vo = orc.init_velocities(s, 310.0, True, 1234)
+    assert np.array_equal(v, vo.astype(np.float32)), "same seed must mean the same velocities, bit for bit"
+    assert t == pytest.approx(310.0, rel=0.1)
+
+
+@pytest.mark.parametrize("kind", [1, 2])
+def test_thermostat_matches_oracle(mdx, orc, kind):
+    """VerletVelocity{thermostat: Some(tau)} with temp_target (src/ui/panels/md.rs:296-305)."""
+    s = systems.water_box(6, seed=4, jitter=0.0)
+    cfg = MdConfig(lj_cutoff=7.0, coulomb_cutoff=7.0, skin=1.5, coulomb_mode=1)
+    with mdx.MdState(s, cfg) as md:
+        md.set_thermostat(kind, 280.0, 0.05, every_n_steps=10, seed=99)
+        md.set_zero_com_drift(True)
+        temps = []
+        for _ in range(8):
+            md.step(0.0005, None, 10)
+            temps.append(md.energy()["temperature"])
+        v = md.velocities().astype(np.float64)
+    xo, vo, to = orc.step_thermo(s, cfg, 0.0005, 80, kind, 280.0, 0.05, 10, 99, zero_com=True)
+    assert np.allclose(temps, to, rtol=2e-3), (temps, to)
+    assert np.abs((v * s.mass[:, None]).sum(0)).max() < 0.5
+    assert math.sqrt(((v - vo) ** 2).sum(1).mean()) < 0.05
+
+
+def test_csvr_long_run_samples_target_temperature(mdx):
+    s = systems.water_box(8, seed=5, jitter=0.0)
+    cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, coulomb_mode=1)
+    with mdx.MdState(s, cfg) as md:
+        md.set_thermostat(2, 300.0, 0.05, every_n_steps=10, seed=5)
+        md.step(0.0005, None, 1500)
+        ts = []
+        for _ in range(40):
+            md.step(0.0005, None, 25)
+            ts.append(md.energy()["temperature"])
+    assert np.mean(ts) == pytest.approx(300.0, rel=0.05), np.mean(ts)
+
+
+def test_snapshots_cadence_and_contents(mdx):
+    """snapshot_handlers.memory: Some(n) -> md.snapshots; flush_snapshot_queues (src/md/mod.rs:118-122)."""
+    s = systems.water_box(6, seed=6)
+    cfg = MdConfig(lj_cutoff=7.0, coulomb_cutoff=7.0, skin=1.5, chunk_steps=16)
+    with mdx.MdState(s, cfg) as md, mdx.MdState(s, cfg) as md2:
+        md.set_snapshot_cadence(7, with_velocities=True)
+        md.step(0.0005, None, 30)
+        snaps = md.snapshots
+        assert [sn["step"] for sn in snaps] == [7, 14, 21, 28]
+        assert np.allclose([sn["time"] for sn in snaps], [0.0035, 0.007, 0.0105, 0.014], rtol=1e-5)
+        assert md.time_ps == pytest.approx(0.015, rel=1e-5) and md.step_count == 30
+        # the third snapshot equals the state of an independent run stopped at step 21
+        md2.step(0.0005, None, 21)
+        assert np.abs(snaps[2]["atom_posits"] - md2.positions()).max() < 1e-4
+        e2 = md2.energy()
+        assert snaps[2]["energy_data"]["potential"] == pytest.approx(e2["potential"], rel=1e-5, abs=1e-2)
+        assert snaps[2]["atom_velocities"] is not None
+        md.flush_snapshot_queues()
+        assert md.snapshots == []
+        md.set_snapshot_cadence(0)
+        md.step(0.0005, None, 10)
+        assert md.snapshots == []

@@ -1,0 +1,94 @@
+"""Pins the oracle's restatement of the SURVEY §8f rows (minimiser, velocity initialisation,
+thermostats) with closed forms and statistics.  CPU only."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from molchanica_amd import MdConfig, MdSystem, systems
+
+KB = 0.0019872041
+NOCUT = dict(lj_cutoff=0.0, coulomb_cutoff=0.0)
+
+
+def test_initialize_velocities_statistics_and_determinism(orc):
+    s = systems.water_box(8, seed=1)
+    v1 = orc.init_velocities(s, 300.0, True, 42)
+    v2 = orc.init_velocities(s, 300.0, True, 42)
+    v3 = orc.init_velocities(s, 300.0, True, 43)
+    assert np.array_equal(v1, v2) and not np.array_equal(v1, v3)
+    p = (v1 * s.mass[:, None].astype(np.float64)).sum(0)
+    assert np.abs(p).max() < 1e-9                                  # zero COM drift
+    t = 2 * orc.kinetic(s, v1) / (orc.dof(s) * KB)
+    assert t == pytest.approx(300.0, rel=0.05)
+    # per-species Maxwell-Boltzmann width
+    vh = v1[1::3]
+    assert vh.std() == pytest.approx(math.sqrt(KB * 300 * 418.4 / 1.008), rel=0.05)
+    # static atoms stay at rest but do not shift the stream of the others
+    s.flags = np.zeros(s.n_atoms, np.uint8)
+    s.flags[10] = 1
+    v4 = orc.init_velocities(s, 300.0, False, 42)
+    v5 = orc.init_velocities(systems.water_box(8, seed=1), 300.0, False, 42)
+    assert np.array_equal(v4[10], [0, 0, 0]) and np.array_equal(v4[11:], v5[11:])
+
+
+def test_berendsen_lambda_closed_form(orc):
+    lib = orc.lib()
+    rng = C.c_uint64(0)
+    nf, t0, tau, dt = 300.0, 300.0, 0.5, 0.01
+    for t in (150.0, 300.0, 600.0):
+        ke = 0.5 * nf * KB * t
+        lam = lib.orc_thermostat_lambda(1, ke, nf, t0, tau, dt, C.byref(rng))
+        assert lam == pytest.approx(math.sqrt(1 + dt / tau * (t0 / t - 1)), rel=1e-12)
+
+
+def test_csvr_relaxes_to_target_with_canonical_fluctuations(orc):
+    """<K'> = c K + (1-c) K0 for one application; the stationary distribution is the canonical
+    (gamma) one: mean K0, relative variance 2/Nf."""
+    lib = orc.lib()
+    nf, t0 = 60.0, 300.0
+    k0 = 0.5 * nf * KB * t0
+    rng = C.c_uint64(7)
+    c = math.exp(-0.1 / 0.5)
+    ks = np.array([0.5 * k0 * lib.orc_thermostat_lambda(2, 0.5 * k0, nf, t0, 0.5, 0.1, C.byref(rng)) ** 2
+                   for _ in range(20000)])
+    assert ks.mean() == pytest.approx(c * 0.5 * k0 + (1 - c) * k0, rel=0.01)
+    k, traj = k0, []
+    for _ in range(40000):
+        k *= lib.orc_thermostat_lambda(2, k, nf, t0, 0.05, 0.1, C.byref(rng)) ** 2
+        traj.append(k)
+    traj = np.array(traj[2000:])
+    assert traj.mean() == pytest.approx(k0, rel=0.02)
+    assert traj.var() / traj.mean() ** 2 == pytest.approx(2.0 / nf, rel=0.1)
+
+
+def test_thermostatted_run_reaches_target(orc):
+    s = systems.water_box(4, seed=2, jitter=0.0)
+    cfg = MdConfig(lj_cutoff=5.0, coulomb_cutoff=5.0, skin=0.5, coulomb_mode=1)
+    x, v, temps = orc.step_thermo(s, cfg, 0.0005, 400, 1, 250.0, 0.02, 10, 0, zero_com=True)
+    assert abs(temps[-5:].mean() - 250.0) < 40.0
+    p = (v * s.mass[:, None]).sum(0)
+    assert np.abs(p).max() < 1e-6
+
+
+def test_minimizer_harmonic_dimer_and_monotone_energy(orc):
+    k, r0 = 300.0, 1.4
+    s = MdSystem(pos=[[0, 0, 0], [1.9, 0, 0]], mass=[12, 12], charge=[0, 0], lj_type=[0, 0], lj_sigma=[1.0],
+                 lj_eps=[0.0], bond_idx=[[0, 1]], bond_k=[k], bond_r0=[r0], excl_offsets=[0, 1, 2],
+                 excl_idx=[1, 0]).normalise()
+    x, e, it = orc.minimize(s, MdConfig(**NOCUT), 200, f_tol=1e-3)
+    assert np.linalg.norm(x[0] - x[1]) == pytest.approx(r0, abs=1e-4) and e["bond"] < 1e-6 and it < 200
+    s = systems.lig50()
+    e0 = orc.forces(s, MdConfig(**NOCUT))[1]["potential"]
+    last = e0
+    for n in (5, 20, 60):
+        _, e, it = orc.minimize(s, MdConfig(**NOCUT), n)
+        assert e["potential"] <= last + 1e-12 and it == n
+        last = e["potential"]
+    assert last < 0.5 * e0
+    # static atoms do not move
+    s.flags = np.zeros(50, np.uint8)
+    s.flags[:10] = 1
+    x, _, _ = orc.minimize(s, MdConfig(**NOCUT), 20)
+    assert np.array_equal(x[:10], s.pos[:10].astype(np.float64))
