@@ -99,6 +99,17 @@ typedef struct mdx_system {
     int32_t periodic;              /* 1: orthorhombic PBC in box_lo..box_hi; 0: vacuum            */
     float   box_lo[3];             /* [ref: SimBox{bounds_low,bounds_high}, sol_shrinking_box.rs:600-603] */
     float   box_hi[3];
+
+    /* SURVEY §8f rank 1 — the reference's default operating point is dt = 2 fs with constrained
+     * hydrogens and 4-site OPC water  [ref: HydrogenConstraint::{Shake,Linear,Flexible},
+     * src/ui/panels/md.rs:362-371; md.water[i].{o,h0,h1,m}, sol_shrinking_box.rs:605-613]. */
+    uint32_t        n_constraints;  /* holonomic distance constraints: X-H bonds; rigid water = O-H, O-H, H-H.
+                                       Connected clusters may span at most 4 atoms / 6 constraints. */
+    const uint32_t* constraint_idx; /* [2n] */
+    const float*    constraint_len; /* [n] Å */
+    uint32_t        n_vsites;       /* massless 3-parent virtual sites (OPC / TIP4P "M"):            */
+    const uint32_t* vsite_idx;      /* [4n] site, p0, p1, p2;  r = r0 + a (r1 - r0) + b (r2 - r0)     */
+    const float*    vsite_w;        /* [2n] a, b                                                      */
 } mdx_system;
 
 /* The subset of MdConfig the force/integrate path reads  [ref: src/ui/panels/md.rs:252-261,
@@ -117,7 +128,9 @@ typedef struct mdx_config {
     float    softening_sq;     /* Å², added to r² in the Coulomb force (src/cuda/util.cu:9 uses 1e-6); default 0 */
     uint32_t chunk_steps;      /* steps enqueued between host checks of the rebuild flag (default 16) */
     uint32_t nb_variant;       /* pair kernel: 0 = library default, 1 = whole-tile, 2 = cluster-masked (A/B knob) */
-    uint32_t reserved[7];
+    float    constraint_tol;   /* relative tolerance of SHAKE/RATTLE (HydrogenConstraint::Shake{shake_tolerance}); default 1e-5 */
+    uint32_t constraint_max_iter; /* default 64 */
+    uint32_t reserved[5];
 } mdx_config;
 
 /* Superset of SnapshotEnergyData  [ref: src/ui/panels/md_viewer.rs:195-257; src/md/mod.rs:1241-1245] */

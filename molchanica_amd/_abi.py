@@ -44,6 +44,8 @@ class CSystem(C.Structure):
         ("n_pairs14", C.c_uint32), ("pairs14_idx", _u32p),
         ("n_mols", C.c_uint32), ("mol_start", _u32p),
         ("periodic", C.c_int32), ("box_lo", C.c_float * 3), ("box_hi", C.c_float * 3),
+        ("n_constraints", C.c_uint32), ("constraint_idx", _u32p), ("constraint_len", _fp),
+        ("n_vsites", C.c_uint32), ("vsite_idx", _u32p), ("vsite_w", _fp),
     ]
 
 
@@ -53,7 +55,8 @@ class CConfig(C.Structure):
         ("coulomb_k", C.c_float), ("scale14_lj", C.c_float), ("scale14_coulomb", C.c_float),
         ("coulomb_mode", C.c_int32), ("ewald_alpha", C.c_float), ("combining_rule", C.c_int32),
         ("overrides", C.c_uint32), ("softening_sq", C.c_float), ("chunk_steps", C.c_uint32),
-        ("nb_variant", C.c_uint32), ("reserved", C.c_uint32 * 7),
+        ("nb_variant", C.c_uint32), ("constraint_tol", C.c_float), ("constraint_max_iter", C.c_uint32),
+        ("reserved", C.c_uint32 * 5),
     ]
 
 
@@ -101,12 +104,15 @@ class MdConfig:
     softening_sq: float = 0.0
     chunk_steps: int = 16
     nb_variant: int = 0
+    constraint_tol: float = 1e-5
+    constraint_max_iter: int = 64
 
     def to_c(self) -> CConfig:
         c = CConfig()
         for k in ("lj_cutoff", "coulomb_cutoff", "skin", "coulomb_k", "scale14_lj",
                   "scale14_coulomb", "coulomb_mode", "ewald_alpha", "combining_rule",
-                  "overrides", "softening_sq", "chunk_steps", "nb_variant"):
+                  "overrides", "softening_sq", "chunk_steps", "nb_variant", "constraint_tol",
+                  "constraint_max_iter"):
             setattr(c, k, getattr(self, k))
         return c
 
@@ -145,6 +151,10 @@ class MdSystem:
     excl_idx: np.ndarray | None = None
     pairs14_idx: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.uint32))
     mol_start: np.ndarray | None = None
+    constraint_idx: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.uint32))
+    constraint_len: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))
+    vsite_idx: np.ndarray = field(default_factory=lambda: np.zeros((0, 4), np.uint32))
+    vsite_w: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.float32))
     periodic: bool = False
     box_lo: tuple = (0.0, 0.0, 0.0)
     box_hi: tuple = (0.0, 0.0, 0.0)
@@ -184,6 +194,10 @@ class MdSystem:
         self.pairs14_idx = _arr(self.pairs14_idx, np.uint32, (-1, 2))
         if self.mol_start is not None:
             self.mol_start = _arr(self.mol_start, np.uint32)
+        self.constraint_idx = _arr(self.constraint_idx, np.uint32, (-1, 2))
+        self.constraint_len = _arr(self.constraint_len, np.float32)
+        self.vsite_idx = _arr(self.vsite_idx, np.uint32, (-1, 4))
+        self.vsite_w = _arr(self.vsite_w, np.float32, (-1, 2))
         return self
 
     def to_c(self) -> CSystem:
@@ -218,4 +232,8 @@ class MdSystem:
         s.periodic = 1 if self.periodic else 0
         s.box_lo = (C.c_float * 3)(*[float(v) for v in self.box_lo])
         s.box_hi = (C.c_float * 3)(*[float(v) for v in self.box_hi])
+        s.n_constraints = int(self.constraint_idx.shape[0])
+        s.constraint_idx, s.constraint_len = p(self.constraint_idx, _u32p), p(self.constraint_len, _fp)
+        s.n_vsites = int(self.vsite_idx.shape[0])
+        s.vsite_idx, s.vsite_w = p(self.vsite_idx, _u32p), p(self.vsite_w, _fp)
         return s

@@ -56,6 +56,7 @@ extern "C" void mdx_config_default(mdx_config* c) {
     c->coulomb_mode = MDX_COULOMB_SHIFTED; c->combining_rule = MDX_COMBINE_LORENTZ_BERTHELOT;
     c->overrides = MDX_OVR_LONG_RANGE_RECIP_DISABLED;
     c->chunk_steps = 16;
+    c->constraint_tol = 1e-5f; c->constraint_max_iter = 64;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -139,7 +140,7 @@ static void free_device(mdx_handle* h) {
                     d.tile_col, d.scan_tmp, d.cl_lo, d.cl_hi, d.list_counts, d.entry_cnt, d.entry_off,
                     d.mchunk_cnt, d.mchunk_off, d.entries, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
                     d.role_off_s, d.role_rec_s, d.ctl, d.energy,
-                    d.flags_dev, d.bbox_red, d.pair_count};
+                    d.flags_dev, d.bbox_red, d.pair_count, d.cons_o, d.cons_s, d.vsite_o, d.vsite_s};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = DeviceState{};
 }
@@ -303,6 +304,8 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
     HIP_TRY(hipHostMalloc((void**)&h->h_ctl, sizeof(StepCtl), hipHostMallocDefault));
     HIP_TRY(hipStreamSynchronize(st));  // host vectors go out of scope
     h->in_slot_space = false; h->list_valid = false; h->forces_valid = false;
+    MDX_TRY(mdx_build_constraints(h, s));
+    h->cons_dirty = h->n_groups > 0;
     MDX_TRY(mdx_rebuild(h));
     return MDX_OK;
 }
@@ -327,8 +330,10 @@ static uint32_t stale_threshold_bits(const mdx_handle* h) {
 }
 
 static int compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint32_t thr) {
+    MDX_TRY(mdx_launch_vsite_construct(h, gate, thr));     // massless sites follow their parents
     MDX_TRY(mdx_launch_nonbonded(h, energy, gate, thr));
     MDX_TRY(mdx_launch_bonded(h, energy, gate, thr));
+    MDX_TRY(mdx_launch_vsite_spread(h, gate, thr));        // ... and hand their force back to them
     MDX_TRY(mdx_launch_add_ext(h, gate, thr));
     return MDX_OK;
 }
@@ -343,6 +348,11 @@ int mdx_ensure_ready(mdx_handle* h) { return ensure_ready(h); }
 static int ensure_ready(mdx_handle* h) {
     HIP_TRY(hipSetDevice(h->device));
     if (!h->list_valid) MDX_TRY(mdx_rebuild(h));
+    if (h->cons_dirty) {   // coordinates came from outside: project them onto the constraints once
+        MDX_TRY(mdx_launch_constrain_positions(h, 0.f, nullptr, nullptr, 0));
+        MDX_TRY(mdx_launch_constrain_velocities(h, nullptr, 0));
+        h->cons_dirty = false; h->forces_valid = false;
+    }
     if (!h->forces_valid) {
         MDX_TRY(compute_forces(h, false, nullptr, 0));
         h->forces_valid = true;
@@ -412,13 +422,22 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
     while (remaining) {
         const uint32_t chunk = std::min(std::min(remaining, h->cfg.chunk_steps), mdx_steps_to_next_event(h));
         HIP_TRY(hipMemsetAsync(d.ctl, 0, sizeof(StepCtl), st));
+        // Without constraints the closing half kick of step s and the opening one of step s+1 are
+        // one pass (mode 1).  With constraints every step is kick-drift-SHAKE-forces-kick-RATTLE,
+        // so the velocity projection sits between the two half kicks exactly as in RATTLE.
+        const bool fused = h->n_groups == 0;
         for (uint32_t s = 0; s < chunk; ++s) {
             h->prof_tag = (int)s;
-            MDX_TRY(mdx_launch_integrate(h, s == 0 ? 0 : 1, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr));
+            MDX_TRY(mdx_launch_integrate(h, (s == 0 || !fused) ? 0 : 1, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr));
+            MDX_TRY(mdx_launch_constrain_positions(h, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr));
             MDX_TRY(compute_forces(h, false, &d.ctl->disp2[s + 1], thr));
+            if (!fused) {
+                MDX_TRY(mdx_launch_integrate(h, 2, dt, &d.ctl->disp2[s + 1], nullptr, thr));
+                MDX_TRY(mdx_launch_constrain_velocities(h, &d.ctl->disp2[s + 1], thr));
+            }
         }
         h->prof_tag = (int)chunk;
-        MDX_TRY(mdx_launch_integrate(h, 2, dt, &d.ctl->disp2[chunk], nullptr, thr));
+        if (fused) MDX_TRY(mdx_launch_integrate(h, 2, dt, &d.ctl->disp2[chunk], nullptr, thr));
         h->prof_tag = -1;
         HIP_TRY(hipMemcpyAsync(h->h_ctl, d.ctl, sizeof(StepCtl), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -439,6 +458,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
                 MDX_TRY(mdx_rebuild(h));
                 MDX_TRY(compute_forces(h, false, nullptr, 0));
                 MDX_TRY(mdx_launch_integrate(h, 2, dt, nullptr, nullptr, thr));
+                MDX_TRY(mdx_launch_constrain_velocities(h, nullptr, 0));
                 done = s + 1;
                 break;
             }
@@ -462,6 +482,7 @@ int mdx_energy_impl(mdx_handle* h, mdx_energies* out) {
     if (!h || !out) FAIL(MDX_EPARAM, "null argument");
     HIP_TRY(hipSetDevice(h->device));
     if (!h->list_valid) MDX_TRY(mdx_rebuild(h));
+    if (h->cons_dirty) MDX_TRY(ensure_ready(h));
     hipStream_t st = h->stream;
     HIP_TRY(hipMemsetAsync(h->d.energy, 0, sizeof(double) * (EN_COUNT + 8), st));
     MDX_TRY(compute_forces(h, true, nullptr, 0));
@@ -478,7 +499,7 @@ int mdx_energy_impl(mdx_handle* h, mdx_energies* out) {
     out->potential_bonded = out->bond + out->angle + out->dihedral;
     out->potential_nonbonded = out->lj + out->coulomb + out->lj14 + out->coulomb14;
     out->potential = out->potential_bonded + out->potential_nonbonded;
-    const double dof = std::max(1.0, 3.0 * (double)h->n_mobile - 3.0);
+    const double dof = mdx_dof(h);
     out->temperature = 2.0 * out->kinetic / (dof * MDX_KB);
     if (h->periodic) {
         out->volume = (double)(h->box_hi[0] - h->box_lo[0]) * (h->box_hi[1] - h->box_lo[1]) *
@@ -562,6 +583,7 @@ extern "C" int mdx_upload(mdx_handle* h, int which, const float* src) {
                            hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->list_valid = false; h->forces_valid = false;
+    if (h->n_groups) h->cons_dirty = true;
     return MDX_OK;
 }
 
@@ -655,6 +677,8 @@ extern "C" int mdx_set_local_atoms(mdx_handle* h, uint32_t n_local, const uint32
                                    int32_t periodic) {
     if (!h || !d_gid || !d_ghost || !d_pos4 || !d_vel4 || !lo || !hi) FAIL(MDX_EPARAM, "null argument");
     if (n_local == 0 || n_local > h->N) FAIL(MDX_EPARAM, "n_local must be in 1..n_atoms (each atom at most once)");
+    if (h->n_groups || h->n_vsites)
+        FAIL(MDX_EPARAM, "constraints / virtual sites are not supported on a decomposed handle yet");
     HIP_TRY(hipSetDevice(h->device));
     int per[3];
     decode_periodic(periodic, per);

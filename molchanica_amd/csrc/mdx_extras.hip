@@ -108,7 +108,7 @@ int mdx_launch_momentum(mdx_handle* h) {
 }
 
 // ---- thermostat / COM / snapshots at their cadence ----------------------------------------------------
-static double dof(const mdx_handle* h) { return std::max(1.0, 3.0 * (double)h->n_mobile - 3.0); }
+static double dof(const mdx_handle* h) { return mdx_dof(h); }
 
 static int kinetic_energy(mdx_handle* h, double* ke) {
     HIP_TRY(hipMemsetAsync(h->d.energy + EN_KIN, 0, sizeof(double), h->stream));
@@ -289,6 +289,11 @@ extern "C" int mdx_minimize_energy(mdx_handle* h, uint32_t max_iters, const floa
             hipStreamSynchronize(st) != hipSuccess) { mdx_set_error("HIP error in minimiser"); return done(MDX_EDEVICE); }
         if (flag > thr) h->list_valid = false;     // moved more than skin/2 since the last rebuild
         h->forces_valid = false;
+        if (h->n_groups) {                           // keep constrained bonds at their length
+            if (!h->list_valid) { rc = mdx_rebuild(h); if (rc != MDX_OK) return done(rc); }
+            rc = mdx_launch_constrain_positions(h, 0.f, nullptr, nullptr, 0);
+            if (rc != MDX_OK) return done(rc);
+        }
         mdx_energies trial{};
         rc = mdx_energy_impl(h, &trial);
         ++it;

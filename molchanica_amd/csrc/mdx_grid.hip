@@ -846,9 +846,11 @@ int mdx_rebuild(mdx_handle* h) {
         hipLaunchKernelGGL(role_fill_kernel, dim3(div_up(S, 256)), dim3(256), 0, st, S, d.orig_of, d.gid, d.lflag,
                            d.slot_of, d.role_off_o, d.role_rec_o, d.role_off_s, d.role_rec_s, d.flags_dev);
     }
+    MDX_TRY(mdx_remap_constraints(h));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(flags, d.flags_dev, sizeof(flags), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (flags[0] & 8u) { mdx_set_error("a constrained / virtual-site atom is missing from the local atom set"); return MDX_EPARAM; }
     if (flags[0] & 3u) { mdx_set_error("exclusion table overflow while building the pair list"); return MDX_EPARAM; }
     if (flags[0] & 4u) {
         mdx_set_error("a bonded partner of an owned atom is missing from the local atom set (halo too thin)");

@@ -80,6 +80,18 @@ struct __attribute__((aligned(16))) RoleRec {
     float prm[4];    // bond: k, r0 | angle: k, theta0 | dihedral: v, phase, n | 1-4: sigma, 4 s eps, s ke qq
 };
 
+// A cluster of atoms tied by distance constraints (rigid water: 3 atoms / 3 constraints; X-H3: 4 / 3).
+struct __attribute__((aligned(16))) ConsGroup {
+    uint32_t atom[4];     // caller index (*_o) or slot (*_s); MDX_INVALID pads
+    float    len[6];
+    uint8_t  ca[6], cb[6]; // constraint k ties local atoms ca[k], cb[k]
+    uint32_t ncons, natoms;
+};
+struct __attribute__((aligned(16))) VSite {  // r_site = r0 + a (r1 - r0) + b (r2 - r0)
+    uint32_t site, p0, p1, p2;
+    float a, b, pad0, pad1;
+};
+
 struct ListCounts {  // per tile
     uint32_t n_masked;  // entries in the masked run (multiple of 8)
     uint32_t n_plain;   // entries in the plain run (multiple of 8)
@@ -132,6 +144,9 @@ struct DeviceState {
     uint32_t* role_off_o = nullptr; RoleRec* role_rec_o = nullptr;   // [N+1], [R]
     uint32_t* role_cnt_s = nullptr; uint32_t* role_off_s = nullptr;  // [S+1]
     RoleRec*  role_rec_s = nullptr;                                  // [R]
+    // constraints and virtual sites
+    ConsGroup* cons_o = nullptr; ConsGroup* cons_s = nullptr;
+    VSite* vsite_o = nullptr; VSite* vsite_s = nullptr;
     // control / reductions
     StepCtl* ctl = nullptr;
     double*  energy = nullptr;     // [EN_COUNT + 8]: energies, max|F|^2 bits, momentum (px,py,pz,mass)
@@ -154,6 +169,8 @@ struct mdx_handle {
     float box_lo[3]{}, box_hi[3]{};
     uint32_t n_bonds = 0, n_angles = 0, n_dih = 0, n_p14 = 0;
     uint32_t n_roles = 0;
+    uint32_t n_groups = 0, n_cons = 0, n_vsites = 0;   // constraint clusters / constraints / virtual sites
+    bool cons_dirty = false;                           // positions were set from outside: project them once
     uint32_t n_mobile = 0;
     double total_mass = 0.0;
     std::vector<uint8_t> flags;
@@ -228,6 +245,14 @@ static inline int mdx_nb_variant(const mdx_handle* h) {
     return (v >= 1 && v <= 4) ? (int)v : MDX_NB_DEFAULT_VARIANT;   // 3/4: cluster kernel, 1/4 waves per tile forced
 }
 
+// constraints / virtual sites (mdx_constraints.hip)
+int mdx_build_constraints(mdx_handle* h, const mdx_system* s);
+int mdx_remap_constraints(mdx_handle* h);                  // caller order -> slot order, at every rebuild
+int mdx_launch_constrain_positions(mdx_handle* h, float dt, const uint32_t* d_gate, uint32_t* d_disp_out, uint32_t thr);
+int mdx_launch_constrain_velocities(mdx_handle* h, const uint32_t* d_gate, uint32_t thr);
+int mdx_launch_vsite_construct(mdx_handle* h, const uint32_t* d_gate, uint32_t thr);
+int mdx_launch_vsite_spread(mdx_handle* h, const uint32_t* d_gate, uint32_t thr);
+
 // shared between mdx_api.hip and mdx_extras.hip
 int mdx_compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint32_t thr);
 int mdx_ensure_ready(mdx_handle* h);
@@ -236,6 +261,12 @@ int mdx_after_steps(mdx_handle* h, float dt, uint32_t done);      // thermostat 
 uint32_t mdx_steps_to_next_event(const mdx_handle* h);            // chunk lengths stop at these boundaries
 int mdx_launch_scale_velocities(mdx_handle* h, float lambda, const double* com_v_or_null);
 int mdx_launch_momentum(mdx_handle* h);                           // energy[EN_COUNT+1..] <- sum m v (3 doubles) + mass
+
+// degrees of freedom: 3 per mobile atom, minus constraints, minus the centre of mass
+static inline double mdx_dof(const mdx_handle* h) {
+    const double d = 3.0 * (double)h->n_mobile - (double)h->n_cons - 3.0;
+    return d < 1.0 ? 1.0 : d;
+}
 
 // counter-based RNG shared (bit for bit) with the oracle
 static inline uint64_t mdx_splitmix64(uint64_t* s) {

@@ -77,10 +77,63 @@ def _water_topology(first_atom: int, w: int, type_o: int, type_h: int):
     )
 
 
+# OPC 4-site water (Izadi, Anandakrishnan, Onufriev 2014), the reference's water model
+# (README.md:239; md.water[i].{o,h0,h1,m}, src/properties/sol_shrinking_box.rs:605-613)
+OPC = dict(o_sigma=3.16655, o_eps=0.21280, q_h=0.6791, q_m=-1.3582, r_oh=0.8724,
+           theta=math.radians(103.6), r_om=0.1594, m_o=15.9994, m_h=1.008)
+
+
+def opc_water_box(n_side: int = 6, seed: int = 5, spacing: float = 3.1034, temp: float = 300.0) -> MdSystem:
+    """n_side³ rigid 4-site OPC waters: three distance constraints per water, the M site is a
+    massless virtual site (flagged static) carrying the negative charge."""
+    rng = np.random.default_rng(seed)
+    w = n_side ** 3
+    box = n_side * spacing
+    g = (np.arange(n_side) + 0.5) * spacing
+    sites = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    o = OPC
+    hx, hy = o["r_oh"] * math.sin(o["theta"] / 2), o["r_oh"] * math.cos(o["theta"] / 2)
+    a = o["r_om"] / (2.0 * hy)
+    rot = _random_rotations(w, rng)
+    local = np.array([[0, 0, 0], [hx, hy, 0], [-hx, hy, 0], [0, o["r_om"], 0]], dtype=np.float64)
+    pos = (sites[:, None, :] + np.einsum("wij,kj->wki", rot, local)).reshape(-1, 3)
+    base = 4 * np.arange(w, dtype=np.int64)
+    cons = np.stack([np.stack([base, base + 1], 1), np.stack([base, base + 2], 1),
+                     np.stack([base + 1, base + 2], 1)], 1).reshape(-1, 2)
+    clen = np.tile([o["r_oh"], o["r_oh"], 2 * hx], w)
+    pairs = np.concatenate([np.stack([base + i, base + j], 1) for i in range(4) for j in range(i + 1, 4)], 0)
+    off, idx = topo.csr_from_pairs(4 * w, pairs)
+    mass = np.tile([o["m_o"], o["m_h"], o["m_h"], 0.0], w).astype(np.float32)
+    flags = np.tile([0, 0, 0, 1], w).astype(np.uint8)
+    vel = np.zeros((4 * w, 3), dtype=np.float32)
+    real = flags == 0
+    vel[real] = maxwell_boltzmann(mass[real], temp, np.random.default_rng(seed + 100))
+    return MdSystem(
+        pos=pos, mass=mass, charge=np.tile([0.0, o["q_h"], o["q_h"], o["q_m"]], w),
+        lj_type=np.tile([0, 1, 1, 1], w), lj_sigma=[o["o_sigma"], 0.0], lj_eps=[o["o_eps"], 0.0], vel=vel, flags=flags,
+        excl_offsets=off, excl_idx=idx, mol_start=base, constraint_idx=cons, constraint_len=clen,
+        vsite_idx=np.stack([base + 3, base, base + 1, base + 2], 1), vsite_w=np.tile([a, a], (w, 1)),
+        periodic=True, box_lo=(0, 0, 0), box_hi=(box, box, box), name=f"opc{4 * w}",
+    ).normalise()
+
+
 def water_box(n_side: int = 6, seed: int = 5, spacing: float = 3.1034, jitter: float = 0.05,
-              temp: float = 300.0, name: str | None = None) -> MdSystem:
+              temp: float = 300.0, name: str | None = None, rigid: bool = False) -> MdSystem:
     """n_side³ flexible TIP3P waters on a jittered lattice.  n_side=70 is S4/C5 `water1M`
-    (1,029,000 atoms, 217.24 Å cube)."""
+    (1,029,000 atoms, 217.24 Å cube).  rigid=True replaces the bond/angle terms by three distance
+    constraints per water (jitter is then applied to whole molecules)."""
+    if rigid:
+        s = water_box(n_side, seed, spacing, 0.0, temp, name, rigid=False)
+        t = TIP3P
+        base = 3 * np.arange(n_side ** 3, dtype=np.int64)
+        hh = 2 * t["r_oh"] * math.sin(t["theta"] / 2)
+        s.constraint_idx = np.stack([np.stack([base, base + 1], 1), np.stack([base, base + 2], 1),
+                                     np.stack([base + 1, base + 2], 1)], 1).reshape(-1, 2)
+        s.constraint_len = np.tile([t["r_oh"], t["r_oh"], hh], n_side ** 3)
+        s.bond_idx = np.zeros((0, 2), np.uint32); s.bond_k = np.zeros(0); s.bond_r0 = np.zeros(0)
+        s.angle_idx = np.zeros((0, 3), np.uint32); s.angle_k = np.zeros(0); s.angle_theta0 = np.zeros(0)
+        s.name = f"rigidwater{s.n_atoms}"
+        return s.normalise()
     rng = np.random.default_rng(seed)
     w = n_side ** 3
     box = n_side * spacing

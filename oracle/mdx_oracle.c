@@ -348,6 +348,87 @@ static int neighbour_cells(const grid_t* g, int cx, int cy, int cz, uint32_t* id
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* Virtual sites r = r0 + a (r1 - r0) + b (r2 - r0) (OPC / TIP4P "M"; md.water[i].m,
+ * src/properties/sol_shrinking_box.rs:605-613) and holonomic distance constraints
+ * (HydrogenConstraint::Shake, src/ui/panels/md.rs:362-371): SHAKE positions, RATTLE velocities. */
+void orc_vsite_construct(const mdx_system* s, double* x) {
+    for (uint32_t i = 0; i < s->n_vsites; ++i) {
+        uint32_t m = s->vsite_idx[4*i], p0 = s->vsite_idx[4*i+1], p1 = s->vsite_idx[4*i+2], p2 = s->vsite_idx[4*i+3];
+        double a = s->vsite_w[2*i], b = s->vsite_w[2*i+1];
+        double d1[3] = { x[3*p1]-x[3*p0], x[3*p1+1]-x[3*p0+1], x[3*p1+2]-x[3*p0+2] };
+        double d2[3] = { x[3*p2]-x[3*p0], x[3*p2+1]-x[3*p0+1], x[3*p2+2]-x[3*p0+2] };
+        min_image(s, d1); min_image(s, d2);
+        for (int k = 0; k < 3; ++k) x[3*m+k] = x[3*p0+k] + a * d1[k] + b * d2[k];
+    }
+}
+void orc_vsite_spread(const mdx_system* s, double* f) {
+    for (uint32_t i = 0; i < s->n_vsites; ++i) {
+        uint32_t m = s->vsite_idx[4*i], p0 = s->vsite_idx[4*i+1], p1 = s->vsite_idx[4*i+2], p2 = s->vsite_idx[4*i+3];
+        double a = s->vsite_w[2*i], b = s->vsite_w[2*i+1];
+        for (int k = 0; k < 3; ++k) {
+            f[3*p0+k] += (1.0 - a - b) * f[3*m+k];
+            f[3*p1+k] += a * f[3*m+k];
+            f[3*p2+k] += b * f[3*m+k];
+            f[3*m+k] = 0.0;
+        }
+    }
+}
+static double inv_mass(const mdx_system* s, uint32_t i) {
+    if (s->flags && (s->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST))) return 0.0;
+    return 1.0 / (double)s->mass[i];
+}
+/* SHAKE: x (new) corrected along the old bond vectors x_old; if v != NULL, v += dx/dt. */
+int orc_constrain_positions(const mdx_system* s, double* x, const double* x_old, double* v, double dt, double tol) {
+    uint32_t N = s->n_atoms;
+    double* x0 = (double*)malloc(sizeof(double) * 3 * N);
+    memcpy(x0, x, sizeof(double) * 3 * N);
+    int it;
+    for (it = 0; it < 1000; ++it) {
+        int done = 1;
+        for (uint32_t c = 0; c < s->n_constraints; ++c) {
+            uint32_t a = s->constraint_idx[2*c], b = s->constraint_idx[2*c+1];
+            double l2 = (double)s->constraint_len[c] * s->constraint_len[c];
+            double sv[3] = { x[3*a]-x[3*b], x[3*a+1]-x[3*b+1], x[3*a+2]-x[3*b+2] };
+            double rv[3] = { x_old[3*a]-x_old[3*b], x_old[3*a+1]-x_old[3*b+1], x_old[3*a+2]-x_old[3*b+2] };
+            min_image(s, sv); min_image(s, rv);
+            double diff = l2 - (sv[0]*sv[0] + sv[1]*sv[1] + sv[2]*sv[2]);
+            if (fabs(diff) > 2.0 * tol * l2) {
+                done = 0;
+                double ima = inv_mass(s, a), imb = inv_mass(s, b);
+                double g = diff / (2.0 * (sv[0]*rv[0] + sv[1]*rv[1] + sv[2]*rv[2]) * (ima + imb));
+                for (int k = 0; k < 3; ++k) { x[3*a+k] += g * ima * rv[k]; x[3*b+k] -= g * imb * rv[k]; }
+            }
+        }
+        if (done) break;
+    }
+    if (v && dt != 0.0) for (uint32_t i = 0; i < 3 * N; ++i) v[i] += (x[i] - x0[i]) / dt;
+    free(x0);
+    return it;
+}
+/* RATTLE velocity stage: remove the relative velocity along every constrained bond. */
+int orc_constrain_velocities(const mdx_system* s, const double* x, double* v, double tol) {
+    int it;
+    for (it = 0; it < 1000; ++it) {
+        int done = 1;
+        for (uint32_t c = 0; c < s->n_constraints; ++c) {
+            uint32_t a = s->constraint_idx[2*c], b = s->constraint_idx[2*c+1];
+            double l2 = (double)s->constraint_len[c] * s->constraint_len[c];
+            double sv[3] = { x[3*a]-x[3*b], x[3*a+1]-x[3*b+1], x[3*a+2]-x[3*b+2] };
+            min_image(s, sv);
+            double dot = sv[0]*(v[3*a]-v[3*b]) + sv[1]*(v[3*a+1]-v[3*b+1]) + sv[2]*(v[3*a+2]-v[3*b+2]);
+            if (fabs(dot) > tol * l2 * 10.0) {
+                done = 0;
+                double ima = inv_mass(s, a), imb = inv_mass(s, b);
+                double g = dot / (l2 * (ima + imb));
+                for (int k = 0; k < 3; ++k) { v[3*a+k] -= g * ima * sv[k]; v[3*b+k] += g * imb * sv[k]; }
+            }
+        }
+        if (done) break;
+    }
+    return it;
+}
+
+/* ------------------------------------------------------------------------------------------- */
 /* Forces + energies.  x: fp64 positions [3N] (NULL -> s->pos).  f: [3N] out.  en: [E_N] out.
  * use_cells: 0 = O(N^2) brute force, 1 = cell list (needs a cutoff).  Pair inclusion uses the
  * canonical fp32 r2 of the positions rounded to f32.  ext: optional external forces [3N]. */
@@ -360,6 +441,8 @@ int orc_forces(const mdx_system* s, const mdx_config* c, const double* x_in, con
         x[i] = x_in ? x_in[i] : (double)s->pos[i];
         xf[i] = (float)x[i];
     }
+    orc_vsite_construct(s, x);
+    for (uint32_t i = 0; i < 3 * N; ++i) xf[i] = (float)x[i];
     memset(f, 0, sizeof(double) * 3 * N);
     for (int k = 0; k < E_N; ++k) en[k] = 0.0;
     excl_t ex = build_excl(s);
@@ -413,6 +496,7 @@ int orc_forces(const mdx_system* s, const mdx_config* c, const double* x_in, con
     }
     en[E_LJ] = e_lj; en[E_COUL] = e_c;
     bonded_forces(s, c, x, f, en);
+    orc_vsite_spread(s, f);
     if (ext) for (uint32_t i = 0; i < 3 * N; ++i) f[i] += ext[i];
     if (use_cells) free_grid(&g);
     free(ex.off); free(ex.idx); free(x); free(xf);
@@ -435,8 +519,10 @@ int orc_step(const mdx_system* s, const mdx_config* c, double* x, double* v, dou
              uint32_t n_steps, const double* ext, double* en, int use_cells) {
     uint32_t N = s->n_atoms;
     double* f = (double*)malloc(sizeof(double) * 3 * (N ? N : 1));
+    double* xold = s->n_constraints ? (double*)malloc(sizeof(double) * 3 * (N ? N : 1)) : NULL;
     orc_forces(s, c, x, ext, f, en, use_cells);
     for (uint32_t st = 0; st < n_steps; ++st) {
+        if (xold) memcpy(xold, x, sizeof(double) * 3 * N);
         for (uint32_t i = 0; i < N; ++i) {
             int fixed = s->flags && (s->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST));
             double im = fixed ? 0.0 : ACC_CONV / (double)s->mass[i];
@@ -445,13 +531,17 @@ int orc_step(const mdx_system* s, const mdx_config* c, double* x, double* v, dou
                 x[3*i+a] += fixed ? 0.0 : dt * v[3*i+a];
             }
         }
+        if (xold) orc_constrain_positions(s, x, xold, v, dt, 1e-12);
+        orc_vsite_construct(s, x);
         orc_forces(s, c, x, ext, f, en, use_cells);
         for (uint32_t i = 0; i < N; ++i) {
             int fixed = s->flags && (s->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST));
             double im = fixed ? 0.0 : ACC_CONV / (double)s->mass[i];
             for (int a = 0; a < 3; ++a) v[3*i+a] += 0.5 * dt * f[3*i+a] * im;
         }
+        if (xold) orc_constrain_velocities(s, x, v, 1e-12);
     }
+    free(xold);
     en[E_KIN] = orc_kinetic(s, v);
     free(f);
     return 0;
@@ -599,7 +689,7 @@ static uint32_t n_mobile(const mdx_system* s) {
         if (!(s->flags && (s->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST)))) ++n;
     return n;
 }
-double orc_dof(const mdx_system* s) { double d = 3.0 * n_mobile(s) - 3.0; return d < 1.0 ? 1.0 : d; }
+double orc_dof(const mdx_system* s) { double d = 3.0 * n_mobile(s) - (double)s->n_constraints - 3.0; return d < 1.0 ? 1.0 : d; }
 
 /* Maxwell-Boltzmann velocities: three normals per atom in caller order from splitmix64 + Box-Muller. */
 void orc_init_velocities(const mdx_system* s, double temperature, int zero_com, uint64_t seed, double* v) {
@@ -701,6 +791,13 @@ int orc_minimize(const mdx_system* s, const mdx_config* c, double* x, uint32_t m
             int fixed = s->flags && (s->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST));
             for (int a = 0; a < 3; ++a) xt[3*i+a] = x[3*i+a] + (fixed ? 0.0 : scale * f[3*i+a]);
         }
+        if (s->n_constraints) {   /* keep constrained bonds at their length (projection along the moved bonds) */
+            double* tmp = (double*)malloc(sizeof(double) * 3 * N);
+            memcpy(tmp, xt, sizeof(double) * 3 * N);
+            orc_constrain_positions(s, xt, tmp, NULL, 0.0, 1e-12);
+            free(tmp);
+        }
+        orc_vsite_construct(s, xt);
         orc_forces(s, c, xt, ext, ft, ent, use_cells);
         ++it;
         double ep = 0, ept = 0;

@@ -47,6 +47,10 @@ def lib(path: str | None = None):
         l.orc_kinetic.argtypes = [C.POINTER(CSystem), _dp]
         l.orc_kinetic.restype = C.c_double
         l.orc_wrap_f32.argtypes = [C.POINTER(CSystem), _fp, C.c_uint32]
+        l.orc_constrain_positions.argtypes = [C.POINTER(CSystem), _dp, _dp, _dp, C.c_double, C.c_double]
+        l.orc_constrain_velocities.argtypes = [C.POINTER(CSystem), _dp, _dp, C.c_double]
+        l.orc_vsite_construct.argtypes = [C.POINTER(CSystem), _dp]
+        l.orc_vsite_construct.restype = None
         l.orc_dof.argtypes = [C.POINTER(CSystem)]
         l.orc_dof.restype = C.c_double
         l.orc_init_velocities.argtypes = [C.POINTER(CSystem), C.c_double, C.c_int, C.c_uint64, _dp]
@@ -183,3 +187,27 @@ def minimize(sys: MdSystem, cfg: MdConfig, max_iters, f_tol=0.0, pos=None, ext=N
     it = lib().orc_minimize(C.byref(cs), C.byref(cc), _d(x), int(max_iters), _d(e), float(f_tol), _d(en),
                             int(use_cells))
     return x, _energies(en), int(it)
+
+
+def constrain_positions(sys: MdSystem, x_new, x_old, vel=None, dt=0.0, tol=1e-12):
+    cs = sys.to_c()
+    x = np.array(x_new, dtype=np.float64).reshape(-1, 3).copy()
+    xo = np.ascontiguousarray(x_old, dtype=np.float64).reshape(-1, 3)
+    v = None if vel is None else np.array(vel, dtype=np.float64).reshape(-1, 3).copy()
+    it = lib().orc_constrain_positions(C.byref(cs), _d(x), _d(xo), _d(v), float(dt), float(tol))
+    return x, v, int(it)
+
+
+def constrain_velocities(sys: MdSystem, x, vel, tol=1e-12):
+    cs = sys.to_c()
+    xx = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, 3)
+    v = np.array(vel, dtype=np.float64).reshape(-1, 3).copy()
+    lib().orc_constrain_velocities(C.byref(cs), _d(xx), _d(v), float(tol))
+    return v
+
+
+def vsite_construct(sys: MdSystem, x):
+    cs = sys.to_c()
+    xx = np.array(x, dtype=np.float64).reshape(-1, 3).copy()
+    lib().orc_vsite_construct(C.byref(cs), _d(xx))
+    return xx

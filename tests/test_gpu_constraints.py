@@ -1,0 +1,98 @@
+"""GPU parity of constraints (SHAKE/RATTLE) and virtual sites against the oracle — the reference's
+default operating point: dt = 2 fs, constrained hydrogens, 4-site OPC water
+(/root/reference src/prefs/mod.rs:203; src/ui/panels/md.rs:362-371; sol_shrinking_box.rs:605-613)."""
+import math
+
+import numpy as np
+import pytest
+
+from molchanica_amd import MdConfig, systems
+
+pytestmark = pytest.mark.gpu
+KB = 0.0019872041
+
+
+@pytest.fixture(scope="module")
+def mdx():
+    from molchanica_amd import md_state
+    assert md_state.device_count() >= 1
+    return md_state
+
+
+def bond_errors(s, x):
+    b = s.constraint_idx.astype(int)
+    d = x[b[:, 0]] - x[b[:, 1]]
+    L = np.array(s.box_hi, dtype=np.float64)
+    d -= np.round(d / L) * L
+    return np.abs(np.linalg.norm(d, axis=1) - s.constraint_len) / s.constraint_len
+
+
+@pytest.mark.parametrize("model", ["tip3p_rigid", "opc"])
+def test_rigid_water_parity_at_2fs(mdx, orc, model):
+    s = systems.water_box(8, seed=3, rigid=True) if model == "tip3p_rigid" else systems.opc_water_box(8, seed=3)
+    cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, coulomb_mode=1)
+    with mdx.MdState(s, cfg) as md:
+        f = md.forces().astype(np.float64)
+        e = md.energy()
+        pos = md.positions()
+        fo, eo = orc.forces(s, cfg, pos=pos.astype(np.float64))
+        err = np.linalg.norm(f - fo, axis=1)
+        tol = 1e-4 * np.maximum(np.linalg.norm(fo, axis=1), 1.0) + orc.cutoff_slack(s, cfg, pos=pos)
+        assert (err <= tol).all(), float((err / tol).max())
+        if model == "opc":
+            assert np.abs(f[3::4]).max() == 0.0, "a virtual site must not keep a force"
+        for k in ("lj", "coulomb"):
+            assert e[k] == pytest.approx(eo[k], rel=5e-6, abs=2e-2)   # a few cutoff-boundary pairs x 1e-3 kcal/mol: LJ is truncated, not shifted
+        dof = 3 * int((s.mass > 0).sum()) - s.constraint_idx.shape[0] - 3
+        assert e["temperature"] == pytest.approx(2 * e["kinetic"] / (dof * KB), rel=1e-9)
+        x0, v0 = md.positions().astype(np.float64), md.velocities().astype(np.float64)
+        b = s.constraint_idx.astype(int)
+        assert bond_errors(s, x0).max() < 3e-5
+        md.step(0.002, None, 50)                       # the reference's default dt (src/prefs/mod.rs:203)
+        x, v = md.positions().astype(np.float64), md.velocities().astype(np.float64)
+        assert bond_errors(s, x).max() < 3e-5, "constraints drifted"
+        d = x[b[:, 0]] - x[b[:, 1]]
+        d -= np.round(d / s.box_hi[0]) * s.box_hi[0]
+        assert np.abs((d * (v[b[:, 0]] - v[b[:, 1]])).sum(1)).max() < 5e-3, "velocity along a constrained bond"
+        rebuilds = md.stats()["rebuild_count"]
+    xo, vo, _ = orc.step(s, cfg, 0.002, 50, pos=x0, vel=v0, use_cells=True)
+    L = np.array(s.box_hi)
+    dd = x - xo
+    dd -= np.round(dd / L) * L
+    rms = math.sqrt((dd ** 2).sum(1).mean())
+    assert rms < 2e-3, f"constrained trajectory deviates: {rms:.2e} Å"
+    assert rebuilds >= 2
+
+
+def test_xh_constraints_on_a_solvated_chain(mdx, orc):
+    """HydrogenConstraint::Shake on the solute's X-H bonds; input geometry is off the constraint
+    lengths by ~2 %, so creation has to project it first."""
+    s = systems.small_solvated()
+    h_side = np.nonzero(s.lj_type == 3)[0]
+    is_h = np.zeros(s.n_atoms, bool)
+    is_h[h_side] = True
+    sel = is_h[s.bond_idx[:, 0]] | is_h[s.bond_idx[:, 1]]
+    s.constraint_idx = s.bond_idx[sel].copy()
+    s.constraint_len = s.bond_r0[sel].copy()
+    assert sel.sum() > 20
+    cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, coulomb_mode=1)
+    with mdx.MdState(s, cfg) as md:
+        md.forces()
+        x0, v0 = md.positions().astype(np.float64), md.velocities().astype(np.float64)
+        assert bond_errors(s, x0).max() < 3e-5
+        md.step(0.001, None, 40)
+        x = md.positions().astype(np.float64)
+        assert bond_errors(s, x).max() < 3e-5
+    xo, vo, _ = orc.step(s, cfg, 0.001, 40, pos=x0, vel=v0, use_cells=True)
+    L = np.array(s.box_hi)
+    d = x - xo
+    d -= np.round(d / L) * L
+    assert math.sqrt((d ** 2).sum(1).mean()) < 2e-3
+
+
+def test_oversized_constraint_cluster_is_rejected(mdx):
+    s = systems.lig50()
+    s.constraint_idx = s.bond_idx[:12].copy()       # a connected chain of > 4 atoms
+    s.constraint_len = s.bond_r0[:12].copy()
+    with pytest.raises(mdx.ParamError, match="cluster"):
+        mdx.MdState(s, MdConfig(lj_cutoff=0, coulomb_cutoff=0))

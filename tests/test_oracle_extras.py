@@ -92,3 +92,58 @@ def test_minimizer_harmonic_dimer_and_monotone_energy(orc):
     s.flags[:10] = 1
     x, _, _ = orc.minimize(s, MdConfig(**NOCUT), 20)
     assert np.array_equal(x[:10], s.pos[:10].astype(np.float64))
+
+
+# ---- constraints and virtual sites -------------------------------------------------
+def test_shake_rattle_rigid_water_conserves_energy_at_2fs(orc):
+    s = systems.water_box(4, seed=3, rigid=True)
+    cfg = MdConfig(lj_cutoff=5.5, coulomb_cutoff=5.5, skin=0.5, coulomb_mode=1)
+    x0 = s.pos.astype(np.float64)
+    v0 = orc.constrain_velocities(s, x0, s.vel.astype(np.float64))
+    b = s.constraint_idx.astype(int)
+    d = x0[b[:, 0]] - x0[b[:, 1]]
+    assert np.abs((d * (v0[b[:, 0]] - v0[b[:, 1]])).sum(1)).max() < 1e-9      # no velocity along a bond
+    e0 = orc.forces(s, cfg, pos=x0)[1]["potential"] + orc.kinetic(s, v0)
+    x, v, e = orc.step(s, cfg, 0.002, 150, pos=x0, vel=v0)
+    L = s.box_hi[0]
+    d = x[b[:, 0]] - x[b[:, 1]]
+    d -= np.round(d / L) * L
+    assert np.abs(np.linalg.norm(d, axis=1) - s.constraint_len).max() < 1e-9
+    assert abs(e["potential"] + e["kinetic"] - e0) / s.n_atoms < 0.02        # 0.3 ps at 2 fs
+    assert orc.dof(s) == 3 * s.n_atoms - s.constraint_idx.shape[0] - 3
+
+
+def test_virtual_site_geometry_and_force_spreading(orc):
+    s = systems.opc_water_box(3, seed=2)
+    x = orc.vsite_construct(s, s.pos.astype(np.float64) + 0.0)
+    o, h1, h2, m = x[0::4], x[1::4], x[2::4], x[3::4]
+    assert np.allclose(np.linalg.norm(m - o, axis=1), 0.1594, atol=2e-4)        # |OM| of OPC
+    bis = (h1 - o) + (h2 - o)
+    assert np.allclose(np.cross(bis, m - o), 0.0, atol=1e-6)                    # on the bisector
+    cfg = MdConfig(lj_cutoff=4.0, coulomb_cutoff=4.0, skin=0.5, coulomb_mode=1)
+    f, e = orc.forces(s, cfg)
+    assert np.abs(f[3::4]).max() == 0.0                                         # massless site keeps no force
+    assert np.abs(f.sum(0)).max() < 1e-9                                        # spreading conserves the total
+    # F = -dE/dx through the chain rule of the site construction
+    x0 = s.pos.astype(np.float64)
+    h = 1e-5
+    for i in (0, 1, 6):
+        for a in range(3):
+            xp, xm = x0.copy(), x0.copy()
+            xp[i, a] += h
+            xm[i, a] -= h
+            fd = -(orc.forces(s, cfg, pos=xp)[1]["potential"] - orc.forces(s, cfg, pos=xm)[1]["potential"]) / (2 * h)
+            assert fd == pytest.approx(f[i, a], rel=2e-5, abs=2e-5)
+
+
+def test_shake_projects_along_old_bonds_and_respects_static_atoms(orc):
+    s = MdSystem(pos=[[0, 0, 0], [1.2, 0, 0]], mass=[12, 1], charge=[0, 0], lj_type=[0, 0], lj_sigma=[1.0], lj_eps=[0.0],
+                 constraint_idx=[[0, 1]], constraint_len=[1.0], excl_offsets=[0, 1, 2], excl_idx=[1, 0]).normalise()
+    x_old = s.pos.astype(np.float64)
+    x, _, _ = orc.constrain_positions(s, x_old, x_old)
+    assert np.linalg.norm(x[0] - x[1]) == pytest.approx(1.0, abs=1e-10)
+    assert (x * s.mass[:, None]).sum(0) == pytest.approx((x_old * s.mass[:, None]).sum(0))   # COM fixed
+    assert abs(x[0, 0]) == pytest.approx(0.2 / 13, rel=1e-6)                                   # mass weighting
+    s.flags = np.array([1, 0], np.uint8)
+    x, _, _ = orc.constrain_positions(s, x_old, x_old)
+    assert np.array_equal(x[0], [0, 0, 0]) and x[1, 0] == pytest.approx(1.0, abs=1e-10)
