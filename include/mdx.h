@@ -46,7 +46,9 @@ extern "C" {
 /* ---- Coulomb treatment inside the cutoff ----------------------------------------------------- */
 #define MDX_COULOMB_SHIFTED   0 /* E = k q q (1/r - 1/rc), F = k q q / r^2          (default)     */
 #define MDX_COULOMB_REACTION  1 /* reaction field eps_rf = inf: F = k q q (1/r^2 - r/rc^3)        */
-#define MDX_COULOMB_EWALD     2 /* SPME real-space part: E = k q q erfc(a r)/r                    */
+#define MDX_COULOMB_EWALD     2 /* Ewald: real space E = k q q erfc(a r)/r in the pair loop, plus the SPME
+                                   reciprocal sum (hipFFT) unless MDX_OVR_LONG_RANGE_RECIP_DISABLED is set
+                                   [ref: README.md:240; src/util.rs:1094-1100; src/mol_editor/mod.rs:873]  */
 
 #define MDX_COMBINE_LORENTZ_BERTHELOT 0 /* sigma_ij=(si+sj)/2, eps_ij=sqrt(ei ej)   (default)     */
 #define MDX_COMBINE_GEOMETRIC         1 /* sigma_ij=sqrt(si sj), eps_ij=sqrt(ei ej)               */
@@ -130,7 +132,10 @@ typedef struct mdx_config {
     uint32_t nb_variant;       /* pair kernel: 0 = library default, 1 = whole-tile, 2 = cluster-masked (A/B knob) */
     float    constraint_tol;   /* relative tolerance of SHAKE/RATTLE (HydrogenConstraint::Shake{shake_tolerance}); default 1e-5 */
     uint32_t constraint_max_iter; /* default 64 */
-    uint32_t reserved[5];
+    uint32_t pme_grid[3];      /* SPME mesh (MDX_COULOMB_EWALD without MDX_OVR_LONG_RANGE_RECIP_DISABLED);
+                                  0 = smallest 2^a 3^b 5^c size with spacing <= 1 Å */
+    uint32_t pme_order;        /* B-spline order: 4 (default) */
+    uint32_t reserved[1];
 } mdx_config;
 
 /* Superset of SnapshotEnergyData  [ref: src/ui/panels/md_viewer.rs:195-257; src/md/mod.rs:1241-1245] */
@@ -146,6 +151,8 @@ typedef struct mdx_energies {
     double density;             /* amu/Å³ (0 in vacuum) */
     double virial;              /* sum r_ij·f_ij over non-bonded pairs (reserved, 0 for now) */
     double max_force;           /* max |F| kcal/mol/Å — blow-up detector (sol_shrinking_box.rs:776-789) */
+    double coulomb_recip;       /* SPME reciprocal sum + self + excluded-pair + background terms (in
+                                   potential_nonbonded); `coulomb` is the real-space part */
 } mdx_energies;
 
 /* Counters and timers (md.computation_time() analogue, src/md/mod.rs:740-743). */

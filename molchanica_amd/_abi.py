@@ -56,7 +56,7 @@ class CConfig(C.Structure):
         ("coulomb_mode", C.c_int32), ("ewald_alpha", C.c_float), ("combining_rule", C.c_int32),
         ("overrides", C.c_uint32), ("softening_sq", C.c_float), ("chunk_steps", C.c_uint32),
         ("nb_variant", C.c_uint32), ("constraint_tol", C.c_float), ("constraint_max_iter", C.c_uint32),
-        ("reserved", C.c_uint32 * 5),
+        ("pme_grid", C.c_uint32 * 3), ("pme_order", C.c_uint32), ("reserved", C.c_uint32 * 1),
     ]
 
 
@@ -64,7 +64,7 @@ class CEnergies(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "kinetic", "potential", "potential_nonbonded", "potential_bonded",
         "lj", "coulomb", "lj14", "coulomb14", "bond", "angle", "dihedral",
-        "temperature", "volume", "density", "virial", "max_force")]
+        "temperature", "volume", "density", "virial", "max_force", "coulomb_recip")]
 
     def as_dict(self) -> dict:
         return {n: float(getattr(self, n)) for n, _ in self._fields_}
@@ -106,6 +106,8 @@ class MdConfig:
     nb_variant: int = 0
     constraint_tol: float = 1e-5
     constraint_max_iter: int = 64
+    pme_grid: tuple = (0, 0, 0)
+    pme_order: int = 4
 
     def to_c(self) -> CConfig:
         c = CConfig()
@@ -114,6 +116,8 @@ class MdConfig:
                   "overrides", "softening_sq", "chunk_steps", "nb_variant", "constraint_tol",
                   "constraint_max_iter"):
             setattr(c, k, getattr(self, k))
+        c.pme_grid = (C.c_uint32 * 3)(*[int(v) for v in self.pme_grid])
+        c.pme_order = int(self.pme_order)
         return c
 
 

@@ -140,7 +140,8 @@ static void free_device(mdx_handle* h) {
                     d.tile_col, d.scan_tmp, d.cl_lo, d.cl_hi, d.list_counts, d.entry_cnt, d.entry_off,
                     d.mchunk_cnt, d.mchunk_off, d.entries, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
                     d.role_off_s, d.role_rec_s, d.ctl, d.energy,
-                    d.flags_dev, d.bbox_red, d.pair_count, d.cons_o, d.cons_s, d.vsite_o, d.vsite_s};
+                    d.flags_dev, d.bbox_red, d.pair_count, d.cons_o, d.cons_s, d.vsite_o, d.vsite_s, d.pme_q, d.pme_f,
+                    d.pme_theta};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = DeviceState{};
 }
@@ -151,6 +152,7 @@ extern "C" void mdx_destroy(mdx_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto& e : h->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : h->ev_pool) (void)hipEventDestroy(e);
+    mdx_pme_destroy(h);
     free_device(h);
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -204,13 +206,17 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
         if (!(fl & MDX_ATOM_GHOST)) h->total_mass += s->mass[i];
     }
     h->h_mass = mass;
+    h->total_charge = 0.0; h->sum_q2 = 0.0;
+    for (uint32_t i = 0; i < N; ++i) { h->total_charge += q[i]; h->sum_q2 += (double)q[i] * q[i]; }
+    const bool pme_on = c->coulomb_mode == MDX_COULOMB_EWALD && !(c->overrides & MDX_OVR_LONG_RANGE_RECIP_DISABLED) &&
+                        !coul_off;
     MDX_TRY(upload_vec(&d.o_qs, qs, st)); MDX_TRY(upload_vec(&d.o_lj, lj, st));
     MDX_TRY(upload_vec(&d.o_invm, invm, st)); MDX_TRY(upload_vec(&d.o_mass, mass, st));
     MDX_TRY(upload_vec(&d.o_q, q, st)); MDX_TRY(upload_vec(&d.o_lj_raw, ljraw, st));
 
     // ---- merged exclusion CSR (1-2, 1-3 and 1-4), symmetric, sorted, unique ----
+    std::vector<std::vector<uint32_t>> ex(N);
     {
-        std::vector<std::vector<uint32_t>> ex(N);
         if (s->excl_offsets)
             for (uint32_t i = 0; i < N; ++i)
                 for (uint32_t k = s->excl_offsets[i]; k < s->excl_offsets[i + 1]; ++k) {
@@ -243,6 +249,8 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
         };
         count_term(s->bond_idx, s->n_bonds, 2); count_term(s->angle_idx, s->n_angles, 3);
         count_term(s->dihedral_idx, s->n_dihedrals, 4); count_term(s->pairs14_idx, s->n_pairs14, 2);
+        if (pme_on)   // the reciprocal sum sees every pair: excluded and 1-4 partners get erf(beta r)/r removed
+            for (uint32_t i = 0; i < N; ++i) cnt[i + 1] += (uint32_t)ex[i].size();
         for (uint32_t i = 0; i < N; ++i) cnt[i + 1] += cnt[i];
         const uint32_t R = cnt[N];
         std::vector<RoleRec> recs(R);
@@ -274,6 +282,13 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
             add_term(s->pairs14_idx + 2 * k, 2, ROLE_PAIR14, sig, 4.0f * c->scale14_lj * eps,
                      c->scale14_coulomb * c->coulomb_k * q[a] * q[b]);
         }
+        if (pme_on)
+            for (uint32_t i = 0; i < N; ++i)
+                for (uint32_t j : ex[i])
+                    if (i < j) {
+                        const uint32_t at[2] = {i, j};
+                        add_term(at, 2, ROLE_EWALD_EXCL, c->coulomb_k * q[i] * q[j], 0.f, 0.f);
+                    }
         h->n_roles = R;
         MDX_TRY(upload_vec(&d.role_off_o, cnt, st)); MDX_TRY(upload_vec(&d.role_rec_o, recs, st));
         MDX_TRY(alloc_n(&d.role_rec_s, R));
@@ -306,6 +321,7 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
     h->in_slot_space = false; h->list_valid = false; h->forces_valid = false;
     MDX_TRY(mdx_build_constraints(h, s));
     h->cons_dirty = h->n_groups > 0;
+    MDX_TRY(mdx_pme_setup(h));
     MDX_TRY(mdx_rebuild(h));
     return MDX_OK;
 }
@@ -333,6 +349,7 @@ static int compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint
     MDX_TRY(mdx_launch_vsite_construct(h, gate, thr));     // massless sites follow their parents
     MDX_TRY(mdx_launch_nonbonded(h, energy, gate, thr));
     MDX_TRY(mdx_launch_bonded(h, energy, gate, thr));
+    MDX_TRY(mdx_launch_pme(h, energy, gate, thr));         // SPME reciprocal space (hipFFT), if requested
     MDX_TRY(mdx_launch_vsite_spread(h, gate, thr));        // ... and hand their force back to them
     MDX_TRY(mdx_launch_add_ext(h, gate, thr));
     return MDX_OK;
@@ -497,7 +514,8 @@ int mdx_energy_impl(mdx_handle* h, mdx_energies* out) {
     out->lj = e[EN_LJ]; out->coulomb = e[EN_COUL]; out->lj14 = e[EN_LJ14]; out->coulomb14 = e[EN_COUL14];
     out->kinetic = e[EN_KIN];
     out->potential_bonded = out->bond + out->angle + out->dihedral;
-    out->potential_nonbonded = out->lj + out->coulomb + out->lj14 + out->coulomb14;
+    out->coulomb_recip = h->pme_on ? e[EN_RECIP] + h->ewald_self + h->ewald_background : 0.0;
+    out->potential_nonbonded = out->lj + out->coulomb + out->lj14 + out->coulomb14 + out->coulomb_recip;
     out->potential = out->potential_bonded + out->potential_nonbonded;
     const double dof = mdx_dof(h);
     out->temperature = 2.0 * out->kinetic / (dof * MDX_KB);
@@ -595,6 +613,7 @@ extern "C" int mdx_set_box(mdx_handle* h, const float lo[3], const float hi[3]) 
     MDX_TRY(mdx_unsort_state(h));
     for (int d = 0; d < 3; ++d) { h->box_lo[d] = lo[d]; h->box_hi[d] = hi[d]; }
     h->list_valid = false; h->forces_valid = false;
+    MDX_TRY(mdx_pme_setup(h));     // mesh spacing and theta(m) follow the box
     return MDX_OK;
 }
 

@@ -44,7 +44,7 @@ template <bool ENERGY>
 __global__ __launch_bounds__(256) void bonded_gather_kernel(BondedArgs a) {
     if (a.gate && *a.gate > a.thr_bits) return;
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    double e_bond = 0.0, e_angle = 0.0, e_dih = 0.0, e_lj14 = 0.0, e_c14 = 0.0;
+    double e_bond = 0.0, e_angle = 0.0, e_dih = 0.0, e_lj14 = 0.0, e_c14 = 0.0, e_rec = 0.0;
     if (s < a.S) {
         const uint32_t rb = a.role_off[s], re = a.role_off[s + 1];
         if (re > rb) {
@@ -53,6 +53,17 @@ __global__ __launch_bounds__(256) void bonded_gather_kernel(BondedArgs a) {
             for (uint32_t k = rb; k < re; ++k) {
                 const RoleRec r = a.roles[k];
                 const uint32_t kind = r.meta & 0xFu, role = (r.meta >> 4) & 0xFu;
+                if (kind == ROLE_EWALD_EXCL) {
+                    // the reciprocal sum includes this excluded / 1-4 pair: take erf(beta r)/r out again
+                    const float3 d = mimg(sub3(self, a.posq[r.p[0]]), a.p);
+                    const float r2 = dot3(d, d), rinv = rsqrtf(r2), rr = r2 * rinv, br = a.p.ewald_beta * rr;
+                    const float er = erff(br);
+                    const float fs = -r.prm[0] * (er * rinv - 1.1283791671f * a.p.ewald_beta * __expf(-br * br)) * rinv * rinv;
+                    fx += fs * d.x; fy += fs * d.y; fz += fs * d.z;
+                    if (ENERGY && role == 0) e_rec -= (double)(r.prm[0] * er * rinv);
+                    continue;
+                }
+                if (a.p.skip_bonded) continue;
                 if (kind == ROLE_BOND || kind == ROLE_PAIR14) {
                     const float3 d = mimg(sub3(self, a.posq[r.p[0]]), a.p);
                     const float r2 = dot3(d, d);
@@ -134,10 +145,10 @@ __global__ __launch_bounds__(256) void bonded_gather_kernel(BondedArgs a) {
         }
     }
     if (ENERGY) {
-        double v[5] = {e_bond, e_angle, e_dih, e_lj14, e_c14};
-        const int slot[5] = {EN_BOND, EN_ANGLE, EN_DIHEDRAL, EN_LJ14, EN_COUL14};
+        double v[6] = {e_bond, e_angle, e_dih, e_lj14, e_c14, e_rec};
+        const int slot[6] = {EN_BOND, EN_ANGLE, EN_DIHEDRAL, EN_LJ14, EN_COUL14, EN_RECIP};
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
+        for (int q = 0; q < 6; ++q) {
             double t = v[q];
 #pragma unroll
             for (int m = 32; m > 0; m >>= 1) t += __shfl_xor(t, m);
@@ -159,7 +170,8 @@ __global__ void add_ext_kernel(uint32_t S, const uint32_t* __restrict__ orig_of,
 }
 
 int mdx_launch_bonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr_bits) {
-    if (h->cfg.overrides & MDX_OVR_BONDED_DISABLED) return MDX_OK;
+    const bool skip_bonded = (h->cfg.overrides & MDX_OVR_BONDED_DISABLED) != 0;
+    if (skip_bonded && !h->pme_on) return MDX_OK;
     if (!h->n_roles) return MDX_OK;
     BondedArgs a{};
     a.S = h->S; a.role_off = h->d.role_off_s; a.roles = h->d.role_rec_s;
@@ -168,6 +180,7 @@ int mdx_launch_bonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32
         a.p.box[d] = h->per[d] ? (h->box_hi[d] - h->box_lo[d]) : 0.f;
         a.p.inv_box[d] = h->per[d] ? 1.0f / a.p.box[d] : 0.f;
     }
+    a.p.ewald_beta = h->cfg.ewald_alpha; a.p.skip_bonded = skip_bonded ? 1 : 0;
     mdx_prof_begin(h, 1);
     const dim3 g((h->S + 255) / 256), b(256);
     if (energy) hipLaunchKernelGGL(bonded_gather_kernel<true>, g, b, 0, h->stream, a);

@@ -30,7 +30,7 @@
 #define MDX_DUMMY_STEP 64.0f
 #define MDX_MAX_CHUNK 64
 
-enum { EN_BOND = 0, EN_ANGLE, EN_DIHEDRAL, EN_LJ, EN_COUL, EN_LJ14, EN_COUL14, EN_KIN, EN_COUNT };
+enum { EN_BOND = 0, EN_ANGLE, EN_DIHEDRAL, EN_LJ, EN_COUL, EN_LJ14, EN_COUL14, EN_KIN, EN_RECIP, EN_COUNT };
 
 struct GridParams {
     float lo[3];       // origin of the column grid (box_lo, or bounding box in vacuum)
@@ -59,6 +59,8 @@ struct BondedParams {
     float inv_box[3];
     float scale14_lj, scale14_coul;
     int geometric, lj_on, coul_on;
+    float ewald_beta;    // ROLE_EWALD_EXCL: remove erf(beta r)/r of pairs the real-space sum skips
+    int skip_bonded;     // MdOverrides.bonded_disabled: keep only the Ewald exclusion corrections
 };
 
 // Control block in device memory: the rebuild trigger.  disp2[s] holds, as the bit pattern of a
@@ -73,7 +75,7 @@ struct StepCtl {
 };
 
 // One (term, atom-of-that-term) record of the atom-owned bonded gather (mdx_bonded.hip).
-enum { ROLE_BOND = 0, ROLE_ANGLE = 1, ROLE_DIHEDRAL = 2, ROLE_PAIR14 = 3 };
+enum { ROLE_BOND = 0, ROLE_ANGLE = 1, ROLE_DIHEDRAL = 2, ROLE_PAIR14 = 3, ROLE_EWALD_EXCL = 4 };
 struct __attribute__((aligned(16))) RoleRec {
     uint32_t p[3];   // the term's other atoms, in term order (caller index in *_o, slot in *_s)
     uint32_t meta;   // kind | role << 4  (role = this atom's position in the term)
@@ -144,6 +146,8 @@ struct DeviceState {
     uint32_t* role_off_o = nullptr; RoleRec* role_rec_o = nullptr;   // [N+1], [R]
     uint32_t* role_cnt_s = nullptr; uint32_t* role_off_s = nullptr;  // [S+1]
     RoleRec*  role_rec_s = nullptr;                                  // [R]
+    // SPME (mdx_pme.hip)
+    float* pme_q = nullptr; float2* pme_f = nullptr; float* pme_theta = nullptr;
     // constraints and virtual sites
     ConsGroup* cons_o = nullptr; ConsGroup* cons_s = nullptr;
     VSite* vsite_o = nullptr; VSite* vsite_s = nullptr;
@@ -171,6 +175,9 @@ struct mdx_handle {
     uint32_t n_roles = 0;
     uint32_t n_groups = 0, n_cons = 0, n_vsites = 0;   // constraint clusters / constraints / virtual sites
     bool cons_dirty = false;                           // positions were set from outside: project them once
+    // SPME
+    bool pme_on = false; int pme_K[3] = {0, 0, 0}; void* pme_plan = nullptr;  // opaque PmePlan
+    double ewald_self = 0.0, ewald_background = 0.0; double total_charge = 0.0, sum_q2 = 0.0;
     uint32_t n_mobile = 0;
     double total_mass = 0.0;
     std::vector<uint8_t> flags;
@@ -252,6 +259,11 @@ int mdx_launch_constrain_positions(mdx_handle* h, float dt, const uint32_t* d_ga
 int mdx_launch_constrain_velocities(mdx_handle* h, const uint32_t* d_gate, uint32_t thr);
 int mdx_launch_vsite_construct(mdx_handle* h, const uint32_t* d_gate, uint32_t thr);
 int mdx_launch_vsite_spread(mdx_handle* h, const uint32_t* d_gate, uint32_t thr);
+
+// SPME reciprocal space (mdx_pme.hip)
+int mdx_pme_setup(mdx_handle* h);                      // plans, mesh, theta table (again after set_box)
+void mdx_pme_destroy(mdx_handle* h);
+int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr);
 
 // shared between mdx_api.hip and mdx_extras.hip
 int mdx_compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint32_t thr);
