@@ -76,9 +76,15 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
     if (COUL == CM_SHIFTED) fc_r2 = qq * rinv;
     else if (COUL == CM_SOFT) fc_r2 = qq * rinv * r2 * __frcp_rn(r2 + p.soft2);
     else if (COUL == CM_RF) fc_r2 = qq * (rinv - p.k_rf2 * r2);
-    else {
-        const float r = r2 * rinv, ar = p.alpha * r;
-        fc_r2 = qq * (erfcf(ar) * rinv + 1.1283791671f * p.alpha * __expf(-ar * ar));
+    float erfc_ar = 0.f;
+    if (COUL == CM_EWALD) {
+        // erfc by Abramowitz & Stegun 7.1.26 (|error| < 1.5e-7) sharing the exponential the force
+        // needs anyway: ~10 VALU ops instead of the ~45 of libm's erfcf
+        const float ar = p.alpha * r2 * rinv;
+        const float ex = __expf(-ar * ar);
+        const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ar);
+        erfc_ar = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f)))) * ex;
+        fc_r2 = qq * (erfc_ar * rinv + 1.1283791671f * p.alpha * ex);
     }
     float fs;
     if (SAMECUT) fs = (BRANCHY || in_lj) ? (flj_r2 + fc_r2) * rinv2 : 0.0f;
@@ -89,7 +95,7 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
         float e_c;
         if (COUL == CM_SHIFTED || COUL == CM_SOFT) e_c = qq * (rinv - p.coul_shift);
         else if (COUL == CM_RF) e_c = qq * (rinv + p.k_rf * r2 - p.coul_shift);
-        else e_c = qq * erfcf(p.alpha * r2 * rinv) * rinv;
+        else e_c = qq * erfc_ar * rinv;
         elj += in_lj ? (double)e_l : 0.0;
         ecoul += in_c ? (double)e_c : 0.0;
     }
