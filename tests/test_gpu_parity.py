@@ -361,10 +361,14 @@ def test_c5_water1m_properties(mdx, orc):
             have = idx[off[i]:off[i + 1]]
             assert np.isin(want[want != i], have).all()
             assert len(have) <= np.count_nonzero(r2 < rl2 * np.float32(1.0 + 1e-5)) - 1
-        # forces of a sampled sub-volume against the oracle (cell list restricted to those atoms'
-        # neighbourhood would need the whole box; the oracle handles 1M atoms with cells in ~1 min,
-        # so sample-check forces on the first 2,000 atoms only)
+        # every one of the 1,029,000 forces against the oracle (cell list + OpenMP: a few seconds on
+        # the GPU box's host cores), same tolerance as the small cases
+        fo, eo = orc.forces(s, cfg, pos=pos.astype(np.float64), use_cells=True)
+        # coordinates up to 217 Å carry an fp32 ulp of 1.5e-5 Å, so the band in which the two distance
+        # arithmetics may disagree about a cutoff is wider here: 4e-5 relative in r^2
+        assert_forces(f, fo, orc.cutoff_slack(s, cfg, pos=pos, rel=4e-5), "water1M")
         e = md.energy()
+        assert_energies(e, eo, s.n_atoms * 200, "water1M")
         assert np.isfinite(e["potential"]) and e["lj14"] == 0.0 and e["dihedral"] == 0.0
         md.step(0.0005, None, 20)
         assert md.step_count == 20
