@@ -35,7 +35,10 @@ def mdx():
 def assert_forces(f_gpu, f_orc, slack=None, what=""):
     f_gpu = np.asarray(f_gpu, dtype=np.float64)
     err = np.linalg.norm(f_gpu - f_orc, axis=1)
-    tol = 1e-4 * np.maximum(np.linalg.norm(f_orc, axis=1), 1.0)
+    # 1e-4 of the atom's own force, floored at 1e-5 of the system's RMS force: a net force that is a
+    # near-cancellation of ~300 pair terms carries the fp32 rounding of the terms, not of the sum
+    f_rms = math.sqrt(np.mean((f_orc ** 2).sum(1)))
+    tol = 1e-4 * np.maximum(np.linalg.norm(f_orc, axis=1), 1.0) + 1e-5 * f_rms
     if slack is not None:
         tol = tol + slack
     worst = float(np.max(err / tol))
