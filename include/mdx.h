@@ -129,7 +129,9 @@ typedef struct mdx_config {
     uint32_t overrides;        /* MDX_OVR_* bit set                                               */
     float    softening_sq;     /* Å², added to r² in the Coulomb force (src/cuda/util.cu:9 uses 1e-6); default 0 */
     uint32_t chunk_steps;      /* steps enqueued between host checks of the rebuild flag (default 16) */
-    uint32_t nb_variant;       /* pair kernel: 0 = library default, 1 = whole-tile, 2 = cluster-masked (A/B knob) */
+    uint32_t nb_variant;       /* pair kernel (A/B knob): 0 = library default (5); 1 = whole-tile, full list; 2 = cluster-masked, full
+                                  list, bitwise reproducible; 3/4 = 2 with 1/4 waves per tile; 5 = cluster-masked, HALF list, the
+                                  reaction force written back with f32 atomics (fastest; last bits vary run to run) */
     float    constraint_tol;   /* relative tolerance of SHAKE/RATTLE (HydrogenConstraint::Shake{shake_tolerance}); default 1e-5 */
     uint32_t constraint_max_iter; /* default 64 */
     uint32_t pme_grid[3];      /* SPME mesh (MDX_COULOMB_EWALD without MDX_OVR_LONG_RANGE_RECIP_DISABLED);

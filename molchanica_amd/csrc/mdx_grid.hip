@@ -274,22 +274,23 @@ __global__ void gather_slots_kernel(uint32_t S, const uint32_t* __restrict__ ori
 }
 
 __global__ void cluster_bbox_kernel(uint32_t NC, const uint32_t* __restrict__ orig_of,
-                                    const float4* __restrict__ posq, float4* __restrict__ cl_lo,
-                                    float4* __restrict__ cl_hi) {
+                                    const float4* __restrict__ posq, const uint8_t* __restrict__ slot_flags,
+                                    float4* __restrict__ cl_lo, float4* __restrict__ cl_hi) {
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= NC) return;
     float3 lo = make_float3(3.0e38f, 3.0e38f, 3.0e38f), hi = make_float3(-3.0e38f, -3.0e38f, -3.0e38f);
-    int n = 0;
+    int n = 0, n_owned = 0;
     for (int k = 0; k < MDX_CLUSTER; ++k) {
         uint32_t s = c * MDX_CLUSTER + k;
         if (orig_of[s] == MDX_INVALID) continue;
+        n_owned += (slot_flags[s] >> 1) & 1;
         float4 p = posq[s];
         lo.x = fminf(lo.x, p.x); lo.y = fminf(lo.y, p.y); lo.z = fminf(lo.z, p.z);
         hi.x = fmaxf(hi.x, p.x); hi.y = fmaxf(hi.y, p.y); hi.z = fmaxf(hi.z, p.z);
         ++n;
     }
     cl_lo[c] = make_float4(lo.x, lo.y, lo.z, (float)n);
-    cl_hi[c] = make_float4(hi.x, hi.y, hi.z, 0.f);
+    cl_hi[c] = make_float4(hi.x, hi.y, hi.z, (float)n_owned);   // .w: atoms this rank owns (half list)
 }
 
 __global__ void unsort_kernel(uint32_t N, const uint32_t* __restrict__ gid, const uint32_t* __restrict__ slot_of,
@@ -406,6 +407,7 @@ struct ListArgs {
     uint32_t null_cluster;
     int mask_layout;                 // 1: bit (8e+jj) of lane i-atom; 2: bit (8e+ci) of lane (ii, jj)
     unsigned long long* pair_count;  // statistics: sum of popcount(imask)
+    int half;                        // 1: every cluster pair appears in exactly one tile's list
 };
 
 template <bool FILL>
@@ -419,8 +421,10 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     uint32_t* hash = s_hash[wave];
     uint32_t* fl = s_fl[wave];
     const GridParams& g = a.g;
-    // a tile that holds no owned atom (halo copies / padding only) is never an i-tile
-    if (!__any((a.slot_flags[t * MDX_TILE + lane] & 2u) != 0)) {
+    // a tile that holds no owned atom (halo copies / padding only) is never an i-tile of a full list;
+    // in a half list it still owns its share of the pairs with tiles that do hold owned atoms
+    const bool tile_owned = __any((a.slot_flags[t * MDX_TILE + lane] & 2u) != 0);
+    if (!tile_owned && !a.half) {
         if (!FILL && lane == 0) {
             a.counts[t].n_masked = 0; a.counts[t].n_plain = 0; a.entry_cnt[t] = 0; a.mchunk_cnt[t] = 0;
         }
@@ -430,11 +434,14 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     for (int k = lane; k < LB_HASH; k += 64) hash[k] = MDX_INVALID;
     // i-cluster boxes and the tile box
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    uint32_t i_owned = 0;
     if (lane < MDX_CL_PER_TILE) {
         float4 l4 = a.cl_lo[t * MDX_CL_PER_TILE + lane], h4 = a.cl_hi[t * MDX_CL_PER_TILE + lane];
         lo[0] = l4.x; lo[1] = l4.y; lo[2] = l4.z; hi[0] = h4.x; hi[1] = h4.y; hi[2] = h4.z;
         for (int d = 0; d < 3; ++d) { s_ibb[wave][lane][d] = lo[d]; s_ibb[wave][lane][3 + d] = hi[d]; }
+        if (h4.w > 0.f) i_owned = 1u << lane;
     }
+    i_owned = (uint32_t)__ballot(i_owned != 0) & 0xFFu;   // i-clusters that hold an owned atom
 #pragma unroll
     for (int m = 1; m < 8; m <<= 1)
         for (int d = 0; d < 3; ++d) {
@@ -521,6 +528,21 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
                                 float ez = gap(jl.z, jh.z, b[2], b[5]);
                                 if (ex * ex + ey * ey + ez * ez < r2) imask |= 1u << ci;
                             }
+                            if (a.half) {
+                                // one owner per pair.  Different tiles: by the parity of I + J (balances
+                                // the lists).  Same tile: the lower cluster owns (ci, cj); a cluster's
+                                // pair with itself is kept and its mask holds the j > i triangle; its
+                                // pair with its own periodic image goes to the "positive" image code.
+                                const uint32_t J = jc / MDX_CL_PER_TILE;
+                                if (J != t) {
+                                    if ((t < J) != (((t + J) & 1u) == 0u)) imask = 0;
+                                } else {
+                                    const uint32_t cj = jc % MDX_CL_PER_TILE;
+                                    const uint32_t self = (code >= 13u) ? 1u : 0u;
+                                    imask &= ((1u << cj) - 1u) | (self << cj);
+                                }
+                                if (jh.w <= 0.f) imask &= i_owned;   // neither side owned here: not ours
+                            }
                             pass = imask != 0;
                         }
                     }
@@ -531,7 +553,7 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
                         if (flagged) {
                             uint32_t k = nm + __popcll(bm & lt_mask);
                             a.entries[ebase + k] = ent;
-                            if (k < LB_MAXFLAG) fl[k] = jc;
+                            if (k < LB_MAXFLAG) fl[k] = jc | (code << 27);
                         } else if (pass) {
                             uint32_t k = np + __popcll(bp & lt_mask);
                             a.entries[ebase + nm_pad_total + k] = ent;
@@ -570,11 +592,12 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     const uint32_t mbase = a.mchunk_off[t];
     for (uint32_t c = 0; c < (nm_pad >> 3); ++c) {
         unsigned long long m = 0ull;
-        uint32_t jcs[8];
+        uint32_t jcs[8], codes13 = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             uint32_t idx = c * 8 + e;
-            jcs[e] = (idx < nmc) ? fl[idx] : MDX_INVALID;
+            jcs[e] = (idx < nmc) ? (fl[idx] & 0x7FFFFFFu) : MDX_INVALID;
+            if (a.half && idx < nmc && (fl[idx] >> 27) == 13u) codes13 |= 1u << e;
             if (idx < nmc) m |= 0xFFull << (8 * e);
         }
         if (myo == MDX_INVALID) {
@@ -582,7 +605,12 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                if (jcs[e] == (myslot >> 3)) m &= ~(1ull << (8 * e + (myslot & 7)));
+                if (jcs[e] == (myslot >> 3)) {
+                    // self pair; in a half list the cluster's pair with itself keeps only j > i
+                    const unsigned long long gone = ((codes13 >> e) & 1u) ? ((2ull << (myslot & 7)) - 1ull)
+                                                                          : (1ull << (myslot & 7));
+                    m &= ~(gone << (8 * e));
+                }
             for (uint32_t k = eb; k < ee; ++k) {
                 uint32_t sp = a.slot_of[a.excl_idx[k]];
                 if (sp == MDX_INVALID) continue;
@@ -621,9 +649,10 @@ __device__ __forceinline__ float r2_canonical(float4 pi, float4 pj, const float*
 
 template <bool FILL>
 __global__ __launch_bounds__(256) void extract_neighbors_kernel(
-    uint32_t T, GridParams g, float rl2, const uint32_t* __restrict__ entry_off, const uint2* __restrict__ entries,
-    const uint32_t* __restrict__ orig_of, const float4* __restrict__ ref, uint32_t* __restrict__ cnt,
-    const uint32_t* __restrict__ off, uint32_t* __restrict__ idx) {
+    uint32_t T, GridParams g, float rl2, int half, const uint32_t* __restrict__ entry_off,
+    const uint2* __restrict__ entries, const uint32_t* __restrict__ orig_of, const float4* __restrict__ ref,
+    uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, uint32_t* __restrict__ cursor,
+    uint32_t* __restrict__ idx) {
     const int lane = threadIdx.x & 63;
     const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
@@ -631,7 +660,7 @@ __global__ __launch_bounds__(256) void extract_neighbors_kernel(
     const uint32_t oi = orig_of[slot];
     const float4 pi = ref[slot];
     uint32_t k = 0;
-    uint32_t* row = (FILL && oi != MDX_INVALID) ? idx + off[oi] : nullptr;
+    uint32_t* row = (FILL && !half && oi != MDX_INVALID) ? idx + off[oi] : nullptr;
     for (uint32_t e = entry_off[t]; e < entry_off[t + 1]; ++e) {
         const uint32_t jc = entries[e].x;
         for (int jj = 0; jj < MDX_CLUSTER; ++jj) {
@@ -639,12 +668,23 @@ __global__ __launch_bounds__(256) void extract_neighbors_kernel(
             const uint32_t oj = orig_of[js];
             if (oj == MDX_INVALID || oi == MDX_INVALID || oj == oi) continue;
             if (r2_canonical(pi, ref[js], g.len, g.per) < rl2) {
-                if (FILL) row[k] = oj;
-                ++k;
+                if (half) {
+                    // a half list holds the pair on one side only: emit both directions (the host
+                    // sorts the rows and drops duplicates)
+                    if (FILL) {
+                        idx[off[oi] + atomicAdd(&cursor[oi], 1u)] = oj;
+                        idx[off[oj] + atomicAdd(&cursor[oj], 1u)] = oi;
+                    } else {
+                        atomicAdd(&cnt[oi], 1u); atomicAdd(&cnt[oj], 1u);
+                    }
+                } else {
+                    if (FILL) row[k] = oj;
+                    ++k;
+                }
             }
         }
     }
-    if (!FILL && oi != MDX_INVALID) cnt[oi] = k;
+    if (!FILL && !half && oi != MDX_INVALID) cnt[oi] = k;
 }
 
 // ================================================================================================
@@ -795,7 +835,7 @@ int mdx_rebuild(mdx_handle* h) {
                        d.pos_orig, d.vel_orig, d.o_qs, d.o_lj, d.o_invm, d.posq, d.lj, d.vel, d.ref, d.force,
                        d.slot_flags);
     hipLaunchKernelGGL(cluster_bbox_kernel, dim3(div_up(NC, 256)), dim3(256), 0, st, NC, d.orig_of, d.posq,
-                       d.cl_lo, d.cl_hi);
+                       d.slot_flags, d.cl_lo, d.cl_hi);
     h->in_slot_space = true;
 
     // ---- pair list: count, scan, fill ----
@@ -809,6 +849,7 @@ int mdx_rebuild(mdx_handle* h) {
     a.entry_off = d.entry_off; a.mchunk_off = d.mchunk_off; a.entries = d.entries; a.masks = d.masks;
     a.err = d.flags_dev; a.null_cluster = T * MDX_CL_PER_TILE;
     a.mask_layout = mdx_nb_variant(h) >= 2 ? 2 : 1;
+    a.half = mdx_nb_half(h) ? 1 : 0;
     if (!d.pair_count) ALLOC(d.pair_count, 2);
     a.pair_count = d.pair_count;
     HIP_TRY(hipMemsetAsync(d.pair_count, 0, sizeof(unsigned long long) * 2, st));
@@ -879,25 +920,28 @@ int mdx_extract_neighbors(mdx_handle* h, uint32_t* offsets, uint32_t* idx) {
     const uint32_t N = h->n_local, T = h->T;
     hipStream_t st = h->stream;
     const float rl2 = h->r_list * h->r_list;
-    uint32_t *d_cnt = nullptr, *d_off = nullptr, *d_idx = nullptr;
+    uint32_t *d_cnt = nullptr, *d_off = nullptr, *d_idx = nullptr, *d_cur = nullptr;
+    const int half = mdx_nb_half(h) ? 1 : 0;
     HIP_TRY(hipMalloc((void**)&d_cnt, sizeof(uint32_t) * ((size_t)N + 1)));
     HIP_TRY(hipMalloc((void**)&d_off, sizeof(uint32_t) * ((size_t)N + 1)));
+    HIP_TRY(hipMalloc((void**)&d_cur, sizeof(uint32_t) * ((size_t)N + 1)));
     HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * ((size_t)N + 1), st));
-    hipLaunchKernelGGL(extract_neighbors_kernel<false>, dim3(div_up(T, 4)), dim3(256), 0, st, T, h->grid, rl2,
-                       d.entry_off, d.entries, d.orig_of, d.ref, d_cnt, d_off, d_idx);
+    HIP_TRY(hipMemsetAsync(d_cur, 0, sizeof(uint32_t) * ((size_t)N + 1), st));
+    hipLaunchKernelGGL(extract_neighbors_kernel<false>, dim3(div_up(T, 4)), dim3(256), 0, st, T, h->grid, rl2, half,
+                       d.entry_off, d.entries, d.orig_of, d.ref, d_cnt, d_off, d_cur, d_idx);
     int rc = mdx_exclusive_scan_u32(h, d_cnt, d_off, N + 1);
-    if (rc != MDX_OK) { (void)hipFree(d_cnt); (void)hipFree(d_off); return rc; }
+    if (rc != MDX_OK) { (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_cur); return rc; }
     std::vector<uint32_t> off(N + 1);
     HIP_TRY(hipMemcpyAsync(off.data(), d_off, sizeof(uint32_t) * ((size_t)N + 1), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const uint32_t total = off[N];
     std::vector<uint32_t> raw(total ? total : 1);
     HIP_TRY(hipMalloc((void**)&d_idx, sizeof(uint32_t) * (total ? total : 1)));
-    hipLaunchKernelGGL(extract_neighbors_kernel<true>, dim3(div_up(T, 4)), dim3(256), 0, st, T, h->grid, rl2,
-                       d.entry_off, d.entries, d.orig_of, d.ref, d_cnt, d_off, d_idx);
+    hipLaunchKernelGGL(extract_neighbors_kernel<true>, dim3(div_up(T, 4)), dim3(256), 0, st, T, h->grid, rl2, half,
+                       d.entry_off, d.entries, d.orig_of, d.ref, d_cnt, d_off, d_cur, d_idx);
     HIP_TRY(hipMemcpyAsync(raw.data(), d_idx, sizeof(uint32_t) * total, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_idx);
+    (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_idx); (void)hipFree(d_cur);
     // rows: sort, drop duplicates (a cluster may be listed under two images in a small box)
     uint32_t w = 0;
     std::vector<uint32_t> new_off(N + 1);

@@ -245,12 +245,16 @@ int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_ga
 int mdx_launch_kinetic(mdx_handle* h);  // energy[EN_KIN], energy[EN_COUNT] = max |F|^2
 int mdx_exclusive_scan_u32(mdx_handle* h, const uint32_t* in, uint32_t* out, uint32_t n);
 
-// pair-kernel variant actually used: 1 = whole-tile kernel, 2 = cluster-masked kernel
-#define MDX_NB_DEFAULT_VARIANT 2
+// pair-kernel variant actually used: 1 = whole-tile kernel (full list), 2 = cluster-masked kernel (full
+// list, deterministic), 3/4 = the same with 1/4 waves per tile forced, 5 = cluster-masked kernel over a
+// HALF list: each cluster pair is evaluated once and the reaction force goes back to the j-atoms with
+// f32 atomics (half the arithmetic; summation order, hence the last bits, vary run to run).
+#define MDX_NB_DEFAULT_VARIANT 5
 static inline int mdx_nb_variant(const mdx_handle* h) {
     const uint32_t v = h->cfg.nb_variant;
-    return (v >= 1 && v <= 4) ? (int)v : MDX_NB_DEFAULT_VARIANT;   // 3/4: cluster kernel, 1/4 waves per tile forced
+    return (v >= 1 && v <= 5) ? (int)v : MDX_NB_DEFAULT_VARIANT;
 }
+static inline bool mdx_nb_half(const mdx_handle* h) { return mdx_nb_variant(h) == 5; }
 
 // constraints / virtual sites (mdx_constraints.hip)
 int mdx_build_constraints(mdx_handle* h, const mdx_system* s);

@@ -34,6 +34,9 @@
     } while (0)
 
 constexpr int NB_WAVES = 4;
+#ifndef NB_HALF_FLUSH
+#define NB_HALF_FLUSH 0   // 1: j-forces leave once per chunk from LDS; 0: one 24-lane atomic per entry
+#endif
 
 struct NbArgs {
     uint32_t T;
@@ -54,10 +57,11 @@ enum { CM_SHIFTED = 0, CM_RF = 1, CM_EWALD = 2, CM_SOFT = 3 };
 // cutoff costs 7 VALU ops instead of 25 (the cluster kernel: ~40 % of its cluster pairs).  The
 // whole-tile kernel keeps the straight-line select form, which the compiler can software-pipeline
 // across its unrolled j loop.
-template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, bool BRANCHY>
+template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, bool BRANCHY, bool HALF = false>
 __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi, float sgi, float epi,
                                           const float4 pj, const float2 lj, bool allowed, const NbParams& p,
-                                          float& fx, float& fy, float& fz, double& elj, double& ecoul) {
+                                          float& fx, float& fy, float& fz, double& elj, double& ecoul,
+                                          float* g = nullptr) {
     const float dx = xi - pj.x, dy = yi - pj.y, dz = zi - pj.z;   // tgt - src (src/cuda/util.cu:118-140)
     const float r2 = dx * dx + dy * dy + dz * dz;
     const bool in_lj = (r2 < p.rc2_lj) && allowed;
@@ -90,6 +94,7 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
     if (SAMECUT) fs = (BRANCHY || in_lj) ? (flj_r2 + fc_r2) * rinv2 : 0.0f;
     else fs = (in_lj || in_c) ? ((in_lj ? flj_r2 : 0.0f) + (in_c ? fc_r2 : 0.0f)) * rinv2 : 0.0f;
     fx += fs * dx; fy += fs * dy; fz += fs * dz;
+    if (HALF) { g[0] += fs * dx; g[1] += fs * dy; g[2] += fs * dz; }   // minus the force on j
     if (ENERGY) {
         const float e_l = es6 * (s6 - 1.0f) * (1.0f / 6.0f);  // 4 eps (s12 - s6)
         float e_c;
@@ -205,14 +210,31 @@ __global__ __launch_bounds__(NB_WAVES * 64) void nb_tile_kernel(NbArgs a) {
 // through LDS in a fixed order.  A tile's list is a ~270 us dependency chain for one wave, so a
 // launch with fewer tiles than the chip has wave slots (strong scaling: 1/8 of the box per GPU,
 // or any system below ~250 k atoms) is latency-bound; splitting the list 4 ways fills the SIMDs.
-template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT>
-__global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, 4) void nb_cluster_kernel(NbArgs a) {
+//
+// HALF = true (variant 5) walks a half list: a cluster pair lives in ONE tile's list, the force on
+// the i-atoms accumulates in registers as before and the reaction on the eight j-atoms of an entry
+// is summed over the eight i-lanes with three DPP steps and leaves as ONE 24-lane f32 atomic
+// (x, y, z of 8 consecutive float4 records = 128 contiguous bytes).  Measured on gfx950
+// (tools/ubench/atomic_jforce.hip): 3.4 M such wave-level atomics cost < 0.05 ms, while three 8-lane
+// atomics per entry cost 0.7 ms.  The force array must be zero when the kernel starts.
+template <int CTRL>
+__device__ __forceinline__ float dpp_xadd(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF>
+__global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, (HALF && NB_HALF_FLUSH) ? 3 : 4) void nb_cluster_kernel(NbArgs a) {
     if (a.gate && *a.gate > a.thr_bits) return;
     constexpr int BW = WPT > NB_WAVES ? WPT : NB_WAVES;       // waves per workgroup
     __shared__ float4 s_xyzq[BW][64];
     __shared__ float2 s_lj[BW][64];
     __shared__ float s_red[WPT > 1 ? BW : 1][3][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float s_ownj[(ENERGY && HALF) ? BW : 1][64];   // 1.0 <=> the staged j-atom is owned here
+    __shared__ float4 s_g[HALF ? BW : 1][64];                 // minus the chunk's j-forces (.w: the j-slot), until flushed
+    __shared__ unsigned long long s_mask[BW][64];             // a masked chunk's per-lane exclusion bits
+    // the wave index is wave-uniform: say so, and tile number, list bounds and the chunk loop
+    // live in SGPRs with scalar branches instead of VGPR compares and exec-mask loops
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int TPB = BW / WPT;                             // tiles per workgroup
     const uint32_t nblocks = (a.T + TPB - 1) / TPB;
     const uint32_t per_xcd = (nblocks + 7) >> 3;
@@ -247,21 +269,46 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, 4) void nb_
             own_bits |= ((a.slot_flags[t * MDX_TILE + ci * MDX_CLUSTER + ii] >> 1) & 1u) << ci;
     }
 
-    // two-deep software pipeline: entries of the wave's next-but-one chunk and atoms of its next
-    // chunk are in flight while the current chunk is evaluated, so the dependent (entry -> posq)
-    // load never stalls the wave
+    // two-deep software pipeline: entries of the wave's next-but-one chunk, atoms AND exclusion masks
+    // of its next chunk are in flight while the current chunk is evaluated.  Everything a chunk
+    // needs from HBM is issued one iteration ahead and consumed at the top of the loop, so the one
+    // s_waitcnt vmcnt(0) per chunk sits where the data is a whole chunk old and the entry loop has
+    // no vector-memory instruction in it (a mask fetched at its point of use - or an atomic issued
+    // per entry - drags a vmcnt(0) into the loop and serialises the wave on memory latency).
     float4 nj = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 nl = make_float2(0.f, 0.f);
-    uint32_t ny = 13;
+    uint32_t ny = 13, njc = 0;
+    float nown = 0.f;
+    unsigned long long nmq = ~0ull;
     uint2 ent_n = make_uint2(0u, 13u);
     if ((uint32_t)part < nchunks) {
         const uint2 ent = a.entries[e0 + part * 8 + (lane >> 3)];
+        if ((uint32_t)part < nmc) nmq = a.masks[(size_t)(mbase + part) * 64 + lane];
         if ((uint32_t)part + WPT < nchunks) ent_n = a.entries[e0 + (part + WPT) * 8 + (lane >> 3)];
         const uint32_t js = ent.x * MDX_CLUSTER + (lane & 7);
-        nj = a.posq[js]; nl = a.lj[js]; ny = ent.y;
+        nj = a.posq[js]; nl = a.lj[js]; ny = ent.y; njc = ent.x;
+        if (ENERGY && HALF) nown = (float)((a.slot_flags[js] >> 1) & 1u);
     }
+    float* const fbase = reinterpret_cast<float*>(a.force);
+    float4* const sg = s_g[HALF ? wave : 0];
+    // HALF: the j-forces of a chunk collect in the wave's LDS strip and leave as three 64-lane
+    // atomics (x, y, z of j-atom `lane`) when the chunk is done: always three, issued AFTER the
+    // prefetch loads, so the loads' waits at the top of the next chunk are vmcnt(3) and the
+    // atomics stay in flight (lanes of list padding add 0 to their own i-slot)
+    // (HALF) retire the prologue's loads here: the loop then never waits at its top, where the
+    // atomics of the previous chunk are still in flight
+    if (HALF && NB_HALF_FLUSH) __builtin_amdgcn_s_waitcnt(0x0F70);
     for (uint32_t c = part; c < nchunks; c += WPT) {
-        const uint32_t cur_y = ny;
+        const uint32_t cur_y = ny, cur_jc = njc;
+        const bool masked = c < nmc;
+        if (masked) s_mask[wave][lane] = nmq;                   // read back a byte per entry: two VGPRs fewer
+        if (ENERGY && HALF) s_ownj[wave][lane] = nown;
+        if (HALF && NB_HALF_FLUSH) {
+            // the lane that staged j-atom `lane` also flushes its force: remember where it goes.
+            // List padding (imask 0) has no force: it will add 0 to this lane's own i-slot.
+            const bool live = ((ny >> 8) & 0xFFu) != 0u;
+            sg[lane] = make_float4(0.f, 0.f, 0.f, __uint_as_float(live ? njc * MDX_CLUSTER + (uint32_t)ii : t * MDX_TILE + lane));
+        }
         {   // image shift, then park in LDS
             const uint32_t code = ny & 31u;
             const int kx = (int)(code % 3u) - 1, ky = (int)((code / 3u) % 3u) - 1, kz = (int)(code / 9u) - 1;
@@ -272,36 +319,87 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, 4) void nb_
             sl[lane] = nl;
         }
         WAVE_LDS_SYNC();
+        if (c + WPT < nmc) nmq = a.masks[(size_t)(mbase + c + WPT) * 64 + lane];
         if (c + WPT < nchunks) {
             const uint32_t js = ent_n.x * MDX_CLUSTER + (lane & 7);
-            nj = a.posq[js]; nl = a.lj[js]; ny = ent_n.y;
+            nj = a.posq[js]; nl = a.lj[js]; ny = ent_n.y; njc = ent_n.x;
+            if (ENERGY && HALF) nown = (float)((a.slot_flags[js] >> 1) & 1u);
             if (c + 2 * WPT < nchunks) ent_n = a.entries[e0 + (c + 2 * WPT) * 8 + (lane >> 3)];
         }
-        const bool masked = c < nmc;
-        const unsigned long long mq = masked ? a.masks[(size_t)(mbase + c) * 64 + lane] : ~0ull;
         // entry loop: the next entry's j record is fetched from LDS before the current one is evaluated
-        float4 pj_n = sx[jj];
-        float2 lj_n = sl[jj];
+        // (the half-list kernel has no registers to spare for that: it reads the record in place)
+        float4 pj_n = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2 lj_n = make_float2(0.f, 0.f);
+        constexpr bool LDS_AHEAD = false;
+        if (LDS_AHEAD) { pj_n = sx[jj]; lj_n = sl[jj]; }
+        // (HALF, atomics in the loop) the loop is cut in two with an explicit wait for the prefetch
+        // between the halves: by then the loads are ~1 us old, and with them retired on every path
+        // the compiler has no reason to wait at the end of the chunk, where it could only say
+        // vmcnt(0) and would stall on the atomics just issued
+        constexpr int NSPLIT = 1;   // measured: 2 (explicit wait between the halves) is 3 % slower
+#pragma unroll
+        for (int hs = 0; hs < NSPLIT; ++hs) {
+        if (hs == 1) __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll 1
-        for (int e = 0; e < 8; ++e) {
-            const float4 pj = pj_n;
-            const float2 lj = lj_n;
-            if (e < 7) { pj_n = sx[(e + 1) * 8 + jj]; lj_n = sl[(e + 1) * 8 + jj]; }
+        for (int e = hs * (8 / NSPLIT); e < (hs + 1) * (8 / NSPLIT); ++e) {
+            const float4 pj = !LDS_AHEAD ? sx[e * 8 + jj] : pj_n;
+            const float2 lj = !LDS_AHEAD ? sl[e * 8 + jj] : lj_n;
+            if (LDS_AHEAD && e < 7) { pj_n = sx[(e + 1) * 8 + jj]; lj_n = sl[(e + 1) * 8 + jj]; }
             const uint32_t im = (__builtin_amdgcn_readlane(cur_y, e * 8) >> 8) & 0xFFu;  // wave-uniform
             if (im == 0) continue;
             // exclusion bits only exist in masked chunks; elsewhere the (uniform) imask bit suffices
-            const uint32_t m8 = masked ? ((uint32_t)(mq >> (8 * e)) & im) : im;
+            const uint32_t m8 = masked ? ((uint32_t)reinterpret_cast<const uint8_t*>(&s_mask[wave][lane])[e] & im) : im;
+            float g[3] = {0.f, 0.f, 0.f};
+            float wj = 0.f;
+            if (ENERGY && HALF) wj = 0.5f * s_ownj[wave][e * 8 + jj];
 #pragma unroll
             for (int ci = 0; ci < 8; ++ci) {
                 if (im & (1u << ci)) {
                     double e1 = 0.0, e2 = 0.0;
-                    pair_eval<ENERGY, COUL, GEOM, SAMECUT, true>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci], pj, lj,
-                                                                 (m8 >> ci) & 1u, a.p, fx[ci], fy[ci], fz[ci], e1, e2);
-                    if (ENERGY && ((own_bits >> ci) & 1u)) { elj += e1; ecoul += e2; }
+                    pair_eval<ENERGY, COUL, GEOM, SAMECUT, true, HALF>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci],
+                                                                       pj, lj, (m8 >> ci) & 1u, a.p, fx[ci], fy[ci],
+                                                                       fz[ci], e1, e2, g);
+                    if (ENERGY && HALF) {   // a pair's energy is split between the owners of its two atoms
+                        const double w = (double)(wj + (((own_bits >> ci) & 1u) ? 0.5f : 0.f));
+                        elj += w * e1; ecoul += w * e2;
+                    } else if (ENERGY && ((own_bits >> ci) & 1u)) { elj += e1; ecoul += e2; }
+                }
+            }
+            if (HALF) {
+                // sum over the eight i-lanes of every j-atom: xor 1, xor 2 (quad_perm), then the
+                // other quad of the row half (row_half_mirror) - every lane ends with the total
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    g[d] = dpp_xadd<0xB1>(g[d]);
+                    g[d] = dpp_xadd<0x4E>(g[d]);
+                    g[d] = dpp_xadd<0x141>(g[d]);
+                }
+                if (ii < 3) {
+                    const float v = ii == 0 ? g[0] : (ii == 1 ? g[1] : g[2]);
+                    if (NB_HALF_FLUSH) reinterpret_cast<float*>(sg)[(e * 8 + jj) * 4 + ii] = -v;
+                    else unsafeAtomicAdd(fbase + (size_t)__builtin_amdgcn_readlane(cur_jc, e * 8) * (MDX_CLUSTER * 4) + jj * 4 + ii, -v);
                 }
             }
         }
+        }
         WAVE_LDS_SYNC();
+        if (HALF && NB_HALF_FLUSH) {
+            // Flush: 192 floats = 3 instructions x 64 lanes, lane l of instruction k taking float
+            // k*64 + l of the packed [64 atoms][xyz] view, so consecutive lanes hit consecutive words
+            // and an instruction touches each 128-B line once.  (x of all atoms, then y, then z hits
+            // every line three times in a row and is 3x slower; a per-entry 24-lane atomic inside the
+            // entry loop makes every wait in the loop a vmcnt(0): tools/ubench/atomic_flush.hip.)
+            // The prefetch issued before this chunk's arithmetic has landed long ago: retire it here,
+            // so that nothing after the atomics has to wait on the vector-memory counter.
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt/lgkmcnt untouched
+            const float* const sgf = reinterpret_cast<const float*>(sg);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t fidx = (uint32_t)(k * 64 + lane), atom = (fidx * 171u) >> 9, comp = fidx - 3u * atom;
+                const uint32_t slot = __float_as_uint(sgf[atom * 4 + 3]);
+                unsafeAtomicAdd(fbase + (size_t)slot * 4 + comp, sgf[atom * 4 + comp]);
+            }
+        }
     }
     // sum the eight j-lanes of every i-atom (lanes ii, ii+8, ..., ii+56), then lane (ii, jj) keeps
     // i-cluster ci == jj: slot tile*64 + jj*8 + ii == tile*64 + lane, a coalesced store.
@@ -315,6 +413,7 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, 4) void nb_
         }
         if (jj == ci) { ox = x; oy = y; oz = z; }
     }
+    float* const fi = fbase + (size_t)(t * MDX_TILE + lane) * 4;
     if (WPT > 1) {   // fixed-order sum of the waves' partial forces
         s_red[wave][0][lane] = ox; s_red[wave][1][lane] = oy; s_red[wave][2][lane] = oz;
         __syncthreads();
@@ -322,10 +421,12 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, 4) void nb_
             ox = s_red[0][0][lane]; oy = s_red[0][1][lane]; oz = s_red[0][2][lane];
 #pragma unroll
             for (int w = 1; w < WPT; ++w) { ox += s_red[w][0][lane]; oy += s_red[w][1][lane]; oz += s_red[w][2][lane]; }
-            a.force[t * MDX_TILE + lane] = make_float4(ox, oy, oz, 0.f);
+            if (HALF) { unsafeAtomicAdd(fi, ox); unsafeAtomicAdd(fi + 1, oy); unsafeAtomicAdd(fi + 2, oz); }
+            else a.force[t * MDX_TILE + lane] = make_float4(ox, oy, oz, 0.f);
         }
     } else {
-        a.force[t * MDX_TILE + lane] = make_float4(ox, oy, oz, 0.f);
+        if (HALF) { unsafeAtomicAdd(fi, ox); unsafeAtomicAdd(fi + 1, oy); unsafeAtomicAdd(fi + 2, oz); }
+        else a.force[t * MDX_TILE + lane] = make_float4(ox, oy, oz, 0.f);
     }
     if (ENERGY) {
 #pragma unroll
@@ -333,9 +434,9 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, 4) void nb_
             elj += __shfl_xor(elj, m);
             ecoul += __shfl_xor(ecoul, m);
         }
-        if (lane == 0) {
-            atomicAdd(&a.energy[EN_LJ], 0.5 * elj);
-            atomicAdd(&a.energy[EN_COUL], 0.5 * ecoul);
+        if (lane == 0) {   // full list: every pair is seen from both sides
+            atomicAdd(&a.energy[EN_LJ], HALF ? elj : 0.5 * elj);
+            atomicAdd(&a.energy[EN_COUL], HALF ? ecoul : 0.5 * ecoul);
         }
     }
 }
@@ -346,7 +447,8 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
     // waves per tile: split a tile's list over the 4 waves of its workgroup when the launch has
     // fewer tiles than ~3 per SIMD (the chip holds 4 waves/SIMD of this kernel on 1024 SIMDs)
     int wpt = 1;
-    if (var == 2) wpt = (a.T < 4096u) ? 8 : 4;     // measured: 4 beats 1 at every size, 8 below ~200 k atoms
+    const bool half = var == 5;
+    if (var == 2 || half) wpt = (a.T < 4096u) ? 8 : 4;     // measured: 4 beats 1 at every size, 8 below ~200 k atoms
     else if (var == 4) wpt = 4;
     const uint32_t bw = std::max(wpt, NB_WAVES);
     const uint32_t tpb = (var == 1) ? NB_WAVES : bw / wpt;
@@ -356,9 +458,11 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
 #define NB_LAUNCH(G, S)                                                                                    \
     do {                                                                                                   \
         if (var == 1) hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, G, S>), g, b, 0, h->stream, a);     \
-        else if (wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8>), g, b, 0, h->stream, a); \
-        else if (wpt == 4) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4>), g, b, 0, h->stream, a); \
-        else hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 1>), g, b, 0, h->stream, a);        \
+        else if (half && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true>), g, b, 0, h->stream, a); \
+        else if (half) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, true>), g, b, 0, h->stream, a); \
+        else if (wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, false>), g, b, 0, h->stream, a); \
+        else if (wpt == 4) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, false>), g, b, 0, h->stream, a); \
+        else hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 1, false>), g, b, 0, h->stream, a);        \
     } while (0)
     if (geom) { if (samecut) NB_LAUNCH(true, true); else NB_LAUNCH(true, false); }
     else      { if (samecut) NB_LAUNCH(false, true); else NB_LAUNCH(false, false); }
@@ -396,6 +500,9 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
     const bool geom = c.combining_rule == MDX_COMBINE_GEOMETRIC;
     const bool samecut = p.rc2_lj == p.rc2_coul;
     mdx_prof_begin(h, 0);
+    // the half-list kernel accumulates with atomics: start from zero (part of the kernel's cost, so
+    // inside the profiled bracket; harmless when the launch behind it is gated off, see mdx_step)
+    if (mdx_nb_half(h)) HIP_TRY(hipMemsetAsync(h->d.force, 0, sizeof(float4) * (size_t)h->S, h->stream));
 #define NB_DISPATCH(E)                                                              \
     switch (mode) {                                                                 \
     case CM_SHIFTED: launch_variant<E, CM_SHIFTED>(h, a, geom, samecut); break;     \

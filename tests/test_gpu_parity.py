@@ -309,14 +309,34 @@ def test_error_behaviour(mdx):
 
 
 def test_nonbonded_forces_are_bitwise_reproducible(mdx):
-    """Full-list evaluation, no atomics in the pair kernel: same bits every run."""
+    """nb_variant 2 = full-list evaluation, no atomics in the pair kernel: same bits every run."""
     s = systems.water_box(8, seed=2)
-    cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, overrides=0x1 | 0x8)
+    cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, overrides=0x1 | 0x8, nb_variant=2)
     fs = []
     for _ in range(2):
         with mdx.MdState(s, cfg) as md:
             fs.append(md.forces())
     assert np.array_equal(fs[0], fs[1])
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("name", ["small", "dhfr23k"])
+def test_every_pair_kernel_variant_against_the_oracle(mdx, orc, name, variant):
+    """The A/B knob `nb_variant`: whole-tile (1), cluster-masked full list (2, 3, 4 = waves per tile
+    auto / 1 / 4) and the half list with atomic j-force write-back (5, the default) all meet the same
+    force / energy tolerance and produce the same neighbour list."""
+    s = systems.small_solvated() if name == "small" else systems.dhfr23k()
+    cfg = MdConfig(nb_variant=variant)
+    with mdx.MdState(s, cfg) as md:
+        pos = md.positions(); f = md.forces(); e = md.energy()
+        off, idx = md.neighbor_list()
+    fo, eo = orc.forces(s, cfg, pos=pos.astype(np.float64), use_cells=True)
+    assert_forces(f, fo, orc.cutoff_slack(s, cfg, pos=pos), f"{name} v{variant}")
+    assert_energies(e, eo, s.n_atoms * 200, f"{name} v{variant}")
+    ooff, oidx = orc.neighbor_list(s, max(cfg.lj_cutoff, cfg.coulomb_cutoff) + cfg.skin, pos=pos, use_cells=True)
+    assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+    if variant == 5:   # Newton's third law holds pair by pair: the net force is rounding of the sum only
+        assert np.abs(f.astype(np.float64).sum(0)).max() < 2e-3
 
 
 def test_energy_conservation_and_momentum_water(mdx):
