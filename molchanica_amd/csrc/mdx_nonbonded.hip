@@ -215,8 +215,13 @@ __global__ __launch_bounds__(NB_WAVES * 64) void nb_tile_kernel(NbArgs a) {
 // the i-atoms accumulates in registers as before and the reaction on the eight j-atoms of an entry
 // is summed over the eight i-lanes with three DPP steps and leaves as ONE 24-lane f32 atomic
 // (x, y, z of 8 consecutive float4 records = 128 contiguous bytes).  Measured on gfx950
-// (tools/ubench/atomic_jforce.hip): 3.4 M such wave-level atomics cost < 0.05 ms, while three 8-lane
-// atomics per entry cost 0.7 ms.  The force array must be zero when the kernel starts.
+// (tools/ubench/atomic_jforce.hip, atomic_flush.hip): the L2 retires ~250 G f32 atomic words/s, so the
+// 88 M words of a 1 M-atom half list need 0.35 ms of it - hidden behind 0.6 ms of arithmetic as long
+// as no instruction shape hits the same 128-B line twice in a row (x, then y, then z of the same
+// atoms is 3x slower).  Measured and rejected: collecting a chunk's j-forces in LDS and flushing
+// them once per chunk (NB_HALF_FLUSH=1: 0.79 vs 0.66 ms, it needs 137 VGPRs = 3 waves/SIMD);
+// any form of LDS look-ahead of the next entry's j record (+6..8 %, both kernels).
+// The force array must be zero when the kernel starts.
 template <int CTRL>
 __device__ __forceinline__ float dpp_xadd(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
