@@ -46,6 +46,10 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--nb-variant", type=int, default=0)
     ap.add_argument("--decomposed", action="store_true", help="drive the decomposed path even on one GPU")
+    ap.add_argument("--no-equilibrate", dest="equilibrate", action="store_false",
+                    help="skip the untimed relaxation + 300 K thermalisation of the synthetic start")
+    ap.add_argument("--eq-min-iters", type=int, default=100)
+    ap.add_argument("--eq-steps", type=int, default=600)
     ap.add_argument("--pme", action="store_true", help="Ewald Coulomb with the SPME reciprocal sum (not the headline config)")
     return ap.parse_args()
 
@@ -105,6 +109,35 @@ def main():
         cfg = MdConfig(nb_variant=args.nb_variant, coulomb_mode=2, ewald_alpha=0.3, overrides=0)
     n_atoms = system.n_atoms
 
+    # Untimed preparation of the synthetic box (SURVEY 8d asks for Maxwell-Boltzmann at 300 K): the
+    # generator places waters on a jittered lattice with random orientations, and run as-is that
+    # potential energy heats the box to ~1300 K.  So: steepest-descent relaxation, velocities drawn at
+    # 300 K, a short Berendsen-coupled run, thermostat off.  The timed region is plain NVE.  Rank 0
+    # prepares, everyone receives the same state.
+    prep = None
+    if args.equilibrate and system.periodic:
+        t_prep = time.perf_counter()
+        if rank == 0:
+            with MdState(system, cfg, device=local_rank) as eq:
+                eq.minimize_energy(args.eq_min_iters)
+                eq.initialize_velocities(300.0, True, seed=105)
+                eq.set_thermostat(1, 300.0, 0.02, 1)
+                eq.step(args.dt, None, args.eq_steps)
+                eq.set_thermostat(0, 300.0, 0.02, 1)
+                e_eq = eq.energy()
+                pos_eq, vel_eq = eq.positions(), eq.velocities()
+        else:
+            pos_eq = np.zeros((n_atoms, 3), np.float32); vel_eq = np.zeros((n_atoms, 3), np.float32)
+            e_eq = {"temperature": 0.0}
+        if world > 1:
+            tp = torch.from_numpy(np.ascontiguousarray(pos_eq)).cuda(); tv = torch.from_numpy(np.ascontiguousarray(vel_eq)).cuda()
+            dist.broadcast(tp, 0); dist.broadcast(tv, 0)
+            pos_eq, vel_eq = tp.cpu().numpy(), tv.cpu().numpy()
+        system.pos = np.ascontiguousarray(pos_eq, dtype=np.float32)
+        system.vel = np.ascontiguousarray(vel_eq, dtype=np.float32)
+        prep = {"min_iters": args.eq_min_iters, "thermostat_steps": args.eq_steps,
+                "temperature_K": round(float(e_eq["temperature"]), 1), "seconds": round(time.perf_counter() - t_prep, 2)}
+
     if world == 1 and not args.decomposed:
         md = MdState(system, cfg, device=local_rank)
         stepper = lambda k: md.step(args.dt, None, k)
@@ -162,8 +195,9 @@ def main():
         "config": {"workload": args.workload, "n_atoms": n_atoms, "lj_cutoff": cfg.lj_cutoff,
                    "coulomb_cutoff": cfg.coulomb_cutoff, "skin": cfg.skin, "dt_ps": args.dt,
                    "coulomb": "ewald real space + SPME (order 4, ~1 A mesh)" if args.pme else "shifted cutoff", "parallelism": parallelism,
-                   "rebuilds_in_timed_region": int(st["rebuild_count"] - rebuilds0)},
-        "roofline": {"kernel": "nb_cluster_kernel" if args.nb_variant in (0, 2, 3, 4) else "nb_tile_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                   "rebuilds_in_timed_region": int(st["rebuild_count"] - rebuilds0),
+                   "untimed_preparation": prep},
+        "roofline": {"kernel": "nb_tile_kernel" if args.nb_variant == 1 else "nb_cluster_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "launch_ms": nb_ms, "launches": st["nb_launches"],
                      "algorithmic_bytes_per_launch": B_ALG_NONBONDED * atoms_per_launch,
