@@ -69,7 +69,7 @@ def cpu_baseline(system, cfg, dt, n_steps):
     n = system.n_atoms
     x = system.pos.astype(np.float64).copy()
     v = system.vel.astype(np.float64).copy()
-    en = np.zeros(8)
+    en = np.zeros(16)
     dp = C.POINTER(C.c_double)
     t0 = time.perf_counter()
     lib.orc_step(C.byref(cs), C.byref(cc), x.ctypes.data_as(dp), v.ctypes.data_as(dp), float(dt), int(n_steps),

@@ -151,10 +151,13 @@ typedef struct mdx_energies {
     double temperature;         /* K, 2 KE / (dof kB), dof = 3 N_mobile - 3 (>=1) */
     double volume;              /* Å³ (0 in vacuum) */
     double density;             /* amu/Å³ (0 in vacuum) */
-    double virial;              /* sum r_ij·f_ij over non-bonded pairs (reserved, 0 for now) */
+    double virial;              /* W = sum_i r_i·F_i (kcal/mol) of all internal forces: pair, 1-4, bonded, SPME reciprocal
+                                   and - with constraints - the SHAKE forces of the last step */
     double max_force;           /* max |F| kcal/mol/Å — blow-up detector (sol_shrinking_box.rs:776-789) */
     double coulomb_recip;       /* SPME reciprocal sum + self + excluded-pair + background terms (in
                                    potential_nonbonded); `coulomb` is the real-space part */
+    double pressure;            /* bar, (2 KE + W) / (3 V) x 69476.95; 0 in vacuum  [ref: en.pressure,
+                                   src/ui/panels/md_viewer.rs:246; src/properties/crystal.rs:526] */
 } mdx_energies;
 
 /* Counters and timers (md.computation_time() analogue, src/md/mod.rs:740-743). */
@@ -236,6 +239,10 @@ int mdx_get_stats(mdx_handle* h, mdx_stats* out);
 #define MDX_THERMOSTAT_BERENDSEN 1 /* lambda^2 = 1 + (Dt/tau)(T0/T - 1)                              */
 #define MDX_THERMOSTAT_CSVR      2 /* Bussi-Donadio-Parrinello stochastic velocity rescaling         */
 
+#define MDX_BAROSTAT_NONE      0
+#define MDX_BAROSTAT_BERENDSEN 1 /* mu^3 = 1 - compressibility (Dt/tau) (P0 - P); box and coordinates scaled by mu */
+#define MDX_BAR_PER_KCAL_MOL_A3 69476.95
+
 /* Steepest descent with an adaptive maximum displacement (start 0.01 Å; x += h F/|F|max; accepted
  * when the potential energy drops: h *= 1.2, else the move is undone and h *= 0.5); stops after
  * max_iters force evaluations or when max |F| < f_tol.  Velocities are left untouched. */
@@ -245,6 +252,16 @@ int mdx_minimize_energy(mdx_handle* h, uint32_t max_iters, const float* ext_forc
  * normals per atom in caller order) so that a given seed means the same velocities everywhere. */
 int mdx_initialize_velocities(mdx_handle* h, float temperature, int zero_com_drift, uint64_t seed);
 /* Velocity rescaling applied every `every_n_steps` steps (coupling interval Dt = every_n_steps*dt). */
+/* `BarostatCfg{tau, pressure_target}` (src/ui/panels/md.rs:517-557, src/properties/crystal.rs:312-315):
+ * weak-coupling (Berendsen-style) isotropic pressure control applied every `every_n_steps` steps: the
+ * pressure of the current state is evaluated (one energy-flavoured force pass), box edges and atom
+ * coordinates are scaled about box_lo by mu = cbrt(1 - compressibility (Dt/tau) (P0 - P)) (|mu - 1| capped
+ * at 1 %), the pair list is rebuilt and constrained clusters are re-projected.  Periodic systems on one
+ * device only; compressibility <= 0 selects water's 4.5e-5 / bar. */
+/* md.cell read-back: the current box (changes under the barostat). */
+int mdx_get_box(const mdx_handle* h, float lo[3], float hi[3]);
+int mdx_set_barostat(mdx_handle* h, int kind, float pressure_target_bar, float tau_ps, float compressibility_per_bar,
+                     uint32_t every_n_steps);
 int mdx_set_thermostat(mdx_handle* h, int kind, float temp_target, float tau_ps, uint32_t every_n_steps,
                        uint64_t seed);
 int mdx_set_zero_com_drift(mdx_handle* h, int enable);   /* removed at the thermostat cadence (or every 100 steps) */

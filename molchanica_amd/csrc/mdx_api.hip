@@ -140,7 +140,7 @@ static void free_device(mdx_handle* h) {
                     d.tile_col, d.scan_tmp, d.cl_lo, d.cl_hi, d.list_counts, d.entry_cnt, d.entry_off,
                     d.mchunk_cnt, d.mchunk_off, d.entries, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
                     d.role_off_s, d.role_rec_s, d.ctl, d.energy,
-                    d.flags_dev, d.bbox_red, d.pair_count, d.cons_o, d.cons_s, d.vsite_o, d.vsite_s, d.pme_q, d.pme_f,
+                    d.flags_dev, d.bbox_red, d.pair_count, d.cons_o, d.cons_s, d.cons_vir, d.vsite_o, d.vsite_s, d.pme_q, d.pme_f,
                     d.pme_theta};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = DeviceState{};
@@ -437,6 +437,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
     const uint32_t thr = stale_threshold_bits(h);
     uint32_t remaining = n_steps;
     while (remaining) {
+        MDX_TRY(ensure_ready(h));   // a barostat application at the last cadence point left the list to rebuild
         const uint32_t chunk = std::min(std::min(remaining, h->cfg.chunk_steps), mdx_steps_to_next_event(h));
         HIP_TRY(hipMemsetAsync(d.ctl, 0, sizeof(StepCtl), st));
         // Without constraints the closing half kick of step s and the opening one of step s+1 are
@@ -505,6 +506,7 @@ int mdx_energy_impl(mdx_handle* h, mdx_energies* out) {
     MDX_TRY(compute_forces(h, true, nullptr, 0));
     h->forces_valid = true;
     MDX_TRY(mdx_launch_kinetic(h));
+    MDX_TRY(mdx_launch_constraint_virial(h));   // SHAKE forces of the last step (0 after a dt = 0 projection)
     double e[EN_COUNT + 2];
     HIP_TRY(hipMemcpyAsync(e, h->d.energy, sizeof(e), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -523,6 +525,10 @@ int mdx_energy_impl(mdx_handle* h, mdx_energies* out) {
         out->volume = (double)(h->box_hi[0] - h->box_lo[0]) * (h->box_hi[1] - h->box_lo[1]) *
                       (h->box_hi[2] - h->box_lo[2]);
         out->density = h->total_mass / out->volume;
+        // W = sum r_i . F_i: pair + 1-4 + bonds + excluded-pair corrections + reciprocal sum + constraints;
+        // the uniform neutralising background of a charged cell scales as 1/V (W = 3 E), the Ewald self term not at all
+        out->virial = e[EN_VIRIAL] + (h->pme_on ? 3.0 * h->ewald_background : 0.0);
+        out->pressure = (2.0 * out->kinetic + out->virial) / (3.0 * out->volume) * MDX_BAR_PER_KCAL_MOL_A3;
     }
     uint32_t mf2; std::memcpy(&mf2, &e[EN_COUNT], 4);
     out->max_force = std::sqrt((double)u2f(mf2));

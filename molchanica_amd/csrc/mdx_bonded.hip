@@ -44,7 +44,7 @@ template <bool ENERGY>
 __global__ __launch_bounds__(256) void bonded_gather_kernel(BondedArgs a) {
     if (a.gate && *a.gate > a.thr_bits) return;
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    double e_bond = 0.0, e_angle = 0.0, e_dih = 0.0, e_lj14 = 0.0, e_c14 = 0.0, e_rec = 0.0;
+    double e_bond = 0.0, e_angle = 0.0, e_dih = 0.0, e_lj14 = 0.0, e_c14 = 0.0, e_rec = 0.0, e_vir = 0.0;
     if (s < a.S) {
         const uint32_t rb = a.role_off[s], re = a.role_off[s + 1];
         if (re > rb) {
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void bonded_gather_kernel(BondedArgs a) {
                     const float er = erff(br);
                     const float fs = -r.prm[0] * (er * rinv - 1.1283791671f * a.p.ewald_beta * __expf(-br * br)) * rinv * rinv;
                     fx += fs * d.x; fy += fs * d.y; fz += fs * d.z;
-                    if (ENERGY && role == 0) e_rec -= (double)(r.prm[0] * er * rinv);
+                    if (ENERGY && role == 0) { e_rec -= (double)(r.prm[0] * er * rinv); e_vir += (double)(fs * r2); }
                     continue;
                 }
                 if (a.p.skip_bonded) continue;
@@ -82,6 +82,9 @@ __global__ __launch_bounds__(256) void bonded_gather_kernel(BondedArgs a) {
                         }
                     }
                     fx += fs * d.x; fy += fs * d.y; fz += fs * d.z;
+                    // virial: central pair forces only - angle and dihedral energies do not change
+                    // under a uniform scaling, their sum r_i . F_i is identically zero
+                    if (ENERGY && role == 0) e_vir += (double)(fs * r2);
                 } else if (kind == ROLE_ANGLE) {
                     // ordered atoms i - j(apex) - k; this lane is atom `role`
                     const float4 q0 = a.posq[r.p[0]], q1 = a.posq[r.p[1]];
@@ -145,10 +148,10 @@ __global__ __launch_bounds__(256) void bonded_gather_kernel(BondedArgs a) {
         }
     }
     if (ENERGY) {
-        double v[6] = {e_bond, e_angle, e_dih, e_lj14, e_c14, e_rec};
-        const int slot[6] = {EN_BOND, EN_ANGLE, EN_DIHEDRAL, EN_LJ14, EN_COUL14, EN_RECIP};
+        double v[7] = {e_bond, e_angle, e_dih, e_lj14, e_c14, e_rec, e_vir};
+        const int slot[7] = {EN_BOND, EN_ANGLE, EN_DIHEDRAL, EN_LJ14, EN_COUL14, EN_RECIP, EN_VIRIAL};
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
+        for (int q = 0; q < 7; ++q) {
             double t = v[q];
 #pragma unroll
             for (int m = 32; m > 0; m >>= 1) t += __shfl_xor(t, m);

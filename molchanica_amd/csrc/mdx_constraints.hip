@@ -39,6 +39,7 @@ __device__ __forceinline__ float3 mimg3(float3 d, const ConsParams& p) {
 __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_groups, const ConsGroup* __restrict__ groups,
                                                                   float4* __restrict__ posq, float4* __restrict__ vel,
                                                                   const float4* __restrict__ ref, float dt, ConsParams p,
+                                                                  float* __restrict__ cons_vir,
                                                                   const uint32_t* gate, uint32_t* disp_out, uint32_t thr) {
     if (gate && *gate > thr) return;
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -64,6 +65,10 @@ __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_gro
         float3 xs[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) xs[k] = xn[k];
+        // Constraint virial.  A correction gk*im[a]*r of atom a is the work of a force G = 2 gk r / dt^2
+        // (kcal/mol/A: im = 418.4/m, and the force acts through the half kick dt/2 and the drift dt) along
+        // the OLD bond vector r; its contribution to sum r_i . F_i is G . (r_a - r_b) = 2 gk |r|^2 / dt^2.
+        float wc = 0.f;
         for (int it = 0; it < p.max_iter; ++it) {
             bool done = true;
 #pragma unroll
@@ -78,6 +83,7 @@ __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_gro
                     const float3 r = make_float3(xo[a].x - xo[b].x, xo[a].y - xo[b].y, xo[a].z - xo[b].z);
                     const float sr = s.x * r.x + s.y * r.y + s.z * r.z;
                     const float gk = diff / (2.0f * sr * (im[a] + im[b]));
+                    wc += gk * (r.x * r.x + r.y * r.y + r.z * r.z);
                     xn[a].x += gk * im[a] * r.x; xn[a].y += gk * im[a] * r.y; xn[a].z += gk * im[a] * r.z;
                     xn[b].x -= gk * im[b] * r.x; xn[b].y -= gk * im[b] * r.y; xn[b].z -= gk * im[b] * r.z;
                 }
@@ -85,6 +91,7 @@ __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_gro
             if (done) break;
         }
         const float idt = dt != 0.f ? 1.0f / dt : 0.f;
+        if (cons_vir) cons_vir[g] = 2.0f * wc * idt * idt;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k >= (int)cg.natoms) break;
@@ -276,6 +283,9 @@ int mdx_build_constraints(mdx_handle* h, const mdx_system* s) {
         if (h->d.cons_s) (void)hipFree(h->d.cons_s);
         HIP_TRY(hipMalloc((void**)&h->d.cons_o, sizeof(ConsGroup) * groups.size()));
         HIP_TRY(hipMalloc((void**)&h->d.cons_s, sizeof(ConsGroup) * groups.size()));
+        if (h->d.cons_vir) (void)hipFree(h->d.cons_vir);
+        HIP_TRY(hipMalloc((void**)&h->d.cons_vir, sizeof(float) * groups.size()));
+        HIP_TRY(hipMemsetAsync(h->d.cons_vir, 0, sizeof(float) * groups.size(), st));
         HIP_TRY(hipMemcpyAsync(h->d.cons_o, groups.data(), sizeof(ConsGroup) * groups.size(), hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
@@ -320,7 +330,23 @@ int mdx_remap_constraints(mdx_handle* h) {
 int mdx_launch_constrain_positions(mdx_handle* h, float dt, const uint32_t* d_gate, uint32_t* d_disp_out, uint32_t thr) {
     if (!h->n_groups) return MDX_OK;
     hipLaunchKernelGGL(constrain_positions_kernel, dim3(div_up(h->n_groups, 128)), dim3(128), 0, h->stream, h->n_groups,
-                       h->d.cons_s, h->d.posq, h->d.vel, h->d.ref, dt, cons_params(h), d_gate, d_disp_out, thr);
+                       h->d.cons_s, h->d.posq, h->d.vel, h->d.ref, dt, cons_params(h), h->d.cons_vir, d_gate, d_disp_out, thr);
+    HIP_TRY(hipGetLastError());
+    return MDX_OK;
+}
+
+__global__ __launch_bounds__(256) void constraint_virial_kernel(uint32_t n, const float* __restrict__ cons_vir, double* energy) {
+    double w = 0.0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) w += (double)cons_vir[i];
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) w += __shfl_xor(w, m);
+    if ((threadIdx.x & 63) == 0 && w != 0.0) atomicAdd(&energy[EN_VIRIAL], w);
+}
+
+int mdx_launch_constraint_virial(mdx_handle* h) {
+    if (!h->n_groups || !h->d.cons_vir) return MDX_OK;
+    hipLaunchKernelGGL(constraint_virial_kernel, dim3(std::min<uint32_t>(div_up(h->n_groups, 256), 256u)), dim3(256), 0, h->stream,
+                       h->n_groups, h->d.cons_vir, h->d.energy);
     HIP_TRY(hipGetLastError());
     return MDX_OK;
 }

@@ -149,6 +149,37 @@ static int apply_thermostat(mdx_handle* h, double dt_couple) {
     return mdx_launch_scale_velocities(h, (float)lambda, nullptr);
 }
 
+// Weak-coupling barostat: BarostatCfg{tau, pressure_target} (src/ui/panels/md.rs:517-557).  Coordinates
+// (caller-order staging, where mdx_set_box expects the state) and the box edges are scaled about
+// box_lo; the pair list, the cell grid and the PME mesh follow through mdx_set_box + rebuild.
+__global__ void scale_positions_kernel(uint32_t N, float4* __restrict__ pos, float lox, float loy, float loz, float mu) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float4 p = pos[i];
+    p.x = lox + mu * (p.x - lox); p.y = loy + mu * (p.y - loy); p.z = loz + mu * (p.z - loz);
+    pos[i] = p;
+}
+
+static int apply_barostat(mdx_handle* h, double dt_couple) {
+    mdx_energies e;
+    MDX_TRY(mdx_energy_impl(h, &e));
+    if (!std::isfinite(e.pressure)) return MDX_OK;
+    const double mu3 = 1.0 - (double)h->baro_beta * dt_couple / (double)h->baro_tau * ((double)h->baro_p0 - e.pressure);
+    double mu = std::cbrt(std::max(mu3, 0.5));
+    mu = std::min(1.01, std::max(0.99, mu));
+    if (mu == 1.0) return MDX_OK;
+    MDX_TRY(mdx_unsort_state(h));
+    hipLaunchKernelGGL(scale_positions_kernel, dim3(div_up(h->n_local, 256)), dim3(256), 0, h->stream, h->n_local,
+                       h->d.pos_orig, h->box_lo[0], h->box_lo[1], h->box_lo[2], (float)mu);
+    HIP_TRY(hipGetLastError());
+    float hi[3];
+    for (int d = 0; d < 3; ++d) hi[d] = h->box_lo[d] + (float)mu * (h->box_hi[d] - h->box_lo[d]);
+    MDX_TRY(mdx_set_box(h, h->box_lo, hi));
+    if (h->n_groups) h->cons_dirty = true;   // bonds of constrained clusters were scaled too: project back
+    h->last_pressure = e.pressure; h->last_mu = mu;
+    return MDX_OK;
+}
+
 static int take_snapshot(mdx_handle* h) {
     mdx_handle::Snapshot sn;
     sn.time = h->time_ps; sn.step = h->step_count;
@@ -168,6 +199,7 @@ uint32_t mdx_steps_to_next_event(const mdx_handle* h) {
     auto upd = [&](uint32_t every) { if (every) n = std::min<uint32_t>(n, every - (uint32_t)(h->step_count % every)); };
     if (h->tstat_kind) upd(h->tstat_every);
     if (h->zero_com) upd(h->tstat_kind ? h->tstat_every : 100u);
+    if (h->baro_kind) upd(h->baro_every);
     upd(h->snap_every);
     return n;
 }
@@ -177,6 +209,7 @@ int mdx_after_steps(mdx_handle* h, float dt, uint32_t done) {
     const uint64_t sc = h->step_count;
     if (h->zero_com && sc % (h->tstat_kind ? h->tstat_every : 100u) == 0) MDX_TRY(remove_com(h));
     if (h->tstat_kind && sc % h->tstat_every == 0) MDX_TRY(apply_thermostat(h, (double)dt * h->tstat_every));
+    if (h->baro_kind && sc % h->baro_every == 0) MDX_TRY(apply_barostat(h, (double)dt * h->baro_every));
     if (h->snap_every && sc % h->snap_every == 0) MDX_TRY(take_snapshot(h));
     return MDX_OK;
 }
@@ -190,6 +223,28 @@ extern "C" int mdx_set_thermostat(mdx_handle* h, int kind, float temp_target, fl
         FAIL(MDX_EPARAM, "thermostat needs temp_target >= 0, tau > 0 and a coupling interval >= 1 step");
     h->tstat_kind = kind; h->tstat_temp = temp_target; h->tstat_tau = tau_ps;
     h->tstat_every = every_n_steps ? every_n_steps : 10; h->rng_state = seed;
+    return MDX_OK;
+}
+
+extern "C" int mdx_get_box(const mdx_handle* h, float lo[3], float hi[3]) {
+    if (!h || !lo || !hi) FAIL(MDX_EPARAM, "null argument");
+    for (int d = 0; d < 3; ++d) { lo[d] = h->box_lo[d]; hi[d] = h->box_hi[d]; }
+    return MDX_OK;
+}
+
+extern "C" int mdx_set_barostat(mdx_handle* h, int kind, float pressure_target_bar, float tau_ps,
+                                float compressibility_per_bar, uint32_t every_n_steps) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    if (kind < 0 || kind > 1) FAIL(MDX_EPARAM, "unknown barostat kind");
+    if (kind) {
+        if (!h->periodic || !(h->per[0] && h->per[1] && h->per[2])) FAIL(MDX_EPARAM, "the barostat needs a fully periodic box");
+        if (h->n_local != h->N) FAIL(MDX_EPARAM, "the barostat is not supported on a decomposed handle");
+        if (!(tau_ps > 0.f) || every_n_steps == 0 || !std::isfinite(pressure_target_bar))
+            FAIL(MDX_EPARAM, "barostat needs a finite target, tau > 0 and a coupling interval >= 1 step");
+    }
+    h->baro_kind = kind; h->baro_p0 = pressure_target_bar; h->baro_tau = tau_ps;
+    h->baro_beta = compressibility_per_bar > 0.f ? compressibility_per_bar : 4.5e-5f;
+    h->baro_every = every_n_steps ? every_n_steps : 25;
     return MDX_OK;
 }
 

@@ -30,7 +30,7 @@
 #define MDX_DUMMY_STEP 64.0f
 #define MDX_MAX_CHUNK 64
 
-enum { EN_BOND = 0, EN_ANGLE, EN_DIHEDRAL, EN_LJ, EN_COUL, EN_LJ14, EN_COUL14, EN_KIN, EN_RECIP, EN_COUNT };
+enum { EN_BOND = 0, EN_ANGLE, EN_DIHEDRAL, EN_LJ, EN_COUL, EN_LJ14, EN_COUL14, EN_KIN, EN_RECIP, EN_VIRIAL, EN_COUNT };
 
 struct GridParams {
     float lo[3];       // origin of the column grid (box_lo, or bounding box in vacuum)
@@ -150,6 +150,7 @@ struct DeviceState {
     float* pme_q = nullptr; float2* pme_f = nullptr; float* pme_theta = nullptr;
     // constraints and virtual sites
     ConsGroup* cons_o = nullptr; ConsGroup* cons_s = nullptr;
+    float* cons_vir = nullptr;     // per constraint cluster: r . G of the last SHAKE position stage (kcal/mol)
     VSite* vsite_o = nullptr; VSite* vsite_s = nullptr;
     // control / reductions
     StepCtl* ctl = nullptr;
@@ -207,6 +208,8 @@ struct mdx_handle {
     mdx_stats stats{};
     // thermostat / COM / snapshots
     int tstat_kind = 0; float tstat_temp = 300.f, tstat_tau = 1.f; uint32_t tstat_every = 10;
+    int baro_kind = 0; float baro_p0 = 1.f, baro_tau = 5.f, baro_beta = 4.5e-5f; uint32_t baro_every = 25;
+    double last_pressure = 0.0, last_mu = 1.0;
     uint64_t rng_state = 0;
     bool zero_com = false;
     uint32_t snap_every = 0; bool snap_vel = false;
@@ -262,6 +265,7 @@ int mdx_remap_constraints(mdx_handle* h);                  // caller order -> sl
 int mdx_launch_constrain_positions(mdx_handle* h, float dt, const uint32_t* d_gate, uint32_t* d_disp_out, uint32_t thr);
 int mdx_launch_constrain_velocities(mdx_handle* h, const uint32_t* d_gate, uint32_t thr);
 int mdx_launch_vsite_construct(mdx_handle* h, const uint32_t* d_gate, uint32_t thr);
+int mdx_launch_constraint_virial(mdx_handle* h);   // energy[EN_VIRIAL] += sum of cons_vir
 int mdx_launch_vsite_spread(mdx_handle* h, const uint32_t* d_gate, uint32_t thr);
 
 // SPME reciprocal space (mdx_pme.hip)

@@ -61,7 +61,7 @@ template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, bool BRANCHY, bool HAL
 __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi, float sgi, float epi,
                                           const float4 pj, const float2 lj, bool allowed, const NbParams& p,
                                           float& fx, float& fy, float& fz, double& elj, double& ecoul,
-                                          float* g = nullptr) {
+                                          float* g = nullptr, double* evir = nullptr) {
     const float dx = xi - pj.x, dy = yi - pj.y, dz = zi - pj.z;   // tgt - src (src/cuda/util.cu:118-140)
     const float r2 = dx * dx + dy * dy + dz * dz;
     const bool in_lj = (r2 < p.rc2_lj) && allowed;
@@ -103,6 +103,7 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
         else e_c = qq * erfc_ar * rinv;
         elj += in_lj ? (double)e_l : 0.0;
         ecoul += in_c ? (double)e_c : 0.0;
+        if (evir) *evir += (double)(fs * r2);   // r_ij . F_ij of the pair (fs = 0 outside the cutoffs)
     }
 }
 
@@ -110,12 +111,12 @@ template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, bool MASKED>
 __device__ __forceinline__ void chunk_pairs(const float4* __restrict__ sx, const float2* __restrict__ sl,
                                             unsigned long long mask, float xi, float yi, float zi, float qi,
                                             float sgi, float epi, const NbParams& p, float& fx, float& fy,
-                                            float& fz, double& elj, double& ecoul) {
+                                            float& fz, double& elj, double& ecoul, double& evir) {
 #pragma unroll 8
     for (int jj = 0; jj < 64; ++jj) {
         const bool allowed = MASKED ? (bool)((mask >> jj) & 1ull) : true;
         pair_eval<ENERGY, COUL, GEOM, SAMECUT, false>(xi, yi, zi, qi, sgi, epi, sx[jj], sl[jj], allowed, p, fx, fy, fz,
-                                               elj, ecoul);
+                                               elj, ecoul, nullptr, ENERGY ? &evir : nullptr);
     }
 }
 
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(NB_WAVES * 64) void nb_tile_kernel(NbArgs a) {
     float2* sl = s_lj[wave];
 
     float fx = 0.f, fy = 0.f, fz = 0.f;
-    double elj = 0.0, ecoul = 0.0;
+    double elj = 0.0, ecoul = 0.0, evir = 0.0;
 
     // prefetch chunk 0
     float4 nj = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -173,24 +174,26 @@ __global__ __launch_bounds__(NB_WAVES * 64) void nb_tile_kernel(NbArgs a) {
         if (c < nmc) {
             const unsigned long long m = a.masks[(size_t)(mbase + c) * 64 + lane];
             chunk_pairs<ENERGY, COUL, GEOM, SAMECUT, true>(sx, sl, m, pi.x, pi.y, pi.z, pi.w, li.x, li.y, a.p,
-                                                           fx, fy, fz, elj, ecoul);
+                                                           fx, fy, fz, elj, ecoul, evir);
         } else {
             chunk_pairs<ENERGY, COUL, GEOM, SAMECUT, false>(sx, sl, ~0ull, pi.x, pi.y, pi.z, pi.w, li.x, li.y,
-                                                            a.p, fx, fy, fz, elj, ecoul);
+                                                            a.p, fx, fy, fz, elj, ecoul, evir);
         }
         WAVE_LDS_SYNC();
     }
     a.force[islot] = make_float4(fx, fy, fz, 0.f);
     if (ENERGY) {
-        if (!(a.slot_flags[islot] & 2u)) { elj = 0.0; ecoul = 0.0; }
+        if (!(a.slot_flags[islot] & 2u)) { elj = 0.0; ecoul = 0.0; evir = 0.0; }
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) {
             elj += __shfl_xor(elj, m);
             ecoul += __shfl_xor(ecoul, m);
+            evir += __shfl_xor(evir, m);
         }
         if (lane == 0) {   // every pair is seen from both sides
             atomicAdd(&a.energy[EN_LJ], 0.5 * elj);
             atomicAdd(&a.energy[EN_COUL], 0.5 * ecoul);
+            atomicAdd(&a.energy[EN_VIRIAL], 0.5 * evir);
         }
     }
 }
@@ -265,7 +268,7 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, (HALF && NB
     const uint32_t mbase = a.mchunk_off[t];
     float4* sx = s_xyzq[wave];
     float2* sl = s_lj[wave];
-    double elj = 0.0, ecoul = 0.0;
+    double elj = 0.0, ecoul = 0.0, evir = 0.0;
     uint32_t own_bits = 0xFFu;   // ENERGY only: bit ci set <=> i-atom (ci, ii) is owned by this rank
     if (ENERGY) {
         own_bits = 0;
@@ -360,14 +363,14 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, (HALF && NB
 #pragma unroll
             for (int ci = 0; ci < 8; ++ci) {
                 if (im & (1u << ci)) {
-                    double e1 = 0.0, e2 = 0.0;
+                    double e1 = 0.0, e2 = 0.0, e3 = 0.0;
                     pair_eval<ENERGY, COUL, GEOM, SAMECUT, true, HALF>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci],
                                                                        pj, lj, (m8 >> ci) & 1u, a.p, fx[ci], fy[ci],
-                                                                       fz[ci], e1, e2, g);
+                                                                       fz[ci], e1, e2, g, ENERGY ? &e3 : nullptr);
                     if (ENERGY && HALF) {   // a pair's energy is split between the owners of its two atoms
                         const double w = (double)(wj + (((own_bits >> ci) & 1u) ? 0.5f : 0.f));
-                        elj += w * e1; ecoul += w * e2;
-                    } else if (ENERGY && ((own_bits >> ci) & 1u)) { elj += e1; ecoul += e2; }
+                        elj += w * e1; ecoul += w * e2; evir += w * e3;
+                    } else if (ENERGY && ((own_bits >> ci) & 1u)) { elj += e1; ecoul += e2; evir += e3; }
                 }
             }
             if (HALF) {
@@ -438,10 +441,12 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, (HALF && NB
         for (int m = 32; m > 0; m >>= 1) {
             elj += __shfl_xor(elj, m);
             ecoul += __shfl_xor(ecoul, m);
+            evir += __shfl_xor(evir, m);
         }
         if (lane == 0) {   // full list: every pair is seen from both sides
             atomicAdd(&a.energy[EN_LJ], HALF ? elj : 0.5 * elj);
             atomicAdd(&a.energy[EN_COUL], HALF ? ecoul : 0.5 * ecoul);
+            atomicAdd(&a.energy[EN_VIRIAL], HALF ? evir : 0.5 * evir);
         }
     }
 }

@@ -99,12 +99,13 @@ __global__ __launch_bounds__(256) void pme_spread_kernel(uint32_t S, const float
 }
 
 template <bool ENERGY>
-__global__ __launch_bounds__(256) void pme_solve_kernel(size_t n, int K3h, int K3, float2* __restrict__ F,
+__global__ __launch_bounds__(256) void pme_solve_kernel(size_t n, int K1, int K2, int K3h, int K3, float3 inv_len,
+                                                        float pi2_over_beta2, float2* __restrict__ F,
                                                         const float* __restrict__ theta, double* energy,
                                                         const uint32_t* gate, uint32_t thr) {
     if (gate && *gate > thr) return;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    double e = 0.0;
+    double e = 0.0, w = 0.0;
     if (i < n) {
         const float t = theta[i];
         float2 f = F[i];
@@ -112,14 +113,22 @@ __global__ __launch_bounds__(256) void pme_solve_kernel(size_t n, int K3h, int K
             const int k3 = (int)(i % (size_t)K3h);
             const float mult = (k3 == 0 || (2 * k3 == K3)) ? 1.0f : 2.0f;
             e = 0.5 * (double)(mult * t * (f.x * f.x + f.y * f.y));
+            // scalar virial of the reciprocal sum: sum_m E_m (1 - 2 pi^2 m^2 / beta^2)  (= -dE/dlambda
+            // under r -> lambda r, L -> lambda L; the B-spline moduli and S(m) do not change)
+            const size_t ij = i / (size_t)K3h;
+            const int k2 = (int)(ij % (size_t)K2), k1 = (int)(ij / (size_t)K2);
+            const float m1 = (float)(k1 <= K1 / 2 ? k1 : k1 - K1) * inv_len.x;
+            const float m2 = (float)(k2 <= K2 / 2 ? k2 : k2 - K2) * inv_len.y;
+            const float m3 = (float)k3 * inv_len.z;
+            w = e * (1.0 - 2.0 * (double)(pi2_over_beta2 * (m1 * m1 + m2 * m2 + m3 * m3)));
         }
         f.x *= t; f.y *= t;
         F[i] = f;
     }
     if (ENERGY) {
 #pragma unroll
-        for (int m = 32; m > 0; m >>= 1) e += __shfl_xor(e, m);
-        if ((threadIdx.x & 63) == 0 && e != 0.0) atomicAdd(&energy[EN_RECIP], e);
+        for (int m = 32; m > 0; m >>= 1) { e += __shfl_xor(e, m); w += __shfl_xor(w, m); }
+        if ((threadIdx.x & 63) == 0 && e != 0.0) { atomicAdd(&energy[EN_RECIP], e); atomicAdd(&energy[EN_VIRIAL], w); }
     }
 }
 
@@ -280,10 +289,12 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
                        h->d.slot_flags, p->dev, h->d.pme_q, d_gate, thr);
     if (p->exec_r2c(p->fwd, h->d.pme_q, (hipfftComplex*)h->d.pme_f) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecR2C failed");
     const dim3 gs((unsigned)((p->n_cplx + 255) / 256));
-    if (energy) hipLaunchKernelGGL(pme_solve_kernel<true>, gs, dim3(256), 0, st, p->n_cplx, K3h, h->pme_K[2], h->d.pme_f,
-                                   h->d.pme_theta, h->d.energy, d_gate, thr);
-    else hipLaunchKernelGGL(pme_solve_kernel<false>, gs, dim3(256), 0, st, p->n_cplx, K3h, h->pme_K[2], h->d.pme_f,
-                            h->d.pme_theta, h->d.energy, d_gate, thr);
+    const float3 inv_len = make_float3(p->dev.inv_len[0], p->dev.inv_len[1], p->dev.inv_len[2]);
+    const float pb = (float)(M_PI * M_PI / ((double)h->cfg.ewald_alpha * h->cfg.ewald_alpha));
+    if (energy) hipLaunchKernelGGL(pme_solve_kernel<true>, gs, dim3(256), 0, st, p->n_cplx, h->pme_K[0], h->pme_K[1], K3h,
+                                   h->pme_K[2], inv_len, pb, h->d.pme_f, h->d.pme_theta, h->d.energy, d_gate, thr);
+    else hipLaunchKernelGGL(pme_solve_kernel<false>, gs, dim3(256), 0, st, p->n_cplx, h->pme_K[0], h->pme_K[1], K3h,
+                            h->pme_K[2], inv_len, pb, h->d.pme_f, h->d.pme_theta, h->d.energy, d_gate, thr);
     if (p->exec_c2r(p->inv, (hipfftComplex*)h->d.pme_f, h->d.pme_q) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecC2R failed");
     hipLaunchKernelGGL(pme_gather_kernel, dim3(div_up(h->S, 256)), dim3(256), 0, st, h->S, h->d.posq, h->d.slot_flags,
                        p->dev, h->d.pme_q, h->d.force, d_gate, thr);

@@ -84,6 +84,8 @@ def load_library():
     lib.mdx_minimize_energy.argtypes = [H, C.c_uint32, _fp, C.c_float, C.POINTER(CEnergies), _u32p]
     lib.mdx_initialize_velocities.argtypes = [H, C.c_float, C.c_int, C.c_uint64]
     lib.mdx_set_thermostat.argtypes = [H, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_uint64]
+    lib.mdx_set_barostat.argtypes = [H, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint32]
+    lib.mdx_get_box.argtypes = [H, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.mdx_set_zero_com_drift.argtypes = [H, C.c_int]
     lib.mdx_set_snapshot_cadence.argtypes = [H, C.c_uint32, C.c_int]
     lib.mdx_snapshot_count.argtypes = [H]
@@ -245,6 +247,18 @@ class MdState:
         """`Integrator::VerletVelocity{thermostat: Some(tau)}` + `temp_target`; kind 1 Berendsen, 2 CSVR."""
         _check(load_library().mdx_set_thermostat(self._h, int(kind), float(temp_target), float(tau_ps),
                                                  int(every_n_steps), int(seed)))
+
+    def set_barostat(self, kind: int, pressure_target_bar: float = 1.0, tau_ps: float = 5.0,
+                     compressibility_per_bar: float = 4.5e-5, every_n_steps: int = 25):
+        """`MdConfig.barostat_cfg = Some(BarostatCfg{tau, pressure_target})` (md.rs:517-557); kind 1 Berendsen."""
+        _check(load_library().mdx_set_barostat(self._h, int(kind), float(pressure_target_bar), float(tau_ps),
+                                               float(compressibility_per_bar), int(every_n_steps)))
+
+    def cell(self):
+        """`md.cell` -> (bounds_low, bounds_high)."""
+        lo = (C.c_float * 3)(); hi = (C.c_float * 3)()
+        _check(load_library().mdx_get_box(self._h, lo, hi))
+        return np.array(lo[:], np.float32), np.array(hi[:], np.float32)
 
     def set_zero_com_drift(self, enable: bool = True):
         _check(load_library().mdx_set_zero_com_drift(self._h, int(enable)))

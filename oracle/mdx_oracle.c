@@ -34,7 +34,9 @@
 #define ACC_CONV 418.4          /* kcal/mol/Å/Da -> Å/ps² */
 #define KB_KCAL  0.0019872041   /* kcal/mol/K */
 
-enum { E_BOND, E_ANGLE, E_DIHEDRAL, E_LJ, E_COUL, E_LJ14, E_COUL14, E_KIN, E_N };
+enum { E_BOND, E_ANGLE, E_DIHEDRAL, E_LJ, E_COUL, E_LJ14, E_COUL14, E_KIN, E_VIRIAL, E_N };
+/* E_VIRIAL: W = sum_i r_i . F_i of the internal forces (pairs, 1-4, bonds; angle and dihedral terms are
+ * scale invariant and contribute exactly 0), kcal/mol.  Pressure = (2 KE + W + W_constraints) / (3 V). */
 
 int orc_num_energies(void) { return E_N; }
 int orc_max_threads(void) {
@@ -198,6 +200,7 @@ static void bonded_forces(const mdx_system* s, const mdx_config* c, const double
         double dr = r - (double)s->bond_r0[b], k = s->bond_k[b];
         en[E_BOND] += k * dr * dr;
         double fs = -2.0 * k * dr / r;
+        en[E_VIRIAL] += fs * r * r;
         for (int a = 0; a < 3; ++a) { f[3*i+a] += fs * d[a]; f[3*j+a] -= fs * d[a]; }
     }
     for (uint32_t t = 0; t < s->n_angles; ++t) {
@@ -275,6 +278,7 @@ static void bonded_forces(const mdx_system* s, const mdx_config* c, const double
             fs += kqq * inv_r * inv_r * inv_r;
             en[E_COUL14] += kqq * inv_r;
         }
+        en[E_VIRIAL] += fs * r2;
         for (int a = 0; a < 3; ++a) { f[3*i+a] += fs * d[a]; f[3*j+a] -= fs * d[a]; }
     }
 }
@@ -377,8 +381,15 @@ static double inv_mass(const mdx_system* s, uint32_t i) {
     if (s->flags && (s->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST))) return 0.0;
     return 1.0 / (double)s->mass[i];
 }
+/* Constraint virial of the last SHAKE position stage (kcal/mol): a correction g*rv/m_a of atom a is the
+ * work of a force G = 2 m_a dx_a / dt^2 = 2 g rv / dt^2 (it acts through the half kick and the drift of
+ * velocity Verlet) along the old bond vector rv; sum r_i . G_i = 2 g |rv|^2 / dt^2 per correction. */
+static double g_last_cons_virial = 0.0;
+double orc_last_constraint_virial(void) { return g_last_cons_virial; }
+
 /* SHAKE: x (new) corrected along the old bond vectors x_old; if v != NULL, v += dx/dt. */
 int orc_constrain_positions(const mdx_system* s, double* x, const double* x_old, double* v, double dt, double tol) {
+    double wc = 0.0;
     uint32_t N = s->n_atoms;
     double* x0 = (double*)malloc(sizeof(double) * 3 * N);
     memcpy(x0, x, sizeof(double) * 3 * N);
@@ -396,11 +407,13 @@ int orc_constrain_positions(const mdx_system* s, double* x, const double* x_old,
                 done = 0;
                 double ima = inv_mass(s, a), imb = inv_mass(s, b);
                 double g = diff / (2.0 * (sv[0]*rv[0] + sv[1]*rv[1] + sv[2]*rv[2]) * (ima + imb));
+                wc += g * (rv[0]*rv[0] + rv[1]*rv[1] + rv[2]*rv[2]);
                 for (int k = 0; k < 3; ++k) { x[3*a+k] += g * ima * rv[k]; x[3*b+k] -= g * imb * rv[k]; }
             }
         }
         if (done) break;
     }
+    g_last_cons_virial = dt != 0.0 ? 2.0 * wc / (dt * dt) / ACC_CONV : 0.0;
     if (v && dt != 0.0) for (uint32_t i = 0; i < 3 * N; ++i) v[i] += (x[i] - x0[i]) / dt;
     free(x0);
     return it;
@@ -452,9 +465,9 @@ int orc_forces(const mdx_system* s, const mdx_config* c, const double* x_in, con
     if (use_cells && !(cut_lj && cut_c)) use_cells = 0;
 
     grid_t g; if (use_cells) g = build_grid(s, x, rmax);
-    double e_lj = 0.0, e_c = 0.0;
+    double e_lj = 0.0, e_c = 0.0, w_nb = 0.0;
 
-#pragma omp parallel for schedule(dynamic, 64) reduction(+ : e_lj, e_c)
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : e_lj, e_c, w_nb)
     for (uint32_t i = 0; i < N; ++i) {
         if (!nb_active(s, i)) continue;
         double fi[3] = { 0, 0, 0 };
@@ -489,12 +502,12 @@ int orc_forces(const mdx_system* s, const mdx_config* c, const double* x_in, con
                 double fs, el = 0.0, ec = 0.0;
                 pair_terms(c, sig, eps, qq, r2, in_lj, in_c, &fs, &el, &ec);
                 fi[0] += fs * d[0]; fi[1] += fs * d[1]; fi[2] += fs * d[2];
-                e_lj += 0.5 * el; e_c += 0.5 * ec;
+                e_lj += 0.5 * el; e_c += 0.5 * ec; w_nb += 0.5 * fs * r2;
             }
         }
         f[3*i] = fi[0]; f[3*i+1] = fi[1]; f[3*i+2] = fi[2];
     }
-    en[E_LJ] = e_lj; en[E_COUL] = e_c;
+    en[E_LJ] = e_lj; en[E_COUL] = e_c; en[E_VIRIAL] = w_nb;
     bonded_forces(s, c, x, f, en);
     orc_vsite_spread(s, f);
     if (ext) for (uint32_t i = 0; i < 3 * N; ++i) f[i] += ext[i];
@@ -764,6 +777,71 @@ int orc_step_thermo(const mdx_system* s, const mdx_config* c, double* x, double*
         if (temps_out) temps_out[k++] = 2.0 * orc_kinetic(s, v) / (nf * KB_KCAL);
     }
     return 0;
+}
+
+/* Pressure (bar) of a state: en from orc_forces at x, ke in kcal/mol, w_cons from the last SHAKE. */
+double orc_pressure(const mdx_system* s, const double* en, double ke, double w_cons) {
+    if (!s->periodic) return 0.0;
+    double V = ((double)s->box_hi[0] - s->box_lo[0]) * ((double)s->box_hi[1] - s->box_lo[1]) * ((double)s->box_hi[2] - s->box_lo[2]);
+    return (2.0 * ke + en[E_VIRIAL] + w_cons) / (3.0 * V) * 69476.95;
+}
+
+/* Velocity Verlet with thermostat and a weak-coupling (Berendsen-style) barostat, both at their own
+ * cadence, in the order mdx_after_steps applies them: COM removal, thermostat, barostat.  The
+ * barostat scales the box edges and all coordinates about box_lo by
+ * mu = cbrt(1 - beta (n dt / tau_p) (P0 - P)), |mu - 1| <= 1 %, then re-projects constrained clusters.
+ * box_hi_io[3]: in = starting box_hi, out = final.  p_out/vol_out: one value per barostat application. */
+int orc_step_npt(const mdx_system* s_in, const mdx_config* c, double* x, double* v, double dt, uint32_t n_steps,
+                 int tkind, double temp_target, double tau_t, uint32_t every_t, uint64_t seed,
+                 int bkind, double p0, double tau_p, double beta, uint32_t every_b,
+                 float* box_hi_io, double* p_out, double* vol_out, int use_cells) {
+    mdx_system s = *s_in;
+    for (int a = 0; a < 3; ++a) s.box_hi[a] = box_hi_io[a];
+    double en[E_N];
+    uint64_t rng = seed;
+    double nf = orc_dof(&s);
+    uint32_t N = s.n_atoms, kb = 0;
+    double* f = (double*)malloc(sizeof(double) * 3 * (N ? N : 1));
+    if (!tkind) every_t = 0;
+    if (!bkind) every_b = 0;
+    uint32_t st = 0;
+    while (st < n_steps) {
+        uint32_t n = n_steps - st;
+        if (every_t && every_t - st % every_t < n) n = every_t - st % every_t;
+        if (every_b && every_b - st % every_b < n) n = every_b - st % every_b;
+        orc_step(&s, c, x, v, dt, n, NULL, en, use_cells);
+        st += n;
+        if (every_t && st % every_t == 0) {
+            double ke = orc_kinetic(&s, v);
+            double lam = orc_thermostat_lambda(tkind, ke, nf, temp_target, tau_t, dt * every_t, &rng);
+            for (uint32_t i = 0; i < 3 * N; ++i) v[i] *= lam;
+        }
+        if (every_b && st % every_b == 0) {
+            double wc = s.n_constraints ? g_last_cons_virial : 0.0;
+            orc_forces(&s, c, x, NULL, f, en, use_cells);
+            double P = orc_pressure(&s, en, orc_kinetic(&s, v), wc);
+            double mu3 = 1.0 - beta * dt * every_b / tau_p * (p0 - P);
+            double mu = cbrt(mu3 > 0.5 ? mu3 : 0.5);
+            if (mu > 1.01) mu = 1.01; if (mu < 0.99) mu = 0.99;
+            for (uint32_t i = 0; i < N; ++i) for (int a = 0; a < 3; ++a)
+                x[3*i+a] = (double)s.box_lo[a] + mu * (x[3*i+a] - (double)s.box_lo[a]);
+            for (int a = 0; a < 3; ++a) s.box_hi[a] = s.box_lo[a] + (float)mu * (s.box_hi[a] - s.box_lo[a]);
+            if (s.n_constraints) {
+                double* xo = (double*)malloc(sizeof(double) * 3 * N);
+                memcpy(xo, x, sizeof(double) * 3 * N);
+                orc_constrain_positions(&s, x, xo, NULL, 0.0, 1e-12);
+                orc_constrain_velocities(&s, x, v, 1e-12);
+                free(xo);
+            }
+            orc_vsite_construct(&s, x);
+            if (p_out) p_out[kb] = P;
+            if (vol_out) vol_out[kb] = ((double)s.box_hi[0] - s.box_lo[0]) * ((double)s.box_hi[1] - s.box_lo[1]) * ((double)s.box_hi[2] - s.box_lo[2]);
+            ++kb;
+        }
+    }
+    for (int a = 0; a < 3; ++a) box_hi_io[a] = s.box_hi[a];
+    free(f);
+    return (int)kb;
 }
 
 /* Steepest descent with adaptive maximum displacement (same rule as mdx_minimize_energy).

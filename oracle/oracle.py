@@ -12,7 +12,8 @@ import numpy as np
 from molchanica_amd._abi import CConfig, CSystem, MdConfig, MdSystem
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ENERGY_NAMES = ("bond", "angle", "dihedral", "lj", "coulomb", "lj14", "coulomb14", "kinetic")
+ENERGY_NAMES = ("bond", "angle", "dihedral", "lj", "coulomb", "lj14", "coulomb14", "kinetic", "virial")
+BAR_PER_KCAL_MOL_A3 = 69476.95
 
 _dp = C.POINTER(C.c_double)
 _fp = C.POINTER(C.c_float)
@@ -86,6 +87,7 @@ def forces(sys: MdSystem, cfg: MdConfig, pos=None, ext=None, use_cells=False, _l
 
 
 def _energies(en):
+    assert lib().orc_num_energies() == len(ENERGY_NAMES)
     d = dict(zip(ENERGY_NAMES, (float(v) for v in en)))
     d["potential_bonded"] = d["bond"] + d["angle"] + d["dihedral"]
     d["potential_nonbonded"] = d["lj"] + d["coulomb"] + d["lj14"] + d["coulomb14"]
@@ -211,3 +213,36 @@ def vsite_construct(sys: MdSystem, x):
     xx = np.array(x, dtype=np.float64).reshape(-1, 3).copy()
     lib().orc_vsite_construct(C.byref(cs), _d(xx))
     return xx
+
+
+def last_constraint_virial() -> float:
+    """sum r . G of the SHAKE forces of the most recent position stage (kcal/mol)."""
+    l = lib()
+    l.orc_last_constraint_virial.restype = C.c_double
+    return float(l.orc_last_constraint_virial())
+
+
+def pressure(sys: MdSystem, energies: dict, kinetic_energy: float, w_constraints: float = 0.0) -> float:
+    """bar: (2 KE + W + W_constraints) / (3 V) x 69476.95, V from sys.box."""
+    vol = float(np.prod(np.asarray(sys.box_hi, np.float64) - np.asarray(sys.box_lo, np.float64)))
+    return (2.0 * kinetic_energy + energies["virial"] + w_constraints) / (3.0 * vol) * BAR_PER_KCAL_MOL_A3
+
+
+def step_npt(sys: MdSystem, cfg: MdConfig, dt, n_steps, pos=None, vel=None, thermostat=(0, 300.0, 1.0, 10, 0),
+             barostat=(1, 1.0, 5.0, 4.5e-5, 25), use_cells=False):
+    """thermostat = (kind, T, tau, every, seed); barostat = (kind, P0 bar, tau, compressibility, every).
+    -> (pos, vel, box_hi, pressures, volumes) with one pressure/volume per barostat application."""
+    l = lib()
+    cs, cc = sys.to_c(), cfg.to_c()
+    n = sys.n_atoms
+    x = np.array(sys.pos if pos is None else pos, dtype=np.float64).reshape(n, 3).copy()
+    v = np.array(sys.vel if vel is None else vel, dtype=np.float64).reshape(n, 3).copy()
+    hi = np.array(sys.box_hi, dtype=np.float32).copy()
+    nb = max(1, n_steps // max(1, barostat[4]) + 1)
+    ps = np.zeros(nb); vs = np.zeros(nb)
+    k = l.orc_step_npt(C.byref(cs), C.byref(cc), _d(x), _d(v), C.c_double(dt), C.c_uint32(n_steps),
+                       C.c_int(thermostat[0]), C.c_double(thermostat[1]), C.c_double(thermostat[2]), C.c_uint32(thermostat[3]),
+                       C.c_uint64(thermostat[4]),
+                       C.c_int(barostat[0]), C.c_double(barostat[1]), C.c_double(barostat[2]), C.c_double(barostat[3]),
+                       C.c_uint32(barostat[4]), hi.ctypes.data_as(C.POINTER(C.c_float)), _d(ps), _d(vs), C.c_int(int(use_cells)))
+    return x, v, hi, ps[:k], vs[:k]

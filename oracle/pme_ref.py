@@ -140,6 +140,36 @@ def spme_recip(pos, q, box_lo, box, beta, grid, order=4, ke=KE):
     return e, ke * f
 
 
+def spme_recip_virial(pos, q, box_lo, box, beta, grid, order=4, ke=KE):
+    """Scalar virial W = -dE/dlambda of the SPME reciprocal energy under r -> lambda r, L -> lambda L:
+    sum_m E_m (1 - 2 pi^2 m^2 / beta^2)  (S(m) and the B-spline moduli are scale invariant)."""
+    pos, q, box = np.asarray(pos, float), np.asarray(q, float), np.asarray(box, float)
+    grid = list(grid)
+    u = (pos - np.asarray(box_lo, float)) / box
+    u = (u - np.floor(u)) * np.asarray(grid)
+    fl = np.floor(u).astype(int)
+    w = u - fl
+    wts, idx = [], []
+    for d in range(3):
+        m, _ = _bspline(order, w[:, d])
+        wts.append(m)
+        idx.append((fl[:, d][None, :] - (order - 1) + np.arange(order)[:, None]) % grid[d])
+    Q = np.zeros(grid)
+    for a in range(order):
+        for b in range(order):
+            for c in range(order):
+                np.add.at(Q, (idx[0][a], idx[1][b], idx[2][c]), q * wts[0][a] * wts[1][b] * wts[2][c])
+    th = theta_table(grid, box, beta, order)
+    FQ = np.fft.fftn(Q)
+    ms = []
+    for K, L in zip(grid, box):
+        m = np.arange(K)
+        ms.append(np.where(m <= K // 2, m, m - K) / L)
+    m2 = ms[0][:, None, None] ** 2 + ms[1][None, :, None] ** 2 + ms[2][None, None, :] ** 2
+    em = 0.5 * ke * th * (FQ.real ** 2 + FQ.imag ** 2)
+    return float((em * (1.0 - 2.0 * math.pi ** 2 * m2 / beta ** 2)).sum())
+
+
 def ewald_self_energy(q, beta, ke=KE):
     return -ke * beta / math.sqrt(math.pi) * float((np.asarray(q, float) ** 2).sum())
 
