@@ -239,6 +239,18 @@ int mdx_get_stats(mdx_handle* h, mdx_stats* out);
 #define MDX_THERMOSTAT_BERENDSEN 1 /* lambda^2 = 1 + (Dt/tau)(T0/T - 1)                              */
 #define MDX_THERMOSTAT_CSVR      2 /* Bussi-Donadio-Parrinello stochastic velocity rescaling         */
 
+/* `Integrator::{VerletVelocity{thermostat}, Leapfrog{thermostat}, LangevinMiddle{gamma}}`
+ * (src/ui/panels/md.rs:296-305, README.md:237-238).  Velocity Verlet is the default.  Leapfrog keeps
+ * half-step velocities: v(t+dt/2) = v(t-dt/2) + dt a(t), x += dt v.  Langevin "middle" (Zhang et al. 2019):
+ * v += dt a;  x += dt/2 v;  v = a1 v + sqrt(kT (1 - a1^2)/m) xi, a1 = exp(-gamma dt);  x += dt/2 v, with
+ * xi three normals per atom and step from a counter-based stream (seed, step, atom id), so a trajectory does
+ * not depend on how steps are batched or atoms are ordered on the device.  For both, velocities read back
+ * (and the kinetic energy / temperature reported) are the half-step ones. */
+#define MDX_INTEGRATOR_VERLET_VELOCITY 0
+#define MDX_INTEGRATOR_LEAPFROG        1
+#define MDX_INTEGRATOR_LANGEVIN_MIDDLE 2
+int mdx_set_integrator(mdx_handle* h, int kind, float gamma_per_ps, float temperature, uint64_t seed);
+
 #define MDX_BAROSTAT_NONE      0
 #define MDX_BAROSTAT_BERENDSEN 1 /* mu^3 = 1 - compressibility (Dt/tau) (P0 - P); box and coordinates scaled by mu */
 #define MDX_BAR_PER_KCAL_MOL_A3 69476.95

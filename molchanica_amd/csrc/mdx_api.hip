@@ -440,16 +440,26 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         MDX_TRY(ensure_ready(h));   // a barostat application at the last cadence point left the list to rebuild
         const uint32_t chunk = std::min(std::min(remaining, h->cfg.chunk_steps), mdx_steps_to_next_event(h));
         HIP_TRY(hipMemsetAsync(d.ctl, 0, sizeof(StepCtl), st));
-        // Without constraints the closing half kick of step s and the opening one of step s+1 are
-        // one pass (mode 1).  With constraints every step is kick-drift-SHAKE-forces-kick-RATTLE,
-        // so the velocity projection sits between the two half kicks exactly as in RATTLE.
-        const bool fused = h->n_groups == 0;
+        // Velocity Verlet: without constraints the closing half kick of step s and the opening one of
+        // step s+1 are one pass (mode 1).  With constraints every step is kick-drift-SHAKE-forces-kick-
+        // RATTLE, so the velocity projection sits between the two half kicks exactly as in RATTLE.
+        // Leapfrog and Langevin-middle carry half-step velocities: one pass per step (mode 1 / 3), SHAKE
+        // folds its correction into them, and there is no closing kick.
+        const int integ = h->integrator;
+        const bool vv = integ == MDX_INTEGRATOR_VERLET_VELOCITY;
+        const bool fused = vv && h->n_groups == 0;
         for (uint32_t s = 0; s < chunk; ++s) {
             h->prof_tag = (int)s;
-            MDX_TRY(mdx_launch_integrate(h, (s == 0 || !fused) ? 0 : 1, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr));
+            h->lang_step = h->step_count + s;
+            const int mode = !vv ? (integ == MDX_INTEGRATOR_LANGEVIN_MIDDLE ? 3 : 1) : ((s == 0 || !fused) ? 0 : 1);
+            MDX_TRY(mdx_launch_integrate(h, mode, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr));
             MDX_TRY(mdx_launch_constrain_positions(h, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr));
+            // Langevin middle: friction and noise sit between the two half drifts, so SHAKE's dx/dt is not an
+            // exact velocity projection; RATTLE the half-step velocities (same gate as SHAKE: it belongs to the
+            // drift, which has happened even when the step's forces turn out to be gated off)
+            if (integ == MDX_INTEGRATOR_LANGEVIN_MIDDLE) MDX_TRY(mdx_launch_constrain_velocities(h, &d.ctl->disp2[s], thr));
             MDX_TRY(compute_forces(h, false, &d.ctl->disp2[s + 1], thr));
-            if (!fused) {
+            if (vv && !fused) {
                 MDX_TRY(mdx_launch_integrate(h, 2, dt, &d.ctl->disp2[s + 1], nullptr, thr));
                 MDX_TRY(mdx_launch_constrain_velocities(h, &d.ctl->disp2[s + 1], thr));
             }
@@ -475,8 +485,10 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
                 h->list_valid = false;
                 MDX_TRY(mdx_rebuild(h));
                 MDX_TRY(compute_forces(h, false, nullptr, 0));
-                MDX_TRY(mdx_launch_integrate(h, 2, dt, nullptr, nullptr, thr));
-                MDX_TRY(mdx_launch_constrain_velocities(h, nullptr, 0));
+                if (vv) {
+                    MDX_TRY(mdx_launch_integrate(h, 2, dt, nullptr, nullptr, thr));
+                    MDX_TRY(mdx_launch_constrain_velocities(h, nullptr, 0));
+                }
                 done = s + 1;
                 break;
             }

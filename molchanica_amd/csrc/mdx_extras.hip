@@ -226,6 +226,16 @@ extern "C" int mdx_set_thermostat(mdx_handle* h, int kind, float temp_target, fl
     return MDX_OK;
 }
 
+extern "C" int mdx_set_integrator(mdx_handle* h, int kind, float gamma_per_ps, float temperature, uint64_t seed) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    if (kind < 0 || kind > 2) FAIL(MDX_EPARAM, "unknown integrator kind");
+    if (kind == MDX_INTEGRATOR_LANGEVIN_MIDDLE && (!(gamma_per_ps >= 0.f) || !(temperature >= 0.f) || !std::isfinite(gamma_per_ps)))
+        FAIL(MDX_EPARAM, "Langevin middle needs gamma >= 0 and temperature >= 0");
+    if (kind && h->n_local != h->N) FAIL(MDX_EPARAM, "only velocity Verlet is supported on a decomposed handle");
+    h->integrator = kind; h->lang_gamma = gamma_per_ps; h->lang_temp = temperature; h->lang_seed = seed;
+    return MDX_OK;
+}
+
 extern "C" int mdx_get_box(const mdx_handle* h, float lo[3], float hi[3]) {
     if (!h || !lo || !hi) FAIL(MDX_EPARAM, "null argument");
     for (int d = 0; d < 3; ++d) { lo[d] = h->box_lo[d]; hi[d] = h->box_hi[d]; }

@@ -11,12 +11,33 @@
 // atomicMax (non-negative floats order like their bit patterns).  Downstream kernels gate on
 // that word.
 #include "mdx_internal.h"
+#include <cmath>
 
-template <int MODE>  // 0: half kick + drift, 1: full kick + drift, 2: closing half kick
+struct LangevinArgs {
+    float a1;          // exp(-gamma dt)
+    float kt_noise;    // kB T (1 - a1^2): sigma_v^2 = kt_noise * 418.4 / m = kt_noise * vel.w
+    uint64_t seed; uint64_t step;   // global step number of this launch
+    const uint32_t* orig_of; const uint32_t* gid;
+};
+
+// three standard normals for (seed, step, atom): splitmix64 stream keyed by all three, Box-Muller in fp32
+// (the oracle draws the same uniforms and evaluates in fp64)
+__device__ __forceinline__ void langevin_normals(uint64_t seed, uint64_t step, uint32_t atom, float& g0, float& g1, float& g2) {
+    uint64_t st = seed ^ (0x9E3779B97F4A7C15ull * (step + 1ull)) ^ (0xBF58476D1CE4E5B9ull * ((uint64_t)atom + 1ull));
+    const float k = 1.0f / 16777216.0f;
+    const float u1 = ((float)(mdx_splitmix64(&st) >> 40) + 0.5f) * k, u2 = ((float)(mdx_splitmix64(&st) >> 40) + 0.5f) * k;
+    const float u3 = ((float)(mdx_splitmix64(&st) >> 40) + 0.5f) * k, u4 = ((float)(mdx_splitmix64(&st) >> 40) + 0.5f) * k;
+    const float r1 = sqrtf(-2.0f * __logf(u1)), r2 = sqrtf(-2.0f * __logf(u3));
+    float s1, c1, s2, c2;
+    __sincosf(6.2831853f * u2, &s1, &c1); __sincosf(6.2831853f * u4, &s2, &c2);
+    g0 = r1 * c1; g1 = r1 * s1; g2 = r2 * c2; (void)s2;
+}
+
+template <int MODE>  // 0: half kick + drift, 1: full kick + drift, 2: closing half kick, 3: Langevin middle
 __global__ __launch_bounds__(256) void integrate_kernel(uint32_t S, float dt, float4* __restrict__ posq,
                                                         float4* __restrict__ vel, const float4* __restrict__ force,
                                                         const float4* __restrict__ ref, const uint32_t* gate_in,
-                                                        uint32_t* disp_out, uint32_t thr_bits) {
+                                                        uint32_t* disp_out, uint32_t thr_bits, LangevinArgs lg) {
     const uint32_t gate = gate_in ? *gate_in : 0u;
     if (gate > thr_bits) {  // list already stale: stay a no-op, keep the flag raised
         if (MODE != 2 && blockIdx.x == 0 && threadIdx.x == 0) atomicMax(disp_out, gate);
@@ -28,18 +49,28 @@ __global__ __launch_bounds__(256) void integrate_kernel(uint32_t S, float dt, fl
         float4 v = vel[s];
         if (v.w != 0.f) {   // w = 418.4/m; 0 marks static, ghost and dummy slots
             const float4 f = force[s];
-            const float kdt = (MODE == 1 ? dt : 0.5f * dt) * v.w;
+            const float kdt = ((MODE == 1 || MODE == 3) ? dt : 0.5f * dt) * v.w;
             v.x += kdt * f.x; v.y += kdt * f.y; v.z += kdt * f.z;
-            vel[s] = v;
             if (MODE != 2) {
                 float4 p = posq[s];
-                p.x += dt * v.x; p.y += dt * v.y; p.z += dt * v.z;
+                if (MODE == 3) {
+                    const float hdt = 0.5f * dt;
+                    p.x += hdt * v.x; p.y += hdt * v.y; p.z += hdt * v.z;
+                    float g0, g1, g2;
+                    langevin_normals(lg.seed, lg.step, lg.gid[lg.orig_of[s]], g0, g1, g2);
+                    const float sig = sqrtf(lg.kt_noise * v.w);
+                    v.x = lg.a1 * v.x + sig * g0; v.y = lg.a1 * v.y + sig * g1; v.z = lg.a1 * v.z + sig * g2;
+                    p.x += hdt * v.x; p.y += hdt * v.y; p.z += hdt * v.z;
+                } else {
+                    p.x += dt * v.x; p.y += dt * v.y; p.z += dt * v.z;
+                }
                 posq[s] = p;
                 const float4 r = ref[s];
                 const float dx = p.x - r.x, dy = p.y - r.y, dz = p.z - r.z;
                 d2 = dx * dx + dy * dy + dz * dz;
                 if (!(d2 < 1.0e30f)) d2 = 3.0e38f;  // NaN/inf -> huge, forces a stop
             }
+            vel[s] = v;
         }
     }
     if (MODE != 2) {
@@ -84,14 +115,22 @@ int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_ga
     const dim3 g((h->S + 255) / 256), b(256);
     DeviceState& d = h->d;
     mdx_prof_begin(h, 2);
-    switch (mode) {
-    case 0: hipLaunchKernelGGL(integrate_kernel<0>, g, b, 0, h->stream, h->S, dt, d.posq, d.vel, d.force, d.ref,
-                               d_gate_in, d_disp_out, thr_bits); break;
-    case 1: hipLaunchKernelGGL(integrate_kernel<1>, g, b, 0, h->stream, h->S, dt, d.posq, d.vel, d.force, d.ref,
-                               d_gate_in, d_disp_out, thr_bits); break;
-    default: hipLaunchKernelGGL(integrate_kernel<2>, g, b, 0, h->stream, h->S, dt, d.posq, d.vel, d.force, d.ref,
-                                d_gate_in, d_disp_out, thr_bits); break;
+    LangevinArgs lg{};
+    if (mode == 3) {
+        lg.a1 = std::exp(-h->lang_gamma * dt);
+        lg.kt_noise = (float)(MDX_KB * (double)h->lang_temp * (1.0 - (double)lg.a1 * lg.a1));
+        lg.seed = h->lang_seed; lg.step = h->lang_step;
+        lg.orig_of = d.orig_of; lg.gid = d.gid;
     }
+#define INTEG(M) hipLaunchKernelGGL(integrate_kernel<M>, g, b, 0, h->stream, h->S, dt, d.posq, d.vel, d.force, d.ref, \
+                                    d_gate_in, d_disp_out, thr_bits, lg)
+    switch (mode) {
+    case 0: INTEG(0); break;
+    case 1: INTEG(1); break;
+    case 3: INTEG(3); break;
+    default: INTEG(2); break;
+    }
+#undef INTEG
     mdx_prof_end(h);
     HIP_TRY(hipGetLastError());
     return MDX_OK;

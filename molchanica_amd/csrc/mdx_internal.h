@@ -208,6 +208,7 @@ struct mdx_handle {
     mdx_stats stats{};
     // thermostat / COM / snapshots
     int tstat_kind = 0; float tstat_temp = 300.f, tstat_tau = 1.f; uint32_t tstat_every = 10;
+    int integrator = 0; float lang_gamma = 1.f, lang_temp = 300.f; uint64_t lang_seed = 0, lang_step = 0;
     int baro_kind = 0; float baro_p0 = 1.f, baro_tau = 5.f, baro_beta = 4.5e-5f; uint32_t baro_every = 25;
     double last_pressure = 0.0, last_mu = 1.0;
     uint64_t rng_state = 0;
@@ -242,7 +243,8 @@ int mdx_extract_neighbors(mdx_handle* h, uint32_t* offsets, uint32_t* idx);
 int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr_bits);
 int mdx_launch_bonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr_bits);
 int mdx_launch_add_ext(mdx_handle* h, const uint32_t* d_gate, uint32_t thr_bits);
-// integration (mode: 0 = half kick + drift, 1 = full kick + drift, 2 = closing half kick)
+// integration (mode: 0 = half kick + drift, 1 = full kick + drift (also: one leapfrog step), 2 = closing half
+// kick, 3 = one Langevin-middle step: full kick, half drift, friction + noise, half drift)
 int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_gate_in,
                          uint32_t* d_disp_out, uint32_t thr_bits);
 int mdx_launch_kinetic(mdx_handle* h);  // energy[EN_KIN], energy[EN_COUNT] = max |F|^2
@@ -289,7 +291,7 @@ static inline double mdx_dof(const mdx_handle* h) {
 }
 
 // counter-based RNG shared (bit for bit) with the oracle
-static inline uint64_t mdx_splitmix64(uint64_t* s) {
+__host__ __device__ static inline uint64_t mdx_splitmix64(uint64_t* s) {
     uint64_t z = (*s += 0x9E3779B97F4A7C15ull);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;

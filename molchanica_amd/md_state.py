@@ -85,6 +85,7 @@ def load_library():
     lib.mdx_initialize_velocities.argtypes = [H, C.c_float, C.c_int, C.c_uint64]
     lib.mdx_set_thermostat.argtypes = [H, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_uint64]
     lib.mdx_set_barostat.argtypes = [H, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint32]
+    lib.mdx_set_integrator.argtypes = [H, C.c_int, C.c_float, C.c_float, C.c_uint64]
     lib.mdx_get_box.argtypes = [H, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.mdx_set_zero_com_drift.argtypes = [H, C.c_int]
     lib.mdx_set_snapshot_cadence.argtypes = [H, C.c_uint32, C.c_int]
@@ -247,6 +248,10 @@ class MdState:
         """`Integrator::VerletVelocity{thermostat: Some(tau)}` + `temp_target`; kind 1 Berendsen, 2 CSVR."""
         _check(load_library().mdx_set_thermostat(self._h, int(kind), float(temp_target), float(tau_ps),
                                                  int(every_n_steps), int(seed)))
+
+    def set_integrator(self, kind: int, gamma_per_ps: float = 1.0, temperature: float = 300.0, seed: int = 0):
+        """`Integrator::{VerletVelocity (0), Leapfrog (1), LangevinMiddle{gamma} (2)}` (md.rs:296-305)."""
+        _check(load_library().mdx_set_integrator(self._h, int(kind), float(gamma_per_ps), float(temperature), int(seed)))
 
     def set_barostat(self, kind: int, pressure_target_bar: float = 1.0, tau_ps: float = 5.0,
                      compressibility_per_bar: float = 4.5e-5, every_n_steps: int = 25):

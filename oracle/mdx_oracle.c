@@ -779,6 +779,66 @@ int orc_step_thermo(const mdx_system* s, const mdx_config* c, double* x, double*
     return 0;
 }
 
+/* Three standard normals for (seed, step, atom): the stream mdx_integrate.hip draws from (24-bit uniforms
+ * out of four splitmix64 words keyed by all three), Box-Muller evaluated in fp64 here. */
+void orc_langevin_normals(uint64_t seed, uint64_t step, uint32_t atom, double* g) {
+    uint64_t st = seed ^ (0x9E3779B97F4A7C15ull * (step + 1ull)) ^ (0xBF58476D1CE4E5B9ull * ((uint64_t)atom + 1ull));
+    double u[4];
+    for (int k = 0; k < 4; ++k) u[k] = ((double)(splitmix64(&st) >> 40) + 0.5) / 16777216.0;
+    double r1 = sqrt(-2.0 * log(u[0])), r2 = sqrt(-2.0 * log(u[2]));
+    g[0] = r1 * cos(6.283185307179586 * u[1]);
+    g[1] = r1 * sin(6.283185307179586 * u[1]);
+    g[2] = r2 * cos(6.283185307179586 * u[3]);
+}
+
+/* `Integrator::{Leapfrog (kind 1), LangevinMiddle{gamma} (kind 2)}` (src/ui/panels/md.rs:296-305) in fp64.
+ * v holds half-step velocities.  Leapfrog: v += dt a; x += dt v.  Langevin middle (Zhang, Ding, Shang, Liu,
+ * Leimkuhler 2019): v += dt a; x += dt/2 v; v = a1 v + sqrt(kT (1 - a1^2)/m) xi; x += dt/2 v, a1 = exp(-gamma dt).
+ * Constraints: SHAKE along the bond vectors of x - dt v (exactly the previous positions for leapfrog), the
+ * correction folded into v.  step0: global number of the first step (keys the noise).  en: final state. */
+int orc_step_integrator(const mdx_system* s, const mdx_config* c, double* x, double* v, double dt, uint32_t n_steps,
+                        int kind, double gamma, double temperature, uint64_t seed, uint64_t step0, double* en,
+                        int use_cells) {
+    uint32_t N = s->n_atoms;
+    double* f = (double*)malloc(sizeof(double) * 3 * (N ? N : 1));
+    double* xo = s->n_constraints ? (double*)malloc(sizeof(double) * 3 * (N ? N : 1)) : NULL;
+    double a1 = exp(-gamma * dt), ktn = KB_KCAL * temperature * (1.0 - a1 * a1);
+    /* velocities handed in are projected onto the constraints first, as the engine does for any state it
+     * receives (mdx ensure_ready) */
+    if (xo) orc_constrain_velocities(s, x, v, 1e-12);
+    orc_forces(s, c, x, NULL, f, en, use_cells);
+    for (uint32_t st = 0; st < n_steps; ++st) {
+        for (uint32_t i = 0; i < N; ++i) {
+            int fixed = s->flags && (s->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST));
+            if (fixed) continue;
+            double im = ACC_CONV / (double)s->mass[i];
+            for (int a = 0; a < 3; ++a) v[3*i+a] += dt * f[3*i+a] * im;
+            if (kind == 2) {
+                double g[3]; orc_langevin_normals(seed, step0 + st, i, g);
+                double sig = sqrt(ktn * im);
+                for (int a = 0; a < 3; ++a) {
+                    x[3*i+a] += 0.5 * dt * v[3*i+a];
+                    v[3*i+a] = a1 * v[3*i+a] + sig * g[a];
+                    x[3*i+a] += 0.5 * dt * v[3*i+a];
+                }
+            } else {
+                for (int a = 0; a < 3; ++a) x[3*i+a] += dt * v[3*i+a];
+            }
+        }
+        if (xo) {
+            for (uint32_t i = 0; i < 3 * N; ++i) xo[i] = x[i] - dt * v[i];
+            orc_constrain_positions(s, x, xo, v, dt, 1e-12);
+            /* friction + noise sit between the half drifts: dx/dt is not an exact velocity projection */
+            if (kind == 2) orc_constrain_velocities(s, x, v, 1e-12);
+        }
+        orc_vsite_construct(s, x);
+        orc_forces(s, c, x, NULL, f, en, use_cells);
+    }
+    en[E_KIN] = orc_kinetic(s, v);
+    free(f); free(xo);
+    return 0;
+}
+
 /* Pressure (bar) of a state: en from orc_forces at x, ke in kcal/mol, w_cons from the last SHAKE. */
 double orc_pressure(const mdx_system* s, const double* en, double ke, double w_cons) {
     if (!s->periodic) return 0.0;

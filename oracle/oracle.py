@@ -246,3 +246,25 @@ def step_npt(sys: MdSystem, cfg: MdConfig, dt, n_steps, pos=None, vel=None, ther
                        C.c_int(barostat[0]), C.c_double(barostat[1]), C.c_double(barostat[2]), C.c_double(barostat[3]),
                        C.c_uint32(barostat[4]), hi.ctypes.data_as(C.POINTER(C.c_float)), _d(ps), _d(vs), C.c_int(int(use_cells)))
     return x, v, hi, ps[:k], vs[:k]
+
+
+def step_integrator(sys: MdSystem, cfg: MdConfig, dt, n_steps, kind, gamma=1.0, temperature=300.0, seed=0, step0=0,
+                    pos=None, vel=None, use_cells=False):
+    """kind 1 leapfrog, 2 Langevin middle.  -> (pos, half-step vel, energies of the final state)."""
+    l = lib()
+    cs, cc = sys.to_c(), cfg.to_c()
+    n = sys.n_atoms
+    x = np.array(sys.pos if pos is None else pos, dtype=np.float64).reshape(n, 3).copy()
+    v = np.array(sys.vel if vel is None else vel, dtype=np.float64).reshape(n, 3).copy()
+    en = np.zeros(len(ENERGY_NAMES), dtype=np.float64)
+    rc = l.orc_step_integrator(C.byref(cs), C.byref(cc), _d(x), _d(v), C.c_double(dt), C.c_uint32(n_steps), C.c_int(kind),
+                               C.c_double(gamma), C.c_double(temperature), C.c_uint64(seed), C.c_uint64(step0), _d(en),
+                               C.c_int(int(use_cells)))
+    assert rc == 0
+    return x, v, _energies(en)
+
+
+def langevin_normals(seed, step, atom):
+    g = np.zeros(3)
+    lib().orc_langevin_normals(C.c_uint64(seed), C.c_uint64(step), C.c_uint32(atom), _d(g))
+    return g
