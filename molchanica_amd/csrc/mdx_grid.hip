@@ -408,6 +408,7 @@ struct ListArgs {
     int mask_layout;                 // 1: bit (8e+jj) of lane i-atom; 2: bit (8e+ci) of lane (ii, jj)
     unsigned long long* pair_count;  // statistics: sum of popcount(imask)
     int half;                        // 1: every cluster pair appears in exactly one tile's list
+    const uint32_t* cell_start;      // [ncol * nzb + 1]: first sorted atom of every (column, z-bin) cell
 };
 
 template <bool FILL>
@@ -509,11 +510,30 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
             for (int kz = kz0; kz <= kz1; ++kz) {
                 const float sz = (float)kz * g.len[2];
                 const uint32_t code = (uint32_t)((kx + 1) + 3 * (ky + 1) + 9 * (kz + 1));
-                for (uint32_t base = cl0; base < cl1; base += 64) {
+                // A column's tiles are consecutive z-ranges of its z-sorted atoms: only the tiles that hold
+                // atoms of the z-bins within r of this tile can contribute (a 217 A column is 25 tiles tall,
+                // the window ~4), so look the window up in the cell table instead of testing every cluster.
+                uint32_t clA = cl0, clB = cl1;
+                if (r < 1.0e30f) {
+                    int zb0 = (int)floorf((lo[2] - r - sz - g.lo[2]) * g.inv_zbin) - 1;
+                    int zb1 = (int)floorf((hi[2] + r - sz - g.lo[2]) * g.inv_zbin) + 1;
+                    if (zb1 < 0 || zb0 >= g.nzb) continue;
+                    zb0 = max(zb0, 0); zb1 = min(zb1, g.nzb - 1);
+                    const uint32_t* cs = a.cell_start + (size_t)c2 * g.nzb;
+                    const uint32_t aA = cs[zb0] - cs[0], aB = cs[zb1 + 1] - cs[0];
+                    if (aB <= aA) continue;
+                    clA = cl0 + (aA / MDX_TILE) * MDX_CL_PER_TILE;
+                    clB = min(cl1, cl0 + ((aB + MDX_TILE - 1) / MDX_TILE) * MDX_CL_PER_TILE);
+                }
+                for (uint32_t base = clA; base < clB; base += 64) {
                     const uint32_t jc = base + lane;
                     bool pass = false;
                     uint32_t imask = 0;
-                    if (jc < cl1) {
+                    // half list: a tile pair has one owner, decided by the parity of I + J - test that first,
+                    // it spares the non-owner the bounding-box arithmetic
+                    const uint32_t Jt = jc / MDX_CL_PER_TILE;
+                    const bool mine = !a.half || Jt == t || ((t < Jt) == (((t + Jt) & 1u) == 0u));
+                    if (jc < clB && mine) {
                         float4 jl = a.cl_lo[jc], jh = a.cl_hi[jc];
                         jl.x += sx; jh.x += sx; jl.y += sy; jh.y += sy; jl.z += sz; jh.z += sz;
                         float dx = gap(jl.x, jh.x, lo[0], hi[0]);
@@ -533,10 +553,7 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
                                 // the lists).  Same tile: the lower cluster owns (ci, cj); a cluster's
                                 // pair with itself is kept and its mask holds the j > i triangle; its
                                 // pair with its own periodic image goes to the "positive" image code.
-                                const uint32_t J = jc / MDX_CL_PER_TILE;
-                                if (J != t) {
-                                    if ((t < J) != (((t + J) & 1u) == 0u)) imask = 0;
-                                } else {
+                                if (Jt == t) {
                                     const uint32_t cj = jc % MDX_CL_PER_TILE;
                                     const uint32_t self = (code >= 13u) ? 1u : 0u;
                                     imask &= ((1u << cj) - 1u) | (self << cj);
@@ -850,6 +867,7 @@ int mdx_rebuild(mdx_handle* h) {
     a.err = d.flags_dev; a.null_cluster = T * MDX_CL_PER_TILE;
     a.mask_layout = mdx_nb_variant(h) >= 2 ? 2 : 1;
     a.half = mdx_nb_half(h) ? 1 : 0;
+    a.cell_start = d.cell_start;
     if (!d.pair_count) ALLOC(d.pair_count, 2);
     a.pair_count = d.pair_count;
     HIP_TRY(hipMemsetAsync(d.pair_count, 0, sizeof(unsigned long long) * 2, st));
