@@ -12,8 +12,19 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    m = re.match(r"(?:void )?([A-Za-z0-9_]+)", name)
-    return m.group(1) if m else name
+    """Kernel name without return type and argument list.  The pair kernels keep their template arguments
+    <ENERGY, COUL, GEOM, SAMECUT, WPT, HALF>: the energy flavour (minimiser, snapshots, barostat) and the
+    force-only flavour of the step loop are different kernels with different costs."""
+    m = re.match(r"(?:void )?([A-Za-z0-9_]+)(<[^>]*>)?", name)
+    if not m:
+        return name
+    if m.group(1).startswith("nb_") and m.group(2):
+        return m.group(1) + m.group(2).replace(" ", "")
+    return m.group(1)
+
+
+def is_step_pair_kernel(k):
+    return k.startswith("nb_") and "<false," in k
 
 
 lines = []
@@ -29,16 +40,17 @@ if kt:
         d[0] += 1; d[1] += dur; d[2] = min(d[2], dur); d[3] = max(d[3], dur)
     total = sum(v[1] for v in stats.values())
     lines.append(f"# rocprofv3 --kernel-trace --stats  ({tag}; python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline)")
-    lines.append(f"{'kernel':44s} {'calls':>7s} {'total_us':>12s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
+    lines.append("# includes the untimed preparation of the box (minimiser = energy-flavour kernels, 600 thermostatted steps)")
+    lines.append(f"{'kernel':58s} {'calls':>7s} {'total_us':>12s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
     for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1]):
-        lines.append(f"{k:44s} {v[0]:7d} {v[1]:12.1f} {v[1] / v[0]:10.2f} {v[2]:10.2f} {v[3]:10.2f} {100 * v[1] / total:6.2f}")
+        lines.append(f"{k:58s} {v[0]:7d} {v[1]:12.1f} {v[1] / v[0]:10.2f} {v[2]:10.2f} {v[3]:10.2f} {100 * v[1] / total:6.2f}")
     lines.append("")
     lines.append("note: pair-kernel launches that were gated off behind a stale neighbour list (no-ops, a few us)")
     lines.append("      are included in 'calls'; see the per-kernel avg of launches > 100 us below.")
-    big = [(en - st) / 1e3 for name, st, en in rows if short(name).startswith("nb_") and (en - st) > 100e3]
+    big = [(en - st) / 1e3 for name, st, en in rows if is_step_pair_kernel(short(name)) and (en - st) > 100e3]
     if big:
-        lines.append(f"nb pair kernel, executed launches only: n={len(big)} avg_us={sum(big) / len(big):.2f} "
-                     f"min_us={min(big):.2f} max_us={max(big):.2f}")
+        lines.append(f"pair kernel of the step loop (force-only flavour), executed launches only: n={len(big)} "
+                     f"avg_us={sum(big) / len(big):.2f} min_us={min(big):.2f} max_us={max(big):.2f}")
 
 # ---- PMC passes ----------------------------------------------------------------------------------
 pmc = {}
@@ -82,8 +94,23 @@ print("\n".join(lines))
 
 # ---- HBM traffic of the pair kernel (MI355X_MICROARCH.md §HBM: FETCH_SIZE on gfx950 reports 1/2 of the
 # bytes of wide coalesced reads -> x2; units are KiB-ish 'FETCH_SIZE'=KB, WRITE_SIZE uncalibrated) ----
-nbk = [k for k in pmc if k.startswith("nb_")]
+nbk = sorted((k for k in pmc if is_step_pair_kernel(k)), key=lambda k: -max(v[0] for v in pmc[k].values()))
 if nbk:
     cs = pmc[nbk[0]]
-    out = {"kernel": nbk[0], "raw": {c: v[1] / v[0] for c, v in cs.items()}}
-    json.dump(out, open(os.path.join(dst, f"{tag}_nb_pmc_raw.json"), "w"), indent=1)
+    raw = {c: v[1] / v[0] for c, v in cs.items()}
+    json.dump({"kernel": nbk[0], "raw": raw}, open(os.path.join(dst, f"{tag}_nb_pmc_raw.json"), "w"), indent=1)
+    if "FETCH_SIZE" in raw and "WRITE_SIZE" in raw:
+        fetch, write = raw["FETCH_SIZE"] * 1024.0, raw["WRITE_SIZE"] * 1024.0
+        traffic = {
+            "workload": "water1M", "kernel": nbk[0], "round": tag,
+            "FETCH_SIZE_KB_per_launch": raw["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": raw["WRITE_SIZE"],
+            "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE tallies 128-B read requests at 64 B -> x2 "
+                          "for wide coalesced reads; WRITE_SIZE taken as reported (uncalibrated)",
+            "hbm_bytes_per_launch": 2.0 * fetch + write, "hbm_bytes_per_launch_uncorrected": fetch + write,
+            "algorithmic_bytes_per_launch": 32.0 * 1029000,
+            "note": "memory-side (fabric) request bytes.  Reads: pair list (3.5 M entries x 8 B) + posq/lj of j-clusters that miss "
+                    "the 4 MiB per-XCD L2.  Writes: the half-list kernel returns the reaction force with f32 atomics, which "
+                    "gfx950 executes on the memory side - ~88 M atomic words per launch appear here as write requests "
+                    "(~6 B each); the full-list kernel (nb_variant 2) writes 16.5 MB, exactly the force array, and is 40 % slower",
+        }
+        json.dump(traffic, open(os.path.join(dst, "nb_traffic.json"), "w"), indent=1)
