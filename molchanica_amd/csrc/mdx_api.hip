@@ -313,9 +313,9 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
         HIP_TRY(hipStreamSynchronize(st));
     }
     MDX_TRY(alloc_n(&d.slot_of, N)); MDX_TRY(alloc_n(&d.cell_of, N)); MDX_TRY(alloc_n(&d.sorted_orig, N));
-    MDX_TRY(alloc_n(&d.ctl, 1)); MDX_TRY(alloc_n(&d.energy, EN_COUNT + 8)); MDX_TRY(alloc_n(&d.flags_dev, 4));
+    MDX_TRY(alloc_n(&d.ctl, 1)); MDX_TRY(alloc_n(&d.energy, EN_COUNT + 8 + 4 * MDX_EPART)); MDX_TRY(alloc_n(&d.flags_dev, 4));
     HIP_TRY(hipMemsetAsync(d.ctl, 0, sizeof(StepCtl), st));
-    HIP_TRY(hipMemsetAsync(d.energy, 0, sizeof(double) * (EN_COUNT + 8), st));
+    HIP_TRY(hipMemsetAsync(d.energy, 0, sizeof(double) * (EN_COUNT + 8 + 4 * MDX_EPART), st));
     HIP_TRY(hipHostMalloc((void**)&h->h_ctl, sizeof(StepCtl), hipHostMallocDefault));
     HIP_TRY(hipStreamSynchronize(st));  // host vectors go out of scope
     h->in_slot_space = false; h->list_valid = false; h->forces_valid = false;
@@ -404,7 +404,7 @@ void mdx_prof_collect(mdx_handle* h, int first_stale_step) {
         if (ran && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             if (p.kind == 0) { h->stats.nb_ms_sum += ms; h->stats.nb_launches++; }
             else if (p.kind == 1) { h->stats.bonded_ms_sum += ms; h->stats.bonded_launches++; }
-            else { h->stats.integ_ms_sum += ms; h->stats.integ_launches++; }
+            else if (p.kind == 2) { h->stats.integ_ms_sum += ms; h->stats.integ_launches++; }
         }
         h->ev_pool.push_back(p.a); h->ev_pool.push_back(p.b);
     }
@@ -514,14 +514,18 @@ int mdx_energy_impl(mdx_handle* h, mdx_energies* out) {
     if (!h->list_valid) MDX_TRY(mdx_rebuild(h));
     if (h->cons_dirty) MDX_TRY(ensure_ready(h));
     hipStream_t st = h->stream;
-    HIP_TRY(hipMemsetAsync(h->d.energy, 0, sizeof(double) * (EN_COUNT + 8), st));
+    HIP_TRY(hipMemsetAsync(h->d.energy, 0, sizeof(double) * (EN_COUNT + 8 + 4 * MDX_EPART), st));
     MDX_TRY(compute_forces(h, true, nullptr, 0));
     h->forces_valid = true;
     MDX_TRY(mdx_launch_kinetic(h));
     MDX_TRY(mdx_launch_constraint_virial(h));   // SHAKE forces of the last step (0 after a dt = 0 projection)
-    double e[EN_COUNT + 2];
+    double e[EN_COUNT + 8 + 4 * MDX_EPART];
     HIP_TRY(hipMemcpyAsync(e, h->d.energy, sizeof(e), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    for (int k = 0; k < MDX_EPART; ++k) {   // the pair kernel's partial sums
+        const double* q = e + EN_COUNT + 8 + 4 * k;
+        e[EN_LJ] += q[0]; e[EN_COUL] += q[1]; e[EN_VIRIAL] += q[2];
+    }
     if (h->profile) mdx_prof_collect(h);
     std::memset(out, 0, sizeof(*out));
     out->bond = e[EN_BOND]; out->angle = e[EN_ANGLE]; out->dihedral = e[EN_DIHEDRAL];

@@ -148,6 +148,9 @@ __global__ __launch_bounds__(256) void bonded_gather_kernel(BondedArgs a) {
         }
     }
     if (ENERGY) {
+        // wave shuffle, then the block's four waves through LDS: one atomic per term and block (one per wave
+        // was 7 x 16 k contended atomics at 1 M atoms: 0.42 ms for a 0.04 ms kernel)
+        __shared__ double s_e[4][7];
         double v[7] = {e_bond, e_angle, e_dih, e_lj14, e_c14, e_rec, e_vir};
         const int slot[7] = {EN_BOND, EN_ANGLE, EN_DIHEDRAL, EN_LJ14, EN_COUL14, EN_RECIP, EN_VIRIAL};
 #pragma unroll
@@ -155,7 +158,12 @@ __global__ __launch_bounds__(256) void bonded_gather_kernel(BondedArgs a) {
             double t = v[q];
 #pragma unroll
             for (int m = 32; m > 0; m >>= 1) t += __shfl_xor(t, m);
-            if ((threadIdx.x & 63) == 0 && t != 0.0) atomicAdd(&a.energy[slot[q]], t);
+            if ((threadIdx.x & 63) == 0) s_e[threadIdx.x >> 6][q] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < 7) {
+            const double t = s_e[0][threadIdx.x] + s_e[1][threadIdx.x] + s_e[2][threadIdx.x] + s_e[3][threadIdx.x];
+            if (t != 0.0) atomicAdd(&a.energy[slot[threadIdx.x]], t);
         }
     }
 }
@@ -184,7 +192,7 @@ int mdx_launch_bonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32
         a.p.inv_box[d] = h->per[d] ? 1.0f / a.p.box[d] : 0.f;
     }
     a.p.ewald_beta = h->cfg.ewald_alpha; a.p.skip_bonded = skip_bonded ? 1 : 0;
-    mdx_prof_begin(h, 1);
+    mdx_prof_begin(h, energy ? 3 : 1);
     const dim3 g((h->S + 255) / 256), b(256);
     if (energy) hipLaunchKernelGGL(bonded_gather_kernel<true>, g, b, 0, h->stream, a);
     else hipLaunchKernelGGL(bonded_gather_kernel<false>, g, b, 0, h->stream, a);

@@ -30,6 +30,7 @@
 #define MDX_DUMMY_STEP 64.0f
 #define MDX_MAX_CHUNK 64
 
+#define MDX_EPART 256   // the pair kernel spreads its energy atomics over this many slots (contended f64 atomics cost ~10 ns each)
 enum { EN_BOND = 0, EN_ANGLE, EN_DIHEDRAL, EN_LJ, EN_COUL, EN_LJ14, EN_COUL14, EN_KIN, EN_RECIP, EN_VIRIAL, EN_COUNT };
 
 struct GridParams {
@@ -154,7 +155,8 @@ struct DeviceState {
     VSite* vsite_o = nullptr; VSite* vsite_s = nullptr;
     // control / reductions
     StepCtl* ctl = nullptr;
-    double*  energy = nullptr;     // [EN_COUNT + 8]: energies, max|F|^2 bits, momentum (px,py,pz,mass)
+    double*  energy = nullptr;     // [EN_COUNT + 8 + 4*MDX_EPART]: energies, max|F|^2 bits, momentum (px,py,pz,mass),
+                                   // then MDX_EPART x {lj, coulomb, virial, -} partial sums of the pair kernel
     uint32_t* flags_dev = nullptr; // misc error flags
     unsigned long long* pair_count = nullptr;  // cluster pairs in the list (statistics)
     float*   bbox_red = nullptr;   // [6] min/max reduction (vacuum grid)

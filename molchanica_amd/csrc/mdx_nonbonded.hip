@@ -60,8 +60,8 @@ enum { CM_SHIFTED = 0, CM_RF = 1, CM_EWALD = 2, CM_SOFT = 3 };
 template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, bool BRANCHY, bool HALF = false>
 __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi, float sgi, float epi,
                                           const float4 pj, const float2 lj, bool allowed, const NbParams& p,
-                                          float& fx, float& fy, float& fz, double& elj, double& ecoul,
-                                          float* g = nullptr, double* evir = nullptr) {
+                                          float& fx, float& fy, float& fz, float& elj, float& ecoul,
+                                          float* g = nullptr, float* evir = nullptr) {
     const float dx = xi - pj.x, dy = yi - pj.y, dz = zi - pj.z;   // tgt - src (src/cuda/util.cu:118-140)
     const float r2 = dx * dx + dy * dy + dz * dz;
     const bool in_lj = (r2 < p.rc2_lj) && allowed;
@@ -101,9 +101,10 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
         if (COUL == CM_SHIFTED || COUL == CM_SOFT) e_c = qq * (rinv - p.coul_shift);
         else if (COUL == CM_RF) e_c = qq * (rinv + p.k_rf * r2 - p.coul_shift);
         else e_c = qq * erfc_ar * rinv;
-        elj += in_lj ? (double)e_l : 0.0;
-        ecoul += in_c ? (double)e_c : 0.0;
-        if (evir) *evir += (double)(fs * r2);   // r_ij . F_ij of the pair (fs = 0 outside the cutoffs)
+        // fp32 partial sums: the callers fold them into fp64 once per chunk of 64 j-atoms
+        elj += in_lj ? e_l : 0.f;
+        ecoul += in_c ? e_c : 0.f;
+        if (evir) *evir += fs * r2;   // r_ij . F_ij of the pair (fs = 0 outside the cutoffs)
     }
 }
 
@@ -112,12 +113,14 @@ __device__ __forceinline__ void chunk_pairs(const float4* __restrict__ sx, const
                                             unsigned long long mask, float xi, float yi, float zi, float qi,
                                             float sgi, float epi, const NbParams& p, float& fx, float& fy,
                                             float& fz, double& elj, double& ecoul, double& evir) {
+    float e1 = 0.f, e2 = 0.f, e3 = 0.f;
 #pragma unroll 8
     for (int jj = 0; jj < 64; ++jj) {
         const bool allowed = MASKED ? (bool)((mask >> jj) & 1ull) : true;
         pair_eval<ENERGY, COUL, GEOM, SAMECUT, false>(xi, yi, zi, qi, sgi, epi, sx[jj], sl[jj], allowed, p, fx, fy, fz,
-                                               elj, ecoul, nullptr, ENERGY ? &evir : nullptr);
+                                               e1, e2, nullptr, ENERGY ? &e3 : nullptr);
     }
+    if (ENERGY) { elj += (double)e1; ecoul += (double)e2; evir += (double)e3; }
 }
 
 template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT>
@@ -191,9 +194,8 @@ __global__ __launch_bounds__(NB_WAVES * 64) void nb_tile_kernel(NbArgs a) {
             evir += __shfl_xor(evir, m);
         }
         if (lane == 0) {   // every pair is seen from both sides
-            atomicAdd(&a.energy[EN_LJ], 0.5 * elj);
-            atomicAdd(&a.energy[EN_COUL], 0.5 * ecoul);
-            atomicAdd(&a.energy[EN_VIRIAL], 0.5 * evir);
+            double* q = a.energy + EN_COUNT + 8 + 4 * (blk & (MDX_EPART - 1));
+            atomicAdd(q, 0.5 * elj); atomicAdd(q + 1, 0.5 * ecoul); atomicAdd(q + 2, 0.5 * evir);
         }
     }
 }
@@ -231,7 +233,7 @@ __device__ __forceinline__ float dpp_xadd(float v) {
 }
 
 template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF>
-__global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, (HALF && NB_HALF_FLUSH) ? 3 : 4) void nb_cluster_kernel(NbArgs a) {
+__global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && NB_HALF_FLUSH) || ENERGY) ? 3 : 4) void nb_cluster_kernel(NbArgs a) {
     if (a.gate && *a.gate > a.thr_bits) return;
     constexpr int BW = WPT > NB_WAVES ? WPT : NB_WAVES;       // waves per workgroup
     __shared__ float4 s_xyzq[BW][64];
@@ -334,25 +336,12 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, (HALF && NB
             if (ENERGY && HALF) nown = (float)((a.slot_flags[js] >> 1) & 1u);
             if (c + 2 * WPT < nchunks) ent_n = a.entries[e0 + (c + 2 * WPT) * 8 + (lane >> 3)];
         }
-        // entry loop: the next entry's j record is fetched from LDS before the current one is evaluated
-        // (the half-list kernel has no registers to spare for that: it reads the record in place)
-        float4 pj_n = make_float4(0.f, 0.f, 0.f, 0.f);
-        float2 lj_n = make_float2(0.f, 0.f);
-        constexpr bool LDS_AHEAD = false;
-        if (LDS_AHEAD) { pj_n = sx[jj]; lj_n = sl[jj]; }
-        // (HALF, atomics in the loop) the loop is cut in two with an explicit wait for the prefetch
-        // between the halves: by then the loads are ~1 us old, and with them retired on every path
-        // the compiler has no reason to wait at the end of the chunk, where it could only say
-        // vmcnt(0) and would stall on the atomics just issued
-        constexpr int NSPLIT = 1;   // measured: 2 (explicit wait between the halves) is 3 % slower
-#pragma unroll
-        for (int hs = 0; hs < NSPLIT; ++hs) {
-        if (hs == 1) __builtin_amdgcn_s_waitcnt(0x0F70);
+        float celj = 0.f, cecoul = 0.f, cevir = 0.f;   // (ENERGY) fp32 partial sums of this chunk
+        // entry loop: each entry's j record is read from LDS where it is needed (any look-ahead measured slower)
 #pragma unroll 1
-        for (int e = hs * (8 / NSPLIT); e < (hs + 1) * (8 / NSPLIT); ++e) {
-            const float4 pj = !LDS_AHEAD ? sx[e * 8 + jj] : pj_n;
-            const float2 lj = !LDS_AHEAD ? sl[e * 8 + jj] : lj_n;
-            if (LDS_AHEAD && e < 7) { pj_n = sx[(e + 1) * 8 + jj]; lj_n = sl[(e + 1) * 8 + jj]; }
+        for (int e = 0; e < 8; ++e) {
+            const float4 pj = sx[e * 8 + jj];
+            const float2 lj = sl[e * 8 + jj];
             const uint32_t im = (__builtin_amdgcn_readlane(cur_y, e * 8) >> 8) & 0xFFu;  // wave-uniform
             if (im == 0) continue;
             // exclusion bits only exist in masked chunks; elsewhere the (uniform) imask bit suffices
@@ -363,14 +352,14 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, (HALF && NB
 #pragma unroll
             for (int ci = 0; ci < 8; ++ci) {
                 if (im & (1u << ci)) {
-                    double e1 = 0.0, e2 = 0.0, e3 = 0.0;
+                    float e1 = 0.f, e2 = 0.f, e3 = 0.f;
                     pair_eval<ENERGY, COUL, GEOM, SAMECUT, true, HALF>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci],
                                                                        pj, lj, (m8 >> ci) & 1u, a.p, fx[ci], fy[ci],
                                                                        fz[ci], e1, e2, g, ENERGY ? &e3 : nullptr);
                     if (ENERGY && HALF) {   // a pair's energy is split between the owners of its two atoms
-                        const double w = (double)(wj + (((own_bits >> ci) & 1u) ? 0.5f : 0.f));
-                        elj += w * e1; ecoul += w * e2; evir += w * e3;
-                    } else if (ENERGY && ((own_bits >> ci) & 1u)) { elj += e1; ecoul += e2; evir += e3; }
+                        const float w = wj + (((own_bits >> ci) & 1u) ? 0.5f : 0.f);
+                        celj += w * e1; cecoul += w * e2; cevir += w * e3;
+                    } else if (ENERGY && ((own_bits >> ci) & 1u)) { celj += e1; cecoul += e2; cevir += e3; }
                 }
             }
             if (HALF) {
@@ -389,7 +378,7 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, (HALF && NB
                 }
             }
         }
-        }
+        if (ENERGY) { elj += (double)celj; ecoul += (double)cecoul; evir += (double)cevir; }
         WAVE_LDS_SYNC();
         if (HALF && NB_HALF_FLUSH) {
             // Flush: 192 floats = 3 instructions x 64 lanes, lane l of instruction k taking float
@@ -443,10 +432,12 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, (HALF && NB
             ecoul += __shfl_xor(ecoul, m);
             evir += __shfl_xor(evir, m);
         }
-        if (lane == 0) {   // full list: every pair is seen from both sides
-            atomicAdd(&a.energy[EN_LJ], HALF ? elj : 0.5 * elj);
-            atomicAdd(&a.energy[EN_COUL], HALF ? ecoul : 0.5 * ecoul);
-            atomicAdd(&a.energy[EN_VIRIAL], HALF ? evir : 0.5 * evir);
+        if (lane == 0) {   // full list: every pair is seen from both sides.  The atomics are spread over MDX_EPART
+                           // slots: 65 k waves adding into three words took 2 ms (contended f64 atomics, ~10 ns each)
+            double* q = a.energy + EN_COUNT + 8 + 4 * ((blk * BW + wave) & (MDX_EPART - 1));
+            atomicAdd(q, HALF ? elj : 0.5 * elj);
+            atomicAdd(q + 1, HALF ? ecoul : 0.5 * ecoul);
+            atomicAdd(q + 2, HALF ? evir : 0.5 * evir);
         }
     }
 }
@@ -509,7 +500,7 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
     }
     const bool geom = c.combining_rule == MDX_COMBINE_GEOMETRIC;
     const bool samecut = p.rc2_lj == p.rc2_coul;
-    mdx_prof_begin(h, 0);
+    mdx_prof_begin(h, energy ? 3 : 0);   // 3: the energy flavour is a different kernel, keep it out of the step-loop average
     // the half-list kernel accumulates with atomics: start from zero (part of the kernel's cost, so
     // inside the profiled bracket; harmless when the launch behind it is gated off, see mdx_step)
     if (mdx_nb_half(h)) HIP_TRY(hipMemsetAsync(h->d.force, 0, sizeof(float4) * (size_t)h->S, h->stream));

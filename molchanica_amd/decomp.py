@@ -446,7 +446,7 @@ class DecomposedMd:
 
     def energy(self) -> dict:
         e = self.engine.energy()
-        keys = ["kinetic", "lj", "coulomb", "lj14", "coulomb14", "bond", "angle", "dihedral"]
+        keys = ["kinetic", "lj", "coulomb", "lj14", "coulomb14", "bond", "angle", "dihedral", "virial"]
         t = torch.tensor([e[k] for k in keys], dtype=torch.float64, device=self.dev)
         if self.world > 1:
             self.comm.all_reduce(t, "sum")
@@ -454,6 +454,9 @@ class DecomposedMd:
         out["potential_bonded"] = out["bond"] + out["angle"] + out["dihedral"]
         out["potential_nonbonded"] = out["lj"] + out["coulomb"] + out["lj14"] + out["coulomb14"]
         out["potential"] = out["potential_bonded"] + out["potential_nonbonded"]
+        vol = float(torch.prod(self.part.len).item()) if self.system.periodic else 0.0
+        out["volume"] = vol
+        out["pressure"] = (2.0 * out["kinetic"] + out["virial"]) / (3.0 * vol) * 69476.95 if vol > 0 else 0.0
         return out
 
     def stats(self) -> dict:

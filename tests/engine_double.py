@@ -137,7 +137,7 @@ class NumpyEngine:
             self.flags[flag_word] = max(int(self.flags[flag_word]), got)
 
     def energy(self):
-        return {k: 0.0 for k in ("kinetic", "lj", "coulomb", "lj14", "coulomb14", "bond", "angle", "dihedral")}
+        return {k: 0.0 for k in ("kinetic", "lj", "coulomb", "lj14", "coulomb14", "bond", "angle", "dihedral", "virial")}
 
     def stats(self):
         return {"n_atoms": self.n_local, "rebuild_count": 0}
