@@ -156,6 +156,9 @@ typedef struct mdx_energies {
     double max_force;           /* max |F| kcal/mol/Å — blow-up detector (sol_shrinking_box.rs:776-789) */
     double coulomb_recip;       /* SPME reciprocal sum + self + excluded-pair + background terms (in
                                    potential_nonbonded); `coulomb` is the real-space part */
+    double dh_dlambda;          /* kcal/mol: dU/dlambda of the alchemical window (0 when none is configured)       */
+    double coupled_interaction; /* kcal/mol: (1 - lambda) x the non-bonded energy between the coupled molecule and the
+                                   rest (mean_coupled_interaction_kcal's sample, src/properties/water_sol.rs:442)       */
     double pressure;            /* bar, (2 KE + W) / (3 V) x 69476.95; 0 in vacuum  [ref: en.pressure,
                                    src/ui/panels/md_viewer.rs:246; src/properties/crystal.rs:526] */
 } mdx_energies;
@@ -250,6 +253,16 @@ int mdx_get_stats(mdx_handle* h, mdx_stats* out);
 #define MDX_INTEGRATOR_LEAPFROG        1
 #define MDX_INTEGRATOR_LANGEVIN_MIDDLE 2
 int mdx_set_integrator(mdx_handle* h, int kind, float gamma_per_ps, float temperature, uint64_t seed);
+
+/* `md.configure_alchemical_window(dev, mol_index, lambda)` (src/properties/water_sol.rs:556): thermodynamic
+ * integration windows, lambda from 0 (full interaction between the molecule and its environment) to 1 (none,
+ * water_sol.rs:52-56).  The coupling form lives in the absent crate; built here: LINEAR coupling of the
+ * non-bonded (LJ + real-space Coulomb) interactions between the atoms of molecule `mol_index` and every other
+ * atom, U(lambda) = U_rest + (1 - lambda) U_cross; intramolecular terms (bonded, 1-4, intra non-bonded) are not
+ * scaled.  Every energy evaluation (hence every snapshot) reports dh_dlambda = -U_cross.  Needs mol_start in the
+ * system description; not available with the SPME reciprocal sum or on a decomposed handle.  lambda < 0 switches
+ * the window off. */
+int mdx_configure_alchemical_window(mdx_handle* h, uint32_t mol_index, double lambda);
 
 #define MDX_BAROSTAT_NONE      0
 #define MDX_BAROSTAT_BERENDSEN 1 /* mu^3 = 1 - compressibility (Dt/tau) (P0 - P); box and coordinates scaled by mu */

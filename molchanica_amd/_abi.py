@@ -64,7 +64,7 @@ class CEnergies(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "kinetic", "potential", "potential_nonbonded", "potential_bonded",
         "lj", "coulomb", "lj14", "coulomb14", "bond", "angle", "dihedral",
-        "temperature", "volume", "density", "virial", "max_force", "coulomb_recip", "pressure")]
+        "temperature", "volume", "density", "virial", "max_force", "coulomb_recip", "dh_dlambda", "coupled_interaction", "pressure")]
 
     def as_dict(self) -> dict:
         return {n: float(getattr(self, n)) for n, _ in self._fields_}

@@ -205,7 +205,8 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
         if (!fixed) { h->n_mobile++; }
         if (!(fl & MDX_ATOM_GHOST)) h->total_mass += s->mass[i];
     }
-    h->h_mass = mass;
+    h->h_mass = mass; h->h_lj = lj;
+    h->mol_start.assign(s->mol_start ? s->mol_start : nullptr, s->mol_start ? s->mol_start + s->n_mols : nullptr);
     h->total_charge = 0.0; h->sum_q2 = 0.0;
     for (uint32_t i = 0; i < N; ++i) { h->total_charge += q[i]; h->sum_q2 += (double)q[i] * q[i]; }
     const bool pme_on = c->coulomb_mode == MDX_COULOMB_EWALD && !(c->overrides & MDX_OVR_LONG_RANGE_RECIP_DISABLED) &&
@@ -522,9 +523,10 @@ int mdx_energy_impl(mdx_handle* h, mdx_energies* out) {
     double e[EN_COUNT + 8 + 4 * MDX_EPART];
     HIP_TRY(hipMemcpyAsync(e, h->d.energy, sizeof(e), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    double u_cross = 0.0;
     for (int k = 0; k < MDX_EPART; ++k) {   // the pair kernel's partial sums
         const double* q = e + EN_COUNT + 8 + 4 * k;
-        e[EN_LJ] += q[0]; e[EN_COUL] += q[1]; e[EN_VIRIAL] += q[2];
+        e[EN_LJ] += q[0]; e[EN_COUL] += q[1]; e[EN_VIRIAL] += q[2]; u_cross += q[3];
     }
     if (h->profile) mdx_prof_collect(h);
     std::memset(out, 0, sizeof(*out));
@@ -546,6 +548,7 @@ int mdx_energy_impl(mdx_handle* h, mdx_energies* out) {
         out->virial = e[EN_VIRIAL] + (h->pme_on ? 3.0 * h->ewald_background : 0.0);
         out->pressure = (2.0 * out->kinetic + out->virial) / (3.0 * out->volume) * MDX_BAR_PER_KCAL_MOL_A3;
     }
+    if (h->alch_on) { out->dh_dlambda = -u_cross; out->coupled_interaction = (1.0 - h->alch_lambda) * u_cross; }
     uint32_t mf2; std::memcpy(&mf2, &e[EN_COUNT], 4);
     out->max_force = std::sqrt((double)u2f(mf2));
     const double tot = out->potential + out->kinetic;

@@ -236,6 +236,30 @@ extern "C" int mdx_set_integrator(mdx_handle* h, int kind, float gamma_per_ps, f
     return MDX_OK;
 }
 
+extern "C" int mdx_configure_alchemical_window(mdx_handle* h, uint32_t mol_index, double lambda) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    const bool on = lambda >= 0.0;
+    if (on) {
+        if (!(lambda <= 1.0)) FAIL(MDX_EPARAM, "lambda must lie in [0, 1] (negative switches the window off)");
+        if (h->mol_start.empty() || mol_index >= h->mol_start.size()) FAIL(MDX_EPARAM, "molecule index out of range (mol_start missing?)");
+        if (h->pme_on) FAIL(MDX_EPARAM, "alchemical windows are not available with the SPME reciprocal sum");
+        if (h->n_local != h->N) FAIL(MDX_EPARAM, "alchemical windows are not supported on a decomposed handle");
+    }
+    const uint32_t lo = on ? h->mol_start[mol_index] : 0;
+    const uint32_t hi = on ? (mol_index + 1 < h->mol_start.size() ? h->mol_start[mol_index + 1] : h->N) : 0;
+    for (uint32_t i = 0; i < h->N; ++i) {
+        const float m = std::fabs(h->h_lj[i].y);
+        h->h_lj[i].y = (i >= lo && i < hi) ? -m : m;     // -0.0 for eps = 0: the sign bit is the flag
+    }
+    HIP_TRY(hipMemcpyAsync(h->d.o_lj, h->h_lj.data(), sizeof(float2) * h->N, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    MDX_TRY(mdx_unsort_state(h));       // the per-slot copy of the LJ record is refreshed by the next rebuild
+    h->alch_on = on; h->alch_lambda = on ? lambda : 0.0; h->alch_lo = lo; h->alch_hi = hi;
+    h->list_valid = false; h->forces_valid = false;
+    return MDX_OK;
+}
+
 extern "C" int mdx_get_box(const mdx_handle* h, float lo[3], float hi[3]) {
     if (!h || !lo || !hi) FAIL(MDX_EPARAM, "null argument");
     for (int d = 0; d < 3; ++d) { lo[d] = h->box_lo[d]; hi[d] = h->box_hi[d]; }

@@ -51,6 +51,7 @@ struct NbParams {
     float alpha;             // Ewald real-space
     float soft2;
     int coul_mode;
+    float alch_scale;        // 1 - lambda: factor on pairs with exactly one atom in the coupled molecule (ALCH kernels)
     int geometric;           // combining rule
     int lj_on, coul_on;
 };
@@ -185,6 +186,9 @@ struct mdx_handle {
     double total_mass = 0.0;
     std::vector<uint8_t> flags;
     std::vector<float> h_mass;
+    std::vector<float2> h_lj;          // host copy of the per-atom LJ record (sign of .y marks the alchemical molecule)
+    std::vector<uint32_t> mol_start;   // first atom of each molecule
+    bool alch_on = false; double alch_lambda = 0.0; uint32_t alch_lo = 0, alch_hi = 0;
     // grid
     GridParams grid{};
     uint32_t ncol = 0, ncells = 0;
@@ -259,6 +263,7 @@ int mdx_exclusive_scan_u32(mdx_handle* h, const uint32_t* in, uint32_t* out, uin
 #define MDX_NB_DEFAULT_VARIANT 5
 static inline int mdx_nb_variant(const mdx_handle* h) {
     const uint32_t v = h->cfg.nb_variant;
+    if (h->alch_on) return 5;   // the alchemical flavour exists for the half-list kernel only
     return (v >= 1 && v <= 5) ? (int)v : MDX_NB_DEFAULT_VARIANT;
 }
 static inline bool mdx_nb_half(const mdx_handle* h) { return mdx_nb_variant(h) == 5; }

@@ -57,11 +57,16 @@ enum { CM_SHIFTED = 0, CM_RF = 1, CM_EWALD = 2, CM_SOFT = 3 };
 // cutoff costs 7 VALU ops instead of 25 (the cluster kernel: ~40 % of its cluster pairs).  The
 // whole-tile kernel keeps the straight-line select form, which the compiler can software-pipeline
 // across its unrolled j loop.
-template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, bool BRANCHY, bool HALF = false>
+//
+// ALCH = true: thermodynamic-integration window.  The atoms of the coupled molecule carry a negative (or -0.0)
+// sqrt(24 eps); the sign of the product eps_i * eps_j is then the "exactly one of the two is coupled" flag, and
+// such a pair's force and energy are scaled by p.alch_scale = 1 - lambda (3 VALU ops; a separate instantiation,
+// the default kernels do not pay for it).  *ecross collects the UNSCALED energy of those pairs: dU/dlambda = -it.
+template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, bool BRANCHY, bool HALF = false, bool ALCH = false>
 __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi, float sgi, float epi,
                                           const float4 pj, const float2 lj, bool allowed, const NbParams& p,
                                           float& fx, float& fy, float& fz, float& elj, float& ecoul,
-                                          float* g = nullptr, float* evir = nullptr) {
+                                          float* g = nullptr, float* evir = nullptr, float* ecross = nullptr) {
     const float dx = xi - pj.x, dy = yi - pj.y, dz = zi - pj.z;   // tgt - src (src/cuda/util.cu:118-140)
     const float r2 = dx * dx + dy * dy + dz * dz;
     const bool in_lj = (r2 < p.rc2_lj) && allowed;
@@ -70,7 +75,9 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
     const float rinv = __builtin_amdgcn_rsqf(r2);
     const float rinv2 = rinv * rinv;
     const float sig = GEOM ? sgi * lj.x : sgi + lj.x;
-    const float eps = epi * lj.y;                   // 24 eps_ij
+    const float eps_s = epi * lj.y;                 // 24 eps_ij (ALCH: signed)
+    const float eps = ALCH ? fabsf(eps_s) : eps_s;
+    const float ascale = (ALCH && __float_as_int(eps_s) < 0) ? p.alch_scale : 1.0f;
     const float s2 = sig * sig * rinv2;
     const float s6 = s2 * s2 * s2;
     const float es6 = eps * s6;
@@ -93,6 +100,7 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
     float fs;
     if (SAMECUT) fs = (BRANCHY || in_lj) ? (flj_r2 + fc_r2) * rinv2 : 0.0f;
     else fs = (in_lj || in_c) ? ((in_lj ? flj_r2 : 0.0f) + (in_c ? fc_r2 : 0.0f)) * rinv2 : 0.0f;
+    if (ALCH) fs *= ascale;
     fx += fs * dx; fy += fs * dy; fz += fs * dz;
     if (HALF) { g[0] += fs * dx; g[1] += fs * dy; g[2] += fs * dz; }   // minus the force on j
     if (ENERGY) {
@@ -102,8 +110,10 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
         else if (COUL == CM_RF) e_c = qq * (rinv + p.k_rf * r2 - p.coul_shift);
         else e_c = qq * erfc_ar * rinv;
         // fp32 partial sums: the callers fold them into fp64 once per chunk of 64 j-atoms
-        elj += in_lj ? e_l : 0.f;
-        ecoul += in_c ? e_c : 0.f;
+        const float u_l = in_lj ? e_l : 0.f, u_c = in_c ? e_c : 0.f;
+        elj += ALCH ? ascale * u_l : u_l;
+        ecoul += ALCH ? ascale * u_c : u_c;
+        if (ALCH && ecross && __float_as_int(eps_s) < 0) *ecross += u_l + u_c;
         if (evir) *evir += fs * r2;   // r_ij . F_ij of the pair (fs = 0 outside the cutoffs)
     }
 }
@@ -232,7 +242,7 @@ __device__ __forceinline__ float dpp_xadd(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
-template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF>
+template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF, bool ALCH = false>
 __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && NB_HALF_FLUSH) || ENERGY) ? 3 : 4) void nb_cluster_kernel(NbArgs a) {
     if (a.gate && *a.gate > a.thr_bits) return;
     constexpr int BW = WPT > NB_WAVES ? WPT : NB_WAVES;       // waves per workgroup
@@ -270,7 +280,7 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
     const uint32_t mbase = a.mchunk_off[t];
     float4* sx = s_xyzq[wave];
     float2* sl = s_lj[wave];
-    double elj = 0.0, ecoul = 0.0, evir = 0.0;
+    double elj = 0.0, ecoul = 0.0, evir = 0.0, ecross = 0.0;
     uint32_t own_bits = 0xFFu;   // ENERGY only: bit ci set <=> i-atom (ci, ii) is owned by this rank
     if (ENERGY) {
         own_bits = 0;
@@ -336,7 +346,7 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
             if (ENERGY && HALF) nown = (float)((a.slot_flags[js] >> 1) & 1u);
             if (c + 2 * WPT < nchunks) ent_n = a.entries[e0 + (c + 2 * WPT) * 8 + (lane >> 3)];
         }
-        float celj = 0.f, cecoul = 0.f, cevir = 0.f;   // (ENERGY) fp32 partial sums of this chunk
+        float celj = 0.f, cecoul = 0.f, cevir = 0.f, cecross = 0.f;   // (ENERGY) fp32 partial sums of this chunk
         // entry loop: each entry's j record is read from LDS where it is needed (any look-ahead measured slower)
 #pragma unroll 1
         for (int e = 0; e < 8; ++e) {
@@ -352,14 +362,15 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
 #pragma unroll
             for (int ci = 0; ci < 8; ++ci) {
                 if (im & (1u << ci)) {
-                    float e1 = 0.f, e2 = 0.f, e3 = 0.f;
-                    pair_eval<ENERGY, COUL, GEOM, SAMECUT, true, HALF>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci],
-                                                                       pj, lj, (m8 >> ci) & 1u, a.p, fx[ci], fy[ci],
-                                                                       fz[ci], e1, e2, g, ENERGY ? &e3 : nullptr);
+                    float e1 = 0.f, e2 = 0.f, e3 = 0.f, e4 = 0.f;
+                    pair_eval<ENERGY, COUL, GEOM, SAMECUT, true, HALF, ALCH>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci],
+                                                                             pj, lj, (m8 >> ci) & 1u, a.p, fx[ci], fy[ci],
+                                                                             fz[ci], e1, e2, g, ENERGY ? &e3 : nullptr,
+                                                                             (ENERGY && ALCH) ? &e4 : nullptr);
                     if (ENERGY && HALF) {   // a pair's energy is split between the owners of its two atoms
                         const float w = wj + (((own_bits >> ci) & 1u) ? 0.5f : 0.f);
-                        celj += w * e1; cecoul += w * e2; cevir += w * e3;
-                    } else if (ENERGY && ((own_bits >> ci) & 1u)) { celj += e1; cecoul += e2; cevir += e3; }
+                        celj += w * e1; cecoul += w * e2; cevir += w * e3; cecross += w * e4;
+                    } else if (ENERGY && ((own_bits >> ci) & 1u)) { celj += e1; cecoul += e2; cevir += e3; cecross += e4; }
                 }
             }
             if (HALF) {
@@ -378,7 +389,7 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
                 }
             }
         }
-        if (ENERGY) { elj += (double)celj; ecoul += (double)cecoul; evir += (double)cevir; }
+        if (ENERGY) { elj += (double)celj; ecoul += (double)cecoul; evir += (double)cevir; ecross += (double)cecross; }
         WAVE_LDS_SYNC();
         if (HALF && NB_HALF_FLUSH) {
             // Flush: 192 floats = 3 instructions x 64 lanes, lane l of instruction k taking float
@@ -431,6 +442,7 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
             elj += __shfl_xor(elj, m);
             ecoul += __shfl_xor(ecoul, m);
             evir += __shfl_xor(evir, m);
+            if (ALCH) ecross += __shfl_xor(ecross, m);
         }
         if (lane == 0) {   // full list: every pair is seen from both sides.  The atomics are spread over MDX_EPART
                            // slots: 65 k waves adding into three words took 2 ms (contended f64 atomics, ~10 ns each)
@@ -438,6 +450,7 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
             atomicAdd(q, HALF ? elj : 0.5 * elj);
             atomicAdd(q + 1, HALF ? ecoul : 0.5 * ecoul);
             atomicAdd(q + 2, HALF ? evir : 0.5 * evir);
+            if (ALCH) atomicAdd(q + 3, HALF ? ecross : 0.5 * ecross);
         }
     }
 }
@@ -458,7 +471,9 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
     dim3 g(grid), b(bw * 64);
 #define NB_LAUNCH(G, S)                                                                                    \
     do {                                                                                                   \
-        if (var == 1) hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, G, S>), g, b, 0, h->stream, a);     \
+        if (h->alch_on && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true, true>), g, b, 0, h->stream, a); \
+        else if (h->alch_on) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, true, true>), g, b, 0, h->stream, a); \
+        else if (var == 1) hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, G, S>), g, b, 0, h->stream, a);     \
         else if (half && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true>), g, b, 0, h->stream, a); \
         else if (half) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, true>), g, b, 0, h->stream, a); \
         else if (wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, false>), g, b, 0, h->stream, a); \
@@ -487,6 +502,7 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
     const float rc = c.coulomb_cutoff;
     p.alpha = c.ewald_alpha; p.soft2 = c.softening_sq;
     p.k_rf = 0.f; p.k_rf2 = 0.f; p.coul_shift = 0.f;
+    p.alch_scale = h->alch_on ? (float)(1.0 - h->alch_lambda) : 1.0f;
     int mode = CM_SHIFTED;
     switch (c.coulomb_mode) {
     case MDX_COULOMB_REACTION:

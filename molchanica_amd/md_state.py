@@ -86,6 +86,7 @@ def load_library():
     lib.mdx_set_thermostat.argtypes = [H, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_uint64]
     lib.mdx_set_barostat.argtypes = [H, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint32]
     lib.mdx_set_integrator.argtypes = [H, C.c_int, C.c_float, C.c_float, C.c_uint64]
+    lib.mdx_configure_alchemical_window.argtypes = [H, C.c_uint32, C.c_double]
     lib.mdx_get_box.argtypes = [H, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.mdx_set_zero_com_drift.argtypes = [H, C.c_int]
     lib.mdx_set_snapshot_cadence.argtypes = [H, C.c_uint32, C.c_int]
@@ -248,6 +249,10 @@ class MdState:
         """`Integrator::VerletVelocity{thermostat: Some(tau)}` + `temp_target`; kind 1 Berendsen, 2 CSVR."""
         _check(load_library().mdx_set_thermostat(self._h, int(kind), float(temp_target), float(tau_ps),
                                                  int(every_n_steps), int(seed)))
+
+    def configure_alchemical_window(self, mol_index: int, lam: float):
+        """`md.configure_alchemical_window(dev, mol_index, lambda)` (src/properties/water_sol.rs:556); lam < 0 = off."""
+        _check(load_library().mdx_configure_alchemical_window(self._h, int(mol_index), float(lam)))
 
     def set_integrator(self, kind: int, gamma_per_ps: float = 1.0, temperature: float = 300.0, seed: int = 0):
         """`Integrator::{VerletVelocity (0), Leapfrog (1), LangevinMiddle{gamma} (2)}` (md.rs:296-305)."""

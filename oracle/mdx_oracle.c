@@ -34,7 +34,8 @@
 #define ACC_CONV 418.4          /* kcal/mol/Å/Da -> Å/ps² */
 #define KB_KCAL  0.0019872041   /* kcal/mol/K */
 
-enum { E_BOND, E_ANGLE, E_DIHEDRAL, E_LJ, E_COUL, E_LJ14, E_COUL14, E_KIN, E_VIRIAL, E_N };
+enum { E_BOND, E_ANGLE, E_DIHEDRAL, E_LJ, E_COUL, E_LJ14, E_COUL14, E_KIN, E_VIRIAL, E_CROSS, E_N };
+/* E_CROSS: unscaled non-bonded energy between the alchemical molecule and the rest (0 without a window) */
 /* E_VIRIAL: W = sum_i r_i . F_i of the internal forces (pairs, 1-4, bonds; angle and dihedral terms are
  * scale invariant and contribute exactly 0), kcal/mol.  Pressure = (2 KE + W + W_constraints) / (3 V). */
 
@@ -441,6 +442,13 @@ int orc_constrain_velocities(const mdx_system* s, const double* x, double* v, do
     return it;
 }
 
+/* Alchemical window (`md.configure_alchemical_window(dev, mol_index, lambda)`, src/properties/water_sol.rs:556):
+ * linear coupling of the cut-off non-bonded pairs between atoms [lo, hi) and all others,
+ * U(lambda) = U_rest + (1 - lambda) U_cross; en[E_CROSS] = U_cross, so dU/dlambda = -en[E_CROSS].
+ * lambda < 0 switches it off.  Test infrastructure state, like the rest of this file. */
+static double g_alch_lambda = -1.0; static uint32_t g_alch_lo = 0, g_alch_hi = 0;
+void orc_set_alchemical(uint32_t lo, uint32_t hi, double lambda) { g_alch_lo = lo; g_alch_hi = hi; g_alch_lambda = lambda; }
+
 /* ------------------------------------------------------------------------------------------- */
 /* Forces + energies.  x: fp64 positions [3N] (NULL -> s->pos).  f: [3N] out.  en: [E_N] out.
  * use_cells: 0 = O(N^2) brute force, 1 = cell list (needs a cutoff).  Pair inclusion uses the
@@ -465,9 +473,11 @@ int orc_forces(const mdx_system* s, const mdx_config* c, const double* x_in, con
     if (use_cells && !(cut_lj && cut_c)) use_cells = 0;
 
     grid_t g; if (use_cells) g = build_grid(s, x, rmax);
-    double e_lj = 0.0, e_c = 0.0, w_nb = 0.0;
+    double e_lj = 0.0, e_c = 0.0, w_nb = 0.0, e_x = 0.0;
+    const int alch = g_alch_lambda >= 0.0;
+    const double asc = alch ? 1.0 - g_alch_lambda : 1.0;
 
-#pragma omp parallel for schedule(dynamic, 64) reduction(+ : e_lj, e_c, w_nb)
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : e_lj, e_c, w_nb, e_x)
     for (uint32_t i = 0; i < N; ++i) {
         if (!nb_active(s, i)) continue;
         double fi[3] = { 0, 0, 0 };
@@ -501,13 +511,17 @@ int orc_forces(const mdx_system* s, const mdx_config* c, const double* x_in, con
                 double qq = (double)s->charge[i] * (double)s->charge[j];
                 double fs, el = 0.0, ec = 0.0;
                 pair_terms(c, sig, eps, qq, r2, in_lj, in_c, &fs, &el, &ec);
+                if (alch && ((i >= g_alch_lo && i < g_alch_hi) != (j >= g_alch_lo && j < g_alch_hi))) {
+                    e_x += 0.5 * (el + ec);
+                    fs *= asc; el *= asc; ec *= asc;
+                }
                 fi[0] += fs * d[0]; fi[1] += fs * d[1]; fi[2] += fs * d[2];
                 e_lj += 0.5 * el; e_c += 0.5 * ec; w_nb += 0.5 * fs * r2;
             }
         }
         f[3*i] = fi[0]; f[3*i+1] = fi[1]; f[3*i+2] = fi[2];
     }
-    en[E_LJ] = e_lj; en[E_COUL] = e_c; en[E_VIRIAL] = w_nb;
+    en[E_LJ] = e_lj; en[E_COUL] = e_c; en[E_VIRIAL] = w_nb; en[E_CROSS] = e_x;
     bonded_forces(s, c, x, f, en);
     orc_vsite_spread(s, f);
     if (ext) for (uint32_t i = 0; i < 3 * N; ++i) f[i] += ext[i];

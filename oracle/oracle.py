@@ -12,7 +12,7 @@ import numpy as np
 from molchanica_amd._abi import CConfig, CSystem, MdConfig, MdSystem
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ENERGY_NAMES = ("bond", "angle", "dihedral", "lj", "coulomb", "lj14", "coulomb14", "kinetic", "virial")
+ENERGY_NAMES = ("bond", "angle", "dihedral", "lj", "coulomb", "lj14", "coulomb14", "kinetic", "virial", "cross")
 BAR_PER_KCAL_MOL_A3 = 69476.95
 
 _dp = C.POINTER(C.c_double)
@@ -268,3 +268,9 @@ def langevin_normals(seed, step, atom):
     g = np.zeros(3)
     lib().orc_langevin_normals(C.c_uint64(seed), C.c_uint64(step), C.c_uint32(atom), _d(g))
     return g
+
+
+def set_alchemical(lo: int, hi: int, lam: float):
+    """Couple atoms [lo, hi) to the rest with factor (1 - lam) on their mutual non-bonded pairs; lam < 0 = off.
+    Energies then carry "cross" (unscaled U_cross): dU/dlambda = -cross."""
+    lib().orc_set_alchemical(C.c_uint32(int(lo)), C.c_uint32(int(hi)), C.c_double(float(lam)))

@@ -1,0 +1,95 @@
+"""Pins the alchemical window (`md.configure_alchemical_window`, src/properties/water_sol.rs:556; TI helpers
+water_sol.rs:442,516,568) - CPU only.
+
+  A1  U(lambda) = U(0) - lambda U_cross exactly (linear coupling), forces are -grad U(lambda) by finite
+      differences, dU/dlambda = -U_cross by finite differences in lambda.
+  A2  lambda = 0 is the plain system; lambda = 1 removes every force between the molecule and the rest.
+  A3  the TI helpers: trapezoid of a known integrand, error propagation, block SEM, input checks.
+"""
+import numpy as np
+import pytest
+
+from molchanica_amd import MdConfig, systems
+from molchanica_amd import alchemical as A
+
+
+@pytest.fixture()
+def sys_cfg():
+    s = systems.small_solvated()
+    cfg = MdConfig(lj_cutoff=8.0, coulomb_cutoff=8.0, skin=1.0, coulomb_mode=1)
+    lo, hi = int(s.mol_start[0]), int(s.mol_start[1])
+    assert 10 < hi - lo < s.n_atoms // 2, "molecule 0 is the solute chain"
+    return s, cfg, lo, hi
+
+
+def test_a1_linear_coupling_forces_and_dh_dlambda(orc, sys_cfg):
+    s, cfg, lo, hi = sys_cfg
+    try:
+        orc.set_alchemical(lo, hi, 0.0)
+        f0, e0 = orc.forces(s, cfg, use_cells=True)
+        ux = e0["cross"]
+        assert abs(ux) > 1.0
+        for lam in (0.3, 0.85):
+            orc.set_alchemical(lo, hi, lam)
+            f, e = orc.forces(s, cfg, use_cells=True)
+            assert e["cross"] == pytest.approx(ux, rel=1e-12)
+            assert e["potential"] == pytest.approx(e0["potential"] - lam * ux, rel=1e-12, abs=1e-9)
+            # dU/dlambda by finite differences in lambda
+            h = 1e-4
+            orc.set_alchemical(lo, hi, lam + h); up = orc.forces(s, cfg, use_cells=True)[1]["potential"]
+            orc.set_alchemical(lo, hi, lam - h); dn = orc.forces(s, cfg, use_cells=True)[1]["potential"]
+            assert (up - dn) / (2 * h) == pytest.approx(-ux, rel=1e-7)
+            # forces: central differences on a solute atom and a nearby water atom
+            orc.set_alchemical(lo, hi, lam)
+            x = np.asarray(s.pos, np.float64)
+            d = np.linalg.norm(x[hi:] - x[lo], axis=1)
+            for a in (lo, hi + int(d.argmin())):
+                for k in range(3):
+                    xp = x.copy(); xp[a, k] += 1e-5
+                    xm = x.copy(); xm[a, k] -= 1e-5
+                    num = -(orc.forces(s, cfg, pos=xp, use_cells=True)[1]["potential"]
+                            - orc.forces(s, cfg, pos=xm, use_cells=True)[1]["potential"]) / 2e-5
+                    assert f[a, k] == pytest.approx(num, rel=2e-5, abs=2e-4)
+    finally:
+        orc.set_alchemical(0, 0, -1.0)
+
+
+def test_a2_end_points(orc, sys_cfg):
+    s, cfg, lo, hi = sys_cfg
+    try:
+        orc.set_alchemical(0, 0, -1.0)
+        f_plain, e_plain = orc.forces(s, cfg, use_cells=True)
+        orc.set_alchemical(lo, hi, 0.0)
+        f0, e0 = orc.forces(s, cfg, use_cells=True)
+        assert np.array_equal(f0, f_plain) and e0["potential"] == e_plain["potential"] and e_plain["cross"] == 0.0
+        orc.set_alchemical(lo, hi, 1.0)
+        f1, e1 = orc.forces(s, cfg, use_cells=True)
+        # decoupled: the total force the environment receives from the molecule vanishes, i.e. momentum is
+        # conserved separately by the two subsystems (it is not in the coupled system)
+        assert np.abs(f1[hi:].sum(0)).max() < 1e-8 and np.abs(f1[lo:hi].sum(0)).max() < 1e-8
+        assert np.abs(f_plain[hi:].sum(0)).max() > 1e-3
+    finally:
+        orc.set_alchemical(0, 0, -1.0)
+
+
+def test_a3_ti_helpers():
+    # <dH/dl> = 6 l^2 - 2 on the reference's lambda grid: integral 0 (trapezoid error O(h^2))
+    lams = [0.0, 0.05, 0.10, 0.20, 0.30, 0.40, 0.50, 0.60, 0.70, 0.80, 0.90, 0.95, 1.0]
+    ws = []
+    rng = np.random.default_rng(1)
+    for l in lams:
+        xs = 6 * l * l - 2 + rng.normal(0, 0.5, 400)
+        ws.append(A.collect_window(l, [dict(energy_data=dict(dh_dlambda=float(x), coupled_interaction=float(-x))) for x in xs]))
+        assert ws[-1].n_samples == 400 and ws[-1].sem_dh_dl == pytest.approx(0.5 / 20, rel=0.8)
+    dg, sem = A.free_energy_ti_with_sem(ws)
+    assert dg == pytest.approx(0.0, abs=0.03 + 4 * sem) and 0.003 < sem < 0.03
+    exact = A.free_energy_ti_with_sem([A.LambdaWindow(l, 2 * l, 0.0, 1) for l in lams])
+    assert exact[0] == pytest.approx(1.0, rel=1e-12) and exact[1] == 0.0          # linear integrand: trapezoid exact
+    assert A.mean_coupled_interaction_kcal([dict(coupled_interaction=-3.0), dict(coupled_interaction=-5.0)]) == -4.0
+    assert A.mean_coupled_interaction_kcal([]) is None
+    with pytest.raises(A.AlchemicalError):
+        A.collect_window(0.0, [])
+    with pytest.raises(A.AlchemicalError):
+        A.free_energy_ti_with_sem(ws[:1])
+    with pytest.raises(A.AlchemicalError):
+        A.free_energy_ti_with_sem([ws[0], ws[0]])
