@@ -302,7 +302,7 @@ def test_error_behaviour(mdx):
             md.set_positions(np.full((s.n_atoms, 3), np.nan, np.float32))
         # a blow-up is reported, not silently integrated (cf. sol_shrinking_box.rs:776-789)
         v = md.velocities()
-        v[0] = [1e9, 0, 0]
+        v[0] = [1e20, 0, 0]          # 1e18 A in one step: a runaway coordinate, whatever the forces do
         md.set_velocities(v)
         with pytest.raises(mdx.BlowUpError):
             md.step(0.01, None, 50)
