@@ -141,10 +141,17 @@ class DistComm:
     def exchange(self, sends, recvs):
         """sends: [(peer, tensor)], recvs: [(peer, tensor)] -> one batched group of point-to-point ops
         (ncclGroupStart / ncclSend / ncclRecv ... / ncclGroupEnd under the nccl backend)."""
-        ops = [dist.P2POp(dist.isend, t, q) for q, t in sends] + [dist.P2POp(dist.irecv, t, q) for q, t in recvs]
+        self.run(self.prepare(sends, recvs))
+
+    def prepare(self, sends, recvs):
+        """The op list of a halo exchange is the same every step until the next repartition (same peers, same
+        slices of the same buffers): build the P2POp objects once."""
+        return [dist.P2POp(dist.isend, t, q) for q, t in sends] + [dist.P2POp(dist.irecv, t, q) for q, t in recvs]
+
+    def run(self, ops):
         if ops:
             for w in dist.batch_isend_irecv(ops):
-                w.wait()
+                w.wait()      # nccl: the current stream waits for the transfer; the host does not block
 
 
 class ThreadComm:
@@ -181,6 +188,12 @@ class ThreadComm:
         t.copy_(red)
         self._sync(t)
         sh.barrier.wait()
+
+    def prepare(self, sends, recvs):
+        return (sends, recvs)
+
+    def run(self, prepared):
+        self.exchange(*prepared)
 
     def exchange(self, sends, recvs):
         sh = self.sh
@@ -357,6 +370,7 @@ class DecomposedMd:
         self.recv_shift = mk(r_shift, (0, 4), torch.float32)
         self.send_buf = torch.zeros((s0, 4), dtype=torch.float32, device=self.dev)
         self.recv_buf = torch.zeros((r0, 4), dtype=torch.float32, device=self.dev)
+        self._halo_ops = None          # rebuilt lazily: new buffers, new slices
         # the flag can ride on the halo only if every other rank is a peer in both directions
         self.flag_on_halo = (len(self.send) == self.world - 1 and len(self.recv) == self.world - 1)
         self.repartitions += 1
@@ -380,8 +394,10 @@ class DecomposedMd:
         fw = flag_word if self.flag_on_halo else -1
         if self.send_ids.numel():
             self.engine.pack(self.send_ids, self.send_buf, fw)
-        self.comm.exchange([(q, self.send_buf[a:b]) for q, a, b in self.send],
-                           [(q, self.recv_buf[a:b]) for q, a, b in self.recv])
+        if self._halo_ops is None:
+            self._halo_ops = self.comm.prepare([(q, self.send_buf[a:b]) for q, a, b in self.send],
+                                               [(q, self.recv_buf[a:b]) for q, a, b in self.recv])
+        self.comm.run(self._halo_ops)
         if self.recv_ids.numel():
             self.engine.unpack(self.recv_ids, self.recv_buf, self.recv_shift, fw)
 
