@@ -409,6 +409,7 @@ struct ListArgs {
     unsigned long long* pair_count;  // statistics: sum of popcount(imask)
     int half;                        // 1: every cluster pair appears in exactly one tile's list
     const uint32_t* cell_start;      // [ncol * nzb + 1]: first sorted atom of every (column, z-bin) cell
+    const float4* posq;              // slot-space coordinates, for the exact test of borderline cluster pairs
 };
 
 template <bool FILL>
@@ -419,6 +420,7 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t t = blockIdx.x * LB_WAVES + wave;
     if (t >= a.T) return;
+
     uint32_t* hash = s_hash[wave];
     uint32_t* fl = s_fl[wave];
     const GridParams& g = a.g;
@@ -654,6 +656,89 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
 }
 
 // ================================================================================================
+// Exact pruning of the cluster-pair masks.  The list kernel accepts (i-cluster, j-cluster) on bounding
+// boxes; bricks of 8 atoms rarely fill their corners, and at rc 10 + skin 2 about 23 % of the accepted
+// cluster pairs have NO atom pair inside the list radius - each of them a wasted 64-lane evaluation per
+// step until the next rebuild.  This pass walks the finished list with the pair kernel's own lane mapping
+// (lane = i-atom ii of every i-cluster x j-atom jj of the entry), so one cluster pair costs one distance
+// test per lane and a ballot, and clears the imask bits of pairs without any atom pair inside r.  Entries of
+// the plain run whose mask empties are squeezed out (the run is compacted in place and re-padded); entries of
+// the masked run keep their position, which addresses their exclusion masks.  One wave per tile.
+// ================================================================================================
+__global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, float shx, float shy, float shz,
+                                                         const float4* __restrict__ posq, ListCounts* __restrict__ counts,
+                                                         const uint32_t* __restrict__ entry_off, uint2* __restrict__ entries,
+                                                         uint32_t null_cluster, unsigned long long* __restrict__ pair_count) {
+    __shared__ float4 s_j[4][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t t = blockIdx.x * 4 + wave;      // one wave per tile: the plain run is compacted in place
+    if (t >= T) return;
+    const int ii = lane & 7, jj = lane >> 3;
+    float xi[8], yi[8], zi[8];
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) {
+        const float4 p = posq[(size_t)t * MDX_TILE + ci * MDX_CLUSTER + ii];
+        xi[ci] = p.x; yi[ci] = p.y; zi[ci] = p.z;
+    }
+    const ListCounts cnt = counts[t];
+    const uint32_t e0 = entry_off[t], nmc = cnt.n_masked >> 3, nchunks = (cnt.n_masked + cnt.n_plain) >> 3;
+    uint32_t kept = 0, wcur = 0;                   // wcur: plain entries written back so far
+    // prefetch chunk 0
+    uint2 ent_n = make_uint2(null_cluster, 13u);
+    float4 pj_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nchunks) { ent_n = entries[e0 + (lane >> 3)]; pj_n = posq[(size_t)ent_n.x * MDX_CLUSTER + (lane & 7)]; }
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        const uint2 ent = ent_n;
+        float4 pj = pj_n;
+        if (c + 1 < nchunks) {
+            ent_n = entries[e0 + (c + 1) * 8 + (lane >> 3)];
+            pj_n = posq[(size_t)ent_n.x * MDX_CLUSTER + (lane & 7)];
+        }
+        const uint32_t code = ent.y & 31u;
+        pj.x += (float)((int)(code % 3u) - 1) * shx;
+        pj.y += (float)((int)((code / 3u) % 3u) - 1) * shy;
+        pj.z += (float)((int)(code / 9u) - 1) * shz;
+        s_j[wave][lane] = pj;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+        uint32_t newy = ent.y;                     // lanes 8e .. 8e+7 hold entry e
+#pragma unroll 2
+        for (int e = 0; e < 8; ++e) {
+            const float4 q = s_j[wave][e * 8 + jj];
+            uint32_t any = 0;                      // all eight i-clusters, no branches: eight independent ballots
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci) {
+                const float dx = xi[ci] - q.x, dy = yi[ci] - q.y, dz = zi[ci] - q.z;
+                any |= (__ballot(dx * dx + dy * dy + dz * dz < r2) != 0ull ? 1u : 0u) << ci;
+            }
+            const uint32_t y = __builtin_amdgcn_readlane(ent.y, e * 8);
+            const uint32_t im = (y >> 8) & any;
+            kept += __popc(im & 0xFFu);
+            if ((lane >> 3) == e) newy = (y & 0xFFu) | ((im & 0xFFu) << 8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+        if (c < nmc) {
+            // masked run: per-lane exclusion masks are addressed by chunk position, entries stay where they are
+            if ((lane & 7) == 0 && newy != ent.y) entries[e0 + c * 8 + (lane >> 3)].y = newy;
+        } else {
+            // plain run: survivors move down (write cursor <= read position, and the next chunk is already in registers)
+            const bool alive = (lane & 7) == 0 && (newy >> 8) != 0u;
+            const unsigned long long bal = __ballot(alive);
+            if (alive) {
+                const uint32_t rank = __popcll(bal & ((1ull << lane) - 1ull));
+                entries[e0 + cnt.n_masked + wcur + rank] = make_uint2(ent.x, newy);
+            }
+            wcur += __popcll(bal);
+        }
+    }
+    const uint32_t np_pad = (wcur + 7u) & ~7u;
+    if (lane < (int)(np_pad - wcur)) entries[e0 + cnt.n_masked + wcur + lane] = make_uint2(null_cluster, 13u);
+    if (lane == 0) {
+        counts[t].n_plain = np_pad;
+        if (kept) atomicAdd(pair_count + 1, (unsigned long long)kept);
+    }
+}
+
+// ================================================================================================
 // neighbour-list extraction (parity / debugging API): canonical fp32 distances
 // ================================================================================================
 __device__ __forceinline__ float r2_canonical(float4 pi, float4 pj, const float* L, const int* per) {
@@ -868,6 +953,7 @@ int mdx_rebuild(mdx_handle* h) {
     a.mask_layout = mdx_nb_variant(h) >= 2 ? 2 : 1;
     a.half = mdx_nb_half(h) ? 1 : 0;
     a.cell_start = d.cell_start;
+    a.posq = d.posq;
     if (!d.pair_count) ALLOC(d.pair_count, 2);
     a.pair_count = d.pair_count;
     HIP_TRY(hipMemsetAsync(d.pair_count, 0, sizeof(unsigned long long) * 2, st));
@@ -896,6 +982,14 @@ int mdx_rebuild(mdx_handle* h) {
     }
     h->E = E; h->MC = MC;
     hipLaunchKernelGGL(build_list_kernel<true>, dim3(div_up(T, LB_WAVES)), dim3(LB_WAVES * 64), 0, st, a);
+    const bool prune = !std::isinf(h->r_list) && mdx_nb_variant(h) >= 2;   // the whole-tile kernel ignores imask
+    if (prune && T) {
+        const float rb = a.r_build;
+        hipLaunchKernelGGL(prune_list_kernel, dim3(div_up(T, 4)), dim3(256), 0, st, T, rb * rb,
+                           h->per[0] ? h->box_hi[0] - h->box_lo[0] : 0.f, h->per[1] ? h->box_hi[1] - h->box_lo[1] : 0.f,
+                           h->per[2] ? h->box_hi[2] - h->box_lo[2] : 0.f, d.posq, d.list_counts, d.entry_off, d.entries,
+                           a.null_cluster, d.pair_count);
+    }
 
     // ---- bonded role lists into slot space ----
     if (h->n_roles) {
@@ -907,8 +1001,11 @@ int mdx_rebuild(mdx_handle* h) {
     }
     MDX_TRY(mdx_remap_constraints(h));
     HIP_TRY(hipGetLastError());
+    unsigned long long npairs_pruned = 0;
     HIP_TRY(hipMemcpyAsync(flags, d.flags_dev, sizeof(flags), hipMemcpyDeviceToHost, st));
+    if (prune) HIP_TRY(hipMemcpyAsync(&npairs_pruned, d.pair_count + 1, sizeof(npairs_pruned), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (prune) npairs = npairs_pruned;
     if (flags[0] & 8u) { mdx_set_error("a constrained / virtual-site atom is missing from the local atom set"); return MDX_EPARAM; }
     if (flags[0] & 3u) { mdx_set_error("exclusion table overflow while building the pair list"); return MDX_EPARAM; }
     if (flags[0] & 4u) {
