@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--energy-every", type=int, default=100,
                     help="evaluate energies (an energy-flavoured force pass + reduction) every this many timed steps, "
                          "as SURVEY 8d's measurement contract asks; 0 = never")
+    ap.add_argument("--skin", type=float, default=2.0, help="Verlet buffer in A (the measurement contract says 2)")
     ap.add_argument("--pme", action="store_true", help="Ewald Coulomb with the SPME reciprocal sum (not the headline config)")
     return ap.parse_args()
 
@@ -107,7 +108,7 @@ def main():
     from molchanica_amd.md_state import MdState
 
     system = systems.BY_NAME[args.workload]()
-    cfg = MdConfig(nb_variant=args.nb_variant)  # rc 10 Å (LJ & Coulomb), skin 2 Å, shifted cutoff Coulomb
+    cfg = MdConfig(nb_variant=args.nb_variant, skin=args.skin)  # rc 10 Å (LJ & Coulomb), skin 2 Å, shifted cutoff Coulomb
     if args.pme:
         cfg = MdConfig(nb_variant=args.nb_variant, coulomb_mode=2, ewald_alpha=0.3, overrides=0)
     n_atoms = system.n_atoms

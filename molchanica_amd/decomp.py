@@ -148,7 +148,27 @@ class DistComm:
         slices of the same buffers): build the P2POp objects once."""
         return [dist.P2POp(dist.isend, t, q) for q, t in sends] + [dist.P2POp(dist.irecv, t, q) for q, t in recvs]
 
+    def prepare_halo(self, send_buf, recv_buf, send_segs, recv_segs):
+        """Halo exchange over ONE send and ONE receive buffer whose per-peer segments are stored in rank order
+        (send_segs / recv_segs: [(peer, row0, row1)]).  Default: a single `all_to_all_single` with uneven
+        splits - under the nccl backend one ncclGroupStart / ncclSend + ncclRecv per peer / ncclGroupEnd, i.e.
+        the same wire traffic as the batched point-to-point list, at a fraction of its per-step Python cost
+        (one collective call instead of 2 x peers work objects).  MDX_HALO_P2P=1 selects the P2P list."""
+        import os
+        if os.environ.get("MDX_HALO_P2P", "0") == "1":
+            return self.prepare([(q, send_buf[a:b]) for q, a, b in send_segs], [(q, recv_buf[a:b]) for q, a, b in recv_segs])
+        ins, outs = [0] * self.world, [0] * self.world
+        for q, a, b in send_segs:
+            ins[q] = b - a
+        for q, a, b in recv_segs:
+            outs[q] = b - a
+        return ("a2a", send_buf, recv_buf, ins, outs)
+
     def run(self, ops):
+        if isinstance(ops, tuple) and ops and ops[0] == "a2a":
+            _, send_buf, recv_buf, ins, outs = ops
+            dist.all_to_all_single(recv_buf, send_buf, output_split_sizes=outs, input_split_sizes=ins)
+            return
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()      # nccl: the current stream waits for the transfer; the host does not block
@@ -191,6 +211,9 @@ class ThreadComm:
 
     def prepare(self, sends, recvs):
         return (sends, recvs)
+
+    def prepare_halo(self, send_buf, recv_buf, send_segs, recv_segs):
+        return ([(q, send_buf[a:b]) for q, a, b in send_segs], [(q, recv_buf[a:b]) for q, a, b in recv_segs])
 
     def run(self, prepared):
         self.exchange(*prepared)
@@ -395,8 +418,7 @@ class DecomposedMd:
         if self.send_ids.numel():
             self.engine.pack(self.send_ids, self.send_buf, fw)
         if self._halo_ops is None:
-            self._halo_ops = self.comm.prepare([(q, self.send_buf[a:b]) for q, a, b in self.send],
-                                               [(q, self.recv_buf[a:b]) for q, a, b in self.recv])
+            self._halo_ops = self.comm.prepare_halo(self.send_buf, self.recv_buf, self.send, self.recv)
         self.comm.run(self._halo_ops)
         if self.recv_ids.numel():
             self.engine.unpack(self.recv_ids, self.recv_buf, self.recv_shift, fw)

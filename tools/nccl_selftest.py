@@ -30,10 +30,16 @@ with torch.cuda.stream(eng.stream):
         ok_self = bool(torch.equal(sbuf, rbuf))
     except Exception as e:
         ok_self = f"self send/recv unsupported: {type(e).__name__}: {str(e)[:80]}"
+    try:
+        rbuf2 = torch.zeros((4, 4), device="cuda")
+        comm.run(comm.prepare_halo(sbuf, rbuf2, [(0, 0, 4)], [(0, 0, 4)]))      # the default halo path: all_to_all_single
+        ok_a2a = bool(torch.equal(sbuf, rbuf2))
+    except Exception as e:
+        ok_a2a = f"all_to_all_single failed: {type(e).__name__}: {str(e)[:80]}"
     eng.chunk_forces(0)
     eng.chunk_integrate(2, 0.0005, 1)
     words = eng.chunk_end(2)
 torch.cuda.synchronize()
 print("all_reduce ok:", bool(torch.equal(st.cpu(), torch.arange(12.).reshape(3, 4))), "| flag word:", int(words[1]),
-      "| self exchange:", ok_self, "| packed row0:", sbuf[0].tolist())
+      "| self exchange:", ok_self, "| all_to_all_single halo:", ok_a2a, "| packed row0:", sbuf[0].tolist())
 dist.destroy_process_group()
