@@ -131,6 +131,8 @@ static int check_box(const int per[3], const float* lo, const float* hi, const m
     return MDX_OK;
 }
 
+int mdx_check_box(const mdx_handle* h, const float* lo, const float* hi) { return check_box(h->per, lo, hi, &h->cfg); }
+
 static void free_device(mdx_handle* h) {
     DeviceState& d = h->d;
     void* ptrs[] = {d.o_qs, d.o_lj, d.o_invm, d.o_mass, d.o_q, d.o_lj_raw, d.excl_off, d.excl_idx, d.pos_orig,

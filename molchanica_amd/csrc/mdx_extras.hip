@@ -168,12 +168,13 @@ static int apply_barostat(mdx_handle* h, double dt_couple) {
     double mu = std::cbrt(std::max(mu3, 0.5));
     mu = std::min(1.01, std::max(0.99, mu));
     if (mu == 1.0) return MDX_OK;
+    float hi[3];
+    for (int d = 0; d < 3; ++d) hi[d] = h->box_lo[d] + (float)mu * (h->box_hi[d] - h->box_lo[d]);
+    MDX_TRY(mdx_check_box(h, h->box_lo, hi));   // refuse BEFORE touching the state (box < 2 (rc + skin): stop, cf. sol_shrinking_box.rs guards)
     MDX_TRY(mdx_unsort_state(h));
     hipLaunchKernelGGL(scale_positions_kernel, dim3(div_up(h->n_local, 256)), dim3(256), 0, h->stream, h->n_local,
                        h->d.pos_orig, h->box_lo[0], h->box_lo[1], h->box_lo[2], (float)mu);
     HIP_TRY(hipGetLastError());
-    float hi[3];
-    for (int d = 0; d < 3; ++d) hi[d] = h->box_lo[d] + (float)mu * (h->box_hi[d] - h->box_lo[d]);
     MDX_TRY(mdx_set_box(h, h->box_lo, hi));
     if (h->n_groups) h->cons_dirty = true;   // bonds of constrained clusters were scaled too: project back
     h->last_pressure = e.pressure; h->last_mu = mu;

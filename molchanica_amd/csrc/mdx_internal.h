@@ -274,7 +274,8 @@ int mdx_remap_constraints(mdx_handle* h);                  // caller order -> sl
 int mdx_launch_constrain_positions(mdx_handle* h, float dt, const uint32_t* d_gate, uint32_t* d_disp_out, uint32_t thr);
 int mdx_launch_constrain_velocities(mdx_handle* h, const uint32_t* d_gate, uint32_t thr);
 int mdx_launch_vsite_construct(mdx_handle* h, const uint32_t* d_gate, uint32_t thr);
-int mdx_launch_constraint_virial(mdx_handle* h);   // energy[EN_VIRIAL] += sum of cons_vir
+int mdx_launch_constraint_virial(mdx_handle* h);
+int mdx_check_box(const mdx_handle* h, const float* lo, const float* hi);   // the checks mdx_set_box applies   // energy[EN_VIRIAL] += sum of cons_vir
 int mdx_launch_vsite_spread(mdx_handle* h, const uint32_t* d_gate, uint32_t thr);
 
 // SPME reciprocal space (mdx_pme.hip)
