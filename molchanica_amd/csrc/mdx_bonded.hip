@@ -40,17 +40,28 @@ __device__ __forceinline__ float3 cross3(float3 a, float3 b) {
 }
 __device__ __forceinline__ float3 scale3(float3 a, float s) { return make_float3(a.x * s, a.y * s, a.z * s); }
 
+// Four lanes per atom: lane q of the quad takes roles q, q+4, ... of the atom's list and the quad sums its
+// forces with two DPP steps.  A chain atom has ~20 roles (each a chain of dependent partner loads) against a
+// water atom's 2.3; with one lane per atom every wave waited for its longest list (23 k-atom solvated chain:
+// 26 us, as long as the pair kernel) - and a quad reads four consecutive 32-B role records as one 128-B line.
+template <int CTRL>
+__device__ __forceinline__ float quad_xadd(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+constexpr int BONDED_LPA = 4;
+
 template <bool ENERGY>
 __global__ __launch_bounds__(256) void bonded_gather_kernel(BondedArgs a) {
     if (a.gate && *a.gate > a.thr_bits) return;
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = tid / BONDED_LPA, q4 = tid % BONDED_LPA;
     double e_bond = 0.0, e_angle = 0.0, e_dih = 0.0, e_lj14 = 0.0, e_c14 = 0.0, e_rec = 0.0, e_vir = 0.0;
     if (s < a.S) {
         const uint32_t rb = a.role_off[s], re = a.role_off[s + 1];
-        if (re > rb) {
+        if (re > rb) {     // quad-uniform
             const float4 self = a.posq[s];
             float fx = 0.f, fy = 0.f, fz = 0.f;
-            for (uint32_t k = rb; k < re; ++k) {
+            for (uint32_t k = rb + q4; k < re; k += BONDED_LPA) {
                 const RoleRec r = a.roles[k];
                 const uint32_t kind = r.meta & 0xFu, role = (r.meta >> 4) & 0xFu;
                 if (kind == ROLE_EWALD_EXCL) {
@@ -142,9 +153,13 @@ __global__ __launch_bounds__(256) void bonded_gather_kernel(BondedArgs a) {
                     }
                 }
             }
-            float4 f = a.force[s];
-            f.x += fx; f.y += fy; f.z += fz;
-            a.force[s] = f;
+            fx = quad_xadd<0xB1>(fx); fy = quad_xadd<0xB1>(fy); fz = quad_xadd<0xB1>(fz);   // lane ^ 1
+            fx = quad_xadd<0x4E>(fx); fy = quad_xadd<0x4E>(fy); fz = quad_xadd<0x4E>(fz);   // lane ^ 2
+            if (q4 == 0) {
+                float4 f = a.force[s];
+                f.x += fx; f.y += fy; f.z += fz;
+                a.force[s] = f;
+            }
         }
     }
     if (ENERGY) {
@@ -193,7 +208,7 @@ int mdx_launch_bonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32
     }
     a.p.ewald_beta = h->cfg.ewald_alpha; a.p.skip_bonded = skip_bonded ? 1 : 0;
     mdx_prof_begin(h, energy ? 3 : 1);
-    const dim3 g((h->S + 255) / 256), b(256);
+    const dim3 g((uint32_t)(((size_t)h->S * BONDED_LPA + 255) / 256)), b(256);
     if (energy) hipLaunchKernelGGL(bonded_gather_kernel<true>, g, b, 0, h->stream, a);
     else hipLaunchKernelGGL(bonded_gather_kernel<false>, g, b, 0, h->stream, a);
     mdx_prof_end(h);
