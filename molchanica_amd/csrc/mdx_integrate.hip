@@ -34,9 +34,11 @@ __device__ __forceinline__ void langevin_normals(uint64_t seed, uint64_t step, u
     g0 = r1 * c1; g1 = r1 * s1; g2 = r2 * c2; (void)s2;
 }
 
-template <int MODE>  // 0: half kick + drift, 1: full kick + drift, 2: closing half kick, 3: Langevin middle
+// ZERO: clear the force array once it has been consumed - the half-list pair kernel that follows accumulates
+// with atomics and needs it zero; doing it here saves a separate fill launch per step.
+template <int MODE, bool ZERO>  // 0: half kick + drift, 1: full kick + drift, 2: closing half kick, 3: Langevin middle
 __global__ __launch_bounds__(256) void integrate_kernel(uint32_t S, float dt, float4* __restrict__ posq,
-                                                        float4* __restrict__ vel, const float4* __restrict__ force,
+                                                        float4* __restrict__ vel, float4* __restrict__ force,
                                                         const float4* __restrict__ ref, const uint32_t* gate_in,
                                                         uint32_t* disp_out, uint32_t thr_bits, LangevinArgs lg) {
     const uint32_t gate = gate_in ? *gate_in : 0u;
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(256) void integrate_kernel(uint32_t S, float dt, fl
             }
             vel[s] = v;
         }
+        if (ZERO) force[s] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (MODE != 2) {
 #pragma unroll
@@ -131,14 +134,22 @@ int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_ga
         lg.seed = h->lang_seed; lg.step = h->lang_step;
         lg.orig_of = d.orig_of; lg.gid = d.gid;
     }
-#define INTEG(M) hipLaunchKernelGGL(integrate_kernel<M>, g, b, 0, h->stream, h->S, dt, d.posq, d.vel, d.force, d.ref, \
-                                    d_gate_in, d_disp_out, thr_bits, lg)
+    // the force array is consumed here and rebuilt by the force pass that follows modes 0/1/3
+    const bool zero = mode != 2 && mdx_nb_half(h);
+#define INTEG(M)                                                                                                      \
+    do {                                                                                                              \
+        if (zero) hipLaunchKernelGGL((integrate_kernel<M, true>), g, b, 0, h->stream, h->S, dt, d.posq, d.vel, d.force, \
+                                     d.ref, d_gate_in, d_disp_out, thr_bits, lg);                                    \
+        else hipLaunchKernelGGL((integrate_kernel<M, false>), g, b, 0, h->stream, h->S, dt, d.posq, d.vel, d.force,  \
+                                d.ref, d_gate_in, d_disp_out, thr_bits, lg);                                          \
+    } while (0)
     switch (mode) {
     case 0: INTEG(0); break;
     case 1: INTEG(1); break;
     case 3: INTEG(3); break;
     default: INTEG(2); break;
     }
+    if (zero) h->force_zeroed = true;
 #undef INTEG
     mdx_prof_end(h);
     HIP_TRY(hipGetLastError());

@@ -217,6 +217,7 @@ struct mdx_handle {
     int integrator = 0; float lang_gamma = 1.f, lang_temp = 300.f; uint64_t lang_seed = 0, lang_step = 0;
     int baro_kind = 0; float baro_p0 = 1.f, baro_tau = 5.f, baro_beta = 4.5e-5f; uint32_t baro_every = 25;
     double last_pressure = 0.0, last_mu = 1.0;
+    bool force_zeroed = false;   // the integrate pass just enqueued cleared the force array (half-list kernel: skip the fill)
     uint64_t rng_state = 0;
     bool zero_com = false;
     uint32_t snap_every = 0; bool snap_vel = false;

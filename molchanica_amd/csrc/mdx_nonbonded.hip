@@ -519,7 +519,8 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
     mdx_prof_begin(h, energy ? 3 : 0);   // 3: the energy flavour is a different kernel, keep it out of the step-loop average
     // the half-list kernel accumulates with atomics: start from zero (part of the kernel's cost, so
     // inside the profiled bracket; harmless when the launch behind it is gated off, see mdx_step)
-    if (mdx_nb_half(h)) HIP_TRY(hipMemsetAsync(h->d.force, 0, sizeof(float4) * (size_t)h->S, h->stream));
+    if (mdx_nb_half(h) && !h->force_zeroed) HIP_TRY(hipMemsetAsync(h->d.force, 0, sizeof(float4) * (size_t)h->S, h->stream));
+    h->force_zeroed = false;
 #define NB_DISPATCH(E)                                                              \
     switch (mode) {                                                                 \
     case CM_SHIFTED: launch_variant<E, CM_SHIFTED>(h, a, geom, samecut); break;     \
