@@ -225,7 +225,9 @@ uint64_t mdx_step_count(const mdx_handle* h);
  * (offsets[N] = total), then again with idx sized offsets[N]. */
 int mdx_neighbor_list(mdx_handle* h, uint32_t* offsets /* [N+1] */, uint32_t* idx /* or NULL */);
 
-/* Kernel timing with HIP events on the library's stream; mdx_get_stats reads the sums. */
+/* Kernel timing with HIP events on the library's stream; mdx_get_stats reads the sums.  enable: 0 off, 1 every
+ * step kernel, 2 the pair kernel only (each event pair is two extra packets in the queue: level 2 disturbs the
+ * step loop least). */
 int mdx_profile(mdx_handle* h, int enable);
 int mdx_get_stats(mdx_handle* h, mdx_stats* out);
 

@@ -382,7 +382,10 @@ static int ensure_ready(mdx_handle* h) {
 
 // ---- profiling -------------------------------------------------------------------------------
 void mdx_prof_begin(mdx_handle* h, int kind) {
+    h->prof_open = false;
     if (!h->profile) return;
+    if (h->profile_level == 2 && kind != 0) return;   // pair kernel of the step loop only
+    h->prof_open = true;
     mdx_handle::EvPair p{};
     p.kind = kind; p.tag = h->prof_tag;
     hipEvent_t* ev[2] = {&p.a, &p.b};
@@ -394,7 +397,8 @@ void mdx_prof_begin(mdx_handle* h, int kind) {
     h->ev_pending.push_back(p);
 }
 void mdx_prof_end(mdx_handle* h) {
-    if (!h->profile || h->ev_pending.empty()) return;
+    if (!h->profile || !h->prof_open || h->ev_pending.empty()) return;
+    h->prof_open = false;
     (void)hipEventRecord(h->ev_pending.back().b, h->stream);
 }
 void mdx_prof_collect(mdx_handle* h, int first_stale_step) {
@@ -664,7 +668,7 @@ extern "C" int mdx_profile(mdx_handle* h, int enable) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     mdx_prof_collect(h);
-    h->profile = enable != 0;
+    h->profile = enable != 0; h->profile_level = enable;
     if (enable) {
         h->stats.nb_ms_sum = h->stats.bonded_ms_sum = h->stats.integ_ms_sum = 0.0;
         h->stats.rebuild_ms_sum = h->stats.wall_ms_sum = 0.0;

@@ -206,7 +206,7 @@ struct mdx_handle {
     bool have_ext = false;
     uint64_t step_count = 0, rebuild_count = 0;
     // profiling
-    bool profile = false;
+    bool profile = false; int profile_level = 0; bool prof_open = false;
     struct EvPair { hipEvent_t a, b; int kind; int tag; };
     int prof_tag = -1;       // chunk step of the launches being enqueued (-1: ungated)
     std::vector<EvPair> ev_pending;

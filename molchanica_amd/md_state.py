@@ -303,8 +303,9 @@ class MdState:
         return float(load_library().mdx_time_ps(self._h))
 
     # -- profiling ---------------------------------------------------------------------------
-    def profile(self, enable: bool = True):
-        _check(load_library().mdx_profile(self._h, 1 if enable else 0))
+    def profile(self, enable=True):
+        """0/False off, 1/True every step kernel, 2 the pair kernel only."""
+        _check(load_library().mdx_profile(self._h, int(enable)))
 
     def stats(self) -> dict:
         s = CStats()
