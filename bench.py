@@ -102,10 +102,19 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    # Verification aid for 1-GPU boxes: MDX_BENCH_SAME_GPU=1 maps every rank to device 0 and uses the gloo backend
+    # (RCCL refuses two ranks on one device), so the complete multi-process flow - rendezvous, broadcast of the
+    # prepared state, repartition all-reduce, per-step halo exchange, energy all-reduce - runs on real kernels.
+    same_gpu = os.environ.get("MDX_BENCH_SAME_GPU", "0") == "1"
+    if same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if same_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from molchanica_amd import MdConfig, systems
     from molchanica_amd.md_state import MdState

@@ -116,3 +116,25 @@ def test_local_rebuilds_between_repartitions():
     d -= np.round(d / L) * L
     assert math.sqrt((d ** 2).sum(1).mean()) < 3e-3
     assert rebuilds_ref >= 3
+
+
+def test_bench_multiprocess_flow_two_ranks_one_gpu():
+    """The driver's launch line for N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`) with two ranks
+    mapped onto this box's one GPU (MDX_BENCH_SAME_GPU=1: gloo instead of RCCL, which refuses two ranks per device):
+    rendezvous, broadcast of the prepared state, repartition all-reduce, per-step halo exchange (all_to_all_single),
+    energy all-reduce and the JSON line all run for real."""
+    import json, os, socket, subprocess, sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MDX_BENCH_SAME_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "8",
+           "--workload", "dna100k", "--no-cpu-baseline", "--energy-every", "20"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 40 and j["value"] > 0 and j["scaling"] == "strong"
+    assert j["config"]["energy_evaluations_in_timed_region"] == 2 and "2x1x1" in j["config"]["parallelism"]
