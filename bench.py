@@ -232,7 +232,8 @@ def main():
                    "coulomb_cutoff": cfg.coulomb_cutoff, "skin": cfg.skin, "dt_ps": args.dt,
                    "coulomb": "ewald real space + SPME (order 4, ~1 A mesh)" if args.pme else "shifted cutoff", "parallelism": parallelism,
                    "rebuilds_in_timed_region": int(st["rebuild_count"] - rebuilds0),
-                   "energy_evaluations_in_timed_region": n_energy, "untimed_preparation": prep},
+                   "energy_evaluations_in_timed_region": n_energy, "untimed_preparation": prep,
+                   "repartitions": getattr(md, "repartitions", None), "local_rebuilds": getattr(md, "local_rebuilds_total", None)},
         "roofline": {"kernel": "nb_tile_kernel" if args.nb_variant == 1 else "nb_cluster_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "launch_ms": nb_ms, "launches": st["nb_launches"],

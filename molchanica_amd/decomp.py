@@ -306,9 +306,12 @@ class DecomposedMd:
                     for d in range(3) if grid[d] > 1] or [halo_margin])
         self.halo_margin = max(0.0, min(float(halo_margin), room))
         self.halo = r_list + self.halo_margin
-        per_rebuild = 0.5 * cfg.skin + 0.15          # drift that triggers a rebuild + one step of overshoot
-        self.local_rebuilds_allowed = int((0.5 * self.halo_margin) // per_rebuild) if world > 1 else 0
+        # How long is that?  Counting rebuilds (each "uses up" skin/2 + overshoot of the budget) is the worst
+        # case and allowed ONE local rebuild per repartition; measuring is better: at every rebuild event the
+        # largest displacement since the last repartition is reduced over the ranks (one small all-reduce), and
+        # the local atom set is kept while it stays below margin/2.  At 300 K that is hundreds of steps, not ~50.
         self.local_rebuilds = 0
+        self.local_rebuilds_total = 0
         self.part = Partition(system.box_lo, system.box_hi, world, self.halo)
         self.engine = engine if engine is not None else HipEngine(system, cfg, device)
         self.comm = comm if comm is not None else DistComm(rank, world)
@@ -334,7 +337,7 @@ class DecomposedMd:
     def describe(self) -> str:
         g = self.part.grid
         return (f"spatial {g[0]}x{g[1]}x{g[2]} bricks, ghost halo {self.halo:.1f} A, RCCL send/recv per peer, "
-                f"{self.local_rebuilds_allowed} local rebuilds per repartition")
+                f"local list rebuilds while max drift < {0.5 * self.halo_margin:.1f} A, then repartition")
 
     def _repartition_from(self, pos_all: torch.Tensor, vel_all: torch.Tensor):
         """pos_all/vel_all: [N,3] global state, identical on every rank."""
@@ -359,6 +362,7 @@ class DecomposedMd:
         self.gid_local = gid_local.to(torch.int32).contiguous()
         self.engine.set_local_atoms(self.gid_local, ghost.contiguous(), pos4.contiguous(), vel4.contiguous(),
                                     lo, hi, part.periodic_mask())
+        self.pos_at_part = pos4[:, :3].clone()
         # halo lists, derived identically on every rank: what rank q needs from rank p.  All peers'
         # rows live in ONE send and ONE receive buffer (one pack and one unpack launch per step); a
         # peer's segment ends with a flag row (id -1) that carries the rebuild-flag word.
@@ -397,6 +401,24 @@ class DecomposedMd:
         # the flag can ride on the halo only if every other rank is a peer in both directions
         self.flag_on_halo = (len(self.send) == self.world - 1 and len(self.recv) == self.world - 1)
         self.repartitions += 1
+
+    def _local_set_still_valid(self) -> bool:
+        """May the owned + ghost set of the last repartition serve one more list rebuild?  Yes while no atom has
+        moved further than margin/2 from where it was then (a stranger and an owned atom approaching each other
+        can then not have closed the `margin` that separated the stranger from the halo)."""
+        if self.world == 1:
+            return True                       # nothing is left out of a one-rank box
+        if self.halo_margin <= 0.0 or self.local_rebuilds >= 256:
+            return False
+        pos4, _ = self.engine.local_state()
+        d = pos4[:, :3] - self.pos_at_part
+        L = self.part.len.to(d.device)
+        for k in range(3):                    # an uncut dimension stays periodic inside the engine: it may have wrapped
+            if self.part.grid[k] == 1:
+                d[:, k] -= torch.round(d[:, k] / L[k]) * L[k]
+        d2 = (d * d).sum(1).max().reshape(1)
+        self.comm.all_reduce(d2, "max")
+        return float(d2.item()) ** 0.5 <= 0.5 * self.halo_margin - 0.05
 
     def _gather_global(self):
         """-> (pos [N,3], vel [N,3]) of the whole box on every rank: owned rows scattered into a zero
@@ -451,8 +473,8 @@ class DecomposedMd:
                         if np.uint32(words[s + 1]).view(np.float32) > 1.0e29:
                             raise FloatingPointError("non-finite or runaway coordinates during decomposed step")
                         # the drift of step s happened everywhere, its forces nowhere: repartition, finish it
-                        if self.local_rebuilds < self.local_rebuilds_allowed:
-                            self.local_rebuilds += 1          # same decision on every rank: the flag is global
+                        if self._local_set_still_valid():      # same decision on every rank: reduced over all
+                            self.local_rebuilds += 1; self.local_rebuilds_total += 1
                             eng.rebuild()
                         else:
                             import time as _t
