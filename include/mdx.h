@@ -272,7 +272,7 @@ int mdx_configure_alchemical_window(mdx_handle* h, uint32_t mol_index, double la
 
 /* Steepest descent with an adaptive maximum displacement (start 0.01 Å; x += h F/|F|max; accepted
  * when the potential energy drops: h *= 1.2, else the move is undone and h *= 0.5); stops after
- * max_iters force evaluations or when max |F| < f_tol.  Velocities are left untouched. */
+ * max_iters force evaluations or when max |F| < f_tol; h never exceeds 0.2 Å.  Velocities are left untouched. */
 int mdx_minimize_energy(mdx_handle* h, uint32_t max_iters, const float* ext_forces_or_null, float f_tol,
                         mdx_energies* final_or_null, uint32_t* iters_done_or_null);
 /* Maxwell-Boltzmann velocities from a counter-based generator (splitmix64 + Box-Muller, three

@@ -349,6 +349,12 @@ extern "C" int mdx_initialize_velocities(mdx_handle* h, float temperature, int z
     return mdx_upload(h, MDX_VEL, v.data());
 }
 
+// The largest displacement one iteration may give the most-forced atom.  Without a ceiling the x1.2 growth reaches
+// several A after ~30 accepted steps, and in a 1 M-atom box a step that tears one water apart (+600 kcal/mol) is
+// still "downhill" because the other million atoms gain more: one vibrationally hot molecule then triggers a list
+// rebuild every 2-3 steps for the rest of the run.
+static constexpr double MDX_MIN_MAX_STEP = 0.2;
+
 extern "C" int mdx_minimize_energy(mdx_handle* h, uint32_t max_iters, const float* ext_forces, float f_tol,
                                    mdx_energies* final_e, uint32_t* iters_done) {
     if (!h) FAIL(MDX_EPARAM, "null handle");
@@ -391,7 +397,7 @@ extern "C" int mdx_minimize_energy(mdx_handle* h, uint32_t max_iters, const floa
         if (rc != MDX_OK) return done(rc);
         if (trial.potential < cur.potential) {
             cur = trial;
-            hstep *= 1.2;
+            hstep = std::min(hstep * 1.2, MDX_MIN_MAX_STEP);
             rc = mdx_gather_to_orig(h, h->d.posq, backup);
             if (rc != MDX_OK) return done(rc);
         } else {

@@ -957,7 +957,7 @@ int orc_minimize(const mdx_system* s, const mdx_config* c, double* x, uint32_t m
         if (ept < ep) {
             memcpy(x, xt, sizeof(double) * 3 * N); memcpy(f, ft, sizeof(double) * 3 * N);
             memcpy(en, ent, sizeof(en));
-            h *= 1.2;
+            h *= 1.2; if (h > 0.2) h = 0.2;   /* ceiling on the largest displacement per iteration, as in mdx_minimize_energy */
         } else {
             h *= 0.5;
         }
