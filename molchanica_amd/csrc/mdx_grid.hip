@@ -3,7 +3,7 @@
 //
 // Replaces what `MdState::new` / `md.rebuild_spatial_caches()` do inside the absent `dynamics`
 // crate  [ref: /root/reference src/md/mod.rs:689; src/properties/sol_shrinking_box.rs:632].
-// Everything here is integer / bounding-box work and HBM-bound; it runs once per ~40-80 steps.
+// Everything here is integer / bounding-box work, HBM- or latency-bound; it runs once per ~25 steps at 300 K.
 //
 // Pipeline (all on the handle's stream):
 //   bin      atom -> (column, z-bin) cell id, wrap into the box, histogram       (1 thread/atom)
@@ -14,8 +14,11 @@
 //            y | x | z so that each run of 8 lanes (a cluster) is a compact brick
 //   gather   slot-space arrays (posq, lj, vel, ref) from caller-order data; dummies parked far away
 //   bbox     per-cluster bounding boxes
-//   list     per tile: all (j-cluster, image) within r_list of the tile, with the per-i-cluster
-//            mask, exclusion-bearing entries first + their 64-bit per-lane interaction masks
+//   list     per tile: all (j-cluster, image) within r_list of the tile (bounding boxes; candidates looked up through
+//            the column's z-bins), with the per-i-cluster mask, exclusion-bearing entries first + their 64-bit
+//            per-lane interaction masks; half list: every cluster pair in ONE tile's list (parity of I + J)
+//   prune    the pair kernel's lane mapping asks the atoms: cluster pairs without any atom pair inside r_list lose
+//            their mask bit (24 % of them), the plain run is compacted in place
 //   remap    bonded index lists caller order -> slot order
 #include "mdx_internal.h"
 #include <algorithm>

@@ -7,22 +7,25 @@
 // sources (src/cuda/cuda.cu:10-37, 73-102); this kernel keeps "one atom per lane" and replaces the
 // O(N) inner loop by the tile pair list, with the neighbour atoms staged through LDS.
 //
-// Mapping (gfx950, wave64):
-//   * one wavefront = one i-tile: lane l owns slot tile*64+l, its force accumulates in registers
-//     and is written once with a coalesced 16-B store.  No atomics, no Newton-3 write-back: every
-//     pair is evaluated from both sides, which makes forces bitwise reproducible run to run.
-//   * the tile's list is consumed in chunks of 8 entries = 64 j-atoms: lane l fetches j-atom l of
-//     the chunk (8 x 128-B contiguous cluster records of posq + 8 x 64 B of lj: coalesced), adds
-//     the periodic image shift once, and parks it in the wave's private LDS strip; the next
-//     chunk's global loads are issued before the current chunk is computed (register prefetch).
-//   * the inner loop reads each j record as one broadcast ds_read_b128 + ds_read_b64 (all lanes
-//     the same address: conflict-free) and runs ~25 VALU ops per pair.
-//   * exclusions/self pairs: only the first n_masked entries of a tile can contain them; those
-//     chunks carry a 64-bit per-lane interaction mask, the (vast) rest runs mask-free.
-//   * workgroup = 4 waves = 4 consecutive tiles of a column (shared neighbourhood -> L1/L2 hits);
-//     blockIdx is remapped so that each XCD walks one contiguous eighth of the tile range and its
-//     private L2 sees a compact spatial region.
-// No MFMA: this is pairwise scalar work.  Roofline: fp32 VALU bound.
+// Three kernels share the tile pair list (mdx_grid.hip) and the LDS staging of the neighbour atoms:
+//   nb_cluster_kernel<.., HALF = true>   the default (nb_variant 5): half list, a lane is the pair (i-atom ii of
+//       every i-cluster, j-atom jj of the entry), 4 or 8 waves per tile; the force on the i-atoms accumulates in
+//       registers, the reaction on the 8 j-atoms of an entry leaves as ONE 24-lane f32 atomic (DPP reduction over
+//       the i-lanes).  Fastest; the last bits of a force depend on the order the atomics land in.
+//   nb_cluster_kernel<.., HALF = false>  nb_variant 2-4: same lane mapping over a full list - every pair is seen
+//       from both sides, one owner per force component, no atomics, bitwise reproducible.
+//   nb_tile_kernel                       nb_variant 1: lane = i-atom, j broadcast from LDS, branch-free; the A/B
+//       baseline the cluster kernels are measured against.
+// Common to all (gfx950, wave64):
+//   * the tile's list is consumed in chunks of 8 entries = 64 j-atoms: lane l fetches j-atom l of the chunk
+//     (8 x 128-B contiguous cluster records of posq + 8 x 64 B of lj: coalesced), adds the periodic image shift
+//     once, and parks it in the wave's private LDS strip (no workgroup barrier in the loop); entries of chunk c+2,
+//     atoms and exclusion masks of chunk c+1 are in flight while chunk c is evaluated.
+//   * ~30 VALU ops per in-range pair behind an exec-masked early-out (9 ops for a cluster pair with no lane inside
+//     the cutoff); exclusions/self pairs only in the first n_masked entries of a tile, which carry per-lane masks.
+//   * blockIdx is remapped so that each XCD walks one contiguous eighth of the tile range and its private L2 sees
+//     a compact spatial region.
+// No MFMA: this is pairwise scalar work.  Roofline: fp32 VALU bound (with the PMC numbers).
 #include "mdx_internal.h"
 #include <algorithm>
 #include <cfloat>
