@@ -330,7 +330,9 @@ int mdx_remap_constraints(mdx_handle* h) {
 int mdx_launch_constrain_positions(mdx_handle* h, float dt, const uint32_t* d_gate, uint32_t* d_disp_out, uint32_t thr) {
     if (!h->n_groups) return MDX_OK;
     hipLaunchKernelGGL(constrain_positions_kernel, dim3(div_up(h->n_groups, 128)), dim3(128), 0, h->stream, h->n_groups,
-                       h->d.cons_s, h->d.posq, h->d.vel, h->d.ref, dt, cons_params(h), h->d.cons_vir, d_gate, d_disp_out, thr);
+                       h->d.cons_s, h->d.posq, h->d.vel, h->d.ref, dt, cons_params(h),
+                       dt != 0.f ? h->d.cons_vir : nullptr,   // a dt = 0 projection (new coordinates, rescaled box) keeps the last step's virial
+                       d_gate, d_disp_out, thr);
     HIP_TRY(hipGetLastError());
     return MDX_OK;
 }
