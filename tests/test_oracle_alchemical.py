@@ -61,7 +61,8 @@ def test_a2_end_points(orc, sys_cfg):
         f_plain, e_plain = orc.forces(s, cfg, use_cells=True)
         orc.set_alchemical(lo, hi, 0.0)
         f0, e0 = orc.forces(s, cfg, use_cells=True)
-        assert np.array_equal(f0, f_plain) and e0["potential"] == e_plain["potential"] and e_plain["cross"] == 0.0
+        # (energies are OpenMP reductions under a dynamic schedule: equal up to summation order)
+        assert np.array_equal(f0, f_plain) and e0["potential"] == pytest.approx(e_plain["potential"], rel=1e-13) and e_plain["cross"] == 0.0
         orc.set_alchemical(lo, hi, 1.0)
         f1, e1 = orc.forces(s, cfg, use_cells=True)
         # decoupled: the total force the environment receives from the molecule vanishes, i.e. momentum is
