@@ -29,6 +29,7 @@
 #include "mdx_internal.h"
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 
 #define WAVE_LDS_SYNC()                                        \
     do {                                                       \
@@ -263,9 +264,11 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
     const uint32_t per_xcd = (nblocks + 7) >> 3;
     const uint32_t blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (blk >= nblocks) return;                               // whole workgroup
-    const uint32_t t = blk * TPB + (WPT == 1 ? wave : 0);
-    const int part = WPT == 1 ? 0 : wave;                     // which share of the tile's chunks
-    if (WPT == 1 && t >= a.T) return;
+    const int tib = wave / WPT;                               // tile within the workgroup
+    const int part = wave % WPT;                              // which share of the tile's chunks
+    const bool t_ok = blk * TPB + tib < a.T;                  // (the last workgroup may have a tile too many)
+    if (WPT == 1 && !t_ok) return;
+    const uint32_t t = t_ok ? blk * TPB + tib : a.T;          // a.T = the null tile: empty list, nothing stored
     const int ii = lane & 7, jj = lane >> 3;
 
     float xi[8], yi[8], zi[8], qi[8], sgi[8], epi[8], fx[8], fy[8], fz[8];
@@ -277,10 +280,11 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
         xi[ci] = pi.x; yi[ci] = pi.y; zi[ci] = pi.z; qi[ci] = pi.w; sgi[ci] = li.x; epi[ci] = li.y;
         fx[ci] = 0.f; fy[ci] = 0.f; fz[ci] = 0.f;
     }
-    const ListCounts cnt = a.counts[t];
-    const uint32_t e0 = a.entry_off[t];
+    ListCounts cnt = a.counts[t_ok ? t : 0];
+    if (!t_ok) { cnt.n_masked = 0; cnt.n_plain = 0; }
+    const uint32_t e0 = a.entry_off[t_ok ? t : 0];
     const uint32_t nmc = cnt.n_masked >> 3, nchunks = (cnt.n_masked + cnt.n_plain) >> 3;
-    const uint32_t mbase = a.mchunk_off[t];
+    const uint32_t mbase = a.mchunk_off[t_ok ? t : 0];
     float4* sx = s_xyzq[wave];
     float2* sl = s_lj[wave];
     double elj = 0.0, ecoul = 0.0, evir = 0.0, ecross = 0.0;
@@ -428,10 +432,11 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
     if (WPT > 1) {   // fixed-order sum of the waves' partial forces
         s_red[wave][0][lane] = ox; s_red[wave][1][lane] = oy; s_red[wave][2][lane] = oz;
         __syncthreads();
-        if (wave == 0) {
-            ox = s_red[0][0][lane]; oy = s_red[0][1][lane]; oz = s_red[0][2][lane];
+        if (part == 0 && t_ok) {
+            const int w0 = tib * WPT;
+            ox = s_red[w0][0][lane]; oy = s_red[w0][1][lane]; oz = s_red[w0][2][lane];
 #pragma unroll
-            for (int w = 1; w < WPT; ++w) { ox += s_red[w][0][lane]; oy += s_red[w][1][lane]; oz += s_red[w][2][lane]; }
+            for (int w = 1; w < WPT; ++w) { ox += s_red[w0 + w][0][lane]; oy += s_red[w0 + w][1][lane]; oz += s_red[w0 + w][2][lane]; }
             if (HALF) { unsafeAtomicAdd(fi, ox); unsafeAtomicAdd(fi + 1, oy); unsafeAtomicAdd(fi + 2, oz); }
             else a.force[t * MDX_TILE + lane] = make_float4(ox, oy, oz, 0.f);
         }
@@ -466,7 +471,12 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
     int wpt = 1;
     const bool half = var == 5;
     if (var == 2 || half) wpt = (a.T < 4096u) ? 8 : 4;     // measured: 4 beats 1 at every size, 8 below ~200 k atoms
-    else if (var == 4) wpt = 4;
+    if (half && a.T >= 12000u) wpt = 2;                    // half list at ~1 M atoms: 0.550 vs 0.572 ms (2 tiles per workgroup)
+    if (var == 4) wpt = 4;
+    if (half) {   // A/B knob
+        const char* e = std::getenv("MDX_WPT");
+        if (e && (e[0] == '1' || e[0] == '2' || e[0] == '4' || e[0] == '8')) wpt = e[0] - '0';
+    }
     const uint32_t bw = std::max(wpt, NB_WAVES);
     const uint32_t tpb = (var == 1) ? NB_WAVES : bw / wpt;
     const uint32_t nblocks = (a.T + tpb - 1) / tpb;
@@ -478,6 +488,8 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
         else if (h->alch_on) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, true, true>), g, b, 0, h->stream, a); \
         else if (var == 1) hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, G, S>), g, b, 0, h->stream, a);     \
         else if (half && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true>), g, b, 0, h->stream, a); \
+        else if (half && wpt == 2) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 2, true>), g, b, 0, h->stream, a); \
+        else if (half && wpt == 1) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 1, true>), g, b, 0, h->stream, a); \
         else if (half) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, true>), g, b, 0, h->stream, a); \
         else if (wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, false>), g, b, 0, h->stream, a); \
         else if (wpt == 4) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, false>), g, b, 0, h->stream, a); \
