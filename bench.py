@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--profile-level", type=int, default=2, choices=[0, 1, 2],
                     help="HIP-event timing inside the timed region: 2 = the pair kernel only (two extra queue packets per step), "
                          "1 = every step kernel, 0 = none; bonded/integrate times always come from a short profiled tail")
+    ap.add_argument("--chunk-steps", type=int, default=0, help="steps enqueued between host checks of the rebuild flag (0 = library default)")
     ap.add_argument("--skin", type=float, default=2.0, help="Verlet buffer in A (the measurement contract says 2)")
     ap.add_argument("--pme", action="store_true", help="Ewald Coulomb with the SPME reciprocal sum (not the headline config)")
     return ap.parse_args()
@@ -120,7 +121,7 @@ def main():
     from molchanica_amd.md_state import MdState
 
     system = systems.BY_NAME[args.workload]()
-    cfg = MdConfig(nb_variant=args.nb_variant, skin=args.skin)  # rc 10 Å (LJ & Coulomb), skin 2 Å, shifted cutoff Coulomb
+    cfg = MdConfig(nb_variant=args.nb_variant, skin=args.skin, chunk_steps=args.chunk_steps or 16)  # rc 10 Å (LJ & Coulomb), skin 2 Å, shifted cutoff Coulomb
     if args.pme:
         cfg = MdConfig(nb_variant=args.nb_variant, coulomb_mode=2, ewald_alpha=0.3, overrides=0)
     n_atoms = system.n_atoms

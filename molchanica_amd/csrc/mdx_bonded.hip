@@ -16,7 +16,7 @@
 // every neighbour rebuild, so a lane's records are contiguous and its partners sit in the same
 // or an adjacent tile (L1/L2 hits).  HBM-bound: ~36 + 32 r B per atom-step, r = roles per atom
 // (2.33 for water).
-#include "mdx_internal.h"
+#include "mdx_bonded_dev.h"
 
 struct BondedArgs {
     uint32_t S;
@@ -25,20 +25,6 @@ struct BondedArgs {
     BondedParams p;
     const uint32_t* gate; uint32_t thr_bits;
 };
-
-__device__ __forceinline__ float3 mimg(float3 d, const BondedParams& p) {
-    // minimum image d - rint(d/L) L (src/cuda/util.cu:65-71); box[] = 0 disables it in vacuum
-    if (p.box[0] > 0.f) d.x -= rintf(d.x * p.inv_box[0]) * p.box[0];
-    if (p.box[1] > 0.f) d.y -= rintf(d.y * p.inv_box[1]) * p.box[1];
-    if (p.box[2] > 0.f) d.z -= rintf(d.z * p.inv_box[2]) * p.box[2];
-    return d;
-}
-__device__ __forceinline__ float3 sub3(float4 a, float4 b) { return make_float3(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ float dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ float3 cross3(float3 a, float3 b) {
-    return make_float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
-}
-__device__ __forceinline__ float3 scale3(float3 a, float s) { return make_float3(a.x * s, a.y * s, a.z * s); }
 
 // Four lanes per atom: lane q of the quad takes roles q, q+4, ... of the atom's list and the quad sums its
 // forces with two DPP steps.  A chain atom has ~20 roles (each a chain of dependent partner loads) against a
@@ -55,7 +41,7 @@ __global__ __launch_bounds__(256) void bonded_gather_kernel(BondedArgs a) {
     if (a.gate && *a.gate > a.thr_bits) return;
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t s = tid / BONDED_LPA, q4 = tid % BONDED_LPA;
-    double e_bond = 0.0, e_angle = 0.0, e_dih = 0.0, e_lj14 = 0.0, e_c14 = 0.0, e_rec = 0.0, e_vir = 0.0;
+    RoleEnergies en;
     if (s < a.S) {
         const uint32_t rb = a.role_off[s], re = a.role_off[s + 1];
         if (re > rb) {     // quad-uniform
@@ -63,95 +49,7 @@ __global__ __launch_bounds__(256) void bonded_gather_kernel(BondedArgs a) {
             float fx = 0.f, fy = 0.f, fz = 0.f;
             for (uint32_t k = rb + q4; k < re; k += BONDED_LPA) {
                 const RoleRec r = a.roles[k];
-                const uint32_t kind = r.meta & 0xFu, role = (r.meta >> 4) & 0xFu;
-                if (kind == ROLE_EWALD_EXCL) {
-                    // the reciprocal sum includes this excluded / 1-4 pair: take erf(beta r)/r out again
-                    const float3 d = mimg(sub3(self, a.posq[r.p[0]]), a.p);
-                    const float r2 = dot3(d, d), rinv = rsqrtf(r2), rr = r2 * rinv, br = a.p.ewald_beta * rr;
-                    const float er = erff(br);
-                    const float fs = -r.prm[0] * (er * rinv - 1.1283791671f * a.p.ewald_beta * __expf(-br * br)) * rinv * rinv;
-                    fx += fs * d.x; fy += fs * d.y; fz += fs * d.z;
-                    if (ENERGY && role == 0) { e_rec -= (double)(r.prm[0] * er * rinv); e_vir += (double)(fs * r2); }
-                    continue;
-                }
-                if (a.p.skip_bonded) continue;
-                if (kind == ROLE_BOND || kind == ROLE_PAIR14) {
-                    const float3 d = mimg(sub3(self, a.posq[r.p[0]]), a.p);
-                    const float r2 = dot3(d, d);
-                    float fs;
-                    if (kind == ROLE_BOND) {
-                        const float rr = sqrtf(r2), dr = rr - r.prm[1];
-                        fs = -2.0f * r.prm[0] * dr / rr;
-                        if (ENERGY && role == 0) e_bond += (double)r.prm[0] * dr * dr;
-                    } else {   // prm: sigma_ij, 4*scale*eps_ij, scale*ke*qi*qj
-                        const float rinv = rsqrtf(r2), rinv2 = rinv * rinv;
-                        const float s2 = r.prm[0] * r.prm[0] * rinv2, s6 = s2 * s2 * s2;
-                        fs = (6.0f * r.prm[1] * s6 * (2.0f * s6 - 1.0f) + r.prm[2] * rinv) * rinv2;
-                        if (ENERGY && role == 0) {
-                            e_lj14 += (double)(r.prm[1] * s6 * (s6 - 1.0f));
-                            e_c14 += (double)(r.prm[2] * rinv);
-                        }
-                    }
-                    fx += fs * d.x; fy += fs * d.y; fz += fs * d.z;
-                    // virial: central pair forces only - angle and dihedral energies do not change
-                    // under a uniform scaling, their sum r_i . F_i is identically zero
-                    if (ENERGY && role == 0) e_vir += (double)(fs * r2);
-                } else if (kind == ROLE_ANGLE) {
-                    // ordered atoms i - j(apex) - k; this lane is atom `role`
-                    const float4 q0 = a.posq[r.p[0]], q1 = a.posq[r.p[1]];
-                    const float4 pi = role == 0 ? self : q0;
-                    const float4 pj = role == 1 ? self : (role == 0 ? q0 : q1);
-                    const float4 pk = role == 2 ? self : q1;
-                    const float3 v1 = mimg(sub3(pi, pj), a.p), v2 = mimg(sub3(pk, pj), a.p);
-                    const float ir1 = rsqrtf(dot3(v1, v1)), ir2 = rsqrtf(dot3(v2, v2));
-                    float cs = dot3(v1, v2) * ir1 * ir2;
-                    cs = fminf(1.0f, fmaxf(-1.0f, cs));
-                    const float th = acosf(cs), dth = th - r.prm[1];
-                    const float sn = fmaxf(sqrtf(1.0f - cs * cs), 1e-6f);
-                    const float de = 2.0f * r.prm[0] * dth;   // dE/dtheta
-                    // dtheta/dr_i = -(v2/|v2| - cos v1/|v1|) / (|v1| sin)
-                    const float ci = de * ir1 / sn, ck = de * ir2 / sn;
-                    const float3 u1 = scale3(v1, ir1), u2 = scale3(v2, ir2);
-                    const float3 fi = make_float3(ci * (u2.x - cs * u1.x), ci * (u2.y - cs * u1.y), ci * (u2.z - cs * u1.z));
-                    const float3 fk = make_float3(ck * (u1.x - cs * u2.x), ck * (u1.y - cs * u2.y), ck * (u1.z - cs * u2.z));
-                    if (role == 0) { fx += fi.x; fy += fi.y; fz += fi.z; }
-                    else if (role == 2) { fx += fk.x; fy += fk.y; fz += fk.z; }
-                    else { fx -= fi.x + fk.x; fy -= fi.y + fk.y; fz -= fi.z + fk.z; }
-                    if (ENERGY && role == 0) e_angle += (double)r.prm[0] * dth * dth;
-                } else {   // ROLE_DIHEDRAL: ordered atoms 0-1-2-3, this lane is atom `role`
-                    const float4 q0 = a.posq[r.p[0]], q1 = a.posq[r.p[1]], q2 = a.posq[r.p[2]];
-                    const float4 p0 = role == 0 ? self : q0;
-                    const float4 p1 = role == 1 ? self : (role == 0 ? q0 : q1);
-                    const float4 p2 = role == 2 ? self : (role < 2 ? q1 : q2);
-                    const float4 p3 = role == 3 ? self : q2;
-                    // Blondel-Karplus: F = r0-r1, G = r1-r2, H = r3-r2, A = F x G, B = H x G
-                    const float3 F = mimg(sub3(p0, p1), a.p), G = mimg(sub3(p1, p2), a.p), H = mimg(sub3(p3, p2), a.p);
-                    const float3 A = cross3(F, G), B = cross3(H, G);
-                    const float A2 = dot3(A, A), B2 = dot3(B, B), G2 = dot3(G, G);
-                    if (A2 > 1e-12f && B2 > 1e-12f && G2 > 1e-12f) {
-                        const float Gn = sqrtf(G2), iGn = 1.0f / Gn;
-                        const float cosphi = dot3(A, B);
-                        const float sinphi = dot3(cross3(B, A), G) * iGn;
-                        const float phi = atan2f(sinphi, cosphi);
-                        float sn, cn;
-                        sincosf(r.prm[2] * phi - r.prm[1], &sn, &cn);
-                        const float de = -r.prm[0] * r.prm[2] * sn;   // dE/dphi
-                        const float iA2 = 1.0f / A2, iB2 = 1.0f / B2;
-                        const float FG = dot3(F, G), HG = dot3(H, G);
-                        const float ca = -Gn * iA2, cb = Gn * iB2;
-                        const float ta = FG * iA2 * iGn, tb = HG * iB2 * iGn;
-                        // f_x = -dE/dphi * dphi/dr_x = -de * (wa * A + wb * B)
-                        float wa, wb;
-                        if (role == 0) { wa = ca; wb = 0.f; }
-                        else if (role == 3) { wa = 0.f; wb = cb; }
-                        else if (role == 1) { wa = -ca + ta; wb = -tb; }
-                        else { wa = -ta; wb = -cb + tb; }
-                        fx -= de * (wa * A.x + wb * B.x);
-                        fy -= de * (wa * A.y + wb * B.y);
-                        fz -= de * (wa * A.z + wb * B.z);
-                        if (ENERGY && role == 0) e_dih += (double)r.prm[0] * (1.0 + (double)cn);
-                    }
-                }
+                role_eval<ENERGY>(r, self, a.posq, a.p, fx, fy, fz, en);
             }
             fx = quad_xadd<0xB1>(fx); fy = quad_xadd<0xB1>(fy); fz = quad_xadd<0xB1>(fz);   // lane ^ 1
             fx = quad_xadd<0x4E>(fx); fy = quad_xadd<0x4E>(fy); fz = quad_xadd<0x4E>(fz);   // lane ^ 2
@@ -166,7 +64,7 @@ __global__ __launch_bounds__(256) void bonded_gather_kernel(BondedArgs a) {
         // wave shuffle, then the block's four waves through LDS: one atomic per term and block (one per wave
         // was 7 x 16 k contended atomics at 1 M atoms: 0.42 ms for a 0.04 ms kernel)
         __shared__ double s_e[4][7];
-        double v[7] = {e_bond, e_angle, e_dih, e_lj14, e_c14, e_rec, e_vir};
+        double v[7] = {en.bond, en.angle, en.dih, en.lj14, en.c14, en.rec, en.vir};
         const int slot[7] = {EN_BOND, EN_ANGLE, EN_DIHEDRAL, EN_LJ14, EN_COUL14, EN_RECIP, EN_VIRIAL};
 #pragma unroll
         for (int q = 0; q < 7; ++q) {
