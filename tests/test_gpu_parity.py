@@ -339,6 +339,20 @@ def test_every_pair_kernel_variant_against_the_oracle(mdx, orc, name, variant):
         assert np.abs(f.astype(np.float64).sum(0)).max() < 2e-3
 
 
+def test_half_list_four_waves_per_tile_size_class(mdx, orc):
+    """The default kernel picks 8 / 4 / 2 waves per tile by system size; the small and the 1 M-atom cases exercise
+    8 and 2 - this one (273 k atoms, ~4300 tiles) the 4-waves-per-tile class."""
+    s = systems.water_box(45, seed=6)
+    cfg = MdConfig()
+    with mdx.MdState(s, cfg) as md:
+        st = md.stats()
+        assert 4096 <= st["n_tiles"] < 12000
+        pos = md.positions(); f = md.forces(); e = md.energy()
+    fo, eo = orc.forces(s, cfg, pos=pos.astype(np.float64), use_cells=True)
+    assert_forces(f, fo, orc.cutoff_slack(s, cfg, pos=pos, rel=2e-5), "water273k")
+    assert_energies(e, eo, s.n_atoms * 200, "water273k")
+
+
 def test_energy_conservation_and_momentum_water(mdx):
     """Size-independent properties: sum F = 0 and NVE conservation with a continuous potential."""
     s = systems.water_box(12, seed=4, jitter=0.0)
