@@ -16,6 +16,7 @@
 // Self term, neutralising background and the erf(beta r)/r of excluded / 1-4 pairs (an extra role
 // kind in the bonded gather) complete the Ewald sum.  All mesh kernels are HBM/atomic-bound.
 #include "mdx_internal.h"
+#include <cstdlib>
 #include <hipfft/hipfft.h>
 #include <dlfcn.h>
 #include <algorithm>
@@ -98,21 +99,106 @@ __global__ __launch_bounds__(256) void pme_spread_kernel(uint32_t S, const float
     }
 }
 
+// Tile-local spread (default).  The 64 atoms of a tile sit in an ~8.6 A brick, i.e. they touch a block of about
+// 13^3 mesh points: one workgroup per tile accumulates the tile's 64 x 64 contributions in an LDS block with
+// ds_add_f32 and flushes each touched point ONCE with a global atomic - ~2200 memory-side atomics per tile instead
+// of 4096, in rows of consecutive floats.  (The memory side retires ~250 G f32 atomics/s: the 66 M adds of the
+// per-atom kernel above cannot take less than 0.26 ms at 1 M atoms, and took 0.68.)  Mesh indices are kept
+// unwrapped inside the block - an atom that has drifted across the box face since the last rebuild is still a
+// neighbour of the rest of its tile - and wrapped at the flush; an atom whose footprint does not fit the block
+// (a sparse tile) falls back to direct atomics.
+constexpr int PME_TB = 14;    // LDS block edge in mesh points
+__global__ __launch_bounds__(256) void pme_spread_tile_kernel(uint32_t T, const float4* __restrict__ posq,
+                                                              const uint8_t* __restrict__ slot_flags, PmeDev g,
+                                                              float* __restrict__ Q, const uint32_t* gate, uint32_t thr) {
+    if (gate && *gate > thr) return;
+    __shared__ float s_q[PME_TB * PME_TB * PME_TB];
+    __shared__ int s_org[3];
+    const uint32_t t = blockIdx.x;
+    if (t >= T) return;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < PME_TB * PME_TB * PME_TB; k += 256) s_q[k] = 0.f;
+    // atom a = tid >> 2 of the tile; its quarter q4 = tid & 3 of the 16 (y, z) offset pairs
+    const int atom = tid >> 2, q4 = tid & 3;
+    const uint32_t slot = t * MDX_TILE + atom;
+    const float4 p = posq[slot];
+    const bool live = (slot_flags[slot] & 1u) && p.w != 0.f;
+    int k0[3] = {0, 0, 0}; float w[3] = {0.f, 0.f, 0.f};
+    {   // unwrapped mesh coordinates: floor may be < 0 or >= K for an atom just outside the box
+        const float x[3] = {p.x, p.y, p.z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float u = (x[a] - g.lo[a]) * g.inv_len[a] * (float)g.K[a];
+            const float fl = floorf(u);
+            w[a] = u - fl; k0[a] = (int)fl - 3;
+        }
+    }
+    // block origin: minimum k0 over the live atoms of the tile (wave minimum, then the four waves through LDS)
+    __shared__ int s_min[4][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        int m = live ? k0[a] : 0x3fffffff;
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) m = min(m, __shfl_xor(m, sft));
+        if ((tid & 63) == 0) s_min[tid >> 6][a] = m;
+    }
+    __syncthreads();
+    if (tid < 3) s_org[tid] = min(min(s_min[0][tid], s_min[1][tid]), min(s_min[2][tid], s_min[3][tid]));
+    __syncthreads();
+    const int ox = s_org[0], oy = s_org[1], oz = s_org[2];
+    if (live) {
+        float mx[4], my[4], mz[4], dd[4];
+        bspline4(w[0], mx, dd); bspline4(w[1], my, dd); bspline4(w[2], mz, dd);
+        const int lx = k0[0] - ox, ly = k0[1] - oy, lz = k0[2] - oz;
+        const bool fits = lx + 4 <= PME_TB && ly + 4 <= PME_TB && lz + 4 <= PME_TB;
+        // this lane: y offset b = q4, all four z offsets, all four x offsets
+        const int b = q4;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float v = p.w * mx[a] * my[b] * mz[c];
+                if (fits) {
+                    atomicAdd(&s_q[((lx + a) * PME_TB + (ly + b)) * PME_TB + (lz + c)], v);
+                } else {
+                    int kx = (k0[0] + a) % g.K[0]; if (kx < 0) kx += g.K[0];
+                    int ky = (k0[1] + b) % g.K[1]; if (ky < 0) ky += g.K[1];
+                    int kz = (k0[2] + c) % g.K[2]; if (kz < 0) kz += g.K[2];
+                    atomicAdd(Q + ((size_t)kx * g.K[1] + ky) * g.K[2] + kz, v);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (ox == 0x3fffffff) return;      // no live atom in the tile
+    for (int k = tid; k < PME_TB * PME_TB * PME_TB; k += 256) {
+        const float v = s_q[k];
+        if (v != 0.f) {
+            const int lz = k % PME_TB, ly = (k / PME_TB) % PME_TB, lx = k / (PME_TB * PME_TB);
+            int kx = (ox + lx) % g.K[0]; if (kx < 0) kx += g.K[0];
+            int ky = (oy + ly) % g.K[1]; if (ky < 0) ky += g.K[1];
+            int kz = (oz + lz) % g.K[2]; if (kz < 0) kz += g.K[2];
+            atomicAdd(Q + ((size_t)kx * g.K[1] + ky) * g.K[2] + kz, v);
+        }
+    }
+}
+
 template <bool ENERGY>
 __global__ __launch_bounds__(256) void pme_solve_kernel(size_t n, int K1, int K2, int K3h, int K3, float3 inv_len,
                                                         float pi2_over_beta2, float2* __restrict__ F,
                                                         const float* __restrict__ theta, double* energy,
                                                         const uint32_t* gate, uint32_t thr) {
     if (gate && *gate > thr) return;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     double e = 0.0, w = 0.0;
-    if (i < n) {
+    // grid-stride: the energy flavour runs on at most 1024 blocks so that its two f64 atomics per block stay cheap
+    // (one pair per wave over 27 k blocks was 2.6 ms of serialised atomics around 20 us of work)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float t = theta[i];
         float2 f = F[i];
         if (ENERGY) {
             const int k3 = (int)(i % (size_t)K3h);
             const float mult = (k3 == 0 || (2 * k3 == K3)) ? 1.0f : 2.0f;
-            e = 0.5 * (double)(mult * t * (f.x * f.x + f.y * f.y));
+            const double ei = 0.5 * (double)(mult * t * (f.x * f.x + f.y * f.y));
             // scalar virial of the reciprocal sum: sum_m E_m (1 - 2 pi^2 m^2 / beta^2)  (= -dE/dlambda
             // under r -> lambda r, L -> lambda L; the B-spline moduli and S(m) do not change)
             const size_t ij = i / (size_t)K3h;
@@ -120,15 +206,22 @@ __global__ __launch_bounds__(256) void pme_solve_kernel(size_t n, int K1, int K2
             const float m1 = (float)(k1 <= K1 / 2 ? k1 : k1 - K1) * inv_len.x;
             const float m2 = (float)(k2 <= K2 / 2 ? k2 : k2 - K2) * inv_len.y;
             const float m3 = (float)k3 * inv_len.z;
-            w = e * (1.0 - 2.0 * (double)(pi2_over_beta2 * (m1 * m1 + m2 * m2 + m3 * m3)));
+            e += ei;
+            w += ei * (1.0 - 2.0 * (double)(pi2_over_beta2 * (m1 * m1 + m2 * m2 + m3 * m3)));
         }
         f.x *= t; f.y *= t;
         F[i] = f;
     }
     if (ENERGY) {
+        __shared__ double s_e[4], s_w[4];
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) { e += __shfl_xor(e, m); w += __shfl_xor(w, m); }
-        if ((threadIdx.x & 63) == 0 && e != 0.0) { atomicAdd(&energy[EN_RECIP], e); atomicAdd(&energy[EN_VIRIAL], w); }
+        if ((threadIdx.x & 63) == 0) { s_e[threadIdx.x >> 6] = e; s_w[threadIdx.x >> 6] = w; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            e = s_e[0] + s_e[1] + s_e[2] + s_e[3]; w = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+            if (e != 0.0) { atomicAdd(&energy[EN_RECIP], e); atomicAdd(&energy[EN_VIRIAL], w); }
+        }
     }
 }
 
@@ -285,10 +378,15 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
     hipStream_t st = h->stream;
     const int K3h = h->pme_K[2] / 2 + 1;
     HIP_TRY(hipMemsetAsync(h->d.pme_q, 0, sizeof(float) * p->n_real, st));
-    hipLaunchKernelGGL(pme_spread_kernel, dim3(div_up(h->S * 16u, 256)), dim3(256), 0, st, h->S, h->d.posq,
-                       h->d.slot_flags, p->dev, h->d.pme_q, d_gate, thr);
+    static const bool per_atom_spread = [] { const char* e = std::getenv("MDX_PME_SPREAD_PER_ATOM"); return e && e[0] == '1'; }();
+    if (per_atom_spread || !h->in_slot_space)
+        hipLaunchKernelGGL(pme_spread_kernel, dim3(div_up(h->S * 16u, 256)), dim3(256), 0, st, h->S, h->d.posq,
+                           h->d.slot_flags, p->dev, h->d.pme_q, d_gate, thr);
+    else
+        hipLaunchKernelGGL(pme_spread_tile_kernel, dim3(h->T), dim3(256), 0, st, h->T, h->d.posq, h->d.slot_flags, p->dev,
+                           h->d.pme_q, d_gate, thr);
     if (p->exec_r2c(p->fwd, h->d.pme_q, (hipfftComplex*)h->d.pme_f) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecR2C failed");
-    const dim3 gs((unsigned)((p->n_cplx + 255) / 256));
+    const dim3 gs((unsigned)std::min<size_t>((p->n_cplx + 255) / 256, energy ? 1024 : (size_t)1 << 30));
     const float3 inv_len = make_float3(p->dev.inv_len[0], p->dev.inv_len[1], p->dev.inv_len[2]);
     const float pb = (float)(M_PI * M_PI / ((double)h->cfg.ewald_alpha * h->cfg.ewald_alpha));
     if (energy) hipLaunchKernelGGL(pme_solve_kernel<true>, gs, dim3(256), 0, st, p->n_cplx, h->pme_K[0], h->pme_K[1], K3h,
