@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--workload", default="water1M", choices=["water1M", "dhfr23k", "complex50k", "dna100k"])
     ap.add_argument("--dt", type=float, default=0.0005)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=10, help="oracle steps of the cpu_baseline leg (about 1.2 s each on the GPU box's 128 cores)")
     ap.add_argument("--nb-variant", type=int, default=0)
     ap.add_argument("--decomposed", action="store_true", help="drive the decomposed path even on one GPU")
     ap.add_argument("--no-equilibrate", dest="equilibrate", action="store_false",
