@@ -66,13 +66,23 @@ enum { CM_SHIFTED = 0, CM_RF = 1, CM_EWALD = 2, CM_SOFT = 3 };
 // sqrt(24 eps); the sign of the product eps_i * eps_j is then the "exactly one of the two is coupled" flag, and
 // such a pair's force and energy are scaled by p.alch_scale = 1 - lambda (3 VALU ops; a separate instantiation,
 // the default kernels do not pay for it).  *ecross collects the UNSCALED energy of those pairs: dU/dlambda = -it.
-template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, bool BRANCHY, bool HALF = false, bool ALCH = false>
+//
+// NANMASK = true (the cluster kernels): the exclusion bit arrives as `r2bias` = 0.0f (allowed) or NaN (excluded) and
+// is the addend of the first FMA of r^2, so an excluded pair fails every cutoff comparison by itself: one VALU op
+// (v_bfe_i32 of the mask byte) instead of v_and + v_cmp + s_and, and one step less in the dependent chain in front
+// of the exec-mask branch.  Adding 0.0f is exact: r^2 has the bits of the plain expression.  Requires BRANCHY (the
+// NaN must never reach an accumulator).
+template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, bool BRANCHY, bool HALF = false, bool ALCH = false, bool NANMASK = false>
 __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi, float sgi, float epi,
                                           const float4 pj, const float2 lj, bool allowed, const NbParams& p,
                                           float& fx, float& fy, float& fz, float& elj, float& ecoul,
-                                          float* g = nullptr, float* evir = nullptr, float* ecross = nullptr) {
+                                          float* g = nullptr, float* evir = nullptr, float* ecross = nullptr,
+                                          float r2bias = 0.f) {
+    static_assert(!NANMASK || BRANCHY, "the NaN-coded exclusion needs the early-out");
     const float dx = xi - pj.x, dy = yi - pj.y, dz = zi - pj.z;   // tgt - src (src/cuda/util.cu:118-140)
-    const float r2 = dx * dx + dy * dy + dz * dz;
+    const float r2 = NANMASK ? __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, r2bias)))
+                             : dx * dx + dy * dy + dz * dz;
+    if (NANMASK) allowed = true;
     const bool in_lj = (r2 < p.rc2_lj) && allowed;
     const bool in_c = SAMECUT ? in_lj : ((r2 < p.rc2_coul) && allowed);
     if (BRANCHY && !(in_lj || in_c)) return;
@@ -362,7 +372,8 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
             const uint32_t im = (__builtin_amdgcn_readlane(cur_y, e * 8) >> 8) & 0xFFu;  // wave-uniform
             if (im == 0) continue;
             // exclusion bits only exist in masked chunks; elsewhere the (uniform) imask bit suffices
-            const uint32_t m8 = masked ? ((uint32_t)reinterpret_cast<const uint8_t*>(&s_mask[wave][lane])[e] & im) : im;
+            // (as EXCLUDED bits: bit ci set <=> this lane's pair with i-cluster ci is masked out)
+            const int x8 = masked ? (int)(~(uint32_t)reinterpret_cast<const uint8_t*>(&s_mask[wave][lane])[e]) : 0;
             float g[3] = {0.f, 0.f, 0.f};
             float wj = 0.f;
             if (ENERGY && HALF) wj = 0.5f * s_ownj[wave][e * 8 + jj];
@@ -370,10 +381,12 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
             for (int ci = 0; ci < 8; ++ci) {
                 if (im & (1u << ci)) {
                     float e1 = 0.f, e2 = 0.f, e3 = 0.f, e4 = 0.f;
-                    pair_eval<ENERGY, COUL, GEOM, SAMECUT, true, HALF, ALCH>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci],
-                                                                             pj, lj, (m8 >> ci) & 1u, a.p, fx[ci], fy[ci],
+                    // 0.0f or NaN: sign-extend bit ci of the exclusion byte over the word (one v_bfe_i32)
+                    const float bias = __int_as_float((x8 << (31 - ci)) >> 31);
+                    pair_eval<ENERGY, COUL, GEOM, SAMECUT, true, HALF, ALCH, true>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci],
+                                                                             pj, lj, true, a.p, fx[ci], fy[ci],
                                                                              fz[ci], e1, e2, g, ENERGY ? &e3 : nullptr,
-                                                                             (ENERGY && ALCH) ? &e4 : nullptr);
+                                                                             (ENERGY && ALCH) ? &e4 : nullptr, bias);
                     if (ENERGY && HALF) {   // a pair's energy is split between the owners of its two atoms
                         const float w = wj + (((own_bits >> ci) & 1u) ? 0.5f : 0.f);
                         celj += w * e1; cecoul += w * e2; cevir += w * e3; cecross += w * e4;

@@ -21,7 +21,7 @@ from ._abi import (CConfig, CEnergies, CStats, CSystem, FORCE, MDX_EDEVICE, MDX_
                    MDX_EPARAM, MDX_OK, POS, VEL, MdConfig, MdSystem)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmdx.so")
+LIB_PATH = os.environ.get("MDX_LIB") or os.path.join(_HERE, "libmdx.so")   # MDX_LIB: A/B builds of the same ABI
 
 
 class ParamError(ValueError):
