@@ -58,6 +58,8 @@ def parse():
                          "1 = every step kernel, 0 = none; bonded/integrate times always come from a short profiled tail")
     ap.add_argument("--chunk-steps", type=int, default=0, help="steps enqueued between host checks of the rebuild flag (0 = library default)")
     ap.add_argument("--skin", type=float, default=2.0, help="Verlet buffer in A (the measurement contract says 2)")
+    ap.add_argument("--inner-skin", type=float, default=0.0,
+                    help="dual pair list: buffer of the rolling-pruned inner list in A (0 = library default 0.5, < 0 = off)")
     ap.add_argument("--pme", action="store_true", help="Ewald Coulomb with the SPME reciprocal sum (not the headline config)")
     return ap.parse_args()
 
@@ -121,9 +123,9 @@ def main():
     from molchanica_amd.md_state import MdState
 
     system = systems.BY_NAME[args.workload]()
-    cfg = MdConfig(nb_variant=args.nb_variant, skin=args.skin, chunk_steps=args.chunk_steps or 16)  # rc 10 Å (LJ & Coulomb), skin 2 Å, shifted cutoff Coulomb
+    cfg = MdConfig(nb_variant=args.nb_variant, skin=args.skin, chunk_steps=args.chunk_steps or 16, inner_skin=args.inner_skin)  # rc 10 Å (LJ & Coulomb), skin 2 Å, shifted cutoff Coulomb
     if args.pme:
-        cfg = MdConfig(nb_variant=args.nb_variant, coulomb_mode=2, ewald_alpha=0.3, overrides=0)
+        cfg = MdConfig(nb_variant=args.nb_variant, coulomb_mode=2, ewald_alpha=0.3, overrides=0, inner_skin=args.inner_skin)
     n_atoms = system.n_atoms
 
     # Untimed preparation of the synthetic box (SURVEY 8d asks for Maxwell-Boltzmann at 300 K): the
@@ -213,7 +215,10 @@ def main():
     nb_ms = st["nb_ms_sum"] / max(st["nb_launches"], 1)
     atoms_per_launch = st["n_atoms"]
     achieved = B_ALG_NONBONDED * atoms_per_launch / (nb_ms * 1e-3) / 1e9 if nb_ms > 0 else 0.0
-    pair_evals = float(st["n_cluster_pairs"]) * 64   # (i-cluster, j-cluster) pairs x 8 x 8 lanes
+    # (i-cluster, j-cluster) pairs x 8 x 8 lanes; with the dual list the step loop walks the inner list (mean over the
+    # pruning passes), and one launch in ~`steps / prune_passes` walks the Verlet list while it re-prunes
+    dual = st.get("prune_passes", 0) > 0
+    pair_evals = float(st["n_inner_cluster_pairs"] if dual else st["n_cluster_pairs"]) * 64
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "nb_traffic.json")
     if os.path.exists(tfile):
@@ -233,6 +238,8 @@ def main():
                    "coulomb_cutoff": cfg.coulomb_cutoff, "skin": cfg.skin, "dt_ps": args.dt,
                    "coulomb": "ewald real space + SPME (order 4, ~1 A mesh)" if args.pme else "shifted cutoff", "parallelism": parallelism,
                    "rebuilds_in_timed_region": int(st["rebuild_count"] - rebuilds0),
+                   "dual_list": ({"inner_skin": cfg.inner_skin or 0.5, "verlet_pair_evals": float(st["n_cluster_pairs"]) * 64,
+                                  "prune_passes_total": int(st["prune_passes"])} if dual else None),
                    "energy_evaluations_in_timed_region": n_energy, "untimed_preparation": prep,
                    "repartitions": getattr(md, "repartitions", None), "local_rebuilds": getattr(md, "local_rebuilds_total", None)},
         "roofline": {"kernel": "nb_tile_kernel" if args.nb_variant == 1 else "nb_cluster_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,

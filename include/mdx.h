@@ -137,7 +137,10 @@ typedef struct mdx_config {
     uint32_t pme_grid[3];      /* SPME mesh (MDX_COULOMB_EWALD without MDX_OVR_LONG_RANGE_RECIP_DISABLED);
                                   0 = smallest 2^a 3^b 5^c size with spacing <= 1 Å */
     uint32_t pme_order;        /* B-spline order: 4 (default) */
-    uint32_t reserved[1];
+    float    inner_skin;       /* Å; dual pair list: the pair kernel walks an INNER list = the cluster pairs of the Verlet list with an
+                                  atom pair inside cutoff + inner_skin, re-pruned on the device (inside the pair kernel, no host
+                                  round trip) whenever an atom's path length since the last pruning exceeds inner_skin/2.
+                                  0 = library default (0.5); < 0 or >= skin: off.  Results are those of the plain list. */
 } mdx_config;
 
 /* Superset of SnapshotEnergyData  [ref: src/ui/panels/md_viewer.rs:195-257; src/md/mod.rs:1241-1245] */
@@ -177,6 +180,8 @@ typedef struct mdx_stats {
     double   integ_ms_sum;  uint64_t integ_launches;
     double   rebuild_ms_sum;
     double   wall_ms_sum;       /* host wall time inside mdx_step */
+    uint64_t n_inner_cluster_pairs; /* dual list: cluster pairs the last pruning pass kept (0 when off) */
+    uint64_t prune_passes;      /* dual list: pruning passes executed so far */
 } mdx_stats;
 
 typedef struct mdx_handle mdx_handle;

@@ -56,7 +56,7 @@ class CConfig(C.Structure):
         ("coulomb_mode", C.c_int32), ("ewald_alpha", C.c_float), ("combining_rule", C.c_int32),
         ("overrides", C.c_uint32), ("softening_sq", C.c_float), ("chunk_steps", C.c_uint32),
         ("nb_variant", C.c_uint32), ("constraint_tol", C.c_float), ("constraint_max_iter", C.c_uint32),
-        ("pme_grid", C.c_uint32 * 3), ("pme_order", C.c_uint32), ("reserved", C.c_uint32 * 1),
+        ("pme_grid", C.c_uint32 * 3), ("pme_order", C.c_uint32), ("inner_skin", C.c_float),
     ]
 
 
@@ -81,6 +81,7 @@ class CStats(C.Structure):
         ("bonded_ms_sum", C.c_double), ("bonded_launches", C.c_uint64),
         ("integ_ms_sum", C.c_double), ("integ_launches", C.c_uint64),
         ("rebuild_ms_sum", C.c_double), ("wall_ms_sum", C.c_double),
+        ("n_inner_cluster_pairs", C.c_uint64), ("prune_passes", C.c_uint64),
     ]
 
     def as_dict(self) -> dict:
@@ -108,6 +109,7 @@ class MdConfig:
     constraint_max_iter: int = 64
     pme_grid: tuple = (0, 0, 0)
     pme_order: int = 4
+    inner_skin: float = 0.0     # dual pair list buffer; 0 = library default (0.5 A), < 0 = off
 
     def to_c(self) -> CConfig:
         c = CConfig()
@@ -118,6 +120,7 @@ class MdConfig:
             setattr(c, k, getattr(self, k))
         c.pme_grid = (C.c_uint32 * 3)(*[int(v) for v in self.pme_grid])
         c.pme_order = int(self.pme_order)
+        c.inner_skin = float(self.inner_skin)
         return c
 
 

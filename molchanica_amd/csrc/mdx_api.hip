@@ -142,7 +142,7 @@ static void free_device(mdx_handle* h) {
                     d.tile_col, d.scan_tmp, d.cl_lo, d.cl_hi, d.list_counts, d.entry_cnt, d.entry_off,
                     d.mchunk_cnt, d.mchunk_off, d.entries, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
                     d.role_off_s, d.role_rec_s, d.ctl, d.energy,
-                    d.flags_dev, d.bbox_red, d.pair_count, d.cons_o, d.cons_s, d.cons_vir, d.vsite_o, d.vsite_s, d.pme_q, d.pme_f,
+                    d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.cons_o, d.cons_s, d.cons_vir, d.vsite_o, d.vsite_s, d.pme_q, d.pme_f,
                     d.pme_theta};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = DeviceState{};
@@ -441,6 +441,9 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
     }
     if (n_steps == 0) return MDX_OK;
     MDX_TRY(ensure_ready(h));
+    // dual list: whatever moved the atoms since the last call (upload, minimiser, barostat, another driver) did not
+    // feed the path accumulators - the first force call of every mdx_step re-prunes the inner list
+    h->prune_pending = true;
     const uint32_t thr = stale_threshold_bits(h);
     uint32_t remaining = n_steps;
     while (remaining) {
@@ -459,13 +462,16 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
             h->prof_tag = (int)s;
             h->lang_step = h->step_count + s;
             const int mode = !vv ? (integ == MDX_INTEGRATOR_LANGEVIN_MIDDLE ? 3 : 1) : ((s == 0 || !fused) ? 0 : 1);
-            MDX_TRY(mdx_launch_integrate(h, mode, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr));
+            MDX_TRY(mdx_launch_integrate(h, mode, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
             MDX_TRY(mdx_launch_constrain_positions(h, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr));
             // Langevin middle: friction and noise sit between the two half drifts, so SHAKE's dx/dt is not an
             // exact velocity projection; RATTLE the half-step velocities (same gate as SHAKE: it belongs to the
             // drift, which has happened even when the step's forces turn out to be gated off)
             if (integ == MDX_INTEGRATOR_LANGEVIN_MIDDLE) MDX_TRY(mdx_launch_constrain_velocities(h, &d.ctl->disp2[s], thr));
-            MDX_TRY(compute_forces(h, false, &d.ctl->disp2[s + 1], thr));
+            h->nb_step = (int)s;      // the pair kernel of this call may walk the inner masks / prune (prune[s + 1])
+            const int frc = compute_forces(h, false, &d.ctl->disp2[s + 1], thr);
+            h->nb_step = -1;
+            MDX_TRY(frc);
             if (vv && !fused) {
                 MDX_TRY(mdx_launch_integrate(h, 2, dt, &d.ctl->disp2[s + 1], nullptr, thr));
                 MDX_TRY(mdx_launch_constrain_velocities(h, &d.ctl->disp2[s + 1], thr));
@@ -683,6 +689,17 @@ extern "C" int mdx_get_stats(mdx_handle* h, mdx_stats* out) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     mdx_prof_collect(h);
     h->stats.step_count = h->step_count; h->stats.rebuild_count = h->rebuild_count;
+    h->stats.n_inner_cluster_pairs = 0; h->stats.prune_passes = 0;
+    if (h->d.inner_count) {   // dual list: cumulative kept cluster pairs (spread over MDX_EPART words) and passes
+        unsigned long long c[MDX_EPART + 1];
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipMemcpyAsync(c, h->d.inner_count, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        unsigned long long tot = 0;
+        for (int k = 0; k < MDX_EPART; ++k) tot += c[k];
+        h->stats.prune_passes = c[MDX_EPART];
+        h->stats.n_inner_cluster_pairs = c[MDX_EPART] ? tot / c[MDX_EPART] : 0;   // mean per pass
+    }
     *out = h->stats;
     return MDX_OK;
 }

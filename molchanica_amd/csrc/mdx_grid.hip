@@ -271,7 +271,7 @@ __global__ void gather_slots_kernel(uint32_t S, const uint32_t* __restrict__ ori
         v = make_float4(0.f, 0.f, 0.f, 0.f);
         l = make_float2(0.f, 0.f);
     }
-    posq[s] = p; vel[s] = v; lj[s] = l; ref[s] = p;
+    posq[s] = p; vel[s] = v; lj[s] = l; ref[s] = make_float4(p.x, p.y, p.z, 0.f);   // .w: path length (dual list)
     force[s] = make_float4(0.f, 0.f, 0.f, 0.f);
     slot_flags[s] = fl;
 }
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, f
             const uint32_t y = __builtin_amdgcn_readlane(ent.y, e * 8);
             const uint32_t im = (y >> 8) & any;
             kept += __popc(im & 0xFFu);
-            if ((lane >> 3) == e) newy = (y & 0xFFu) | ((im & 0xFFu) << 8);
+            if ((lane >> 3) == e) newy = (y & 0xFFu) | ((im & 0xFFu) << 8) | ((im & 0xFFu) << 16);   // inner mask := outer mask
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
         if (c < nmc) {
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, f
             if ((lane & 7) == 0 && newy != ent.y) entries[e0 + c * 8 + (lane >> 3)].y = newy;
         } else {
             // plain run: survivors move down (write cursor <= read position, and the next chunk is already in registers)
-            const bool alive = (lane & 7) == 0 && (newy >> 8) != 0u;
+            const bool alive = (lane & 7) == 0 && ((newy >> 8) & 0xFFu) != 0u;
             const unsigned long long bal = __ballot(alive);
             if (alive) {
                 const uint32_t rank = __popcll(bal & ((1ull << lane) - 1ull));
@@ -895,6 +895,8 @@ int mdx_gather_to_orig(mdx_handle* h, const float4* slot_arr, float4* orig_arr) 
     return MDX_OK;
 }
 
+static float c_inner_skin(const mdx_config& c) { return c.inner_skin == 0.f ? 0.5f : c.inner_skin; }
+
 int mdx_rebuild(mdx_handle* h) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profile) {
@@ -1019,6 +1021,13 @@ int mdx_rebuild(mdx_handle* h) {
     h->list_valid = true;
     h->forces_valid = false;
     h->rebuild_count++;
+    // dual pair list: the step loop of a plain (flexible, single-domain) half-list run walks rolling-pruned inner
+    // masks; positions that move by anything but the drift pass (SHAKE, virtual sites) keep the plain list
+    h->inner_skin = c_inner_skin(h->cfg);
+    h->dual_on = mdx_nb_half(h) && prune && h->inner_skin > 0.f && h->inner_skin < h->cfg.skin && h->n_groups == 0 &&
+                 h->n_vsites == 0 && h->n_local == h->N && !h->have_local_bounds;
+    h->prune_pending = true;
+    if (!d.inner_count) { ALLOC(d.inner_count, MDX_EPART + 1); HIP_TRY(hipMemsetAsync(d.inner_count, 0, sizeof(unsigned long long) * (MDX_EPART + 1), st)); }
     uint64_t nmask = (uint64_t)MC * 8;
     h->stats.n_atoms = N; h->stats.n_slots = S; h->stats.n_tiles = T; h->stats.n_clusters = NC;
     h->stats.n_list_entries = E; h->stats.n_masked_entries = nmask;

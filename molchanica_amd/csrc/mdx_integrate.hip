@@ -36,18 +36,24 @@ __device__ __forceinline__ void langevin_normals(uint64_t seed, uint64_t step, u
 
 // ZERO: clear the force array once it has been consumed - the half-list pair kernel that follows accumulates
 // with atomics and needs it zero; doing it here saves a separate fill launch per step.
-template <int MODE, bool ZERO>  // 0: half kick + drift, 1: full kick + drift, 2: closing half kick, 3: Langevin middle
+//
+// DUAL (dual pair list): ref[].w accumulates the atom's PATH LENGTH since the last pruning pass of the inner list
+// (sum of the step displacements: an upper bound of its displacement, so one scalar per atom suffices and rides
+// in the float4 this pass reads anyway; +16 B of writes per slot).  A wave whose maximum exceeds inner_skin/2
+// raises the step's prune word; the pair kernel of this step then re-prunes on the spot (mdx_nonbonded.hip).
+template <int MODE, bool ZERO, bool DUAL>  // 0: half kick + drift, 1: full kick + drift, 2: closing half kick, 3: Langevin middle
 __global__ __launch_bounds__(256) void integrate_kernel(uint32_t S, float dt, float4* __restrict__ posq,
                                                         float4* __restrict__ vel, float4* __restrict__ force,
-                                                        const float4* __restrict__ ref, const uint32_t* gate_in,
-                                                        uint32_t* disp_out, uint32_t thr_bits, LangevinArgs lg) {
+                                                        float4* __restrict__ ref, const uint32_t* gate_in,
+                                                        uint32_t* disp_out, uint32_t thr_bits, LangevinArgs lg,
+                                                        uint32_t* prune_out, float path_thr) {
     const uint32_t gate = gate_in ? *gate_in : 0u;
     if (gate > thr_bits) {  // list already stale: stay a no-op, keep the flag raised
         if (MODE != 2 && blockIdx.x == 0 && threadIdx.x == 0) atomicMax(disp_out, gate);
         return;
     }
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    float d2 = 0.f;
+    float d2 = 0.f, path = 0.f;
     if (s < S) {
         float4 v = vel[s];
         if (v.w != 0.f) {   // w = 418.4/m; 0 marks static, ghost and dummy slots
@@ -56,6 +62,7 @@ __global__ __launch_bounds__(256) void integrate_kernel(uint32_t S, float dt, fl
             v.x += kdt * f.x; v.y += kdt * f.y; v.z += kdt * f.z;
             if (MODE != 2) {
                 float4 p = posq[s];
+                const float ox = p.x, oy = p.y, oz = p.z;
                 if (MODE == 3) {
                     const float hdt = 0.5f * dt;
                     p.x += hdt * v.x; p.y += hdt * v.y; p.z += hdt * v.z;
@@ -68,10 +75,16 @@ __global__ __launch_bounds__(256) void integrate_kernel(uint32_t S, float dt, fl
                     p.x += dt * v.x; p.y += dt * v.y; p.z += dt * v.z;
                 }
                 posq[s] = p;
-                const float4 r = ref[s];
+                float4 r = ref[s];
                 const float dx = p.x - r.x, dy = p.y - r.y, dz = p.z - r.z;
                 d2 = dx * dx + dy * dy + dz * dz;
                 if (!(d2 < 1.0e30f)) d2 = 3.0e38f;  // NaN/inf -> huge, forces a stop
+                if (DUAL) {
+                    const float mx = p.x - ox, my = p.y - oy, mz = p.z - oz;
+                    path = r.w + __builtin_sqrtf(mx * mx + my * my + mz * mz);
+                    r.w = path;
+                    ref[s] = r;
+                }
             }
             vel[s] = v;
         }
@@ -84,6 +97,11 @@ __global__ __launch_bounds__(256) void integrate_kernel(uint32_t S, float dt, fl
         // (not stale) case the pass issues no atomics at all.  One contended atomicMax per wave
         // cost 9x the streaming time of this kernel (~12 ns each, serialised in L2).
         if ((threadIdx.x & 63) == 0 && __float_as_uint(d2) > thr_bits) atomicMax(disp_out, __float_as_uint(d2));
+        if (DUAL) {
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) path = fmaxf(path, __shfl_xor(path, m));
+            if ((threadIdx.x & 63) == 0 && !(path <= path_thr)) *prune_out = 1u;   // idempotent plain store, rare
+        }
     }
 }
 
@@ -123,7 +141,7 @@ __global__ __launch_bounds__(256) void kinetic_kernel(uint32_t S, const float4* 
 }
 
 int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_gate_in, uint32_t* d_disp_out,
-                         uint32_t thr_bits) {
+                         uint32_t thr_bits, uint32_t* d_prune_out) {
     const dim3 g((h->S + 255) / 256), b(256);
     DeviceState& d = h->d;
     mdx_prof_begin(h, 2);
@@ -136,12 +154,17 @@ int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_ga
     }
     // the force array is consumed here and rebuilt by the force pass that follows modes 0/1/3
     const bool zero = mode != 2 && mdx_nb_half(h);
+    // dual list: only the drift passes of the step loop accumulate path lengths (d_prune_out set by mdx_step)
+    const bool dual = h->dual_on && d_prune_out != nullptr && mode != 2 && zero;
+    const float path_thr = 0.5f * h->inner_skin * (1.0f - 1.0e-4f);
 #define INTEG(M)                                                                                                      \
     do {                                                                                                              \
-        if (zero) hipLaunchKernelGGL((integrate_kernel<M, true>), g, b, 0, h->stream, h->S, dt, d.posq, d.vel, d.force, \
-                                     d.ref, d_gate_in, d_disp_out, thr_bits, lg);                                    \
-        else hipLaunchKernelGGL((integrate_kernel<M, false>), g, b, 0, h->stream, h->S, dt, d.posq, d.vel, d.force,  \
-                                d.ref, d_gate_in, d_disp_out, thr_bits, lg);                                          \
+        if (dual) hipLaunchKernelGGL((integrate_kernel<M, true, true>), g, b, 0, h->stream, h->S, dt, d.posq, d.vel, d.force, \
+                                     d.ref, d_gate_in, d_disp_out, thr_bits, lg, d_prune_out, path_thr);              \
+        else if (zero) hipLaunchKernelGGL((integrate_kernel<M, true, false>), g, b, 0, h->stream, h->S, dt, d.posq, d.vel, d.force, \
+                                     d.ref, d_gate_in, d_disp_out, thr_bits, lg, nullptr, 0.f);                       \
+        else hipLaunchKernelGGL((integrate_kernel<M, false, false>), g, b, 0, h->stream, h->S, dt, d.posq, d.vel, d.force,  \
+                                d.ref, d_gate_in, d_disp_out, thr_bits, lg, nullptr, 0.f);                            \
     } while (0)
     switch (mode) {
     case 0: INTEG(0); break;

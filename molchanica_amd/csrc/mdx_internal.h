@@ -9,7 +9,8 @@
 //   widest coalesced access):
 //     posq [S] x,y,z, q*sqrt(k_e)          lj   [S] (sigma/2 | sqrt(sigma), sqrt(24 eps))
 //     vel  [S] vx,vy,vz, 418.4/mass (0 = never integrated)
-//     force[S] fx,fy,fz,-                  ref  [S] position at the last rebuild
+//     force[S] fx,fy,fz,-                  ref  [S] position at the last rebuild, .w = path length since the last
+//                                                   pruning pass of the dual list
 //   The pair list is per tile: a run of (j-cluster, image shift, i-cluster mask) entries, the
 //   ones that need exclusion masks first, each run padded to a multiple of 8 entries (= one
 //   64-atom chunk staged through LDS).
@@ -70,10 +71,15 @@ struct BondedParams {
 // seen after the drift of chunk-step s-1; every kernel of chunk-step s first tests
 // disp2[s] > thr and turns into a no-op when the list has gone stale, so the host may enqueue a
 // whole chunk of steps without synchronising.
+//
+// Dual pair list: prune[s] != 0 <=> after the drift of chunk-step s-1 some atom's path length since the last
+// pruning pass exceeded inner_skin/2; the pair kernel of chunk-step s-1's force call then walks the OUTER masks,
+// re-derives the inner masks and clears the path accumulators (ref[].w).  Device-side only, no host decision.
 struct StepCtl {
     uint32_t disp2[MDX_MAX_CHUNK + 2];
     uint32_t nonfinite;
     uint32_t pad;
+    uint32_t prune[MDX_MAX_CHUNK + 2];
 };
 
 // One (term, atom-of-that-term) record of the atom-owned bonded gather (mdx_bonded.hip).
@@ -160,6 +166,7 @@ struct DeviceState {
                                    // then MDX_EPART x {lj, coulomb, virial, -} partial sums of the pair kernel
     uint32_t* flags_dev = nullptr; // misc error flags
     unsigned long long* pair_count = nullptr;  // cluster pairs in the list (statistics)
+    unsigned long long* inner_count = nullptr; // [MDX_EPART + 1] dual list: kept cluster pairs per pruning pass (spread), passes
     float*   bbox_red = nullptr;   // [6] min/max reduction (vacuum grid)
 };
 
@@ -199,6 +206,11 @@ struct mdx_handle {
     uint64_t E = 0, cap_entries = 0;
     uint32_t MC = 0, cap_mchunks = 0;
     float r_list = 0.f;
+    // dual pair list (rolling pruning inside the pair kernel)
+    bool dual_on = false;        // this handle's step loop walks the inner masks
+    float inner_skin = 0.f;
+    bool prune_pending = true;   // the next step-loop force call must prune (after a rebuild / at the start of mdx_step)
+    int nb_step = -1;            // chunk step of the force call being enqueued (-1: not from the step loop -> outer masks)
     // state flags
     bool list_valid = false;    // spatial caches match the slot-space state
     bool forces_valid = false;
@@ -253,7 +265,7 @@ int mdx_launch_add_ext(mdx_handle* h, const uint32_t* d_gate, uint32_t thr_bits)
 // integration (mode: 0 = half kick + drift, 1 = full kick + drift (also: one leapfrog step), 2 = closing half
 // kick, 3 = one Langevin-middle step: full kick, half drift, friction + noise, half drift)
 int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_gate_in,
-                         uint32_t* d_disp_out, uint32_t thr_bits);
+                         uint32_t* d_disp_out, uint32_t thr_bits, uint32_t* d_prune_out = nullptr);
 int mdx_launch_kinetic(mdx_handle* h);  // energy[EN_KIN], energy[EN_COUNT] = max |F|^2
 int mdx_exclusive_scan_u32(mdx_handle* h, const uint32_t* in, uint32_t* out, uint32_t n);
 

@@ -51,6 +51,12 @@ struct NbArgs {
     const uint8_t* slot_flags;   // bit1: owned (energy of a ghost i-atom belongs to its owner's rank)
     NbParams p;
     const uint32_t* gate; uint32_t thr_bits;
+    // dual pair list (half-list force kernel of the step loop only; `inner` = 0 elsewhere)
+    uint32_t inner;               // 1: walk the inner masks (bits 16..23 of entry.y) unless this launch prunes
+    uint32_t force_prune;         // 1: this launch prunes regardless of the flag word
+    const uint32_t* prune_flag;   // ctl.prune[step + 1], raised by the drift pass
+    float rin2;                   // (cutoff + inner_skin)^2
+    uint2* entries_rw; float4* ref; unsigned long long* inner_count;
 };
 
 enum { CM_SHIFTED = 0, CM_RF = 1, CM_EWALD = 2, CM_SOFT = 3 };
@@ -77,12 +83,13 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
                                           const float4 pj, const float2 lj, bool allowed, const NbParams& p,
                                           float& fx, float& fy, float& fz, float& elj, float& ecoul,
                                           float* g = nullptr, float* evir = nullptr, float* ecross = nullptr,
-                                          float r2bias = 0.f) {
+                                          float r2bias = 0.f, float* r2_out = nullptr) {
     static_assert(!NANMASK || BRANCHY, "the NaN-coded exclusion needs the early-out");
     const float dx = xi - pj.x, dy = yi - pj.y, dz = zi - pj.z;   // tgt - src (src/cuda/util.cu:118-140)
     const float r2 = NANMASK ? __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, r2bias)))
                              : dx * dx + dy * dy + dz * dz;
     if (NANMASK) allowed = true;
+    if (r2_out) *r2_out = r2;
     const bool in_lj = (r2 < p.rc2_lj) && allowed;
     const bool in_c = SAMECUT ? in_lj : ((r2 < p.rc2_coul) && allowed);
     if (BRANCHY && !(in_lj || in_c)) return;
@@ -256,9 +263,19 @@ __device__ __forceinline__ float dpp_xadd(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
-template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF, bool ALCH = false>
+// DUAL (dual pair list, half-list force flavour only): 0 = plain list; 1 = walk the INNER masks, a no-op when this step
+// must prune; 2 = the pruning pass, a no-op unless this step must prune.  The step loop enqueues 1 and 2 back to back
+// and the device decides which one runs (a gated-off launch costs ~3 us).  A single kernel with a run-time switch was
+// measured first: the two scalar instructions it adds per cluster pair cost 11 % (0.537 -> 0.598 ms) - every
+// instruction in this loop is ~5 cycles of a latency-bound wave.
+template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF, bool ALCH = false, int DUAL = 0>
 __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && NB_HALF_FLUSH) || ENERGY) ? 3 : 4) void nb_cluster_kernel(NbArgs a) {
     if (a.gate && *a.gate > a.thr_bits) return;
+    static_assert(DUAL == 0 || (HALF && !ENERGY), "the dual list exists for the half-list force kernel");
+    if (DUAL != 0) {
+        const bool want_prune = (a.force_prune | *a.prune_flag) != 0u;
+        if (want_prune != (DUAL == 2)) return;
+    }
     constexpr int BW = WPT > NB_WAVES ? WPT : NB_WAVES;       // waves per workgroup
     __shared__ float4 s_xyzq[BW][64];
     __shared__ float2 s_lj[BW][64];
@@ -328,6 +345,15 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
     }
     float* const fbase = reinterpret_cast<float*>(a.force);
     float4* const sg = s_g[HALF ? wave : 0];
+    // Dual pair list.  Normal launch: the cluster-pair masks are the INNER ones (bits 16..23 of entry.y): pairs that had
+    // an atom pair within cutoff + inner_skin at the last pruning pass.  Pruning launch (forced by the host after a
+    // rebuild, or asked for by the drift pass through the step's prune word when some atom's path length since the
+    // last pass exceeded inner_skin/2): walk the OUTER masks (bits 8..15), evaluate as usual, and while the distances
+    // are at hand ballot every cluster pair against the inner radius, write the new inner masks back and clear the
+    // tile's path accumulators.  Decided on the device (see DUAL above): the host enqueues steps blind.
+    constexpr bool prune = DUAL == 2;
+    constexpr uint32_t msh = DUAL == 1 ? 16u : 8u;
+    uint32_t kept = 0;
     // HALF: the j-forces of a chunk collect in the wave's LDS strip and leave as three 64-lane
     // atomics (x, y, z of j-atom `lane`) when the chunk is done: always three, issued AFTER the
     // prefetch loads, so the loads' waits at the top of the next chunk are vmcnt(3) and the
@@ -364,13 +390,15 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
             if (c + 2 * WPT < nchunks) ent_n = a.entries[e0 + (c + 2 * WPT) * 8 + (lane >> 3)];
         }
         float celj = 0.f, cecoul = 0.f, cevir = 0.f, cecross = 0.f;   // (ENERGY) fp32 partial sums of this chunk
+        uint32_t newy = cur_y & 0xFF00FFFFu;                          // (pruning launch) this lane's entry word, inner mask rebuilt
         // entry loop: each entry's j record is read from LDS where it is needed (any look-ahead measured slower)
 #pragma unroll 1
         for (int e = 0; e < 8; ++e) {
             const float4 pj = sx[e * 8 + jj];
             const float2 lj = sl[e * 8 + jj];
-            const uint32_t im = (__builtin_amdgcn_readlane(cur_y, e * 8) >> 8) & 0xFFu;  // wave-uniform
+            const uint32_t im = (__builtin_amdgcn_readlane(cur_y, e * 8) >> msh) & 0xFFu;  // wave-uniform
             if (im == 0) continue;
+            uint32_t newm = 0;
             // exclusion bits only exist in masked chunks; elsewhere the (uniform) imask bit suffices
             // (as EXCLUDED bits: bit ci set <=> this lane's pair with i-cluster ci is masked out)
             const int x8 = masked ? (int)(~(uint32_t)reinterpret_cast<const uint8_t*>(&s_mask[wave][lane])[e]) : 0;
@@ -383,15 +411,24 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
                     float e1 = 0.f, e2 = 0.f, e3 = 0.f, e4 = 0.f;
                     // 0.0f or NaN: sign-extend bit ci of the exclusion byte over the word (one v_bfe_i32)
                     const float bias = __int_as_float((x8 << (31 - ci)) >> 31);
+                    float r2v = 0.f;
                     pair_eval<ENERGY, COUL, GEOM, SAMECUT, true, HALF, ALCH, true>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci],
                                                                              pj, lj, true, a.p, fx[ci], fy[ci],
                                                                              fz[ci], e1, e2, g, ENERGY ? &e3 : nullptr,
-                                                                             (ENERGY && ALCH) ? &e4 : nullptr, bias);
+                                                                             (ENERGY && ALCH) ? &e4 : nullptr, bias,
+                                                                             prune ? &r2v : nullptr);
+                    if (prune) {   // any allowed atom pair of this cluster pair inside the inner radius?
+                        if (__ballot(r2v < a.rin2) != 0ull) newm |= 1u << ci;
+                    }
                     if (ENERGY && HALF) {   // a pair's energy is split between the owners of its two atoms
                         const float w = wj + (((own_bits >> ci) & 1u) ? 0.5f : 0.f);
                         celj += w * e1; cecoul += w * e2; cevir += w * e3; cecross += w * e4;
                     } else if (ENERGY && ((own_bits >> ci) & 1u)) { celj += e1; cecoul += e2; cevir += e3; cecross += e4; }
                 }
+            }
+            if (prune) {
+                kept += __popc(newm);
+                if (jj == e) newy |= newm << 16;
             }
             if (HALF) {
                 // sum over the eight i-lanes of every j-atom: xor 1, xor 2 (quad_perm), then the
@@ -410,6 +447,7 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
             }
         }
         if (ENERGY) { elj += (double)celj; ecoul += (double)cecoul; evir += (double)cevir; ecross += (double)cecross; }
+        if (prune && ii == 0) a.entries_rw[e0 + c * 8 + jj].y = newy;   // this wave's own chunk: nobody else reads it
         WAVE_LDS_SYNC();
         if (HALF && NB_HALF_FLUSH) {
             // Flush: 192 floats = 3 instructions x 64 lanes, lane l of instruction k taking float
@@ -442,6 +480,11 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
         if (jj == ci) { ox = x; oy = y; oz = z; }
     }
     float* const fi = fbase + (size_t)(t * MDX_TILE + lane) * 4;
+    if (prune) {
+        if (part == 0 && t_ok) a.ref[t * MDX_TILE + lane].w = 0.f;       // path lengths count from this pass
+        if (lane == 0 && kept) atomicAdd(a.inner_count + ((blk * BW + wave) & (MDX_EPART - 1)), (unsigned long long)kept);
+        if (lane == 0 && blk == 0 && wave == 0) atomicAdd(a.inner_count + MDX_EPART, 1ull);
+    }
     if (WPT > 1) {   // fixed-order sum of the waves' partial forces
         s_red[wave][0][lane] = ox; s_red[wave][1][lane] = oy; s_red[wave][2][lane] = oz;
         __syncthreads();
@@ -495,11 +538,21 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
     const uint32_t nblocks = (a.T + tpb - 1) / tpb;
     const uint32_t grid = ((nblocks + 7) / 8) * 8;
     dim3 g(grid), b(bw * 64);
+    // dual list: the inner-walk kernel and the pruning kernel back to back, the device runs exactly one of them
+#define NB_DUAL(G, S, D)                                                                                              \
+    do {                                                                                                               \
+        if (ENERGY) break;                                                                                             \
+        if (wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, D>), g, b, 0, h->stream, a);      \
+        else if (wpt == 2) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 2, true, false, D>), g, b, 0, h->stream, a); \
+        else if (wpt == 1) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 1, true, false, D>), g, b, 0, h->stream, a); \
+        else hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 4, true, false, D>), g, b, 0, h->stream, a);               \
+    } while (0)
 #define NB_LAUNCH(G, S)                                                                                    \
     do {                                                                                                   \
         if (h->alch_on && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true, true>), g, b, 0, h->stream, a); \
         else if (h->alch_on) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, true, true>), g, b, 0, h->stream, a); \
         else if (var == 1) hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, G, S>), g, b, 0, h->stream, a);     \
+        else if (half && a.inner) { NB_DUAL(G, S, 1); NB_DUAL(G, S, 2); }                                          \
         else if (half && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true>), g, b, 0, h->stream, a); \
         else if (half && wpt == 2) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 2, true>), g, b, 0, h->stream, a); \
         else if (half && wpt == 1) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 1, true>), g, b, 0, h->stream, a); \
@@ -511,6 +564,7 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
     if (geom) { if (samecut) NB_LAUNCH(true, true); else NB_LAUNCH(true, false); }
     else      { if (samecut) NB_LAUNCH(false, true); else NB_LAUNCH(false, false); }
 #undef NB_LAUNCH
+#undef NB_DUAL
 }
 
 static bool cut_on(float rc) { return rc > 0.f && std::isfinite(rc); }
@@ -522,6 +576,17 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
     a.posq = h->d.posq; a.lj = h->d.lj; a.counts = h->d.list_counts; a.entry_off = h->d.entry_off;
     a.mchunk_off = h->d.mchunk_off; a.entries = h->d.entries; a.masks = h->d.masks;
     a.force = h->d.force; a.energy = h->d.energy; a.slot_flags = h->d.slot_flags; a.gate = d_gate; a.thr_bits = thr_bits;
+    // dual list: only force calls of the step loop (nb_step >= 0) use the inner masks; everything else - energies, the
+    // minimiser, the first evaluation after a rebuild - walks the plain list, which is always valid
+    a.inner = (h->dual_on && !h->alch_on && !energy && h->nb_step >= 0 && d_gate != nullptr) ? 1u : 0u;
+    if (a.inner) {
+        a.force_prune = h->prune_pending ? 1u : 0u;
+        a.prune_flag = &h->d.ctl->prune[h->nb_step + 1];
+        const float rin = std::max(cut_on(c.lj_cutoff) ? c.lj_cutoff : 0.f, cut_on(c.coulomb_cutoff) ? c.coulomb_cutoff : 0.f) + h->inner_skin;
+        a.rin2 = rin * rin;
+        a.entries_rw = h->d.entries; a.ref = h->d.ref; a.inner_count = h->d.inner_count;
+        h->prune_pending = false;   // (a launch gated off behind a stale list is followed by a rebuild, which sets it again)
+    }
     NbParams& p = a.p;
     p.rc2_lj = cut_on(c.lj_cutoff) ? c.lj_cutoff * c.lj_cutoff : FLT_MAX;
     p.rc2_coul = cut_on(c.coulomb_cutoff) ? c.coulomb_cutoff * c.coulomb_cutoff : FLT_MAX;

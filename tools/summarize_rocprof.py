@@ -51,6 +51,15 @@ if kt:
     if big:
         lines.append(f"pair kernel of the step loop (force-only flavour), executed launches only: n={len(big)} "
                      f"avg_us={sum(big) / len(big):.2f} min_us={min(big):.2f} max_us={max(big):.2f}")
+    # dual pair list: <...,1> walks the inner list, <...,2> is the pruning pass (walks the Verlet list); each step
+    # enqueues both and the device runs one (the other returns at once and shows up as a ~4 us launch)
+    per = {}
+    for name, st, en in rows:
+        k = short(name)
+        if is_step_pair_kernel(k) and (en - st) > 100e3:
+            per.setdefault(k, []).append((en - st) / 1e3)
+    for k, v in sorted(per.items()):
+        lines.append(f"  executed {k}: n={len(v)} avg_us={sum(v) / len(v):.2f} min_us={min(v):.2f} max_us={max(v):.2f}")
 
 # ---- PMC passes ----------------------------------------------------------------------------------
 pmc = {}
