@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, f
             const uint32_t y = __builtin_amdgcn_readlane(ent.y, e * 8);
             const uint32_t im = (y >> 8) & any;
             kept += __popc(im & 0xFFu);
-            if ((lane >> 3) == e) newy = (y & 0xFFu) | ((im & 0xFFu) << 8) | ((im & 0xFFu) << 16);   // inner mask := outer mask
+            if ((lane >> 3) == e) newy = (y & 0xFFu) | ((im & 0xFFu) << 8);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
         if (c < nmc) {
@@ -873,6 +873,7 @@ static int setup_grid(mdx_handle* h) {
         ALLOC(d.tile_col, need_tiles);
         ALLOC(d.cl_lo, NC); ALLOC(d.cl_hi, NC);
         ALLOC(d.list_counts, need_tiles);
+        ALLOC(d.inner_nch, (size_t)need_tiles * 8);
         ALLOC(d.entry_cnt, (size_t)need_tiles + 1); ALLOC(d.entry_off, (size_t)need_tiles + 1);
         ALLOC(d.mchunk_cnt, (size_t)need_tiles + 1); ALLOC(d.mchunk_off, (size_t)need_tiles + 1);
     }
@@ -978,6 +979,7 @@ int mdx_rebuild(mdx_handle* h) {
     if (E > h->cap_entries || !d.entries) {
         h->cap_entries = (uint64_t)(E * 1.25) + 1024;
         ALLOC(d.entries, h->cap_entries);
+        ALLOC(d.entries_in, h->cap_entries);   // dual list: the pruning pass of the pair kernel fills it
         a.entries = d.entries;
     }
     if (MC > h->cap_mchunks || !d.masks) {

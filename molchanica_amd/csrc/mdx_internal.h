@@ -149,6 +149,8 @@ struct DeviceState {
     uint32_t* mchunk_cnt = nullptr;     // [T+1]
     uint32_t* mchunk_off = nullptr;     // [T+1]
     uint2*    entries = nullptr;        // [E]
+    uint2*    entries_in = nullptr;     // [E] dual list: the inner list (masked run in place, plain run compacted per wave)
+    uint32_t* inner_nch = nullptr;      // [T*8] dual list: chunk-loop bound per (tile, wave of the tile)
     unsigned long long* masks = nullptr; // [MC*64]
     // bonded terms as per-atom role lists: caller order (static) and slot order (per rebuild)
     uint32_t* role_off_o = nullptr; RoleRec* role_rec_o = nullptr;   // [N+1], [R]

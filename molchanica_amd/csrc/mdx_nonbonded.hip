@@ -52,11 +52,13 @@ struct NbArgs {
     NbParams p;
     const uint32_t* gate; uint32_t thr_bits;
     // dual pair list (half-list force kernel of the step loop only; `inner` = 0 elsewhere)
-    uint32_t inner;               // 1: walk the inner masks (bits 16..23 of entry.y) unless this launch prunes
+    uint32_t inner;               // 1: walk the inner list unless this launch prunes
     uint32_t force_prune;         // 1: this launch prunes regardless of the flag word
     const uint32_t* prune_flag;   // ctl.prune[step + 1], raised by the drift pass
     float rin2;                   // (cutoff + inner_skin)^2
-    uint2* entries_rw; float4* ref; unsigned long long* inner_count;
+    uint2* entries_in;            // the inner list: same layout as `entries`, every wave's share of the plain run compacted
+    uint32_t* inner_nch;          // [T * 8 + part] chunk-loop bound of wave `part` of a tile in the inner list
+    float4* ref; unsigned long long* inner_count;
 };
 
 enum { CM_SHIFTED = 0, CM_RF = 1, CM_EWALD = 2, CM_SOFT = 3 };
@@ -263,8 +265,8 @@ __device__ __forceinline__ float dpp_xadd(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
-// DUAL (dual pair list, half-list force flavour only): 0 = plain list; 1 = walk the INNER masks, a no-op when this step
-// must prune; 2 = the pruning pass, a no-op unless this step must prune.  The step loop enqueues 1 and 2 back to back
+// DUAL (dual pair list, half-list force flavour only): 0 = plain list; 1 = walk the INNER list, a no-op when this step
+// must prune; 2 = the pruning pass (walks the Verlet list, writes the inner list), a no-op unless this step must prune.  The step loop enqueues 1 and 2 back to back
 // and the device decides which one runs (a gated-off launch costs ~3 us).  A single kernel with a run-time switch was
 // measured first: the two scalar instructions it adds per cluster pair cost 11 % (0.537 -> 0.598 ms) - every
 // instruction in this loop is ~5 cycles of a latency-bound wave.
@@ -310,7 +312,12 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
     ListCounts cnt = a.counts[t_ok ? t : 0];
     if (!t_ok) { cnt.n_masked = 0; cnt.n_plain = 0; }
     const uint32_t e0 = a.entry_off[t_ok ? t : 0];
-    const uint32_t nmc = cnt.n_masked >> 3, nchunks = (cnt.n_masked + cnt.n_plain) >> 3;
+    // DUAL == 1: the inner list.  Same offsets and the same masked run as the Verlet list (exclusion masks are addressed
+    // by chunk position); of the plain run, wave `part` finds the survivors of ITS chunks (c = part, part + WPT, ...)
+    // compacted into the first of those chunk positions, and its own loop bound in inner_nch.
+    const uint2* __restrict__ const entries = DUAL == 1 ? a.entries_in : a.entries;
+    const uint32_t nmc = cnt.n_masked >> 3;
+    const uint32_t nchunks = DUAL == 1 ? (t_ok ? a.inner_nch[t * 8 + part] : 0u) : (cnt.n_masked + cnt.n_plain) >> 3;
     const uint32_t mbase = a.mchunk_off[t_ok ? t : 0];
     float4* sx = s_xyzq[wave];
     float2* sl = s_lj[wave];
@@ -336,24 +343,26 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
     unsigned long long nmq = ~0ull;
     uint2 ent_n = make_uint2(0u, 13u);
     if ((uint32_t)part < nchunks) {
-        const uint2 ent = a.entries[e0 + part * 8 + (lane >> 3)];
+        const uint2 ent = entries[e0 + part * 8 + (lane >> 3)];
         if ((uint32_t)part < nmc) nmq = a.masks[(size_t)(mbase + part) * 64 + lane];
-        if ((uint32_t)part + WPT < nchunks) ent_n = a.entries[e0 + (part + WPT) * 8 + (lane >> 3)];
+        if ((uint32_t)part + WPT < nchunks) ent_n = entries[e0 + (part + WPT) * 8 + (lane >> 3)];
         const uint32_t js = ent.x * MDX_CLUSTER + (lane & 7);
         nj = a.posq[js]; nl = a.lj[js]; ny = ent.y; njc = ent.x;
         if (ENERGY && HALF) nown = (float)((a.slot_flags[js] >> 1) & 1u);
     }
     float* const fbase = reinterpret_cast<float*>(a.force);
     float4* const sg = s_g[HALF ? wave : 0];
-    // Dual pair list.  Normal launch: the cluster-pair masks are the INNER ones (bits 16..23 of entry.y): pairs that had
-    // an atom pair within cutoff + inner_skin at the last pruning pass.  Pruning launch (forced by the host after a
-    // rebuild, or asked for by the drift pass through the step's prune word when some atom's path length since the
-    // last pass exceeded inner_skin/2): walk the OUTER masks (bits 8..15), evaluate as usual, and while the distances
-    // are at hand ballot every cluster pair against the inner radius, write the new inner masks back and clear the
-    // tile's path accumulators.  Decided on the device (see DUAL above): the host enqueues steps blind.
+    // Dual pair list.  Normal launch (DUAL 1): the list is the INNER one: cluster pairs that had an atom pair within
+    // cutoff + inner_skin at the last pruning pass.  Pruning launch (DUAL 2; forced by the host after a rebuild, or asked
+    // for by the drift pass through the step's prune word when some atom's path length since the last pass exceeded
+    // inner_skin/2): walk the Verlet list, evaluate as usual, and while the distances are at hand ballot every cluster
+    // pair against the inner radius; the surviving masks go to the inner list (masked run in place, this wave's plain
+    // entries compacted), and the tile's path accumulators are cleared.  Decided on the device: the host enqueues blind.
     constexpr bool prune = DUAL == 2;
-    constexpr uint32_t msh = DUAL == 1 ? 16u : 8u;
     uint32_t kept = 0;
+    // (pruning launch) first plain chunk of this wave's share, and how many compacted plain entries it has written
+    const uint32_t c_first = nmc + ((uint32_t)part + WPT - nmc % WPT) % WPT;
+    uint32_t wcur = 0;
     // HALF: the j-forces of a chunk collect in the wave's LDS strip and leave as three 64-lane
     // atomics (x, y, z of j-atom `lane`) when the chunk is done: always three, issued AFTER the
     // prefetch loads, so the loads' waits at the top of the next chunk are vmcnt(3) and the
@@ -387,16 +396,16 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
             const uint32_t js = ent_n.x * MDX_CLUSTER + (lane & 7);
             nj = a.posq[js]; nl = a.lj[js]; ny = ent_n.y; njc = ent_n.x;
             if (ENERGY && HALF) nown = (float)((a.slot_flags[js] >> 1) & 1u);
-            if (c + 2 * WPT < nchunks) ent_n = a.entries[e0 + (c + 2 * WPT) * 8 + (lane >> 3)];
+            if (c + 2 * WPT < nchunks) ent_n = entries[e0 + (c + 2 * WPT) * 8 + (lane >> 3)];
         }
         float celj = 0.f, cecoul = 0.f, cevir = 0.f, cecross = 0.f;   // (ENERGY) fp32 partial sums of this chunk
-        uint32_t newy = cur_y & 0xFF00FFFFu;                          // (pruning launch) this lane's entry word, inner mask rebuilt
+        uint32_t newy = cur_y & 0xFFu;                                // (pruning launch) this lane's entry word with the inner mask
         // entry loop: each entry's j record is read from LDS where it is needed (any look-ahead measured slower)
 #pragma unroll 1
         for (int e = 0; e < 8; ++e) {
             const float4 pj = sx[e * 8 + jj];
             const float2 lj = sl[e * 8 + jj];
-            const uint32_t im = (__builtin_amdgcn_readlane(cur_y, e * 8) >> msh) & 0xFFu;  // wave-uniform
+            const uint32_t im = (__builtin_amdgcn_readlane(cur_y, e * 8) >> 8) & 0xFFu;  // wave-uniform
             if (im == 0) continue;
             uint32_t newm = 0;
             // exclusion bits only exist in masked chunks; elsewhere the (uniform) imask bit suffices
@@ -428,7 +437,7 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
             }
             if (prune) {
                 kept += __popc(newm);
-                if (jj == e) newy |= newm << 16;
+                if (jj == e) newy |= newm << 8;
             }
             if (HALF) {
                 // sum over the eight i-lanes of every j-atom: xor 1, xor 2 (quad_perm), then the
@@ -447,7 +456,19 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
             }
         }
         if (ENERGY) { elj += (double)celj; ecoul += (double)cecoul; evir += (double)cevir; ecross += (double)cecross; }
-        if (prune && ii == 0) a.entries_rw[e0 + c * 8 + jj].y = newy;   // this wave's own chunk: nobody else reads it
+        if (prune) {
+            if (masked) {                       // exclusion masks are addressed by chunk position: the entry stays where it is
+                if (ii == 0) a.entries_in[e0 + c * 8 + jj] = make_uint2(cur_jc, newy);
+            } else {                            // plain run: survivors move up into this wave's first chunk positions
+                const bool alive = ii == 0 && (newy >> 8) != 0u;
+                const unsigned long long bal = __ballot(alive);
+                if (alive) {
+                    const uint32_t k = wcur + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    a.entries_in[e0 + (c_first + (k >> 3) * WPT) * 8 + (k & 7u)] = make_uint2(cur_jc, newy);
+                }
+                wcur += (uint32_t)__popcll(bal);
+            }
+        }
         WAVE_LDS_SYNC();
         if (HALF && NB_HALF_FLUSH) {
             // Flush: 192 floats = 3 instructions x 64 lanes, lane l of instruction k taking float
@@ -480,6 +501,15 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
         if (jj == ci) { ox = x; oy = y; oz = z; }
     }
     float* const fi = fbase + (size_t)(t * MDX_TILE + lane) * 4;
+    if (prune && t_ok) {
+        // pad the last compacted chunk with null entries (imask 0), publish this wave's loop bound
+        const uint32_t nfull = (wcur + 7u) >> 3;
+        if ((uint32_t)lane < nfull * 8u - wcur) {
+            const uint32_t k = wcur + (uint32_t)lane;
+            a.entries_in[e0 + (c_first + (k >> 3) * WPT) * 8 + (k & 7u)] = make_uint2(a.T * MDX_CL_PER_TILE, 13u);
+        }
+        if (lane == 0) a.inner_nch[t * 8 + part] = nfull ? c_first + (nfull - 1u) * WPT + 1u : nmc;
+    }
     if (prune) {
         if (part == 0 && t_ok) a.ref[t * MDX_TILE + lane].w = 0.f;       // path lengths count from this pass
         if (lane == 0 && kept) atomicAdd(a.inner_count + ((blk * BW + wave) & (MDX_EPART - 1)), (unsigned long long)kept);
@@ -584,7 +614,7 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
         a.prune_flag = &h->d.ctl->prune[h->nb_step + 1];
         const float rin = std::max(cut_on(c.lj_cutoff) ? c.lj_cutoff : 0.f, cut_on(c.coulomb_cutoff) ? c.coulomb_cutoff : 0.f) + h->inner_skin;
         a.rin2 = rin * rin;
-        a.entries_rw = h->d.entries; a.ref = h->d.ref; a.inner_count = h->d.inner_count;
+        a.entries_in = h->d.entries_in; a.inner_nch = h->d.inner_nch; a.ref = h->d.ref; a.inner_count = h->d.inner_count;
         h->prune_pending = false;   // (a launch gated off behind a stale list is followed by a rebuild, which sets it again)
     }
     NbParams& p = a.p;
