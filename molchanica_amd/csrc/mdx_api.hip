@@ -463,7 +463,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
             h->lang_step = h->step_count + s;
             const int mode = !vv ? (integ == MDX_INTEGRATOR_LANGEVIN_MIDDLE ? 3 : 1) : ((s == 0 || !fused) ? 0 : 1);
             MDX_TRY(mdx_launch_integrate(h, mode, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
-            MDX_TRY(mdx_launch_constrain_positions(h, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr));
+            MDX_TRY(mdx_launch_constrain_positions(h, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
             // Langevin middle: friction and noise sit between the two half drifts, so SHAKE's dx/dt is not an
             // exact velocity projection; RATTLE the half-step velocities (same gate as SHAKE: it belongs to the
             // drift, which has happened even when the step's forces turn out to be gated off)

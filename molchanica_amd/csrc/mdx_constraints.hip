@@ -38,12 +38,13 @@ __device__ __forceinline__ float3 mimg3(float3 d, const ConsParams& p) {
 // ---- SHAKE: positions ---------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_groups, const ConsGroup* __restrict__ groups,
                                                                   float4* __restrict__ posq, float4* __restrict__ vel,
-                                                                  const float4* __restrict__ ref, float dt, ConsParams p,
+                                                                  float4* __restrict__ ref, float dt, ConsParams p,
                                                                   float* __restrict__ cons_vir,
-                                                                  const uint32_t* gate, uint32_t* disp_out, uint32_t thr) {
+                                                                  const uint32_t* gate, uint32_t* disp_out, uint32_t thr,
+                                                                  uint32_t* prune_out, float path_thr) {
     if (gate && *gate > thr) return;
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    float d2max = 0.f;
+    float d2max = 0.f, pmax = 0.f;   // pmax: dual pair list, the longest path since the last pruning pass (ref[].w)
     if (g < n_groups) {
         const ConsGroup cg = groups[g];
         // local frame: displacement of every atom from atom 0 (minimum image), new and old
@@ -104,6 +105,11 @@ __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_gro
                 const float4 r = ref[cg.atom[k]];
                 const float ex = pk.x - r.x, ey = pk.y - r.y, ez = pk.z - r.z;
                 d2max = fmaxf(d2max, ex * ex + ey * ey + ez * ez);
+                if (prune_out) {   // the SHAKE correction lengthens the atom's path like the drift did
+                    const float w = r.w + sqrtf(dx.x * dx.x + dx.y * dx.y + dx.z * dx.z);
+                    ref[cg.atom[k]].w = w;
+                    pmax = fmaxf(pmax, w);
+                }
             }
         }
         (void)x0;
@@ -113,6 +119,11 @@ __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_gro
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) d2max = fmaxf(d2max, __shfl_xor(d2max, m));
         if ((threadIdx.x & 63) == 0 && __float_as_uint(d2max) > thr) atomicMax(disp_out, __float_as_uint(d2max));
+    }
+    if (prune_out) {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, m));
+        if ((threadIdx.x & 63) == 0 && !(pmax <= path_thr)) *prune_out = 1u;
     }
 }
 
@@ -297,6 +308,8 @@ int mdx_build_constraints(mdx_handle* h, const mdx_system* s) {
             VSite v{};
             v.site = s->vsite_idx[4 * i]; v.p0 = s->vsite_idx[4 * i + 1]; v.p1 = s->vsite_idx[4 * i + 2];
             v.p2 = s->vsite_idx[4 * i + 3]; v.a = s->vsite_w[2 * i]; v.b = s->vsite_w[2 * i + 1];
+            // a site inside the triangle of its parents never moves further than they do (dual pair list)
+            if (!(v.a >= 0.f && v.b >= 0.f && v.a + v.b <= 1.f)) h->vsites_convex = false;
             const uint32_t ids[4] = {v.site, v.p0, v.p1, v.p2};
             for (uint32_t id : ids) {
                 if (id >= N) FAIL(MDX_EPARAM, "virtual-site atom index out of range");
@@ -327,12 +340,14 @@ int mdx_remap_constraints(mdx_handle* h) {
     return MDX_OK;
 }
 
-int mdx_launch_constrain_positions(mdx_handle* h, float dt, const uint32_t* d_gate, uint32_t* d_disp_out, uint32_t thr) {
+int mdx_launch_constrain_positions(mdx_handle* h, float dt, const uint32_t* d_gate, uint32_t* d_disp_out, uint32_t thr,
+                                   uint32_t* d_prune_out) {
     if (!h->n_groups) return MDX_OK;
+    if (!h->dual_on) d_prune_out = nullptr;
     hipLaunchKernelGGL(constrain_positions_kernel, dim3(div_up(h->n_groups, 128)), dim3(128), 0, h->stream, h->n_groups,
                        h->d.cons_s, h->d.posq, h->d.vel, h->d.ref, dt, cons_params(h),
                        dt != 0.f ? h->d.cons_vir : nullptr,   // a dt = 0 projection (new coordinates, rescaled box) keeps the last step's virial
-                       d_gate, d_disp_out, thr);
+                       d_gate, d_disp_out, thr, d_prune_out, 0.5f * h->inner_skin * (1.0f - 1.0e-4f));
     HIP_TRY(hipGetLastError());
     return MDX_OK;
 }

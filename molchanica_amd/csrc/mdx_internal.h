@@ -188,6 +188,7 @@ struct mdx_handle {
     uint32_t n_roles = 0;
     uint32_t n_groups = 0, n_cons = 0, n_vsites = 0;   // constraint clusters / constraints / virtual sites
     bool cons_dirty = false;                           // positions were set from outside: project them once
+    bool vsites_convex = true;                         // every virtual site lies inside the triangle of its parents
     // SPME
     bool pme_on = false; int pme_K[3] = {0, 0, 0}; void* pme_plan = nullptr;  // opaque PmePlan
     double ewald_self = 0.0, ewald_background = 0.0; double total_charge = 0.0, sum_q2 = 0.0;
@@ -286,7 +287,8 @@ static inline bool mdx_nb_half(const mdx_handle* h) { return mdx_nb_variant(h) =
 // constraints / virtual sites (mdx_constraints.hip)
 int mdx_build_constraints(mdx_handle* h, const mdx_system* s);
 int mdx_remap_constraints(mdx_handle* h);                  // caller order -> slot order, at every rebuild
-int mdx_launch_constrain_positions(mdx_handle* h, float dt, const uint32_t* d_gate, uint32_t* d_disp_out, uint32_t thr);
+int mdx_launch_constrain_positions(mdx_handle* h, float dt, const uint32_t* d_gate, uint32_t* d_disp_out, uint32_t thr,
+                                   uint32_t* d_prune_out = nullptr);
 int mdx_launch_constrain_velocities(mdx_handle* h, const uint32_t* d_gate, uint32_t thr);
 int mdx_launch_vsite_construct(mdx_handle* h, const uint32_t* d_gate, uint32_t thr);
 int mdx_launch_constraint_virial(mdx_handle* h);

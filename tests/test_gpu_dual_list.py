@@ -8,7 +8,7 @@ Checked here on the GPU:
     also on the last steps before a re-pruning pass,
   * trajectories with the dual list on and off agree,
   * the pruning passes happen on the device (statistics), keep fewer cluster pairs than the Verlet list, and
-  * the configurations that move atoms outside the drift pass (constraints) silently keep the plain list.
+  * SHAKE corrections and virtual sites (rigid TIP3P, OPC) are covered by the same path-length bound.
 """
 import math
 
@@ -82,8 +82,18 @@ def test_trajectory_with_and_without_dual_list(mdx):
     assert st1["prune_passes"] > 0
 
 
-def test_constrained_runs_keep_the_plain_list(mdx):
-    s = systems.water_box(8, seed=34, rigid=True)
-    with mdx.MdState(s, MdConfig(lj_cutoff=8.0, coulomb_cutoff=8.0, skin=1.5, coulomb_mode=1)) as md:
-        md.step(0.002, None, 30)
-        assert md.stats()["prune_passes"] == 0
+@pytest.mark.parametrize("kind", ["rigid_tip3p", "opc"])
+def test_constrained_and_virtual_site_runs(mdx, kind):
+    """SHAKE corrections lengthen the path accumulators like the drift does; OPC's M site lies inside the triangle of
+    its parents, so it never moves further than they do: the reference's default operating point (rigid 4-site water,
+    dt = 2 fs, /root/reference src/prefs/mod.rs:203) walks the inner list too."""
+    s = systems.water_box(10, seed=34, rigid=True, temp=400.0) if kind == "rigid_tip3p" else systems.opc_water_box(10, seed=35, temp=400.0)
+    with mdx.MdState(s, MdConfig(lj_cutoff=8.0, coulomb_cutoff=8.0, skin=1.5, coulomb_mode=1, inner_skin=0.3)) as md:
+        for burst in (1, 3, 7, 19, 30):
+            md.step(0.002, None, burst)
+            f_inner = md.forces().astype(np.float64)
+            md.energy()
+            assert _force_err(f_inner, md.forces().astype(np.float64)) < 1.0, f"{kind}: burst {burst}"
+        st = md.stats()
+        assert st["prune_passes"] > 5 + st["rebuild_count"]
+        assert 0 < st["n_inner_cluster_pairs"] < st["n_cluster_pairs"]
