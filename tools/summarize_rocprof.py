@@ -117,7 +117,7 @@ if nbk:
                           "for wide coalesced reads; WRITE_SIZE taken as reported (uncalibrated)",
             "hbm_bytes_per_launch": 2.0 * fetch + write, "hbm_bytes_per_launch_uncorrected": fetch + write,
             "algorithmic_bytes_per_launch": 32.0 * 1029000,
-            "note": "memory-side (fabric) request bytes.  Reads: pair list (3.5 M entries x 8 B) + posq/lj of j-clusters that miss "
+            "note": "memory-side (fabric) request bytes.  Reads: pair list (3.2 M entries x 8 B) + posq/lj of j-clusters that miss "
                     "the 4 MiB per-XCD L2.  Writes: the half-list kernel returns the reaction force with f32 atomics, which "
                     "gfx950 executes on the memory side - ~88 M atomic words per launch appear here as write requests "
                     "(~6 B each); the full-list kernel (nb_variant 2) writes 16.5 MB, exactly the force array, and is 40 % slower",

@@ -41,6 +41,25 @@ __global__ __launch_bounds__(64) void chain_branchy(float* out, int iters, float
     if (acc == 12345.678f) out[0] = acc;
 }
 
+// does the SIMD skip the passes of a wave64 instruction whose lanes are all masked off?  `keep` selects the active lanes
+__global__ __launch_bounds__(64) void fma_masked(float* out, int iters, float a, float b, unsigned long long keep) {
+    float x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = (float)threadIdx.x + k;
+    if ((keep >> threadIdx.x) & 1ull) {
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[k]) : "v"(a), "v"(b));
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += x[k];
+    if (s == 12345.678f) out[0] = s;
+}
+
 template <typename K, typename... A>
 static double run(K k, int blocks, A... args) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -73,6 +92,16 @@ int main() {
         const int blocks = 256 * 4 * W;
         double t = run(chain_branchy, blocks, out, iters, 0.25f, 1e30f);
         printf("W=%d: %.1f cycles per unit per SIMD, %.1f per unit per wave\n", W, t * clk / ((double)iters * 8 * W), t * clk / ((double)iters * 8));
+    }
+    printf("exec-masked v_fma_f32 (8 waves/SIMD, ILP 8): cycles per instruction per SIMD by active-lane pattern\n");
+    struct { const char* name; unsigned long long keep; } pats[] = {
+        {"all 64", ~0ull}, {"lanes 0-31", 0xFFFFFFFFull}, {"lanes 0-15", 0xFFFFull}, {"lanes 0-7", 0xFFull},
+        {"lanes 0-15 + 32-47", 0x0000FFFF0000FFFFull}, {"every 2nd lane", 0x5555555555555555ull},
+        {"every 8th lane", 0x0101010101010101ull}, {"lane 0 only", 1ull}};
+    for (auto& pt : pats) {
+        const int W = 8, blocks = 256 * 4 * W;
+        double t = run(fma_masked, blocks, out, iters, 1.0001f, 0.5f, pt.keep);
+        printf("  %-20s %.2f\n", pt.name, t * clk / ((double)iters * 64 * W));
     }
     return 0;
 }
