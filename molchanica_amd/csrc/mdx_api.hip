@@ -720,9 +720,11 @@ __global__ void pack_pos_kernel(uint32_t n, const uint32_t* __restrict__ atom_id
     const uint32_t s = slot_of[g];
     out[i] = (s == MDX_INVALID) ? make_float4(0.f, 0.f, 0.f, 0.f) : posq[s];
 }
+// Dual pair list: a ghost moves by halo message, not by the drift pass, so its path accumulator (ref[].w) is fed here.
 __global__ void unpack_pos_kernel(uint32_t n, const uint32_t* __restrict__ atom_idx, const uint32_t* __restrict__ slot_of,
                                   float4* __restrict__ posq, const float4* __restrict__ in,
-                                  const float4* __restrict__ shift, uint32_t* __restrict__ flag_word) {
+                                  const float4* __restrict__ shift, uint32_t* __restrict__ flag_word,
+                                  float4* __restrict__ ref, uint32_t* __restrict__ prune_out, float path_thr) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t g = atom_idx[i];
@@ -735,6 +737,12 @@ __global__ void unpack_pos_kernel(uint32_t n, const uint32_t* __restrict__ atom_
     float4 v = in[i];
     if (shift) { const float4 sh = shift[i]; v.x += sh.x; v.y += sh.y; v.z += sh.z; }
     float4 p = posq[s];
+    if (ref) {
+        const float mx = v.x - p.x, my = v.y - p.y, mz = v.z - p.z;
+        const float w = ref[s].w + sqrtf(mx * mx + my * my + mz * mz);
+        ref[s].w = w;
+        if (!(w <= path_thr)) *prune_out = 1u;   // idempotent, rare
+    }
     p.x = v.x; p.y = v.y; p.z = v.z;
     posq[s] = p;
 }
@@ -782,14 +790,16 @@ extern "C" int mdx_chunk_begin(mdx_handle* h) {
     HIP_TRY(hipSetDevice(h->device));
     if (!h->list_valid) MDX_TRY(mdx_rebuild(h));
     HIP_TRY(hipMemsetAsync(h->d.ctl, 0, sizeof(StepCtl), h->stream));
+    h->chunk_s = -1;
     return MDX_OK;
 }
 
 extern "C" int mdx_chunk_integrate(mdx_handle* h, int mode, float dt, uint32_t s) {
     if (!h || s > MDX_MAX_CHUNK || mode < 0 || mode > 2) FAIL(MDX_EPARAM, "bad argument");
     h->prof_tag = (int)s;
+    if (mode != 2) h->chunk_s = (int)s;   // the halo unpack and the force call of this step share its prune word
     int rc = mdx_launch_integrate(h, mode, dt, &h->d.ctl->disp2[s], mode == 2 ? nullptr : &h->d.ctl->disp2[s + 1],
-                                  stale_threshold_bits(h));
+                                  stale_threshold_bits(h), mode == 2 ? nullptr : &h->d.ctl->prune[s + 1]);
     h->prof_tag = -1;
     return rc;
 }
@@ -799,7 +809,9 @@ extern "C" int mdx_chunk_forces(mdx_handle* h, int32_t s) {
     HIP_TRY(hipSetDevice(h->device));
     if (!h->list_valid) MDX_TRY(mdx_rebuild(h));
     h->prof_tag = s;
+    h->nb_step = s;   // s >= 0: a step-loop force call, may walk the inner list / prune on ctl.prune[s + 1]
     int rc = compute_forces(h, false, s < 0 ? nullptr : &h->d.ctl->disp2[s + 1], stale_threshold_bits(h));
+    h->nb_step = -1;
     h->prof_tag = -1;
     if (rc == MDX_OK) h->forces_valid = true;
     return rc;
@@ -841,9 +853,12 @@ extern "C" int mdx_unpack_positions(mdx_handle* h, const uint32_t* d_gid, uint32
                                     const float* d_shift4, int32_t flag_word) {
     if (!h || (n && (!d_gid || !d_in4)) || flag_word > (int32_t)MDX_MAX_CHUNK + 1) FAIL(MDX_EPARAM, "bad argument");
     if (!h->in_slot_space) FAIL(MDX_EPARAM, "spatial caches not built");
+    const bool dual = h->dual_on && h->chunk_s >= 0;
     if (n) hipLaunchKernelGGL(unpack_pos_kernel, dim3(div_up(n, 256)), dim3(256), 0, h->stream, n, d_gid,
                               h->d.slot_of, h->d.posq, (const float4*)d_in4, (const float4*)d_shift4,
-                              flag_word >= 0 ? &h->d.ctl->disp2[flag_word] : nullptr);
+                              flag_word >= 0 ? &h->d.ctl->disp2[flag_word] : nullptr,
+                              dual ? h->d.ref : nullptr, dual ? &h->d.ctl->prune[h->chunk_s + 1] : nullptr,
+                              0.5f * h->inner_skin * (1.0f - 1.0e-4f));
     HIP_TRY(hipGetLastError());
     h->forces_valid = false;
     return MDX_OK;

@@ -1023,12 +1023,13 @@ int mdx_rebuild(mdx_handle* h) {
     h->list_valid = true;
     h->forces_valid = false;
     h->rebuild_count++;
-    // dual pair list: the step loop of a single-domain half-list run walks a rolling-pruned inner list.  What moves an
-    // atom inside the step loop feeds its path accumulator: the drift pass and SHAKE; a virtual site inside the
-    // triangle of its parents never moves further than they do (anything else keeps the plain list)
+    // dual pair list: the step loop of a half-list run walks a rolling-pruned inner list.  What moves an atom inside
+    // the step loop feeds its path accumulator: the drift pass, SHAKE, and - for the ghosts of a decomposed handle - the
+    // halo unpack; a virtual site inside the triangle of its parents never moves further than they do (anything else
+    // keeps the plain list)
     h->inner_skin = c_inner_skin(h->cfg);
     h->dual_on = mdx_nb_half(h) && prune && h->inner_skin > 0.f && h->inner_skin < h->cfg.skin &&
-                 (h->n_vsites == 0 || h->vsites_convex) && h->n_local == h->N && !h->have_local_bounds;
+                 (h->n_vsites == 0 || h->vsites_convex);
     h->prune_pending = true;
     if (!d.inner_count) { ALLOC(d.inner_count, MDX_EPART + 1); HIP_TRY(hipMemsetAsync(d.inner_count, 0, sizeof(unsigned long long) * (MDX_EPART + 1), st)); }
     uint64_t nmask = (uint64_t)MC * 8;

@@ -214,6 +214,7 @@ struct mdx_handle {
     float inner_skin = 0.f;
     bool prune_pending = true;   // the next step-loop force call must prune (after a rebuild / at the start of mdx_step)
     int nb_step = -1;            // chunk step of the force call being enqueued (-1: not from the step loop -> outer masks)
+    int chunk_s = -1;            // decomposed driver: chunk step whose drift has been enqueued (its prune word is shared by the halo unpack)
     // state flags
     bool list_valid = false;    // spatial caches match the slot-space state
     bool forces_valid = false;

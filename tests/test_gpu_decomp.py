@@ -138,3 +138,24 @@ def test_bench_multiprocess_flow_two_ranks_one_gpu():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 40 and j["value"] > 0 and j["scaling"] == "strong"
     assert j["config"]["energy_evaluations_in_timed_region"] == 2 and "2x1x1" in j["config"]["parallelism"]
+
+
+def test_dual_pair_list_on_decomposed_handles():
+    """The inner list of a decomposed rank: owned atoms feed their path accumulators in the drift pass, ghosts in the
+    halo unpack; every rank prunes on its own.  A hot box, 4 virtual ranks with a thin inner skin against one GPU
+    walking the plain Verlet list."""
+    from molchanica_amd.md_state import MdState
+    s = systems.water_box(16, seed=9, temp=600.0)            # 12,288 atoms, 49.7 Å box
+    with MdState(s, MdConfig(**CFG, inner_skin=-1.0)) as md:
+        md.step(0.0005, None, 40)
+        p_ref = md.positions().astype(np.float64)
+        assert md.stats()["prune_passes"] == 0
+    res = run_ranks(s, MdConfig(**CFG, inner_skin=0.3), 4, 40)
+    L = np.array(s.box_hi, dtype=np.float64)
+    d = res[0]["pos"].astype(np.float64) - p_ref
+    d -= np.round(d / L) * L
+    assert math.sqrt((d ** 2).sum(1).mean()) < 3e-3
+    for r in range(4):
+        st = res[r]["stats"]
+        assert st["prune_passes"] > st["rebuild_count"], (r, st["prune_passes"], st["rebuild_count"])
+        assert 0 < st["n_inner_cluster_pairs"] < st["n_cluster_pairs"]
