@@ -97,3 +97,18 @@ def test_constrained_and_virtual_site_runs(mdx, kind):
         st = md.stats()
         assert st["prune_passes"] > 5 + st["rebuild_count"]
         assert 0 < st["n_inner_cluster_pairs"] < st["n_cluster_pairs"]
+
+
+def test_full_size_box(mdx):
+    """BASELINE.json's 1,029,000-atom water box as generated (it heats towards 1300 K: the hardest case for a
+    path-length bound): at every checkpoint all 1,029,000 step-loop forces equal a fresh plain-list evaluation."""
+    s = systems.water1m()
+    with mdx.MdState(s, MdConfig()) as md:                  # rc 10, skin 2, inner skin 0.5: the bench configuration
+        for burst in (3, 20, 41, 64):
+            md.step(0.0005, None, burst)
+            f_inner = md.forces().astype(np.float64)
+            md.energy()
+            assert _force_err(f_inner, md.forces().astype(np.float64)) < 1.0, f"burst of {burst}"
+        st = md.stats()
+        assert st["prune_passes"] > 4 + st["rebuild_count"]
+        assert st["n_inner_cluster_pairs"] < 0.85 * st["n_cluster_pairs"]
