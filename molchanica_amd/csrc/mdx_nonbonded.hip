@@ -59,6 +59,7 @@ struct NbArgs {
     uint2* entries_in;            // the inner list: same layout as `entries`, every wave's share of the plain run compacted
     uint32_t* inner_nch;          // [T * 8 + part] chunk-loop bound of wave `part` of a tile in the inner list
     float4* ref; unsigned long long* inner_count;
+    uint32_t xcd_interleave;      // 1: workgroup b takes tile group b (round-robin over the XCDs) instead of a contiguous eighth per XCD
 };
 
 enum { CM_SHIFTED = 0, CM_RF = 1, CM_EWALD = 2, CM_SOFT = 3 };
@@ -291,7 +292,9 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
     constexpr int TPB = BW / WPT;                             // tiles per workgroup
     const uint32_t nblocks = (a.T + TPB - 1) / TPB;
     const uint32_t per_xcd = (nblocks + 7) >> 3;
-    const uint32_t blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    // a decomposed rank's tile range is owned bricks (long lists) and halo shells (short lists) in spatial order: a
+    // contiguous eighth per XCD would leave whole XCDs with halo tiles only, so there the tiles go round-robin
+    const uint32_t blk = a.xcd_interleave ? blockIdx.x : (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (blk >= nblocks) return;                               // whole workgroup
     const int tib = wave / WPT;                               // tile within the workgroup
     const int part = wave % WPT;                              // which share of the tile's chunks
@@ -606,6 +609,10 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
     a.posq = h->d.posq; a.lj = h->d.lj; a.counts = h->d.list_counts; a.entry_off = h->d.entry_off;
     a.mchunk_off = h->d.mchunk_off; a.entries = h->d.entries; a.masks = h->d.masks;
     a.force = h->d.force; a.energy = h->d.energy; a.slot_flags = h->d.slot_flags; a.gate = d_gate; a.thr_bits = thr_bits;
+    {
+        static const int xcd_env = [] { const char* e = std::getenv("MDX_XCD_INTERLEAVE"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+        a.xcd_interleave = xcd_env >= 0 ? (uint32_t)xcd_env : ((h->have_local_bounds && h->n_local != h->N) ? 1u : 0u);
+    }
     // dual list: only force calls of the step loop (nb_step >= 0) use the inner masks; everything else - energies, the
     // minimiser, the first evaluation after a rebuild - walks the plain list, which is always valid
     a.inner = (h->dual_on && !h->alch_on && !energy && h->nb_step >= 0 && d_gate != nullptr) ? 1u : 0u;
