@@ -3,8 +3,9 @@
 // `MdState::step` with `Integrator::VerletVelocity` (/root/reference README.md:237,
 // src/ui/panels/md.rs:303-305) as kick(dt/2) - drift(dt) - [forces] - kick(dt/2); inside a
 // multi-step burst the closing half kick of step n and the opening half kick of step n+1 are one
-// pass (mode 1), so a step streams x, v, f once: R posq+vel+force+ref (64 B), W posq+vel (32 B)
-// per slot, one slot per lane, 16-B accesses.  Pure HBM streaming.
+// pass (mode 1), so a step streams x, v, f once: R posq+vel+force+ref (64 B), W posq+vel (32 B) + the cleared
+// force (16 B) + - dual pair list - ref with the path accumulator (16 B) per slot, one slot per lane, 16-B accesses.
+// Pure HBM streaming.
 //
 // The same pass measures each atom's squared displacement from its position at the last
 // neighbour rebuild; a wave whose maximum exceeds (skin/2)^2 raises ctl.disp2[step+1] with an

@@ -16,13 +16,18 @@
 //       from both sides, one owner per force component, no atomics, bitwise reproducible.
 //   nb_tile_kernel                       nb_variant 1: lane = i-atom, j broadcast from LDS, branch-free; the A/B
 //       baseline the cluster kernels are measured against.
+// The step loop runs the half-list kernel over a DUAL pair list (DUAL template argument): most
+// steps walk the inner list (cluster pairs with an atom pair within cutoff + inner_skin at the last pruning pass), and
+// when the drift pass reports a path length above inner_skin/2 the same kernel walks the Verlet list and rebuilds the
+// inner list on the side.  Energies, the minimiser and single points always walk the Verlet list.
 // Common to all (gfx950, wave64):
 //   * the tile's list is consumed in chunks of 8 entries = 64 j-atoms: lane l fetches j-atom l of the chunk
 //     (8 x 128-B contiguous cluster records of posq + 8 x 64 B of lj: coalesced), adds the periodic image shift
 //     once, and parks it in the wave's private LDS strip (no workgroup barrier in the loop); entries of chunk c+2,
 //     atoms and exclusion masks of chunk c+1 are in flight while chunk c is evaluated.
-//   * ~30 VALU ops per in-range pair behind an exec-masked early-out (9 ops for a cluster pair with no lane inside
-//     the cutoff); exclusions/self pairs only in the first n_masked entries of a tile, which carry per-lane masks.
+//   * 29 VALU ops per in-range pair behind an exec-masked early-out (8 ops for a cluster pair with no lane inside
+//     the cutoff); exclusions/self pairs only in the first n_masked entries of a tile, which carry per-lane masks
+//     (an excluded lane's bit enters r^2 as a NaN addend and fails the cutoff test by itself).
 //   * blockIdx is remapped so that each XCD walks one contiguous eighth of the tile range and its private L2 sees
 //     a compact spatial region.
 // No MFMA: this is pairwise scalar work.  Roofline: fp32 VALU bound (with the PMC numbers).
