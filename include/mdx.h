@@ -290,6 +290,15 @@ int mdx_initialize_velocities(mdx_handle* h, float temperature, int zero_com_dri
  * coordinates are scaled about box_lo by mu = cbrt(1 - compressibility (Dt/tau) (P0 - P)) (|mu - 1| capped
  * at 1 %), the pair list is rebuilt and constrained clusters are re-projected.  Periodic systems on one
  * device only; compressibility <= 0 selects water's 4.5e-5 / bar. */
+/* `md.shrink_cell_towards(dev, target_cell, ShrinkingBoxCfg{box_shrink_per_step, ..}) -> bool`
+ * [ref: src/properties/sol_shrinking_box.rs:990, called once per MD step of the packing run].  Every edge of the
+ * cell shrinks by shrink_per_step Å but not below the target's edge, the cell keeps its centre (the rule the
+ * reference states at sol_shrinking_box.rs:765-774); coordinates follow affinely about the centre, velocities are
+ * untouched, the spatial caches are rebuilt by the next step and constrained clusters re-projected.  *shrank_out
+ * (may be NULL) = 1 when any edge changed.  MDX_EPARAM (state untouched) when an edge would drop below
+ * 2 (cutoff + skin).  Fully periodic, single-device handles. */
+int mdx_shrink_cell_towards(mdx_handle* h, const float target_lo[3], const float target_hi[3], float shrink_per_step,
+                            int* shrank_out);
 /* md.cell read-back: the current box (changes under the barostat). */
 int mdx_get_box(const mdx_handle* h, float lo[3], float hi[3]);
 int mdx_set_barostat(mdx_handle* h, int kind, float pressure_target_bar, float tau_ps, float compressibility_per_bar,

@@ -121,6 +121,12 @@ public:
         return b;
     }
     void rebuild_spatial_caches() { check(mdx_rebuild_spatial_caches(h_)); }
+    /// `md.shrink_cell_towards(dev, target_cell, cfg) -> bool` (src/properties/sol_shrinking_box.rs:990).
+    bool shrink_cell_towards(const SimBox& target, float box_shrink_per_step) {
+        int shrank = 0;
+        check(mdx_shrink_cell_towards(h_, target.bounds_low.data(), target.bounds_high.data(), box_shrink_per_step, &shrank));
+        return shrank != 0;
+    }
 
     /// `md.minimize_energy(dev, iters, external_forces)` (src/ui/mol_editor.rs:375; src/mol_alignment.rs:356).
     /// Returns the final energies; `iters_done` receives the force evaluations used.

@@ -181,6 +181,50 @@ static int apply_barostat(mdx_handle* h, double dt_couple) {
     return MDX_OK;
 }
 
+// `md.shrink_cell_towards(dev, target_cell, ShrinkingBoxCfg{box_shrink_per_step, ..})`
+// (/root/reference src/properties/sol_shrinking_box.rs:990, once per MD step of the packing run).  The crate is absent;
+// the rule is the one the reference states for its other backend (sol_shrinking_box.rs:765-774, shrink_cell_by_amount):
+// every edge shrinks by `shrink_per_step` but not below the target's, the cell keeps its centre; coordinates follow
+// affinely (what GROMACS' `deform` does to them in that backend, :1263-1275).  Returns whether any edge changed.
+__global__ void scale_positions_about_kernel(uint32_t N, float4* __restrict__ pos, float cx, float cy, float cz,
+                                             float mx, float my, float mz) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float4 p = pos[i];
+    p.x = cx + mx * (p.x - cx); p.y = cy + my * (p.y - cy); p.z = cz + mz * (p.z - cz);
+    pos[i] = p;
+}
+
+extern "C" int mdx_shrink_cell_towards(mdx_handle* h, const float target_lo[3], const float target_hi[3],
+                                       float shrink_per_step, int* shrank_out) {
+    if (!h || !target_lo || !target_hi) FAIL(MDX_EPARAM, "null argument");
+    if (!h->periodic || !(h->per[0] && h->per[1] && h->per[2])) FAIL(MDX_EPARAM, "shrink_cell_towards needs a fully periodic box");
+    if (h->n_local != h->N) FAIL(MDX_EPARAM, "shrink_cell_towards is not supported on a decomposed handle");
+    if (!(shrink_per_step >= 0.f) || !std::isfinite(shrink_per_step)) FAIL(MDX_EPARAM, "shrink_per_step must be >= 0");
+    float lo[3], hi[3], c[3], mu[3];
+    bool shrank = false;
+    for (int d = 0; d < 3; ++d) {
+        const float e = h->box_hi[d] - h->box_lo[d], te = target_hi[d] - target_lo[d];
+        if (!(te > 0.f) || !std::isfinite(te)) FAIL(MDX_EPARAM, "target cell must have positive finite edges");
+        const float ne = std::max(e - shrink_per_step, te);
+        c[d] = 0.5f * (h->box_lo[d] + h->box_hi[d]);
+        lo[d] = c[d] - 0.5f * ne; hi[d] = c[d] + 0.5f * ne;
+        mu[d] = ne / e;
+        shrank |= ne != e;
+    }
+    if (shrank_out) *shrank_out = shrank ? 1 : 0;
+    if (!shrank) return MDX_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    MDX_TRY(mdx_check_box(h, lo, hi));   // refuse BEFORE touching the state (an edge below 2 (rc + skin))
+    MDX_TRY(mdx_unsort_state(h));
+    hipLaunchKernelGGL(scale_positions_about_kernel, dim3(div_up(h->n_local, 256)), dim3(256), 0, h->stream, h->n_local,
+                       h->d.pos_orig, c[0], c[1], c[2], mu[0], mu[1], mu[2]);
+    HIP_TRY(hipGetLastError());
+    MDX_TRY(mdx_set_box(h, lo, hi));
+    if (h->n_groups) h->cons_dirty = true;   // constrained bonds were scaled too: project back
+    return MDX_OK;
+}
+
 static int take_snapshot(mdx_handle* h) {
     mdx_handle::Snapshot sn;
     sn.time = h->time_ps; sn.step = h->step_count;

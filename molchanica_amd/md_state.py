@@ -75,6 +75,7 @@ def load_library():
     lib.mdx_download.argtypes = [H, C.c_int, _fp]
     lib.mdx_upload.argtypes = [H, C.c_int, _fp]
     lib.mdx_set_box.argtypes = [H, C.c_float * 3, C.c_float * 3]
+    lib.mdx_shrink_cell_towards.argtypes = [H, C.c_float * 3, C.c_float * 3, C.c_float, C.POINTER(C.c_int)]
     lib.mdx_rebuild_spatial_caches.argtypes = [H]
     lib.mdx_step_count.argtypes = [H]
     lib.mdx_step_count.restype = C.c_uint64
@@ -217,6 +218,13 @@ class MdState:
         """`md.cell = SimBox::new(lo, hi)` (sol_shrinking_box.rs:600-603)."""
         _check(load_library().mdx_set_box(self._h, (C.c_float * 3)(*map(float, lo)),
                                           (C.c_float * 3)(*map(float, hi))))
+
+    def shrink_cell_towards(self, target_lo, target_hi, shrink_per_step: float) -> bool:
+        """`md.shrink_cell_towards(dev, target_cell, cfg) -> bool` (src/properties/sol_shrinking_box.rs:990)."""
+        lo = (C.c_float * 3)(*[float(v) for v in target_lo]); hi = (C.c_float * 3)(*[float(v) for v in target_hi])
+        out = C.c_int(0)
+        _check(load_library().mdx_shrink_cell_towards(self._h, lo, hi, float(shrink_per_step), C.byref(out)))
+        return bool(out.value)
 
     def rebuild_spatial_caches(self):
         _check(load_library().mdx_rebuild_spatial_caches(self._h))

@@ -274,3 +274,19 @@ def set_alchemical(lo: int, hi: int, lam: float):
     """Couple atoms [lo, hi) to the rest with factor (1 - lam) on their mutual non-bonded pairs; lam < 0 = off.
     Energies then carry "cross" (unscaled U_cross): dU/dlambda = -cross."""
     lib().orc_set_alchemical(C.c_uint32(int(lo)), C.c_uint32(int(hi)), C.c_double(float(lam)))
+
+
+def shrink_cell_towards(box_lo, box_hi, target_lo, target_hi, shrink_per_step, pos):
+    """`md.shrink_cell_towards` as the reference states the rule for its GROMACS backend
+    (/root/reference src/properties/sol_shrinking_box.rs:765-774 `shrink_cell_by_amount`: every edge shrinks by the amount
+    but not below the limit's, the cell keeps its centre) with the coordinates following affinely (its `deform`,
+    :1263-1275).  fp32 cell arithmetic like the engine's SimBox; -> (lo, hi, pos, shrank)."""
+    lo = np.asarray(box_lo, np.float32); hi = np.asarray(box_hi, np.float32)
+    e = hi - lo
+    te = np.asarray(target_hi, np.float32) - np.asarray(target_lo, np.float32)
+    ne = np.maximum(e - np.float32(shrink_per_step), te).astype(np.float32)
+    c = (np.float32(0.5) * (lo + hi)).astype(np.float32)
+    nlo = (c - np.float32(0.5) * ne).astype(np.float32); nhi = (c + np.float32(0.5) * ne).astype(np.float32)
+    mu = (ne / e).astype(np.float32)
+    x = np.asarray(pos, np.float64)
+    return nlo, nhi, c.astype(np.float64) + mu.astype(np.float64) * (x - c.astype(np.float64)), bool((ne != e).any())

@@ -130,3 +130,43 @@ def test_snapshots_cadence_and_contents(mdx):
         md.set_snapshot_cadence(0)
         md.step(0.0005, None, 10)
         assert md.snapshots == []
+
+
+def test_shrink_cell_towards_matches_the_oracle(mdx, orc):
+    """`md.shrink_cell_towards(dev, target, cfg)` + `md.step(dev, DT, None)` per iteration, as the packing loop of
+    src/properties/sol_shrinking_box.rs:989-995 does: cell, coordinates and the trajectory follow the oracle's."""
+    s = systems.water_box(9, seed=41)                                   # 2187 atoms, 27.9 A box
+    cfg = MdConfig(lj_cutoff=8.0, coulomb_cutoff=8.0, skin=1.0, coulomb_mode=1)
+    lo0, hi0 = np.asarray(s.box_lo, np.float64), np.asarray(s.box_hi, np.float64)
+    c = 0.5 * (lo0 + hi0)
+    tlo, thi = c - 13.0, c + 13.0                                       # 26 A target cube
+    dt, shrink = 0.0005, 0.05
+    with mdx.MdState(s, cfg) as md:
+        x, v = md.positions().astype(np.float64), md.velocities().astype(np.float64)
+        lo, hi = lo0.copy(), hi0.copy()
+        sys_o = s
+        for it in range(12):
+            shrank = md.shrink_cell_towards(tlo, thi, shrink)
+            lo, hi, x, shrank_o = orc.shrink_cell_towards(lo, hi, tlo, thi, shrink, x)
+            assert shrank == shrank_o == True
+            md.step(dt, None, 1)
+            import dataclasses
+            sys_o = dataclasses.replace(s, box_lo=tuple(float(a) for a in lo), box_hi=tuple(float(a) for a in hi))
+            x, v, _ = orc.step(sys_o, cfg, dt, 1, pos=x, vel=v)
+        blo, bhi = md.cell()
+        assert np.allclose(blo, lo, atol=1e-4) and np.allclose(bhi, hi, atol=1e-4)
+        assert np.allclose(np.asarray(bhi) - np.asarray(blo), (hi0 - lo0) - 12 * shrink, atol=1e-3)
+        L = np.asarray(hi, np.float64) - np.asarray(lo, np.float64)
+        d = md.positions().astype(np.float64) - x
+        d -= np.round(d / L) * L
+        assert math.sqrt((d ** 2).sum(1).mean()) < 1e-3
+        # at the target the call reports "did not shrink" and leaves the state alone
+        for _ in range(40):
+            md.shrink_cell_towards(tlo, thi, 0.5)
+        assert md.shrink_cell_towards(tlo, thi, 0.5) is False
+        blo, bhi = md.cell()
+        assert np.allclose(np.asarray(bhi) - np.asarray(blo), 26.0, atol=1e-3)
+        # an edge below 2 (cutoff + skin) is refused with the state untouched
+        with pytest.raises(mdx.ParamError):
+            md.shrink_cell_towards(c - 5.0, c + 5.0, 20.0)
+        assert np.allclose(np.asarray(md.cell()[1]) - np.asarray(md.cell()[0]), 26.0, atol=1e-3)

@@ -147,3 +147,18 @@ def test_shake_projects_along_old_bonds_and_respects_static_atoms(orc):
     s.flags = np.array([1, 0], np.uint8)
     x, _, _ = orc.constrain_positions(s, x_old, x_old)
     assert np.array_equal(x[0], [0, 0, 0]) and x[1, 0] == pytest.approx(1.0, abs=1e-10)
+
+
+def test_shrink_cell_rule(orc):
+    """K: the cell rule of sol_shrinking_box.rs:765-774 - edges shrink by the amount, stop at the target's, centre kept;
+    coordinates follow affinely (the centre is a fixed point, the faces map onto the new faces)."""
+    lo, hi = np.array([0.0, 1.0, -2.0]), np.array([30.0, 21.0, 8.0])
+    tlo, thi = np.array([5.0, 5.0, 0.0]), np.array([25.0, 24.9, 9.9])        # target edges 20, 19.9, 9.9
+    pos = np.array([[15.0, 11.0, 3.0], [0.0, 1.0, -2.0], [30.0, 21.0, 8.0]])
+    nlo, nhi, x, shrank = orc.shrink_cell_towards(lo, hi, tlo, thi, 0.5, pos)
+    assert shrank
+    assert np.allclose(nhi - nlo, [29.5, 19.9, 9.9], atol=1e-5)              # y stops at the target edge, z likewise
+    assert np.allclose(0.5 * (nlo + nhi), 0.5 * (lo + hi), atol=1e-5)
+    assert np.allclose(x[0], pos[0], atol=1e-5) and np.allclose(x[1], nlo, atol=1e-4) and np.allclose(x[2], nhi, atol=1e-4)
+    nlo2, nhi2, _, shrank2 = orc.shrink_cell_towards(tlo, thi, tlo, thi, 0.5, pos)
+    assert not shrank2 and np.allclose(nlo2, tlo) and np.allclose(nhi2, thi)
