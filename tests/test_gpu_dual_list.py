@@ -112,3 +112,23 @@ def test_full_size_box(mdx):
         st = md.stats()
         assert st["prune_passes"] > 4 + st["rebuild_count"]
         assert st["n_inner_cluster_pairs"] < 0.85 * st["n_cluster_pairs"]
+
+
+@pytest.mark.parametrize("geometric", [False, True])
+def test_solvated_chain_with_exclusions_and_14_pairs(mdx, geometric):
+    """A bonded chain in water: the masked run of the list (exclusions, 1-4 pairs, self pairs) stays in place in the
+    inner list while the plain run is compacted; both combining rules."""
+    s = systems.small_solvated(n_chain=400, box=44.0)
+    cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=2.0, coulomb_mode=1, inner_skin=0.4,
+                   combining_rule=1 if geometric else 0)
+    with mdx.MdState(s, cfg) as md:
+        md.minimize_energy(40)
+        md.initialize_velocities(500.0, True, seed=3)
+        for burst in (2, 9, 16, 33):
+            md.step(0.0005, None, burst)
+            f_inner = md.forces().astype(np.float64)
+            md.energy()
+            assert _force_err(f_inner, md.forces().astype(np.float64)) < 1.0, f"burst {burst}"
+        st = md.stats()
+        assert st["prune_passes"] >= 4 and st["n_masked_entries"] > 0
+        assert 0 < st["n_inner_cluster_pairs"] < st["n_cluster_pairs"]
