@@ -21,7 +21,7 @@ class FrozenComm:
 
 worlds = [int(sys.argv[1])] if len(sys.argv) > 1 else [1, 2, 4, 8]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-s = systems.water1m()
+s = systems.water1m() if "ONE_RANK_NSIDE" not in os.environ else systems.water_box(int(os.environ["ONE_RANK_NSIDE"]))   # a small box shows the host-side floor per step
 if os.environ.get("ONE_RANK_HOT", "0") != "1":      # same untimed preparation as bench.py: relaxed, 300 K
     import numpy as np
     from molchanica_amd.md_state import MdState
