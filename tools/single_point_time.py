@@ -1,0 +1,23 @@
+"""Latency of the stateless scorer `compute_energy_snapshot` (/root/reference src/md/mod.rs:1036; the docking energy path,
+src/docking/mod.rs:235) on BASELINE.json's complex50k, and of a resident handle's repeated `energy()` calls."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from molchanica_amd import systems, MdConfig
+from molchanica_amd.md_state import MdState, compute_energy_snapshot
+for name in ("complex50k", "dhfr23k"):
+    s = systems.BY_NAME[name]()
+    cfg = MdConfig()
+    compute_energy_snapshot(s, cfg)          # warm-up (module load, first kernel launches)
+    t = time.perf_counter(); n = 5
+    for _ in range(n): e = compute_energy_snapshot(s, cfg)
+    sp = (time.perf_counter() - t) / n
+    with MdState(s, cfg) as md:
+        md.energy()
+        t = time.perf_counter(); m = 50
+        for _ in range(m): md.energy()
+        en = (time.perf_counter() - t) / m
+        t = time.perf_counter()
+        for _ in range(m): md.set_positions(s.pos); md.energy()
+        up = (time.perf_counter() - t) / m
+    print("%s (%d atoms): compute_energy_snapshot %.2f ms (create + upload + list build + energy + destroy) | resident handle: energy() %.3f ms, "
+          "set_positions + energy() %.2f ms (new pose: upload + list rebuild + energy) | E_pot %.1f" % (name, s.n_atoms, 1e3 * sp, 1e3 * en, 1e3 * up, e["potential"]))
