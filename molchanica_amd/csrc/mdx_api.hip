@@ -140,7 +140,7 @@ static void free_device(mdx_handle* h) {
                     d.slot_flags, d.cell_of,
                     d.cell_count, d.cell_start, d.cell_cursor, d.sorted_orig, d.col_tiles, d.tile_start,
                     d.tile_col, d.scan_tmp, d.cl_lo, d.cl_hi, d.list_counts, d.entry_cnt, d.entry_off,
-                    d.mchunk_cnt, d.mchunk_off, d.entries, d.entries_in, d.inner_nch, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
+                    d.mchunk_cnt, d.mchunk_off, d.entries, d.entries_in, d.inner_nch, d.list_cursors, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
                     d.role_off_s, d.role_rec_s, d.ctl, d.energy,
                     d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.cons_o, d.cons_s, d.cons_vir, d.vsite_o, d.vsite_s, d.pme_q, d.pme_f,
                     d.pme_theta};

@@ -360,6 +360,7 @@ __global__ void role_fill_kernel(uint32_t S, const uint32_t* __restrict__ orig_o
 constexpr int LB_WAVES = 4;
 constexpr int LB_HASH = 1024;
 constexpr int LB_MAXFLAG = 512;
+constexpr int LB_PLAIN = 512;   // single-pass build: plain entries of a tile buffered in LDS before its slice of the list is claimed
 
 __device__ __forceinline__ uint32_t hash_u32(uint32_t k) { return (k * 2654435761u) >> 22; }  // 10 bits
 
@@ -403,8 +404,10 @@ struct ListArgs {
     const uint32_t* excl_off; const uint32_t* excl_idx;
     // count pass out
     ListCounts* counts; uint32_t* entry_cnt; uint32_t* mchunk_cnt;
-    // fill pass in/out
-    const uint32_t* entry_off; const uint32_t* mchunk_off;
+    // fill pass in/out (the single-pass build writes them: a tile claims its slice with two atomics)
+    uint32_t* entry_off; uint32_t* mchunk_off;
+    uint32_t* cursors;               // single pass: [0] entries claimed so far, [1] masked chunks claimed so far
+    uint32_t cap_entries, cap_mchunks;
     uint2* entries; unsigned long long* masks;
     uint32_t* err;
     uint32_t null_cluster;
@@ -415,11 +418,21 @@ struct ListArgs {
     const float4* posq;              // slot-space coordinates, for the exact test of borderline cluster pairs
 };
 
-template <bool FILL>
+// MODE 0: count pass (sizes per tile, then a scan); MODE 1: fill pass; MODE 2: SINGLE pass - the tile's entries are
+// buffered in LDS while its neighbourhood is searched ONCE, then the wave claims its slice of the entry array and of the
+// mask array with two atomics and writes everything out.  Tiles land in completion order, which nothing depends on
+// (every consumer addresses a tile's list by entry_off[t] and its counts).  A tile that does not fit the LDS buffers, or
+// a list that outgrows the arrays, raises an error bit and the host falls back to count + fill (with larger arrays).
+enum { LB_COUNT = 0, LB_FILL = 1, LB_SINGLE = 2 };
+template <int MODE>
 __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
+    constexpr bool FILL = MODE != LB_COUNT;        // entries are produced (to memory, or to LDS first)
+    constexpr bool SINGLE = MODE == LB_SINGLE;
     __shared__ uint32_t s_hash[LB_WAVES][LB_HASH];
     __shared__ uint32_t s_fl[LB_WAVES][LB_MAXFLAG];
     __shared__ float s_ibb[LB_WAVES][MDX_CL_PER_TILE][6];
+    __shared__ uint2 s_plain[SINGLE ? LB_WAVES : 1][SINGLE ? LB_PLAIN : 1];
+    __shared__ uint8_t s_mimask[SINGLE ? LB_WAVES : 1][SINGLE ? LB_MAXFLAG : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t t = blockIdx.x * LB_WAVES + wave;
     if (t >= a.T) return;
@@ -431,8 +444,9 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     // in a half list it still owns its share of the pairs with tiles that do hold owned atoms
     const bool tile_owned = __any((a.slot_flags[t * MDX_TILE + lane] & 2u) != 0);
     if (!tile_owned && !a.half) {
-        if (!FILL && lane == 0) {
-            a.counts[t].n_masked = 0; a.counts[t].n_plain = 0; a.entry_cnt[t] = 0; a.mchunk_cnt[t] = 0;
+        if (MODE != LB_FILL && lane == 0) {
+            a.counts[t].n_masked = 0; a.counts[t].n_plain = 0;
+            if (SINGLE) { a.entry_off[t] = 0; a.mchunk_off[t] = 0; } else { a.entry_cnt[t] = 0; a.mchunk_cnt[t] = 0; }
         }
         return;
     }
@@ -474,7 +488,7 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     const float r = a.r_build, r2 = r * r;
     uint32_t nm = 0, np = 0, npairs = 0;
     uint32_t ebase = 0, nm_pad_total = 0;
-    if (FILL) { ebase = a.entry_off[t]; nm_pad_total = a.counts[t].n_masked; }
+    if (MODE == LB_FILL) { ebase = a.entry_off[t]; nm_pad_total = a.counts[t].n_masked; }
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
     int ix0, ix1, iy0, iy1, kz0 = 0, kz1 = 0;
@@ -574,25 +588,28 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
                         const uint2 ent = make_uint2(jc, code | (imask << 8));
                         if (flagged) {
                             uint32_t k = nm + __popcll(bm & lt_mask);
-                            a.entries[ebase + k] = ent;
-                            if (k < LB_MAXFLAG) fl[k] = jc | (code << 27);
+                            if (!SINGLE) a.entries[ebase + k] = ent;
+                            if (k < LB_MAXFLAG) { fl[k] = jc | (code << 27); if (SINGLE) s_mimask[wave][k] = (uint8_t)imask; }
                         } else if (pass) {
                             uint32_t k = np + __popcll(bp & lt_mask);
-                            a.entries[ebase + nm_pad_total + k] = ent;
+                            if (!SINGLE) a.entries[ebase + nm_pad_total + k] = ent;
+                            else if (k < LB_PLAIN) s_plain[wave][k] = ent;
                         }
                     }
                     nm += __popcll(bm);
                     np += __popcll(bp);
-                    if (!FILL && pass) npairs += __popc(imask);
+                    if (MODE != LB_FILL && pass) npairs += __popc(imask);
                 }
             }
         }
     }
     const uint32_t nm_pad = (nm + 7) & ~7u, np_pad = (np + 7) & ~7u;
-    if (nm > LB_MAXFLAG) atomicOr(a.err, 2u);
-    if (!FILL) {
+    if (nm > LB_MAXFLAG) atomicOr(a.err, SINGLE ? 16u : 2u);
+    if (MODE != LB_FILL) {
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) npairs += __shfl_xor(npairs, m);
+    }
+    if (MODE == LB_COUNT) {
         if (lane == 0) {
             atomicAdd(a.pair_count, (unsigned long long)npairs);
             a.counts[t].n_masked = nm_pad;
@@ -601,6 +618,35 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
             a.mchunk_cnt[t] = nm_pad >> 3;
         }
         return;
+    }
+    uint32_t mbase = 0;
+    if (SINGLE) {
+        // claim this tile's slice of the entry array and of the mask array, then drain the LDS buffers into it
+        bool fits = nm <= LB_MAXFLAG && np <= LB_PLAIN;
+        if (!fits) atomicOr(a.err, 16u);
+        uint32_t eb_claim = 0, mb_claim = 0;
+        if (lane == 0 && fits) {
+            eb_claim = atomicAdd(a.cursors, nm_pad + np_pad);
+            mb_claim = atomicAdd(a.cursors + 1, nm_pad >> 3);
+        }
+        ebase = __shfl(eb_claim, 0); mbase = __shfl(mb_claim, 0);
+        if (fits && (ebase + nm_pad + np_pad > a.cap_entries || mbase + (nm_pad >> 3) > a.cap_mchunks)) {
+            atomicOr(a.err, 32u);      // the host reads the cursors, grows the arrays and repeats
+            fits = false;
+        }
+        if (lane == 0) {
+            a.counts[t].n_masked = fits ? nm_pad : 0u;
+            a.counts[t].n_plain = fits ? np_pad : 0u;
+            a.entry_off[t] = fits ? ebase : 0u;
+            a.mchunk_off[t] = fits ? mbase : 0u;
+            if (fits) atomicAdd(a.pair_count, (unsigned long long)npairs);
+        }
+        if (!fits) return;
+        nm_pad_total = nm_pad;
+        WAVE_LDS_SYNC();
+        for (uint32_t k = lane; k < nm; k += 64)
+            a.entries[ebase + k] = make_uint2(fl[k] & 0x7FFFFFFu, (fl[k] >> 27) | ((uint32_t)s_mimask[wave][k] << 8));
+        for (uint32_t k = lane; k < np; k += 64) a.entries[ebase + nm_pad_total + k] = s_plain[wave][k];
     }
     // pad both runs with null entries
     const uint2 null_ent = make_uint2(a.null_cluster, 13u);
@@ -611,7 +657,7 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     // interaction masks of the masked run: bit (8*e + jj) of lane i <=> i interacts with atom jj
     // of the chunk's e-th entry.
     const uint32_t nmc = min(nm, (uint32_t)LB_MAXFLAG);
-    const uint32_t mbase = a.mchunk_off[t];
+    if (!SINGLE) mbase = a.mchunk_off[t];
     for (uint32_t c = 0; c < (nm_pad >> 3); ++c) {
         unsigned long long m = 0ull;
         uint32_t jcs[8], codes13 = 0;
@@ -754,7 +800,7 @@ __device__ __forceinline__ float r2_canonical(float4 pi, float4 pj, const float*
 
 template <bool FILL>
 __global__ __launch_bounds__(256) void extract_neighbors_kernel(
-    uint32_t T, GridParams g, float rl2, int half, const uint32_t* __restrict__ entry_off,
+    uint32_t T, GridParams g, float rl2, int half, const uint32_t* __restrict__ entry_off, const ListCounts* __restrict__ counts,
     const uint2* __restrict__ entries, const uint32_t* __restrict__ orig_of, const float4* __restrict__ ref,
     uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, uint32_t* __restrict__ cursor,
     uint32_t* __restrict__ idx) {
@@ -766,7 +812,8 @@ __global__ __launch_bounds__(256) void extract_neighbors_kernel(
     const float4 pi = ref[slot];
     uint32_t k = 0;
     uint32_t* row = (FILL && !half && oi != MDX_INVALID) ? idx + off[oi] : nullptr;
-    for (uint32_t e = entry_off[t]; e < entry_off[t + 1]; ++e) {
+    const uint32_t e_end = entry_off[t] + counts[t].n_masked + counts[t].n_plain;   // (tiles are not stored in tile order)
+    for (uint32_t e = entry_off[t]; e < e_end; ++e) {
         const uint32_t jc = entries[e].x;
         for (int jj = 0; jj < MDX_CLUSTER; ++jj) {
             const uint32_t js = jc * MDX_CLUSTER + jj;
@@ -962,14 +1009,40 @@ int mdx_rebuild(mdx_handle* h) {
     a.posq = d.posq;
     if (!d.pair_count) ALLOC(d.pair_count, 2);
     a.pair_count = d.pair_count;
+    uint32_t E = 0, MC = 0;
+    unsigned long long npairs = 0;
+    // Single pass when the arrays of the previous build are there to be reused (every rebuild but the first): one
+    // search of every tile's neighbourhood instead of count + scan + fill.  MDX_LIST_TWO_PASS=1 keeps the two passes.
+    static const bool two_pass_env = [] { const char* e = std::getenv("MDX_LIST_TWO_PASS"); return e && e[0] == '1'; }();
+    bool built = false;
+    if (d.entries && d.masks && h->cap_entries && h->cap_mchunks && T && !two_pass_env) {
+        if (!d.list_cursors) ALLOC(d.list_cursors, 2);
+        HIP_TRY(hipMemsetAsync(d.pair_count, 0, sizeof(unsigned long long) * 2, st));
+        HIP_TRY(hipMemsetAsync(d.list_cursors, 0, sizeof(uint32_t) * 2, st));
+        a.cursors = d.list_cursors;
+        a.cap_entries = (uint32_t)std::min<uint64_t>(h->cap_entries, 0xFFFFFFFFull); a.cap_mchunks = h->cap_mchunks;
+        hipLaunchKernelGGL(build_list_kernel<LB_SINGLE>, dim3(div_up(T, LB_WAVES)), dim3(LB_WAVES * 64), 0, st, a);
+        uint32_t cur[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(&npairs, d.pair_count, sizeof(npairs), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(cur, d.list_cursors, sizeof(cur), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(flags, d.flags_dev, sizeof(flags), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (flags[0] & 1u) { mdx_set_error("exclusion table overflow while building the pair list"); return MDX_EPARAM; }
+        if (flags[0] & (16u | 32u)) {
+            // a tile beyond the LDS buffers, or a list that outgrew the arrays: count + fill below sizes them afresh
+            HIP_TRY(hipMemsetAsync(d.flags_dev, 0, sizeof(uint32_t), st));
+        } else {
+            E = cur[0]; MC = cur[1]; built = true;
+            h->E = E; h->MC = MC;
+        }
+    }
+    if (!built) {
     HIP_TRY(hipMemsetAsync(d.pair_count, 0, sizeof(unsigned long long) * 2, st));
     HIP_TRY(hipMemsetAsync(d.entry_cnt + T, 0, sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(d.mchunk_cnt + T, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL(build_list_kernel<false>, dim3(div_up(T, LB_WAVES)), dim3(LB_WAVES * 64), 0, st, a);
+    hipLaunchKernelGGL(build_list_kernel<LB_COUNT>, dim3(div_up(T, LB_WAVES)), dim3(LB_WAVES * 64), 0, st, a);
     MDX_TRY(mdx_exclusive_scan_u32(h, d.entry_cnt, d.entry_off, T + 1));
     MDX_TRY(mdx_exclusive_scan_u32(h, d.mchunk_cnt, d.mchunk_off, T + 1));
-    uint32_t E = 0, MC = 0;
-    unsigned long long npairs = 0;
     HIP_TRY(hipMemcpyAsync(&npairs, d.pair_count, sizeof(npairs), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&E, d.entry_off + T, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&MC, d.mchunk_off + T, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -988,7 +1061,8 @@ int mdx_rebuild(mdx_handle* h) {
         a.masks = d.masks;
     }
     h->E = E; h->MC = MC;
-    hipLaunchKernelGGL(build_list_kernel<true>, dim3(div_up(T, LB_WAVES)), dim3(LB_WAVES * 64), 0, st, a);
+    hipLaunchKernelGGL(build_list_kernel<LB_FILL>, dim3(div_up(T, LB_WAVES)), dim3(LB_WAVES * 64), 0, st, a);
+    }
     const bool prune = !std::isinf(h->r_list) && mdx_nb_variant(h) >= 2;   // the whole-tile kernel ignores imask
     if (prune && T) {
         const float rb = a.r_build;
@@ -1059,7 +1133,7 @@ int mdx_extract_neighbors(mdx_handle* h, uint32_t* offsets, uint32_t* idx) {
     HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * ((size_t)N + 1), st));
     HIP_TRY(hipMemsetAsync(d_cur, 0, sizeof(uint32_t) * ((size_t)N + 1), st));
     hipLaunchKernelGGL(extract_neighbors_kernel<false>, dim3(div_up(T, 4)), dim3(256), 0, st, T, h->grid, rl2, half,
-                       d.entry_off, d.entries, d.orig_of, d.ref, d_cnt, d_off, d_cur, d_idx);
+                       d.entry_off, d.list_counts, d.entries, d.orig_of, d.ref, d_cnt, d_off, d_cur, d_idx);
     int rc = mdx_exclusive_scan_u32(h, d_cnt, d_off, N + 1);
     if (rc != MDX_OK) { (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_cur); return rc; }
     std::vector<uint32_t> off(N + 1);
@@ -1069,7 +1143,7 @@ int mdx_extract_neighbors(mdx_handle* h, uint32_t* offsets, uint32_t* idx) {
     std::vector<uint32_t> raw(total ? total : 1);
     HIP_TRY(hipMalloc((void**)&d_idx, sizeof(uint32_t) * (total ? total : 1)));
     hipLaunchKernelGGL(extract_neighbors_kernel<true>, dim3(div_up(T, 4)), dim3(256), 0, st, T, h->grid, rl2, half,
-                       d.entry_off, d.entries, d.orig_of, d.ref, d_cnt, d_off, d_cur, d_idx);
+                       d.entry_off, d.list_counts, d.entries, d.orig_of, d.ref, d_cnt, d_off, d_cur, d_idx);
     HIP_TRY(hipMemcpyAsync(raw.data(), d_idx, sizeof(uint32_t) * total, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_idx); (void)hipFree(d_cur);

@@ -173,6 +173,33 @@ def test_neighbor_list_bit_exact(mdx, orc, which):
     assert idx.size > 0
 
 
+@pytest.mark.parametrize("variant", [5, 2])
+def test_neighbor_list_bit_exact_after_a_rebuild(mdx, orc, variant):
+    """Every list build but a handle's first is the SINGLE-pass build (tiles claim their slice of the entry array with
+    atomics, in completion order): same list, bit for bit, for the half list and for the full list; forces unchanged."""
+    s, cfg = systems.dhfr23k(), MdConfig(nb_variant=variant)
+    with mdx.MdState(s, cfg) as md:
+        f0 = md.forces().astype(np.float64)
+        md.rebuild_spatial_caches()                       # second build of this handle
+        pos = md.positions()
+        off, idx = md.neighbor_list()
+        f1 = md.forces().astype(np.float64)
+        md.step(0.0005, None, 60)                         # and a few more under way
+        pos2 = md.positions()
+        md.rebuild_spatial_caches()
+        off2, idx2 = md.neighbor_list()
+    r = max(cfg.lj_cutoff, cfg.coulomb_cutoff) + cfg.skin
+    ooff, oidx = orc.neighbor_list(s, r, pos=pos, use_cells=True)
+    assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+    ooff2, oidx2 = orc.neighbor_list(s, r, pos=pos2, use_cells=True)
+    assert np.array_equal(off2, ooff2) and np.array_equal(idx2, oidx2)
+    tol = 1e-4 * np.maximum(np.linalg.norm(f0, axis=1), 1.0) + 1e-5 * np.sqrt((f0 ** 2).sum(1).mean())
+    if variant == 2:
+        assert np.array_equal(f1, f0), "the full list is bitwise reproducible whatever order its tiles are stored in"
+    else:
+        assert (np.linalg.norm(f1 - f0, axis=1) <= tol).all()
+
+
 # ---- configs[1]: DHFR-sized, cutoff LJ + Coulomb ------------------------------------------------------
 def test_c2_dhfr23k_forces_and_energies(mdx, orc):
     check_single_point(mdx, orc, systems.dhfr23k(), MdConfig(), "dhfr23k", use_cells=True)
