@@ -1,0 +1,87 @@
+"""Geometry edge cases of the periodic hot path on the GPU, each against the oracle AND through the step loop:
+a strongly orthorhombic cell, the smallest cell the list radius allows (an atom sees neighbours through several faces),
+and a sparse cell (most tiles of the column grid empty).  The reference states only the minimum-image rule
+(/root/reference src/md/mod.rs:278-296, src/cuda/util.cu:65-71); these are the places where a cell/tile list can lose or
+double a pair."""
+import math
+
+import numpy as np
+import pytest
+
+from molchanica_amd import MdConfig, MdSystem, systems
+from tests.test_gpu_parity import assert_energies, assert_forces
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mdx():
+    from molchanica_amd import md_state
+    assert md_state.device_count() >= 1
+    return md_state
+
+
+def _waters_in_cell(n_waters, box, seed):
+    """n_waters flexible TIP3P molecules at random non-overlapping sites of an orthorhombic cell."""
+    rng = np.random.default_rng(seed)
+    base = systems.water_box(max(2, int(math.ceil(n_waters ** (1 / 3))) + 1), seed=seed)
+    keep = 3 * n_waters
+    box = np.asarray(box, np.float64)
+    # oxygen sites: a random subset of a 3.1 A lattice that fills the cell, jittered by 0.1 A
+    g = np.maximum((box / 3.1).astype(int), 1)
+    grid = np.stack(np.meshgrid(*[(np.arange(k) + 0.5) * (box[d] / k) for d, k in enumerate(g)], indexing="ij"), -1).reshape(-1, 3)
+    assert len(grid) >= n_waters
+    sites = grid[rng.permutation(len(grid))[:n_waters]] + rng.normal(0.0, 0.1, (n_waters, 3))
+    pos = base.pos[:keep].astype(np.float64).reshape(n_waters, 3, 3)
+    pos = pos - pos[:, :1, :] + np.asarray(sites)[:, None, :]
+    off = np.asarray(base.excl_offsets)[: keep + 1]
+    return MdSystem(pos=pos.reshape(-1, 3).astype(np.float32), mass=base.mass[:keep], charge=base.charge[:keep],
+                    lj_type=base.lj_type[:keep], lj_sigma=base.lj_sigma, lj_eps=base.lj_eps, vel=base.vel[:keep],
+                    bond_idx=base.bond_idx[: 2 * n_waters], bond_k=base.bond_k[: 2 * n_waters], bond_r0=base.bond_r0[: 2 * n_waters],
+                    angle_idx=base.angle_idx[:n_waters], angle_k=base.angle_k[:n_waters], angle_theta0=base.angle_theta0[:n_waters],
+                    excl_offsets=off, excl_idx=np.asarray(base.excl_idx)[: off[-1]], mol_start=3 * np.arange(n_waters),
+                    periodic=True, box_lo=(0, 0, 0), box_hi=tuple(float(b) for b in box)).normalise()
+
+
+CASES = {
+    # name: (waters, cell, cutoff, skin)
+    "orthorhombic 21 x 44 x 90": (2300, (21.0, 44.0, 90.0), 8.0, 1.5),
+    "smallest cell for the list radius": (200, (19.2, 19.4, 19.6), 8.0, 1.5),      # 2 (rc + skin) = 19.0
+    "sparse: 40 waters in 70 A": (40, (70.0, 70.0, 70.0), 10.0, 2.0),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_single_point_and_step_loop(mdx, orc, name):
+    nw, box, rc, skin = CASES[name]
+    s = _waters_in_cell(nw, box, seed=len(name))
+    cfg = MdConfig(lj_cutoff=rc, coulomb_cutoff=rc, skin=skin, coulomb_mode=1)
+    with mdx.MdState(s, cfg) as md:
+        pos = md.positions()
+        f, e = md.forces(), md.energy()
+        fo, eo = orc.forces(s, cfg, pos=pos.astype(np.float64), use_cells=False)
+        assert_forces(f, fo, orc.cutoff_slack(s, cfg, pos=pos), name)
+        assert_energies(e, eo, s.n_atoms * 200, name)
+        # neighbour list of this geometry, bit for bit (brute-force oracle)
+        off, idx = md.neighbor_list()
+        ooff, oidx = orc.neighbor_list(s, rc + skin, pos=pos, use_cells=False)
+        assert np.array_equal(off, ooff) and np.array_equal(idx, oidx), name
+        # 60 steps through the step loop (rebuilds, the dual pair list), then the forces it left behind against a fresh
+        # plain-list evaluation and against the oracle at the same positions
+        md.minimize_energy(30)
+        md.initialize_velocities(400.0, True, seed=2)
+        md.step(0.0005, None, 60)
+        f_loop = md.forces().astype(np.float64)
+        md.energy()
+        f_plain = md.forces().astype(np.float64)
+        scale = 1e-4 * np.maximum(np.linalg.norm(f_plain, axis=1), 1.0) + 1e-5 * math.sqrt((f_plain ** 2).sum(1).mean())
+        assert (np.linalg.norm(f_loop - f_plain, axis=1) <= scale).all(), name
+        assert md.stats()["rebuild_count"] >= 2
+        # Against the oracle at the SAME fp32 coordinates: between rebuilds an atom that left the cell is kept unwrapped
+        # on the device, and the wrapped copy a download returns differs from it by an ulp of the cell edge - 4e-6 A, which
+        # the 553 kcal/mol/A^2 bonds of flexible water turn into 4e-3 kcal/mol/A.  A rebuild wraps the device state too.
+        md.rebuild_spatial_caches()
+        pos2 = md.positions()
+        md.energy()
+        fo2, _ = orc.forces(s, cfg, pos=pos2.astype(np.float64), use_cells=False)
+        assert_forces(md.forces(), fo2, orc.cutoff_slack(s, cfg, pos=pos2), name + " after 60 steps")
