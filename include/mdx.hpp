@@ -219,6 +219,9 @@ inline mdx_energies compute_energy_snapshot(const mdx_system& system, const mdx_
     return e;
 }
 
+/// Frees the device state the scorer keeps between poses of the same molecules (mdx_single_point_release).
+inline void release_single_point_cache() { mdx_single_point_release(); }
+
 /// `run_dynamics_blocking` (src/md/mod.rs:696-724): n steps in one go.
 inline void run_dynamics_blocking(MdState& md, uint32_t n_steps, float dt) { md.step(dt, nullptr, n_steps); }
 

@@ -374,6 +374,13 @@ def run_dynamics_blocking(md: MdState, dt: float, n_steps: int):
     md.step(dt, None, n_steps)
 
 
+def release_single_point_cache():
+    """Frees the device state `compute_energy_snapshot` keeps between calls (mdx_single_point_release)."""
+    lib = load_library()
+    lib.mdx_single_point_release.restype = None
+    lib.mdx_single_point_release()
+
+
 def compute_energy_snapshot(system: MdSystem, cfg: MdConfig | None = None, device: int = 0,
                             with_forces: bool = False):
     """`dynamics::compute_energy_snapshot` (src/md/mod.rs:1036): stateless single-point scorer.

@@ -317,6 +317,41 @@ def test_single_point_scorer(mdx, orc):
         assert e[k] == pytest.approx(eo[k], rel=1e-5, abs=1e-3)
 
 
+def test_single_point_scorer_pose_after_pose(mdx, orc):
+    """The docking loop scores pose after pose of the same molecules (src/docking/mod.rs:235): the scorer keeps its device
+    state between calls and uploads only the coordinates.  Every pose must score exactly like a fresh build; a different
+    molecule set, a different config or a different box is a fresh build by itself."""
+    s = systems.small_solvated()
+    cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, nb_variant=2)      # the full-list kernel: no atomics
+    close = lambda a, b: abs(a - b) <= 1e-3 + 1e-6 * abs(b)   # (slot order, hence summation order, is per build)
+    rng = np.random.default_rng(7)
+    base = s.pos.copy()
+    mdx.release_single_point_cache()
+    for pose in range(4):
+        s.pos = (base + rng.normal(0.0, 0.02 * pose, base.shape)).astype(np.float32)
+        e, f = mdx.compute_energy_snapshot(s, cfg, with_forces=True)             # pose 0 builds, 1-3 reuse
+        with mdx.MdState(s, cfg) as md:
+            f_fresh, e_fresh = md.forces(), md.energy()
+        df = np.linalg.norm(f.astype(np.float64) - f_fresh, axis=1)
+        assert (df <= 2e-5 * np.maximum(np.linalg.norm(f_fresh, axis=1), 1.0)).all(), f"pose {pose}: forces differ from a fresh build"
+        for k in ("potential", "lj", "coulomb", "bond", "angle", "dihedral"):
+            assert close(e[k], e_fresh[k]), (pose, k, e[k], e_fresh[k])
+    # a different config, then a different system, then back: each scored like a fresh build
+    cfg2 = MdConfig(lj_cutoff=8.0, coulomb_cutoff=8.0, skin=1.5, nb_variant=2)
+    e2 = mdx.compute_energy_snapshot(s, cfg2)
+    with mdx.MdState(s, cfg2) as md:
+        assert close(e2["potential"], md.energy()["potential"])
+    lig = systems.lig50()
+    e3 = mdx.compute_energy_snapshot(lig, MdConfig(**NOCUT))
+    _, eo = orc.forces(lig, MdConfig(**NOCUT))
+    assert abs(e3["potential"] - eo["potential"]) < 1e-3 + 2e-6 * abs(eo["potential"]) * 50
+    e4 = mdx.compute_energy_snapshot(s, cfg)
+    with mdx.MdState(s, cfg) as md:
+        assert close(e4["potential"], md.energy()["potential"])
+    mdx.release_single_point_cache()
+    mdx.release_single_point_cache()      # idempotent
+
+
 def test_error_behaviour(mdx):
     s = systems.water_box(4)             # 12.4 Å box: shorter than 2*(rc+skin)
     with pytest.raises(mdx.ParamError, match="minimum image"):

@@ -19,5 +19,5 @@ for name in ("complex50k", "dhfr23k"):
         t = time.perf_counter()
         for _ in range(m): md.set_positions(s.pos); md.energy()
         up = (time.perf_counter() - t) / m
-    print("%s (%d atoms): compute_energy_snapshot %.2f ms (create + upload + list build + energy + destroy) | resident handle: energy() %.3f ms, "
+    print("%s (%d atoms): compute_energy_snapshot %.2f ms (per pose; a first call or a new molecule set also builds the device state) | resident handle: energy() %.3f ms, "
           "set_positions + energy() %.2f ms (new pose: upload + list rebuild + energy) | E_pot %.1f" % (name, s.n_atoms, 1e3 * sp, 1e3 * en, 1e3 * up, e["potential"]))
