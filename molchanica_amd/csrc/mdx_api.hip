@@ -142,7 +142,7 @@ static void free_device(mdx_handle* h) {
                     d.tile_col, d.scan_tmp, d.cl_lo, d.cl_hi, d.list_counts, d.entry_cnt, d.entry_off,
                     d.mchunk_cnt, d.mchunk_off, d.entries, d.entries_in, d.inner_nch, d.list_cursors, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
                     d.role_off_s, d.role_rec_s, d.ctl, d.energy,
-                    d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.cons_o, d.cons_s, d.cons_vir, d.vsite_o, d.vsite_s, d.pme_q, d.pme_f,
+                    d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.pme_force, d.cons_o, d.cons_s, d.cons_vir, d.vsite_o, d.vsite_s, d.pme_q, d.pme_f,
                     d.pme_theta};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = DeviceState{};
@@ -350,9 +350,14 @@ static uint32_t stale_threshold_bits(const mdx_handle* h) {
 
 static int compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint32_t thr) {
     MDX_TRY(mdx_launch_vsite_construct(h, gate, thr));     // massless sites follow their parents
+    if (h->pme_on && h->pme_overlap) {                     // SPME reciprocal space on its side stream, beside the pair kernel
+        MDX_TRY(mdx_pme_fork(h));
+        MDX_TRY(mdx_launch_pme(h, energy, gate, thr));
+    }
     MDX_TRY(mdx_launch_nonbonded(h, energy, gate, thr));
     MDX_TRY(mdx_launch_bonded(h, energy, gate, thr));
-    MDX_TRY(mdx_launch_pme(h, energy, gate, thr));         // SPME reciprocal space (hipFFT), if requested
+    if (h->pme_on && h->pme_overlap) MDX_TRY(mdx_pme_join(h, gate, thr));
+    else MDX_TRY(mdx_launch_pme(h, energy, gate, thr));    // SPME reciprocal space (hipFFT), if requested
     MDX_TRY(mdx_launch_vsite_spread(h, gate, thr));        // ... and hand their force back to them
     MDX_TRY(mdx_launch_add_ext(h, gate, thr));
     return MDX_OK;

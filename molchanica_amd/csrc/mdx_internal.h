@@ -159,6 +159,7 @@ struct DeviceState {
     RoleRec*  role_rec_s = nullptr;                                  // [R]
     // SPME (mdx_pme.hip)
     float* pme_q = nullptr; float2* pme_f = nullptr; float* pme_theta = nullptr;
+    float4* pme_force = nullptr;   // [S] reciprocal-space force when the chain runs on its side stream
     // constraints and virtual sites
     ConsGroup* cons_o = nullptr; ConsGroup* cons_s = nullptr;
     float* cons_vir = nullptr;     // per constraint cluster: r . G of the last SHAKE position stage (kcal/mol)
@@ -192,6 +193,7 @@ struct mdx_handle {
     bool vsites_convex = true;                         // every virtual site lies inside the triangle of its parents
     // SPME
     bool pme_on = false; int pme_K[3] = {0, 0, 0}; void* pme_plan = nullptr;  // opaque PmePlan
+    bool pme_overlap = false; hipStream_t stream_pme = nullptr; hipEvent_t ev_pme_fork = nullptr, ev_pme_join = nullptr;
     double ewald_self = 0.0, ewald_background = 0.0; double total_charge = 0.0, sum_q2 = 0.0;
     uint32_t n_mobile = 0;
     double total_mass = 0.0;
@@ -301,6 +303,8 @@ int mdx_launch_vsite_spread(mdx_handle* h, const uint32_t* d_gate, uint32_t thr)
 int mdx_pme_setup(mdx_handle* h);                      // plans, mesh, theta table (again after set_box)
 void mdx_pme_destroy(mdx_handle* h);
 int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr);
+int mdx_pme_fork(mdx_handle* h);                                             // side stream starts behind the handle's stream
+int mdx_pme_join(mdx_handle* h, const uint32_t* d_gate, uint32_t thr);       // ... and hands its force back
 
 // shared between mdx_api.hip and mdx_extras.hip
 int mdx_compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint32_t thr);

@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256) void pme_solve_kernel(size_t n, int K1, int K2
     }
 }
 
+template <bool SEPARATE>
 __global__ __launch_bounds__(256) void pme_gather_kernel(uint32_t S, const float4* __restrict__ posq,
                                                          const uint8_t* __restrict__ slot_flags, PmeDev g,
                                                          const float* __restrict__ phi, float4* __restrict__ force,
@@ -232,9 +233,11 @@ __global__ __launch_bounds__(256) void pme_gather_kernel(uint32_t S, const float
     if (gate && *gate > thr) return;
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
-    if (!(slot_flags[s] & 1u)) return;
     const float4 p = posq[s];
-    if (p.w == 0.f) return;
+    if (!(slot_flags[s] & 1u) || p.w == 0.f) {
+        if (SEPARATE) force[s] = make_float4(0.f, 0.f, 0.f, 0.f);   // nothing to add for this slot
+        return;
+    }
     int k0[3]; float w[3];
     mesh_coords(p, g, k0, w);
     float mx[4], my[4], mz[4], dx[4], dy[4], dz[4];
@@ -258,8 +261,21 @@ __global__ __launch_bounds__(256) void pme_gather_kernel(uint32_t S, const float
             fz += mx[a] * my[b] * s1;
         }
     }
-    float4 f = force[s];
+    // SEPARATE: the reciprocal force goes to its own array (the chain runs on a side stream beside the pair and bonded
+    // kernels, which are busy with `force`); the caller adds it once both streams have met again
+    float4 f = SEPARATE ? make_float4(0.f, 0.f, 0.f, 0.f) : force[s];
     f.x -= p.w * fx * g.scale[0]; f.y -= p.w * fy * g.scale[1]; f.z -= p.w * fz * g.scale[2];
+    force[s] = f;
+}
+
+__global__ __launch_bounds__(256) void pme_add_force_kernel(uint32_t S, float4* __restrict__ force, const float4* __restrict__ add,
+                                                            const uint32_t* gate, uint32_t thr) {
+    if (gate && *gate > thr) return;
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    float4 f = force[s];
+    const float4 a = add[s];
+    f.x += a.x; f.y += a.y; f.z += a.z;
     force[s] = f;
 }
 
@@ -284,6 +300,12 @@ static std::vector<double> bspline_moduli4(int K) {
 }
 
 void mdx_pme_destroy(mdx_handle* h) {
+    if (h->stream_pme) {
+        (void)hipStreamSynchronize(h->stream_pme);
+        (void)hipEventDestroy(h->ev_pme_fork); (void)hipEventDestroy(h->ev_pme_join);
+        (void)hipStreamDestroy(h->stream_pme);
+        h->stream_pme = nullptr;
+    }
     PmePlan* p = (PmePlan*)h->pme_plan;
     if (!p) return;
     if (p->have_plans) { p->destroy(p->fwd); p->destroy(p->inv); }
@@ -334,7 +356,17 @@ int mdx_pme_setup(mdx_handle* h) {
         if (p->plan3d(&p->fwd, K[0], K[1], K[2], HIPFFT_R2C) != HIPFFT_SUCCESS ||
             p->plan3d(&p->inv, K[0], K[1], K[2], HIPFFT_C2R) != HIPFFT_SUCCESS)
             FAIL(MDX_EDEVICE, "hipfftPlan3d failed");
-        p->set_stream(p->fwd, h->stream); p->set_stream(p->inv, h->stream);
+        {   // side stream of the reciprocal-space chain (MDX_PME_OVERLAP=0: everything on the handle's stream)
+            static const bool off = [] { const char* e = std::getenv("MDX_PME_OVERLAP"); return e && e[0] == '0'; }();
+            h->pme_overlap = !off;
+            if (h->pme_overlap && !h->stream_pme) {
+                HIP_TRY(hipStreamCreateWithFlags(&h->stream_pme, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&h->ev_pme_fork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&h->ev_pme_join, hipEventDisableTiming));
+            }
+        }
+        hipStream_t fst = h->pme_overlap ? h->stream_pme : h->stream;
+        p->set_stream(p->fwd, fst); p->set_stream(p->inv, fst);
         p->have_plans = true;
         for (void** q : {(void**)&h->d.pme_q, (void**)&h->d.pme_f, (void**)&h->d.pme_theta})
             if (*q) { (void)hipFree(*q); *q = nullptr; }
@@ -372,10 +404,29 @@ int mdx_pme_setup(mdx_handle* h) {
     return MDX_OK;
 }
 
+// With h->pme_overlap the whole chain (spread, FFT, solve, FFT, gather) runs on a SIDE stream, forked before the pair
+// kernel and joined after the bonded gather (mdx_pme_fork / mdx_pme_join around them in compute_forces): the pair kernel
+// is VALU-bound, this chain is atomics- and bandwidth-bound.  The gather then writes to pme_force, added at the join.
+int mdx_pme_fork(mdx_handle* h) {
+    if (!h->pme_on || !h->pme_overlap) return MDX_OK;
+    HIP_TRY(hipEventRecord(h->ev_pme_fork, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->stream_pme, h->ev_pme_fork, 0));
+    return MDX_OK;
+}
+int mdx_pme_join(mdx_handle* h, const uint32_t* d_gate, uint32_t thr) {
+    if (!h->pme_on || !h->pme_overlap) return MDX_OK;
+    HIP_TRY(hipEventRecord(h->ev_pme_join, h->stream_pme));
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_pme_join, 0));
+    hipLaunchKernelGGL(pme_add_force_kernel, dim3(div_up(h->S, 256)), dim3(256), 0, h->stream, h->S, h->d.force,
+                       h->d.pme_force, d_gate, thr);
+    HIP_TRY(hipGetLastError());
+    return MDX_OK;
+}
+
 int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr) {
     if (!h->pme_on) return MDX_OK;
     PmePlan* p = (PmePlan*)h->pme_plan;
-    hipStream_t st = h->stream;
+    hipStream_t st = h->pme_overlap ? h->stream_pme : h->stream;
     const int K3h = h->pme_K[2] / 2 + 1;
     HIP_TRY(hipMemsetAsync(h->d.pme_q, 0, sizeof(float) * p->n_real, st));
     static const bool per_atom_spread = [] { const char* e = std::getenv("MDX_PME_SPREAD_PER_ATOM"); return e && e[0] == '1'; }();
@@ -394,8 +445,12 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
     else hipLaunchKernelGGL(pme_solve_kernel<false>, gs, dim3(256), 0, st, p->n_cplx, h->pme_K[0], h->pme_K[1], K3h,
                             h->pme_K[2], inv_len, pb, h->d.pme_f, h->d.pme_theta, h->d.energy, d_gate, thr);
     if (p->exec_c2r(p->inv, (hipfftComplex*)h->d.pme_f, h->d.pme_q) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecC2R failed");
-    hipLaunchKernelGGL(pme_gather_kernel, dim3(div_up(h->S, 256)), dim3(256), 0, st, h->S, h->d.posq, h->d.slot_flags,
-                       p->dev, h->d.pme_q, h->d.force, d_gate, thr);
+    if (h->pme_overlap)
+        hipLaunchKernelGGL(pme_gather_kernel<true>, dim3(div_up(h->S, 256)), dim3(256), 0, st, h->S, h->d.posq, h->d.slot_flags,
+                           p->dev, h->d.pme_q, h->d.pme_force, d_gate, thr);
+    else
+        hipLaunchKernelGGL(pme_gather_kernel<false>, dim3(div_up(h->S, 256)), dim3(256), 0, st, h->S, h->d.posq, h->d.slot_flags,
+                           p->dev, h->d.pme_q, h->d.force, d_gate, thr);
     HIP_TRY(hipGetLastError());
     return MDX_OK;
 }
