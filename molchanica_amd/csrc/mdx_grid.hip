@@ -1101,8 +1101,8 @@ int mdx_rebuild(mdx_handle* h) {
     // the step loop feeds its path accumulator: the drift pass, SHAKE, and - for the ghosts of a decomposed handle - the
     // halo unpack; a virtual site inside the triangle of its parents never moves further than they do (anything else
     // keeps the plain list)
-    h->inner_skin = c_inner_skin(h->cfg);
-    h->dual_on = mdx_nb_half(h) && prune && h->inner_skin > 0.f && h->inner_skin < h->cfg.skin &&
+    h->inner_skin = h->inner_skin_auto > 0.f ? h->inner_skin_auto : c_inner_skin(h->cfg);
+    h->dual_on = !h->dual_auto_off && mdx_nb_half(h) && prune && h->inner_skin > 0.f && h->inner_skin < h->cfg.skin &&
                  (h->n_vsites == 0 || h->vsites_convex);
     h->prune_pending = true;
     if (!d.inner_count) { ALLOC(d.inner_count, MDX_EPART + 1); HIP_TRY(hipMemsetAsync(d.inner_count, 0, sizeof(unsigned long long) * (MDX_EPART + 1), st)); }

@@ -215,6 +215,8 @@ struct mdx_handle {
     // dual pair list (rolling pruning inside the pair kernel)
     bool dual_on = false;        // this handle's step loop walks the inner masks
     float inner_skin = 0.f;
+    // self-tuning of the library-default buffer (cfg.inner_skin == 0): pruning passes per step over a window of steps
+    float inner_skin_auto = 0.f; bool dual_auto_off = false; uint32_t dual_win_steps = 0, dual_win_prunes = 0;
     bool prune_pending = true;   // the next step-loop force call must prune (after a rebuild / at the start of mdx_step)
     int nb_step = -1;            // chunk step of the force call being enqueued (-1: not from the step loop -> outer masks)
     int chunk_s = -1;            // decomposed driver: chunk step whose drift has been enqueued (its prune word is shared by the halo unpack)
