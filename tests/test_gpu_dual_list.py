@@ -132,3 +132,20 @@ def test_solvated_chain_with_exclusions_and_14_pairs(mdx, geometric):
         st = md.stats()
         assert st["prune_passes"] >= 4 and st["n_masked_entries"] > 0
         assert 0 < st["n_inner_cluster_pairs"] < st["n_cluster_pairs"]
+
+
+def test_default_buffer_tunes_itself_at_long_steps(mdx):
+    """dt = 2 fs moves atoms four times as far per step: a fixed 0.5 A buffer would prune every other step and lose to
+    the plain list.  The library-default buffer grows (or the handle returns to the plain list) until pruning passes are
+    rare enough to pay; results stay those of the plain list throughout."""
+    s = systems.water_box(12, seed=36, rigid=True, temp=330.0)
+    with mdx.MdState(s, MdConfig(lj_cutoff=8.0, coulomb_cutoff=8.0, skin=2.0, coulomb_mode=1)) as md:   # inner_skin = 0: default
+        md.step(0.002, None, 500)
+        p0 = md.stats()["prune_passes"]
+        for _ in range(4):
+            md.step(0.002, None, 50)
+            f_inner = md.forces().astype(np.float64)
+            md.energy()
+            assert _force_err(f_inner, md.forces().astype(np.float64)) < 1.0
+        p1 = md.stats()["prune_passes"]
+        assert (p1 - p0) / 200.0 < 0.5, "the dual list is still pruning on most steps"
