@@ -215,12 +215,19 @@ int mdx_single_point(const mdx_system* sys, const mdx_config* cfg, int device,
 /* The scorer is called pose after pose on the same molecules [ref: src/docking/mod.rs:235]: the calling thread keeps the
  * device state of its last mdx_single_point call, and a call whose system has the same static content (everything but
  * pos / vel / box, compared by a fingerprint of the arrays) and the same config only uploads the new coordinates
- * (complex50k: 8.8 ms -> ~1.5 ms per pose).  Results are those of a fresh build.  This frees the kept state. */
+ * that changed since the last pose (mdx_upload_range: the Verlet list survives small ligand moves).  Results are
+ * those of a fresh build.  This frees the kept state; a thread's kept state is also freed when the thread exits. */
 void mdx_single_point_release(void);
 
 /* State read-back / host-side mutation  [ref: md.atoms[i].posit/.force public fields]. */
 int mdx_download(mdx_handle* h, int which, float* dst /* [3N] */);
 int mdx_upload(mdx_handle* h, int which, const float* src /* [3N] */);
+/* The docking loop moves ~50 ligand atoms of a ~50 k-atom complex from pose to pose [ref: src/docking/mod.rs:81-154,
+ * 235]: new values for atoms [first, first + count) only.  For MDX_POS the spatial caches are KEPT while every moved
+ * atom stays within skin/2 of where it was when the Verlet list was built (the same rule the step loop uses); beyond
+ * that the list is rebuilt on next use.  Results are those of a fresh build.  mdx_upload (whole array) always
+ * invalidates the caches, as `md.rebuild_spatial_caches()` after a host-side edit does. */
+int mdx_upload_range(mdx_handle* h, int which, uint32_t first, uint32_t count, const float* src /* [3 count] */);
 
 /* md.cell = SimBox::new(lo,hi) followed by md.rebuild_spatial_caches()
  * [ref: src/properties/sol_shrinking_box.rs:600-603, 632]. */
@@ -282,7 +289,9 @@ int mdx_configure_alchemical_window(mdx_handle* h, uint32_t mol_index, double la
 
 /* Steepest descent with an adaptive maximum displacement (start 0.01 Å; x += h F/|F|max; accepted
  * when the potential energy drops: h *= 1.2, else the move is undone and h *= 0.5); stops after
- * max_iters force evaluations or when max |F| < f_tol; h never exceeds 0.2 Å.  Velocities are left untouched. */
+ * max_iters force evaluations or when max |F| < f_tol; h never exceeds 0.2 Å.  Velocities are left untouched.
+ * With external forces (the alignment pull, src/mol_alignment.rs:356) the accepted quantity is U - sum F_ext . x
+ * (the internal potential minus the work of the external forces along the move), so the molecule follows the pull. */
 int mdx_minimize_energy(mdx_handle* h, uint32_t max_iters, const float* ext_forces_or_null, float f_tol,
                         mdx_energies* final_or_null, uint32_t* iters_done_or_null);
 /* Maxwell-Boltzmann velocities from a counter-based generator (splitmix64 + Box-Muller, three

@@ -143,7 +143,7 @@ static void free_device(mdx_handle* h) {
                     d.mchunk_cnt, d.mchunk_off, d.entries, d.entries_in, d.inner_nch, d.list_cursors, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
                     d.role_off_s, d.role_rec_s, d.ctl, d.energy,
                     d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.pme_force, d.cons_o, d.cons_s, d.cons_vir, d.vsite_o, d.vsite_s, d.pme_q, d.pme_f,
-                    d.pme_theta};
+                    d.pme_theta, d.scratch4};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = DeviceState{};
 }
@@ -629,12 +629,23 @@ static uint64_t system_fingerprint(const mdx_system* s, const mdx_config* c, int
     h = fp_mix(h, s->vsite_idx, 16 * (size_t)s->n_vsites); h = fp_mix(h, s->vsite_w, 8 * (size_t)s->n_vsites);
     return h ? h : 1;
 }
-struct SinglePointCache { mdx_handle* h = nullptr; uint64_t key = 0; ~SinglePointCache() { /* process exit: the runtime may be gone */ } };
+struct SinglePointCache {
+    mdx_handle* h = nullptr; uint64_t key = 0;
+    std::vector<float> pos, vel;      // coordinates / velocities of the last pose (vel empty = none given)
+    // A worker thread that scored poses and exits must not leak its handle (device buffers, stream, FFT plans).  At
+    // process exit the HIP runtime may already be gone: only destroy when it still answers.
+    ~SinglePointCache() {
+        int n = 0;
+        if (h && hipGetDeviceCount(&n) == hipSuccess && n > 0) mdx_destroy(h);
+        h = nullptr;
+    }
+};
 static thread_local SinglePointCache g_sp_cache;
 
 extern "C" void mdx_single_point_release(void) {
     if (g_sp_cache.h) { std::string keep = g_last_error; mdx_destroy(g_sp_cache.h); g_last_error = keep; }
     g_sp_cache.h = nullptr; g_sp_cache.key = 0;
+    g_sp_cache.pos.clear(); g_sp_cache.vel.clear();
 }
 
 extern "C" int mdx_single_point(const mdx_system* sys, const mdx_config* cfg, int device, mdx_energies* out,
@@ -650,16 +661,44 @@ extern "C" int mdx_single_point(const mdx_system* sys, const mdx_config* cfg, in
             for (int d = 0; d < 3; ++d) same &= h->box_lo[d] == sys->box_lo[d] && h->box_hi[d] == sys->box_hi[d];
             if (!same) rc = mdx_set_box(h, sys->box_lo, sys->box_hi);
         }
-        if (rc == MDX_OK) rc = mdx_upload(h, MDX_POS, sys->pos);
+        // Docking moves the ligand, ~50 atoms of ~50 k (src/docking/mod.rs:81-154): only the span of atoms whose
+        // coordinates differ from the last pose travels, and while they stay within skin/2 of where the Verlet list
+        // was built the list is reused (mdx_upload_range) - a pose then costs one energy-flavoured force pass.
+        const size_t n3 = 3 * (size_t)sys->n_atoms;
+        auto changed_span = [&](const float* now, const std::vector<float>& last, uint32_t* first, uint32_t* count) {
+            size_t a = 0, b = n3;
+            while (a < n3 && std::memcmp(&now[a], &last[a], sizeof(float)) == 0) ++a;
+            if (a == n3) { *first = 0; *count = 0; return; }
+            while (b > a && std::memcmp(&now[b - 1], &last[b - 1], sizeof(float)) == 0) --b;
+            *first = (uint32_t)(a / 3); *count = (uint32_t)((b + 2) / 3) - *first;
+        };
+        uint32_t f0 = 0, cnt = 0;
         if (rc == MDX_OK) {
-            if (sys->vel) rc = mdx_upload(h, MDX_VEL, sys->vel);
-            else { std::vector<float> z(3 * (size_t)sys->n_atoms, 0.f); rc = mdx_upload(h, MDX_VEL, z.data()); }
+            changed_span(sys->pos, g_sp_cache.pos, &f0, &cnt);
+            rc = mdx_upload_range(h, MDX_POS, f0, cnt, sys->pos + 3 * (size_t)f0);
+            if (rc == MDX_OK && cnt) std::memcpy(&g_sp_cache.pos[3 * (size_t)f0], sys->pos + 3 * (size_t)f0, sizeof(float) * 3 * cnt);
+        }
+        if (rc == MDX_OK) {
+            if (sys->vel) {
+                if (g_sp_cache.vel.empty()) { f0 = 0; cnt = sys->n_atoms; g_sp_cache.vel.assign(sys->vel, sys->vel + n3); }
+                else {
+                    changed_span(sys->vel, g_sp_cache.vel, &f0, &cnt);
+                    if (cnt) std::memcpy(&g_sp_cache.vel[3 * (size_t)f0], sys->vel + 3 * (size_t)f0, sizeof(float) * 3 * cnt);
+                }
+                rc = mdx_upload_range(h, MDX_VEL, f0, cnt, sys->vel + 3 * (size_t)f0);
+            } else if (!g_sp_cache.vel.empty()) {
+                std::vector<float> z(n3, 0.f);
+                rc = mdx_upload(h, MDX_VEL, z.data());
+                g_sp_cache.vel.clear();
+            }
         }
         if (rc != MDX_OK) { mdx_single_point_release(); return rc; }
     } else {
         mdx_single_point_release();
         MDX_TRY(mdx_create(sys, cfg, device, &h));
         g_sp_cache.h = h; g_sp_cache.key = key;
+        g_sp_cache.pos.assign(sys->pos, sys->pos + 3 * (size_t)sys->n_atoms);
+        if (sys->vel) g_sp_cache.vel.assign(sys->vel, sys->vel + 3 * (size_t)sys->n_atoms);
     }
     int rc = out ? mdx_energy(h, out) : MDX_OK;
     if (rc == MDX_OK && forces_or_null) rc = mdx_download(h, MDX_FORCE, forces_or_null);
@@ -681,18 +720,16 @@ extern "C" int mdx_download(mdx_handle* h, int which, float* dst) {
         src = which == MDX_POS ? h->d.pos_orig : h->d.vel_orig;
     } else if (which == MDX_FORCE) {
         MDX_TRY(ensure_ready(h));
-        // cell_of/sorted_orig are rebuild scratch; borrow pos-sized scratch via a temporary buffer
-        float4* tmp = nullptr;
-        HIP_TRY(hipMalloc((void**)&tmp, sizeof(float4) * N));
-        int rc = mdx_gather_to_orig(h, h->d.force, tmp);
-        std::vector<float4> hf(N);
-        if (rc == MDX_OK) {
-            hipError_t e = hipMemcpyAsync(hf.data(), tmp, sizeof(float4) * N, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
-            if (e != hipSuccess) { (void)hipFree(tmp); FAIL(MDX_EDEVICE, hipGetErrorString(e)); }
+        // caller-order scratch kept with the handle (the scorer reads forces pose after pose: no malloc per call)
+        if (!h->d.scratch4 || h->cap_scratch4 < N) {
+            if (h->d.scratch4) { (void)hipFree(h->d.scratch4); h->d.scratch4 = nullptr; }
+            HIP_TRY(hipMalloc((void**)&h->d.scratch4, sizeof(float4) * (size_t)std::max(N, h->cap_local)));
+            h->cap_scratch4 = std::max(N, h->cap_local);
         }
-        (void)hipFree(tmp);
-        MDX_TRY(rc);
+        MDX_TRY(mdx_gather_to_orig(h, h->d.force, h->d.scratch4));
+        std::vector<float4> hf(N);
+        HIP_TRY(hipMemcpyAsync(hf.data(), h->d.scratch4, sizeof(float4) * N, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
         for (uint32_t i = 0; i < N; ++i) {
             const bool ghost = h->n_local == h->N && (h->flags[i] & MDX_ATOM_GHOST) != 0;
             dst[3 * i] = ghost ? 0.f : hf[i].x; dst[3 * i + 1] = ghost ? 0.f : hf[i].y;
@@ -725,6 +762,80 @@ extern "C" int mdx_upload(mdx_handle* h, int which, const float* src) {
                            hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->list_valid = false; h->forces_valid = false;
+    if (h->n_groups) h->cons_dirty = true;
+    return MDX_OK;
+}
+
+// New coordinates for atoms [first, first + count) while the spatial caches stay: each atom is put at the periodic image
+// nearest to where it was at the last list build, and the largest displacement from there decides (as the drift pass
+// does in the step loop) whether the Verlet list still covers the new pose.
+__global__ __launch_bounds__(256) void pose_update_kernel(uint32_t first, uint32_t count, const float4* __restrict__ src,
+                                                          const uint32_t* __restrict__ slot_of, float4* __restrict__ posq,
+                                                          const float4* __restrict__ ref, float lx, float ly, float lz,
+                                                          uint32_t* __restrict__ flag, uint32_t thr_bits) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    float d2 = 0.f;
+    if (k < count) {
+        const uint32_t s = slot_of[first + k];
+        if (s != MDX_INVALID) {
+            const float4 p = src[k], r = ref[s];
+            float dx = p.x - r.x, dy = p.y - r.y, dz = p.z - r.z;
+            if (lx > 0.f) dx -= rintf(dx / lx) * lx;
+            if (ly > 0.f) dy -= rintf(dy / ly) * ly;
+            if (lz > 0.f) dz -= rintf(dz / lz) * lz;
+            float4 q = posq[s];
+            q.x = r.x + dx; q.y = r.y + dy; q.z = r.z + dz;
+            posq[s] = q;
+            d2 = dx * dx + dy * dy + dz * dz;
+            if (!(d2 < 1.0e30f)) d2 = 3.0e38f;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, m));
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(d2) > thr_bits) atomicMax(flag, __float_as_uint(d2));
+}
+
+extern "C" int mdx_upload_range(mdx_handle* h, int which, uint32_t first, uint32_t count, const float* src) {
+    if (!h || (count && !src)) FAIL(MDX_EPARAM, "null argument");
+    if (which != MDX_POS && which != MDX_VEL) FAIL(MDX_EPARAM, "only MDX_POS and MDX_VEL can be uploaded");
+    if (h->n_local != h->N) FAIL(MDX_EPARAM, "mdx_upload_range on a decomposed handle");
+    if ((uint64_t)first + count > h->N) FAIL(MDX_EPARAM, "atom range out of bounds");
+    if (count == 0) return MDX_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    for (size_t k = 0; k < 3 * (size_t)count; ++k)
+        if (!std::isfinite(src[k])) FAIL(MDX_EPARAM, "non-finite value in upload");
+    hipStream_t st = h->stream;
+    std::vector<float4> b(count);
+    for (uint32_t k = 0; k < count; ++k) {
+        b[k] = make_float4(src[3 * k], src[3 * k + 1], src[3 * k + 2], 0.f);
+        if (which == MDX_VEL && (h->flags[first + k] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST))) b[k] = make_float4(0, 0, 0, 0);
+    }
+    const bool keep_list = which == MDX_POS && h->in_slot_space && h->list_valid && !std::isinf(h->r_list);
+    if (!keep_list) {
+        MDX_TRY(mdx_unsort_state(h));
+        HIP_TRY(hipMemcpyAsync((which == MDX_POS ? h->d.pos_orig : h->d.vel_orig) + first, b.data(), sizeof(float4) * count,
+                               hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        h->list_valid = false; h->forces_valid = false;
+        if (h->n_groups) h->cons_dirty = true;
+        return MDX_OK;
+    }
+    // pose update in slot space: ext_orig is free between steps (mdx_step re-installs it), use its head as the stage
+    if (h->have_ext) FAIL(MDX_EPARAM, "mdx_upload_range while external forces are installed");
+    HIP_TRY(hipMemcpyAsync(h->d.ext_orig + first, b.data(), sizeof(float4) * count, hipMemcpyHostToDevice, st));
+    const uint32_t thr = stale_threshold_bits(h);
+    HIP_TRY(hipMemsetAsync(&h->d.ctl->disp2[0], 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(pose_update_kernel, dim3(div_up(count, 256)), dim3(256), 0, st, first, count, h->d.ext_orig + first,
+                       h->d.slot_of, h->d.posq, h->d.ref, h->per[0] ? h->box_hi[0] - h->box_lo[0] : 0.f,
+                       h->per[1] ? h->box_hi[1] - h->box_lo[1] : 0.f, h->per[2] ? h->box_hi[2] - h->box_lo[2] : 0.f,
+                       &h->d.ctl->disp2[0], thr);
+    uint32_t flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, &h->d.ctl->disp2[0], sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemsetAsync(&h->d.ctl->disp2[0], 0, sizeof(uint32_t), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    h->forces_valid = false;
+    h->prune_pending = true;               // dual list: the path accumulators did not see this move
+    if (flag > thr) h->list_valid = false; // moved further than skin/2 from the list's reference: rebuild on next use
     if (h->n_groups) h->cons_dirty = true;
     return MDX_OK;
 }
@@ -841,6 +952,10 @@ extern "C" int mdx_set_local_atoms(mdx_handle* h, uint32_t n_local, const uint32
     if (n_local == 0 || n_local > h->N) FAIL(MDX_EPARAM, "n_local must be in 1..n_atoms (each atom at most once)");
     if (h->n_groups || h->n_vsites)
         FAIL(MDX_EPARAM, "constraints / virtual sites are not supported on a decomposed handle yet");
+    if (h->pme_on) FAIL(MDX_EPARAM, "the SPME reciprocal sum is not supported on a decomposed handle (each rank would spread only its own charges)");
+    if (h->alch_on) FAIL(MDX_EPARAM, "alchemical windows are not supported on a decomposed handle");
+    if (h->integrator != MDX_INTEGRATOR_VERLET_VELOCITY) FAIL(MDX_EPARAM, "only velocity Verlet is supported on a decomposed handle");
+    if (h->baro_kind) FAIL(MDX_EPARAM, "the barostat is not supported on a decomposed handle");
     HIP_TRY(hipSetDevice(h->device));
     int per[3];
     decode_periodic(periodic, per);

@@ -92,6 +92,30 @@ __global__ __launch_bounds__(256) void min_move_kernel(uint32_t S, float4* __res
     if ((threadIdx.x & 63) == 0 && __float_as_uint(d2) > thr_bits) atomicMax(flag, __float_as_uint(d2));
 }
 
+// Work the external forces do along a trial move: sum_i F_ext,i . (x_i - x_accepted,i), minimum image per periodic
+// dimension (a rebuild between the two may have wrapped an atom).  Caller order on both sides.
+__global__ __launch_bounds__(256) void ext_work_kernel(uint32_t N, const uint32_t* __restrict__ slot_of,
+                                                       const float4* __restrict__ posq, const float4* __restrict__ accepted,
+                                                       const float4* __restrict__ ext, float lx, float ly, float lz,
+                                                       double* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    double w = 0.0;
+    if (i < N) {
+        const uint32_t s = slot_of[i];
+        if (s != MDX_INVALID) {
+            const float4 p = posq[s], a = accepted[i], f = ext[i];
+            float dx = p.x - a.x, dy = p.y - a.y, dz = p.z - a.z;
+            if (lx > 0.f) dx -= rintf(dx / lx) * lx;
+            if (ly > 0.f) dy -= rintf(dy / ly) * ly;
+            if (lz > 0.f) dz -= rintf(dz / lz) * lz;
+            w = (double)f.x * dx + (double)f.y * dy + (double)f.z * dz;
+        }
+    }
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) w += __shfl_xor(w, k);
+    if ((threadIdx.x & 63) == 0 && w != 0.0) atomicAdd(out, w);
+}
+
 int mdx_launch_scale_velocities(mdx_handle* h, float lambda, const double* com) {
     hipLaunchKernelGGL(scale_vel_kernel, dim3(div_up(h->S, 256)), dim3(256), 0, h->stream, h->S, h->d.vel, lambda,
                        com ? (float)com[0] : 0.f, com ? (float)com[1] : 0.f, com ? (float)com[2] : 0.f);
@@ -439,7 +463,20 @@ extern "C" int mdx_minimize_energy(mdx_handle* h, uint32_t max_iters, const floa
         ++it;
         if (rc == MDX_ENAN) { trial.potential = INFINITY; rc = MDX_OK; }
         if (rc != MDX_OK) return done(rc);
-        if (trial.potential < cur.potential) {
+        // With external forces (the alignment pull, src/mol_alignment.rs:356) the quantity that must drop is
+        // U_total = U - sum F_ext . x: a move along the pull raises the internal potential of a relaxed molecule and
+        // would otherwise be refused for ever.  The work is measured from the accepted point, so no origin is needed.
+        double ext_work = 0.0;
+        if (h->have_ext && std::isfinite(trial.potential)) {
+            double* wdev = h->d.energy + EN_COUNT + 1;      // the momentum scratch words
+            if (hipMemsetAsync(wdev, 0, sizeof(double), st) != hipSuccess) return done(MDX_EDEVICE);
+            hipLaunchKernelGGL(ext_work_kernel, dim3(div_up(h->N, 256)), dim3(256), 0, st, h->N, h->d.slot_of, h->d.posq,
+                               backup, h->d.ext_orig, h->per[0] ? h->box_hi[0] - h->box_lo[0] : 0.f,
+                               h->per[1] ? h->box_hi[1] - h->box_lo[1] : 0.f, h->per[2] ? h->box_hi[2] - h->box_lo[2] : 0.f, wdev);
+            if (hipMemcpyAsync(&ext_work, wdev, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) { mdx_set_error("HIP error in minimiser"); return done(MDX_EDEVICE); }
+        }
+        if (trial.potential - ext_work < cur.potential) {
             cur = trial;
             hstep = std::min(hstep * 1.2, MDX_MIN_MAX_STEP);
             rc = mdx_gather_to_orig(h, h->d.posq, backup);

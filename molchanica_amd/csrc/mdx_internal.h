@@ -172,6 +172,7 @@ struct DeviceState {
     unsigned long long* pair_count = nullptr;  // cluster pairs in the list (statistics)
     unsigned long long* inner_count = nullptr; // [MDX_EPART + 1] dual list: kept cluster pairs per pruning pass (spread), passes
     float*   bbox_red = nullptr;   // [6] min/max reduction (vacuum grid)
+    float4*  scratch4 = nullptr;   // [cap_scratch4] caller-order scratch (force read-back)
 };
 
 struct mdx_handle {
@@ -183,6 +184,7 @@ struct mdx_handle {
     bool periodic = false;      // any dimension periodic
     int per[3] = {0, 0, 0};     // per-dimension periodicity
     uint32_t n_local = 0, cap_local = 0;  // atoms simulated by this handle (== N on a single GPU)
+    uint32_t cap_scratch4 = 0;
     float local_lo[3]{}, local_hi[3]{};   // extent of the local region in non-periodic dimensions (decomposed runs)
     bool have_local_bounds = false;
     float box_lo[3]{}, box_hi[3]{};

@@ -74,6 +74,7 @@ def load_library():
                                      C.POINTER(CEnergies), _fp]
     lib.mdx_download.argtypes = [H, C.c_int, _fp]
     lib.mdx_upload.argtypes = [H, C.c_int, _fp]
+    lib.mdx_upload_range.argtypes = [H, C.c_int, C.c_uint32, C.c_uint32, _fp]
     lib.mdx_set_box.argtypes = [H, C.c_float * 3, C.c_float * 3]
     lib.mdx_shrink_cell_towards.argtypes = [H, C.c_float * 3, C.c_float * 3, C.c_float, C.POINTER(C.c_int)]
     lib.mdx_rebuild_spatial_caches.argtypes = [H]
@@ -208,6 +209,12 @@ class MdState:
     def set_positions(self, pos):
         a = np.ascontiguousarray(pos, dtype=np.float32).reshape(self.n_atoms, 3)
         _check(load_library().mdx_upload(self._h, POS, a.ctypes.data_as(_fp)))
+
+    def set_positions_range(self, first: int, pos):
+        """New coordinates for atoms [first, first + len(pos)) - the docking loop's pose update
+        (src/docking/mod.rs:81-154): the Verlet list is kept while the moved atoms stay inside its skin."""
+        a = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
+        _check(load_library().mdx_upload_range(self._h, POS, int(first), a.shape[0], a.ctypes.data_as(_fp)))
 
     def set_velocities(self, vel):
         a = np.ascontiguousarray(vel, dtype=np.float32).reshape(self.n_atoms, 3)

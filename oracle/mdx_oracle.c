@@ -954,6 +954,9 @@ int orc_minimize(const mdx_system* s, const mdx_config* c, double* x, uint32_t m
         ++it;
         double ep = 0, ept = 0;
         for (int k = 0; k < E_KIN; ++k) { ep += en[k]; ept += ent[k]; }
+        /* external forces (the alignment pull, src/mol_alignment.rs:356): what must drop is U - sum F_ext . x, i.e. the
+           internal potential minus the work the external forces do along the trial move */
+        if (ext) for (uint32_t i = 0; i < 3 * N; ++i) ept -= ext[i] * (xt[i] - x[i]);
         if (ept < ep) {
             memcpy(x, xt, sizeof(double) * 3 * N); memcpy(f, ft, sizeof(double) * 3 * N);
             memcpy(en, ent, sizeof(en));

@@ -98,6 +98,36 @@ def test_chain_solute_across_brick_faces(reference):
     assert math.sqrt((d ** 2).sum(1).mean()) < 2e-3
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_c4_dna100k_decomposed_trajectory(world):
+    """BASELINE config 4 (solvated duplex, ~100 k atoms, spatial decomposition): the two strands run along z through
+    the box centre, so the x = 50 (and, at 4 ranks, y = 50) brick faces cut their bonded terms.  Energies of the
+    decomposed start equal the single-GPU ones term by term; 24 steps follow the single-GPU trajectory."""
+    from molchanica_amd.md_state import MdState
+    s = systems.dna100k()
+    cfg = MdConfig(chunk_steps=8)
+    with MdState(s, cfg) as md:
+        e_ref = md.energy()
+        md.step(0.0005, None, 24)
+        p_ref = md.positions().astype(np.float64)
+        e1_ref = md.energy()
+    res = run_ranks(s, cfg, world, 24)
+    e = res[0]["e0"]
+    for k in ("bond", "angle", "dihedral", "lj14", "coulomb14", "lj", "coulomb", "kinetic"):
+        assert abs(e[k] - e_ref[k]) <= max(5e-2, 3e-6 * abs(e_ref[k])), (k, e[k], e_ref[k])
+    L = np.array(s.box_hi, dtype=np.float64)
+    d = res[0]["pos"].astype(np.float64) - p_ref
+    d -= np.round(d / L) * L
+    assert math.sqrt((d ** 2).sum(1).mean()) < 2e-3
+    e1 = res[0]["e1"]
+    assert abs((e1["potential"] + e1["kinetic"]) - (e1_ref["potential"] + e1_ref["kinetic"])) < 2e-4 * s.n_atoms
+    # the strands really are cut: both ranks of an x-split own solute atoms
+    n_sol = int(s.mol_start[2])
+    x = s.pos[:n_sol, 0]
+    assert (x < 50.0).any() and (x >= 50.0).any()
+    assert sum(res[r]["stats"]["n_owned"] for r in range(world)) == s.n_atoms
+
+
 def test_local_rebuilds_between_repartitions():
     """A box large enough for a halo margin: stale lists are first rebuilt locally (owned + ghost
     set unchanged, no host work), ownership migrates only every other time."""

@@ -65,6 +65,27 @@ def test_minimize_with_external_forces_and_static_atoms(mdx, orc):
     assert math.sqrt(((x - xo) ** 2).sum(1).mean()) < 2e-3
 
 
+def test_minimizer_follows_an_external_pull_from_a_relaxed_structure(mdx, orc):
+    """The acceptance energy includes the work of the external forces (src/mol_alignment.rs:356 hands the pulling
+    forces to the minimiser): a relaxed ligand moves with the pull instead of refusing every step."""
+    s = systems.lig50()
+    cfg = MdConfig(**NOCUT)
+    xr, _, _ = orc.minimize(s, cfg, 400, f_tol=0.5)          # relax first (oracle), then pull half of it
+    s.pos = xr.astype(np.float32)
+    ext = np.zeros((50, 3), np.float32)
+    ext[25:, 0] = 4.0; ext[:25, 0] = -4.0
+    with mdx.MdState(s, cfg) as md:
+        e0 = md.energy()["potential"]
+        e, it = md.minimize_energy(60, ext)
+        x = md.positions().astype(np.float64)
+    xo, eo, ito = orc.minimize(s, cfg, 60, ext=ext)
+    work = float((ext * (x - s.pos)).sum())
+    assert work > 0.5, "the molecule did not follow the pull"
+    assert e["potential"] - work < e0, "U - F.x must have dropped"
+    assert e["potential"] == pytest.approx(eo["potential"], rel=5e-3, abs=5e-2)
+    assert math.sqrt(((x - xo) ** 2).sum(1).mean()) < 5e-3
+
+
 def test_initialize_velocities_equals_oracle(mdx, orc):
     s = systems.water_box(6, seed=3)
     with mdx.MdState(s, MdConfig(lj_cutoff=7.0, coulomb_cutoff=7.0, skin=1.5)) as md:

@@ -352,6 +352,77 @@ def test_single_point_scorer_pose_after_pose(mdx, orc):
     mdx.release_single_point_cache()      # idempotent
 
 
+def test_pose_update_keeps_the_verlet_list_while_it_covers_the_move(mdx, orc):
+    """mdx_upload_range: a ligand-sized pose update (src/docking/mod.rs:81-154).  Inside skin/2 of the list's reference
+    positions the list survives (no rebuild) and the forces are the oracle's at the new pose; a larger move, or a jump
+    by a whole box edge plus a small move, is handled too (rebuild on demand / nearest image)."""
+    s = systems.small_solvated()
+    cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5)
+    rng = np.random.default_rng(5)
+    lig = slice(40, 90)
+    L = np.array(s.box_hi) - np.array(s.box_lo)
+    with mdx.MdState(s, cfg) as md:
+        md.forces()
+        p0 = md.positions()
+        rb0 = md.stats()["rebuild_count"]
+        for k, (amp, jump) in enumerate([(0.2, 0.0), (0.3, 1.0), (1.6, 0.0)]):
+            p = p0.copy()
+            u = rng.normal(0, 1, 3); u /= np.linalg.norm(u)
+            p[lig] += (u * amp).astype(np.float32) + np.float32(jump) * L.astype(np.float32)
+            md.set_positions_range(lig.start, p[lig])
+            f, e = md.forces(), md.energy()
+            pw = orc.wrap(s, p)
+            fo, eo = orc.forces(s, cfg, pos=pw.astype(np.float64))
+            assert_forces(f, fo, orc.cutoff_slack(s, cfg, pos=pw), f"pose update {k}")
+            assert_energies(e, eo, s.n_atoms * 200, f"pose update {k}")
+            rb = md.stats()["rebuild_count"]
+            if amp < 0.5 * cfg.skin:
+                assert rb == rb0, "a move inside skin/2 must not rebuild the list"
+            else:
+                assert rb == rb0 + 1, "a move beyond skin/2 must rebuild the list"
+            d = md.positions().astype(np.float64) - pw
+            d -= np.round(d / L) * L
+            assert np.abs(d).max() < 1e-4
+
+
+# ---- configs[2]: protein-ligand complex through the docking scorer, ~51 k atoms -----------------------------
+def test_c3_complex50k_scorer_pose_after_pose(mdx, orc):
+    """BASELINE config 3: `compute_energy_snapshot` (src/md/mod.rs:1036) as the docking loop calls it
+    (src/docking/mod.rs:235) - the same ~51 k-atom complex, pose after pose, only the 50 ligand atoms move.  Pose 0
+    builds the scorer's device state; poses 1-4 ride its pose cache (and, for small ligand moves, its Verlet list).
+    EVERY pose is compared with the oracle: all forces, every energy term."""
+    s = systems.complex50k()
+    cfg = MdConfig()
+    lig = slice(int(s.mol_start[1]), int(s.mol_start[2]))
+    assert lig.stop - lig.start == 50
+    rng = np.random.default_rng(17)
+    base = s.pos.copy()
+    mdx.release_single_point_cache()
+    for pose in range(5):
+        p = base.copy()
+        if pose:   # rigid shift + small rotation about the ligand centroid + per-atom noise; growing with the pose
+            c = p[lig].mean(0)
+            ang = 0.05 * pose
+            rot = np.array([[math.cos(ang), -math.sin(ang), 0], [math.sin(ang), math.cos(ang), 0], [0, 0, 1]])
+            p[lig] = (p[lig] - c) @ rot.T + c + rng.normal(0, 0.15 * pose, 3) + rng.normal(0, 0.01, (50, 3))
+        s.pos = p.astype(np.float32)
+        e, f = mdx.compute_energy_snapshot(s, cfg, with_forces=True)
+        pw = orc.wrap(s, s.pos)
+        fo, eo = orc.forces(s, cfg, pos=pw.astype(np.float64), use_cells=True)
+        assert_forces(f, fo, orc.cutoff_slack(s, cfg, pos=pw), f"complex50k pose {pose}")
+        assert_energies(e, eo, s.n_atoms * 200, f"complex50k pose {pose}")
+        for k in ("potential", "potential_nonbonded", "potential_bonded"):      # src/md/mod.rs:1241-1245
+            assert e[k] == pytest.approx(eo[k], rel=2e-6, abs=0.5)
+    mdx.release_single_point_cache()
+
+
+# ---- configs[3]: solvated DNA-like duplex, ~100 k atoms --------------------------------------------------------
+def test_c4_dna100k_forces_and_energies(mdx, orc):
+    s = systems.dna100k()
+    assert 99_000 < s.n_atoms <= 100_000
+    check_single_point(mdx, orc, s, MdConfig(), "dna100k", use_cells=True)
+
+
 def test_error_behaviour(mdx):
     s = systems.water_box(4)             # 12.4 Å box: shorter than 2*(rc+skin)
     with pytest.raises(mdx.ParamError, match="minimum image"):

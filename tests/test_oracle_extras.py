@@ -94,6 +94,20 @@ def test_minimizer_harmonic_dimer_and_monotone_energy(orc):
     assert np.array_equal(x[:10], s.pos[:10].astype(np.float64))
 
 
+def test_minimizer_follows_an_external_pull_from_a_relaxed_structure(orc):
+    """`md.minimize_energy(dev, iters, Some(forces))` (src/mol_alignment.rs:356): the accepted quantity is
+    U - sum F_ext . x.  A harmonic dimer at rest pulled apart by +-F settles where k-bond force balances the pull:
+    2 k (r - r0) = F  =>  r = r0 + F / (2 k); judged on the internal potential alone every move would be refused."""
+    k, r0, F = 300.0, 1.4, 30.0
+    s = MdSystem(pos=[[0, 0, 0], [r0, 0, 0]], mass=[12, 12], charge=[0, 0], lj_type=[0, 0], lj_sigma=[1.0],
+                 lj_eps=[0.0], bond_idx=[[0, 1]], bond_k=[k], bond_r0=[r0], excl_offsets=[0, 1, 2],
+                 excl_idx=[1, 0]).normalise()
+    ext = np.array([[-F, 0, 0], [F, 0, 0]], np.float64)
+    x, e, it = orc.minimize(s, MdConfig(**NOCUT), 300, f_tol=1e-3, ext=ext)
+    assert np.linalg.norm(x[0] - x[1]) == pytest.approx(r0 + F / (2 * k), abs=1e-4)
+    assert e["bond"] == pytest.approx(k * (F / (2 * k)) ** 2, rel=1e-3) and it < 300
+
+
 # ---- SURVEY §8f rank 1: constraints and virtual sites -------------------------------------------------
 def test_shake_rattle_rigid_water_conserves_energy_at_2fs(orc):
     s = systems.water_box(4, seed=3, rigid=True)
