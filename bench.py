@@ -13,7 +13,11 @@ across the ranks (strong scaling) with ghost-atom halo exchange over RCCL.
 Prints ONE JSON line on rank 0: the contract keys plus
   roofline     — dominant kernel (nb_cluster_kernel): algorithmic bytes (32 B per atom)
                  x atoms per launch / mean launch duration from HIP events on the library's stream
-  cpu_baseline — the CPU oracle (C, OpenMP, all host cores) on a bounded sample of the same box
+  cpu_baseline — oracle/cpu_production.c (fp32, half Verlet list reused across steps, OpenMP over all host cores,
+                 built -O3 -march=native on the machine it runs on) on a bounded sample of the same box
+The driver's command times 20 steps (12 ms: no list rebuild, no energy evaluation falls into it), so after the timed
+region an UNTIMED-for-`value` tail of 1000 steps runs with rebuilds at their natural cadence and energies every 100
+steps; its rate is reported beside `value` as `steps_per_s_1000`.
 """
 from __future__ import annotations
 
@@ -31,8 +35,11 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3
 B_ALG_NONBONDED = 32.0         # R x(12)+q(4)+type(4), W f(12)  per atom per launch
+B_ALG_INTEGRATE = 64.0         # R x,v,f (36) + 1/m (4), W x,v (24)
+B_ALG_BONDED_WATER = 52.0      # 36 + 16 t, t = 1 bonded term per atom in flexible water
 B_ALG_STEP_WATER = 170.0       # whole step, water box
 FLOP_PER_PAIR = 45.0
+NB_KERNEL_REV = "r02a"         # revision tag of the default pair kernel the cached PMC traffic figure belongs to
 
 
 def parse():
@@ -43,7 +50,11 @@ def parse():
     ap.add_argument("--workload", default="water1M", choices=["water1M", "dhfr23k", "complex50k", "dna100k"])
     ap.add_argument("--dt", type=float, default=0.0005)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=10, help="oracle steps of the cpu_baseline leg (about 1.2 s each on the GPU box's 128 cores)")
+    ap.add_argument("--cpu-steps", type=int, default=100, help="steps of the cpu_baseline leg (SURVEY 8d: 100 at the 1 M-atom box)")
+    ap.add_argument("--cpu-kind", default="port-production", choices=["port-production", "port"],
+                    help="port-production: oracle/cpu_production.c (fp32, half Verlet list reused across steps); port: the fp64 parity oracle")
+    ap.add_argument("--tail-steps", type=int, default=-1,
+                    help="untimed-for-value tail with natural rebuilds and energies every 100 steps; -1 = 1000 when --steps < 1000, else 0")
     ap.add_argument("--nb-variant", type=int, default=0)
     ap.add_argument("--decomposed", action="store_true", help="drive the decomposed path even on one GPU")
     ap.add_argument("--no-equilibrate", dest="equilibrate", action="store_false",
@@ -62,6 +73,25 @@ def parse():
                     help="dual pair list: buffer of the rolling-pruned inner list in A (0 = library default 0.5, < 0 = off)")
     ap.add_argument("--pme", action="store_true", help="Ewald Coulomb with the SPME reciprocal sum (not the headline config)")
     return ap.parse_args()
+
+
+def cpu_baseline_production(system, cfg, dt, n_steps):
+    """Times oracle/cpu_production.c (kind "port-production": this repo's fp32 restatement of a production CPU MD
+    loop - the reference's Rust engine cannot be built here) on all host cores: n_steps velocity-Verlet steps of the
+    same system, the half Verlet list reused until an atom has moved skin/2 (first build included)."""
+    from oracle import cpu_production as cp
+    lib = cp.lib(native=True)
+    t0 = time.perf_counter()
+    _, _, _, builds = cp.run(system, cfg, dt, n_steps, energy_every=100, native=True)
+    el = time.perf_counter() - t0
+    n = system.n_atoms
+    return {
+        "value": n * n_steps / el, "unit": "atom-updates/s", "steps_per_s": n_steps / el,
+        "cores": int(lib.cpu_prod_max_threads()), "kind": "port-production",
+        "sample": f"{n_steps} velocity-Verlet steps of the same {n}-atom box, fp32, cell search -> half Verlet list (rc + skin) "
+                  f"reused across steps ({builds} list builds incl. the first), Newton-3 pair loop, energies every 100 steps, "
+                  f"gcc -O3 -march=native, OpenMP over all host cores, {el:.1f} s",
+    }
 
 
 def cpu_baseline(system, cfg, dt, n_steps):
@@ -176,89 +206,152 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def run_steps(n):
+        """n steps with energies every --energy-every steps -> number of energy evaluations."""
+        n_e = 0
+        if args.energy_every > 0:
+            done = 0
+            while done < n:
+                k = min(args.energy_every, n - done)
+                stepper(k); done += k
+                if done % args.energy_every == 0:
+                    md.energy(); n_e += 1
+        else:
+            stepper(n)
+        return n_e
+
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
     stepper(args.warmup)
     prof(args.profile_level)
-    rebuilds0 = stats()["rebuild_count"]
+    st0 = stats()
     sync()
     t0 = time.perf_counter()
-    n_energy = 0
-    if args.energy_every > 0:
-        done = 0
-        while done < args.steps:
-            k = min(args.energy_every, args.steps - done)
-            stepper(k); done += k
-            if done % args.energy_every == 0:
-                last_energy = md.energy(); n_energy += 1
-    else:
-        stepper(args.steps)
+    n_energy = run_steps(args.steps)
     sync()
-    el = time.perf_counter() - t0
+    el = max_over_ranks(time.perf_counter() - t0)
     st = stats()
+    # Untimed-for-`value` tail: the driver's 20-step window holds no list rebuild and no energy evaluation, so the
+    # representative rate (natural rebuild cadence, energies every 100 steps) is measured here and reported beside it.
+    tail_steps = args.tail_steps if args.tail_steps >= 0 else (1000 if args.steps < 1000 else 0)
+    tail = None
+    if tail_steps > 0:
+        sync()
+        t1 = time.perf_counter()
+        n_energy_tail = run_steps(tail_steps)
+        sync()
+        el_tail = max_over_ranks(time.perf_counter() - t1)
+        st_t = stats()
+        tail = {"steps": tail_steps, "steps_per_s": tail_steps / el_tail, "ms_per_step": 1e3 * el_tail / tail_steps,
+                "rebuilds": int(st_t["rebuild_count"] - st["rebuild_count"]), "energy_evaluations": n_energy_tail,
+                "rebuild_ms_per_step_amortised": (st_t["rebuild_ms_sum"] - st["rebuild_ms_sum"]) / tail_steps,
+                "prune_passes": int(st_t.get("prune_passes", 0) - st.get("prune_passes", 0))}
+        st_nb = st_t                       # pair-kernel launch statistics: timed region + tail
+    else:
+        st_nb = st
     # bonded / integrate kernel times: a short tail outside the timed region with every kernel bracketed
     prof(1)
     stepper(48)
     sync()
     st_tail = stats()
     prof(0)
-    for k in ("bonded_ms_sum", "bonded_launches", "integ_ms_sum", "integ_launches"):
-        st[k] = st_tail[k]
     if args.profile_level == 0:
-        for k in ("nb_ms_sum", "nb_launches"):
-            st[k] = st_tail[k]
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        st_nb = st_tail
 
     steps_per_s = args.steps / el
     value = n_atoms * steps_per_s
-    nb_ms = st["nb_ms_sum"] / max(st["nb_launches"], 1)
-    atoms_per_launch = st["n_atoms"]
-    achieved = B_ALG_NONBONDED * atoms_per_launch / (nb_ms * 1e-3) / 1e9 if nb_ms > 0 else 0.0
-    # (i-cluster, j-cluster) pairs x 8 x 8 lanes; with the dual list the step loop walks the inner list (mean over the
-    # pruning passes), and one launch in ~`steps / prune_passes` walks the Verlet list while it re-prunes
-    dual = st.get("prune_passes", 0) > 0
-    pair_evals = float(st["n_inner_cluster_pairs"] if dual else st["n_cluster_pairs"]) * 64
-    traffic = None
+    nb_launches = st_nb["nb_launches"]
+    nb_ms = st_nb["nb_ms_sum"] / max(nb_launches, 1)
+    bonded_ms = st_tail["bonded_ms_sum"] / max(st_tail["bonded_launches"], 1)
+    integ_ms = st_tail["integ_ms_sum"] / max(st_tail["integ_launches"], 1)
+    atoms_per_launch = st["n_atoms"]                 # owned + ghost atoms of this rank's launch
+    gbs = lambda b_per_atom, ms: b_per_atom * atoms_per_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    achieved = gbs(B_ALG_NONBONDED, nb_ms)
+    # (i-cluster, j-cluster) pairs x 8 x 8 lanes.  With the dual list most step-loop launches walk the inner list (mean
+    # over the pruning passes) and a fraction `prune_frac` walks the Verlet list while it re-prunes.
+    n_steps_nb = max(int(st_nb["step_count"] - st0["step_count"]), 1)
+    prune_frac = min(1.0, (st_nb.get("prune_passes", 0) - st0.get("prune_passes", 0)) / n_steps_nb)
+    dual = st_nb.get("prune_passes", 0) > 0 and st_nb["n_inner_cluster_pairs"] > 0
+    verlet_evals = float(st_nb["n_cluster_pairs"]) * 64
+    inner_evals = float(st_nb["n_inner_cluster_pairs"]) * 64 if dual else verlet_evals
+    pair_evals = (1.0 - prune_frac) * inner_evals + prune_frac * verlet_evals if dual else verlet_evals
+    # algorithmic flops: 45 per half pair INSIDE the cutoff; their number follows from the density (homogeneous box,
+    # exclusions neglected: 209.4 per atom for water at rc = 10 A) - only priced for the plain cutoff flavour
+    alg_tflops = None
+    if system.periodic and not args.pme and world == 1:
+        vol = float(np.prod(np.asarray(system.box_hi, np.float64) - np.asarray(system.box_lo, np.float64)))
+        half_pairs_per_atom = 0.5 * (4.0 / 3.0) * np.pi * max(cfg.lj_cutoff, cfg.coulomb_cutoff) ** 3 * n_atoms / vol
+        alg_tflops = FLOP_PER_PAIR * half_pairs_per_atom * n_atoms / (nb_ms * 1e-3) / 1e12 if nb_ms > 0 else 0.0
+    traffic, traffic_source = None, None
     tfile = os.path.join(ROOT, "profiles", "nb_traffic.json")
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
-            if tj.get("workload") == args.workload and world == 1:
+            # a CACHED figure: PMC passes cannot run inside the bench.  Only quoted for the kernel/flavour it was
+            # collected on; a stale or foreign entry is nulled rather than repeated.
+            if (tj.get("workload") == args.workload and world == 1 and not args.pme and args.nb_variant in (0, 5)
+                    and tj.get("kernel_rev") == NB_KERNEL_REV):
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = f"profiles/nb_traffic.json ({tj.get('source', 'rocprofv3 --pmc')}; cached, not measured by this run)"
         except Exception:
             pass
+    if args.nb_variant == 1:
+        kernel = "nb_tile_kernel"
+    elif dual:
+        kernel = (f"nb_cluster_kernel: {100 * (1 - prune_frac):.0f} % inner-list walks + {100 * prune_frac:.0f} % pruning passes "
+                  f"(the no-op twin of each launch pair is inside the bracket)")
+    else:
+        kernel = "nb_cluster_kernel (plain Verlet list)"
     out = {
         "metric": "MD atom-updates/sec (and steps/sec), 1M-atom solvated box",
         "value": value, "unit": "atom-updates/s", "steps_per_s": steps_per_s,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,   # the ONE 1M-atom box at every N (BASELINE.json)
         "dtype": "f32", "data": "synthetic",
+        "steps_per_s_1000": tail["steps_per_s"] if tail else steps_per_s,
+        "rebuild_ms_per_step_amortised": (tail["rebuild_ms_per_step_amortised"] if tail
+                                          else (st["rebuild_ms_sum"] - st0["rebuild_ms_sum"]) / args.steps),
+        "tail": tail,
         "config": {"workload": args.workload, "n_atoms": n_atoms, "lj_cutoff": cfg.lj_cutoff,
                    "coulomb_cutoff": cfg.coulomb_cutoff, "skin": cfg.skin, "dt_ps": args.dt,
                    "coulomb": "ewald real space + SPME (order 4, ~1 A mesh)" if args.pme else "shifted cutoff", "parallelism": parallelism,
-                   "rebuilds_in_timed_region": int(st["rebuild_count"] - rebuilds0),
-                   "dual_list": ({"inner_skin": cfg.inner_skin or 0.5, "verlet_pair_evals": float(st["n_cluster_pairs"]) * 64,
-                                  "prune_passes_total": int(st["prune_passes"])} if dual else None),
+                   "rebuilds_in_timed_region": int(st["rebuild_count"] - st0["rebuild_count"]),
+                   "dual_list": ({"inner_skin": cfg.inner_skin or 0.5, "verlet_pair_evals": verlet_evals, "inner_pair_evals": inner_evals,
+                                  "prune_frac": prune_frac} if dual else None),
                    "energy_evaluations_in_timed_region": n_energy, "untimed_preparation": prep,
                    "repartitions": getattr(md, "repartitions", None), "local_rebuilds": getattr(md, "local_rebuilds_total", None)},
-        "roofline": {"kernel": "nb_tile_kernel" if args.nb_variant == 1 else "nb_cluster_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "launch_ms": nb_ms, "launches": st["nb_launches"],
+        "roofline": {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "launch_ms": nb_ms, "launches": nb_launches,
                      "algorithmic_bytes_per_launch": B_ALG_NONBONDED * atoms_per_launch,
-                     "note": "pair loop is fp32-VALU bound, see valu_frac; HBM fraction is low by physics"},
+                     "note": "pair loop is fp32-VALU bound, see valu.frac; HBM fraction is low by physics"},
+        # the streaming kernels, in SURVEY 8d's algorithmic bytes (profiled 48-step tail, every kernel bracketed)
+        "roofline_streaming": {
+            "integrate_kernel": {"bound": "hbm", "bytes_per_atom": B_ALG_INTEGRATE, "launch_ms": integ_ms,
+                                 "achieved": gbs(B_ALG_INTEGRATE, integ_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": gbs(B_ALG_INTEGRATE, integ_ms) / HBM_PEAK_GBS},
+            "bonded_gather_kernel": ({"bound": "hbm", "bytes_per_atom": B_ALG_BONDED_WATER, "launch_ms": bonded_ms,
+                                      "achieved": gbs(B_ALG_BONDED_WATER, bonded_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": gbs(B_ALG_BONDED_WATER, bonded_ms) / HBM_PEAK_GBS}
+                                     if args.workload == "water1M" else {"launch_ms": bonded_ms, "achieved": None})},
         "valu": {"pair_evals_per_launch": pair_evals,
                  "pair_evals_per_s": pair_evals / (nb_ms * 1e-3) if nb_ms > 0 else 0.0,
-                 "algorithmic_tflops": FLOP_PER_PAIR * 209.4 * atoms_per_launch / (nb_ms * 1e-3) / 1e12 if nb_ms > 0 else 0.0,
-                 "peak_tflops": FP32_PEAK_TFLOPS},
-        "step_hbm_frac": B_ALG_STEP_WATER * value / (world * HBM_PEAK_GBS * 1e9),
-        "kernel_ms": {"nonbonded": nb_ms, "bonded": st["bonded_ms_sum"] / max(st["bonded_launches"], 1),
-                      "integrate": st["integ_ms_sum"] / max(st["integ_launches"], 1),
-                      "rebuild_total": st["rebuild_ms_sum"]},
+                 "algorithmic_tflops": alg_tflops, "peak_tflops": FP32_PEAK_TFLOPS,
+                 "frac": alg_tflops / FP32_PEAK_TFLOPS if alg_tflops is not None else None},
+        "step_hbm_frac": B_ALG_STEP_WATER * value / (world * HBM_PEAK_GBS * 1e9) if args.workload == "water1M" else None,
+        "kernel_ms": {"nonbonded": nb_ms, "bonded": bonded_ms, "integrate": integ_ms,
+                      "rebuild_total": st_nb["rebuild_ms_sum"] - st0["rebuild_ms_sum"]},
     }
-    out["valu"]["frac"] = out["valu"]["algorithmic_tflops"] / FP32_PEAK_TFLOPS
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(system, cfg, args.dt, args.cpu_steps)
+        if args.cpu_kind == "port-production" and not args.pme:
+            out["cpu_baseline"] = cpu_baseline_production(system, cfg, args.dt, args.cpu_steps)
+        else:
+            out["cpu_baseline"] = cpu_baseline(system, cfg, args.dt, min(args.cpu_steps, 10))
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -399,7 +399,13 @@ class DecomposedMd:
         self.recv_buf = torch.zeros((r0, 4), dtype=torch.float32, device=self.dev)
         self._halo_ops = None          # rebuilt lazily: new buffers, new slices
         # the flag can ride on the halo only if every other rank is a peer in both directions
-        self.flag_on_halo = (len(self.send) == self.world - 1 and len(self.recv) == self.world - 1)
+        # ... on EVERY rank: the per-step flag all-reduce is a collective, so all ranks must take the same branch.
+        # One small all-reduce per repartition settles it (an empty or sparse brick may lack a peer segment).
+        lacking = torch.tensor([0 if (len(self.send) == self.world - 1 and len(self.recv) == self.world - 1) else 1],
+                               dtype=torch.int32, device=self.dev)
+        if self.world > 1:
+            self.comm.all_reduce(lacking, "max")
+        self.flag_on_halo = int(lacking.item()) == 0
         self.repartitions += 1
 
     def _local_set_still_valid(self) -> bool:
