@@ -182,6 +182,11 @@ typedef struct mdx_stats {
     double   wall_ms_sum;       /* host wall time inside mdx_step */
     uint64_t n_inner_cluster_pairs; /* dual list: cluster pairs the last pruning pass kept (0 when off) */
     uint64_t prune_passes;      /* dual list: pruning passes executed so far */
+    /* decomposed handles (mdx_comm_init): this rank's share and its repartition history */
+    uint32_t n_owned, n_ghost;
+    uint64_t repartitions;      /* times the ranks re-derived owners / ghosts / halo lists from the gathered state */
+    uint64_t local_rebuilds;    /* stale lists rebuilt on the unchanged owned + ghost set */
+    double   repartition_ms_sum;
 } mdx_stats;
 
 typedef struct mdx_handle mdx_handle;
@@ -328,8 +333,40 @@ int      mdx_snapshot_read(mdx_handle* h, uint32_t k, double* time_ps, uint64_t*
 int      mdx_flush_snapshot_queues(mdx_handle* h);       /* drop the stored snapshots (after the host cloned them) */
 double   mdx_time_ps(const mdx_handle* h);
 
-/* ---- multi-GPU spatial decomposition support (the reference is single-device,
- * src/util.rs:1086, so this is new capability, not parity) -------------------------------------
+/* ---- multi-GPU: one periodic box spatially decomposed over the GPUs of a node (the reference is
+ * single-device, src/util.rs:1086 `CudaContext::new(0)`, so this is new capability, not parity) -------------------
+ * One rank (process or thread) per GPU.  Every rank creates a handle from the SAME global system (static per-atom data
+ * and topology are replicated), then joins the communicator; from then on
+ *     mdx_step      runs the decomposed step loop: drift -> pack -> ncclGroupStart / ncclSend + ncclRecv per peer /
+ *                   ncclGroupEnd on the handle's communication stream -> unpack -> forces, the "list went stale" word
+ *                   riding on the halo message; stale lists are rebuilt locally or the ranks repartition (decided alike
+ *                   everywhere), all below this ABI
+ *     mdx_energy    returns the totals of the whole box on every rank
+ *     mdx_download  gathers the global array on every rank
+ * and these three are COLLECTIVE: every rank must make the same calls in the same order.  Constraints, virtual sites,
+ * thermostats, every integrator and snapshots work on a decomposed handle (a constraint cluster / virtual-site family is
+ * owned as a whole by one rank); the barostat, alchemical windows, external forces, the minimiser, uploads and the SPME
+ * reciprocal sum are refused (MDX_EPARAM) - configure those, and initial velocities, before joining.
+ *
+ * mdx_comm_unique_id: rank 0 draws the id (ncclGetUniqueId; librccl is dlopen'd on first use) and hands the 128 bytes
+ * to the other ranks by whatever means the host has.  mdx_comm_init is ncclCommInitRank + the first partition. */
+#define MDX_COMM_ID_BYTES 128
+int mdx_comm_unique_id(uint8_t id[MDX_COMM_ID_BYTES]);
+int mdx_comm_init(mdx_handle* h, const uint8_t id[MDX_COMM_ID_BYTES], int rank, int world);
+/* The same decomposition inside ONE process: `world` handles (one thread each; on one device or several) meet through
+ * an in-process fabric instead of RCCL - plain device-to-device copies between their halo buffers.  What single-GPU
+ * test boxes use (RCCL refuses two ranks on one device) and what a single-process host may use. */
+typedef struct mdx_fabric mdx_fabric;
+mdx_fabric* mdx_fabric_create(int world);
+void mdx_fabric_destroy(mdx_fabric* f);
+void mdx_fabric_abort(mdx_fabric* f);          /* a rank failed: release everybody who waits for it */
+int mdx_comm_init_fabric(mdx_handle* h, mdx_fabric* f, int rank);
+/* Rank `rank` of `world` with a transport that delivers nothing: what ONE rank of a decomposition costs per step,
+ * measured alone on a single GPU (tools/one_rank_profile.py). */
+int mdx_comm_init_null(mdx_handle* h, int rank, int world);
+int mdx_comm_info(const mdx_handle* h, int* rank, int* world, int grid[3], uint32_t* n_owned, uint32_t* n_ghost, float* halo);
+
+/* ---- the building blocks underneath (kept for hosts that drive the decomposition themselves, and for the tests) ----
  * One handle per GPU/rank, created from the GLOBAL system (static per-atom data and topology are
  * replicated: 288 GB of HBM per GPU make that free), then told which atoms it simulates:
  * its owned atoms plus ghost copies of every atom within cutoff+skin of its brick.  In a

@@ -82,6 +82,8 @@ class CStats(C.Structure):
         ("integ_ms_sum", C.c_double), ("integ_launches", C.c_uint64),
         ("rebuild_ms_sum", C.c_double), ("wall_ms_sum", C.c_double),
         ("n_inner_cluster_pairs", C.c_uint64), ("prune_passes", C.c_uint64),
+        ("n_owned", C.c_uint32), ("n_ghost", C.c_uint32), ("repartitions", C.c_uint64),
+        ("local_rebuilds", C.c_uint64), ("repartition_ms_sum", C.c_double),
     ]
 
     def as_dict(self) -> dict:

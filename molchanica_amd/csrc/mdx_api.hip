@@ -9,7 +9,7 @@
 //                                                   [ref: src/properties/sol_shrinking_box.rs:600-632]
 // There is no CPU fallback in this library: without a gfx950 device every entry point fails with
 // MDX_EDEVICE and the host keeps its own CPU path (src/util.rs:1072-1119 semantics).
-#include "mdx_internal.h"
+#include "mdx_comm.h"
 #include <algorithm>
 #include <chrono>
 #include <cfloat>
@@ -152,6 +152,7 @@ extern "C" void mdx_destroy(mdx_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    mdx_dd_destroy(h);
     for (auto& e : h->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : h->ev_pool) (void)hipEventDestroy(e);
     mdx_pme_destroy(h);
@@ -350,6 +351,11 @@ static uint32_t stale_threshold_bits(const mdx_handle* h) {
 
 static int compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint32_t thr) {
     MDX_TRY(mdx_launch_vsite_construct(h, gate, thr));     // massless sites follow their parents
+    if (h->dd && h->dd->halo_pending) {                    // decomposed handle, step loop: ghost positions travel now
+        h->dd->halo_pending = false;
+        MDX_TRY(mdx_dd_halo_begin(h));
+        MDX_TRY(mdx_dd_halo_end(h));
+    }
     if (h->pme_on && h->pme_overlap) {                     // SPME reciprocal space on its side stream, beside the pair kernel
         MDX_TRY(mdx_pme_fork(h));
         MDX_TRY(mdx_launch_pme(h, energy, gate, thr));
@@ -434,7 +440,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
     // external forces (held constant over the burst)  [ref: src/mol_alignment.rs:318-346]
     const bool had_ext = h->have_ext;
     if (ext_forces) {
-        if (h->n_local != h->N) FAIL(MDX_EPARAM, "external forces are not supported on a decomposed handle");
+        if (h->n_local != h->N || h->dd) FAIL(MDX_EPARAM, "external forces are not supported on a decomposed handle");
         std::vector<float4> e4(h->N);
         for (uint32_t i = 0; i < h->N; ++i)
             e4[i] = make_float4(ext_forces[3 * i], ext_forces[3 * i + 1], ext_forces[3 * i + 2], 0.f);
@@ -474,6 +480,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
             // drift, which has happened even when the step's forces turn out to be gated off)
             if (integ == MDX_INTEGRATOR_LANGEVIN_MIDDLE) MDX_TRY(mdx_launch_constrain_velocities(h, &d.ctl->disp2[s], thr));
             h->nb_step = (int)s;      // the pair kernel of this call may walk the inner masks / prune (prune[s + 1])
+            if (h->dd) { h->dd->halo_pending = true; h->dd->halo_step = (int)s; h->chunk_s = (int)s; }
             const int frc = compute_forces(h, false, &d.ctl->disp2[s + 1], thr);
             h->nb_step = -1;
             MDX_TRY(frc);
@@ -485,6 +492,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         h->prof_tag = (int)chunk;
         if (fused) MDX_TRY(mdx_launch_integrate(h, 2, dt, &d.ctl->disp2[chunk], nullptr, thr));
         h->prof_tag = -1;
+        if (h->dd) h->chunk_s = -1;
         HIP_TRY(hipMemcpyAsync(h->h_ctl, d.ctl, sizeof(StepCtl), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         uint32_t done = chunk;
@@ -499,9 +507,12 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
                     h->step_count += s;
                     FAIL(MDX_ENAN, "non-finite or runaway coordinates during mdx_step");
                 }
-                // the drift of step s happened, its forces did not: rebuild, finish the step
+                // the drift of step s happened, its forces did not: rebuild, finish the step.  On a decomposed handle
+                // every rank is here at the same step (the flag rides on the halo message): rebuild locally while the
+                // owned + ghost set is still complete, else repartition - decided alike on every rank
                 h->list_valid = false;
-                MDX_TRY(mdx_rebuild(h));
+                if (h->dd) { h->chunk_s = -1; MDX_TRY(mdx_dd_on_stale(h)); }
+                else MDX_TRY(mdx_rebuild(h));
                 MDX_TRY(compute_forces(h, false, nullptr, 0));
                 if (vv) {
                     MDX_TRY(mdx_launch_integrate(h, 2, dt, nullptr, nullptr, thr));
@@ -567,6 +578,18 @@ int mdx_energy_impl(mdx_handle* h, mdx_energies* out) {
         e[EN_LJ] += q[0]; e[EN_COUL] += q[1]; e[EN_VIRIAL] += q[2]; u_cross += q[3];
     }
     if (h->profile) mdx_prof_collect(h);
+    if (h->dd) {   // every rank evaluated its share (a pair's energy is split between the owners of its atoms): sum them
+        double v[EN_COUNT + 2];
+        for (int k = 0; k < EN_COUNT; ++k) v[k] = e[k];
+        v[EN_COUNT] = u_cross;
+        MDX_TRY(mdx_dd_allreduce_host(h, v, EN_COUNT + 1));
+        for (int k = 0; k < EN_COUNT; ++k) e[k] = v[k];
+        u_cross = v[EN_COUNT];
+        uint32_t mfb; std::memcpy(&mfb, &e[EN_COUNT], 4);
+        double mv = (double)mfb;
+        MDX_TRY(mdx_dd_allreduce_host(h, &mv, 1, true));
+        mfb = (uint32_t)mv; std::memcpy(&e[EN_COUNT], &mfb, 4);
+    }
     std::memset(out, 0, sizeof(*out));
     out->bond = e[EN_BOND]; out->angle = e[EN_ANGLE]; out->dihedral = e[EN_DIHEDRAL];
     out->lj = e[EN_LJ]; out->coulomb = e[EN_COUL]; out->lj14 = e[EN_LJ14]; out->coulomb14 = e[EN_COUL14];
@@ -710,6 +733,10 @@ extern "C" int mdx_single_point(const mdx_system* sys, const mdx_config* cfg, in
 extern "C" int mdx_download(mdx_handle* h, int which, float* dst) {
     if (!h || !dst) FAIL(MDX_EPARAM, "null argument");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->dd) {   // decomposed: a collective - every rank receives the global array (all ranks must make the call)
+        if (which != MDX_POS && which != MDX_VEL && which != MDX_FORCE) FAIL(MDX_EPARAM, "unknown array selector");
+        return mdx_dd_download(h, which, dst);
+    }
     hipStream_t st = h->stream;
     const uint32_t N = h->n_local;   // == n_atoms unless mdx_set_local_atoms narrowed the set
     const float4* src = nullptr;
@@ -898,6 +925,11 @@ extern "C" int mdx_get_stats(mdx_handle* h, mdx_stats* out) {
         h->stats.prune_passes = c[MDX_EPART];
         h->stats.n_inner_cluster_pairs = c[MDX_EPART] ? tot / c[MDX_EPART] : 0;   // mean per pass
     }
+    h->stats.n_owned = h->dd ? h->dd->n_owned : h->n_local;
+    h->stats.n_ghost = h->dd ? h->dd->n_local - h->dd->n_owned : 0;
+    h->stats.repartitions = h->dd ? h->dd->repartitions : 0;
+    h->stats.local_rebuilds = h->dd ? h->dd->local_rebuilds : 0;
+    h->stats.repartition_ms_sum = h->dd ? h->dd->repartition_ms : 0.0;
     *out = h->stats;
     return MDX_OK;
 }
@@ -949,9 +981,16 @@ extern "C" int mdx_set_local_atoms(mdx_handle* h, uint32_t n_local, const uint32
                                    const float* d_pos4, const float* d_vel4, const float lo[3], const float hi[3],
                                    int32_t periodic) {
     if (!h || !d_gid || !d_ghost || !d_pos4 || !d_vel4 || !lo || !hi) FAIL(MDX_EPARAM, "null argument");
-    if (n_local == 0 || n_local > h->N) FAIL(MDX_EPARAM, "n_local must be in 1..n_atoms (each atom at most once)");
+    if (h->dd) FAIL(MDX_EPARAM, "the handle's decomposition is managed by the library (mdx_comm_init)");
     if (h->n_groups || h->n_vsites)
-        FAIL(MDX_EPARAM, "constraints / virtual sites are not supported on a decomposed handle yet");
+        FAIL(MDX_EPARAM, "constraints / virtual sites need cluster-wise ownership: use mdx_comm_init, which decides it");
+    return mdx_set_local_atoms_impl(h, n_local, d_gid, d_ghost, d_pos4, d_vel4, lo, hi, periodic);
+}
+
+int mdx_set_local_atoms_impl(mdx_handle* h, uint32_t n_local, const uint32_t* d_gid, const uint8_t* d_ghost,
+                             const float* d_pos4, const float* d_vel4, const float lo[3], const float hi[3],
+                             int32_t periodic) {
+    if (n_local == 0 || n_local > h->N) FAIL(MDX_EPARAM, "n_local must be in 1..n_atoms (each atom at most once)");
     if (h->pme_on) FAIL(MDX_EPARAM, "the SPME reciprocal sum is not supported on a decomposed handle (each rank would spread only its own charges)");
     if (h->alch_on) FAIL(MDX_EPARAM, "alchemical windows are not supported on a decomposed handle");
     if (h->integrator != MDX_INTEGRATOR_VERLET_VELOCITY) FAIL(MDX_EPARAM, "only velocity Verlet is supported on a decomposed handle");

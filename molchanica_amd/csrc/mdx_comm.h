@@ -1,0 +1,85 @@
+// mdx_comm.h — multi-GPU plumbing below the C ABI (not part of the public ABI): the transport a decomposed handle
+// talks through and the per-handle decomposition state.  SURVEY.md §8e: spatial decomposition, ghost-atom halo
+// exchange with ncclSend / ncclRecv groups on a dedicated communication stream, interior tiles computed while the
+// halo is in flight.  The reference is single-device (/root/reference src/util.rs:1086), so this is new capability.
+#pragma once
+#include "mdx_internal.h"
+#include <vector>
+
+struct MdxSeg { int peer; uint32_t row0, nrows; };   // rows are float4
+
+// What a decomposed handle needs from the wire.  Two implementations (mdx_comm.hip): RCCL over xGMI (one process or
+// thread per GPU, librccl dlopen'd on first use) and an in-process fabric (N handles of ONE process, any mix of
+// devices: plain device-to-device copies between their buffers; what the single-GPU tests and a single-process host use).
+struct MdxTransport {
+    int rank = 0, world = 1;
+    virtual ~MdxTransport() {}
+    // Enqueue on `stream`: rows [row0, row0 + nrows) of `send` travel to `peer` for every send segment, the rows of
+    // every receive segment land in `recv`.  A peer's send segment towards this rank and this rank's receive segment
+    // from that peer have the same length by construction.  A segment whose peer is this rank is a local copy.
+    virtual int exchange(const float4* send, const std::vector<MdxSeg>& ssegs, float4* recv, const std::vector<MdxSeg>& rsegs,
+                         hipStream_t stream) = 0;
+    // In-place all-reduce of a small DEVICE array (n <= 4096).  kind: 0 = sum of doubles, 1 = max of uint32.
+    virtual int all_reduce(void* dev, size_t n, int kind, hipStream_t stream) = 0;
+    // every rank contributes one word, every rank gets all of them (host values; synchronises `stream`)
+    virtual int all_gather_u32(uint32_t mine, uint32_t* all, hipStream_t stream) = 0;
+    virtual const char* name() const = 0;
+    virtual bool delivers() const { return true; }   // false: the null transport (peers' rows never arrive)
+};
+
+struct mdx_fabric;   // the in-process transport's meeting point (C ABI: mdx_fabric_create / _destroy)
+MdxTransport* mdx_make_rccl_transport(const uint8_t* id128, int rank, int world, int device);    // nullptr + error text on failure
+MdxTransport* mdx_make_fabric_transport(mdx_fabric* f, int rank);
+MdxTransport* mdx_make_null_transport(int rank, int world);   // delivers nothing: one rank of N profiled alone (tools/one_rank_profile.py)
+
+// ---- decomposition state of one handle -------------------------------------------------------------------------
+struct MdxDecomp {
+    MdxTransport* tr = nullptr;
+    int rank = 0, world = 1;
+    int grid[3] = {1, 1, 1}, coord[3] = {0, 0, 0};
+    float box_lo[3]{}, box_len[3]{};
+    float brick_lo[3]{}, brick_hi[3]{};
+    float r_list = 0.f, margin = 0.f, ext = 0.f, halo = 0.f;   // halo = r_list + margin + ext
+    // replicated static data
+    uint32_t* anchor = nullptr;        // [N] the atom whose position decides the owner of atom g (constraint cluster / virtual-site parent)
+    // global dynamic state at the last gather (device, replicated)
+    float4* g_pos = nullptr; float4* g_vel = nullptr; float4* g_frc = nullptr;   // [N]
+    // classification scratch
+    uint8_t* cls = nullptr;            // [N] 0: not here, 1: owned, 2: ghost
+    uint8_t* owner = nullptr;          // [N] owning rank
+    uint8_t* shift_code = nullptr;     // [N] image that brings the atom into this rank's frame: (kx+1) | (ky+1) << 2 | (kz+1) << 4
+    uint32_t* send_mask = nullptr;     // [N] owned atoms: bit q <=> rank q keeps a ghost copy
+    uint32_t* flags = nullptr; uint32_t* scan = nullptr; uint32_t* scan_sums = nullptr; size_t cap_flags = 0;
+    // local atom set (ascending global id)
+    uint32_t n_local = 0, n_owned = 0, cap_local = 0;
+    uint32_t* gid_local = nullptr; uint8_t* ghost_local = nullptr; float4* pos_l = nullptr; float4* vel_l = nullptr;
+    float4* pos_at_part = nullptr;     // local positions at the last repartition ("is the local set still complete?")
+    uint32_t* owned_gid = nullptr;     // [n_owned]
+    // halo lists: all peers' rows in ONE send and ONE receive buffer, a peer's segment ends with a flag row (id 0xFFFFFFFF)
+    uint32_t* send_ids = nullptr; uint32_t* recv_ids = nullptr; float4* recv_shift = nullptr;
+    float4* send_buf = nullptr; float4* recv_buf = nullptr;
+    uint32_t n_send = 0, n_recv = 0, cap_send = 0, cap_recv = 0;
+    std::vector<MdxSeg> send_segs, recv_segs;
+    // gather of the global state (repartition, read-back)
+    float4* gat_send = nullptr; float4* gat_recv = nullptr; size_t cap_gat_send = 0, cap_gat_recv = 0;
+    // communication stream and the events that order it with the compute stream
+    hipStream_t comm_stream = nullptr; hipEvent_t ev_packed = nullptr, ev_arrived = nullptr;
+    bool halo_pending = false;         // the next force call of the step loop starts with a halo exchange
+    int halo_step = -1;                // chunk step of that exchange (flag word = step + 1)
+    bool overlap = true;               // interior tiles run while the message is in flight
+    double* red = nullptr;             // [64] device scratch of the small all-reduces
+    // statistics
+    uint64_t repartitions = 0, local_rebuilds = 0; uint32_t local_rebuilds_since = 0;
+    double repartition_ms = 0.0;
+};
+
+int  mdx_set_local_atoms_impl(mdx_handle* h, uint32_t n_local, const uint32_t* d_gid, const uint8_t* d_ghost, const float* d_pos4,
+                              const float* d_vel4, const float lo[3], const float hi[3], int32_t periodic);
+int  mdx_dd_attach(mdx_handle* h, MdxTransport* tr);     // takes ownership of `tr`; partitions and builds the local state
+void mdx_dd_destroy(mdx_handle* h);
+int  mdx_dd_halo_begin(mdx_handle* h);                   // pack + exchange (async on the comm stream)
+int  mdx_dd_halo_end(mdx_handle* h);                     // wait + unpack: ghost positions, peers' flag words
+int  mdx_dd_on_stale(mdx_handle* h);                     // the list went stale somewhere: local rebuild or repartition (same branch on every rank)
+int  mdx_dd_allreduce_host(mdx_handle* h, double* v, int n, bool max_u32 = false);
+int  mdx_dd_download(mdx_handle* h, int which, float* dst);   // collective: the global array on every rank
+int  mdx_dd_gather_global(mdx_handle* h, bool with_force);    // g_pos / g_vel (/ g_frc) <- all ranks' owned atoms

@@ -1,0 +1,251 @@
+// mdx_comm.hip — the wire under a decomposed handle.
+//
+//   RcclTransport    one rank per GPU (process or thread).  librccl is dlopen'd on first use, the way hipFFT is
+//                    (libmdx.so links no communication library); a halo exchange is ONE ncclGroupStart / ncclSend +
+//                    ncclRecv per peer / ncclGroupEnd on the stream it is given (the handle's communication stream).
+//                    xGMI is point to point - 7 links per MI355X - and a 2x2x2 decomposition has exactly 7 peers per
+//                    rank, so every message has a link of its own; nothing here is a ring collective except the
+//                    few-word all-reduces (energies, "is the local atom set still complete").
+//   FabricTransport  N handles inside ONE process (threads), on one device or several: a rank posts its send buffer,
+//                    peers copy their segments out of it device-to-device.  Same interface, same call sequence, no
+//                    RCCL: what the single-GPU tests drive (RCCL refuses two ranks per device) and what a
+//                    single-process host with several devices can use.
+//   NullTransport    delivers nothing (one rank of N measured alone).
+// The reference has no multi-device code at all (/root/reference src/util.rs:1086: CudaContext::new(0)).
+#include "mdx_comm.h"
+#include <dlfcn.h>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+
+#define FAIL(code, msg) do { mdx_set_error(msg); return (code); } while (0)
+
+// ---- RCCL through dlopen ----------------------------------------------------------------------------------------
+namespace {
+typedef struct ncclComm* ncclComm_t;
+struct ncclUniqueId { char internal[128]; };
+enum { ncclSuccess = 0 };
+enum { ncclSum = 0, ncclMax = 2 };
+enum { ncclUint32 = 3, ncclFloat32 = 7, ncclFloat64 = 8 };
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mutex;
+
+bool load_rccl() {
+    std::lock_guard<std::mutex> lk(g_rccl_mutex);
+    if (g_rccl.lib) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+    if (!lib) { mdx_set_error(std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?")); return false; }
+    RcclApi a; a.lib = lib;
+#define SYM(field, name) *(void**)(&a.field) = dlsym(lib, name); if (!a.field) { mdx_set_error("librccl lacks " name); return false; }
+    SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+    SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv")
+    SYM(AllReduce, "ncclAllReduce") SYM(AllGather, "ncclAllGather") SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    g_rccl = a;
+    return true;
+}
+
+#define NCCL_TRY(expr)                                                                                        \
+    do {                                                                                                      \
+        const int _r = (expr);                                                                                \
+        if (_r != ncclSuccess) {                                                                              \
+            mdx_set_error(std::string(#expr) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "rccl error")); \
+            return MDX_EDEVICE;                                                                               \
+        }                                                                                                     \
+    } while (0)
+
+struct RcclTransport : MdxTransport {
+    ncclComm_t comm = nullptr;
+    uint32_t* d_words = nullptr;   // [world + 1] all-gather scratch
+    ~RcclTransport() override {
+        if (comm) (void)g_rccl.CommDestroy(comm);
+        if (d_words) (void)hipFree(d_words);
+    }
+    const char* name() const override { return "rccl"; }
+    int exchange(const float4* send, const std::vector<MdxSeg>& ssegs, float4* recv, const std::vector<MdxSeg>& rsegs,
+                 hipStream_t stream) override {
+        NCCL_TRY(g_rccl.GroupStart());
+        for (const MdxSeg& s : ssegs)
+            if (s.nrows) NCCL_TRY(g_rccl.Send(send + s.row0, (size_t)s.nrows * 4, ncclFloat32, s.peer, comm, stream));
+        for (const MdxSeg& r : rsegs)
+            if (r.nrows) NCCL_TRY(g_rccl.Recv(recv + r.row0, (size_t)r.nrows * 4, ncclFloat32, r.peer, comm, stream));
+        NCCL_TRY(g_rccl.GroupEnd());
+        return MDX_OK;
+    }
+    int all_reduce(void* dev, size_t n, int kind, hipStream_t stream) override {
+        NCCL_TRY(g_rccl.AllReduce(dev, dev, n, kind == 0 ? ncclFloat64 : ncclUint32, kind == 0 ? ncclSum : ncclMax, comm, stream));
+        return MDX_OK;
+    }
+    int all_gather_u32(uint32_t mine, uint32_t* all, hipStream_t stream) override {
+        HIP_TRY(hipMemcpyAsync(d_words + world, &mine, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        NCCL_TRY(g_rccl.AllGather(d_words + world, d_words, 1, ncclUint32, comm, stream));
+        HIP_TRY(hipMemcpyAsync(all, d_words, sizeof(uint32_t) * world, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return MDX_OK;
+    }
+};
+}  // namespace
+
+MdxTransport* mdx_make_rccl_transport(const uint8_t* id128, int rank, int world, int device) {
+    if (!load_rccl()) return nullptr;
+    if (hipSetDevice(device) != hipSuccess) { mdx_set_error("hipSetDevice failed"); return nullptr; }
+    RcclTransport* t = new RcclTransport();
+    t->rank = rank; t->world = world;
+    ncclUniqueId id;
+    std::memcpy(id.internal, id128, 128);
+    const int r = g_rccl.CommInitRank(&t->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        mdx_set_error(std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+        t->comm = nullptr; delete t; return nullptr;
+    }
+    if (hipMalloc((void**)&t->d_words, sizeof(uint32_t) * (world + 1)) != hipSuccess) { mdx_set_error("hipMalloc failed"); delete t; return nullptr; }
+    return t;
+}
+
+extern "C" int mdx_comm_unique_id(uint8_t id[128]) {
+    if (!id) FAIL(MDX_EPARAM, "null argument");
+    if (!load_rccl()) return MDX_EDEVICE;
+    ncclUniqueId u;
+    NCCL_TRY(g_rccl.GetUniqueId(&u));
+    std::memcpy(id, u.internal, 128);
+    return MDX_OK;
+}
+
+// ---- in-process fabric ------------------------------------------------------------------------------------------
+struct mdx_fabric {
+    int world = 0;
+    std::mutex m; std::condition_variable cv;
+    int arrived = 0; uint64_t generation = 0; bool aborted = false;
+    struct Post { const float4* send = nullptr; const std::vector<MdxSeg>* ssegs = nullptr; const void* host = nullptr; uint32_t word = 0; };
+    std::vector<Post> post;
+    int taken = 0;
+    // returns false when the fabric was aborted (a rank failed: nobody may wait for it for ever)
+    bool barrier() {
+        std::unique_lock<std::mutex> lk(m);
+        if (aborted) return false;
+        const uint64_t gen = generation;
+        if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); return true; }
+        cv.wait(lk, [&] { return generation != gen || aborted; });
+        return !aborted;
+    }
+    void abort() { std::lock_guard<std::mutex> lk(m); aborted = true; cv.notify_all(); }
+};
+
+extern "C" mdx_fabric* mdx_fabric_create(int world) {
+    if (world < 1 || world > 64) { mdx_set_error("fabric world must be in 1..64"); return nullptr; }
+    mdx_fabric* f = new (std::nothrow) mdx_fabric();
+    if (!f) return nullptr;
+    f->world = world; f->post.resize(world);
+    return f;
+}
+extern "C" void mdx_fabric_destroy(mdx_fabric* f) { delete f; }
+extern "C" void mdx_fabric_abort(mdx_fabric* f) { if (f) f->abort(); }
+
+namespace {
+struct FabricTransport : MdxTransport {
+    mdx_fabric* f = nullptr;
+    const char* name() const override { return "in-process fabric"; }
+    int fail() { f->abort(); FAIL(MDX_EDEVICE, "in-process fabric: a rank failed or aborted"); }
+    int exchange(const float4* send, const std::vector<MdxSeg>& ssegs, float4* recv, const std::vector<MdxSeg>& rsegs,
+                 hipStream_t stream) override {
+        if (hipStreamSynchronize(stream) != hipSuccess) return fail();   // my rows are complete
+        f->post[rank].send = send; f->post[rank].ssegs = &ssegs;
+        if (!f->barrier()) return fail();
+        for (const MdxSeg& r : rsegs) {
+            if (!r.nrows) continue;
+            const mdx_fabric::Post& p = f->post[r.peer];
+            const MdxSeg* src = nullptr;
+            for (const MdxSeg& s : *p.ssegs) if (s.peer == rank) { src = &s; break; }
+            if (!src || src->nrows != r.nrows) { f->abort(); FAIL(MDX_EDEVICE, "in-process fabric: send / receive segment mismatch"); }
+            if (hipMemcpyAsync(recv + r.row0, p.send + src->row0, sizeof(float4) * r.nrows, hipMemcpyDefault, stream) != hipSuccess) return fail();
+        }
+        if (hipStreamSynchronize(stream) != hipSuccess) return fail();
+        if (!f->barrier()) return fail();                                 // peers may reuse their send buffers
+        return MDX_OK;
+    }
+    int all_reduce(void* dev, size_t n, int kind, hipStream_t stream) override {
+        if (n > 4096) FAIL(MDX_EPARAM, "fabric all_reduce is for small arrays");
+        const size_t bytes = n * (kind == 0 ? sizeof(double) : sizeof(uint32_t));
+        std::vector<unsigned char> mine(bytes), out(bytes);
+        if (hipMemcpyAsync(mine.data(), dev, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return fail();
+        f->post[rank].host = mine.data();
+        if (!f->barrier()) return fail();
+        for (size_t i = 0; i < n; ++i) {
+            if (kind == 0) { double s = 0.0; for (int q = 0; q < world; ++q) s += ((const double*)f->post[q].host)[i]; ((double*)out.data())[i] = s; }
+            else { uint32_t s = 0; for (int q = 0; q < world; ++q) s = std::max(s, ((const uint32_t*)f->post[q].host)[i]); ((uint32_t*)out.data())[i] = s; }
+        }
+        if (!f->barrier()) return fail();                                 // everybody has read everybody's input
+        if (hipMemcpyAsync(dev, out.data(), bytes, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return fail();
+        return MDX_OK;
+    }
+    int all_gather_u32(uint32_t mine, uint32_t* all, hipStream_t stream) override {
+        (void)stream;
+        f->post[rank].word = mine;
+        if (!f->barrier()) return fail();
+        for (int q = 0; q < world; ++q) all[q] = f->post[q].word;
+        if (!f->barrier()) return fail();
+        return MDX_OK;
+    }
+};
+
+struct NullTransport : MdxTransport {
+    const char* name() const override { return "null (delivers nothing)"; }
+    bool delivers() const override { return false; }
+    int exchange(const float4*, const std::vector<MdxSeg>&, float4*, const std::vector<MdxSeg>&, hipStream_t) override { return MDX_OK; }
+    int all_reduce(void*, size_t, int, hipStream_t) override { return MDX_OK; }
+    int all_gather_u32(uint32_t mine, uint32_t* all, hipStream_t) override { for (int q = 0; q < world; ++q) all[q] = mine; return MDX_OK; }
+};
+}  // namespace
+
+MdxTransport* mdx_make_fabric_transport(mdx_fabric* f, int rank) {
+    if (!f || rank < 0 || rank >= f->world) { mdx_set_error("bad fabric / rank"); return nullptr; }
+    FabricTransport* t = new FabricTransport();
+    t->f = f; t->rank = rank; t->world = f->world;
+    return t;
+}
+MdxTransport* mdx_make_null_transport(int rank, int world) {
+    NullTransport* t = new NullTransport();
+    t->rank = rank; t->world = world;
+    return t;
+}
+
+// ---- C ABI: attach a transport to a handle -----------------------------------------------------------------------
+extern "C" int mdx_comm_init(mdx_handle* h, const uint8_t id[128], int rank, int world) {
+    if (!h || !id) FAIL(MDX_EPARAM, "null argument");
+    if (world < 1 || world > 32 || rank < 0 || rank >= world) FAIL(MDX_EPARAM, "rank / world out of range (world <= 32)");
+    if (h->dd) FAIL(MDX_EPARAM, "the handle is already decomposed");
+    MdxTransport* t = mdx_make_rccl_transport(id, rank, world, h->device);
+    if (!t) return MDX_EDEVICE;
+    return mdx_dd_attach(h, t);
+}
+extern "C" int mdx_comm_init_fabric(mdx_handle* h, mdx_fabric* f, int rank) {
+    if (!h || !f) FAIL(MDX_EPARAM, "null argument");
+    if (h->dd) FAIL(MDX_EPARAM, "the handle is already decomposed");
+    if (f->world > 32) FAIL(MDX_EPARAM, "world <= 32");
+    MdxTransport* t = mdx_make_fabric_transport(f, rank);
+    if (!t) return MDX_EPARAM;
+    const int rc = mdx_dd_attach(h, t);
+    if (rc != MDX_OK) f->abort();
+    return rc;
+}
+extern "C" int mdx_comm_init_null(mdx_handle* h, int rank, int world) {
+    if (!h) FAIL(MDX_EPARAM, "null argument");
+    if (world < 1 || world > 32 || rank < 0 || rank >= world) FAIL(MDX_EPARAM, "rank / world out of range");
+    if (h->dd) FAIL(MDX_EPARAM, "the handle is already decomposed");
+    return mdx_dd_attach(h, mdx_make_null_transport(rank, world));
+}

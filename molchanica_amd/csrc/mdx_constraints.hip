@@ -187,6 +187,7 @@ __global__ void vsite_construct_kernel(uint32_t n, const VSite* __restrict__ vs,
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const VSite v = vs[i];
+    if (v.site == MDX_INVALID) return;
     const float4 r0 = posq[v.p0], r1 = posq[v.p1], r2 = posq[v.p2];
     const float3 d1 = mimg3(make_float3(r1.x - r0.x, r1.y - r0.y, r1.z - r0.z), p);
     const float3 d2 = mimg3(make_float3(r2.x - r0.x, r2.y - r0.y, r2.z - r0.z), p);
@@ -203,6 +204,7 @@ __global__ void vsite_spread_kernel(uint32_t n, const VSite* __restrict__ vs, fl
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const VSite v = vs[i];
+    if (v.site == MDX_INVALID) return;
     const float4 fm = force[v.site];
     const float w0 = 1.0f - v.a - v.b;
     float4 f0 = force[v.p0], f1 = force[v.p1], f2 = force[v.p2];
@@ -213,11 +215,18 @@ __global__ void vsite_spread_kernel(uint32_t n, const VSite* __restrict__ vs, fl
     force[v.site] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// On a decomposed handle (slot_flags given) a cluster is solved by the rank that OWNS it (ownership goes by cluster, so
+// its first atom decides); everywhere else - absent, or present as ghosts whose positions arrive by halo message - the
+// record is emptied.
 __global__ void remap_groups_kernel(uint32_t n, const ConsGroup* __restrict__ go, const uint32_t* __restrict__ slot_of,
-                                    ConsGroup* __restrict__ gs, uint32_t* err) {
+                                    ConsGroup* __restrict__ gs, uint32_t* err, const uint8_t* __restrict__ slot_flags) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     ConsGroup g = go[i];
+    if (slot_flags) {
+        const uint32_t s0 = slot_of[g.atom[0]];
+        if (s0 == MDX_INVALID || !(slot_flags[s0] & 2u)) { g.natoms = 0; g.ncons = 0; gs[i] = g; return; }
+    }
     for (uint32_t k = 0; k < g.natoms; ++k) {
         const uint32_t s = slot_of[g.atom[k]];
         if (s == MDX_INVALID) atomicOr(err, 8u);
@@ -227,10 +236,14 @@ __global__ void remap_groups_kernel(uint32_t n, const ConsGroup* __restrict__ go
 }
 
 __global__ void remap_vsites_kernel(uint32_t n, const VSite* __restrict__ vo, const uint32_t* __restrict__ slot_of,
-                                    VSite* __restrict__ vs, uint32_t* err) {
+                                    VSite* __restrict__ vs, uint32_t* err, const uint8_t* __restrict__ slot_flags) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     VSite v = vo[i];
+    if (slot_flags) {   // decomposed handle: the owner of the family constructs the site and spreads its force
+        const uint32_t s0 = slot_of[v.p0];
+        if (s0 == MDX_INVALID || !(slot_flags[s0] & 2u)) { v.site = MDX_INVALID; vs[i] = v; return; }
+    }
     v.site = slot_of[v.site]; v.p0 = slot_of[v.p0]; v.p1 = slot_of[v.p1]; v.p2 = slot_of[v.p2];
     if (v.site == MDX_INVALID || v.p0 == MDX_INVALID || v.p1 == MDX_INVALID || v.p2 == MDX_INVALID) atomicOr(err, 8u);
     vs[i] = v;
@@ -290,6 +303,7 @@ int mdx_build_constraints(mdx_handle* h, const mdx_system* s) {
             g.ncons++;
         }
         h->n_groups = (uint32_t)groups.size();
+        h->h_groups = groups;
         if (h->d.cons_o) (void)hipFree(h->d.cons_o);
         if (h->d.cons_s) (void)hipFree(h->d.cons_s);
         HIP_TRY(hipMalloc((void**)&h->d.cons_o, sizeof(ConsGroup) * groups.size()));
@@ -319,6 +333,7 @@ int mdx_build_constraints(mdx_handle* h, const mdx_system* s) {
                 FAIL(MDX_EPARAM, "a virtual site must be flagged MDX_ATOM_STATIC (it is massless and never integrated)");
             vs[i] = v;
         }
+        h->h_vsites = vs;
         if (h->d.vsite_o) (void)hipFree(h->d.vsite_o);
         if (h->d.vsite_s) (void)hipFree(h->d.vsite_s);
         HIP_TRY(hipMalloc((void**)&h->d.vsite_o, sizeof(VSite) * vs.size()));
@@ -332,10 +347,10 @@ int mdx_build_constraints(mdx_handle* h, const mdx_system* s) {
 int mdx_remap_constraints(mdx_handle* h) {
     if (h->n_groups)
         hipLaunchKernelGGL(remap_groups_kernel, dim3(div_up(h->n_groups, 256)), dim3(256), 0, h->stream, h->n_groups,
-                           h->d.cons_o, h->d.slot_of, h->d.cons_s, h->d.flags_dev);
+                           h->d.cons_o, h->d.slot_of, h->d.cons_s, h->d.flags_dev, (h->dd || h->n_local != h->N) ? h->d.slot_flags : nullptr);
     if (h->n_vsites)
         hipLaunchKernelGGL(remap_vsites_kernel, dim3(div_up(h->n_vsites, 256)), dim3(256), 0, h->stream, h->n_vsites,
-                           h->d.vsite_o, h->d.slot_of, h->d.vsite_s, h->d.flags_dev);
+                           h->d.vsite_o, h->d.slot_of, h->d.vsite_s, h->d.flags_dev, (h->dd || h->n_local != h->N) ? h->d.slot_flags : nullptr);
     HIP_TRY(hipGetLastError());
     return MDX_OK;
 }

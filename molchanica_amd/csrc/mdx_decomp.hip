@@ -1,0 +1,564 @@
+// mdx_decomp.hip — spatial domain decomposition of one periodic box over the GPUs of a node, below the C ABI
+// (the reference is single-device, /root/reference src/util.rs:1086, so this is new capability).
+//
+//   * The box is cut into px x py x pz bricks (2 -> 2x1x1, 4 -> 2x2x1, 8 -> 2x2x2: with periodic wrap every rank of a
+//     2x2x2 grid has exactly 7 peers = the 7 xGMI links of an MI355X).  Every rank holds one handle created from the
+//     GLOBAL system: static per-atom data and topology are replicated (288 GB of HBM make that free), only dynamic
+//     state is distributed.
+//   * A rank integrates the atoms it OWNS and keeps GHOST copies of every other atom within halo = r_list + margin
+//     (+ the reach of a constraint cluster) of its brick, shifted into its own frame: a cut dimension is not periodic
+//     locally.  Ownership is decided per constraint cluster / virtual-site family (by the position of its first atom),
+//     so SHAKE, RATTLE and the construction / force spreading of virtual sites never cross a rank boundary.
+//   * Per step: drift (+ SHAKE, + virtual sites) -> pack -> ONE group of ncclSend / ncclRecv on the communication
+//     stream -> unpack -> forces.  A pair with at least one owned atom is evaluated on every rank that owns one of its
+//     atoms, so no force message travels back.  The "list went stale" word of every rank rides on the message (each
+//     peer's segment ends with a flag row), so all ranks stop at the same step without a separate collective.
+//   * A stale list is rebuilt LOCALLY while the owned + ghost set is still complete (no atom further than margin/2 from
+//     where it was at the last repartition: one small all-reduce decides, the same way on every rank); otherwise the
+//     ranks REPARTITION: every rank's owned rows are gathered everywhere (one group of sends/receives: each rank's block
+//     goes straight to its 7 peers) and every rank re-derives owners, ghosts, image shifts and both halo lists from the
+//     same data with the same arithmetic, so no index list is ever exchanged.
+// All partition arithmetic runs in device kernels in fp32 and is bit-identical on every rank.
+#include "mdx_comm.h"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+#define FAIL(code, msg) do { mdx_set_error(msg); return (code); } while (0)
+static inline unsigned div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+int mdx_exclusive_scan_u32_ex(mdx_handle* h, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums);   // mdx_grid.hip
+int mdx_set_local_atoms_impl(mdx_handle* h, uint32_t n_local, const uint32_t* d_gid, const uint8_t* d_ghost, const float* d_pos4,
+                             const float* d_vel4, const float lo[3], const float hi[3], int32_t periodic);     // mdx_api.hip
+
+#define DD_MAX_WORLD 32
+
+struct DdPart {
+    float lo[3], len[3];
+    int grid[3], coord[3];
+    int rank, world;
+    float halo;
+};
+
+__device__ __forceinline__ float dd_wrap1(float x, float lo, float L) {
+    float t = x - floorf((x - lo) / L) * L;
+    if (t < lo) t += L;
+    if (t >= lo + L) t -= L;
+    return t;
+}
+__device__ __forceinline__ int dd_owner(const DdPart& p, float x, float y, float z) {
+    const float v[3] = {x, y, z};
+    int c[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        int k = (int)floorf((v[d] - p.lo[d]) / p.len[d] * (float)p.grid[d]);
+        c[d] = min(max(k, 0), p.grid[d] - 1);
+    }
+    return (c[0] * p.grid[1] + c[1]) * p.grid[2] + c[2];
+}
+// Is the (wrapped) point inside brick `c` widened by the halo, under one of the images k = -1, 0, +1 of every cut
+// dimension?  code: (kx + 1) | (ky + 1) << 2 | (kz + 1) << 4 of the first image that is.
+__device__ __forceinline__ bool dd_in_halo(const DdPart& p, const int c[3], float x, float y, float z, uint32_t* code) {
+    const float v[3] = {x, y, z};
+    uint32_t cd = 1u | (1u << 2) | (1u << 4);
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (p.grid[d] == 1) continue;
+        const float blo = p.lo[d] + p.len[d] * (float)c[d] / (float)p.grid[d];
+        const float bhi = p.lo[d] + p.len[d] * (float)(c[d] + 1) / (float)p.grid[d];
+        const float lo_h = blo - p.halo, hi_h = bhi + p.halo;
+        int kk = 2;
+#pragma unroll
+        for (int k = -1; k <= 1; ++k) {
+            const float xs = v[d] + (float)k * p.len[d];
+            if (kk == 2 && xs >= lo_h && xs < hi_h) kk = k;
+        }
+        if (kk == 2) ok = false;
+        else cd = (cd & ~(3u << (2 * d))) | ((uint32_t)(kk + 1) << (2 * d));
+    }
+    *code = cd;
+    return ok;
+}
+
+// one pass over the global state: owner, class here, image code, and - for owned atoms - the peers that keep a ghost
+__global__ __launch_bounds__(256) void dd_classify_kernel(uint32_t N, const float4* __restrict__ g_pos, const uint32_t* __restrict__ anchor,
+                                                          DdPart p, uint8_t* __restrict__ cls, uint8_t* __restrict__ owner,
+                                                          uint8_t* __restrict__ shift_code, uint32_t* __restrict__ send_mask,
+                                                          uint32_t* __restrict__ flags, uint32_t* __restrict__ err) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    const float4 pa = g_pos[anchor[g]], pg = g_pos[g];
+    const int own = dd_owner(p, dd_wrap1(pa.x, p.lo[0], p.len[0]), dd_wrap1(pa.y, p.lo[1], p.len[1]), dd_wrap1(pa.z, p.lo[2], p.len[2]));
+    const float x = dd_wrap1(pg.x, p.lo[0], p.len[0]), y = dd_wrap1(pg.y, p.lo[1], p.len[1]), z = dd_wrap1(pg.z, p.lo[2], p.len[2]);
+    uint32_t code;
+    const bool here = dd_in_halo(p, p.coord, x, y, z, &code);
+    const bool mine = own == p.rank;
+    if (mine && !here) atomicOr(err, 1u);      // an owned atom outside its own halo region: the halo is thinner than the cluster reach
+    const uint32_t c = mine ? 1u : (here ? 2u : 0u);
+    uint32_t mask = 0;
+    if (mine) {
+        for (int q = 0; q < p.world; ++q) {
+            if (q == p.rank) continue;
+            const int cq[3] = {q / (p.grid[1] * p.grid[2]), (q / p.grid[2]) % p.grid[1], q % p.grid[2]};
+            uint32_t dummy;
+            if (dd_in_halo(p, cq, x, y, z, &dummy)) mask |= 1u << q;
+        }
+    }
+    cls[g] = (uint8_t)c; owner[g] = (uint8_t)own; shift_code[g] = (uint8_t)code; send_mask[g] = mask;
+    // compaction flags: segment 2q = "send to q", 2q + 1 = "received from q", 2W = local, 2W + 1 = owned
+    const size_t Ns = N;
+    for (int q = 0; q < p.world; ++q) {
+        flags[(size_t)(2 * q) * Ns + g] = (mask >> q) & 1u;
+        flags[(size_t)(2 * q + 1) * Ns + g] = (c == 2u && own == q) ? 1u : 0u;
+    }
+    flags[(size_t)(2 * p.world) * Ns + g] = c != 0u;
+    flags[(size_t)(2 * p.world + 1) * Ns + g] = c == 1u;
+}
+
+struct DdFill {
+    uint32_t seg_start[2 * DD_MAX_WORLD + 3];   // scan value at the head of every segment (+ the grand total)
+    uint32_t send_base[DD_MAX_WORLD], recv_base[DD_MAX_WORLD];   // first row of a peer's segment in the halo buffers
+};
+
+__global__ __launch_bounds__(256) void dd_fill_kernel(uint32_t N, int world, DdPart p, DdFill f, const uint32_t* __restrict__ flags,
+                                                      const uint32_t* __restrict__ scan, const float4* __restrict__ g_pos,
+                                                      const float4* __restrict__ g_vel, const uint8_t* __restrict__ cls,
+                                                      const uint8_t* __restrict__ shift_code, uint32_t* __restrict__ send_ids,
+                                                      uint32_t* __restrict__ recv_ids, float4* __restrict__ recv_shift,
+                                                      uint32_t* __restrict__ gid_local, uint8_t* __restrict__ ghost_local,
+                                                      float4* __restrict__ pos_l, float4* __restrict__ vel_l, uint32_t* __restrict__ owned_gid) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int seg = blockIdx.y;
+    if (g >= N) return;
+    const size_t idx = (size_t)seg * N + g;
+    if (!flags[idx]) return;
+    const uint32_t k = scan[idx] - f.seg_start[seg];
+    const uint32_t code = shift_code[g];
+    const float sx = (float)((int)(code & 3u) - 1) * p.len[0], sy = (float)((int)((code >> 2) & 3u) - 1) * p.len[1],
+                sz = (float)((int)((code >> 4) & 3u) - 1) * p.len[2];
+    if (seg < 2 * world) {
+        const int q = seg >> 1;
+        if (!(seg & 1)) send_ids[f.send_base[q] + k] = g;
+        else { recv_ids[f.recv_base[q] + k] = g; recv_shift[f.recv_base[q] + k] = make_float4(sx, sy, sz, 0.f); }
+    } else if (seg == 2 * world) {
+        const float4 pg = g_pos[g];
+        gid_local[k] = g; ghost_local[k] = cls[g] == 2 ? 1 : 0;
+        pos_l[k] = make_float4(dd_wrap1(pg.x, p.lo[0], p.len[0]) + sx, dd_wrap1(pg.y, p.lo[1], p.len[1]) + sy,
+                               dd_wrap1(pg.z, p.lo[2], p.len[2]) + sz, 0.f);
+        vel_l[k] = g_vel[g];
+    } else owned_gid[k] = g;
+}
+
+__global__ void dd_seg_heads_kernel(int nseg, uint32_t N, const uint32_t* __restrict__ scan, uint32_t* __restrict__ out) {
+    const int s = threadIdx.x;
+    if (s <= nseg) out[s] = scan[(size_t)s * N];
+}
+
+// owned rows of the global gather: (x, y, z, global id), (vx, vy, vz, -)[, (fx, fy, fz, -)]
+__global__ __launch_bounds__(256) void dd_gather_pack_kernel(uint32_t n_owned, int rows, const uint32_t* __restrict__ owned_gid,
+                                                             const uint32_t* __restrict__ slot_of, const float4* __restrict__ posq,
+                                                             const float4* __restrict__ vel, const float4* __restrict__ force,
+                                                             float4* __restrict__ out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_owned) return;
+    const uint32_t g = owned_gid[k], s = slot_of[g];
+    float4 p = posq[s]; p.w = __uint_as_float(g);
+    out[(size_t)rows * k] = p;
+    out[(size_t)rows * k + 1] = vel[s];
+    if (rows == 3) out[(size_t)rows * k + 2] = force[s];
+}
+__global__ __launch_bounds__(256) void dd_gather_scatter_kernel(uint32_t n, int rows, const float4* __restrict__ in, float4* __restrict__ g_pos,
+                                                                float4* __restrict__ g_vel, float4* __restrict__ g_frc, uint32_t N,
+                                                                uint32_t* __restrict__ err) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    float4 p = in[(size_t)rows * k];
+    const uint32_t g = __float_as_uint(p.w);
+    if (g >= N) { atomicOr(err, 2u); return; }
+    p.w = 0.f;
+    g_pos[g] = p;
+    float4 v = in[(size_t)rows * k + 1]; v.w = 0.f;
+    g_vel[g] = v;
+    if (rows == 3) g_frc[g] = in[(size_t)rows * k + 2];
+}
+
+// largest squared displacement of a local atom since the last repartition (uncut dimensions stay periodic inside the engine)
+__global__ __launch_bounds__(256) void dd_drift_kernel(uint32_t n_local, const uint32_t* __restrict__ gid_local, const uint32_t* __restrict__ slot_of,
+                                                       const float4* __restrict__ posq, const float4* __restrict__ pos_at_part, DdPart p,
+                                                       uint32_t* __restrict__ out_bits) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float d2 = 0.f;
+    if (i < n_local) {
+        const uint32_t s = slot_of[gid_local[i]];
+        if (s != MDX_INVALID) {
+            const float4 a = posq[s], b = pos_at_part[i];
+            float d[3] = {a.x - b.x, a.y - b.y, a.z - b.z};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) if (p.grid[k] == 1) d[k] -= rintf(d[k] / p.len[k]) * p.len[k];
+            d2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+            if (!(d2 < 1.0e30f)) d2 = 3.0e38f;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, m));
+    if ((threadIdx.x & 63) == 0 && d2 > 0.f) atomicMax(out_bits, __float_as_uint(d2));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+static void process_grid(int world, int g[3]) {
+    if (world == 1) { g[0] = g[1] = g[2] = 1; return; }
+    if (world == 2) { g[0] = 2; g[1] = 1; g[2] = 1; return; }
+    if (world == 4) { g[0] = 2; g[1] = 2; g[2] = 1; return; }
+    if (world == 8) { g[0] = 2; g[1] = 2; g[2] = 2; return; }
+    int v[3] = {1, 1, 1};
+    int n = world;
+    for (int f = 2; n > 1; ++f)
+        while (n % f == 0) { int m = 0; for (int d = 1; d < 3; ++d) if (v[d] < v[m]) m = d; v[m] *= f; n /= f; }
+    std::sort(v, v + 3, [](int a, int b) { return a > b; });
+    g[0] = v[0]; g[1] = v[1]; g[2] = v[2];
+}
+
+template <typename T>
+static int dd_alloc(T** p, size_t n) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    HIP_TRY(hipMalloc((void**)p, std::max<size_t>(sizeof(T) * n, 16)));
+    return MDX_OK;
+}
+
+static DdPart make_part(const MdxDecomp* dd) {
+    DdPart p{};
+    for (int d = 0; d < 3; ++d) { p.lo[d] = dd->box_lo[d]; p.len[d] = dd->box_len[d]; p.grid[d] = dd->grid[d]; p.coord[d] = dd->coord[d]; }
+    p.rank = dd->rank; p.world = dd->world; p.halo = dd->halo;
+    return p;
+}
+
+// Owners, ghosts, image shifts and both halo lists from g_pos / g_vel; the engine is told its new local atom set.
+static int dd_partition(mdx_handle* h) {
+    MdxDecomp* dd = h->dd;
+    const uint32_t N = h->N; const int W = dd->world;
+    hipStream_t st = h->stream;
+    const DdPart p = make_part(dd);
+    const int nseg = 2 * W + 2;
+    const size_t nflags = (size_t)nseg * N + 1;
+    if (nflags > 0xFFFFFFF0ull) FAIL(MDX_EPARAM, "system too large for the partition scan");
+    if (nflags > dd->cap_flags) {
+        MDX_TRY(dd_alloc(&dd->flags, nflags)); MDX_TRY(dd_alloc(&dd->scan, nflags));
+        MDX_TRY(dd_alloc(&dd->scan_sums, nflags / 2048 + 64));
+        dd->cap_flags = nflags;
+    }
+    HIP_TRY(hipMemsetAsync(h->d.flags_dev, 0, sizeof(uint32_t) * 4, st));
+    HIP_TRY(hipMemsetAsync(dd->flags + (nflags - 1), 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(dd_classify_kernel, dim3(div_up(N, 256)), dim3(256), 0, st, N, dd->g_pos, dd->anchor, p, dd->cls, dd->owner,
+                       dd->shift_code, dd->send_mask, dd->flags, h->d.flags_dev);
+    MDX_TRY(mdx_exclusive_scan_u32_ex(h, dd->flags, dd->scan, (uint32_t)nflags, dd->scan_sums));
+    uint32_t* d_heads = (uint32_t*)dd->red;     // 64 doubles = 128 words of scratch
+    hipLaunchKernelGGL(dd_seg_heads_kernel, dim3(1), dim3(128), 0, st, nseg, N, dd->scan, d_heads);
+    uint32_t heads[2 * DD_MAX_WORLD + 3], err[4];
+    HIP_TRY(hipMemcpyAsync(heads, d_heads, sizeof(uint32_t) * (nseg + 1), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(err, h->d.flags_dev, sizeof(err), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (err[0] & 1u) FAIL(MDX_EPARAM, "decomposition: an owned atom lies outside its rank's halo region (constraint cluster larger than the halo allows)");
+    DdFill f{};
+    for (int s = 0; s <= nseg; ++s) f.seg_start[s] = heads[s];
+    dd->send_segs.clear(); dd->recv_segs.clear();
+    uint32_t s0 = 0, r0 = 0;
+    for (int q = 0; q < W; ++q) {
+        if (q == dd->rank) continue;
+        const uint32_t ns = heads[2 * q + 1] - heads[2 * q], nr = heads[2 * q + 2] - heads[2 * q + 1];
+        f.send_base[q] = s0; f.recv_base[q] = r0;
+        dd->send_segs.push_back({q, s0, ns + 1}); dd->recv_segs.push_back({q, r0, nr + 1});   // + the flag row
+        s0 += ns + 1; r0 += nr + 1;
+    }
+    dd->n_send = s0; dd->n_recv = r0;
+    dd->n_local = heads[2 * W + 1] - heads[2 * W];
+    dd->n_owned = heads[2 * W + 2] - heads[2 * W + 1];
+    if (dd->n_local == 0) FAIL(MDX_EPARAM, "decomposition: a rank received no atoms (empty brick)");
+    if (s0 > dd->cap_send) { dd->cap_send = s0 + s0 / 4 + 64; MDX_TRY(dd_alloc(&dd->send_ids, dd->cap_send)); MDX_TRY(dd_alloc(&dd->send_buf, dd->cap_send)); }
+    if (r0 > dd->cap_recv) {
+        dd->cap_recv = r0 + r0 / 4 + 64;
+        MDX_TRY(dd_alloc(&dd->recv_ids, dd->cap_recv)); MDX_TRY(dd_alloc(&dd->recv_buf, dd->cap_recv)); MDX_TRY(dd_alloc(&dd->recv_shift, dd->cap_recv));
+    }
+    if (s0) HIP_TRY(hipMemsetAsync(dd->send_ids, 0xFF, sizeof(uint32_t) * s0, st));
+    if (r0) { HIP_TRY(hipMemsetAsync(dd->recv_ids, 0xFF, sizeof(uint32_t) * r0, st)); HIP_TRY(hipMemsetAsync(dd->recv_shift, 0, sizeof(float4) * r0, st)); }
+    hipLaunchKernelGGL(dd_fill_kernel, dim3(div_up(N, 256), nseg), dim3(256), 0, st, N, W, p, f, dd->flags, dd->scan, dd->g_pos, dd->g_vel,
+                       dd->cls, dd->shift_code, dd->send_ids, dd->recv_ids, dd->recv_shift, dd->gid_local, dd->ghost_local, dd->pos_l,
+                       dd->vel_l, dd->owned_gid);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(dd->pos_at_part, dd->pos_l, sizeof(float4) * dd->n_local, hipMemcpyDeviceToDevice, st));
+    // the local region: brick + halo (+ a little room) in cut dimensions, the whole box in the others
+    float lo[3], hi[3];
+    int per_mask = 0x10;
+    for (int d = 0; d < 3; ++d) {
+        if (dd->grid[d] > 1) { lo[d] = dd->brick_lo[d] - dd->halo - 1.0f; hi[d] = dd->brick_hi[d] + dd->halo + 1.0f; }
+        else { lo[d] = dd->box_lo[d]; hi[d] = dd->box_lo[d] + dd->box_len[d]; per_mask |= 1 << d; }
+    }
+    MDX_TRY(mdx_set_local_atoms_impl(h, dd->n_local, dd->gid_local, dd->ghost_local, (const float*)dd->pos_l, (const float*)dd->vel_l,
+                                     lo, hi, per_mask));
+    dd->repartitions++;
+    dd->local_rebuilds_since = 0;
+    return MDX_OK;
+}
+
+int mdx_dd_gather_global(mdx_handle* h, bool with_force) {
+    MdxDecomp* dd = h->dd;
+    hipStream_t st = h->stream;
+    const int W = dd->world, R = with_force ? 3 : 2;
+    const uint32_t N = h->N;
+    if (!h->in_slot_space) MDX_TRY(mdx_rebuild(h));
+    if ((size_t)R * dd->n_owned > dd->cap_gat_send) { dd->cap_gat_send = (size_t)3 * dd->n_owned + 1024; MDX_TRY(dd_alloc(&dd->gat_send, dd->cap_gat_send)); }
+    if ((size_t)R * N > dd->cap_gat_recv) { dd->cap_gat_recv = (size_t)3 * N; MDX_TRY(dd_alloc(&dd->gat_recv, dd->cap_gat_recv)); }
+    if (with_force && !dd->g_frc) MDX_TRY(dd_alloc(&dd->g_frc, N));
+    hipLaunchKernelGGL(dd_gather_pack_kernel, dim3(div_up(std::max(dd->n_owned, 1u), 256)), dim3(256), 0, st, dd->n_owned, R, dd->owned_gid,
+                       h->d.slot_of, h->d.posq, h->d.vel, h->d.force, dd->gat_send);
+    uint32_t counts[DD_MAX_WORLD];
+    MDX_TRY(dd->tr->all_gather_u32(dd->n_owned, counts, st));
+    if (!dd->tr->delivers()) {   // one rank of N alone: the others' rows keep their last known values
+        hipLaunchKernelGGL(dd_gather_scatter_kernel, dim3(div_up(std::max(dd->n_owned, 1u), 256)), dim3(256), 0, st, dd->n_owned, R, dd->gat_send,
+                           dd->g_pos, dd->g_vel, dd->g_frc, N, h->d.flags_dev);
+        HIP_TRY(hipGetLastError());
+        return MDX_OK;
+    }
+    uint64_t tot = 0;
+    std::vector<MdxSeg> ss, rs;
+    uint32_t my_off = 0;
+    for (int q = 0; q < W; ++q) {
+        if (q == dd->rank) my_off = (uint32_t)tot;
+        else { ss.push_back({q, 0u, (uint32_t)R * dd->n_owned}); rs.push_back({q, (uint32_t)(R * tot), (uint32_t)R * counts[q]}); }
+        tot += counts[q];
+    }
+    if (tot != N) FAIL(MDX_EDEVICE, "decomposition: the ranks' owned atoms do not add up to the system (an atom was lost or duplicated)");
+    HIP_TRY(hipMemcpyAsync(dd->gat_recv + (size_t)R * my_off, dd->gat_send, sizeof(float4) * R * dd->n_owned, hipMemcpyDeviceToDevice, st));
+    MDX_TRY(dd->tr->exchange(dd->gat_send, ss, dd->gat_recv, rs, st));
+    HIP_TRY(hipMemsetAsync(h->d.flags_dev, 0, sizeof(uint32_t) * 4, st));
+    hipLaunchKernelGGL(dd_gather_scatter_kernel, dim3(div_up(N, 256)), dim3(256), 0, st, N, R, dd->gat_recv, dd->g_pos, dd->g_vel, dd->g_frc, N,
+                       h->d.flags_dev);
+    HIP_TRY(hipGetLastError());
+    return MDX_OK;
+}
+
+int mdx_dd_allreduce_host(mdx_handle* h, double* v, int n, bool max_u32) {
+    MdxDecomp* dd = h->dd;
+    if (!dd || dd->world == 1 || n <= 0) return MDX_OK;
+    if (n > 64) FAIL(MDX_EPARAM, "internal: small all-reduce only");
+    hipStream_t st = h->stream;
+    if (max_u32) {
+        uint32_t w[64];
+        for (int k = 0; k < n; ++k) w[k] = (uint32_t)v[k];
+        HIP_TRY(hipMemcpyAsync(dd->red, w, sizeof(uint32_t) * n, hipMemcpyHostToDevice, st));
+        MDX_TRY(dd->tr->all_reduce(dd->red, n, 1, st));
+        HIP_TRY(hipMemcpyAsync(w, dd->red, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int k = 0; k < n; ++k) v[k] = (double)w[k];
+    } else {
+        HIP_TRY(hipMemcpyAsync(dd->red, v, sizeof(double) * n, hipMemcpyHostToDevice, st));
+        MDX_TRY(dd->tr->all_reduce(dd->red, n, 0, st));
+        HIP_TRY(hipMemcpyAsync(v, dd->red, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return MDX_OK;
+}
+
+// ---- per-step halo ------------------------------------------------------------------------------------------------
+int mdx_dd_halo_begin(mdx_handle* h) {
+    MdxDecomp* dd = h->dd;
+    if (dd->world == 1) return MDX_OK;
+    const int fw = dd->halo_step >= 0 ? dd->halo_step + 1 : -1;
+    MDX_TRY(mdx_pack_positions(h, dd->send_ids, dd->n_send, (float*)dd->send_buf, fw));
+    HIP_TRY(hipEventRecord(dd->ev_packed, h->stream));
+    HIP_TRY(hipStreamWaitEvent(dd->comm_stream, dd->ev_packed, 0));
+    MDX_TRY(dd->tr->exchange(dd->send_buf, dd->send_segs, dd->recv_buf, dd->recv_segs, dd->comm_stream));
+    HIP_TRY(hipEventRecord(dd->ev_arrived, dd->comm_stream));
+    return MDX_OK;
+}
+
+int mdx_dd_halo_end(mdx_handle* h) {
+    MdxDecomp* dd = h->dd;
+    if (dd->world == 1) return MDX_OK;
+    const int fw = dd->halo_step >= 0 ? dd->halo_step + 1 : -1;
+    HIP_TRY(hipStreamWaitEvent(h->stream, dd->ev_arrived, 0));
+    if (dd->tr->delivers())
+        MDX_TRY(mdx_unpack_positions(h, dd->recv_ids, dd->n_recv, (const float*)dd->recv_buf, (const float*)dd->recv_shift, fw));
+    return MDX_OK;
+}
+
+// ---- stale list: local rebuild or repartition (the same branch on every rank) --------------------------------------
+static int dd_local_set_still_valid(mdx_handle* h, bool* valid) {
+    MdxDecomp* dd = h->dd;
+    *valid = true;
+    if (dd->world == 1) return MDX_OK;
+    *valid = false;
+    if (dd->margin <= 0.f || dd->local_rebuilds_since >= 256) { /* still a collective below: every rank takes this path alike */ }
+    hipStream_t st = h->stream;
+    uint32_t* bits = (uint32_t*)dd->red;
+    HIP_TRY(hipMemsetAsync(bits, 0, sizeof(uint32_t), st));
+    if (h->in_slot_space)
+        hipLaunchKernelGGL(dd_drift_kernel, dim3(div_up(dd->n_local, 256)), dim3(256), 0, st, dd->n_local, dd->gid_local, h->d.slot_of,
+                           h->d.posq, dd->pos_at_part, make_part(dd), bits);
+    MDX_TRY(dd->tr->all_reduce(bits, 1, 1, st));
+    uint32_t b = 0;
+    HIP_TRY(hipMemcpyAsync(&b, bits, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float d2; std::memcpy(&d2, &b, 4);
+    *valid = dd->margin > 0.f && dd->local_rebuilds_since < 256 && std::sqrt(d2) <= 0.5f * dd->margin - 0.05f;
+    return MDX_OK;
+}
+
+static int dd_repartition(mdx_handle* h) {
+    MdxDecomp* dd = h->dd;
+    const auto t0 = std::chrono::steady_clock::now();
+    MDX_TRY(mdx_dd_gather_global(h, false));
+    MDX_TRY(dd_partition(h));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    dd->repartition_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MDX_OK;
+}
+
+int mdx_dd_on_stale(mdx_handle* h) {
+    MdxDecomp* dd = h->dd;
+    bool valid = true;
+    MDX_TRY(dd_local_set_still_valid(h, &valid));
+    if (valid) { dd->local_rebuilds++; dd->local_rebuilds_since++; h->list_valid = false; }
+    else MDX_TRY(dd_repartition(h));
+    return mdx_rebuild(h);
+}
+
+// ---- collective read-back -------------------------------------------------------------------------------------------
+int mdx_dd_download(mdx_handle* h, int which, float* dst) {
+    MdxDecomp* dd = h->dd;
+    if (which == MDX_FORCE) MDX_TRY(mdx_ensure_ready(h));
+    MDX_TRY(mdx_dd_gather_global(h, which == MDX_FORCE));
+    const uint32_t N = h->N;
+    std::vector<float4> hb(N);
+    const float4* src = which == MDX_POS ? dd->g_pos : (which == MDX_VEL ? dd->g_vel : dd->g_frc);
+    HIP_TRY(hipMemcpyAsync(hb.data(), src, sizeof(float4) * N, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (uint32_t i = 0; i < N; ++i) {
+        float v[3] = {hb[i].x, hb[i].y, hb[i].z};
+        if (which == MDX_POS)      // back from the owner's frame into the box
+            for (int d = 0; d < 3; ++d) {
+                const float lo = dd->box_lo[d], L = dd->box_len[d];
+                float t = v[d] - std::floor((v[d] - lo) / L) * L;
+                if (t < lo) t += L;
+                if (t >= lo + L) t -= L;
+                v[d] = t;
+            }
+        dst[3 * i] = v[0]; dst[3 * i + 1] = v[1]; dst[3 * i + 2] = v[2];
+    }
+    return MDX_OK;
+}
+
+// ---- attach / destroy -------------------------------------------------------------------------------------------------
+void mdx_dd_destroy(mdx_handle* h) {
+    MdxDecomp* dd = h->dd;
+    if (!dd) return;
+    if (dd->comm_stream) (void)hipStreamSynchronize(dd->comm_stream);
+    void* ptrs[] = {dd->anchor, dd->g_pos, dd->g_vel, dd->g_frc, dd->cls, dd->owner, dd->shift_code, dd->send_mask, dd->flags, dd->scan,
+                    dd->scan_sums, dd->gid_local, dd->ghost_local, dd->pos_l, dd->vel_l, dd->pos_at_part, dd->owned_gid, dd->send_ids,
+                    dd->recv_ids, dd->recv_shift, dd->send_buf, dd->recv_buf, dd->gat_send, dd->gat_recv, dd->red};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (dd->ev_packed) (void)hipEventDestroy(dd->ev_packed);
+    if (dd->ev_arrived) (void)hipEventDestroy(dd->ev_arrived);
+    if (dd->comm_stream) (void)hipStreamDestroy(dd->comm_stream);
+    delete dd->tr;
+    delete dd;
+    h->dd = nullptr;
+}
+
+int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
+    auto bail = [&](int rc) { std::string keep = mdx_last_error(); if (!h->dd) delete tr; else mdx_dd_destroy(h); mdx_set_error(keep); return rc; };
+    if (!(h->per[0] && h->per[1] && h->per[2])) { mdx_set_error("spatial decomposition needs a fully periodic box"); return bail(MDX_EPARAM); }
+    if (h->n_local != h->N) { mdx_set_error("the handle already simulates a subset"); return bail(MDX_EPARAM); }
+    if (h->pme_on) { mdx_set_error("the SPME reciprocal sum is not supported on a decomposed handle"); return bail(MDX_EPARAM); }
+    if (h->alch_on) { mdx_set_error("alchemical windows are not supported on a decomposed handle"); return bail(MDX_EPARAM); }
+    if (h->baro_kind) { mdx_set_error("the barostat is not supported on a decomposed handle"); return bail(MDX_EPARAM); }
+    if (h->have_ext) { mdx_set_error("external forces are not supported on a decomposed handle"); return bail(MDX_EPARAM); }
+    if (hipSetDevice(h->device) != hipSuccess) { mdx_set_error("hipSetDevice failed"); return bail(MDX_EDEVICE); }
+    const uint32_t N = h->N;
+    MdxDecomp* dd = new MdxDecomp();
+    dd->tr = tr; dd->rank = tr->rank; dd->world = tr->world;
+    h->dd = dd;
+    process_grid(dd->world, dd->grid);
+    dd->coord[0] = dd->rank / (dd->grid[1] * dd->grid[2]); dd->coord[1] = (dd->rank / dd->grid[2]) % dd->grid[1]; dd->coord[2] = dd->rank % dd->grid[2];
+    for (int d = 0; d < 3; ++d) {
+        dd->box_lo[d] = h->box_lo[d]; dd->box_len[d] = h->box_hi[d] - h->box_lo[d];
+        dd->brick_lo[d] = dd->box_lo[d] + dd->box_len[d] * (float)dd->coord[d] / (float)dd->grid[d];
+        dd->brick_hi[d] = dd->box_lo[d] + dd->box_len[d] * (float)(dd->coord[d] + 1) / (float)dd->grid[d];
+    }
+    dd->r_list = h->r_list;
+    if (std::isinf(dd->r_list)) { mdx_set_error("spatial decomposition needs finite cut-offs"); return bail(MDX_EPARAM); }
+    // ownership anchors and the reach of a constraint cluster / virtual-site family from its anchor
+    std::vector<uint32_t> anchor(N);
+    for (uint32_t i = 0; i < N; ++i) anchor[i] = i;
+    double ext = 0.0;
+    for (const auto& g : h->h_groups) {
+        double dist[4][4];
+        for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) dist[a][b] = a == b ? 0.0 : 1e30;
+        for (uint32_t c = 0; c < g.ncons; ++c) { dist[g.ca[c]][g.cb[c]] = std::min(dist[g.ca[c]][g.cb[c]], (double)g.len[c]); dist[g.cb[c]][g.ca[c]] = dist[g.ca[c]][g.cb[c]]; }
+        for (int k = 0; k < 4; ++k) for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) dist[a][b] = std::min(dist[a][b], dist[a][k] + dist[k][b]);
+        for (uint32_t k = 0; k < g.natoms; ++k) { anchor[g.atom[k]] = g.atom[0]; if (dist[0][k] < 1e29) ext = std::max(ext, dist[0][k]); }
+    }
+    for (const auto& v : h->h_vsites) {   // a site follows its first parent (inside the parents' triangle: no extra reach)
+        const uint32_t a = anchor[v.p0];
+        anchor[v.site] = a; anchor[v.p1] = a; anchor[v.p2] = a;
+        if (!h->vsites_convex) ext = std::max(ext, 3.0);
+    }
+    if (!h->h_vsites.empty() && h->h_groups.empty()) ext = std::max(ext, 2.0);   // flexible parents: a bond length of room
+    dd->ext = (float)(ext * 1.05 + (ext > 0.0 ? 0.05 : 0.0));
+    // ghosts are kept out to r_list + margin (+ ext): atoms may then drift margin/2 before a rank can miss a neighbour
+    double room = 4.4;
+    for (int d = 0; d < 3; ++d)
+        if (dd->grid[d] > 1) room = std::min(room, (double)dd->box_len[d] * (1.0 - 1.0 / dd->grid[d]) / 2.0 - dd->r_list - dd->ext - 0.01);
+    {
+        const char* e = std::getenv("MDX_HALO_MARGIN");
+        if (e) room = std::min(room, std::max(0.0, std::atof(e)));
+    }
+    dd->margin = (float)std::max(0.0, room);
+    dd->halo = dd->r_list + dd->margin + dd->ext;
+    for (int d = 0; d < 3; ++d)
+        if (dd->grid[d] > 1 && dd->box_len[d] / dd->grid[d] + 2.0f * dd->halo > dd->box_len[d] + 1e-3f) {
+            mdx_set_error("decomposition: brick + 2 halo exceeds the box: an atom would be needed under two images (box too small for this many ranks)");
+            return bail(MDX_EPARAM);
+        }
+    {
+        const char* e = std::getenv("MDX_HALO_OVERLAP");
+        dd->overlap = !(e && e[0] == '0');
+    }
+    int rc = MDX_OK;
+#define DD_TRY(x) do { rc = (x); if (rc != MDX_OK) return bail(rc); } while (0)
+#define DD_HIP(x) do { if ((x) != hipSuccess) { mdx_set_error(#x " failed"); return bail(MDX_EDEVICE); } } while (0)
+    DD_TRY(dd_alloc(&dd->anchor, N)); DD_TRY(dd_alloc(&dd->g_pos, N)); DD_TRY(dd_alloc(&dd->g_vel, N));
+    DD_TRY(dd_alloc(&dd->cls, N)); DD_TRY(dd_alloc(&dd->owner, N)); DD_TRY(dd_alloc(&dd->shift_code, N)); DD_TRY(dd_alloc(&dd->send_mask, N));
+    DD_TRY(dd_alloc(&dd->gid_local, N)); DD_TRY(dd_alloc(&dd->ghost_local, N)); DD_TRY(dd_alloc(&dd->pos_l, N)); DD_TRY(dd_alloc(&dd->vel_l, N));
+    DD_TRY(dd_alloc(&dd->pos_at_part, N)); DD_TRY(dd_alloc(&dd->owned_gid, N)); DD_TRY(dd_alloc(&dd->red, 64));
+    dd->cap_local = N;
+    DD_HIP(hipStreamCreateWithFlags(&dd->comm_stream, hipStreamNonBlocking));
+    DD_HIP(hipEventCreateWithFlags(&dd->ev_packed, hipEventDisableTiming));
+    DD_HIP(hipEventCreateWithFlags(&dd->ev_arrived, hipEventDisableTiming));
+    DD_HIP(hipMemcpyAsync(dd->anchor, anchor.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice, h->stream));
+    DD_HIP(hipStreamSynchronize(h->stream));
+    // the global state every rank starts from is the handle's own (it was created from the whole system)
+    DD_TRY(mdx_unsort_state(h));
+    DD_HIP(hipMemcpyAsync(dd->g_pos, h->d.pos_orig, sizeof(float4) * N, hipMemcpyDeviceToDevice, h->stream));
+    DD_HIP(hipMemcpyAsync(dd->g_vel, h->d.vel_orig, sizeof(float4) * N, hipMemcpyDeviceToDevice, h->stream));
+    DD_TRY(dd_partition(h));
+    DD_TRY(mdx_rebuild(h));
+    h->forces_valid = false;
+#undef DD_TRY
+#undef DD_HIP
+    return MDX_OK;
+}
+
+// ---- C ABI: what a host may ask about the decomposition -------------------------------------------------------------
+extern "C" int mdx_comm_info(const mdx_handle* h, int* rank, int* world, int grid[3], uint32_t* n_owned, uint32_t* n_ghost, float* halo) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    const MdxDecomp* dd = h->dd;
+    if (rank) *rank = dd ? dd->rank : 0;
+    if (world) *world = dd ? dd->world : 1;
+    if (grid) for (int d = 0; d < 3; ++d) grid[d] = dd ? dd->grid[d] : 1;
+    if (n_owned) *n_owned = dd ? dd->n_owned : h->N;
+    if (n_ghost) *n_ghost = dd ? dd->n_local - dd->n_owned : 0;
+    if (halo) *halo = dd ? dd->halo : 0.f;
+    return MDX_OK;
+}

@@ -10,7 +10,7 @@
 //   snapshot_handlers.memory / md.snapshots /
 //   md.flush_snapshot_queues()                   src/properties/water_sol.rs:185-189, src/md/mod.rs:118-122
 // All of these reuse the force path; their own kernels are streaming passes (HBM-bound).
-#include "mdx_internal.h"
+#include "mdx_comm.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -139,6 +139,7 @@ static int kinetic_energy(mdx_handle* h, double* ke) {
     MDX_TRY(mdx_launch_kinetic(h));
     HIP_TRY(hipMemcpyAsync(ke, h->d.energy + EN_KIN, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->dd) MDX_TRY(mdx_dd_allreduce_host(h, ke, 1));   // decomposed: ONE kinetic energy, hence one scale factor, for the whole box
     return MDX_OK;
 }
 
@@ -147,6 +148,7 @@ static int remove_com(mdx_handle* h) {
     MDX_TRY(mdx_launch_momentum(h));
     HIP_TRY(hipMemcpyAsync(p, h->d.energy + EN_COUNT + 1, sizeof(p), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->dd) MDX_TRY(mdx_dd_allreduce_host(h, p, 4));
     if (p[3] <= 0.0) return MDX_OK;
     const double com[3] = {p[0] / p[3], p[1] / p[3], p[2] / p[3]};
     return mdx_launch_scale_velocities(h, 1.0f, com);
@@ -300,7 +302,7 @@ extern "C" int mdx_set_integrator(mdx_handle* h, int kind, float gamma_per_ps, f
     if (kind < 0 || kind > 2) FAIL(MDX_EPARAM, "unknown integrator kind");
     if (kind == MDX_INTEGRATOR_LANGEVIN_MIDDLE && (!(gamma_per_ps >= 0.f) || !(temperature >= 0.f) || !std::isfinite(gamma_per_ps)))
         FAIL(MDX_EPARAM, "Langevin middle needs gamma >= 0 and temperature >= 0");
-    if (kind && h->n_local != h->N) FAIL(MDX_EPARAM, "only velocity Verlet is supported on a decomposed handle");
+    if (kind && h->n_local != h->N && !h->dd) FAIL(MDX_EPARAM, "only velocity Verlet is supported on a decomposed handle");
     h->integrator = kind; h->lang_gamma = gamma_per_ps; h->lang_temp = temperature; h->lang_seed = seed;
     return MDX_OK;
 }

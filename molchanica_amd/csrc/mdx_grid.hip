@@ -101,9 +101,12 @@ __global__ void scan_add_kernel(uint32_t* __restrict__ out, const uint32_t* __re
 }
 
 int mdx_exclusive_scan_u32(mdx_handle* h, const uint32_t* in, uint32_t* out, uint32_t n) {
+    return mdx_exclusive_scan_u32_ex(h, in, out, n, h->d.scan_tmp);
+}
+
+int mdx_exclusive_scan_u32_ex(mdx_handle* h, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums) {
     if (n == 0) return MDX_OK;
     uint32_t nb = div_up(n, SCAN_TILE);
-    uint32_t* sums = h->d.scan_tmp;
     hipLaunchKernelGGL(scan_tile_kernel, dim3(nb), dim3(SCAN_THREADS), 0, h->stream, in, out, sums, n);
     if (nb > 1) {
         hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, h->stream, sums, nb);

@@ -175,8 +175,11 @@ struct DeviceState {
     float4*  scratch4 = nullptr;   // [cap_scratch4] caller-order scratch (force read-back)
 };
 
+struct MdxDecomp;   // mdx_comm.h: the handle is one rank of a spatially decomposed box
+
 struct mdx_handle {
     int device = 0;
+    MdxDecomp* dd = nullptr;
     hipStream_t stream = nullptr;
     uint32_t N = 0;
     mdx_config cfg{};
@@ -191,6 +194,7 @@ struct mdx_handle {
     uint32_t n_bonds = 0, n_angles = 0, n_dih = 0, n_p14 = 0;
     uint32_t n_roles = 0;
     uint32_t n_groups = 0, n_cons = 0, n_vsites = 0;   // constraint clusters / constraints / virtual sites
+    std::vector<ConsGroup> h_groups; std::vector<VSite> h_vsites;   // host copies (caller order): ownership anchors of a decomposition
     bool cons_dirty = false;                           // positions were set from outside: project them once
     bool vsites_convex = true;                         // every virtual site lies inside the triangle of its parents
     // SPME
@@ -279,6 +283,7 @@ int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_ga
                          uint32_t* d_disp_out, uint32_t thr_bits, uint32_t* d_prune_out = nullptr);
 int mdx_launch_kinetic(mdx_handle* h);  // energy[EN_KIN], energy[EN_COUNT] = max |F|^2
 int mdx_exclusive_scan_u32(mdx_handle* h, const uint32_t* in, uint32_t* out, uint32_t n);
+int mdx_exclusive_scan_u32_ex(mdx_handle* h, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums);   // caller's scratch: n / 2048 + 1 words
 
 // pair-kernel variant actually used: 1 = whole-tile kernel (full list), 2 = cluster-masked kernel (full
 // list, deterministic), 3/4 = the same with 1/4 waves per tile forced, 5 = cluster-masked kernel over a

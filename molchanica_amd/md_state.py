@@ -115,6 +115,17 @@ def load_library():
     lib.mdx_unpack_positions.argtypes = [H, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int32]
     lib.mdx_stream.argtypes = [H]
     lib.mdx_stream.restype = C.c_void_p
+    lib.mdx_comm_unique_id.argtypes = [C.c_char_p]
+    lib.mdx_comm_init.argtypes = [H, C.c_char_p, C.c_int, C.c_int]
+    lib.mdx_fabric_create.argtypes = [C.c_int]
+    lib.mdx_fabric_create.restype = C.c_void_p
+    lib.mdx_fabric_destroy.argtypes = [C.c_void_p]
+    lib.mdx_fabric_destroy.restype = None
+    lib.mdx_fabric_abort.argtypes = [C.c_void_p]
+    lib.mdx_fabric_abort.restype = None
+    lib.mdx_comm_init_fabric.argtypes = [H, C.c_void_p, C.c_int]
+    lib.mdx_comm_init_null.argtypes = [H, C.c_int, C.c_int]
+    lib.mdx_comm_info.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _u32p, _u32p, _fp]
     _lib = lib
     return lib
 
@@ -331,6 +342,28 @@ class MdState:
         """`md.computation_time()` (src/md/mod.rs:740-743): ms spent inside step calls."""
         return float(self.stats()["wall_ms_sum"])
 
+    # -- multi-GPU: one box decomposed over the ranks, all below the C ABI (include/mdx.h) --------------
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        """Join the RCCL communicator (ncclCommInitRank) and take this rank's share of the box.  From here on
+        `step`, `energy`, `positions` / `velocities` / `forces` are COLLECTIVE calls."""
+        assert len(unique_id) == 128
+        _check(load_library().mdx_comm_init(self._h, bytes(unique_id), int(rank), int(world)))
+
+    def comm_init_fabric(self, fabric: "Fabric", rank: int):
+        """The same decomposition between handles of ONE process (one thread per rank) through an in-process fabric."""
+        self._fabric = fabric            # keep it alive as long as the handle
+        _check(load_library().mdx_comm_init_fabric(self._h, fabric.ptr, int(rank)))
+
+    def comm_init_null(self, rank: int, world: int):
+        """Rank `rank` of `world` with a transport that delivers nothing (one rank's cost measured alone)."""
+        _check(load_library().mdx_comm_init_null(self._h, int(rank), int(world)))
+
+    def comm_info(self) -> dict:
+        r, w, g = C.c_int(), C.c_int(), (C.c_int * 3)()
+        no, ng, halo = C.c_uint32(), C.c_uint32(), C.c_float()
+        _check(load_library().mdx_comm_info(self._h, C.byref(r), C.byref(w), g, C.byref(no), C.byref(ng), C.byref(halo)))
+        return dict(rank=r.value, world=w.value, grid=tuple(g), n_owned=no.value, n_ghost=ng.value, halo=halo.value)
+
     # -- multi-GPU plumbing (raw device pointers; used by molchanica_amd.decomp) -------------------
     def set_local_atoms(self, n_local, d_gid, d_ghost, d_pos4, d_vel4, lo, hi, periodic_mask: int):
         _check(load_library().mdx_set_local_atoms(
@@ -372,6 +405,35 @@ class MdState:
 
     def stream_ptr(self) -> int:
         return int(load_library().mdx_stream(self._h) or 0)
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the library (rank 0 calls it and hands the 128 bytes to the other ranks)."""
+    buf = C.create_string_buffer(128)
+    _check(load_library().mdx_comm_unique_id(buf))
+    return buf.raw
+
+
+class Fabric:
+    """In-process meeting point of `world` decomposed handles (mdx_fabric_create)."""
+
+    def __init__(self, world: int):
+        self.world = int(world)
+        self.ptr = load_library().mdx_fabric_create(self.world)
+        if not self.ptr:
+            raise ParamError("mdx_fabric_create failed")
+
+    def abort(self):
+        if self.ptr:
+            load_library().mdx_fabric_abort(self.ptr)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                load_library().mdx_fabric_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
 
 
 def run_dynamics_blocking(md: MdState, dt: float, n_steps: int):

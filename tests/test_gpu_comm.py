@@ -1,0 +1,254 @@
+"""The decomposed step loop BELOW the C ABI (mdx_comm_init*): `world` ranks run as threads of this one
+process, each with its own handle and HIP streams on the single available MI355X, and meet through the library's
+in-process fabric - the same internal transport interface RCCL sits behind (RCCL itself refuses two ranks on one
+device, so its own leg is covered by the single-rank self test at the bottom).  Everything else of the multi-GPU path
+is the production code: device-side partition (owners, ghosts, image shifts, halo lists), pack / exchange / unpack on
+the communication stream, the stale flag riding on the halo message, local rebuilds vs repartition, global gathers,
+energy all-reduces, constraint clusters and virtual sites owned as a whole, one thermostat for the whole box."""
+import math
+import threading
+
+import numpy as np
+import pytest
+
+from molchanica_amd import MdConfig, systems
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, chunk_steps=8)
+
+
+def run_ranks(system, cfg, world, n_steps, dt=0.0005, setup=None, want_forces=False):
+    """-> {rank: results}.  `setup(md)` configures a handle before it joins (thermostat, integrator, ...)."""
+    from molchanica_amd.md_state import Fabric, MdState
+    fabric = Fabric(world)
+    res, errs = {}, []
+
+    def run(rank):
+        try:
+            with MdState(system, cfg) as md:
+                if setup:
+                    setup(md)
+                md.comm_init_fabric(fabric, rank)
+                info = md.comm_info()
+                e0 = md.energy()
+                f0 = md.forces() if want_forces else None
+                md.step(dt, None, n_steps)
+                res[rank] = dict(pos=md.positions(), vel=md.velocities(), e0=e0, f0=f0, e1=md.energy(), stats=md.stats(),
+                                 steps=md.step_count, info=info)
+        except BaseException as e:   # pragma: no cover
+            errs.append(e)
+            fabric.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    if errs:
+        raise errs[0]
+    return res
+
+
+def rms_dev(a, b, L):
+    d = np.asarray(a, np.float64) - np.asarray(b, np.float64)
+    d -= np.round(d / L) * L
+    return math.sqrt((d ** 2).sum(1).mean())
+
+
+@pytest.fixture(scope="module")
+def reference():
+    from molchanica_amd.md_state import MdState
+    s = systems.water_box(14, seed=6)            # 8,232 atoms, 43.4 A box
+    cfg = MdConfig(**CFG)
+    with MdState(s, cfg) as md:
+        e0 = md.energy()
+        f0 = md.forces().astype(np.float64)
+        md.step(0.0005, None, 30)
+        out = dict(pos=md.positions().astype(np.float64), vel=md.velocities().astype(np.float64), e0=e0, f0=f0,
+                   e1=md.energy(), rebuilds=md.stats()["rebuild_count"])
+    return s, cfg, out
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_ranks_below_the_abi_match_single_gpu(reference, world):
+    s, cfg, ref = reference
+    res = run_ranks(s, cfg, world, 30, want_forces=True)
+    L = np.array(s.box_hi, dtype=np.float64)
+    r0 = res[0]
+    for r in range(1, world):
+        assert np.array_equal(res[r]["pos"], r0["pos"]), "ranks disagree on the gathered global state"
+        assert res[r]["e0"] == r0["e0"], "every rank reports the same (all-reduced) totals"
+    for k in ("lj", "coulomb", "bond", "angle", "kinetic", "virial"):
+        tol = max(2e-2, 3e-6 * abs(ref["e0"][k]))
+        assert abs(r0["e0"][k] - ref["e0"][k]) <= tol, (k, r0["e0"][k], ref["e0"][k])
+    # forces of the decomposed start, gathered from their owners, equal the single-GPU ones
+    df = np.linalg.norm(r0["f0"].astype(np.float64) - ref["f0"], axis=1)
+    assert (df <= 2e-4 * np.maximum(np.linalg.norm(ref["f0"], axis=1), 1.0) + 2e-4).all()
+    assert rms_dev(r0["pos"], ref["pos"], L) < 2e-3
+    assert abs((r0["e1"]["potential"] + r0["e1"]["kinetic"]) - (ref["e1"]["potential"] + ref["e1"]["kinetic"])) < 2e-4 * s.n_atoms
+    assert r0["steps"] == 30
+    assert sum(res[r]["stats"]["n_owned"] for r in range(world)) == s.n_atoms
+    assert r0["info"]["world"] == world and int(np.prod(r0["info"]["grid"])) == world
+    if world > 1:
+        assert all(res[r]["stats"]["n_ghost"] > 0 for r in range(world))
+        assert r0["stats"]["repartitions"] >= 2, "the run never repartitioned: migration is not covered"
+
+
+def test_chain_solute_across_brick_faces():
+    """Bonded terms whose atoms sit on different ranks: each owner evaluates its own role."""
+    from molchanica_amd.md_state import MdState
+    s = systems.small_solvated(n_chain=400, box=44.0)
+    cfg = MdConfig(**CFG)
+    with MdState(s, cfg) as md:
+        e_ref = md.energy()
+        md.step(0.0005, None, 12)
+        p_ref = md.positions().astype(np.float64)
+    res = run_ranks(s, cfg, 8, 12)
+    e = res[0]["e0"]
+    for k in ("bond", "angle", "dihedral", "lj14", "coulomb14", "lj", "coulomb"):
+        assert abs(e[k] - e_ref[k]) <= max(2e-2, 3e-6 * abs(e_ref[k])), (k, e[k], e_ref[k])
+    assert rms_dev(res[0]["pos"], p_ref, 44.0) < 2e-3
+
+
+def test_local_rebuilds_between_repartitions():
+    """A box large enough for a halo margin: stale lists are first rebuilt locally (owned + ghost set unchanged),
+    ownership migrates only when an atom has drifted margin/2."""
+    from molchanica_amd.md_state import MdState
+    s = systems.water_box(18, seed=8)            # 17,496 atoms, 55.9 A box
+    cfg = MdConfig(**CFG)
+    with MdState(s, cfg) as md:
+        md.step(0.0005, None, 45)
+        p_ref = md.positions().astype(np.float64)
+        assert md.stats()["rebuild_count"] >= 3
+    res = run_ranks(s, cfg, 2, 45)
+    st = res[0]["stats"]
+    assert st["local_rebuilds"] >= 1 and st["repartitions"] >= 2, (st["local_rebuilds"], st["repartitions"])
+    assert rms_dev(res[0]["pos"], p_ref, np.array(s.box_hi, dtype=np.float64)) < 3e-3
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_c4_dna100k_decomposed_trajectory(world):
+    """BASELINE config 4 (solvated duplex, ~100 k atoms): the strands run along z through the box centre, so the
+    x = 50 (and y = 50) brick faces cut their bonded terms."""
+    from molchanica_amd.md_state import MdState
+    s = systems.dna100k()
+    cfg = MdConfig(chunk_steps=8)
+    with MdState(s, cfg) as md:
+        e_ref = md.energy()
+        md.step(0.0005, None, 24)
+        p_ref = md.positions().astype(np.float64)
+        e1_ref = md.energy()
+    res = run_ranks(s, cfg, world, 24)
+    e = res[0]["e0"]
+    for k in ("bond", "angle", "dihedral", "lj14", "coulomb14", "lj", "coulomb", "kinetic"):
+        assert abs(e[k] - e_ref[k]) <= max(5e-2, 3e-6 * abs(e_ref[k])), (k, e[k], e_ref[k])
+    assert rms_dev(res[0]["pos"], p_ref, np.array(s.box_hi, dtype=np.float64)) < 2e-3
+    e1 = res[0]["e1"]
+    assert abs((e1["potential"] + e1["kinetic"]) - (e1_ref["potential"] + e1_ref["kinetic"])) < 2e-4 * s.n_atoms
+    assert sum(res[r]["stats"]["n_owned"] for r in range(world)) == s.n_atoms
+
+
+def test_dual_pair_list_on_decomposed_handles():
+    from molchanica_amd.md_state import MdState
+    s = systems.water_box(16, seed=9, temp=600.0)            # 12,288 atoms, 49.7 A box
+    with MdState(s, MdConfig(**CFG, inner_skin=-1.0)) as md:
+        md.step(0.0005, None, 40)
+        p_ref = md.positions().astype(np.float64)
+    res = run_ranks(s, MdConfig(**CFG, inner_skin=0.3), 4, 40)
+    assert rms_dev(res[0]["pos"], p_ref, np.array(s.box_hi, dtype=np.float64)) < 3e-3
+    for r in range(4):
+        st = res[r]["stats"]
+        assert st["prune_passes"] > st["rebuild_count"], (r, st["prune_passes"], st["rebuild_count"])
+        assert 0 < st["n_inner_cluster_pairs"] < st["n_cluster_pairs"]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_default_operating_point_on_decomposed_handles(world):
+    """The reference's default operating point - dt = 2 fs (src/prefs/mod.rs:203), constrained hydrogens
+    (src/ui/panels/md.rs:362-371), rigid 4-site OPC water with its massless M site
+    (src/properties/sol_shrinking_box.rs:605-613), CSVR thermostat (README.md:237-238) - on 2 / 4 / 8 ranks against one
+    GPU: every water is owned as a whole by one rank, SHAKE / RATTLE and the M-site construction / force spreading never
+    cross a rank boundary, ONE all-reduced kinetic energy drives the (identically seeded) thermostat."""
+    from molchanica_amd.md_state import MdState
+    s = systems.opc_water_box(16, seed=3)        # 4,096 waters = 16,384 sites, 49.7 A box
+    cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, coulomb_mode=1, chunk_steps=8)
+
+    def setup(md):
+        md.set_thermostat(2, 300.0, 0.1, 5, seed=77)        # CSVR every 5 steps
+
+    with MdState(s, cfg) as md:
+        setup(md)
+        e_ref = md.energy()
+        md.step(0.002, None, 40)
+        p_ref, v_ref = md.positions().astype(np.float64), md.velocities().astype(np.float64)
+        e1_ref = md.energy()
+    res = run_ranks(s, cfg, world, 40, dt=0.002, setup=setup)
+    r0 = res[0]
+    for k in ("lj", "coulomb", "kinetic"):
+        assert abs(r0["e0"][k] - e_ref[k]) <= max(2e-2, 3e-6 * abs(e_ref[k])), (k, r0["e0"][k], e_ref[k])
+    L = np.array(s.box_hi, dtype=np.float64)
+    assert rms_dev(r0["pos"], p_ref, L) < 2e-3, "decomposed rigid-water trajectory deviates"
+    assert math.sqrt(((r0["vel"] - v_ref) ** 2).sum(1).mean()) < 0.1
+    assert abs(r0["e1"]["temperature"] - e1_ref["temperature"]) < 0.5
+    # constraints hold on every water (gathered positions: O-H bond lengths)
+    w = r0["pos"].reshape(-1, 4, 3).astype(np.float64)
+    d = w[:, 1] - w[:, 0]
+    d -= np.round(d / L) * L
+    assert np.abs(np.linalg.norm(d, axis=1) - 0.8724).max() < 2e-4
+    assert sum(res[r]["stats"]["n_owned"] for r in range(world)) == s.n_atoms
+
+
+@pytest.mark.parametrize("kind", [1, 2])
+def test_other_integrators_on_decomposed_handles(kind):
+    """Leapfrog and Langevin middle (src/ui/panels/md.rs:296-305) on 4 ranks: the Langevin noise is keyed by
+    (seed, step, global atom id), so the decomposed trajectory is the single-GPU one."""
+    from molchanica_amd.md_state import MdState
+    s = systems.water_box(14, seed=12)
+    cfg = MdConfig(**CFG)
+
+    def setup(md):
+        md.set_integrator(kind, 2.0, 300.0, seed=5)
+
+    with MdState(s, cfg) as md:
+        setup(md)
+        md.step(0.0005, None, 25)
+        p_ref = md.positions().astype(np.float64)
+    res = run_ranks(s, cfg, 4, 25, setup=setup)
+    assert rms_dev(res[0]["pos"], p_ref, np.array(s.box_hi, dtype=np.float64)) < 2e-3
+
+
+def test_refusals_and_errors_on_decomposed_handles():
+    from molchanica_amd.md_state import Fabric, MdState, ParamError
+    s = systems.water_box(14, seed=6)
+    with MdState(s, MdConfig(**CFG)) as md:
+        md.comm_init_fabric(Fabric(1), 0)
+        with pytest.raises(ParamError):
+            md.comm_init_fabric(Fabric(1), 0)                 # already decomposed
+        with pytest.raises(ParamError):
+            md.set_barostat(1, 1.0, 1.0)
+        with pytest.raises(ParamError):
+            md.step(0.0005, np.zeros((s.n_atoms, 3), np.float32), 1)
+        md.step(0.0005, None, 5)                               # a one-rank decomposition just runs
+        assert md.step_count == 5
+    small = systems.water_box(8, seed=1)                       # 24.8 A: too small to cut at rc 9 + skin 1.5
+    with MdState(small, MdConfig(**CFG)) as md:
+        with pytest.raises(ParamError, match="two images|too small"):
+            md.comm_init_fabric(Fabric(2), 0)
+
+
+def test_rccl_transport_single_rank_selftest():
+    """The RCCL leg itself (dlopen of librccl, ncclGetUniqueId, ncclCommInitRank, the all-reduce and all-gather wrappers)
+    with the one rank a single-GPU box allows: a world-1 communicator runs the decomposed step loop and reports totals."""
+    from molchanica_amd.md_state import MdState, comm_unique_id
+    s = systems.water_box(10, seed=2)
+    cfg = MdConfig(lj_cutoff=7.0, coulomb_cutoff=7.0, skin=1.5)
+    with MdState(s, cfg) as md:
+        e_ref = md.energy()
+    uid = comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    with MdState(s, cfg) as md:
+        md.comm_init(uid, 0, 1)
+        assert md.comm_info()["world"] == 1
+        e = md.energy()
+        assert abs(e["potential"] - e_ref["potential"]) < 1e-2
+        md.step(0.0005, None, 20)
+        assert md.step_count == 20 and md.positions().shape == (s.n_atoms, 3)
