@@ -135,19 +135,10 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    # Verification aid for 1-GPU boxes: MDX_BENCH_SAME_GPU=1 maps every rank to device 0 and uses the gloo backend
-    # (RCCL refuses two ranks on one device), so the complete multi-process flow - rendezvous, broadcast of the
-    # prepared state, repartition all-reduce, per-step halo exchange, energy all-reduce - runs on real kernels.
-    same_gpu = os.environ.get("MDX_BENCH_SAME_GPU", "0") == "1"
-    if same_gpu:
-        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if same_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from molchanica_amd import MdConfig, systems
     from molchanica_amd.md_state import MdState
@@ -187,19 +178,28 @@ def main():
         prep = {"min_iters": args.eq_min_iters, "thermostat_steps": args.eq_steps,
                 "temperature_K": round(float(e_eq["temperature"]), 1), "seconds": round(time.perf_counter() - t_prep, 2)}
 
-    if world == 1 and not args.decomposed:
-        md = MdState(system, cfg, device=local_rank)
-        stepper = lambda k: md.step(args.dt, None, k)
-        stats = md.stats
-        prof = md.profile
-        parallelism = "single"
-    else:
-        from molchanica_amd.decomp import DecomposedMd
-        md = DecomposedMd(system, cfg, rank=rank, world=world, device=local_rank)
-        stepper = lambda k: md.step(args.dt, k)
-        stats = md.stats
-        prof = md.profile
-        parallelism = md.describe()
+    md = MdState(system, cfg, device=local_rank)
+    stepper = lambda k: md.step(args.dt, None, k)
+    stats = md.stats
+    prof = md.profile
+    parallelism = "single"
+    if world > 1 or args.decomposed:
+        # The decomposed step loop lives below the C ABI (include/mdx.h, mdx_comm_init): rank 0 draws the RCCL id, the
+        # launcher's process group only carries those 128 bytes; halo exchange, stale-list protocol, repartition and
+        # the energy all-reduce are the library's own RCCL calls.
+        from molchanica_amd.md_state import comm_unique_id
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8).clone()
+        if world > 1:
+            uid = uid.cuda()
+            dist.broadcast(uid, 0)
+            uid = uid.cpu()
+        md.comm_init(bytes(uid.numpy().tobytes()), rank, world)
+        info = md.comm_info()
+        g = info["grid"]
+        parallelism = (f"spatial {g[0]}x{g[1]}x{g[2]} bricks, ghost halo {info['halo']:.1f} A, ncclSend/ncclRecv group per step on a "
+                       f"communication stream (below the C ABI), stale flag on the halo message, local list rebuilds, then repartition")
 
     def sync():
         if world > 1:
@@ -324,7 +324,9 @@ def main():
                    "dual_list": ({"inner_skin": cfg.inner_skin or 0.5, "verlet_pair_evals": verlet_evals, "inner_pair_evals": inner_evals,
                                   "prune_frac": prune_frac} if dual else None),
                    "energy_evaluations_in_timed_region": n_energy, "untimed_preparation": prep,
-                   "repartitions": getattr(md, "repartitions", None), "local_rebuilds": getattr(md, "local_rebuilds_total", None)},
+                   "repartitions": int(st_nb["repartitions"]) if (world > 1 or args.decomposed) else None,
+                   "local_rebuilds": int(st_nb["local_rebuilds"]) if (world > 1 or args.decomposed) else None,
+                   "n_owned_rank0": int(st_nb["n_owned"]), "n_ghost_rank0": int(st_nb["n_ghost"])},
         "roofline": {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "launch_ms": nb_ms, "launches": nb_launches,

@@ -143,7 +143,7 @@ static void free_device(mdx_handle* h) {
                     d.mchunk_cnt, d.mchunk_off, d.entries, d.entries_in, d.inner_nch, d.list_cursors, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
                     d.role_off_s, d.role_rec_s, d.ctl, d.energy,
                     d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.pme_force, d.cons_o, d.cons_s, d.cons_vir, d.vsite_o, d.vsite_s, d.pme_q, d.pme_f,
-                    d.pme_theta, d.scratch4};
+                    d.pme_theta, d.scratch4, d.tile_bnd, d.tile_scan, d.tile_order};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = DeviceState{};
 }
@@ -351,16 +351,20 @@ static uint32_t stale_threshold_bits(const mdx_handle* h) {
 
 static int compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint32_t thr) {
     MDX_TRY(mdx_launch_vsite_construct(h, gate, thr));     // massless sites follow their parents
+    bool split = false;
     if (h->dd && h->dd->halo_pending) {                    // decomposed handle, step loop: ghost positions travel now
         h->dd->halo_pending = false;
-        MDX_TRY(mdx_dd_halo_begin(h));
+        MDX_TRY(mdx_dd_halo_begin(h));                     // pack + ncclSend/ncclRecv group on the communication stream
+        // tiles whose lists involve no ghost run while the message is in flight, the rest after the unpack
+        split = !energy && h->tile_split && h->dd->overlap && h->dd->world > 1 && mdx_nb_variant(h) >= 2 && !h->pme_on;
+        if (split) MDX_TRY(mdx_launch_nonbonded(h, energy, gate, thr, 1));
         MDX_TRY(mdx_dd_halo_end(h));
     }
     if (h->pme_on && h->pme_overlap) {                     // SPME reciprocal space on its side stream, beside the pair kernel
         MDX_TRY(mdx_pme_fork(h));
         MDX_TRY(mdx_launch_pme(h, energy, gate, thr));
     }
-    MDX_TRY(mdx_launch_nonbonded(h, energy, gate, thr));
+    MDX_TRY(mdx_launch_nonbonded(h, energy, gate, thr, split ? 2 : 0));
     MDX_TRY(mdx_launch_bonded(h, energy, gate, thr));
     if (h->pme_on && h->pme_overlap) MDX_TRY(mdx_pme_join(h, gate, thr));
     else MDX_TRY(mdx_launch_pme(h, energy, gate, thr));    // SPME reciprocal space (hipFFT), if requested
@@ -395,7 +399,7 @@ static int ensure_ready(mdx_handle* h) {
 void mdx_prof_begin(mdx_handle* h, int kind) {
     h->prof_open = false;
     if (!h->profile) return;
-    if (h->profile_level == 2 && kind != 0) return;   // pair kernel of the step loop only
+    if (h->profile_level == 2 && kind != 0 && kind != 4) return;   // pair kernel of the step loop only
     h->prof_open = true;
     mdx_handle::EvPair p{};
     p.kind = kind; p.tag = h->prof_tag;
@@ -419,8 +423,10 @@ void mdx_prof_collect(mdx_handle* h, int first_stale_step) {
         // launches enqueued behind a stale list were no-ops: the integrate pass of the stale step
         // itself still ran (it detected it), force kernels of that step and everything later did not
         const bool ran = p.tag < 0 || (p.kind == 2 ? p.tag <= first_stale_step : p.tag < first_stale_step);
+        // (level 2 = "the pair kernel only" covers both halves of a split launch)
         if (ran && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             if (p.kind == 0) { h->stats.nb_ms_sum += ms; h->stats.nb_launches++; }
+            else if (p.kind == 4) h->stats.nb_ms_sum += ms;     // the boundary half of a split pair-kernel launch
             else if (p.kind == 1) { h->stats.bonded_ms_sum += ms; h->stats.bonded_launches++; }
             else if (p.kind == 2) { h->stats.integ_ms_sum += ms; h->stats.integ_launches++; }
         }
@@ -600,7 +606,7 @@ int mdx_energy_impl(mdx_handle* h, mdx_energies* out) {
     out->potential = out->potential_bonded + out->potential_nonbonded;
     const double dof = mdx_dof(h);
     out->temperature = 2.0 * out->kinetic / (dof * MDX_KB);
-    if (h->periodic) {
+    if (h->periodic || h->dd) {   // (a rank of a fully cut box is not periodic locally: the box is still the global one)
         out->volume = (double)(h->box_hi[0] - h->box_lo[0]) * (h->box_hi[1] - h->box_lo[1]) *
                       (h->box_hi[2] - h->box_lo[2]);
         out->density = h->total_mass / out->volume;
@@ -775,7 +781,7 @@ extern "C" int mdx_upload(mdx_handle* h, int which, const float* src) {
     if (!h || !src) FAIL(MDX_EPARAM, "null argument");
     if (which != MDX_POS && which != MDX_VEL) FAIL(MDX_EPARAM, "only MDX_POS and MDX_VEL can be uploaded");
     HIP_TRY(hipSetDevice(h->device));
-    if (h->n_local != h->N) FAIL(MDX_EPARAM, "mdx_upload on a decomposed handle: use mdx_set_local_atoms");
+    if (h->dd || h->n_local != h->N) FAIL(MDX_EPARAM, "mdx_upload on a decomposed handle");
     const uint32_t N = h->N;
     for (size_t k = 0; k < 3 * (size_t)N; ++k)
         if (!std::isfinite(src[k])) FAIL(MDX_EPARAM, "non-finite value in upload");
@@ -825,7 +831,7 @@ __global__ __launch_bounds__(256) void pose_update_kernel(uint32_t first, uint32
 extern "C" int mdx_upload_range(mdx_handle* h, int which, uint32_t first, uint32_t count, const float* src) {
     if (!h || (count && !src)) FAIL(MDX_EPARAM, "null argument");
     if (which != MDX_POS && which != MDX_VEL) FAIL(MDX_EPARAM, "only MDX_POS and MDX_VEL can be uploaded");
-    if (h->n_local != h->N) FAIL(MDX_EPARAM, "mdx_upload_range on a decomposed handle");
+    if (h->dd || h->n_local != h->N) FAIL(MDX_EPARAM, "mdx_upload_range on a decomposed handle");
     if ((uint64_t)first + count > h->N) FAIL(MDX_EPARAM, "atom range out of bounds");
     if (count == 0) return MDX_OK;
     HIP_TRY(hipSetDevice(h->device));
@@ -993,7 +999,7 @@ int mdx_set_local_atoms_impl(mdx_handle* h, uint32_t n_local, const uint32_t* d_
     if (n_local == 0 || n_local > h->N) FAIL(MDX_EPARAM, "n_local must be in 1..n_atoms (each atom at most once)");
     if (h->pme_on) FAIL(MDX_EPARAM, "the SPME reciprocal sum is not supported on a decomposed handle (each rank would spread only its own charges)");
     if (h->alch_on) FAIL(MDX_EPARAM, "alchemical windows are not supported on a decomposed handle");
-    if (h->integrator != MDX_INTEGRATOR_VERLET_VELOCITY) FAIL(MDX_EPARAM, "only velocity Verlet is supported on a decomposed handle");
+    if (h->integrator != MDX_INTEGRATOR_VERLET_VELOCITY && !h->dd) FAIL(MDX_EPARAM, "only velocity Verlet is supported when the host drives the decomposition itself (mdx_comm_init handles every integrator)");
     if (h->baro_kind) FAIL(MDX_EPARAM, "the barostat is not supported on a decomposed handle");
     HIP_TRY(hipSetDevice(h->device));
     int per[3];
@@ -1098,7 +1104,9 @@ extern "C" int mdx_unpack_positions(mdx_handle* h, const uint32_t* d_gid, uint32
     if (n) hipLaunchKernelGGL(unpack_pos_kernel, dim3(div_up(n, 256)), dim3(256), 0, h->stream, n, d_gid,
                               h->d.slot_of, h->d.posq, (const float4*)d_in4, (const float4*)d_shift4,
                               flag_word >= 0 ? &h->d.ctl->disp2[flag_word] : nullptr,
-                              dual ? h->d.ref : nullptr, dual ? &h->d.ctl->prune[h->chunk_s + 1] : nullptr,
+                              dual ? h->d.ref : nullptr,
+                              dual ? ((h->dd && h->tile_split && h->dd->overlap && h->dd->world > 1) ? &h->d.ctl->prune_ghost[h->chunk_s + 1]
+                                                                                                      : &h->d.ctl->prune[h->chunk_s + 1]) : nullptr,
                               0.5f * h->inner_skin * (1.0f - 1.0e-4f));
     HIP_TRY(hipGetLastError());
     h->forces_valid = false;

@@ -417,11 +417,21 @@ static int dd_repartition(mdx_handle* h) {
 
 int mdx_dd_on_stale(mdx_handle* h) {
     MdxDecomp* dd = h->dd;
+    // The drift (and SHAKE) of the stale step happened, its force call - which starts by constructing the virtual sites -
+    // did not: bring the owned sites up to date before their positions travel (gather or halo), or the peers would
+    // evaluate this step's forces against last step's M sites.
+    if (h->n_vsites && h->in_slot_space) MDX_TRY(mdx_launch_vsite_construct(h, nullptr, 0));
     bool valid = true;
     MDX_TRY(dd_local_set_still_valid(h, &valid));
     if (valid) { dd->local_rebuilds++; dd->local_rebuilds_since++; h->list_valid = false; }
     else MDX_TRY(dd_repartition(h));
-    return mdx_rebuild(h);
+    MDX_TRY(mdx_rebuild(h));
+    if (valid && h->n_vsites && dd->world > 1) {   // same atom set: the ghosts' sites were packed before the construction above
+        dd->halo_step = -1;
+        MDX_TRY(mdx_dd_halo_begin(h));
+        MDX_TRY(mdx_dd_halo_end(h));
+    }
+    return MDX_OK;
 }
 
 // ---- collective read-back -------------------------------------------------------------------------------------------
@@ -542,6 +552,7 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
     DD_TRY(mdx_unsort_state(h));
     DD_HIP(hipMemcpyAsync(dd->g_pos, h->d.pos_orig, sizeof(float4) * N, hipMemcpyDeviceToDevice, h->stream));
     DD_HIP(hipMemcpyAsync(dd->g_vel, h->d.vel_orig, sizeof(float4) * N, hipMemcpyDeviceToDevice, h->stream));
+    h->want_tile_split = dd->world > 1 && dd->overlap;
     DD_TRY(dd_partition(h));
     DD_TRY(mdx_rebuild(h));
     h->forces_valid = false;

@@ -225,7 +225,7 @@ extern "C" int mdx_shrink_cell_towards(mdx_handle* h, const float target_lo[3], 
                                        float shrink_per_step, int* shrank_out) {
     if (!h || !target_lo || !target_hi) FAIL(MDX_EPARAM, "null argument");
     if (!h->periodic || !(h->per[0] && h->per[1] && h->per[2])) FAIL(MDX_EPARAM, "shrink_cell_towards needs a fully periodic box");
-    if (h->n_local != h->N) FAIL(MDX_EPARAM, "shrink_cell_towards is not supported on a decomposed handle");
+    if (h->dd || h->n_local != h->N) FAIL(MDX_EPARAM, "shrink_cell_towards is not supported on a decomposed handle");
     if (!(shrink_per_step >= 0.f) || !std::isfinite(shrink_per_step)) FAIL(MDX_EPARAM, "shrink_per_step must be >= 0");
     float lo[3], hi[3], c[3], mu[3];
     bool shrank = false;
@@ -315,7 +315,7 @@ extern "C" int mdx_configure_alchemical_window(mdx_handle* h, uint32_t mol_index
         if (!(lambda <= 1.0)) FAIL(MDX_EPARAM, "lambda must lie in [0, 1] (negative switches the window off)");
         if (h->mol_start.empty() || mol_index >= h->mol_start.size()) FAIL(MDX_EPARAM, "molecule index out of range (mol_start missing?)");
         if (h->pme_on) FAIL(MDX_EPARAM, "alchemical windows are not available with the SPME reciprocal sum");
-        if (h->n_local != h->N) FAIL(MDX_EPARAM, "alchemical windows are not supported on a decomposed handle");
+        if (h->dd || h->n_local != h->N) FAIL(MDX_EPARAM, "alchemical windows are not supported on a decomposed handle");
     }
     const uint32_t lo = on ? h->mol_start[mol_index] : 0;
     const uint32_t hi = on ? (mol_index + 1 < h->mol_start.size() ? h->mol_start[mol_index + 1] : h->N) : 0;
@@ -343,7 +343,7 @@ extern "C" int mdx_set_barostat(mdx_handle* h, int kind, float pressure_target_b
     if (kind < 0 || kind > 1) FAIL(MDX_EPARAM, "unknown barostat kind");
     if (kind) {
         if (!h->periodic || !(h->per[0] && h->per[1] && h->per[2])) FAIL(MDX_EPARAM, "the barostat needs a fully periodic box");
-        if (h->n_local != h->N) FAIL(MDX_EPARAM, "the barostat is not supported on a decomposed handle");
+        if (h->dd || h->n_local != h->N) FAIL(MDX_EPARAM, "the barostat is not supported on a decomposed handle");
         if (!(tau_ps > 0.f) || every_n_steps == 0 || !std::isfinite(pressure_target_bar))
             FAIL(MDX_EPARAM, "barostat needs a finite target, tau > 0 and a coupling interval >= 1 step");
     }
@@ -395,7 +395,7 @@ extern "C" int mdx_initialize_velocities(mdx_handle* h, float temperature, int z
 #pragma clang fp contract(off)   // no FMA contraction: the oracle (built -ffp-contract=off) must get the same bits
     if (!h) FAIL(MDX_EPARAM, "null handle");
     if (!(temperature >= 0.f) || !std::isfinite(temperature)) FAIL(MDX_EPARAM, "temperature must be >= 0");
-    if (h->n_local != h->N) FAIL(MDX_EPARAM, "initialize_velocities on a decomposed handle");
+    if (h->dd || h->n_local != h->N) FAIL(MDX_EPARAM, "initialize_velocities on a decomposed handle (draw them before mdx_comm_init)");
     const uint32_t N = h->N;
     std::vector<float> v(3 * (size_t)N);
     std::vector<double> vd(3 * (size_t)N);
@@ -428,7 +428,7 @@ static constexpr double MDX_MIN_MAX_STEP = 0.2;
 extern "C" int mdx_minimize_energy(mdx_handle* h, uint32_t max_iters, const float* ext_forces, float f_tol,
                                    mdx_energies* final_e, uint32_t* iters_done) {
     if (!h) FAIL(MDX_EPARAM, "null handle");
-    if (h->n_local != h->N) FAIL(MDX_EPARAM, "minimize_energy on a decomposed handle");
+    if (h->dd || h->n_local != h->N) FAIL(MDX_EPARAM, "minimize_energy on a decomposed handle");
     HIP_TRY(hipSetDevice(h->device));
     MDX_TRY(mdx_step(h, 0.f, ext_forces, 0));      // installs / clears the external forces
     hipStream_t st = h->stream;

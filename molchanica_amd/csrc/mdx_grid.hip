@@ -1097,6 +1097,8 @@ int mdx_rebuild(mdx_handle* h) {
         return MDX_EPARAM;
     }
 
+    h->tile_split = false; h->n_interior = 0;
+    if (h->want_tile_split && mdx_nb_variant(h) >= 2) MDX_TRY(mdx_classify_tiles(h));
     h->list_valid = true;
     h->forces_valid = false;
     h->rebuild_count++;
@@ -1120,6 +1122,59 @@ int mdx_rebuild(mdx_handle* h) {
         h->stats.rebuild_ms_sum += ms;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
+    return MDX_OK;
+}
+
+// ---- decomposed handle: interior / boundary tiles ---------------------------------------------------------------------
+// A tile is a BOUNDARY tile when it holds a ghost atom or its (Verlet) list names a cluster that does; everything an
+// interior tile's pair evaluation reads is owned by this rank, so it can run before the halo message has arrived.
+__global__ __launch_bounds__(256) void tile_class_kernel(uint32_t T, const uint8_t* __restrict__ slot_flags,
+                                                         const ListCounts* __restrict__ counts, const uint32_t* __restrict__ entry_off,
+                                                         const uint2* __restrict__ entries, uint32_t* __restrict__ tile_bnd) {
+    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= T) return;
+    const uint8_t f = slot_flags[t * MDX_TILE + lane];
+    bool ghost = (f & 1u) && !(f & 2u);
+    const ListCounts c = counts[t];
+    const uint32_t e0 = entry_off[t], n = c.n_masked + c.n_plain;
+    for (uint32_t k = lane; k < n; k += 64) {
+        const uint2 e = entries[e0 + k];
+        if (((e.y >> 8) & 0xFFu) == 0u) continue;
+        const unsigned long long fl = *reinterpret_cast<const unsigned long long*>(slot_flags + (size_t)e.x * MDX_CLUSTER);
+        // a byte with bit0 set and bit1 clear: real atom, not owned
+        ghost |= ((fl & 0x0101010101010101ull) & ~((fl >> 1) & 0x0101010101010101ull)) != 0ull;
+    }
+    const bool any = __any(ghost);
+    if (lane == 0) tile_bnd[t] = any ? 0u : 1u;     // stored as "is interior" so that the scan counts interior tiles
+}
+__global__ void tile_order_kernel(uint32_t T, const uint32_t* __restrict__ is_int, const uint32_t* __restrict__ scan,
+                                  uint32_t* __restrict__ order) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const uint32_t n_int = scan[T];
+    order[is_int[t] ? scan[t] : n_int + (t - scan[t])] = t;
+}
+
+int mdx_classify_tiles(mdx_handle* h) {
+    DeviceState& d = h->d;
+    const uint32_t T = h->T;
+    hipStream_t st = h->stream;
+    h->tile_split = false; h->n_interior = 0;
+    if (!T) return MDX_OK;
+    if (!d.tile_bnd || h->cap_tile_split < T + 1) {
+        h->cap_tile_split = h->cap_tiles + 1;
+        ALLOC(d.tile_bnd, h->cap_tile_split); ALLOC(d.tile_scan, h->cap_tile_split); ALLOC(d.tile_order, h->cap_tile_split);
+    }
+    HIP_TRY(hipMemsetAsync(d.tile_bnd + T, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(tile_class_kernel, dim3(div_up(T, 4)), dim3(256), 0, st, T, d.slot_flags, d.list_counts, d.entry_off, d.entries,
+                       d.tile_bnd);
+    MDX_TRY(mdx_exclusive_scan_u32(h, d.tile_bnd, d.tile_scan, T + 1));
+    hipLaunchKernelGGL(tile_order_kernel, dim3(div_up(T, 256)), dim3(256), 0, st, T, d.tile_bnd, d.tile_scan, d.tile_order);
+    uint32_t n_int = 0;
+    HIP_TRY(hipMemcpyAsync(&n_int, d.tile_scan + T, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    h->n_interior = n_int; h->tile_split = true;
     return MDX_OK;
 }
 

@@ -80,6 +80,9 @@ struct StepCtl {
     uint32_t nonfinite;
     uint32_t pad;
     uint32_t prune[MDX_MAX_CHUNK + 2];
+    // decomposed handle with interior / boundary split: raised by the halo unpack when a GHOST's path length since the last
+    // pruning pass of the boundary tiles exceeded inner_skin/2 (interior tiles never see a ghost and never read it)
+    uint32_t prune_ghost[MDX_MAX_CHUNK + 2];
 };
 
 // One (term, atom-of-that-term) record of the atom-owned bonded gather (mdx_bonded.hip).
@@ -172,6 +175,9 @@ struct DeviceState {
     unsigned long long* pair_count = nullptr;  // cluster pairs in the list (statistics)
     unsigned long long* inner_count = nullptr; // [MDX_EPART + 1] dual list: kept cluster pairs per pruning pass (spread), passes
     float*   bbox_red = nullptr;   // [6] min/max reduction (vacuum grid)
+    uint32_t* tile_bnd = nullptr;  // [T+1] decomposed handle: 1 <=> the tile holds a ghost or lists a cluster that does
+    uint32_t* tile_scan = nullptr; // [T+1]
+    uint32_t* tile_order = nullptr;// [T] interior tiles first (launched while the halo message is in flight), then boundary tiles
     float4*  scratch4 = nullptr;   // [cap_scratch4] caller-order scratch (force read-back)
 };
 
@@ -224,6 +230,10 @@ struct mdx_handle {
     // self-tuning of the library-default buffer (cfg.inner_skin == 0): pruning passes per step over a window of steps
     float inner_skin_auto = 0.f; bool dual_auto_off = false; uint32_t dual_win_steps = 0, dual_win_prunes = 0;
     bool prune_pending = true;   // the next step-loop force call must prune (after a rebuild / at the start of mdx_step)
+    bool prune_latch = false;    // ... latched for the (up to two) launches of that force call
+    uint32_t n_interior = 0;     // decomposed handle: tiles whose lists involve no ghost (0: no split)
+    bool tile_split = false;     // tile_order / n_interior describe the current list
+    bool want_tile_split = false; uint32_t cap_tile_split = 0;   // set by the decomposition (world > 1, overlap on)
     int nb_step = -1;            // chunk step of the force call being enqueued (-1: not from the step loop -> outer masks)
     int chunk_s = -1;            // decomposed driver: chunk step whose drift has been enqueued (its prune word is shared by the halo unpack)
     // state flags
@@ -273,8 +283,11 @@ int mdx_rebuild(mdx_handle* h);
 int mdx_unsort_state(mdx_handle* h);  // slot space -> pos_orig / vel_orig
 int mdx_gather_to_orig(mdx_handle* h, const float4* slot_arr, float4* orig_arr);
 int mdx_extract_neighbors(mdx_handle* h, uint32_t* offsets, uint32_t* idx);
+int mdx_classify_tiles(mdx_handle* h);
 // forces
-int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr_bits);
+// part: 0 = every tile; 1 = the interior tiles of a decomposed handle (no ghost in their lists: they run while the halo
+// message is in flight); 2 = its boundary tiles (after the unpack)
+int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr_bits, int part = 0);
 int mdx_launch_bonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr_bits);
 int mdx_launch_add_ext(mdx_handle* h, const uint32_t* d_gate, uint32_t thr_bits);
 // integration (mode: 0 = half kick + drift, 1 = full kick + drift (also: one leapfrog step), 2 = closing half

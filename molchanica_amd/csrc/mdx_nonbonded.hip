@@ -65,6 +65,10 @@ struct NbArgs {
     uint32_t* inner_nch;          // [T * 8 + part] chunk-loop bound of wave `part` of a tile in the inner list
     float4* ref; unsigned long long* inner_count;
     uint32_t xcd_interleave;      // 1: workgroup b takes tile group b (round-robin over the XCDs) instead of a contiguous eighth per XCD
+    // decomposed handle, interior / boundary split: this launch covers tiles tile_order[t_first .. t_first + t_count)
+    const uint32_t* tile_order; uint32_t t_first, t_count;
+    const uint32_t* prune_flag2;  // boundary launch: the ghosts' prune word (raised by the halo unpack); then only a pass asked for by
+                                  // the owned atoms' word clears the owned atoms' path accumulators (the interior lists depend on them)
 };
 
 enum { CM_SHIFTED = 0, CM_RF = 1, CM_EWALD = 2, CM_SOFT = 3 };
@@ -280,8 +284,10 @@ template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF, bo
 __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && NB_HALF_FLUSH) || ENERGY) ? 3 : 4) void nb_cluster_kernel(NbArgs a) {
     if (a.gate && *a.gate > a.thr_bits) return;
     static_assert(DUAL == 0 || (HALF && !ENERGY), "the dual list exists for the half-list force kernel");
+    bool owned_prune = true;
     if (DUAL != 0) {
-        const bool want_prune = (a.force_prune | *a.prune_flag) != 0u;
+        owned_prune = (a.force_prune | *a.prune_flag) != 0u;
+        const bool want_prune = owned_prune || (a.prune_flag2 && *a.prune_flag2 != 0u);
         if (want_prune != (DUAL == 2)) return;
     }
     constexpr int BW = WPT > NB_WAVES ? WPT : NB_WAVES;       // waves per workgroup
@@ -295,7 +301,8 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
     // live in SGPRs with scalar branches instead of VGPR compares and exec-mask loops
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int TPB = BW / WPT;                             // tiles per workgroup
-    const uint32_t nblocks = (a.T + TPB - 1) / TPB;
+    const uint32_t ntiles = a.tile_order ? a.t_count : a.T;   // (a decomposed handle launches its interior and boundary tiles apart)
+    const uint32_t nblocks = (ntiles + TPB - 1) / TPB;
     const uint32_t per_xcd = (nblocks + 7) >> 3;
     // a decomposed rank's tile range is owned bricks (long lists) and halo shells (short lists) in spatial order: a
     // contiguous eighth per XCD would leave whole XCDs with halo tiles only, so there the tiles go round-robin
@@ -303,9 +310,10 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
     if (blk >= nblocks) return;                               // whole workgroup
     const int tib = wave / WPT;                               // tile within the workgroup
     const int part = wave % WPT;                              // which share of the tile's chunks
-    const bool t_ok = blk * TPB + tib < a.T;                  // (the last workgroup may have a tile too many)
+    const bool t_ok = blk * TPB + tib < ntiles;               // (the last workgroup may have a tile too many)
     if (WPT == 1 && !t_ok) return;
-    const uint32_t t = t_ok ? blk * TPB + tib : a.T;          // a.T = the null tile: empty list, nothing stored
+    // a.T = the null tile: empty list, nothing stored
+    const uint32_t t = t_ok ? (a.tile_order ? __builtin_amdgcn_readfirstlane(a.tile_order[a.t_first + blk * TPB + tib]) : blk * TPB + tib) : a.T;
     const int ii = lane & 7, jj = lane >> 3;
 
     float xi[8], yi[8], zi[8], qi[8], sgi[8], epi[8], fx[8], fy[8], fz[8];
@@ -519,7 +527,8 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
         if (lane == 0) a.inner_nch[t * 8 + part] = nfull ? c_first + (nfull - 1u) * WPT + 1u : nmc;
     }
     if (prune) {
-        if (part == 0 && t_ok) a.ref[t * MDX_TILE + lane].w = 0.f;       // path lengths count from this pass
+        // path lengths count from this pass (a boundary pass asked for by the ghosts alone restarts the ghosts only)
+        if (part == 0 && t_ok && (owned_prune || !(a.slot_flags[t * MDX_TILE + lane] & 2u))) a.ref[t * MDX_TILE + lane].w = 0.f;
         if (lane == 0 && kept) atomicAdd(a.inner_count + ((blk * BW + wave) & (MDX_EPART - 1)), (unsigned long long)kept);
         if (lane == 0 && blk == 0 && wave == 0) atomicAdd(a.inner_count + MDX_EPART, 1ull);
     }
@@ -573,8 +582,9 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
     }
     const uint32_t bw = std::max(wpt, NB_WAVES);
     const uint32_t tpb = (var == 1) ? NB_WAVES : bw / wpt;
-    const uint32_t nblocks = (a.T + tpb - 1) / tpb;
+    const uint32_t nblocks = ((a.tile_order ? a.t_count : a.T) + tpb - 1) / tpb;
     const uint32_t grid = ((nblocks + 7) / 8) * 8;
+    if (nblocks == 0) return;
     dim3 g(grid), b(bw * 64);
     // dual list: the inner-walk kernel and the pruning kernel back to back, the device runs exactly one of them
 #define NB_DUAL(G, S, D)                                                                                              \
@@ -606,11 +616,18 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
 }
 
 static bool cut_on(float rc) { return rc > 0.f && std::isfinite(rc); }
+#define FAIL_NB(msg) do { mdx_set_error(msg); return MDX_EDEVICE; } while (0)
 
-int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr_bits) {
+int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr_bits, int part) {
     const mdx_config& c = h->cfg;
     NbArgs a{};
     a.T = h->T;
+    if (part != 0) {
+        if (!h->tile_split) FAIL_NB("internal: split pair-kernel launch without a tile classification");
+        a.tile_order = h->d.tile_order;
+        a.t_first = part == 1 ? 0u : h->n_interior;
+        a.t_count = part == 1 ? h->n_interior : h->T - h->n_interior;
+    }
     a.posq = h->d.posq; a.lj = h->d.lj; a.counts = h->d.list_counts; a.entry_off = h->d.entry_off;
     a.mchunk_off = h->d.mchunk_off; a.entries = h->d.entries; a.masks = h->d.masks;
     a.force = h->d.force; a.energy = h->d.energy; a.slot_flags = h->d.slot_flags; a.gate = d_gate; a.thr_bits = thr_bits;
@@ -622,12 +639,14 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
     // minimiser, the first evaluation after a rebuild - walks the plain list, which is always valid
     a.inner = (h->dual_on && !h->alch_on && !energy && h->nb_step >= 0 && d_gate != nullptr) ? 1u : 0u;
     if (a.inner) {
-        a.force_prune = h->prune_pending ? 1u : 0u;
+        if (part != 2) { h->prune_latch = h->prune_pending; h->prune_pending = false; }   // one decision for both halves of a split launch
+        a.force_prune = h->prune_latch ? 1u : 0u;
         a.prune_flag = &h->d.ctl->prune[h->nb_step + 1];
+        a.prune_flag2 = part == 2 ? &h->d.ctl->prune_ghost[h->nb_step + 1] : nullptr;
         const float rin = std::max(cut_on(c.lj_cutoff) ? c.lj_cutoff : 0.f, cut_on(c.coulomb_cutoff) ? c.coulomb_cutoff : 0.f) + h->inner_skin;
         a.rin2 = rin * rin;
         a.entries_in = h->d.entries_in; a.inner_nch = h->d.inner_nch; a.ref = h->d.ref; a.inner_count = h->d.inner_count;
-        h->prune_pending = false;   // (a launch gated off behind a stale list is followed by a rebuild, which sets it again)
+        // (a launch gated off behind a stale list is followed by a rebuild, which sets prune_pending again)
     }
     NbParams& p = a.p;
     p.rc2_lj = cut_on(c.lj_cutoff) ? c.lj_cutoff * c.lj_cutoff : FLT_MAX;
@@ -651,11 +670,13 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
     }
     const bool geom = c.combining_rule == MDX_COMBINE_GEOMETRIC;
     const bool samecut = p.rc2_lj == p.rc2_coul;
-    mdx_prof_begin(h, energy ? 3 : 0);   // 3: the energy flavour is a different kernel, keep it out of the step-loop average
+    mdx_prof_begin(h, energy ? 3 : (part == 2 ? 4 : 0));   // 3: the energy flavour is a different kernel, keep it out of the step-loop average
     // the half-list kernel accumulates with atomics: start from zero (part of the kernel's cost, so
     // inside the profiled bracket; harmless when the launch behind it is gated off, see mdx_step)
-    if (mdx_nb_half(h) && !h->force_zeroed) HIP_TRY(hipMemsetAsync(h->d.force, 0, sizeof(float4) * (size_t)h->S, h->stream));
-    h->force_zeroed = false;
+    if (part != 2) {
+        if (mdx_nb_half(h) && !h->force_zeroed) HIP_TRY(hipMemsetAsync(h->d.force, 0, sizeof(float4) * (size_t)h->S, h->stream));
+        h->force_zeroed = false;
+    }
 #define NB_DISPATCH(E)                                                              \
     switch (mode) {                                                                 \
     case CM_SHIFTED: launch_variant<E, CM_SHIFTED>(h, a, geom, samecut); break;     \
