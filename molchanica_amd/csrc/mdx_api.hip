@@ -356,8 +356,20 @@ static int compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint
         h->dd->halo_pending = false;
         MDX_TRY(mdx_dd_halo_begin(h));                     // pack + ncclSend/ncclRecv group on the communication stream
         // tiles whose lists involve no ghost run while the message is in flight, the rest after the unpack
-        split = !energy && h->tile_split && h->dd->overlap && h->dd->world > 1 && mdx_nb_variant(h) >= 2 && !h->pme_on;
-        if (split) MDX_TRY(mdx_launch_nonbonded(h, energy, gate, thr, 1));
+        split = !energy && h->tile_split && h->dd->overlap && h->dd->world > 1 && mdx_nb_variant(h) >= 2 && !h->pme_on && !h->profile;
+        if (split) {
+            // interior tiles on the side stream (they read owned atoms only), beside the unpack and the boundary tiles
+            if (mdx_nb_half(h) && !h->force_zeroed) HIP_TRY(hipMemsetAsync(h->d.force, 0, sizeof(float4) * (size_t)h->S, h->stream));
+            h->force_zeroed = true;
+            HIP_TRY(hipEventRecord(h->dd->ev_fork, h->stream));
+            HIP_TRY(hipStreamWaitEvent(h->dd->side_stream, h->dd->ev_fork, 0));
+            hipStream_t main_stream = h->stream;
+            h->stream = h->dd->side_stream;
+            const int rc_int = mdx_launch_nonbonded(h, energy, gate, thr, 1);
+            h->stream = main_stream;
+            MDX_TRY(rc_int);
+            HIP_TRY(hipEventRecord(h->dd->ev_interior, h->dd->side_stream));
+        }
         MDX_TRY(mdx_dd_halo_end(h));
     }
     if (h->pme_on && h->pme_overlap) {                     // SPME reciprocal space on its side stream, beside the pair kernel
@@ -365,6 +377,7 @@ static int compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint
         MDX_TRY(mdx_launch_pme(h, energy, gate, thr));
     }
     MDX_TRY(mdx_launch_nonbonded(h, energy, gate, thr, split ? 2 : 0));
+    if (split) HIP_TRY(hipStreamWaitEvent(h->stream, h->dd->ev_interior, 0));
     MDX_TRY(mdx_launch_bonded(h, energy, gate, thr));
     if (h->pme_on && h->pme_overlap) MDX_TRY(mdx_pme_join(h, gate, thr));
     else MDX_TRY(mdx_launch_pme(h, energy, gate, thr));    // SPME reciprocal space (hipFFT), if requested

@@ -64,6 +64,9 @@ struct MdxDecomp {
     float4* gat_send = nullptr; float4* gat_recv = nullptr; size_t cap_gat_send = 0, cap_gat_recv = 0;
     // communication stream and the events that order it with the compute stream
     hipStream_t comm_stream = nullptr; hipEvent_t ev_packed = nullptr, ev_arrived = nullptr;
+    // the interior tiles' pair kernel runs on a side stream, beside the unpack + boundary tiles of the main stream (two
+    // half-size launches back to back would each pay their own tail)
+    hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_interior = nullptr;
     bool halo_pending = false;         // the next force call of the step loop starts with a halo exchange
     int halo_step = -1;                // chunk step of that exchange (flag word = step + 1)
     bool overlap = true;               // interior tiles run while the message is in flight

@@ -470,6 +470,9 @@ void mdx_dd_destroy(mdx_handle* h) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (dd->ev_packed) (void)hipEventDestroy(dd->ev_packed);
     if (dd->ev_arrived) (void)hipEventDestroy(dd->ev_arrived);
+    if (dd->ev_fork) (void)hipEventDestroy(dd->ev_fork);
+    if (dd->ev_interior) (void)hipEventDestroy(dd->ev_interior);
+    if (dd->side_stream) { (void)hipStreamSynchronize(dd->side_stream); (void)hipStreamDestroy(dd->side_stream); }
     if (dd->comm_stream) (void)hipStreamDestroy(dd->comm_stream);
     delete dd->tr;
     delete dd;
@@ -546,6 +549,9 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
     DD_HIP(hipStreamCreateWithFlags(&dd->comm_stream, hipStreamNonBlocking));
     DD_HIP(hipEventCreateWithFlags(&dd->ev_packed, hipEventDisableTiming));
     DD_HIP(hipEventCreateWithFlags(&dd->ev_arrived, hipEventDisableTiming));
+    DD_HIP(hipStreamCreateWithFlags(&dd->side_stream, hipStreamNonBlocking));
+    DD_HIP(hipEventCreateWithFlags(&dd->ev_fork, hipEventDisableTiming));
+    DD_HIP(hipEventCreateWithFlags(&dd->ev_interior, hipEventDisableTiming));
     DD_HIP(hipMemcpyAsync(dd->anchor, anchor.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice, h->stream));
     DD_HIP(hipStreamSynchronize(h->stream));
     // the global state every rank starts from is the handle's own (it was created from the whole system)

@@ -1,46 +1,45 @@
 """What ONE rank of an N-GPU run has to do per step, measured alone on the GPU: rank 0 of the N-rank decomposition of the
-1M-atom box with a communicator that delivers nothing (ghosts keep their positions, reductions are the identity).  The
-kernel and host costs per step are those of a real rank; only the wire time of the halo message is missing.
-Usage: timeout 200 python tools/one_rank_profile.py [world] [steps=60]   (keep the timeout: a wrong repartition of a box
-whose other ranks do not exist piles a million atoms on one point)"""
+1M-atom box, driven by the library's own decomposed step loop (mdx_comm_init_null: the production path with a transport
+that delivers nothing - ghosts keep their positions, reductions are the identity).  Kernel and host costs per step are
+those of a real rank; only the wire time of the halo message is missing.
+Usage: timeout 300 python tools/one_rank_profile.py [world] [steps=100]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
+import numpy as np
 from molchanica_amd import systems, MdConfig
-from molchanica_amd.decomp import DecomposedMd
-
-
-class FrozenComm:
-    def __init__(self, world): self.rank, self.world = 0, world
-    def all_reduce(self, t, op): pass
-    def prepare(self, sends, recvs): return None
-    def prepare_halo(self, send_buf, recv_buf, send_segs, recv_segs): return None
-    def run(self, prepared): pass
-    def exchange(self, sends, recvs): pass
-
+from molchanica_amd.md_state import MdState
 
 worlds = [int(sys.argv[1])] if len(sys.argv) > 1 else [1, 2, 4, 8]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 s = systems.water1m() if "ONE_RANK_NSIDE" not in os.environ else systems.water_box(int(os.environ["ONE_RANK_NSIDE"]))   # a small box shows the host-side floor per step
 if os.environ.get("ONE_RANK_HOT", "0") != "1":      # same untimed preparation as bench.py: relaxed, 300 K
-    import numpy as np
-    from molchanica_amd.md_state import MdState
     with MdState(s, MdConfig()) as eq:
         eq.minimize_energy(100); eq.initialize_velocities(300.0, True, seed=105)
         eq.set_thermostat(1, 300.0, 0.02, 1); eq.step(0.0005, None, 600); eq.set_thermostat(0, 300.0, 0.02, 1)
         s.pos = np.ascontiguousarray(eq.positions(), dtype=np.float32); s.vel = np.ascontiguousarray(eq.velocities(), dtype=np.float32)
 for world in worlds:
-    md = DecomposedMd(s, MdConfig(), rank=0, world=world, device=0, comm=FrozenComm(world))
-    md._local_set_still_valid = lambda: True      # never repartition: the other ranks' rows do not exist here
-    md.recv_ids = md.recv_ids[:0]                 # nothing arrives: skip the unpack (a ~4 us kernel), ghosts stay put
-    md.step(0.0005, 8)
-    torch.cuda.synchronize()
-    md.profile(1)
-    t0 = time.perf_counter(); md.step(0.0005, steps); torch.cuda.synchronize(); el = time.perf_counter() - t0
-    st = md.stats()
-    print("world %d rank 0: owned %d ghost %d tiles %d | pair %.3f ms bonded %.3f integrate %.3f | step wall %.3f ms "
-          "(%d list rebuilds in %d steps, %.2f ms each) -> ceiling %.0f steps/s without wire time | cluster pairs verlet %.1f M inner %.1f M" % (
-              world, st["n_owned"], st["n_ghost"], st["n_tiles"], st["nb_ms_sum"] / max(st["nb_launches"], 1),
-              st["bonded_ms_sum"] / max(st["bonded_launches"], 1), st["integ_ms_sum"] / max(st["integ_launches"], 1),
-              1e3 * el / steps, st["rebuild_count"], steps + 8, st["rebuild_ms_sum"] / max(st["rebuild_count"] - 1, 1), steps / el, st["n_cluster_pairs"] / 1e6, st["n_inner_cluster_pairs"] / 1e6), flush=True)
-    del md
+    for overlap in ("1", "0"):
+        os.environ["MDX_HALO_OVERLAP"] = overlap
+        with MdState(s, MdConfig()) as md:
+            md.comm_init_null(0, world)
+            md.step(0.0005, None, 8)
+            md.profile(2); md.profile(0)          # (resets the timers; rebuild_ms_sum only runs while profiling is on)
+            st0 = md.stats()
+            t0 = time.perf_counter(); md.step(0.0005, None, steps); st1 = md.stats(); el = time.perf_counter() - t0    # stats() synchronises
+            md.profile(2); r0 = md.stats()        # a second stretch with the rebuild timer on: what the list builds cost
+            md.step(0.0005, None, steps); r1 = md.stats(); md.profile(0)
+            rb_ms = (r1["rebuild_ms_sum"] - r0["rebuild_ms_sum"]) / max(r1["rebuild_count"] - r0["rebuild_count"], 1)
+            rp_ms = (r1["repartition_ms_sum"] - r0["repartition_ms_sum"]) / max(r1["repartitions"] - r0["repartitions"], 1)
+            md.profile(1)
+            md.step(0.0005, None, 48)
+            st = md.stats()
+            md.profile(0)
+            k_nb = st["nb_ms_sum"] / max(st["nb_launches"], 1); k_b = st["bonded_ms_sum"] / max(st["bonded_launches"], 1)
+            k_i = st["integ_ms_sum"] / max(st["integ_launches"], 1)
+            rebuilds = st1["rebuild_count"] - st0["rebuild_count"]
+            print("world %d rank 0 (interior/boundary split %s): owned %d ghost %d tiles %d | pair %.3f ms bonded %.3f integrate %.3f = %.3f ms of kernels | "
+                  "step wall %.3f ms (%d list rebuilds in %d steps at %.2f ms, %d repartitions at %.2f ms incl. their rebuild: %.3f ms per step amortised) -> ceiling %.0f steps/s without wire time | cluster pairs verlet %.1f M inner %.1f M" % (
+                      world, "on" if overlap == "1" else "off", st["n_owned"], st["n_ghost"], st["n_tiles"], k_nb, k_b, k_i, k_nb + k_b + k_i,
+                      1e3 * el / steps, rebuilds, steps, rb_ms, st1["repartitions"] - st0["repartitions"], rp_ms,
+                      (rebuilds * rb_ms + (st1["repartitions"] - st0["repartitions"]) * max(rp_ms - rb_ms, 0.0)) / steps, steps / el,
+                      st["n_cluster_pairs"] / 1e6, st["n_inner_cluster_pairs"] / 1e6), flush=True)
