@@ -888,6 +888,7 @@ extern "C" int mdx_upload_range(mdx_handle* h, int which, uint32_t first, uint32
 
 extern "C" int mdx_set_box(mdx_handle* h, const float lo[3], const float hi[3]) {
     if (!h || !lo || !hi) FAIL(MDX_EPARAM, "null argument");
+    if (h->dd) FAIL(MDX_EPARAM, "mdx_set_box on a decomposed handle");
     if (!h->periodic) FAIL(MDX_EPARAM, "mdx_set_box on a non-periodic system");
     MDX_TRY(check_box(h->per, lo, hi, &h->cfg));
     HIP_TRY(hipSetDevice(h->device));
@@ -1010,7 +1011,7 @@ int mdx_set_local_atoms_impl(mdx_handle* h, uint32_t n_local, const uint32_t* d_
                              const float* d_pos4, const float* d_vel4, const float lo[3], const float hi[3],
                              int32_t periodic) {
     if (n_local == 0 || n_local > h->N) FAIL(MDX_EPARAM, "n_local must be in 1..n_atoms (each atom at most once)");
-    if (h->pme_on) FAIL(MDX_EPARAM, "the SPME reciprocal sum is not supported on a decomposed handle (each rank would spread only its own charges)");
+    if (h->pme_on && !h->dd) FAIL(MDX_EPARAM, "the SPME reciprocal sum needs the library's own decomposition (mdx_comm_init): here each rank would spread only its own charges");
     if (h->alch_on) FAIL(MDX_EPARAM, "alchemical windows are not supported on a decomposed handle");
     if (h->integrator != MDX_INTEGRATOR_VERLET_VELOCITY && !h->dd) FAIL(MDX_EPARAM, "only velocity Verlet is supported when the host drives the decomposition itself (mdx_comm_init handles every integrator)");
     if (h->baro_kind) FAIL(MDX_EPARAM, "the barostat is not supported on a decomposed handle");

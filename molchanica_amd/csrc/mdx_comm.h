@@ -21,6 +21,8 @@ struct MdxTransport {
                          hipStream_t stream) = 0;
     // In-place all-reduce of a small DEVICE array (n <= 4096).  kind: 0 = sum of doubles, 1 = max of uint32.
     virtual int all_reduce(void* dev, size_t n, int kind, hipStream_t stream) = 0;
+    // In-place sum of a LARGE device array of floats over the ranks (the SPME charge mesh of a decomposed handle).
+    virtual int all_reduce_f32(float* dev, size_t n, hipStream_t stream) = 0;
     // every rank contributes one word, every rank gets all of them (host values; synchronises `stream`)
     virtual int all_gather_u32(uint32_t mine, uint32_t* all, hipStream_t stream) = 0;
     virtual const char* name() const = 0;

@@ -91,6 +91,10 @@ struct RcclTransport : MdxTransport {
         NCCL_TRY(g_rccl.AllReduce(dev, dev, n, kind == 0 ? ncclFloat64 : ncclUint32, kind == 0 ? ncclSum : ncclMax, comm, stream));
         return MDX_OK;
     }
+    int all_reduce_f32(float* dev, size_t n, hipStream_t stream) override {
+        NCCL_TRY(g_rccl.AllReduce(dev, dev, n, ncclFloat32, ncclSum, comm, stream));
+        return MDX_OK;
+    }
     int all_gather_u32(uint32_t mine, uint32_t* all, hipStream_t stream) override {
         HIP_TRY(hipMemcpyAsync(d_words + world, &mine, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         NCCL_TRY(g_rccl.AllGather(d_words + world, d_words, 1, ncclUint32, comm, stream));
@@ -157,8 +161,39 @@ extern "C" void mdx_fabric_destroy(mdx_fabric* f) { delete f; }
 extern "C" void mdx_fabric_abort(mdx_fabric* f) { if (f) f->abort(); }
 
 namespace {
+struct SumPtrs { const float* p[32]; int n; };
+__global__ __launch_bounds__(256) void fabric_sum_kernel(size_t n, SumPtrs src, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int q = 0; q < src.n; ++q) s += src.p[q][i];     // rank order: every rank gets the same bits
+        out[i] = s;
+    }
+}
+
 struct FabricTransport : MdxTransport {
     mdx_fabric* f = nullptr;
+    float* tmp = nullptr; size_t cap_tmp = 0;
+    ~FabricTransport() override { if (tmp) (void)hipFree(tmp); }
+    int all_reduce_f32(float* dev, size_t n, hipStream_t stream) override {
+        if (n > cap_tmp) {
+            if (tmp) (void)hipFree(tmp);
+            tmp = nullptr; cap_tmp = 0;
+            if (hipMalloc((void**)&tmp, sizeof(float) * n) != hipSuccess) return fail();
+            cap_tmp = n;
+        }
+        if (hipStreamSynchronize(stream) != hipSuccess) return fail();
+        f->post[rank].host = dev;
+        if (!f->barrier()) return fail();
+        SumPtrs sp{}; sp.n = world;
+        for (int q = 0; q < world; ++q) sp.p[q] = (const float*)f->post[q].host;
+        hipLaunchKernelGGL(fabric_sum_kernel, dim3(1024), dim3(256), 0, stream, n, sp, tmp);
+        if (hipStreamSynchronize(stream) != hipSuccess) return fail();
+        if (!f->barrier()) return fail();                                 // everybody has read everybody's input
+        if (hipMemcpyAsync(dev, tmp, sizeof(float) * n, hipMemcpyDeviceToDevice, stream) != hipSuccess) return fail();
+        if (hipStreamSynchronize(stream) != hipSuccess) return fail();
+        if (!f->barrier()) return fail();
+        return MDX_OK;
+    }
     const char* name() const override { return "in-process fabric"; }
     int fail() { f->abort(); FAIL(MDX_EDEVICE, "in-process fabric: a rank failed or aborted"); }
     int exchange(const float4* send, const std::vector<MdxSeg>& ssegs, float4* recv, const std::vector<MdxSeg>& rsegs,
@@ -208,6 +243,7 @@ struct NullTransport : MdxTransport {
     bool delivers() const override { return false; }
     int exchange(const float4*, const std::vector<MdxSeg>&, float4*, const std::vector<MdxSeg>&, hipStream_t) override { return MDX_OK; }
     int all_reduce(void*, size_t, int, hipStream_t) override { return MDX_OK; }
+    int all_reduce_f32(float*, size_t, hipStream_t) override { return MDX_OK; }
     int all_gather_u32(uint32_t mine, uint32_t* all, hipStream_t) override { for (int q = 0; q < world; ++q) all[q] = mine; return MDX_OK; }
 };
 }  // namespace

@@ -483,7 +483,6 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
     auto bail = [&](int rc) { std::string keep = mdx_last_error(); if (!h->dd) delete tr; else mdx_dd_destroy(h); mdx_set_error(keep); return rc; };
     if (!(h->per[0] && h->per[1] && h->per[2])) { mdx_set_error("spatial decomposition needs a fully periodic box"); return bail(MDX_EPARAM); }
     if (h->n_local != h->N) { mdx_set_error("the handle already simulates a subset"); return bail(MDX_EPARAM); }
-    if (h->pme_on) { mdx_set_error("the SPME reciprocal sum is not supported on a decomposed handle"); return bail(MDX_EPARAM); }
     if (h->alch_on) { mdx_set_error("alchemical windows are not supported on a decomposed handle"); return bail(MDX_EPARAM); }
     if (h->baro_kind) { mdx_set_error("the barostat is not supported on a decomposed handle"); return bail(MDX_EPARAM); }
     if (h->have_ext) { mdx_set_error("external forces are not supported on a decomposed handle"); return bail(MDX_EPARAM); }
@@ -559,6 +558,11 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
     DD_HIP(hipMemcpyAsync(dd->g_pos, h->d.pos_orig, sizeof(float4) * N, hipMemcpyDeviceToDevice, h->stream));
     DD_HIP(hipMemcpyAsync(dd->g_vel, h->d.vel_orig, sizeof(float4) * N, hipMemcpyDeviceToDevice, h->stream));
     h->want_tile_split = dd->world > 1 && dd->overlap;
+    if (h->pme_on) {   // the reciprocal-space chain of a decomposed handle runs on the handle's own stream (mesh all-reduce inside)
+        if (h->pme_overlap && h->stream_pme) DD_HIP(hipStreamSynchronize(h->stream_pme));
+        h->pme_overlap = false;
+        DD_TRY(mdx_pme_setup(h));
+    }
     DD_TRY(dd_partition(h));
     DD_TRY(mdx_rebuild(h));
     h->forces_valid = false;

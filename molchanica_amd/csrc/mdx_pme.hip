@@ -15,7 +15,7 @@
 // Charges on the mesh already carry sqrt(k_e) (posq.w), so energies and forces come out in kcal/mol.
 // Self term, neutralising background and the erf(beta r)/r of excluded / 1-4 pairs (an extra role
 // kind in the bonded gather) complete the Ewald sum.  All mesh kernels are HBM/atomic-bound.
-#include "mdx_internal.h"
+#include "mdx_comm.h"
 #include <cstdlib>
 #include <hipfft/hipfft.h>
 #include <dlfcn.h>
@@ -76,13 +76,13 @@ __device__ __forceinline__ void mesh_coords(const float4 p, const PmeDev& g, int
 // requests than one-lane-per-atom (1.58 ms -> see profiles/ at 1 M atoms, 240^3 mesh).
 __global__ __launch_bounds__(256) void pme_spread_kernel(uint32_t S, const float4* __restrict__ posq,
                                                          const uint8_t* __restrict__ slot_flags, PmeDev g,
-                                                         float* __restrict__ Q, const uint32_t* gate, uint32_t thr) {
+                                                         float* __restrict__ Q, const uint32_t* gate, uint32_t thr, uint32_t need) {
     if (gate && *gate > thr) return;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t s = t >> 4;
     const int b = (t >> 2) & 3, c = t & 3;
     if (s >= S) return;
-    if (!(slot_flags[s] & 1u)) return;
+    if ((slot_flags[s] & need) != need) return;    // need = 1: every real atom; 3: the atoms this rank owns (decomposed handle)
     const float4 p = posq[s];
     if (p.w == 0.f) return;
     int k0[3]; float w[3];
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void pme_spread_kernel(uint32_t S, const float
 constexpr int PME_TB = 14;    // LDS block edge in mesh points
 __global__ __launch_bounds__(256) void pme_spread_tile_kernel(uint32_t T, const float4* __restrict__ posq,
                                                               const uint8_t* __restrict__ slot_flags, PmeDev g,
-                                                              float* __restrict__ Q, const uint32_t* gate, uint32_t thr) {
+                                                              float* __restrict__ Q, const uint32_t* gate, uint32_t thr, uint32_t need) {
     if (gate && *gate > thr) return;
     __shared__ float s_q[PME_TB * PME_TB * PME_TB];
     __shared__ int s_org[3];
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void pme_spread_tile_kernel(uint32_t T, const 
     const int atom = tid >> 2, q4 = tid & 3;
     const uint32_t slot = t * MDX_TILE + atom;
     const float4 p = posq[slot];
-    const bool live = (slot_flags[slot] & 1u) && p.w != 0.f;
+    const bool live = ((slot_flags[slot] & need) == need) && p.w != 0.f;
     int k0[3] = {0, 0, 0}; float w[3] = {0.f, 0.f, 0.f};
     {   // unwrapped mesh coordinates: floor may be < 0 or >= K for an atom just outside the box
         const float x[3] = {p.x, p.y, p.z};
@@ -187,7 +187,7 @@ template <bool ENERGY>
 __global__ __launch_bounds__(256) void pme_solve_kernel(size_t n, int K1, int K2, int K3h, int K3, float3 inv_len,
                                                         float pi2_over_beta2, float2* __restrict__ F,
                                                         const float* __restrict__ theta, double* energy,
-                                                        const uint32_t* gate, uint32_t thr) {
+                                                        const uint32_t* gate, uint32_t thr, double escale) {
     if (gate && *gate > thr) return;
     double e = 0.0, w = 0.0;
     // grid-stride: the energy flavour runs on at most 1024 blocks so that its two f64 atomics per block stay cheap
@@ -220,7 +220,8 @@ __global__ __launch_bounds__(256) void pme_solve_kernel(size_t n, int K1, int K2
         __syncthreads();
         if (threadIdx.x == 0) {
             e = s_e[0] + s_e[1] + s_e[2] + s_e[3]; w = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-            if (e != 0.0) { atomicAdd(&energy[EN_RECIP], e); atomicAdd(&energy[EN_VIRIAL], w); }
+            // (decomposed handle: every rank solves the same mesh; each reports its 1/world share of the energy)
+            if (e != 0.0) { atomicAdd(&energy[EN_RECIP], e * escale); atomicAdd(&energy[EN_VIRIAL], w * escale); }
         }
     }
 }
@@ -321,7 +322,7 @@ int mdx_pme_setup(mdx_handle* h) {
     if (!h->pme_on) return MDX_OK;
     if (!(h->per[0] && h->per[1] && h->per[2])) FAIL(MDX_EPARAM, "SPME needs a fully periodic box");
     if (c.pme_order != 0 && c.pme_order != 4) FAIL(MDX_EPARAM, "only B-spline order 4 is implemented");
-    if (h->n_local != h->N) FAIL(MDX_EPARAM, "SPME is not supported on a decomposed handle yet");
+    if (h->n_local != h->N && !h->dd) FAIL(MDX_EPARAM, "SPME needs the library's own decomposition (mdx_comm_init) when the box is split");
     PmePlan* p = (PmePlan*)h->pme_plan;
     if (!p) {
         p = new PmePlan();
@@ -356,17 +357,6 @@ int mdx_pme_setup(mdx_handle* h) {
         if (p->plan3d(&p->fwd, K[0], K[1], K[2], HIPFFT_R2C) != HIPFFT_SUCCESS ||
             p->plan3d(&p->inv, K[0], K[1], K[2], HIPFFT_C2R) != HIPFFT_SUCCESS)
             FAIL(MDX_EDEVICE, "hipfftPlan3d failed");
-        {   // side stream of the reciprocal-space chain (MDX_PME_OVERLAP=0: everything on the handle's stream)
-            static const bool off = [] { const char* e = std::getenv("MDX_PME_OVERLAP"); return e && e[0] == '0'; }();
-            h->pme_overlap = !off;
-            if (h->pme_overlap && !h->stream_pme) {
-                HIP_TRY(hipStreamCreateWithFlags(&h->stream_pme, hipStreamNonBlocking));
-                HIP_TRY(hipEventCreateWithFlags(&h->ev_pme_fork, hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&h->ev_pme_join, hipEventDisableTiming));
-            }
-        }
-        hipStream_t fst = h->pme_overlap ? h->stream_pme : h->stream;
-        p->set_stream(p->fwd, fst); p->set_stream(p->inv, fst);
         p->have_plans = true;
         for (void** q : {(void**)&h->d.pme_q, (void**)&h->d.pme_f, (void**)&h->d.pme_theta})
             if (*q) { (void)hipFree(*q); *q = nullptr; }
@@ -374,6 +364,18 @@ int mdx_pme_setup(mdx_handle* h) {
         HIP_TRY(hipMalloc((void**)&h->d.pme_f, sizeof(float2) * p->n_cplx));
         HIP_TRY(hipMalloc((void**)&h->d.pme_theta, sizeof(float) * p->n_cplx));
         for (int d = 0; d < 3; ++d) h->pme_K[d] = K[d];
+    }
+    {   // side stream of the reciprocal-space chain (MDX_PME_OVERLAP=0: everything on the handle's stream; a decomposed
+        // handle keeps the chain on its own stream: the mesh all-reduce sits inside it)
+        static const bool off = [] { const char* e = std::getenv("MDX_PME_OVERLAP"); return e && e[0] == '0'; }();
+        h->pme_overlap = !off && !h->dd;
+        if (h->pme_overlap && !h->stream_pme) {
+            HIP_TRY(hipStreamCreateWithFlags(&h->stream_pme, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_pme_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_pme_join, hipEventDisableTiming));
+        }
+        hipStream_t fst = h->pme_overlap ? h->stream_pme : h->stream;
+        p->set_stream(p->fwd, fst); p->set_stream(p->inv, fst);
     }
     for (int d = 0; d < 3; ++d) {
         p->dev.lo[d] = h->box_lo[d]; p->dev.inv_len[d] = (float)(1.0 / L[d]);
@@ -428,22 +430,27 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
     PmePlan* p = (PmePlan*)h->pme_plan;
     hipStream_t st = h->pme_overlap ? h->stream_pme : h->stream;
     const int K3h = h->pme_K[2] / 2 + 1;
+    const uint32_t need = h->dd ? 3u : 1u;              // decomposed: every rank spreads the charges it OWNS ...
+    const double escale = h->dd ? 1.0 / (double)h->dd->world : 1.0;
     HIP_TRY(hipMemsetAsync(h->d.pme_q, 0, sizeof(float) * p->n_real, st));
     static const bool per_atom_spread = [] { const char* e = std::getenv("MDX_PME_SPREAD_PER_ATOM"); return e && e[0] == '1'; }();
     if (per_atom_spread || !h->in_slot_space)
         hipLaunchKernelGGL(pme_spread_kernel, dim3(div_up(h->S * 16u, 256)), dim3(256), 0, st, h->S, h->d.posq,
-                           h->d.slot_flags, p->dev, h->d.pme_q, d_gate, thr);
+                           h->d.slot_flags, p->dev, h->d.pme_q, d_gate, thr, need);
     else
         hipLaunchKernelGGL(pme_spread_tile_kernel, dim3(h->T), dim3(256), 0, st, h->T, h->d.posq, h->d.slot_flags, p->dev,
-                           h->d.pme_q, d_gate, thr);
+                           h->d.pme_q, d_gate, thr, need);
+    // ... and the meshes are summed over the ranks: a replicated mesh, every rank then solves it and interpolates the
+    // forces of its own atoms (the all-reduce is ungated: a collective must be entered by every rank alike)
+    if (h->dd && h->dd->world > 1) MDX_TRY(h->dd->tr->all_reduce_f32(h->d.pme_q, p->n_real, st));
     if (p->exec_r2c(p->fwd, h->d.pme_q, (hipfftComplex*)h->d.pme_f) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecR2C failed");
     const dim3 gs((unsigned)std::min<size_t>((p->n_cplx + 255) / 256, energy ? 1024 : (size_t)1 << 30));
     const float3 inv_len = make_float3(p->dev.inv_len[0], p->dev.inv_len[1], p->dev.inv_len[2]);
     const float pb = (float)(M_PI * M_PI / ((double)h->cfg.ewald_alpha * h->cfg.ewald_alpha));
     if (energy) hipLaunchKernelGGL(pme_solve_kernel<true>, gs, dim3(256), 0, st, p->n_cplx, h->pme_K[0], h->pme_K[1], K3h,
-                                   h->pme_K[2], inv_len, pb, h->d.pme_f, h->d.pme_theta, h->d.energy, d_gate, thr);
+                                   h->pme_K[2], inv_len, pb, h->d.pme_f, h->d.pme_theta, h->d.energy, d_gate, thr, escale);
     else hipLaunchKernelGGL(pme_solve_kernel<false>, gs, dim3(256), 0, st, p->n_cplx, h->pme_K[0], h->pme_K[1], K3h,
-                            h->pme_K[2], inv_len, pb, h->d.pme_f, h->d.pme_theta, h->d.energy, d_gate, thr);
+                            h->pme_K[2], inv_len, pb, h->d.pme_f, h->d.pme_theta, h->d.energy, d_gate, thr, escale);
     if (p->exec_c2r(p->inv, (hipfftComplex*)h->d.pme_f, h->d.pme_q) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecC2R failed");
     if (h->pme_overlap)
         hipLaunchKernelGGL(pme_gather_kernel<true>, dim3(div_up(h->S, 256)), dim3(256), 0, st, h->S, h->d.posq, h->d.slot_flags,

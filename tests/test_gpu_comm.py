@@ -197,6 +197,31 @@ def test_default_operating_point_on_decomposed_handles(world):
     assert sum(res[r]["stats"]["n_owned"] for r in range(world)) == s.n_atoms
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_spme_on_decomposed_handles(world):
+    """Ewald Coulomb with the SPME reciprocal sum (the reference's default Coulomb, README.md:240) on a decomposed box:
+    every rank spreads the charges it owns, the charge meshes are summed over the ranks (replicated mesh), every rank
+    solves it and interpolates the forces of its own atoms; the reciprocal energy is reported once."""
+    from molchanica_amd.md_state import MdState
+    s = systems.small_solvated(n_chain=400, box=44.0)
+    cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, chunk_steps=8, coulomb_mode=2, ewald_alpha=0.35, overrides=0)
+    with MdState(s, cfg) as md:
+        e_ref = md.energy()
+        f_ref = md.forces().astype(np.float64)
+        md.step(0.0005, None, 20)
+        p_ref = md.positions().astype(np.float64)
+        e1_ref = md.energy()
+    res = run_ranks(s, cfg, world, 20, want_forces=True)
+    r0 = res[0]
+    assert abs(e_ref["coulomb_recip"]) > 100.0
+    for k in ("coulomb", "coulomb_recip", "lj", "bond", "angle", "dihedral", "lj14", "coulomb14", "virial"):
+        assert abs(r0["e0"][k] - e_ref[k]) <= max(5e-2, 1e-5 * abs(e_ref[k])), (k, r0["e0"][k], e_ref[k])
+    df = np.linalg.norm(r0["f0"].astype(np.float64) - f_ref, axis=1)
+    assert (df <= 3e-4 * np.maximum(np.linalg.norm(f_ref, axis=1), 1.0) + 3e-4).all(), float(df.max())
+    assert rms_dev(r0["pos"], p_ref, 44.0) < 2e-3
+    assert abs(r0["e1"]["potential"] - e1_ref["potential"]) < 2e-4 * s.n_atoms
+
+
 @pytest.mark.parametrize("kind", [1, 2])
 def test_other_integrators_on_decomposed_handles(kind):
     """Leapfrog and Langevin middle (src/ui/panels/md.rs:296-305) on 4 ranks: the Langevin noise is keyed by
