@@ -1,23 +1,39 @@
 """Latency of the stateless scorer `compute_energy_snapshot` (/root/reference src/md/mod.rs:1036; the docking energy path,
-src/docking/mod.rs:235) on BASELINE.json's complex50k, and of a resident handle's repeated `energy()` calls."""
+src/docking/mod.rs:235) on BASELINE.json's complex50k, pose after pose as the docking loop calls it (only the 50 ligand
+atoms move), and of a resident handle's `energy()` / ligand-only pose update."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 from molchanica_amd import systems, MdConfig
-from molchanica_amd.md_state import MdState, compute_energy_snapshot
+from molchanica_amd.md_state import MdState, compute_energy_snapshot, release_single_point_cache
 for name in ("complex50k", "dhfr23k"):
     s = systems.BY_NAME[name]()
     cfg = MdConfig()
-    compute_energy_snapshot(s, cfg)          # warm-up (module load, first kernel launches)
-    t = time.perf_counter(); n = 5
-    for _ in range(n): e = compute_energy_snapshot(s, cfg)
-    sp = (time.perf_counter() - t) / n
+    lig = slice(int(s.mol_start[1]), int(s.mol_start[2])) if name == "complex50k" else slice(100, 150)
+    rng = np.random.default_rng(1)
+    base = s.pos.copy()
+    release_single_point_cache()
+    t = time.perf_counter(); compute_energy_snapshot(s, cfg); first = time.perf_counter() - t
+    def poses(n, amp, forces):
+        t = time.perf_counter()
+        for k in range(n):
+            p = base.copy(); p[lig] += rng.normal(0, amp, 3).astype(np.float32)
+            s.pos = p
+            e = compute_energy_snapshot(s, cfg, with_forces=forces)
+        return (time.perf_counter() - t) / n, e
+    poses(3, 0.1, False)
+    small, e = poses(40, 0.15, False)          # ligand moves inside the Verlet skin: list reused
+    small_f, _ = poses(40, 0.15, True)
+    large, _ = poses(20, 1.5, False)           # beyond skin/2: list rebuilt
+    s.pos = base
     with MdState(s, cfg) as md:
         md.energy()
         t = time.perf_counter(); m = 50
         for _ in range(m): md.energy()
         en = (time.perf_counter() - t) / m
         t = time.perf_counter()
-        for _ in range(m): md.set_positions(s.pos); md.energy()
+        for _ in range(m): md.set_positions_range(lig.start, base[lig] + np.float32(0.1)); md.energy()
         up = (time.perf_counter() - t) / m
-    print("%s (%d atoms): compute_energy_snapshot %.2f ms (per pose; a first call or a new molecule set also builds the device state) | resident handle: energy() %.3f ms, "
-          "set_positions + energy() %.2f ms (new pose: upload + list rebuild + energy) | E_pot %.1f" % (name, s.n_atoms, 1e3 * sp, 1e3 * en, 1e3 * up, e["potential"]))
+    print("%s (%d atoms): compute_energy_snapshot first call %.2f ms (builds the device state) | per pose, ligand moved 0.15 A: %.3f ms "
+          "(%.3f ms with forces read back) | ligand moved 1.5 A (list rebuilt): %.2f ms | resident handle: energy() %.3f ms, "
+          "set_positions_range + energy() %.3f ms | E_pot %.1f" % (name, s.n_atoms, 1e3 * first, 1e3 * small, 1e3 * small_f, 1e3 * large, 1e3 * en, 1e3 * up, e["potential"]))
