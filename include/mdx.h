@@ -331,6 +331,41 @@ uint32_t mdx_snapshot_count(const mdx_handle* h);
 int      mdx_snapshot_read(mdx_handle* h, uint32_t k, double* time_ps, uint64_t* step, mdx_energies* e,
                            float* pos /* [3N] */, float* vel_or_null /* [3N] */);
 int      mdx_flush_snapshot_queues(mdx_handle* h);       /* drop the stored snapshots (after the host cloned them) */
+
+/* ---- md.water and the water / hydrogen-bond part of a Snapshot -------------------------------------------------------
+ * The reference keeps solvent water apart from `md.atoms`: `md.water[i].{o,h0,h1,m}.{posit,force}`
+ * [ref: src/properties/sol_shrinking_box.rs:605-613, 780-786], and a Snapshot carries `atom_posits` (the non-water
+ * atoms), `water_o_posits / water_h0_posits / water_h1_posits` and, in its energy data, `hydrogen_bonds`
+ * [ref: src/md/viewer.rs:374-394, 917-960; src/properties/water_sol.rs:268-300].  Here the system is one flat atom
+ * array; the host says where its waters are - n_waters contiguous records of `sites_per_water` atoms in the order
+ * O, H0, H1 (, M) starting at first_atom - and the library hands out the reference's views:
+ *   mdx_water_download      md.water[i].{o,h0,h1,m}.posit / .force of the current state, [3 n_waters] floats each
+ *   mdx_snapshot_read_water water_o/h0/h1_posits of stored snapshot k (atom_posits = rows [0, first_atom) of its pos)
+ * Hydrogen bonds: the detection rule lives in the absent crates (bio_files::bond_inference::h_bond_geometry_strength);
+ * built here, switchable per handle: a hydrogen bound (bond or constraint) to a heavy atom flagged in
+ * `is_hbond_heavy` (N, O, S, F: the reference's candidate elements, water_sol.rs:198-203) donates to another flagged
+ * atom when H...A <= max_h_acc_dist (default 2.5 A) and the angle D-H...A >= min_angle_deg (default 120), minimum
+ * image; strength = (1 - (d - 1.5)/(max - 1.5)) x (angle - min)/(180 - min), clamped to [0, 1].  Detected at every
+ * snapshot (host side, linear-time cell search) once switched on.  Atom references follow the reference's
+ * `(HBondAtomType, index)`: MDX_HB_STANDARD indexes the non-water atoms, the water types index the water. */
+#define MDX_HB_STANDARD 0
+#define MDX_HB_WATER_O  1
+#define MDX_HB_WATER_H0 2
+#define MDX_HB_WATER_H1 3
+typedef struct mdx_hbond {
+    uint32_t donor, acceptor, hydrogen;                 /* indices (see *_type) */
+    uint8_t  donor_type, acceptor_type, hydrogen_type;  /* MDX_HB_* */
+    uint8_t  pad;
+    float    strength;
+} mdx_hbond;
+int      mdx_set_water_layout(mdx_handle* h, uint32_t first_atom, uint32_t n_waters, uint32_t sites_per_water);
+int      mdx_water_download(mdx_handle* h, int which /* MDX_POS | MDX_FORCE */, float* o, float* h0, float* h1,
+                            float* m_or_null /* 4-site water only */);
+int      mdx_set_hbond_detection(mdx_handle* h, const uint8_t* is_hbond_heavy /* [N], NULL = off */, float max_h_acc_dist,
+                                 float min_angle_deg);
+int      mdx_snapshot_read_water(mdx_handle* h, uint32_t k, float* o, float* h0, float* h1 /* [3 n_waters] each */);
+uint32_t mdx_snapshot_hbond_count(const mdx_handle* h, uint32_t k);
+int      mdx_snapshot_read_hbonds(mdx_handle* h, uint32_t k, mdx_hbond* out, uint32_t capacity);
 double   mdx_time_ps(const mdx_handle* h);
 
 /* ---- multi-GPU: one periodic box spatially decomposed over the GPUs of a node (the reference is

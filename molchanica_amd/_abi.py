@@ -70,6 +70,13 @@ class CEnergies(C.Structure):
         return {n: float(getattr(self, n)) for n, _ in self._fields_}
 
 
+class CHBond(C.Structure):
+    """mdx_hbond: (HBondAtomType, index) references of donor / acceptor / hydrogen + strength."""
+    _fields_ = [("donor", C.c_uint32), ("acceptor", C.c_uint32), ("hydrogen", C.c_uint32),
+                ("donor_type", C.c_uint8), ("acceptor_type", C.c_uint8), ("hydrogen_type", C.c_uint8), ("pad", C.c_uint8),
+                ("strength", C.c_float)]
+
+
 class CStats(C.Structure):
     _fields_ = [
         ("step_count", C.c_uint64), ("rebuild_count", C.c_uint64),

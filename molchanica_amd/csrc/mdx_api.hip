@@ -299,6 +299,10 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
         HIP_TRY(hipStreamSynchronize(st));
     }
 
+    // bonded / constrained pairs, kept for the hydrogen-bond donor table (mdx_set_hbond_detection)
+    h->h_bond_pairs.assign(s->bond_idx ? s->bond_idx : nullptr, s->bond_idx ? s->bond_idx + 2 * (size_t)s->n_bonds : nullptr);
+    if (s->constraint_idx) h->h_bond_pairs.insert(h->h_bond_pairs.end(), s->constraint_idx, s->constraint_idx + 2 * (size_t)s->n_constraints);
+
     // ---- dynamic state staging ----
     {
         std::vector<float4> p4(N), v4(N);

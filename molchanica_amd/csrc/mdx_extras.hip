@@ -251,16 +251,106 @@ extern "C" int mdx_shrink_cell_towards(mdx_handle* h, const float target_lo[3], 
     return MDX_OK;
 }
 
+// ---- hydrogen bonds of a configuration (host side: snapshots are rare, the search is linear in N) ----------------------
+// Atom references as the reference's (HBondAtomType, index) pairs (src/md/viewer.rs:893-915).
+static void hb_ref(const mdx_handle* h, uint32_t atom, uint32_t* idx, uint8_t* type) {
+    const uint32_t w0 = h->water_first, w1 = h->water_first + h->n_waters * h->water_sites;
+    if (h->n_waters && atom >= w0 && atom < w1) {
+        const uint32_t k = (atom - w0) % h->water_sites;
+        *idx = (atom - w0) / h->water_sites;
+        *type = k == 0 ? MDX_HB_WATER_O : (k == 1 ? MDX_HB_WATER_H0 : (k == 2 ? MDX_HB_WATER_H1 : MDX_HB_WATER_O));
+    } else {
+        *idx = atom < w0 || !h->n_waters ? atom : atom - h->n_waters * h->water_sites;   // index among the non-water atoms
+        *type = MDX_HB_STANDARD;
+    }
+}
+
+static void detect_hbonds(const mdx_handle* h, const float* pos, std::vector<mdx_hbond>& out) {
+    out.clear();
+    if (h->hb_heavy.empty()) return;
+    const uint32_t N = (uint32_t)h->hb_heavy.size();
+    const bool per = h->per[0] || h->per[1] || h->per[2] || (h->dd != nullptr);
+    double L[3] = {0, 0, 0}, lo[3] = {0, 0, 0};
+    for (int d = 0; d < 3; ++d) { L[d] = (double)h->box_hi[d] - h->box_lo[d]; lo[d] = h->box_lo[d]; }
+    auto mimg = [&](double* v) { if (per) for (int d = 0; d < 3; ++d) if (L[d] > 0) v[d] -= std::rint(v[d] / L[d]) * L[d]; };
+    // cell grid over the acceptors (cell edge >= max distance)
+    const double rc = h->hb_dmax;
+    double glo[3] = {1e300, 1e300, 1e300}, ghi[3] = {-1e300, -1e300, -1e300};
+    if (per) for (int d = 0; d < 3; ++d) { glo[d] = lo[d]; ghi[d] = lo[d] + L[d]; }
+    else for (uint32_t i = 0; i < N; ++i) for (int d = 0; d < 3; ++d) { glo[d] = std::min(glo[d], (double)pos[3 * i + d]); ghi[d] = std::max(ghi[d], (double)pos[3 * i + d] + 1e-3); }
+    int nc[3];
+    for (int d = 0; d < 3; ++d) nc[d] = std::max(1, std::min(256, (int)std::floor((ghi[d] - glo[d]) / rc)));
+    auto cell_of = [&](const float* p, int* c) {
+        for (int d = 0; d < 3; ++d) {
+            double t = (double)p[d] - glo[d]; const double W = ghi[d] - glo[d];
+            if (per) t -= std::floor(t / W) * W;
+            c[d] = std::max(0, std::min(nc[d] - 1, (int)(t / W * nc[d])));
+        }
+    };
+    std::vector<uint32_t> start((size_t)nc[0] * nc[1] * nc[2] + 1, 0), items;
+    std::vector<uint32_t> acc;
+    for (uint32_t i = 0; i < N; ++i) if (h->hb_heavy[i]) acc.push_back(i);
+    std::vector<uint32_t> cid(acc.size());
+    for (size_t k = 0; k < acc.size(); ++k) { int c[3]; cell_of(pos + 3 * (size_t)acc[k], c); cid[k] = (uint32_t)((c[0] * nc[1] + c[1]) * nc[2] + c[2]); start[cid[k] + 1]++; }
+    for (size_t c = 0; c + 1 < start.size(); ++c) start[c + 1] += start[c];
+    items.resize(acc.size());
+    { std::vector<uint32_t> cur(start.begin(), start.end() - 1); for (size_t k = 0; k < acc.size(); ++k) items[cur[cid[k]]++] = acc[k]; }
+    const double cos_min = std::cos(h->hb_angle_min * M_PI / 180.0);
+    for (uint32_t hy = 0; hy < N; ++hy) {
+        const uint32_t dn = h->hb_donor_of[hy];
+        if (dn == MDX_INVALID) continue;
+        int c[3]; cell_of(pos + 3 * (size_t)hy, c);
+        double dh[3] = {(double)pos[3 * dn] - pos[3 * hy], (double)pos[3 * dn + 1] - pos[3 * hy + 1], (double)pos[3 * dn + 2] - pos[3 * hy + 2]};
+        mimg(dh);
+        const double rdh = std::sqrt(dh[0] * dh[0] + dh[1] * dh[1] + dh[2] * dh[2]);
+        // the distinct neighbour cells per dimension (a box of one or two cells wraps onto itself)
+        int nb[3][3], nnb[3];
+        for (int d = 0; d < 3; ++d) {
+            nnb[d] = 0;
+            for (int o = -1; o <= 1; ++o) {
+                int q = c[d] + o;
+                if (per) q = (q + nc[d]) % nc[d]; else if (q < 0 || q >= nc[d]) continue;
+                bool seen = false;
+                for (int k = 0; k < nnb[d]; ++k) seen |= nb[d][k] == q;
+                if (!seen) nb[d][nnb[d]++] = q;
+            }
+        }
+        for (int ia = 0; ia < nnb[0]; ++ia) for (int ib = 0; ib < nnb[1]; ++ib) for (int ic = 0; ic < nnb[2]; ++ic) {
+            const int q[3] = {nb[0][ia], nb[1][ib], nb[2][ic]};
+            const size_t cq = ((size_t)q[0] * nc[1] + q[1]) * nc[2] + q[2];
+            for (uint32_t k = start[cq]; k < start[cq + 1]; ++k) {
+                const uint32_t ac = items[k];
+                if (ac == dn) continue;
+                double ha[3] = {(double)pos[3 * ac] - pos[3 * hy], (double)pos[3 * ac + 1] - pos[3 * hy + 1], (double)pos[3 * ac + 2] - pos[3 * hy + 2]};
+                mimg(ha);
+                const double r = std::sqrt(ha[0] * ha[0] + ha[1] * ha[1] + ha[2] * ha[2]);
+                if (r > rc || r <= 0.0 || rdh <= 0.0) continue;
+                const double cs = (dh[0] * ha[0] + dh[1] * ha[1] + dh[2] * ha[2]) / (rdh * r);   // cos of the angle D-H...A at the hydrogen
+                if (cs > cos_min) continue;                                                      // angle below the minimum
+                const double ang = std::acos(std::max(-1.0, std::min(1.0, cs))) * 180.0 / M_PI;
+                const double sd = std::max(0.0, std::min(1.0, 1.0 - (r - 1.5) / std::max(rc - 1.5, 1e-6)));
+                const double sa = std::max(0.0, std::min(1.0, (ang - h->hb_angle_min) / std::max(180.0 - h->hb_angle_min, 1e-6)));
+                mdx_hbond hb{};
+                hb_ref(h, dn, &hb.donor, &hb.donor_type); hb_ref(h, ac, &hb.acceptor, &hb.acceptor_type); hb_ref(h, hy, &hb.hydrogen, &hb.hydrogen_type);
+                hb.strength = (float)(sd * sa);
+                out.push_back(hb);
+            }
+        }
+    }
+}
+
 static int take_snapshot(mdx_handle* h) {
     mdx_handle::Snapshot sn;
     sn.time = h->time_ps; sn.step = h->step_count;
     MDX_TRY(mdx_energy_impl(h, &sn.e));
-    sn.pos.resize(3 * (size_t)h->n_local);
+    const uint32_t n_rows = h->dd ? h->N : h->n_local;     // (a decomposed handle's read-back is the gathered global array)
+    sn.pos.resize(3 * (size_t)n_rows);
     MDX_TRY(mdx_download(h, MDX_POS, sn.pos.data()));
     if (h->snap_vel) {
-        sn.vel.resize(3 * (size_t)h->n_local);
+        sn.vel.resize(3 * (size_t)n_rows);
         MDX_TRY(mdx_download(h, MDX_VEL, sn.vel.data()));
     }
+    if (!h->hb_heavy.empty() && n_rows == h->N) detect_hbonds(h, sn.pos.data(), sn.hbonds);
     h->snapshots.push_back(std::move(sn));
     return MDX_OK;
 }
@@ -381,6 +471,73 @@ extern "C" int mdx_snapshot_read(mdx_handle* h, uint32_t k, double* time_ps, uin
         if (sn.vel.empty()) FAIL(MDX_EPARAM, "snapshot was taken without velocities");
         std::memcpy(vel, sn.vel.data(), sizeof(float) * sn.vel.size());
     }
+    return MDX_OK;
+}
+
+extern "C" int mdx_set_water_layout(mdx_handle* h, uint32_t first_atom, uint32_t n_waters, uint32_t sites_per_water) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    if (n_waters && sites_per_water != 3 && sites_per_water != 4) FAIL(MDX_EPARAM, "a water record has 3 (O, H0, H1) or 4 (O, H0, H1, M) sites");
+    if ((uint64_t)first_atom + (uint64_t)n_waters * sites_per_water > h->N) FAIL(MDX_EPARAM, "water records reach beyond the atom array");
+    h->water_first = first_atom; h->n_waters = n_waters; h->water_sites = n_waters ? sites_per_water : 0;
+    return MDX_OK;
+}
+
+extern "C" int mdx_water_download(mdx_handle* h, int which, float* o, float* h0, float* h1, float* m) {
+    if (!h || !o || !h0 || !h1) FAIL(MDX_EPARAM, "null argument");
+    if (!h->n_waters) FAIL(MDX_EPARAM, "no water layout set (mdx_set_water_layout)");
+    if (which != MDX_POS && which != MDX_FORCE) FAIL(MDX_EPARAM, "md.water mirrors posit and force");
+    if (m && h->water_sites != 4) FAIL(MDX_EPARAM, "3-site water has no M site");
+    std::vector<float> all(3 * (size_t)h->N);
+    if (!h->dd && h->n_local != h->N) FAIL(MDX_EPARAM, "mdx_water_download needs the whole system on this handle");
+    MDX_TRY(mdx_download(h, which, all.data()));
+    float* dst[4] = {o, h0, h1, m};
+    for (uint32_t w = 0; w < h->n_waters; ++w)
+        for (uint32_t k = 0; k < h->water_sites; ++k)
+            if (dst[k]) std::memcpy(dst[k] + 3 * (size_t)w, all.data() + 3 * ((size_t)h->water_first + (size_t)w * h->water_sites + k), 3 * sizeof(float));
+    return MDX_OK;
+}
+
+extern "C" int mdx_set_hbond_detection(mdx_handle* h, const uint8_t* is_hbond_heavy, float max_h_acc_dist, float min_angle_deg) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    if (!is_hbond_heavy) { h->hb_heavy.clear(); h->hb_donor_of.clear(); return MDX_OK; }
+    if (!(max_h_acc_dist > 1.5f) || !std::isfinite(max_h_acc_dist)) max_h_acc_dist = 2.5f;
+    if (!(min_angle_deg > 0.f && min_angle_deg < 180.f)) min_angle_deg = 120.f;
+    h->hb_dmax = max_h_acc_dist; h->hb_angle_min = min_angle_deg;
+    h->hb_heavy.assign(is_hbond_heavy, is_hbond_heavy + h->N);
+    // donor hydrogens: light atoms (mass < 1.6 Da) bound - bond or constraint - to a flagged heavy atom
+    h->hb_donor_of.assign(h->N, MDX_INVALID);
+    for (size_t k = 0; k + 1 < h->h_bond_pairs.size(); k += 2) {
+        const uint32_t a = h->h_bond_pairs[k], b = h->h_bond_pairs[k + 1];
+        const bool ha = h->h_mass[a] > 0.f && h->h_mass[a] < 1.6f, hb = h->h_mass[b] > 0.f && h->h_mass[b] < 1.6f;
+        if (ha && !hb && h->hb_heavy[b]) h->hb_donor_of[a] = b;
+        else if (hb && !ha && h->hb_heavy[a]) h->hb_donor_of[b] = a;
+    }
+    return MDX_OK;
+}
+
+extern "C" int mdx_snapshot_read_water(mdx_handle* h, uint32_t k, float* o, float* h0, float* h1) {
+    if (!h || !o || !h0 || !h1) FAIL(MDX_EPARAM, "null argument");
+    if (k >= h->snapshots.size()) FAIL(MDX_EPARAM, "snapshot index out of range");
+    if (!h->n_waters) FAIL(MDX_EPARAM, "no water layout set (mdx_set_water_layout)");
+    const auto& sn = h->snapshots[k];
+    if (sn.pos.size() != 3 * (size_t)h->N) FAIL(MDX_EPARAM, "snapshot does not hold the whole system");
+    float* dst[3] = {o, h0, h1};
+    for (uint32_t w = 0; w < h->n_waters; ++w)
+        for (uint32_t s3 = 0; s3 < 3; ++s3)
+            std::memcpy(dst[s3] + 3 * (size_t)w, sn.pos.data() + 3 * ((size_t)h->water_first + (size_t)w * h->water_sites + s3), 3 * sizeof(float));
+    return MDX_OK;
+}
+
+extern "C" uint32_t mdx_snapshot_hbond_count(const mdx_handle* h, uint32_t k) {
+    return (h && k < h->snapshots.size()) ? (uint32_t)h->snapshots[k].hbonds.size() : 0u;
+}
+
+extern "C" int mdx_snapshot_read_hbonds(mdx_handle* h, uint32_t k, mdx_hbond* out, uint32_t capacity) {
+    if (!h || (!out && capacity)) FAIL(MDX_EPARAM, "null argument");
+    if (k >= h->snapshots.size()) FAIL(MDX_EPARAM, "snapshot index out of range");
+    const auto& hb = h->snapshots[k].hbonds;
+    if (hb.size() > capacity) FAIL(MDX_EPARAM, "hydrogen-bond buffer too small (mdx_snapshot_hbond_count)");
+    if (!hb.empty()) std::memcpy(out, hb.data(), sizeof(mdx_hbond) * hb.size());
     return MDX_OK;
 }
 

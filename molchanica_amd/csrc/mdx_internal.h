@@ -259,7 +259,12 @@ struct mdx_handle {
     bool zero_com = false;
     uint32_t snap_every = 0; bool snap_vel = false;
     double time_ps = 0.0;
-    struct Snapshot { double time; uint64_t step; mdx_energies e; std::vector<float> pos, vel; };
+    struct Snapshot { double time; uint64_t step; mdx_energies e; std::vector<float> pos, vel; std::vector<mdx_hbond> hbonds; };
+    // md.water views and hydrogen-bond detection (mdx_set_water_layout / mdx_set_hbond_detection)
+    uint32_t water_first = 0, n_waters = 0, water_sites = 0;
+    std::vector<uint8_t> hb_heavy; float hb_dmax = 2.5f, hb_angle_min = 120.f;
+    std::vector<uint32_t> hb_donor_of;   // [N] heavy atom a hydrogen is bound to (MDX_INVALID: not a donor hydrogen)
+    std::vector<uint32_t> h_bond_pairs;  // bonds + constraints as given at creation (pairs), for the donor table
     std::vector<Snapshot> snapshots;
     DeviceState d;
     StepCtl* h_ctl = nullptr;  // pinned

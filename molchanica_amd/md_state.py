@@ -17,7 +17,7 @@ import os
 
 import numpy as np
 
-from ._abi import (CConfig, CEnergies, CStats, CSystem, FORCE, MDX_EDEVICE, MDX_ENAN, MDX_EOOM,
+from ._abi import (CHBond, CConfig, CEnergies, CStats, CSystem, FORCE, MDX_EDEVICE, MDX_ENAN, MDX_EOOM,
                    MDX_EPARAM, MDX_OK, POS, VEL, MdConfig, MdSystem)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -97,6 +97,13 @@ def load_library():
     lib.mdx_snapshot_read.argtypes = [H, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                       C.POINTER(CEnergies), _fp, _fp]
     lib.mdx_flush_snapshot_queues.argtypes = [H]
+    lib.mdx_set_water_layout.argtypes = [H, C.c_uint32, C.c_uint32, C.c_uint32]
+    lib.mdx_water_download.argtypes = [H, C.c_int, _fp, _fp, _fp, _fp]
+    lib.mdx_set_hbond_detection.argtypes = [H, C.c_void_p, C.c_float, C.c_float]
+    lib.mdx_snapshot_read_water.argtypes = [H, C.c_uint32, _fp, _fp, _fp]
+    lib.mdx_snapshot_hbond_count.argtypes = [H, C.c_uint32]
+    lib.mdx_snapshot_hbond_count.restype = C.c_uint32
+    lib.mdx_snapshot_read_hbonds.argtypes = [H, C.c_uint32, C.POINTER(CHBond), C.c_uint32]
     lib.mdx_time_ps.argtypes = [H]
     lib.mdx_time_ps.restype = C.c_double
     lib.mdx_set_local_atoms.argtypes = [H, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -317,9 +324,49 @@ class MdState:
             if rc != MDX_OK:   # taken without velocities
                 _check(lib.mdx_snapshot_read(self._h, k, C.byref(t), C.byref(st), C.byref(e), pos.ctypes.data_as(_fp), None))
                 vel = None
-            out.append(dict(time=float(t.value), step=int(st.value), energy_data=e.as_dict(), atom_posits=pos,
-                            atom_velocities=vel))
+            snap = dict(time=float(t.value), step=int(st.value), energy_data=e.as_dict(), atom_posits=pos,
+                        atom_velocities=vel)
+            if self._n_waters:      # the reference's Snapshot: non-water atoms + water_o / h0 / h1 (src/md/viewer.rs:374-394)
+                o, h0, h1 = (np.empty((self._n_waters, 3), dtype=np.float32) for _ in range(3))
+                _check(lib.mdx_snapshot_read_water(self._h, k, o.ctypes.data_as(_fp), h0.ctypes.data_as(_fp), h1.ctypes.data_as(_fp)))
+                snap.update(all_posits=pos, atom_posits=pos[:self._water_first], water_o_posits=o, water_h0_posits=h0, water_h1_posits=h1)
+            n_hb = int(lib.mdx_snapshot_hbond_count(self._h, k))
+            hb = (CHBond * max(n_hb, 1))()
+            if n_hb:
+                _check(lib.mdx_snapshot_read_hbonds(self._h, k, hb, n_hb))
+            snap["energy_data"]["hydrogen_bonds"] = [
+                dict(donor=(b.donor_type, b.donor), acceptor=(b.acceptor_type, b.acceptor), hydrogen=(b.hydrogen_type, b.hydrogen),
+                     strength=float(b.strength)) for b in hb[:n_hb]]
+            out.append(snap)
         return out
+
+    # -- md.water / hydrogen bonds ---------------------------------------------------------------
+    _n_waters = 0
+    _water_first = 0
+    _water_sites = 0
+
+    def set_water_layout(self, first_atom: int, n_waters: int, sites_per_water: int):
+        """Where the solvent waters sit in the flat atom array: the reference keeps them apart in `md.water`
+        (src/properties/sol_shrinking_box.rs:605-613)."""
+        _check(load_library().mdx_set_water_layout(self._h, int(first_atom), int(n_waters), int(sites_per_water)))
+        self._water_first, self._n_waters, self._water_sites = int(first_atom), int(n_waters), int(sites_per_water)
+
+    def water(self, which: str = "posit") -> dict:
+        """`md.water[i].{o,h0,h1,m}.posit / .force` as arrays [n_waters, 3] (sol_shrinking_box.rs:780-786)."""
+        n = self._n_waters
+        arr = {k: np.empty((n, 3), dtype=np.float32) for k in (("o", "h0", "h1", "m") if self._water_sites == 4 else ("o", "h0", "h1"))}
+        _check(load_library().mdx_water_download(self._h, POS if which == "posit" else FORCE, arr["o"].ctypes.data_as(_fp),
+                                                 arr["h0"].ctypes.data_as(_fp), arr["h1"].ctypes.data_as(_fp),
+                                                 arr["m"].ctypes.data_as(_fp) if "m" in arr else None))
+        return arr
+
+    def set_hbond_detection(self, is_heavy_nosf, max_h_acc_dist: float = 2.5, min_angle_deg: float = 120.0):
+        """Hydrogen bonds in every snapshot's energy data (src/md/viewer.rs:917-960); None switches it off."""
+        if is_heavy_nosf is None:
+            _check(load_library().mdx_set_hbond_detection(self._h, None, 0.0, 0.0))
+            return
+        m = np.ascontiguousarray(is_heavy_nosf, dtype=np.uint8).reshape(self.n_atoms)
+        _check(load_library().mdx_set_hbond_detection(self._h, m.ctypes.data, float(max_h_acc_dist), float(min_angle_deg)))
 
     def flush_snapshot_queues(self):
         _check(load_library().mdx_flush_snapshot_queues(self._h))

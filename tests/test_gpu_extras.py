@@ -153,6 +153,85 @@ def test_snapshots_cadence_and_contents(mdx):
         assert md.snapshots == []
 
 
+def test_snapshots_follow_the_oracle_trajectory(mdx, orc):
+    """Every stored snapshot - positions, velocities, per-term energies - against the ORACLE's trajectory stopped at the
+    same step (not against a second engine run)."""
+    s = systems.small_solvated()
+    cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, coulomb_mode=1)
+    with mdx.MdState(s, cfg) as md:
+        x0, v0 = md.positions().astype(np.float64), md.velocities().astype(np.float64)
+        md.set_snapshot_cadence(10, with_velocities=True)
+        md.step(0.0005, None, 30)
+        snaps = md.snapshots
+    assert [sn["step"] for sn in snaps] == [10, 20, 30]
+    L = np.array(s.box_hi) - np.array(s.box_lo)
+    x, v = x0, v0
+    for sn in snaps:
+        x, v, _ = orc.step(s, cfg, 0.0005, 10, pos=x, vel=v)
+        d = sn["atom_posits"].astype(np.float64) - x
+        d -= np.round(d / L) * L
+        assert math.sqrt((d ** 2).sum(1).mean()) < 5e-4, sn["step"]
+        assert math.sqrt(((sn["atom_velocities"] - v) ** 2).sum(1).mean()) < 5e-2
+        _, eo = orc.forces(s, cfg, pos=x)
+        for k in ("bond", "angle", "dihedral", "lj", "coulomb", "lj14", "coulomb14"):
+            assert sn["energy_data"][k] == pytest.approx(eo[k], rel=2e-4, abs=0.5), (sn["step"], k)
+        assert sn["energy_data"]["kinetic"] == pytest.approx(orc.kinetic(s, v), rel=1e-3)
+
+
+def test_water_views_and_hydrogen_bonds_of_a_snapshot(mdx):
+    """The reference keeps solvent water apart: `md.water[i].{o,h0,h1,m}.{posit,force}` (sol_shrinking_box.rs:605-613,
+    780-786) and a Snapshot's `atom_posits` (non-water) + `water_o/h0/h1_posits` + `hydrogen_bonds`
+    (src/md/viewer.rs:374-394, 917-960).  Views over the flat atom array, and the library's hydrogen-bond rule against
+    a brute-force evaluation of the same rule."""
+    s = systems.small_solvated()
+    cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5)
+    n_sol = int(s.mol_start[1])                       # one solute chain, then waters (O, H, H)
+    n_w = (s.n_atoms - n_sol) // 3
+    heavy = np.zeros(s.n_atoms, np.uint8)
+    heavy[n_sol::3] = 1                               # water oxygens
+    heavy[:n_sol:5] = 1                               # a few solute atoms play N/O
+    with mdx.MdState(s, cfg) as md:
+        md.set_water_layout(n_sol, n_w, 3)
+        md.set_hbond_detection(heavy, 2.5, 120.0)
+        md.set_snapshot_cadence(5)
+        md.step(0.0005, None, 10)
+        pos, frc = md.positions(), md.forces()
+        w, wf = md.water("posit"), md.water("force")
+        snaps = md.snapshots
+    assert np.array_equal(w["o"], pos[n_sol::3]) and np.array_equal(w["h0"], pos[n_sol + 1::3]) and np.array_equal(w["h1"], pos[n_sol + 2::3])
+    assert np.array_equal(wf["h1"], frc[n_sol + 2::3])
+    sn = snaps[-1]
+    assert sn["step"] == 10 and sn["atom_posits"].shape == (n_sol, 3) and sn["water_o_posits"].shape == (n_w, 3)
+    assert np.array_equal(sn["water_h0_posits"], sn["all_posits"][n_sol + 1::3])
+    # brute force of the documented rule on the snapshot's coordinates
+    P = sn["all_posits"].astype(np.float64)
+    L = np.array(s.box_hi, np.float64) - np.array(s.box_lo, np.float64)
+    donor_of = {}
+    for a, b in np.concatenate([s.bond_idx.reshape(-1, 2)]):
+        for h_, d_ in ((a, b), (b, a)):
+            if s.mass[h_] < 1.6 and s.mass[d_] >= 1.6 and heavy[d_]:
+                donor_of[int(h_)] = int(d_)
+    acc = np.nonzero(heavy)[0]
+    want = set()
+    for h_, d_ in donor_of.items():
+        dh = P[d_] - P[h_]; dh -= np.round(dh / L) * L
+        ha = P[acc] - P[h_]; ha -= np.round(ha / L) * L
+        r = np.linalg.norm(ha, axis=1)
+        cs = (ha @ dh) / (np.maximum(r, 1e-12) * np.linalg.norm(dh))
+        ok = (r <= 2.5) & (r > 0) & (cs <= math.cos(math.radians(120.0))) & (acc != d_)
+        for a_ in acc[ok]:
+            want.add((d_, int(a_), h_))
+
+    def atom_of(ref):
+        t, i = ref
+        return i if t == 0 else n_sol + 3 * i + (t - 1)
+    got = {(atom_of(b["donor"]), atom_of(b["acceptor"]), atom_of(b["hydrogen"])) for b in sn["energy_data"]["hydrogen_bonds"]}
+    assert len(want) > 50, "the test configuration has no hydrogen bonds to find"
+    assert got == want
+    assert all(0.0 <= b["strength"] <= 1.0 for b in sn["energy_data"]["hydrogen_bonds"])
+    assert any(b["donor"][0] == 1 and b["hydrogen"][0] in (2, 3) for b in sn["energy_data"]["hydrogen_bonds"]), "water donors use the water types"
+
+
 def test_shrink_cell_towards_matches_the_oracle(mdx, orc):
     """`md.shrink_cell_towards(dev, target, cfg)` + `md.step(dev, DT, None)` per iteration, as the packing loop of
     src/properties/sol_shrinking_box.rs:989-995 does: cell, coordinates and the trajectory follow the oracle's."""
