@@ -279,13 +279,22 @@ int mdx_get_stats(mdx_handle* h, mdx_stats* out);
 int mdx_set_integrator(mdx_handle* h, int kind, float gamma_per_ps, float temperature, uint64_t seed);
 
 /* `md.configure_alchemical_window(dev, mol_index, lambda)` (src/properties/water_sol.rs:556): thermodynamic
- * integration windows, lambda from 0 (full interaction between the molecule and its environment) to 1 (none,
- * water_sol.rs:52-56).  The coupling form lives in the absent crate; built here: LINEAR coupling of the
- * non-bonded (LJ + real-space Coulomb) interactions between the atoms of molecule `mol_index` and every other
- * atom, U(lambda) = U_rest + (1 - lambda) U_cross; intramolecular terms (bonded, 1-4, intra non-bonded) are not
- * scaled.  Every energy evaluation (hence every snapshot) reports dh_dlambda = -U_cross.  Needs mol_start in the
- * system description; not available with the SPME reciprocal sum or on a decomposed handle.  lambda < 0 switches
- * the window off. */
+ * integration windows, lambda from 0 (full interaction between the molecule and its environment) to 1 (none); the
+ * reference's grid ends ... 0.90, 0.95, 1.0 (water_sol.rs:52-56) and runs under its default SPME Coulomb (README.md:240).
+ * The coupling form lives in the absent crate; built here: the non-bonded interactions between the atoms of molecule
+ * `mol_index` and every other atom are scaled by (1 - lambda) and evaluated at the SOFT-CORE distance
+ *     r_sc = (alpha sigma_ij^6 lambda + r^6)^(1/6)        (Beutler et al. 1994; alpha 0.5; sigma_min 3 A for pairs without LJ)
+ * - LJ and real-space Coulomb alike - so dU/dlambda stays finite at lambda = 1 whatever overlaps the decoupled molecule;
+ * U(lambda) = U_rest + (1 - lambda) U_cross(r_sc).  Intramolecular terms (bonded, 1-4, intra non-bonded) are not scaled.
+ * With the SPME reciprocal sum the mesh part of the cross interaction is scaled exactly: environment and molecule are
+ * spread and transformed separately (the mesh potential is linear in the charges), E_rec(lambda) = E_env,env + E_mol,mol
+ * + (1 - lambda) 2 E_env,mol, and each atom's force is interpolated from its own group's potential plus (1 - lambda)
+ * times the other's; the uniform background of a charged molecule is left unscaled.
+ * Every energy evaluation (hence every snapshot) reports dh_dlambda = dU/dlambda and coupled_interaction =
+ * (1 - lambda) U_cross.  Needs mol_start in the system description; not available on a decomposed handle.
+ * lambda < 0 switches the window off.  mdx_set_alchemical_softcore: alpha = 0 selects plain linear coupling
+ * (singular in dU/dlambda at lambda -> 1 for overlapping sites). */
+int mdx_set_alchemical_softcore(mdx_handle* h, float alpha, float sigma_min);
 int mdx_configure_alchemical_window(mdx_handle* h, uint32_t mol_index, double lambda);
 
 #define MDX_BAROSTAT_NONE      0

@@ -143,7 +143,7 @@ static void free_device(mdx_handle* h) {
                     d.mchunk_cnt, d.mchunk_off, d.entries, d.entries_in, d.inner_nch, d.list_cursors, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
                     d.role_off_s, d.role_rec_s, d.ctl, d.energy,
                     d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.pme_force, d.cons_o, d.cons_s, d.cons_vir, d.vsite_o, d.vsite_s, d.pme_q, d.pme_f,
-                    d.pme_theta, d.scratch4, d.tile_bnd, d.tile_scan, d.tile_order};
+                    d.pme_theta, d.pme_q2, d.pme_f2, d.scratch4, d.tile_bnd, d.tile_scan, d.tile_order};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = DeviceState{};
 }
@@ -321,9 +321,9 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
         HIP_TRY(hipStreamSynchronize(st));
     }
     MDX_TRY(alloc_n(&d.slot_of, N)); MDX_TRY(alloc_n(&d.cell_of, N)); MDX_TRY(alloc_n(&d.sorted_orig, N));
-    MDX_TRY(alloc_n(&d.ctl, 1)); MDX_TRY(alloc_n(&d.energy, EN_COUNT + 8 + 4 * MDX_EPART)); MDX_TRY(alloc_n(&d.flags_dev, 4));
+    MDX_TRY(alloc_n(&d.ctl, 1)); MDX_TRY(alloc_n(&d.energy, EN_COUNT + 8 + MDX_ESTRIDE * MDX_EPART)); MDX_TRY(alloc_n(&d.flags_dev, 4));
     HIP_TRY(hipMemsetAsync(d.ctl, 0, sizeof(StepCtl), st));
-    HIP_TRY(hipMemsetAsync(d.energy, 0, sizeof(double) * (EN_COUNT + 8 + 4 * MDX_EPART), st));
+    HIP_TRY(hipMemsetAsync(d.energy, 0, sizeof(double) * (EN_COUNT + 8 + MDX_ESTRIDE * MDX_EPART), st));
     HIP_TRY(hipHostMalloc((void**)&h->h_ctl, sizeof(StepCtl), hipHostMallocDefault));
     HIP_TRY(hipStreamSynchronize(st));  // host vectors go out of scope
     h->in_slot_space = false; h->list_valid = false; h->forces_valid = false;
@@ -587,18 +587,18 @@ int mdx_energy_impl(mdx_handle* h, mdx_energies* out) {
     if (!h->list_valid) MDX_TRY(mdx_rebuild(h));
     if (h->cons_dirty) MDX_TRY(ensure_ready(h));
     hipStream_t st = h->stream;
-    HIP_TRY(hipMemsetAsync(h->d.energy, 0, sizeof(double) * (EN_COUNT + 8 + 4 * MDX_EPART), st));
+    HIP_TRY(hipMemsetAsync(h->d.energy, 0, sizeof(double) * (EN_COUNT + 8 + MDX_ESTRIDE * MDX_EPART), st));
     MDX_TRY(compute_forces(h, true, nullptr, 0));
     h->forces_valid = true;
     MDX_TRY(mdx_launch_kinetic(h));
     MDX_TRY(mdx_launch_constraint_virial(h));   // SHAKE forces of the last step (0 after a dt = 0 projection)
-    double e[EN_COUNT + 8 + 4 * MDX_EPART];
+    double e[EN_COUNT + 8 + MDX_ESTRIDE * MDX_EPART];
     HIP_TRY(hipMemcpyAsync(e, h->d.energy, sizeof(e), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    double u_cross = 0.0;
+    double u_cross = 0.0, du_dl = 0.0;
     for (int k = 0; k < MDX_EPART; ++k) {   // the pair kernel's partial sums
-        const double* q = e + EN_COUNT + 8 + 4 * k;
-        e[EN_LJ] += q[0]; e[EN_COUL] += q[1]; e[EN_VIRIAL] += q[2]; u_cross += q[3];
+        const double* q = e + EN_COUNT + 8 + MDX_ESTRIDE * k;
+        e[EN_LJ] += q[0]; e[EN_COUL] += q[1]; e[EN_VIRIAL] += q[2]; u_cross += q[3]; du_dl += q[4];
     }
     if (h->profile) mdx_prof_collect(h);
     if (h->dd) {   // every rank evaluated its share (a pair's energy is split between the owners of its atoms): sum them
@@ -632,7 +632,11 @@ int mdx_energy_impl(mdx_handle* h, mdx_energies* out) {
         out->virial = e[EN_VIRIAL] + (h->pme_on ? 3.0 * h->ewald_background : 0.0);
         out->pressure = (2.0 * out->kinetic + out->virial) / (3.0 * out->volume) * MDX_BAR_PER_KCAL_MOL_A3;
     }
-    if (h->alch_on) { out->dh_dlambda = -u_cross; out->coupled_interaction = (1.0 - h->alch_lambda) * u_cross; }
+    if (h->alch_on) {
+        // (with the SPME reciprocal sum: + its dU/dlambda = -2 E_env,mol; the real-space cross energy is the "coupled interaction")
+        out->dh_dlambda = du_dl + (h->pme_on ? e[EN_COUNT + 5] : 0.0);
+        out->coupled_interaction = (1.0 - h->alch_lambda) * (u_cross - (h->pme_on ? e[EN_COUNT + 5] : 0.0));
+    }
     uint32_t mf2; std::memcpy(&mf2, &e[EN_COUNT], 4);
     out->max_force = std::sqrt((double)u2f(mf2));
     const double tot = out->potential + out->kinetic;

@@ -397,6 +397,15 @@ extern "C" int mdx_set_integrator(mdx_handle* h, int kind, float gamma_per_ps, f
     return MDX_OK;
 }
 
+extern "C" int mdx_set_alchemical_softcore(mdx_handle* h, float alpha, float sigma_min) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    if (!(alpha >= 0.f) || !std::isfinite(alpha)) FAIL(MDX_EPARAM, "soft-core alpha must be >= 0 (0 = linear coupling)");
+    if (!(sigma_min > 0.f) || !std::isfinite(sigma_min)) FAIL(MDX_EPARAM, "soft-core sigma_min must be > 0");
+    h->sc_alpha = alpha; h->sc_sigma_min = sigma_min;
+    h->forces_valid = false;
+    return MDX_OK;
+}
+
 extern "C" int mdx_configure_alchemical_window(mdx_handle* h, uint32_t mol_index, double lambda) {
     if (!h) FAIL(MDX_EPARAM, "null handle");
     HIP_TRY(hipSetDevice(h->device));
@@ -404,7 +413,6 @@ extern "C" int mdx_configure_alchemical_window(mdx_handle* h, uint32_t mol_index
     if (on) {
         if (!(lambda <= 1.0)) FAIL(MDX_EPARAM, "lambda must lie in [0, 1] (negative switches the window off)");
         if (h->mol_start.empty() || mol_index >= h->mol_start.size()) FAIL(MDX_EPARAM, "molecule index out of range (mol_start missing?)");
-        if (h->pme_on) FAIL(MDX_EPARAM, "alchemical windows are not available with the SPME reciprocal sum");
         if (h->dd || h->n_local != h->N) FAIL(MDX_EPARAM, "alchemical windows are not supported on a decomposed handle");
     }
     const uint32_t lo = on ? h->mol_start[mol_index] : 0;

@@ -31,6 +31,7 @@
 #define MDX_DUMMY_STEP 64.0f
 #define MDX_MAX_CHUNK 64
 
+#define MDX_ESTRIDE 5   // {lj, coulomb, virial, cross (alchemical: unscaled energy of the coupled pairs), dU/dlambda} per slot
 #define MDX_EPART 256   // the pair kernel spreads its energy atomics over this many slots (contended f64 atomics cost ~10 ns each)
 enum { EN_BOND = 0, EN_ANGLE, EN_DIHEDRAL, EN_LJ, EN_COUL, EN_LJ14, EN_COUL14, EN_KIN, EN_RECIP, EN_VIRIAL, EN_COUNT };
 
@@ -53,6 +54,7 @@ struct NbParams {
     float soft2;
     int coul_mode;
     float alch_scale;        // 1 - lambda: factor on pairs with exactly one atom in the coupled molecule (ALCH kernels)
+    float sc_al, sc_alpha, sc_sigmin;   // soft core of those pairs: r_sc^6 = sc_al sigma^6 + r^6, sc_al = alpha lambda (0: linear coupling)
     int geometric;           // combining rule
     int lj_on, coul_on;
 };
@@ -162,6 +164,7 @@ struct DeviceState {
     RoleRec*  role_rec_s = nullptr;                                  // [R]
     // SPME (mdx_pme.hip)
     float* pme_q = nullptr; float2* pme_f = nullptr; float* pme_theta = nullptr;
+    float* pme_q2 = nullptr; float2* pme_f2 = nullptr;   // alchemical window: the coupled molecule's own mesh
     float4* pme_force = nullptr;   // [S] reciprocal-space force when the chain runs on its side stream
     // constraints and virtual sites
     ConsGroup* cons_o = nullptr; ConsGroup* cons_s = nullptr;
@@ -169,7 +172,7 @@ struct DeviceState {
     VSite* vsite_o = nullptr; VSite* vsite_s = nullptr;
     // control / reductions
     StepCtl* ctl = nullptr;
-    double*  energy = nullptr;     // [EN_COUNT + 8 + 4*MDX_EPART]: energies, max|F|^2 bits, momentum (px,py,pz,mass),
+    double*  energy = nullptr;     // [EN_COUNT + 8 + MDX_ESTRIDE*MDX_EPART]: energies, max|F|^2 bits, momentum (px,py,pz,mass),
                                    // then MDX_EPART x {lj, coulomb, virial, -} partial sums of the pair kernel
     uint32_t* flags_dev = nullptr; // misc error flags
     unsigned long long* pair_count = nullptr;  // cluster pairs in the list (statistics)
@@ -214,6 +217,7 @@ struct mdx_handle {
     std::vector<float2> h_lj;          // host copy of the per-atom LJ record (sign of .y marks the alchemical molecule)
     std::vector<uint32_t> mol_start;   // first atom of each molecule
     bool alch_on = false; double alch_lambda = 0.0; uint32_t alch_lo = 0, alch_hi = 0;
+    float sc_alpha = 0.5f, sc_sigma_min = 3.0f;   // soft core of the alchemical window (mdx_set_alchemical_softcore)
     // grid
     GridParams grid{};
     uint32_t ncol = 0, ncells = 0;

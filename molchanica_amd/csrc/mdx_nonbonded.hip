@@ -95,7 +95,7 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
                                           const float4 pj, const float2 lj, bool allowed, const NbParams& p,
                                           float& fx, float& fy, float& fz, float& elj, float& ecoul,
                                           float* g = nullptr, float* evir = nullptr, float* ecross = nullptr,
-                                          float r2bias = 0.f, float* r2_out = nullptr) {
+                                          float r2bias = 0.f, float* r2_out = nullptr, float* edudl = nullptr) {
     static_assert(!NANMASK || BRANCHY, "the NaN-coded exclusion needs the early-out");
     const float dx = xi - pj.x, dy = yi - pj.y, dz = zi - pj.z;   // tgt - src (src/cuda/util.cu:118-140)
     const float r2 = NANMASK ? __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, r2bias)))
@@ -105,12 +105,24 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
     const bool in_lj = (r2 < p.rc2_lj) && allowed;
     const bool in_c = SAMECUT ? in_lj : ((r2 < p.rc2_coul) && allowed);
     if (BRANCHY && !(in_lj || in_c)) return;
-    const float rinv = __builtin_amdgcn_rsqf(r2);
-    const float rinv2 = rinv * rinv;
     const float sig = GEOM ? sgi * lj.x : sgi + lj.x;
     const float eps_s = epi * lj.y;                 // 24 eps_ij (ALCH: signed)
     const float eps = ALCH ? fabsf(eps_s) : eps_s;
-    const float ascale = (ALCH && __float_as_int(eps_s) < 0) ? p.alch_scale : 1.0f;
+    // ALCH: a pair with exactly one atom in the coupled molecule.  Soft core (Beutler et al. 1994): it interacts at
+    // r_sc = (alpha lambda sigma^6 + r^6)^(1/6) instead of r - LJ and Coulomb alike - scaled by 1 - lambda, so that
+    // dU/dlambda stays finite at lambda = 1 (the reference's last window, src/properties/water_sol.rs:52-56).
+    const bool cross = ALCH && __float_as_int(eps_s) < 0;
+    const float ascale = cross ? p.alch_scale : 1.0f;
+    float rinv, r2e = r2, sg6 = 0.f;
+    if (ALCH) {
+        const float sgsc = (sig > 0.f && eps != 0.f) ? sig : p.sc_sigmin;
+        const float sg2 = sgsc * sgsc;
+        sg6 = sg2 * sg2 * sg2;
+        const float rsc6 = __builtin_fmaf(cross ? p.sc_al : 0.f, sg6, r2 * r2 * r2);
+        rinv = (cross && p.sc_al != 0.f) ? __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(rsc6) * (-1.0f / 6.0f)) : __builtin_amdgcn_rsqf(r2);
+        if (cross && p.sc_al != 0.f) r2e = __builtin_amdgcn_rcpf(rinv * rinv);
+    } else rinv = __builtin_amdgcn_rsqf(r2);
+    const float rinv2 = rinv * rinv;
     const float s2 = sig * sig * rinv2;
     const float s6 = s2 * s2 * s2;
     const float es6 = eps * s6;
@@ -118,13 +130,13 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
     const float qq = qi * pj.w;                     // k_e q_i q_j
     float fc_r2;                                    // Coulomb force * r^2
     if (COUL == CM_SHIFTED) fc_r2 = qq * rinv;
-    else if (COUL == CM_SOFT) fc_r2 = qq * rinv * r2 * __frcp_rn(r2 + p.soft2);
-    else if (COUL == CM_RF) fc_r2 = qq * (rinv - p.k_rf2 * r2);
+    else if (COUL == CM_SOFT) fc_r2 = qq * rinv * r2e * __frcp_rn(r2e + p.soft2);
+    else if (COUL == CM_RF) fc_r2 = qq * (rinv - p.k_rf2 * r2e);
     float erfc_ar = 0.f;
     if (COUL == CM_EWALD) {
         // erfc by Abramowitz & Stegun 7.1.26 (|error| < 1.5e-7) sharing the exponential the force
         // needs anyway: ~10 VALU ops instead of the ~45 of libm's erfcf
-        const float ar = p.alpha * r2 * rinv;
+        const float ar = p.alpha * r2e * rinv;
         const float ex = __expf(-ar * ar);
         const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ar);
         erfc_ar = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f)))) * ex;
@@ -133,20 +145,28 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
     float fs;
     if (SAMECUT) fs = (BRANCHY || in_lj) ? (flj_r2 + fc_r2) * rinv2 : 0.0f;
     else fs = (in_lj || in_c) ? ((in_lj ? flj_r2 : 0.0f) + (in_c ? fc_r2 : 0.0f)) * rinv2 : 0.0f;
-    if (ALCH) fs *= ascale;
+    const float fsc = fs;                           // ALCH: -U'(r_sc) / r_sc of the unscaled pair
+    if (ALCH) {
+        const float w = r2 * rinv2;                 // (r / r_sc)^2: dr_sc/dr = (r / r_sc)^5
+        fs *= cross ? ascale * w * w : 1.0f;
+    }
     fx += fs * dx; fy += fs * dy; fz += fs * dz;
     if (HALF) { g[0] += fs * dx; g[1] += fs * dy; g[2] += fs * dz; }   // minus the force on j
     if (ENERGY) {
         const float e_l = es6 * (s6 - 1.0f) * (1.0f / 6.0f);  // 4 eps (s12 - s6)
         float e_c;
         if (COUL == CM_SHIFTED || COUL == CM_SOFT) e_c = qq * (rinv - p.coul_shift);
-        else if (COUL == CM_RF) e_c = qq * (rinv + p.k_rf * r2 - p.coul_shift);
+        else if (COUL == CM_RF) e_c = qq * (rinv + p.k_rf * r2e - p.coul_shift);
         else e_c = qq * erfc_ar * rinv;
         // fp32 partial sums: the callers fold them into fp64 once per chunk of 64 j-atoms
         const float u_l = in_lj ? e_l : 0.f, u_c = in_c ? e_c : 0.f;
         elj += ALCH ? ascale * u_l : u_l;
         ecoul += ALCH ? ascale * u_c : u_c;
-        if (ALCH && ecross && __float_as_int(eps_s) < 0) *ecross += u_l + u_c;
+        if (ALCH && ecross && cross) {
+            *ecross += u_l + u_c;
+            // dU/dlambda = -U_cross(r_sc) + (1 - lambda) U'(r_sc) alpha sigma^6 / (6 r_sc^5)
+            if (edudl) *edudl += -(u_l + u_c) - ascale * fsc * p.sc_alpha * sg6 * rinv2 * rinv2 * (1.0f / 6.0f);
+        }
         if (evir) *evir += fs * r2;   // r_ij . F_ij of the pair (fs = 0 outside the cutoffs)
     }
 }
@@ -237,7 +257,7 @@ __global__ __launch_bounds__(NB_WAVES * 64) void nb_tile_kernel(NbArgs a) {
             evir += __shfl_xor(evir, m);
         }
         if (lane == 0) {   // every pair is seen from both sides
-            double* q = a.energy + EN_COUNT + 8 + 4 * (blk & (MDX_EPART - 1));
+            double* q = a.energy + EN_COUNT + 8 + MDX_ESTRIDE * (blk & (MDX_EPART - 1));
             atomicAdd(q, 0.5 * elj); atomicAdd(q + 1, 0.5 * ecoul); atomicAdd(q + 2, 0.5 * evir);
         }
     }
@@ -337,7 +357,7 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
     const uint32_t mbase = a.mchunk_off[t_ok ? t : 0];
     float4* sx = s_xyzq[wave];
     float2* sl = s_lj[wave];
-    double elj = 0.0, ecoul = 0.0, evir = 0.0, ecross = 0.0;
+    double elj = 0.0, ecoul = 0.0, evir = 0.0, ecross = 0.0, edudl = 0.0;
     uint32_t own_bits = 0xFFu;   // ENERGY only: bit ci set <=> i-atom (ci, ii) is owned by this rank
     if (ENERGY) {
         own_bits = 0;
@@ -414,7 +434,7 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
             if (ENERGY && HALF) nown = (float)((a.slot_flags[js] >> 1) & 1u);
             if (c + 2 * WPT < nchunks) ent_n = entries[e0 + (c + 2 * WPT) * 8 + (lane >> 3)];
         }
-        float celj = 0.f, cecoul = 0.f, cevir = 0.f, cecross = 0.f;   // (ENERGY) fp32 partial sums of this chunk
+        float celj = 0.f, cecoul = 0.f, cevir = 0.f, cecross = 0.f, cedudl = 0.f;   // (ENERGY) fp32 partial sums of this chunk
         uint32_t newy = cur_y & 0xFFu;                                // (pruning launch) this lane's entry word with the inner mask
         // entry loop: each entry's j record is read from LDS where it is needed (any look-ahead measured slower)
 #pragma unroll 1
@@ -433,7 +453,7 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
 #pragma unroll
             for (int ci = 0; ci < 8; ++ci) {
                 if (im & (1u << ci)) {
-                    float e1 = 0.f, e2 = 0.f, e3 = 0.f, e4 = 0.f;
+                    float e1 = 0.f, e2 = 0.f, e3 = 0.f, e4 = 0.f, e5 = 0.f;
                     // 0.0f or NaN: sign-extend bit ci of the exclusion byte over the word (one v_bfe_i32)
                     const float bias = __int_as_float((x8 << (31 - ci)) >> 31);
                     float r2v = 0.f;
@@ -441,14 +461,14 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
                                                                              pj, lj, true, a.p, fx[ci], fy[ci],
                                                                              fz[ci], e1, e2, g, ENERGY ? &e3 : nullptr,
                                                                              (ENERGY && ALCH) ? &e4 : nullptr, bias,
-                                                                             prune ? &r2v : nullptr);
+                                                                             prune ? &r2v : nullptr, (ENERGY && ALCH) ? &e5 : nullptr);
                     if (prune) {   // any allowed atom pair of this cluster pair inside the inner radius?
                         if (__ballot(r2v < a.rin2) != 0ull) newm |= 1u << ci;
                     }
                     if (ENERGY && HALF) {   // a pair's energy is split between the owners of its two atoms
                         const float w = wj + (((own_bits >> ci) & 1u) ? 0.5f : 0.f);
-                        celj += w * e1; cecoul += w * e2; cevir += w * e3; cecross += w * e4;
-                    } else if (ENERGY && ((own_bits >> ci) & 1u)) { celj += e1; cecoul += e2; cevir += e3; cecross += e4; }
+                        celj += w * e1; cecoul += w * e2; cevir += w * e3; cecross += w * e4; cedudl += w * e5;
+                    } else if (ENERGY && ((own_bits >> ci) & 1u)) { celj += e1; cecoul += e2; cevir += e3; cecross += e4; cedudl += e5; }
                 }
             }
             if (prune) {
@@ -471,7 +491,7 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
                 }
             }
         }
-        if (ENERGY) { elj += (double)celj; ecoul += (double)cecoul; evir += (double)cevir; ecross += (double)cecross; }
+        if (ENERGY) { elj += (double)celj; ecoul += (double)cecoul; evir += (double)cevir; ecross += (double)cecross; edudl += (double)cedudl; }
         if (prune) {
             if (masked) {                       // exclusion masks are addressed by chunk position: the entry stays where it is
                 if (ii == 0) a.entries_in[e0 + c * 8 + jj] = make_uint2(cur_jc, newy);
@@ -553,15 +573,15 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
             elj += __shfl_xor(elj, m);
             ecoul += __shfl_xor(ecoul, m);
             evir += __shfl_xor(evir, m);
-            if (ALCH) ecross += __shfl_xor(ecross, m);
+            if (ALCH) { ecross += __shfl_xor(ecross, m); edudl += __shfl_xor(edudl, m); }
         }
         if (lane == 0) {   // full list: every pair is seen from both sides.  The atomics are spread over MDX_EPART
                            // slots: 65 k waves adding into three words took 2 ms (contended f64 atomics, ~10 ns each)
-            double* q = a.energy + EN_COUNT + 8 + 4 * ((blk * BW + wave) & (MDX_EPART - 1));
+            double* q = a.energy + EN_COUNT + 8 + MDX_ESTRIDE * ((blk * BW + wave) & (MDX_EPART - 1));
             atomicAdd(q, HALF ? elj : 0.5 * elj);
             atomicAdd(q + 1, HALF ? ecoul : 0.5 * ecoul);
             atomicAdd(q + 2, HALF ? evir : 0.5 * evir);
-            if (ALCH) atomicAdd(q + 3, HALF ? ecross : 0.5 * ecross);
+            if (ALCH) { atomicAdd(q + 3, HALF ? ecross : 0.5 * ecross); atomicAdd(q + 4, HALF ? edudl : 0.5 * edudl); }
         }
     }
 }
@@ -657,6 +677,8 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
     p.alpha = c.ewald_alpha; p.soft2 = c.softening_sq;
     p.k_rf = 0.f; p.k_rf2 = 0.f; p.coul_shift = 0.f;
     p.alch_scale = h->alch_on ? (float)(1.0 - h->alch_lambda) : 1.0f;
+    p.sc_alpha = h->alch_on ? h->sc_alpha : 0.f; p.sc_al = h->alch_on ? (float)(h->sc_alpha * h->alch_lambda) : 0.f;
+    p.sc_sigmin = h->sc_sigma_min;
     int mode = CM_SHIFTED;
     switch (c.coulomb_mode) {
     case MDX_COULOMB_REACTION:

@@ -76,13 +76,16 @@ __device__ __forceinline__ void mesh_coords(const float4 p, const PmeDev& g, int
 // requests than one-lane-per-atom (1.58 ms -> see profiles/ at 1 M atoms, 240^3 mesh).
 __global__ __launch_bounds__(256) void pme_spread_kernel(uint32_t S, const float4* __restrict__ posq,
                                                          const uint8_t* __restrict__ slot_flags, PmeDev g,
-                                                         float* __restrict__ Q, const uint32_t* gate, uint32_t thr, uint32_t need) {
+                                                         float* __restrict__ Q, const uint32_t* gate, uint32_t thr, uint32_t need,
+                                                         const float2* __restrict__ lj, int sel) {
     if (gate && *gate > thr) return;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t s = t >> 4;
     const int b = (t >> 2) & 3, c = t & 3;
     if (s >= S) return;
     if ((slot_flags[s] & need) != need) return;    // need = 1: every real atom; 3: the atoms this rank owns (decomposed handle)
+    // alchemical window: sel 1 = the environment only, 2 = the coupled molecule only (its atoms carry a negative sqrt(24 eps))
+    if (sel && ((__float_as_int(lj[s].y) < 0) != (sel == 2))) return;
     const float4 p = posq[s];
     if (p.w == 0.f) return;
     int k0[3]; float w[3];
@@ -110,7 +113,8 @@ __global__ __launch_bounds__(256) void pme_spread_kernel(uint32_t S, const float
 constexpr int PME_TB = 14;    // LDS block edge in mesh points
 __global__ __launch_bounds__(256) void pme_spread_tile_kernel(uint32_t T, const float4* __restrict__ posq,
                                                               const uint8_t* __restrict__ slot_flags, PmeDev g,
-                                                              float* __restrict__ Q, const uint32_t* gate, uint32_t thr, uint32_t need) {
+                                                              float* __restrict__ Q, const uint32_t* gate, uint32_t thr, uint32_t need,
+                                                              const float2* __restrict__ lj, int sel) {
     if (gate && *gate > thr) return;
     __shared__ float s_q[PME_TB * PME_TB * PME_TB];
     __shared__ int s_org[3];
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256) void pme_spread_tile_kernel(uint32_t T, const 
     const int atom = tid >> 2, q4 = tid & 3;
     const uint32_t slot = t * MDX_TILE + atom;
     const float4 p = posq[slot];
-    const bool live = ((slot_flags[slot] & need) == need) && p.w != 0.f;
+    const bool live = ((slot_flags[slot] & need) == need) && p.w != 0.f && (!sel || ((__float_as_int(lj[slot].y) < 0) == (sel == 2)));
     int k0[3] = {0, 0, 0}; float w[3] = {0.f, 0.f, 0.f};
     {   // unwrapped mesh coordinates: floor may be < 0 or >= K for an atom just outside the box
         const float x[3] = {p.x, p.y, p.z};
@@ -226,11 +230,58 @@ __global__ __launch_bounds__(256) void pme_solve_kernel(size_t n, int K1, int K2
     }
 }
 
+// Alchemical window with the reciprocal sum: environment (F) and coupled molecule (G) are transformed separately; the
+// mesh potential is linear in the charges, so E(lambda) = E_FF + E_GG + (1 - lambda) E_x with E_x = sum mult theta Re(F G*)
+// (= 2 E_env,mol) and dE/dlambda = -E_x.  Both meshes are multiplied by theta for their inverse transforms.
+template <bool ENERGY>
+__global__ __launch_bounds__(256) void pme_solve2_kernel(size_t n, int K1, int K2, int K3h, int K3, float3 inv_len,
+                                                         float pi2_over_beta2, float2* __restrict__ F, float2* __restrict__ G,
+                                                         const float* __restrict__ theta, double* energy, double asc,
+                                                         const uint32_t* gate, uint32_t thr) {
+    if (gate && *gate > thr) return;
+    double e = 0.0, w = 0.0, ex = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float t = theta[i];
+        float2 f = F[i], g = G[i];
+        if (ENERGY) {
+            const int k3 = (int)(i % (size_t)K3h);
+            const float mult = (k3 == 0 || (2 * k3 == K3)) ? 1.0f : 2.0f;
+            const double e_self = 0.5 * (double)(mult * t * (f.x * f.x + f.y * f.y + g.x * g.x + g.y * g.y));
+            const double e_x = (double)(mult * t * (f.x * g.x + f.y * g.y));
+            const size_t ij = i / (size_t)K3h;
+            const int k2 = (int)(ij % (size_t)K2), k1 = (int)(ij / (size_t)K2);
+            const float m1 = (float)(k1 <= K1 / 2 ? k1 : k1 - K1) * inv_len.x;
+            const float m2 = (float)(k2 <= K2 / 2 ? k2 : k2 - K2) * inv_len.y;
+            const float m3 = (float)k3 * inv_len.z;
+            const double ei = e_self + asc * e_x;
+            e += ei; ex += e_x;
+            w += ei * (1.0 - 2.0 * (double)(pi2_over_beta2 * (m1 * m1 + m2 * m2 + m3 * m3)));
+        }
+        f.x *= t; f.y *= t; g.x *= t; g.y *= t;
+        F[i] = f; G[i] = g;
+    }
+    if (ENERGY) {
+        __shared__ double s_e[4], s_w[4], s_x[4];
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) { e += __shfl_xor(e, m); w += __shfl_xor(w, m); ex += __shfl_xor(ex, m); }
+        if ((threadIdx.x & 63) == 0) { s_e[threadIdx.x >> 6] = e; s_w[threadIdx.x >> 6] = w; s_x[threadIdx.x >> 6] = ex; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            e = s_e[0] + s_e[1] + s_e[2] + s_e[3]; w = s_w[0] + s_w[1] + s_w[2] + s_w[3]; ex = s_x[0] + s_x[1] + s_x[2] + s_x[3];
+            if (e != 0.0) { atomicAdd(&energy[EN_RECIP], e); atomicAdd(&energy[EN_VIRIAL], w); }
+            if (ex != 0.0) atomicAdd(&energy[EN_COUNT + 5], -ex);     // dU/dlambda of the reciprocal sum
+        }
+    }
+}
+
+// phi2 != nullptr (alchemical window): an atom feels its own group's potential plus (1 - lambda) x the other group's
 template <bool SEPARATE>
 __global__ __launch_bounds__(256) void pme_gather_kernel(uint32_t S, const float4* __restrict__ posq,
                                                          const uint8_t* __restrict__ slot_flags, PmeDev g,
                                                          const float* __restrict__ phi, float4* __restrict__ force,
-                                                         const uint32_t* gate, uint32_t thr) {
+                                                         const uint32_t* gate, uint32_t thr,
+                                                         const float* __restrict__ phi2 = nullptr, const float2* __restrict__ lj = nullptr,
+                                                         float asc = 1.f) {
     if (gate && *gate > thr) return;
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
@@ -247,16 +298,23 @@ __global__ __launch_bounds__(256) void pme_gather_kernel(uint32_t S, const float
 #pragma unroll
     for (int c = 0; c < 4; ++c) { int k = k0[2] + c; iz[c] = k < 0 ? k + g.K[2] : k; }
     float fx = 0.f, fy = 0.f, fz = 0.f;
+    float ca = 1.f, cb = 0.f;          // weights of phi (environment) and phi2 (coupled molecule)
+    if (phi2) { const bool inmol = __float_as_int(lj[s].y) < 0; ca = inmol ? asc : 1.f; cb = inmol ? 1.f : asc; }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         int kx = k0[0] + a; if (kx < 0) kx += g.K[0];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             int ky = k0[1] + b; if (ky < 0) ky += g.K[1];
-            const float* row = phi + ((size_t)kx * g.K[1] + ky) * g.K[2];
+            const size_t ro = ((size_t)kx * g.K[1] + ky) * g.K[2];
+            const float* row = phi + ro;
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { const float v = row[iz[c]]; s0 += mz[c] * v; s1 += dz[c] * v; }
+            for (int c = 0; c < 4; ++c) {
+                float v = row[iz[c]];
+                if (phi2) v = ca * v + cb * phi2[ro + iz[c]];
+                s0 += mz[c] * v; s1 += dz[c] * v;
+            }
             fx += dx[a] * my[b] * s0;
             fy += mx[a] * dy[b] * s0;
             fz += mx[a] * my[b] * s1;
@@ -358,7 +416,7 @@ int mdx_pme_setup(mdx_handle* h) {
             p->plan3d(&p->inv, K[0], K[1], K[2], HIPFFT_C2R) != HIPFFT_SUCCESS)
             FAIL(MDX_EDEVICE, "hipfftPlan3d failed");
         p->have_plans = true;
-        for (void** q : {(void**)&h->d.pme_q, (void**)&h->d.pme_f, (void**)&h->d.pme_theta})
+        for (void** q : {(void**)&h->d.pme_q, (void**)&h->d.pme_f, (void**)&h->d.pme_theta, (void**)&h->d.pme_q2, (void**)&h->d.pme_f2})
             if (*q) { (void)hipFree(*q); *q = nullptr; }
         HIP_TRY(hipMalloc((void**)&h->d.pme_q, sizeof(float) * p->n_real));
         HIP_TRY(hipMalloc((void**)&h->d.pme_f, sizeof(float2) * p->n_cplx));
@@ -432,32 +490,51 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
     const int K3h = h->pme_K[2] / 2 + 1;
     const uint32_t need = h->dd ? 3u : 1u;              // decomposed: every rank spreads the charges it OWNS ...
     const double escale = h->dd ? 1.0 / (double)h->dd->world : 1.0;
-    HIP_TRY(hipMemsetAsync(h->d.pme_q, 0, sizeof(float) * p->n_real, st));
+    const bool alch = h->alch_on;      // two meshes: environment in pme_q / pme_f, coupled molecule in pme_q2 / pme_f2
+    if (alch && !h->d.pme_q2) {
+        HIP_TRY(hipMalloc((void**)&h->d.pme_q2, sizeof(float) * p->n_real));
+        HIP_TRY(hipMalloc((void**)&h->d.pme_f2, sizeof(float2) * p->n_cplx));
+    }
+    const float asc = (float)(1.0 - h->alch_lambda);
     static const bool per_atom_spread = [] { const char* e = std::getenv("MDX_PME_SPREAD_PER_ATOM"); return e && e[0] == '1'; }();
-    if (per_atom_spread || !h->in_slot_space)
-        hipLaunchKernelGGL(pme_spread_kernel, dim3(div_up(h->S * 16u, 256)), dim3(256), 0, st, h->S, h->d.posq,
-                           h->d.slot_flags, p->dev, h->d.pme_q, d_gate, thr, need);
-    else
-        hipLaunchKernelGGL(pme_spread_tile_kernel, dim3(h->T), dim3(256), 0, st, h->T, h->d.posq, h->d.slot_flags, p->dev,
-                           h->d.pme_q, d_gate, thr, need);
-    // ... and the meshes are summed over the ranks: a replicated mesh, every rank then solves it and interpolates the
-    // forces of its own atoms (the all-reduce is ungated: a collective must be entered by every rank alike)
-    if (h->dd && h->dd->world > 1) MDX_TRY(h->dd->tr->all_reduce_f32(h->d.pme_q, p->n_real, st));
-    if (p->exec_r2c(p->fwd, h->d.pme_q, (hipfftComplex*)h->d.pme_f) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecR2C failed");
+    for (int grp = 0; grp < (alch ? 2 : 1); ++grp) {
+        float* Q = grp ? h->d.pme_q2 : h->d.pme_q;
+        const int sel = alch ? grp + 1 : 0;
+        HIP_TRY(hipMemsetAsync(Q, 0, sizeof(float) * p->n_real, st));
+        if (per_atom_spread || !h->in_slot_space)
+            hipLaunchKernelGGL(pme_spread_kernel, dim3(div_up(h->S * 16u, 256)), dim3(256), 0, st, h->S, h->d.posq,
+                               h->d.slot_flags, p->dev, Q, d_gate, thr, need, h->d.lj, sel);
+        else
+            hipLaunchKernelGGL(pme_spread_tile_kernel, dim3(h->T), dim3(256), 0, st, h->T, h->d.posq, h->d.slot_flags, p->dev,
+                               Q, d_gate, thr, need, h->d.lj, sel);
+        // decomposed handle: the meshes are summed over the ranks - a replicated mesh, every rank then solves it and
+        // interpolates the forces of its own atoms (the all-reduce is ungated: a collective must be entered by every rank alike)
+        if (h->dd && h->dd->world > 1) MDX_TRY(h->dd->tr->all_reduce_f32(Q, p->n_real, st));
+        if (p->exec_r2c(p->fwd, Q, (hipfftComplex*)(grp ? h->d.pme_f2 : h->d.pme_f)) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecR2C failed");
+    }
     const dim3 gs((unsigned)std::min<size_t>((p->n_cplx + 255) / 256, energy ? 1024 : (size_t)1 << 30));
     const float3 inv_len = make_float3(p->dev.inv_len[0], p->dev.inv_len[1], p->dev.inv_len[2]);
     const float pb = (float)(M_PI * M_PI / ((double)h->cfg.ewald_alpha * h->cfg.ewald_alpha));
-    if (energy) hipLaunchKernelGGL(pme_solve_kernel<true>, gs, dim3(256), 0, st, p->n_cplx, h->pme_K[0], h->pme_K[1], K3h,
-                                   h->pme_K[2], inv_len, pb, h->d.pme_f, h->d.pme_theta, h->d.energy, d_gate, thr, escale);
-    else hipLaunchKernelGGL(pme_solve_kernel<false>, gs, dim3(256), 0, st, p->n_cplx, h->pme_K[0], h->pme_K[1], K3h,
-                            h->pme_K[2], inv_len, pb, h->d.pme_f, h->d.pme_theta, h->d.energy, d_gate, thr, escale);
+    if (alch) {
+        if (energy) hipLaunchKernelGGL(pme_solve2_kernel<true>, gs, dim3(256), 0, st, p->n_cplx, h->pme_K[0], h->pme_K[1], K3h, h->pme_K[2],
+                                       inv_len, pb, h->d.pme_f, h->d.pme_f2, h->d.pme_theta, h->d.energy, (double)asc, d_gate, thr);
+        else hipLaunchKernelGGL(pme_solve2_kernel<false>, gs, dim3(256), 0, st, p->n_cplx, h->pme_K[0], h->pme_K[1], K3h, h->pme_K[2],
+                                inv_len, pb, h->d.pme_f, h->d.pme_f2, h->d.pme_theta, h->d.energy, (double)asc, d_gate, thr);
+        if (p->exec_c2r(p->inv, (hipfftComplex*)h->d.pme_f2, h->d.pme_q2) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecC2R failed");
+    } else {
+        if (energy) hipLaunchKernelGGL(pme_solve_kernel<true>, gs, dim3(256), 0, st, p->n_cplx, h->pme_K[0], h->pme_K[1], K3h,
+                                       h->pme_K[2], inv_len, pb, h->d.pme_f, h->d.pme_theta, h->d.energy, d_gate, thr, escale);
+        else hipLaunchKernelGGL(pme_solve_kernel<false>, gs, dim3(256), 0, st, p->n_cplx, h->pme_K[0], h->pme_K[1], K3h,
+                                h->pme_K[2], inv_len, pb, h->d.pme_f, h->d.pme_theta, h->d.energy, d_gate, thr, escale);
+    }
     if (p->exec_c2r(p->inv, (hipfftComplex*)h->d.pme_f, h->d.pme_q) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecC2R failed");
+    const float* phi2 = alch ? h->d.pme_q2 : nullptr;
     if (h->pme_overlap)
         hipLaunchKernelGGL(pme_gather_kernel<true>, dim3(div_up(h->S, 256)), dim3(256), 0, st, h->S, h->d.posq, h->d.slot_flags,
-                           p->dev, h->d.pme_q, h->d.pme_force, d_gate, thr);
+                           p->dev, h->d.pme_q, h->d.pme_force, d_gate, thr, phi2, h->d.lj, asc);
     else
         hipLaunchKernelGGL(pme_gather_kernel<false>, dim3(div_up(h->S, 256)), dim3(256), 0, st, h->S, h->d.posq, h->d.slot_flags,
-                           p->dev, h->d.pme_q, h->d.force, d_gate, thr);
+                           p->dev, h->d.pme_q, h->d.force, d_gate, thr, phi2, h->d.lj, asc);
     HIP_TRY(hipGetLastError());
     return MDX_OK;
 }

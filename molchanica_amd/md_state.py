@@ -89,6 +89,7 @@ def load_library():
     lib.mdx_set_barostat.argtypes = [H, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint32]
     lib.mdx_set_integrator.argtypes = [H, C.c_int, C.c_float, C.c_float, C.c_uint64]
     lib.mdx_configure_alchemical_window.argtypes = [H, C.c_uint32, C.c_double]
+    lib.mdx_set_alchemical_softcore.argtypes = [H, C.c_float, C.c_float]
     lib.mdx_get_box.argtypes = [H, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.mdx_set_zero_com_drift.argtypes = [H, C.c_int]
     lib.mdx_set_snapshot_cadence.argtypes = [H, C.c_uint32, C.c_int]
@@ -286,6 +287,10 @@ class MdState:
     def configure_alchemical_window(self, mol_index: int, lam: float):
         """`md.configure_alchemical_window(dev, mol_index, lambda)` (src/properties/water_sol.rs:556); lam < 0 = off."""
         _check(load_library().mdx_configure_alchemical_window(self._h, int(mol_index), float(lam)))
+
+    def set_alchemical_softcore(self, alpha: float = 0.5, sigma_min: float = 3.0):
+        """Soft core of the alchemical window (alpha = 0: linear coupling)."""
+        _check(load_library().mdx_set_alchemical_softcore(self._h, float(alpha), float(sigma_min)))
 
     def set_integrator(self, kind: int, gamma_per_ps: float = 1.0, temperature: float = 300.0, seed: int = 0):
         """`Integrator::{VerletVelocity (0), Leapfrog (1), LangevinMiddle{gamma} (2)}` (md.rs:296-305)."""

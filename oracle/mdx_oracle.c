@@ -34,8 +34,9 @@
 #define ACC_CONV 418.4          /* kcal/mol/Å/Da -> Å/ps² */
 #define KB_KCAL  0.0019872041   /* kcal/mol/K */
 
-enum { E_BOND, E_ANGLE, E_DIHEDRAL, E_LJ, E_COUL, E_LJ14, E_COUL14, E_KIN, E_VIRIAL, E_CROSS, E_N };
-/* E_CROSS: unscaled non-bonded energy between the alchemical molecule and the rest (0 without a window) */
+enum { E_BOND, E_ANGLE, E_DIHEDRAL, E_LJ, E_COUL, E_LJ14, E_COUL14, E_KIN, E_VIRIAL, E_CROSS, E_DUDL, E_N };
+/* E_CROSS: unscaled non-bonded energy between the alchemical molecule and the rest (0 without a window), at the soft-core
+ * distance when the soft core is on.  E_DUDL: dU/dlambda of the window (= -E_CROSS for linear coupling). */
 /* E_VIRIAL: W = sum_i r_i . F_i of the internal forces (pairs, 1-4, bonds; angle and dihedral terms are
  * scale invariant and contribute exactly 0), kcal/mol.  Pressure = (2 KE + W + W_constraints) / (3 V). */
 
@@ -448,6 +449,14 @@ int orc_constrain_velocities(const mdx_system* s, const double* x, double* v, do
  * lambda < 0 switches it off.  Test infrastructure state, like the rest of this file. */
 static double g_alch_lambda = -1.0; static uint32_t g_alch_lo = 0, g_alch_hi = 0;
 void orc_set_alchemical(uint32_t lo, uint32_t hi, double lambda) { g_alch_lo = lo; g_alch_hi = hi; g_alch_lambda = lambda; }
+/* Soft core (Beutler et al., Chem. Phys. Lett. 222, 529 (1994), the form GROMACS uses with sc-power 1, sc-r-power 6):
+ * a cross pair interacts at r_sc = (alpha sigma^6 lambda + r^6)^(1/6) instead of r, LJ and Coulomb alike, and its energy
+ * is scaled by (1 - lambda): U = U_rest + (1 - lambda) U_cross(r_sc(lambda)).  sigma = sigma_ij of the pair, or sigma_min
+ * where the pair has no LJ interaction (sigma or eps zero: hydrogens).  Then
+ *   dU/dlambda = -U_cross(r_sc) + (1 - lambda) U_cross'(r_sc) alpha sigma^6 / (6 r_sc^5),
+ * finite at lambda = 1 whatever the overlap (r_sc >= (alpha sigma^6)^(1/6) there).  alpha = 0: linear coupling. */
+static double g_sc_alpha = 0.0, g_sc_sigma_min = 3.0;
+void orc_set_softcore(double alpha, double sigma_min) { g_sc_alpha = alpha; g_sc_sigma_min = sigma_min; }
 
 /* ------------------------------------------------------------------------------------------- */
 /* Forces + energies.  x: fp64 positions [3N] (NULL -> s->pos).  f: [3N] out.  en: [E_N] out.
@@ -473,11 +482,11 @@ int orc_forces(const mdx_system* s, const mdx_config* c, const double* x_in, con
     if (use_cells && !(cut_lj && cut_c)) use_cells = 0;
 
     grid_t g; if (use_cells) g = build_grid(s, x, rmax);
-    double e_lj = 0.0, e_c = 0.0, w_nb = 0.0, e_x = 0.0;
+    double e_lj = 0.0, e_c = 0.0, w_nb = 0.0, e_x = 0.0, e_dl = 0.0;
     const int alch = g_alch_lambda >= 0.0;
     const double asc = alch ? 1.0 - g_alch_lambda : 1.0;
 
-#pragma omp parallel for schedule(dynamic, 64) reduction(+ : e_lj, e_c, w_nb, e_x)
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : e_lj, e_c, w_nb, e_x, e_dl)
     for (uint32_t i = 0; i < N; ++i) {
         if (!nb_active(s, i)) continue;
         double fi[3] = { 0, 0, 0 };
@@ -510,10 +519,24 @@ int orc_forces(const mdx_system* s, const mdx_config* c, const double* x_in, con
                 double sig, eps; lj_pair(s, c, i, j, &sig, &eps);
                 double qq = (double)s->charge[i] * (double)s->charge[j];
                 double fs, el = 0.0, ec = 0.0;
-                pair_terms(c, sig, eps, qq, r2, in_lj, in_c, &fs, &el, &ec);
-                if (alch && ((i >= g_alch_lo && i < g_alch_hi) != (j >= g_alch_lo && j < g_alch_hi))) {
+                const int cross = alch && ((i >= g_alch_lo && i < g_alch_hi) != (j >= g_alch_lo && j < g_alch_hi));
+                if (cross && g_sc_alpha > 0.0) {
+                    const double sg = (sig > 0.0 && eps > 0.0) ? sig : g_sc_sigma_min;
+                    const double sig6 = sg * sg * sg * sg * sg * sg;
+                    const double rsc6 = g_sc_alpha * sig6 * g_alch_lambda + r2 * r2 * r2;
+                    const double rsc2 = cbrt(rsc6), rsc4 = rsc2 * rsc2;
+                    double fsc;
+                    pair_terms(c, sig, eps, qq, rsc2, in_lj, in_c, &fsc, &el, &ec);   /* fsc = -U'(r_sc) / r_sc */
                     e_x += 0.5 * (el + ec);
-                    fs *= asc; el *= asc; ec *= asc;
+                    e_dl += 0.5 * (-(el + ec) - asc * fsc * g_sc_alpha * sig6 / (6.0 * rsc4));
+                    fs = asc * fsc * r2 * r2 / rsc4;                                  /* -dU/dr / r */
+                    el *= asc; ec *= asc;
+                } else {
+                    pair_terms(c, sig, eps, qq, r2, in_lj, in_c, &fs, &el, &ec);
+                    if (cross) {
+                        e_x += 0.5 * (el + ec); e_dl -= 0.5 * (el + ec);
+                        fs *= asc; el *= asc; ec *= asc;
+                    }
                 }
                 fi[0] += fs * d[0]; fi[1] += fs * d[1]; fi[2] += fs * d[2];
                 e_lj += 0.5 * el; e_c += 0.5 * ec; w_nb += 0.5 * fs * r2;
@@ -521,7 +544,7 @@ int orc_forces(const mdx_system* s, const mdx_config* c, const double* x_in, con
         }
         f[3*i] = fi[0]; f[3*i+1] = fi[1]; f[3*i+2] = fi[2];
     }
-    en[E_LJ] = e_lj; en[E_COUL] = e_c; en[E_VIRIAL] = w_nb; en[E_CROSS] = e_x;
+    en[E_LJ] = e_lj; en[E_COUL] = e_c; en[E_VIRIAL] = w_nb; en[E_CROSS] = e_x; en[E_DUDL] = e_dl;
     bonded_forces(s, c, x, f, en);
     orc_vsite_spread(s, f);
     if (ext) for (uint32_t i = 0; i < 3 * N; ++i) f[i] += ext[i];

@@ -12,7 +12,7 @@ import numpy as np
 from molchanica_amd._abi import CConfig, CSystem, MdConfig, MdSystem
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ENERGY_NAMES = ("bond", "angle", "dihedral", "lj", "coulomb", "lj14", "coulomb14", "kinetic", "virial", "cross")
+ENERGY_NAMES = ("bond", "angle", "dihedral", "lj", "coulomb", "lj14", "coulomb14", "kinetic", "virial", "cross", "dudl")
 BAR_PER_KCAL_MOL_A3 = 69476.95
 
 _dp = C.POINTER(C.c_double)
@@ -274,6 +274,12 @@ def set_alchemical(lo: int, hi: int, lam: float):
     """Couple atoms [lo, hi) to the rest with factor (1 - lam) on their mutual non-bonded pairs; lam < 0 = off.
     Energies then carry "cross" (unscaled U_cross): dU/dlambda = -cross."""
     lib().orc_set_alchemical(C.c_uint32(int(lo)), C.c_uint32(int(hi)), C.c_double(float(lam)))
+
+
+def set_softcore(alpha: float, sigma_min: float = 3.0):
+    """Soft-core coupling of the alchemical window: cross pairs interact at r_sc = (alpha sigma^6 lambda + r^6)^(1/6);
+    alpha = 0 (the oracle's default) is the linear coupling.  Energies carry "dudl" = dU/dlambda either way."""
+    lib().orc_set_softcore(C.c_double(float(alpha)), C.c_double(float(sigma_min)))
 
 
 def shrink_cell_towards(box_lo, box_hi, target_lo, target_hi, shrink_per_step, pos):

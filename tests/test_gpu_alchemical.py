@@ -1,6 +1,8 @@
 """GPU parity of the alchemical window (`md.configure_alchemical_window(dev, mol_index, lambda)`,
 src/properties/water_sol.rs:556) against the oracle pinned by tests/test_oracle_alchemical.py, and the TI
 bookkeeping driven the way `run_hydration_ti_window` drives it (water_sol.rs:532-580)."""
+import math
+
 import numpy as np
 import pytest
 
@@ -21,8 +23,11 @@ def mdx():
 CFG = dict(lj_cutoff=8.0, coulomb_cutoff=8.0, skin=1.0, coulomb_mode=1)
 
 
-@pytest.mark.parametrize("lam", [0.0, 0.35, 1.0])
-def test_forces_energies_and_dh_dlambda_match_the_oracle(mdx, orc, lam):
+@pytest.mark.parametrize("alpha", [0.5, 0.0])
+@pytest.mark.parametrize("lam", [0.0, 0.35, 0.95, 1.0])
+def test_forces_energies_and_dh_dlambda_match_the_oracle(mdx, orc, lam, alpha):
+    """Soft-core coupling (the library default, alpha 0.5) and plain linear coupling (alpha 0) against the oracle pinned
+    by finite differences in tests/test_oracle_alchemical.py: forces, every energy term, dU/dlambda."""
     from tests.test_gpu_parity import assert_forces, assert_energies
     s = systems.small_solvated()
     cfg = MdConfig(**CFG)
@@ -30,22 +35,123 @@ def test_forces_energies_and_dh_dlambda_match_the_oracle(mdx, orc, lam):
     with mdx.MdState(s, cfg) as md:
         e_plain = md.energy()
         assert e_plain["dh_dlambda"] == 0.0 and e_plain["coupled_interaction"] == 0.0
+        md.set_alchemical_softcore(alpha, 3.0)
         md.configure_alchemical_window(0, lam)
         pos = md.positions(); f = md.forces(); e = md.energy()
         md.configure_alchemical_window(0, -1.0)          # off again: the plain energies come back
         e_off = md.energy()
     try:
+        orc.set_softcore(alpha, 3.0)
         orc.set_alchemical(lo, hi, lam)
         fo, eo = orc.forces(s, cfg, pos=pos.astype(np.float64), use_cells=True)
         slack = orc.cutoff_slack(s, cfg, pos=pos)
     finally:
         orc.set_alchemical(0, 0, -1.0)
-    assert_forces(f, fo, slack, f"alchemical lambda={lam}")
-    assert_energies(e, eo, s.n_atoms * 200, f"alchemical lambda={lam}")
-    scale = abs(eo["lj"]) + abs(eo["coulomb"]) + abs(eo["cross"])
-    assert e["dh_dlambda"] == pytest.approx(-eo["cross"], abs=2e-5 * scale + 0.02)
+        orc.set_softcore(0.0)
+    assert_forces(f, fo, slack, f"alchemical lambda={lam} alpha={alpha}")
+    assert_energies(e, eo, s.n_atoms * 200, f"alchemical lambda={lam} alpha={alpha}")
+    scale = abs(eo["lj"]) + abs(eo["coulomb"]) + abs(eo["cross"]) + abs(eo["dudl"])
+    assert e["dh_dlambda"] == pytest.approx(eo["dudl"], abs=2e-5 * scale + 0.02)
     assert e["coupled_interaction"] == pytest.approx((1 - lam) * eo["cross"], abs=2e-5 * scale + 0.02)
+    if alpha == 0.0:
+        assert e["dh_dlambda"] == pytest.approx(-eo["cross"], abs=2e-5 * scale + 0.02)
     assert e_off["potential"] == pytest.approx(e_plain["potential"], rel=1e-9, abs=1e-4) and e_off["dh_dlambda"] == 0.0
+
+
+def excluded_pairs(s):
+    ii = np.repeat(np.arange(s.n_atoms), np.diff(s.excl_offsets))
+    m = ii < s.excl_idx
+    pairs = np.stack([ii[m], s.excl_idx[m]], 1)
+    if s.pairs14_idx is not None and len(s.pairs14_idx):
+        pairs = np.concatenate([pairs, s.pairs14_idx.reshape(-1, 2)])
+    return pairs
+
+
+@pytest.mark.parametrize("lam", [0.0, 0.5, 1.0])
+def test_window_under_spme_scales_the_mesh_part_of_the_cross_interaction(mdx, lam):
+    """The reference runs its lambda windows under its default SPME Coulomb (README.md:240, water_sol.rs:556).  The mesh
+    part is scaled exactly: E_rec(lambda) = E(env) + E(mol) + (1 - lambda) [E(all) - E(env) - E(mol)], checked against the
+    numpy SPME restatement on the same mesh evaluated for the three charge sets; dU/dlambda by finite differences of the
+    engine's own potential; forces by the same decomposition of the numpy forces."""
+    from oracle import pme_ref as P
+    s = systems.small_solvated()
+    lo, hi = int(s.mol_start[0]), int(s.mol_start[1])
+    beta, grid = 0.40, (32, 32, 32)
+    base = dict(lj_cutoff=8.0, coulomb_cutoff=8.0, skin=1.0, coulomb_mode=_abi.COULOMB_EWALD, ewald_alpha=beta)
+    cfg_real = MdConfig(overrides=_abi.OVR_LONG_RANGE_RECIP_DISABLED, **base)
+    cfg_full = MdConfig(overrides=0, pme_grid=grid, **base)
+    h = 1e-3
+    with mdx.MdState(s, cfg_real) as md:
+        md.configure_alchemical_window(0, lam)
+        pos = md.positions(); f_real = md.forces().astype(np.float64); e_real = md.energy()
+    with mdx.MdState(s, cfg_full) as md:
+        md.configure_alchemical_window(0, lam)
+        f_full = md.forces().astype(np.float64); e_full = md.energy()
+        lp, lm = min(lam + h, 1.0), max(lam - h, 0.0)
+        md.configure_alchemical_window(0, lp); up = md.energy()["potential"]
+        md.configure_alchemical_window(0, lm); dn = md.energy()["potential"]
+        md.configure_alchemical_window(0, lam)
+        md.set_thermostat(2, 300.0, 0.1, 10, seed=3)
+        md.step(0.001, None, 30)                           # the window runs
+        assert np.isfinite(md.energy()["dh_dlambda"])
+    box = np.full(3, float(s.box_hi[0]))
+    x = pos.astype(np.float64)
+    q = s.charge.astype(np.float64)
+    q_env, q_mol = q.copy(), q.copy()
+    q_env[lo:hi] = 0.0; q_mol[:lo] = 0.0; q_mol[hi:] = 0.0
+    e_all, f_all = P.spme_recip(x, q, (0, 0, 0), box, beta, grid, 4)
+    e_env, f_env = P.spme_recip(x, q_env, (0, 0, 0), box, beta, grid, 4)
+    e_mol, f_mol = P.spme_recip(x, q_mol, (0, 0, 0), box, beta, grid, 4)
+    e_x2 = e_all - e_env - e_mol
+    e_excl, f_excl = P.excluded_pair_correction(x, q, excluded_pairs(s), box, beta)
+    e_ref = e_env + e_mol + (1 - lam) * e_x2 + e_excl + P.ewald_self_energy(q, beta) + P.ewald_background_energy(q, box, beta)
+    f_ref = f_env + f_mol + (1 - lam) * (f_all - f_env - f_mol) + f_excl
+    assert abs(e_x2) > 1.0
+    assert e_full["coulomb_recip"] == pytest.approx(e_ref, rel=3e-5, abs=5e-2)
+    f_rec = f_full - f_real
+    err = math.sqrt(((f_rec - f_ref) ** 2).sum(1).mean()) / math.sqrt((f_ref ** 2).sum(1).mean())
+    assert err < 3e-4, f"reciprocal force rms error {err:.2e}"
+    # dU/dlambda: real-space soft-core part + mesh part, against finite differences of the engine's own potential
+    fd = (up - dn) / (lp - lm)
+    assert e_full["dh_dlambda"] == pytest.approx(fd, rel=5e-3, abs=0.5)
+    assert e_full["dh_dlambda"] - e_real["dh_dlambda"] == pytest.approx(-e_x2, rel=1e-3, abs=0.05)
+
+
+def test_reference_lambda_grid_with_finite_dh_dlambda_to_the_decoupled_end(mdx):
+    """The reference's grid [0, 0.05, ... 0.90, 0.95, 1.0] (src/properties/water_sol.rs:52-56) under Ewald Coulomb with
+    the SPME reciprocal sum: every window - including 0.95 and 1.0, where waters overlap the decoupled solute - runs at
+    dt = 2 fs (water_sol.rs:43) and reports a finite, bounded dH/dlambda; the linear form blows up there."""
+    lams = [0.0, 0.05, 0.10, 0.20, 0.30, 0.40, 0.50, 0.60, 0.70, 0.80, 0.90, 0.95, 1.0]
+    s = systems.small_solvated()
+    cfg = MdConfig(lj_cutoff=8.0, coulomb_cutoff=8.0, skin=1.0, coulomb_mode=_abi.COULOMB_EWALD, ewald_alpha=0.4, overrides=0)
+    windows, peak = [], 0.0
+    for lam in lams:
+        with mdx.MdState(s, cfg) as md:
+            md.configure_alchemical_window(0, lam)
+            md.set_thermostat(2, 300.0, 0.1, 10, seed=11)
+            md.step(0.001, None, 60)
+            md.set_snapshot_cadence(10)
+            md.step(0.001, None, 100)
+            w = A.collect_window(lam, md.snapshots)
+        assert np.isfinite(w.mean_dh_dl) and abs(w.mean_dh_dl) < 5e3, (lam, w.mean_dh_dl)
+        peak = max(peak, abs(w.mean_dh_dl))
+        windows.append(w)
+    dg, sem = A.free_energy_ti_with_sem(windows)
+    assert np.isfinite(dg) and np.isfinite(sem) and peak > 1.0
+    # a water oxygen 0.8 A from a solute atom at the decoupled end - the overlap a lambda = 1 run ends up with: the soft
+    # core keeps dU/dlambda at the kcal/mol scale, the linear form (dU/dlambda = -U_cross) is at the 1e6 scale
+    lo, hi = int(s.mol_start[0]), int(s.mol_start[1])
+    with mdx.MdState(s, cfg) as md:
+        p = md.positions()
+        d = np.linalg.norm(p[hi::3] - p[lo + 3], axis=1)
+        ow = hi + 3 * int(d.argmin())
+        p[ow:ow + 3] += (p[lo + 3] + np.array([0.8, 0.0, 0.0], np.float32)) - p[ow]
+        md.set_positions(p)
+        md.configure_alchemical_window(0, 1.0)
+        soft = abs(md.energy()["dh_dlambda"])
+        md.set_alchemical_softcore(0.0, 3.0)
+        lin = abs(md.energy()["dh_dlambda"])
+    assert np.isfinite(soft) and soft < 1e3 and lin > 1e3 * (soft + 1.0), (lin, soft)
 
 
 def test_ti_windows_end_to_end(mdx):
@@ -68,7 +174,7 @@ def test_ti_windows_end_to_end(mdx):
             assert w.n_samples == 20 and np.isfinite(w.mean_dh_dl) and w.sem_dh_dl >= 0
             if lam == 0.0:
                 u = A.mean_coupled_interaction_kcal(snaps)
-                assert u == pytest.approx(-w.mean_dh_dl, rel=1e-9)      # (1 - 0) U_cross = -dH/dlambda
+                assert np.isfinite(u) and u < 0                          # the solute attracts its water
             if lam == 1.0:
                 assert abs(A.mean_coupled_interaction_kcal(snaps)) < 1e-9
             windows.append(w)
@@ -85,10 +191,8 @@ def test_alchemical_parameter_errors(mdx):
             md.configure_alchemical_window(10 ** 6, 0.5)
         with pytest.raises(mdx.ParamError):
             md.configure_alchemical_window(0, 1.5)
-    pme = MdConfig(lj_cutoff=8.0, coulomb_cutoff=8.0, skin=1.0, coulomb_mode=_abi.COULOMB_EWALD, ewald_alpha=0.4, overrides=0)
-    with mdx.MdState(s, pme) as md:
         with pytest.raises(mdx.ParamError):
-            md.configure_alchemical_window(0, 0.5)
+            md.set_alchemical_softcore(-1.0, 3.0)
     # the deterministic full-list variant is overridden while a window is active (the alchemical flavour exists for
     # the half-list kernel only) and comes back afterwards
     with mdx.MdState(s, MdConfig(nb_variant=2, **CFG)) as md:

@@ -39,6 +39,7 @@ def test_a1_linear_coupling_forces_and_dh_dlambda(orc, sys_cfg):
             orc.set_alchemical(lo, hi, lam + h); up = orc.forces(s, cfg, use_cells=True)[1]["potential"]
             orc.set_alchemical(lo, hi, lam - h); dn = orc.forces(s, cfg, use_cells=True)[1]["potential"]
             assert (up - dn) / (2 * h) == pytest.approx(-ux, rel=1e-7)
+            assert e["dudl"] == pytest.approx(-ux, rel=1e-12)
             # forces: central differences on a solute atom and a nearby water atom
             orc.set_alchemical(lo, hi, lam)
             x = np.asarray(s.pos, np.float64)
@@ -71,6 +72,51 @@ def test_a2_end_points(orc, sys_cfg):
         assert np.abs(f_plain[hi:].sum(0)).max() > 1e-3
     finally:
         orc.set_alchemical(0, 0, -1.0)
+
+
+def test_a4_soft_core_forces_dudl_and_the_decoupled_end(orc, sys_cfg):
+    """Soft-core coupling: forces are -grad U(lambda) and "dudl" is dU/dlambda, both by finite differences, on the
+    reference's lambda grid including its last windows 0.95 and 1.0 (src/properties/water_sol.rs:52-56); at lambda = 1
+    dU/dlambda stays finite even with a water sitting ON a solute atom, where the linear form diverges."""
+    s, cfg, lo, hi = sys_cfg
+    try:
+        orc.set_softcore(0.5, 3.0)
+        orc.set_alchemical(lo, hi, 0.0)
+        f0, e0 = orc.forces(s, cfg, use_cells=True)
+        orc.set_alchemical(0, 0, -1.0)
+        fp, ep = orc.forces(s, cfg, use_cells=True)
+        assert np.allclose(f0, fp, rtol=0, atol=1e-10) and e0["potential"] == pytest.approx(ep["potential"], rel=1e-13)   # r_sc = r at lambda 0
+        x = np.asarray(s.pos, np.float64)
+        d = np.linalg.norm(x[hi:] - x[lo], axis=1)
+        near = hi + int(d.argmin())
+        for lam in (0.05, 0.5, 0.95, 1.0):
+            orc.set_alchemical(lo, hi, lam)
+            f, e = orc.forces(s, cfg, use_cells=True)
+            h = 1e-5
+            lo_l, hi_l = max(lam - h, 0.0), min(lam + h, 1.0)
+            orc.set_alchemical(lo, hi, hi_l); up = orc.forces(s, cfg, use_cells=True)[1]["potential"]
+            orc.set_alchemical(lo, hi, lo_l); dn = orc.forces(s, cfg, use_cells=True)[1]["potential"]
+            assert e["dudl"] == pytest.approx((up - dn) / (hi_l - lo_l), rel=2e-5, abs=1e-4), lam
+            orc.set_alchemical(lo, hi, lam)
+            for a in (lo, near):
+                for k in range(3):
+                    xp = x.copy(); xp[a, k] += 1e-5
+                    xm = x.copy(); xm[a, k] -= 1e-5
+                    num = -(orc.forces(s, cfg, pos=xp, use_cells=True)[1]["potential"]
+                            - orc.forces(s, cfg, pos=xm, use_cells=True)[1]["potential"]) / 2e-5
+                    assert f[a, k] == pytest.approx(num, rel=2e-5, abs=2e-4), (lam, a, k)
+        # a water oxygen dropped exactly onto a solute atom: finite with the soft core at the decoupled end
+        xo = x.copy()
+        xo[near] = xo[lo]
+        orc.set_alchemical(lo, hi, 1.0)
+        e1 = orc.forces(s, cfg, pos=xo, use_cells=True)[1]
+        assert np.isfinite(e1["dudl"]) and abs(e1["dudl"]) < 1e5
+        orc.set_softcore(0.0)
+        e1_lin = orc.forces(s, cfg, pos=xo, use_cells=True)[1]
+        assert not np.isfinite(e1_lin["dudl"]) or abs(e1_lin["dudl"]) > 1e8, "the linear form is singular for overlapping sites"
+    finally:
+        orc.set_alchemical(0, 0, -1.0)
+        orc.set_softcore(0.0)
 
 
 def test_a3_ti_helpers():
