@@ -86,5 +86,6 @@ int  mdx_dd_halo_begin(mdx_handle* h);                   // pack + exchange (asy
 int  mdx_dd_halo_end(mdx_handle* h);                     // wait + unpack: ghost positions, peers' flag words
 int  mdx_dd_on_stale(mdx_handle* h);                     // the list went stale somewhere: local rebuild or repartition (same branch on every rank)
 int  mdx_dd_allreduce_host(mdx_handle* h, double* v, int n, bool max_u32 = false);
+int  mdx_dd_allreduce_f32(mdx_handle* h, float* dev, size_t n, hipStream_t produced_on);   // sum of a large device array over the ranks
 int  mdx_dd_download(mdx_handle* h, int which, float* dst);   // collective: the global array on every rank
 int  mdx_dd_gather_global(mdx_handle* h, bool with_force);    // g_pos / g_vel (/ g_frc) <- all ranks' owned atoms

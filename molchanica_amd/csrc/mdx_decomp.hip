@@ -301,6 +301,31 @@ static int dd_partition(mdx_handle* h) {
     return MDX_OK;
 }
 
+// Every RCCL operation of a handle is issued on ONE stream - its communication stream - so that the communicator sees one
+// ordered sequence of operations whatever the compute streams are doing.  These two bracket an operation that consumes
+// data produced on the compute stream and whose result the compute stream consumes.
+static int dd_comm_enter(mdx_handle* h) {
+    MdxDecomp* dd = h->dd;
+    HIP_TRY(hipEventRecord(dd->ev_packed, h->stream));
+    HIP_TRY(hipStreamWaitEvent(dd->comm_stream, dd->ev_packed, 0));
+    return MDX_OK;
+}
+static int dd_comm_leave(mdx_handle* h) {
+    MdxDecomp* dd = h->dd;
+    HIP_TRY(hipEventRecord(dd->ev_arrived, dd->comm_stream));
+    HIP_TRY(hipStreamWaitEvent(h->stream, dd->ev_arrived, 0));
+    return MDX_OK;
+}
+int mdx_dd_allreduce_f32(mdx_handle* h, float* dev, size_t n, hipStream_t produced_on) {
+    MdxDecomp* dd = h->dd;
+    HIP_TRY(hipEventRecord(dd->ev_packed, produced_on));
+    HIP_TRY(hipStreamWaitEvent(dd->comm_stream, dd->ev_packed, 0));
+    MDX_TRY(dd->tr->all_reduce_f32(dev, n, dd->comm_stream));
+    HIP_TRY(hipEventRecord(dd->ev_arrived, dd->comm_stream));
+    HIP_TRY(hipStreamWaitEvent(produced_on, dd->ev_arrived, 0));
+    return MDX_OK;
+}
+
 int mdx_dd_gather_global(mdx_handle* h, bool with_force) {
     MdxDecomp* dd = h->dd;
     hipStream_t st = h->stream;
@@ -313,8 +338,10 @@ int mdx_dd_gather_global(mdx_handle* h, bool with_force) {
     hipLaunchKernelGGL(dd_gather_pack_kernel, dim3(div_up(std::max(dd->n_owned, 1u), 256)), dim3(256), 0, st, dd->n_owned, R, dd->owned_gid,
                        h->d.slot_of, h->d.posq, h->d.vel, h->d.force, dd->gat_send);
     uint32_t counts[DD_MAX_WORLD];
-    MDX_TRY(dd->tr->all_gather_u32(dd->n_owned, counts, st));
+    MDX_TRY(dd_comm_enter(h));
+    MDX_TRY(dd->tr->all_gather_u32(dd->n_owned, counts, dd->comm_stream));
     if (!dd->tr->delivers()) {   // one rank of N alone: the others' rows keep their last known values
+        MDX_TRY(dd_comm_leave(h));
         hipLaunchKernelGGL(dd_gather_scatter_kernel, dim3(div_up(std::max(dd->n_owned, 1u), 256)), dim3(256), 0, st, dd->n_owned, R, dd->gat_send,
                            dd->g_pos, dd->g_vel, dd->g_frc, N, h->d.flags_dev);
         HIP_TRY(hipGetLastError());
@@ -329,8 +356,9 @@ int mdx_dd_gather_global(mdx_handle* h, bool with_force) {
         tot += counts[q];
     }
     if (tot != N) FAIL(MDX_EDEVICE, "decomposition: the ranks' owned atoms do not add up to the system (an atom was lost or duplicated)");
-    HIP_TRY(hipMemcpyAsync(dd->gat_recv + (size_t)R * my_off, dd->gat_send, sizeof(float4) * R * dd->n_owned, hipMemcpyDeviceToDevice, st));
-    MDX_TRY(dd->tr->exchange(dd->gat_send, ss, dd->gat_recv, rs, st));
+    HIP_TRY(hipMemcpyAsync(dd->gat_recv + (size_t)R * my_off, dd->gat_send, sizeof(float4) * R * dd->n_owned, hipMemcpyDeviceToDevice, dd->comm_stream));
+    MDX_TRY(dd->tr->exchange(dd->gat_send, ss, dd->gat_recv, rs, dd->comm_stream));
+    MDX_TRY(dd_comm_leave(h));
     HIP_TRY(hipMemsetAsync(h->d.flags_dev, 0, sizeof(uint32_t) * 4, st));
     hipLaunchKernelGGL(dd_gather_scatter_kernel, dim3(div_up(N, 256)), dim3(256), 0, st, N, R, dd->gat_recv, dd->g_pos, dd->g_vel, dd->g_frc, N,
                        h->d.flags_dev);
@@ -342,7 +370,8 @@ int mdx_dd_allreduce_host(mdx_handle* h, double* v, int n, bool max_u32) {
     MdxDecomp* dd = h->dd;
     if (!dd || dd->world == 1 || n <= 0) return MDX_OK;
     if (n > 64) FAIL(MDX_EPARAM, "internal: small all-reduce only");
-    hipStream_t st = h->stream;
+    HIP_TRY(hipStreamSynchronize(h->stream));      // (the values came from a synchronised read-back; the scratch is free)
+    hipStream_t st = dd->comm_stream;
     if (max_u32) {
         uint32_t w[64];
         for (int k = 0; k < n; ++k) w[k] = (uint32_t)v[k];
@@ -396,10 +425,11 @@ static int dd_local_set_still_valid(mdx_handle* h, bool* valid) {
     if (h->in_slot_space)
         hipLaunchKernelGGL(dd_drift_kernel, dim3(div_up(dd->n_local, 256)), dim3(256), 0, st, dd->n_local, dd->gid_local, h->d.slot_of,
                            h->d.posq, dd->pos_at_part, make_part(dd), bits);
-    MDX_TRY(dd->tr->all_reduce(bits, 1, 1, st));
+    MDX_TRY(dd_comm_enter(h));
+    MDX_TRY(dd->tr->all_reduce(bits, 1, 1, dd->comm_stream));
     uint32_t b = 0;
-    HIP_TRY(hipMemcpyAsync(&b, bits, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpyAsync(&b, bits, sizeof(uint32_t), hipMemcpyDeviceToHost, dd->comm_stream));
+    HIP_TRY(hipStreamSynchronize(dd->comm_stream));
     float d2; std::memcpy(&d2, &b, 4);
     *valid = dd->margin > 0.f && dd->local_rebuilds_since < 256 && std::sqrt(d2) <= 0.5f * dd->margin - 0.05f;
     return MDX_OK;

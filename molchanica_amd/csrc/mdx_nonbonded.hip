@@ -300,23 +300,13 @@ __device__ __forceinline__ float dpp_xadd(float v) {
 // and the device decides which one runs (a gated-off launch costs ~3 us).  A single kernel with a run-time switch was
 // measured first: the two scalar instructions it adds per cluster pair cost 11 % (0.537 -> 0.598 ms) - every
 // instruction in this loop is ~5 cycles of a latency-bound wave.
-template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF, bool ALCH = false, int DUAL = 0>
-__global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && NB_HALF_FLUSH) || ENERGY) ? 3 : 4) void nb_cluster_kernel(NbArgs a) {
-    if (a.gate && *a.gate > a.thr_bits) return;
-    static_assert(DUAL == 0 || (HALF && !ENERGY), "the dual list exists for the half-list force kernel");
-    bool owned_prune = true;
-    if (DUAL != 0) {
-        owned_prune = (a.force_prune | *a.prune_flag) != 0u;
-        const bool want_prune = owned_prune || (a.prune_flag2 && *a.prune_flag2 != 0u);
-        if (want_prune != (DUAL == 2)) return;
-    }
-    constexpr int BW = WPT > NB_WAVES ? WPT : NB_WAVES;       // waves per workgroup
-    __shared__ float4 s_xyzq[BW][64];
-    __shared__ float2 s_lj[BW][64];
-    __shared__ float s_red[WPT > 1 ? BW : 1][3][64];
-    __shared__ float s_ownj[(ENERGY && HALF) ? BW : 1][64];   // 1.0 <=> the staged j-atom is owned here
-    __shared__ float4 s_g[HALF ? BW : 1][64];                 // minus the chunk's j-forces (.w: the j-slot), until flushed
-    __shared__ unsigned long long s_mask[BW][64];             // a masked chunk's per-lane exclusion bits
+// The body of the cluster kernel.  DUAL here is 0, 1 or 2; the __global__ wrapper below owns the LDS arrays and, for the
+// merged dual-list launch (DUAL 3), picks the inner-walk or the pruning body at run time: one launch per step instead
+// of a pair of which the device runs one (the gated-off twin cost ~4 us per step - 5 % of a 23 k-atom step).
+template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF, bool ALCH, int DUAL, int BW>
+__device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owned_prune, float4 (*s_xyzq)[64], float2 (*s_lj)[64],
+                                                float (*s_red)[3][64], float (*s_ownj)[64], float4 (*s_g)[64],
+                                                unsigned long long (*s_mask)[64]) {
     // the wave index is wave-uniform: say so, and tile number, list bounds and the chunk loop
     // live in SGPRs with scalar branches instead of VGPR compares and exec-mask loops
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -586,6 +576,32 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
     }
 }
 
+template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF, bool ALCH = false, int DUAL = 0>
+__global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && NB_HALF_FLUSH) || ENERGY) ? 3 : 4) void nb_cluster_kernel(NbArgs a) {
+    if (a.gate && *a.gate > a.thr_bits) return;
+    static_assert(DUAL == 0 || (HALF && !ENERGY), "the dual list exists for the half-list force kernel");
+    constexpr int BW = WPT > NB_WAVES ? WPT : NB_WAVES;       // waves per workgroup
+    __shared__ float4 s_xyzq[BW][64];
+    __shared__ float2 s_lj[BW][64];
+    __shared__ float s_red[WPT > 1 ? BW : 1][3][64];
+    __shared__ float s_ownj[(ENERGY && HALF) ? BW : 1][64];   // 1.0 <=> the staged j-atom is owned here
+    __shared__ float4 s_g[HALF ? BW : 1][64];                 // minus the chunk's j-forces (.w: the j-slot), until flushed
+    __shared__ unsigned long long s_mask[BW][64];             // a masked chunk's per-lane exclusion bits
+    if (DUAL == 0) {
+        nb_cluster_body<ENERGY, COUL, GEOM, SAMECUT, WPT, HALF, ALCH, 0, BW>(a, true, s_xyzq, s_lj, s_red, s_ownj, s_g, s_mask);
+    } else {
+        const bool owned_prune = (a.force_prune | *a.prune_flag) != 0u;
+        const bool want_prune = owned_prune || (a.prune_flag2 && *a.prune_flag2 != 0u);
+        if (DUAL == 3) {        // merged launch: the device picks the body
+            if (want_prune) nb_cluster_body<ENERGY, COUL, GEOM, SAMECUT, WPT, HALF, ALCH, 2, BW>(a, owned_prune, s_xyzq, s_lj, s_red, s_ownj, s_g, s_mask);
+            else nb_cluster_body<ENERGY, COUL, GEOM, SAMECUT, WPT, HALF, ALCH, 1, BW>(a, owned_prune, s_xyzq, s_lj, s_red, s_ownj, s_g, s_mask);
+        } else {
+            if (want_prune != (DUAL == 2)) return;
+            nb_cluster_body<ENERGY, COUL, GEOM, SAMECUT, WPT, HALF, ALCH, DUAL == 2 ? 2 : 1, BW>(a, owned_prune, s_xyzq, s_lj, s_red, s_ownj, s_g, s_mask);
+        }
+    }
+}
+
 template <bool ENERGY, int COUL>
 static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samecut) {
     const int var = mdx_nb_variant(h);
@@ -606,6 +622,10 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
     const uint32_t grid = ((nblocks + 7) / 8) * 8;
     if (nblocks == 0) return;
     dim3 g(grid), b(bw * 64);
+    // Small systems (8 waves per tile) launch ONE kernel that picks the inner-walk or the pruning body on the device; larger
+    // ones launch the two flavours back to back and the device runs exactly one (measured: merged +1 % at 23 k atoms,
+    // -0.4 % at 1 M, where the merged kernel's 92 SGPRs / 127 VGPRs cost more than the ~4 us twin).  MDX_DUAL_MERGED=0: never merge.
+    static const bool dual_merged = [] { const char* e = std::getenv("MDX_DUAL_MERGED"); return !(e && e[0] == '0'); }();
     // dual list: the inner-walk kernel and the pruning kernel back to back, the device runs exactly one of them
 #define NB_DUAL(G, S, D)                                                                                              \
     do {                                                                                                               \
@@ -620,6 +640,7 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
         if (h->alch_on && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true, true>), g, b, 0, h->stream, a); \
         else if (h->alch_on) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, true, true>), g, b, 0, h->stream, a); \
         else if (var == 1) hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, G, S>), g, b, 0, h->stream, a);     \
+        else if (half && a.inner && dual_merged && wpt == 8) { NB_DUAL(G, S, 3); }                                 \
         else if (half && a.inner) { NB_DUAL(G, S, 1); NB_DUAL(G, S, 2); }                                          \
         else if (half && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true>), g, b, 0, h->stream, a); \
         else if (half && wpt == 2) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 2, true>), g, b, 0, h->stream, a); \

@@ -509,7 +509,7 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
                                Q, d_gate, thr, need, h->d.lj, sel);
         // decomposed handle: the meshes are summed over the ranks - a replicated mesh, every rank then solves it and
         // interpolates the forces of its own atoms (the all-reduce is ungated: a collective must be entered by every rank alike)
-        if (h->dd && h->dd->world > 1) MDX_TRY(h->dd->tr->all_reduce_f32(Q, p->n_real, st));
+        if (h->dd && h->dd->world > 1) MDX_TRY(mdx_dd_allreduce_f32(h, Q, p->n_real, st));
         if (p->exec_r2c(p->fwd, Q, (hipfftComplex*)(grp ? h->d.pme_f2 : h->d.pme_f)) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecR2C failed");
     }
     const dim3 gs((unsigned)std::min<size_t>((p->n_cplx + 255) / 256, energy ? 1024 : (size_t)1 << 30));
