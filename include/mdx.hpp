@@ -79,9 +79,9 @@ public:
         check(mdx_create(&system, &cfg, device, &h));
         return MdState(h, system.n_atoms);
     }
-    MdState(MdState&& o) noexcept : h_(std::exchange(o.h_, nullptr)), n_(o.n_) {}
+    MdState(MdState&& o) noexcept : h_(std::exchange(o.h_, nullptr)), n_(o.n_), n_waters_(o.n_waters_), water_sites_(o.water_sites_) {}
     MdState& operator=(MdState&& o) noexcept {
-        if (this != &o) { reset(); h_ = std::exchange(o.h_, nullptr); n_ = o.n_; }
+        if (this != &o) { reset(); h_ = std::exchange(o.h_, nullptr); n_ = o.n_; n_waters_ = o.n_waters_; water_sites_ = o.water_sites_; }
         return *this;
     }
     MdState(const MdState&) = delete;
@@ -111,6 +111,11 @@ public:
     std::vector<float> velocities() { return download(MDX_VEL); }
     std::vector<float> forces() { return download(MDX_FORCE); }
     void set_positions(const std::vector<float>& p) { upload(MDX_POS, p); }
+    /// The docking loop's pose update (src/docking/mod.rs:81-154): atoms [first, first + p.size()/3) only; the Verlet
+    /// list is kept while they stay inside its skin.
+    void set_positions_range(uint32_t first, const std::vector<float>& p) {
+        check(mdx_upload_range(h_, MDX_POS, first, (uint32_t)(p.size() / 3), p.data()));
+    }
     void set_velocities(const std::vector<float>& v) { upload(MDX_VEL, v); }
 
     /// `md.cell = SimBox::new(lo, hi)` + `md.rebuild_spatial_caches()` (sol_shrinking_box.rs:600-603, 632).
@@ -158,6 +163,39 @@ public:
     void configure_alchemical_window(uint32_t mol_index, double lambda) {
         check(mdx_configure_alchemical_window(h_, mol_index, lambda));
     }
+
+    /// Soft core of the alchemical window (alpha = 0: linear coupling).
+    void set_alchemical_softcore(float alpha = 0.5f, float sigma_min = 3.f) { check(mdx_set_alchemical_softcore(h_, alpha, sigma_min)); }
+
+    /// `md.water` (src/properties/sol_shrinking_box.rs:605-613): where the waters sit in the flat atom array ...
+    void set_water_layout(uint32_t first_atom, uint32_t n_waters, uint32_t sites_per_water) {
+        check(mdx_set_water_layout(h_, first_atom, n_waters, sites_per_water));
+        n_waters_ = n_waters; water_sites_ = sites_per_water;
+    }
+    /// ... and `md.water[i].{o,h0,h1,m}.posit` / `.force` (which = MDX_POS / MDX_FORCE) as four [3 n_waters] arrays.
+    struct Water { std::vector<float> o, h0, h1, m; };
+    Water water(int which = MDX_POS) {
+        Water w;
+        w.o.resize(3 * (size_t)n_waters_); w.h0.resize(w.o.size()); w.h1.resize(w.o.size());
+        if (water_sites_ == 4) w.m.resize(w.o.size());
+        check(mdx_water_download(h_, which, w.o.data(), w.h0.data(), w.h1.data(), water_sites_ == 4 ? w.m.data() : nullptr));
+        return w;
+    }
+    /// hydrogen bonds in every snapshot's energy data (src/md/viewer.rs:917-960)
+    void set_hbond_detection(const std::vector<uint8_t>& is_heavy_nosf, float max_h_acc_dist = 2.5f, float min_angle_deg = 120.f) {
+        check(mdx_set_hbond_detection(h_, is_heavy_nosf.empty() ? nullptr : is_heavy_nosf.data(), max_h_acc_dist, min_angle_deg));
+    }
+    std::vector<mdx_hbond> snapshot_hydrogen_bonds(uint32_t k) {
+        std::vector<mdx_hbond> hb(mdx_snapshot_hbond_count(h_, k));
+        check(mdx_snapshot_read_hbonds(h_, k, hb.data(), (uint32_t)hb.size()));
+        return hb;
+    }
+
+    /// One box over several GPUs (the reference is single-device): join a communicator; from then on step /
+    /// energy / positions are collective calls.  `id`: the 128 bytes of mdx::comm_unique_id() drawn by rank 0.
+    void comm_init(const std::array<uint8_t, MDX_COMM_ID_BYTES>& id, int rank, int world) { check(mdx_comm_init(h_, id.data(), rank, world)); }
+    /// ... or, between handles of ONE process (one thread each), an in-process fabric.
+    void comm_init_fabric(mdx_fabric* fabric, int rank) { check(mdx_comm_init_fabric(h_, fabric, rank)); }
 
     /// `snapshot_handlers.memory: Some(every_n)` (src/properties/water_sol.rs:185-189).
     void set_snapshot_cadence(uint32_t every_n, bool with_velocities = false) {
@@ -207,8 +245,15 @@ private:
         check(mdx_upload(h_, which, v.data()));
     }
     mdx_handle* h_ = nullptr;
-    uint32_t n_ = 0;
+    uint32_t n_ = 0, n_waters_ = 0, water_sites_ = 0;
 };
+
+/// ncclGetUniqueId through the library (rank 0; hand the bytes to the other ranks).
+inline std::array<uint8_t, MDX_COMM_ID_BYTES> comm_unique_id() {
+    std::array<uint8_t, MDX_COMM_ID_BYTES> id{};
+    check(mdx_comm_unique_id(id.data()));
+    return id;
+}
 
 /// `dynamics::compute_energy_snapshot(dev, &mols, param_set)` (src/md/mod.rs:1036): stateless single point.
 inline mdx_energies compute_energy_snapshot(const mdx_system& system, const mdx_config& cfg, int device = 0,

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "mdx.hpp"
@@ -123,6 +124,56 @@ int main() {
     mdx::MdState moved = std::move(md);                   // ownership moves like the Rust value
     mdx::run_dynamics_blocking(moved, 5, 0.0005f);
     expect(moved.step_count() == 205 && md.raw() == nullptr, "MdState is move-only; run_dynamics_blocking steps it");
+
+    // md.water views and a ligand-sized pose update on the moved handle
+    {
+        moved.set_water_layout(0, box.sys.n_atoms / 3, 3);
+        const auto w = moved.water(MDX_POS);
+        const auto x = moved.positions();
+        expect(w.o.size() == box.sys.n_atoms && w.m.empty(), "md.water views have one row per water (3-site: no M)");
+        bool same = true;
+        for (uint32_t i = 0; i < box.sys.n_atoms / 3 && same; ++i)
+            for (int k = 0; k < 3; ++k) same = same && w.o[3 * i + k] == x[9 * i + k] && w.h0[3 * i + k] == x[9 * i + 3 + k] && w.h1[3 * i + k] == x[9 * i + 6 + k];
+        expect(same, "md.water[i].{o,h0,h1}.posit are views over the flat atom array");
+        const uint64_t rb = moved.stats().rebuild_count;
+        std::vector<float> lig(x.begin() + 30, x.begin() + 60);
+        for (float& v : lig) v += 0.05f;
+        moved.set_positions_range(10, lig);
+        (void)moved.energy();
+        expect(moved.stats().rebuild_count == rb, "a small pose update (mdx_upload_range) keeps the Verlet list");
+    }
+
+    // One box decomposed over two ranks of THIS process (std::thread + the in-process fabric): the whole multi-GPU path
+    // - partition, halo exchange, stale-list protocol, energy reduction - runs below the ABI, no Python anywhere.
+    {
+        WaterBox big(14);                                 // 8232 atoms, 43.4 A cube: wide enough to cut in two
+        mdx::MdState ref = mdx::MdState::create(big.sys, cfg);
+        const mdx_energies r0 = ref.energy();
+        ref.step(0.0005f, nullptr, 30);
+        const std::vector<float> xr = ref.positions();
+        mdx_fabric* fabric = mdx_fabric_create(2);
+        std::vector<float> xd[2]; mdx_energies d0[2]; int bad[2] = {0, 0};
+        auto rank_main = [&](int rank) {
+            try {
+                mdx::MdState md2 = mdx::MdState::create(big.sys, cfg);
+                md2.comm_init_fabric(fabric, rank);
+                d0[rank] = md2.energy();
+                md2.step(0.0005f, nullptr, 30);
+                xd[rank] = md2.positions();
+            } catch (const std::exception& e) { std::printf("rank %d: %s\n", rank, e.what()); bad[rank] = 1; mdx_fabric_abort(fabric); }
+        };
+        std::thread t0(rank_main, 0), t1(rank_main, 1);
+        t0.join(); t1.join();
+        mdx_fabric_destroy(fabric);
+        expect(!bad[0] && !bad[1], "two decomposed ranks (std::thread + fabric) ran");
+        if (!bad[0] && !bad[1]) {
+            expect(std::fabs(d0[0].potential - r0.potential) < 1e-5 * std::fabs(r0.potential) + 0.05 && d0[0].potential == d0[1].potential,
+                   "decomposed energies are the totals of the box, identical on both ranks");
+            double s2 = 0.0; const double L = big.sys.box_hi[0];
+            for (size_t k = 0; k < xr.size(); ++k) { double d = xd[0][k] - xr[k]; d -= std::round(d / L) * L; s2 += d * d; }
+            expect(std::sqrt(s2 / (xr.size() / 3)) < 2e-3 && xd[0] == xd[1], "decomposed 30-step trajectory follows the single-handle one");
+        }
+    }
 
     std::printf("%s\n", fails ? "FAILED" : "ALL OK");
     return fails ? 1 : 0;

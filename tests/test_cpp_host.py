@@ -19,7 +19,7 @@ def _build():
     os.makedirs(OUT, exist_ok=True)
     cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
            os.path.join(ROOT, "tests", "cpp", "host_driver.cpp"), "-o", EXE,
-           "-L", PKG, "-lmdx", f"-Wl,-rpath,{PKG}", "-Wl,--allow-shlib-undefined"]
+           "-L", PKG, "-lmdx", "-pthread", f"-Wl,-rpath,{PKG}", "-Wl,--allow-shlib-undefined"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return EXE
