@@ -1155,3 +1155,8 @@ extern "C" int mdx_unpack_positions(mdx_handle* h, const uint32_t* d_gid, uint32
 }
 
 extern "C" void* mdx_stream(mdx_handle* h) { return h ? (void*)h->stream : nullptr; }
+extern "C" int mdx_debug_half_stats(mdx_handle* h, unsigned long long out[6]) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out, h->d.inner_count + MDX_EPART, sizeof(unsigned long long) * 6, hipMemcpyDeviceToHost));
+    return MDX_OK;
+}

@@ -1110,7 +1110,7 @@ int mdx_rebuild(mdx_handle* h) {
     h->dual_on = !h->dual_auto_off && mdx_nb_half(h) && prune && h->inner_skin > 0.f && h->inner_skin < h->cfg.skin &&
                  (h->n_vsites == 0 || h->vsites_convex);
     h->prune_pending = true;
-    if (!d.inner_count) { ALLOC(d.inner_count, MDX_EPART + 1); HIP_TRY(hipMemsetAsync(d.inner_count, 0, sizeof(unsigned long long) * (MDX_EPART + 1), st)); }
+    if (!d.inner_count) { ALLOC(d.inner_count, MDX_EPART + 8); HIP_TRY(hipMemsetAsync(d.inner_count, 0, sizeof(unsigned long long) * (MDX_EPART + 8), st)); }
     uint64_t nmask = (uint64_t)MC * 8;
     h->stats.n_atoms = N; h->stats.n_slots = S; h->stats.n_tiles = T; h->stats.n_clusters = NC;
     h->stats.n_list_entries = E; h->stats.n_masked_entries = nmask;

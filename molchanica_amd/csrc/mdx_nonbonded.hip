@@ -386,6 +386,9 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
     // entries compacted), and the tile's path accumulators are cleared.  Decided on the device: the host enqueues blind.
     constexpr bool prune = DUAL == 2;
     uint32_t kept = 0;
+#ifdef NB_HALF_STATS
+    uint32_t dbg_jh = 0, dbg_ih = 0, dbg_q = 0, dbg_pairs = 0;
+#endif
     // (pruning launch) first plain chunk of this wave's share, and how many compacted plain entries it has written
     const uint32_t c_first = nmc + ((uint32_t)part + WPT - nmc % WPT) % WPT;
     uint32_t wcur = 0;
@@ -453,7 +456,18 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
                                                                              (ENERGY && ALCH) ? &e4 : nullptr, bias,
                                                                              prune ? &r2v : nullptr, (ENERGY && ALCH) ? &e5 : nullptr);
                     if (prune) {   // any allowed atom pair of this cluster pair inside the inner radius?
-                        if (__ballot(r2v < a.rin2) != 0ull) newm |= 1u << ci;
+                        const unsigned long long bb = __ballot(r2v < a.rin2);
+                        if (bb != 0ull) newm |= 1u << ci;
+#ifdef NB_HALF_STATS
+                        if (bb != 0ull) {
+                            const unsigned long long ilo = 0x0F0F0F0F0F0F0F0Full;
+                            dbg_jh += ((uint32_t)bb != 0u) + ((bb >> 32) != 0ull);
+                            dbg_ih += ((bb & ilo) != 0ull) + ((bb & ~ilo) != 0ull);
+                            dbg_q += (((uint32_t)bb & 0x0F0F0F0Fu) != 0u) + (((uint32_t)bb & 0xF0F0F0F0u) != 0u) +
+                                     (((uint32_t)(bb >> 32) & 0x0F0F0F0Fu) != 0u) + (((uint32_t)(bb >> 32) & 0xF0F0F0F0u) != 0u);
+                            dbg_pairs += __popcll(bb);
+                        }
+#endif
                     }
                     if (ENERGY && HALF) {   // a pair's energy is split between the owners of its two atoms
                         const float w = wj + (((own_bits >> ci) & 1u) ? 0.5f : 0.f);
@@ -541,6 +555,13 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
         if (part == 0 && t_ok && (owned_prune || !(a.slot_flags[t * MDX_TILE + lane] & 2u))) a.ref[t * MDX_TILE + lane].w = 0.f;
         if (lane == 0 && kept) atomicAdd(a.inner_count + ((blk * BW + wave) & (MDX_EPART - 1)), (unsigned long long)kept);
         if (lane == 0 && blk == 0 && wave == 0) atomicAdd(a.inner_count + MDX_EPART, 1ull);
+#ifdef NB_HALF_STATS
+        if (lane == 0) {
+            atomicAdd(a.inner_count + MDX_EPART + 1, (unsigned long long)dbg_jh); atomicAdd(a.inner_count + MDX_EPART + 2, (unsigned long long)dbg_ih);
+            atomicAdd(a.inner_count + MDX_EPART + 3, (unsigned long long)dbg_q); atomicAdd(a.inner_count + MDX_EPART + 4, (unsigned long long)kept);
+            atomicAdd(a.inner_count + MDX_EPART + 5, (unsigned long long)dbg_pairs);
+        }
+#endif
     }
     if (WPT > 1) {   // fixed-order sum of the waves' partial forces
         s_red[wave][0][lane] = ox; s_red[wave][1][lane] = oy; s_red[wave][2][lane] = oz;
