@@ -358,11 +358,10 @@ static int compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint
     bool split = false;
     if (h->dd && h->dd->halo_pending) {                    // decomposed handle, step loop: ghost positions travel now
         h->dd->halo_pending = false;
-        MDX_TRY(mdx_dd_halo_begin(h));                     // pack + ncclSend/ncclRecv group on the communication stream
-        // tiles whose lists involve no ghost run while the message is in flight, the rest after the unpack
-        split = !energy && h->tile_split && h->dd->overlap && h->dd->world > 1 && mdx_nb_variant(h) >= 2 && !h->pme_on && !h->profile;
+        // tiles whose lists involve no ghost run on the side stream while the message is packed, sent and unpacked on
+        // this one; the tiles that need ghosts follow the unpack
+        split = !energy && mdx_dd_split_now(h);
         if (split) {
-            // interior tiles on the side stream (they read owned atoms only), beside the unpack and the boundary tiles
             if (mdx_nb_half(h) && !h->force_zeroed) HIP_TRY(hipMemsetAsync(h->d.force, 0, sizeof(float4) * (size_t)h->S, h->stream));
             h->force_zeroed = true;
             HIP_TRY(hipEventRecord(h->dd->ev_fork, h->stream));
@@ -374,7 +373,8 @@ static int compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint
             MDX_TRY(rc_int);
             HIP_TRY(hipEventRecord(h->dd->ev_interior, h->dd->side_stream));
         }
-        MDX_TRY(mdx_dd_halo_end(h));
+        MDX_TRY(mdx_dd_halo_begin(h));                     // pack + ncclSend/ncclRecv group
+        MDX_TRY(mdx_dd_halo_end(h));                       // unpack: ghost positions, the peers' flag words
     }
     if (h->pme_on && h->pme_overlap) {                     // SPME reciprocal space on its side stream, beside the pair kernel
         MDX_TRY(mdx_pme_fork(h));
@@ -483,6 +483,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
     while (remaining) {
         MDX_TRY(ensure_ready(h));   // a barostat application at the last cadence point left the list to rebuild
         const uint32_t chunk = std::min(std::min(remaining, h->cfg.chunk_steps), mdx_steps_to_next_event(h));
+        const auto t_chunk = std::chrono::steady_clock::now();
         HIP_TRY(hipMemsetAsync(d.ctl, 0, sizeof(StepCtl), st));
         // Velocity Verlet: without constraints the closing half kick of step s and the opening one of
         // step s+1 are one pass (mode 1).  With constraints every step is kick-drift-SHAKE-forces-kick-
@@ -564,6 +565,25 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
                     }
                 }
                 h->dual_win_steps = 0; h->dual_win_prunes = 0;
+            }
+        }
+        if (h->dd && h->dd->world > 1 && h->dd->tune_phase < 2 && h->tile_split) {
+            // interior / boundary split: try both over the first full, rebuild-free chunks and keep the faster
+            MdxDecomp* dd = h->dd;
+            if (done == chunk && chunk == h->cfg.chunk_steps) {
+                if (dd->tune_chunks >= 2) {   // (the first two chunks of a phase warm it up)
+                    dd->tune_ms[dd->tune_phase] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_chunk).count();
+                    dd->tune_steps[dd->tune_phase] += chunk;
+                }
+                if (++dd->tune_chunks >= 8) {
+                    dd->tune_chunks = 0;
+                    if (dd->tune_phase == 0) { dd->tune_phase = 1; dd->overlap = false; }
+                    else {
+                        const double with_split = dd->tune_ms[0] / std::max(dd->tune_steps[0], 1u), without = dd->tune_ms[1] / std::max(dd->tune_steps[1], 1u);
+                        dd->overlap = with_split < without;
+                        dd->tune_phase = 2;
+                    }
+                }
             }
         }
         h->forces_valid = true;
@@ -1146,7 +1166,7 @@ extern "C" int mdx_unpack_positions(mdx_handle* h, const uint32_t* d_gid, uint32
                               h->d.slot_of, h->d.posq, (const float4*)d_in4, (const float4*)d_shift4,
                               flag_word >= 0 ? &h->d.ctl->disp2[flag_word] : nullptr,
                               dual ? h->d.ref : nullptr,
-                              dual ? ((h->dd && h->tile_split && h->dd->overlap && h->dd->world > 1) ? &h->d.ctl->prune_ghost[h->chunk_s + 1]
+                              dual ? (mdx_dd_split_now(h) ? &h->d.ctl->prune_ghost[h->chunk_s + 1]
                                                                                                       : &h->d.ctl->prune[h->chunk_s + 1]) : nullptr,
                               0.5f * h->inner_skin * (1.0f - 1.0e-4f));
     HIP_TRY(hipGetLastError());

@@ -71,12 +71,23 @@ struct MdxDecomp {
     hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_interior = nullptr;
     bool halo_pending = false;         // the next force call of the step loop starts with a halo exchange
     int halo_step = -1;                // chunk step of that exchange (flag word = step + 1)
-    bool overlap = true;               // interior tiles run while the message is in flight
+    bool overlap = true;               // interior tiles run (on the side stream) while the message is packed, sent and unpacked
+    // ... or not: whether the split pays depends on the wire time it hides against the fork / join it costs, so a handle
+    // tries both over its first chunks and keeps the faster (a local scheduling choice: ranks need not agree).
+    // MDX_HALO_OVERLAP=0 / 1 pins it.
+    int tune_phase = 0;                // 0: measuring with the split, 1: without, 2: decided
+    double tune_ms[2] = {0.0, 0.0}; uint32_t tune_steps[2] = {0, 0}; uint32_t tune_chunks = 0;
     double* red = nullptr;             // [64] device scratch of the small all-reduces
     // statistics
     uint64_t repartitions = 0, local_rebuilds = 0; uint32_t local_rebuilds_since = 0;
     double repartition_ms = 0.0;
 };
+
+// Is the pair kernel of this step-loop force call launched as interior + boundary halves?  ONE predicate for everybody who
+// must agree on it: the launch itself, and the halo unpack (which then raises the ghosts' own prune word).
+static inline bool mdx_dd_split_now(const mdx_handle* h) {
+    return h->dd && h->tile_split && h->dd->overlap && h->dd->world > 1 && mdx_nb_variant(h) >= 2 && !h->pme_on && !h->profile;
+}
 
 int  mdx_set_local_atoms_impl(mdx_handle* h, uint32_t n_local, const uint32_t* d_gid, const uint8_t* d_ghost, const float* d_pos4,
                               const float* d_vel4, const float lo[3], const float hi[3], int32_t periodic);

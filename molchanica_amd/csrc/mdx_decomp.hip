@@ -306,18 +306,21 @@ static int dd_partition(mdx_handle* h) {
 // data produced on the compute stream and whose result the compute stream consumes.
 static int dd_comm_enter(mdx_handle* h) {
     MdxDecomp* dd = h->dd;
+    if (dd->comm_stream == h->stream) return MDX_OK;
     HIP_TRY(hipEventRecord(dd->ev_packed, h->stream));
     HIP_TRY(hipStreamWaitEvent(dd->comm_stream, dd->ev_packed, 0));
     return MDX_OK;
 }
 static int dd_comm_leave(mdx_handle* h) {
     MdxDecomp* dd = h->dd;
+    if (dd->comm_stream == h->stream) return MDX_OK;
     HIP_TRY(hipEventRecord(dd->ev_arrived, dd->comm_stream));
     HIP_TRY(hipStreamWaitEvent(h->stream, dd->ev_arrived, 0));
     return MDX_OK;
 }
 int mdx_dd_allreduce_f32(mdx_handle* h, float* dev, size_t n, hipStream_t produced_on) {
     MdxDecomp* dd = h->dd;
+    if (dd->comm_stream == produced_on) return dd->tr->all_reduce_f32(dev, n, produced_on);
     HIP_TRY(hipEventRecord(dd->ev_packed, produced_on));
     HIP_TRY(hipStreamWaitEvent(dd->comm_stream, dd->ev_packed, 0));
     MDX_TRY(dd->tr->all_reduce_f32(dev, n, dd->comm_stream));
@@ -395,10 +398,12 @@ int mdx_dd_halo_begin(mdx_handle* h) {
     if (dd->world == 1) return MDX_OK;
     const int fw = dd->halo_step >= 0 ? dd->halo_step + 1 : -1;
     MDX_TRY(mdx_pack_positions(h, dd->send_ids, dd->n_send, (float*)dd->send_buf, fw));
-    HIP_TRY(hipEventRecord(dd->ev_packed, h->stream));
-    HIP_TRY(hipStreamWaitEvent(dd->comm_stream, dd->ev_packed, 0));
+    if (dd->comm_stream != h->stream) {
+        HIP_TRY(hipEventRecord(dd->ev_packed, h->stream));
+        HIP_TRY(hipStreamWaitEvent(dd->comm_stream, dd->ev_packed, 0));
+    }
     MDX_TRY(dd->tr->exchange(dd->send_buf, dd->send_segs, dd->recv_buf, dd->recv_segs, dd->comm_stream));
-    HIP_TRY(hipEventRecord(dd->ev_arrived, dd->comm_stream));
+    if (dd->comm_stream != h->stream) HIP_TRY(hipEventRecord(dd->ev_arrived, dd->comm_stream));
     return MDX_OK;
 }
 
@@ -406,7 +411,7 @@ int mdx_dd_halo_end(mdx_handle* h) {
     MdxDecomp* dd = h->dd;
     if (dd->world == 1) return MDX_OK;
     const int fw = dd->halo_step >= 0 ? dd->halo_step + 1 : -1;
-    HIP_TRY(hipStreamWaitEvent(h->stream, dd->ev_arrived, 0));
+    if (dd->comm_stream != h->stream) HIP_TRY(hipStreamWaitEvent(h->stream, dd->ev_arrived, 0));
     if (dd->tr->delivers())
         MDX_TRY(mdx_unpack_positions(h, dd->recv_ids, dd->n_recv, (const float*)dd->recv_buf, (const float*)dd->recv_shift, fw));
     return MDX_OK;
@@ -493,7 +498,7 @@ int mdx_dd_download(mdx_handle* h, int which, float* dst) {
 void mdx_dd_destroy(mdx_handle* h) {
     MdxDecomp* dd = h->dd;
     if (!dd) return;
-    if (dd->comm_stream) (void)hipStreamSynchronize(dd->comm_stream);
+    if (dd->comm_stream && dd->comm_stream != h->stream) (void)hipStreamSynchronize(dd->comm_stream);
     void* ptrs[] = {dd->anchor, dd->g_pos, dd->g_vel, dd->g_frc, dd->cls, dd->owner, dd->shift_code, dd->send_mask, dd->flags, dd->scan,
                     dd->scan_sums, dd->gid_local, dd->ghost_local, dd->pos_l, dd->vel_l, dd->pos_at_part, dd->owned_gid, dd->send_ids,
                     dd->recv_ids, dd->recv_shift, dd->send_buf, dd->recv_buf, dd->gat_send, dd->gat_recv, dd->red};
@@ -503,7 +508,7 @@ void mdx_dd_destroy(mdx_handle* h) {
     if (dd->ev_fork) (void)hipEventDestroy(dd->ev_fork);
     if (dd->ev_interior) (void)hipEventDestroy(dd->ev_interior);
     if (dd->side_stream) { (void)hipStreamSynchronize(dd->side_stream); (void)hipStreamDestroy(dd->side_stream); }
-    if (dd->comm_stream) (void)hipStreamDestroy(dd->comm_stream);
+    if (dd->comm_stream && dd->comm_stream != h->stream) (void)hipStreamDestroy(dd->comm_stream);
     delete dd->tr;
     delete dd;
     h->dd = nullptr;
@@ -566,6 +571,7 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
     {
         const char* e = std::getenv("MDX_HALO_OVERLAP");
         dd->overlap = !(e && e[0] == '0');
+        dd->tune_phase = (e && (e[0] == '0' || e[0] == '1')) ? 2 : 0;
     }
     int rc = MDX_OK;
 #define DD_TRY(x) do { rc = (x); if (rc != MDX_OK) return bail(rc); } while (0)
@@ -575,7 +581,14 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
     DD_TRY(dd_alloc(&dd->gid_local, N)); DD_TRY(dd_alloc(&dd->ghost_local, N)); DD_TRY(dd_alloc(&dd->pos_l, N)); DD_TRY(dd_alloc(&dd->vel_l, N));
     DD_TRY(dd_alloc(&dd->pos_at_part, N)); DD_TRY(dd_alloc(&dd->owned_gid, N)); DD_TRY(dd_alloc(&dd->red, 64));
     dd->cap_local = N;
-    DD_HIP(hipStreamCreateWithFlags(&dd->comm_stream, hipStreamNonBlocking));
+    // Every RCCL operation of a handle goes to ONE stream.  By default that is the compute stream itself: pack -> send/recv
+    // group -> unpack run back to back without cross-stream event hops (each hop is ~5-10 us of idle time on this stack; the
+    // overlap with the message comes from the interior tiles on the side stream).  MDX_COMM_STREAM=1: a separate stream.
+    {
+        const char* e = std::getenv("MDX_COMM_STREAM");
+        if (e && e[0] == '1') DD_HIP(hipStreamCreateWithFlags(&dd->comm_stream, hipStreamNonBlocking));
+        else dd->comm_stream = h->stream;
+    }
     DD_HIP(hipEventCreateWithFlags(&dd->ev_packed, hipEventDisableTiming));
     DD_HIP(hipEventCreateWithFlags(&dd->ev_arrived, hipEventDisableTiming));
     DD_HIP(hipStreamCreateWithFlags(&dd->side_stream, hipStreamNonBlocking));
@@ -587,7 +600,7 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
     DD_TRY(mdx_unsort_state(h));
     DD_HIP(hipMemcpyAsync(dd->g_pos, h->d.pos_orig, sizeof(float4) * N, hipMemcpyDeviceToDevice, h->stream));
     DD_HIP(hipMemcpyAsync(dd->g_vel, h->d.vel_orig, sizeof(float4) * N, hipMemcpyDeviceToDevice, h->stream));
-    h->want_tile_split = dd->world > 1 && dd->overlap;
+    h->want_tile_split = dd->world > 1 && (dd->overlap || dd->tune_phase < 2);
     if (h->pme_on) {   // the reciprocal-space chain of a decomposed handle runs on the handle's own stream (mesh all-reduce inside)
         if (h->pme_overlap && h->stream_pme) DD_HIP(hipStreamSynchronize(h->stream_pme));
         h->pme_overlap = false;

@@ -18,14 +18,17 @@ if os.environ.get("ONE_RANK_HOT", "0") != "1":      # same untimed preparation a
         eq.set_thermostat(1, 300.0, 0.02, 1); eq.step(0.0005, None, 600); eq.set_thermostat(0, 300.0, 0.02, 1)
         s.pos = np.ascontiguousarray(eq.positions(), dtype=np.float32); s.vel = np.ascontiguousarray(eq.velocities(), dtype=np.float32)
 for world in worlds:
-    for overlap in ("1", "0"):
-        os.environ["MDX_HALO_OVERLAP"] = overlap
+    for overlap in (os.environ.get("ONE_RANK_SPLIT", "1,0").split(",")):      # ONE_RANK_SPLIT=1 or 0: one arm only
+        if overlap == "auto": os.environ.pop("MDX_HALO_OVERLAP", None)      # the library tries both and keeps the faster
+        else: os.environ["MDX_HALO_OVERLAP"] = overlap
         with MdState(s, MdConfig()) as md:
             md.comm_init_null(0, world)
             md.step(0.0005, None, 8)
             md.profile(2); md.profile(0)          # (resets the timers; rebuild_ms_sum only runs while profiling is on)
             st0 = md.stats()
             t0 = time.perf_counter(); md.step(0.0005, None, steps); st1 = md.stats(); el = time.perf_counter() - t0    # stats() synchronises
+            if os.environ.get("ONE_RANK_TRACE", "0") == "1":     # under rocprofv3: stop here, the trace ends with plain (event-free) steps
+                print("world %d split %s: step wall %.3f ms" % (world, overlap, 1e3 * el / steps)); continue
             md.profile(2); r0 = md.stats()        # a second stretch with the rebuild timer on: what the list builds cost
             md.step(0.0005, None, steps); r1 = md.stats(); md.profile(0)
             rb_ms = (r1["rebuild_ms_sum"] - r0["rebuild_ms_sum"]) / max(r1["rebuild_count"] - r0["rebuild_count"], 1)
@@ -39,7 +42,7 @@ for world in worlds:
             rebuilds = st1["rebuild_count"] - st0["rebuild_count"]
             print("world %d rank 0 (interior/boundary split %s): owned %d ghost %d tiles %d | pair %.3f ms bonded %.3f integrate %.3f = %.3f ms of kernels | "
                   "step wall %.3f ms (%d list rebuilds in %d steps at %.2f ms, %d repartitions at %.2f ms incl. their rebuild: %.3f ms per step amortised) -> ceiling %.0f steps/s without wire time | cluster pairs verlet %.1f M inner %.1f M" % (
-                      world, "on" if overlap == "1" else "off", st["n_owned"], st["n_ghost"], st["n_tiles"], k_nb, k_b, k_i, k_nb + k_b + k_i,
+                      world, {"1": "on", "0": "off"}.get(overlap, "auto-tuned"), st["n_owned"], st["n_ghost"], st["n_tiles"], k_nb, k_b, k_i, k_nb + k_b + k_i,
                       1e3 * el / steps, rebuilds, steps, rb_ms, st1["repartitions"] - st0["repartitions"], rp_ms,
                       (rebuilds * rb_ms + (st1["repartitions"] - st0["repartitions"]) * max(rp_ms - rb_ms, 0.0)) / steps, steps / el,
                       st["n_cluster_pairs"] / 1e6, st["n_inner_cluster_pairs"] / 1e6), flush=True)
