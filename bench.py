@@ -100,7 +100,10 @@ def cpu_baseline(system, cfg, dt, n_steps):
     same system (n_steps+1 force evaluations)."""
     from oracle import oracle
     try:
-        path = oracle.build(extra="-march=native", target="liborc_native.so")
+        import hashlib
+        flags = next((l for l in open("/proc/cpuinfo") if l.startswith("flags")), "unknown")
+        # one -march=native build per CPU model: such an object must never run on a machine it was not built on
+        path = oracle.build(extra="-march=native", target="liborc_native_%s.so" % hashlib.sha1(flags.encode()).hexdigest()[:10])
         lib = oracle.lib(path)
     except Exception:
         lib = oracle.lib()

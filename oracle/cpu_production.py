@@ -21,7 +21,14 @@ _libs = {}
 def build(native: bool = False) -> str:
     """native=True compiles for the machine it runs on (-march=native): only ever done at run time on that machine,
     the portable build is what tests use."""
-    target = "libcpuprod_native.so" if native else "libcpuprod.so"
+    target = "libcpuprod.so"
+    if native:   # one build per CPU model: a -march=native object must never run on a machine it was not built on
+        import hashlib
+        try:
+            flags = next(l for l in open("/proc/cpuinfo") if l.startswith("flags"))
+        except Exception:
+            flags = "unknown"
+        target = "libcpuprod_native_%s.so" % hashlib.sha1(flags.encode()).hexdigest()[:10]
     path, src = os.path.join(_HERE, target), os.path.join(_HERE, "cpu_production.c")
     if (not os.path.exists(path)) or os.path.getmtime(path) < os.path.getmtime(src):
         arch = "-march=native" if native else ""
