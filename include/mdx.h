@@ -408,6 +408,9 @@ int mdx_comm_init_fabric(mdx_handle* h, mdx_fabric* f, int rank);
 /* Rank `rank` of `world` with a transport that delivers nothing: what ONE rank of a decomposition costs per step,
  * measured alone on a single GPU (tools/one_rank_profile.py). */
 int mdx_comm_init_null(mdx_handle* h, int rank, int world);
+/* Diagnostics: every transport entry point of a joined handle on its real wire (send/recv group to every rank incl. itself,
+ * the small and the large all-reduce, the word all-gather), results checked.  Collective. */
+int mdx_comm_selftest(mdx_handle* h);
 int mdx_comm_info(const mdx_handle* h, int* rank, int* world, int grid[3], uint32_t* n_owned, uint32_t* n_ghost, float* halo);
 
 /* ---- the building blocks underneath (kept for hosts that drive the decomposition themselves, and for the tests) ----

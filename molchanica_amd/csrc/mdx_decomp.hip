@@ -626,3 +626,58 @@ extern "C" int mdx_comm_info(const mdx_handle* h, int* rank, int* world, int gri
     if (halo) *halo = dd ? dd->halo : 0.f;
     return MDX_OK;
 }
+
+// Exercises every transport entry point of a joined handle on the wire it really has - including, with one rank, RCCL's
+// send/recv to self inside a group - and checks the results: what a single-GPU box can verify of the RCCL leg.
+__global__ void dd_selftest_fill_kernel(uint32_t n, float4* a, float seed) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = make_float4(seed + (float)i, 2.f * (float)i, -(float)i, 1.f);
+}
+extern "C" int mdx_comm_selftest(mdx_handle* h) {
+    if (!h || !h->dd) FAIL(MDX_EPARAM, "the handle has not joined a communicator");
+    MdxDecomp* dd = h->dd;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = dd->comm_stream;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const uint32_t n = 1000;
+    float4 *a = nullptr, *b = nullptr;
+    HIP_TRY(hipMalloc((void**)&a, sizeof(float4) * n * (size_t)dd->world));
+    HIP_TRY(hipMalloc((void**)&b, sizeof(float4) * n * (size_t)dd->world));
+    auto done = [&](int rc) { (void)hipFree(a); (void)hipFree(b); return rc; };
+    hipLaunchKernelGGL(dd_selftest_fill_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, n, a, 1000.f * (float)dd->rank);
+    HIP_TRY(hipMemsetAsync(b, 0, sizeof(float4) * n * (size_t)dd->world, st));
+    // every rank sends its block to every rank (itself included) and files what arrives by sender
+    std::vector<MdxSeg> ss, rs;
+    for (int q = 0; q < dd->world; ++q) { ss.push_back({q, 0u, n}); rs.push_back({q, (uint32_t)q * n, n}); }
+    int rc = dd->tr->exchange(a, ss, b, rs, st);
+    if (rc != MDX_OK) return done(rc);
+    std::vector<float4> hb((size_t)n * dd->world);
+    if (hipMemcpyAsync(hb.data(), b, sizeof(float4) * hb.size(), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        { mdx_set_error("selftest: copy failed"); return done(MDX_EDEVICE); }
+    if (dd->tr->delivers())
+        for (int q = 0; q < dd->world; ++q)
+            for (uint32_t i = 0; i < n; i += 97)
+                if (hb[(size_t)q * n + i].x != 1000.f * (float)q + (float)i || hb[(size_t)q * n + i].z != -(float)i)
+                    { mdx_set_error("selftest: a send/recv segment arrived wrong"); return done(MDX_EDEVICE); }
+    // small all-reduces (sum of doubles, max of words), the large f32 sum, the word all-gather
+    double v[3] = {1.0, (double)dd->rank, 0.5};
+    rc = mdx_dd_allreduce_host(h, v, 3);
+    if (rc != MDX_OK) return done(rc);
+    const double W = dd->world;
+    if (dd->tr->delivers() && dd->world > 1 && (v[0] != W || v[1] != W * (W - 1) / 2 || v[2] != 0.5 * W)) { mdx_set_error("selftest: all-reduce(sum) wrong"); return done(MDX_EDEVICE); }
+    double m[1] = {(double)(7 + dd->rank)};
+    rc = mdx_dd_allreduce_host(h, m, 1, true);
+    if (rc != MDX_OK) return done(rc);
+    if (dd->tr->delivers() && m[0] != 7.0 + (W - 1)) { mdx_set_error("selftest: all-reduce(max) wrong"); return done(MDX_EDEVICE); }
+    hipLaunchKernelGGL(dd_selftest_fill_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, n, a, 1.f);
+    rc = dd->tr->all_reduce_f32((float*)a, 4 * (size_t)n, st);
+    if (rc != MDX_OK) return done(rc);
+    if (hipMemcpyAsync(hb.data(), a, sizeof(float4) * n, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        { mdx_set_error("selftest: copy failed"); return done(MDX_EDEVICE); }
+    if (dd->tr->delivers() && (hb[10].x != (float)(W * 11.0) || hb[10].w != (float)W)) { mdx_set_error("selftest: large f32 all-reduce wrong"); return done(MDX_EDEVICE); }
+    uint32_t words[DD_MAX_WORLD];
+    rc = dd->tr->all_gather_u32(100u + (uint32_t)dd->rank, words, st);
+    if (rc != MDX_OK) return done(rc);
+    if (dd->tr->delivers()) for (int q = 0; q < dd->world; ++q) if (words[q] != 100u + (uint32_t)q) { mdx_set_error("selftest: all-gather wrong"); return done(MDX_EDEVICE); }
+    return done(MDX_OK);
+}

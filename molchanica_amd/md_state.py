@@ -133,6 +133,7 @@ def load_library():
     lib.mdx_fabric_abort.restype = None
     lib.mdx_comm_init_fabric.argtypes = [H, C.c_void_p, C.c_int]
     lib.mdx_comm_init_null.argtypes = [H, C.c_int, C.c_int]
+    lib.mdx_comm_selftest.argtypes = [H]
     lib.mdx_comm_info.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _u32p, _u32p, _fp]
     _lib = lib
     return lib
@@ -409,6 +410,10 @@ class MdState:
     def comm_init_null(self, rank: int, world: int):
         """Rank `rank` of `world` with a transport that delivers nothing (one rank's cost measured alone)."""
         _check(load_library().mdx_comm_init_null(self._h, int(rank), int(world)))
+
+    def comm_selftest(self):
+        """Every transport entry point on the real wire, results checked (collective)."""
+        _check(load_library().mdx_comm_selftest(self._h))
 
     def comm_info(self) -> dict:
         r, w, g = C.c_int(), C.c_int(), (C.c_int * 3)()

@@ -260,6 +260,25 @@ def test_refusals_and_errors_on_decomposed_handles():
             md.comm_init_fabric(Fabric(2), 0)
 
 
+@pytest.mark.parametrize("world", [1, 4])
+def test_transport_selftest_on_the_fabric(world):
+    from molchanica_amd.md_state import Fabric, MdState
+    s = systems.water_box(14, seed=6)
+    fabric = Fabric(world)
+    errs = []
+
+    def run(rank):
+        try:
+            with MdState(s, MdConfig(**CFG)) as md:
+                md.comm_init_fabric(fabric, rank)
+                md.comm_selftest()
+        except BaseException as e:   # pragma: no cover
+            errs.append(e); fabric.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+
+
 def test_rccl_transport_single_rank_selftest():
     """The RCCL leg itself (dlopen of librccl, ncclGetUniqueId, ncclCommInitRank, the all-reduce and all-gather wrappers)
     with the one rank a single-GPU box allows: a world-1 communicator runs the decomposed step loop and reports totals."""
@@ -273,6 +292,7 @@ def test_rccl_transport_single_rank_selftest():
     with MdState(s, cfg) as md:
         md.comm_init(uid, 0, 1)
         assert md.comm_info()["world"] == 1
+        md.comm_selftest()          # ncclGroupStart / ncclSend + ncclRecv (to self) / ncclGroupEnd, ncclAllReduce f64 / u32 / f32, ncclAllGather
         e = md.energy()
         assert abs(e["potential"] - e_ref["potential"]) < 1e-2
         md.step(0.0005, None, 20)
