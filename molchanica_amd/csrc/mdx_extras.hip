@@ -619,7 +619,7 @@ extern "C" int mdx_minimize_energy(mdx_handle* h, uint32_t max_iters, const floa
         if (hipMemcpyAsync(&flag, &h->d.ctl->disp2[1], sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) { mdx_set_error("HIP error in minimiser"); return done(MDX_EDEVICE); }
         if (flag > thr) h->list_valid = false;     // moved more than skin/2 since the last rebuild
-        h->forces_valid = false;
+        h->forces_valid = false; h->moved_outside = true;
         if (h->n_groups) {                           // keep constrained bonds at their length
             if (!h->list_valid) { rc = mdx_rebuild(h); if (rc != MDX_OK) return done(rc); }
             rc = mdx_launch_constrain_positions(h, 0.f, nullptr, nullptr, 0);

@@ -235,6 +235,8 @@ struct mdx_handle {
     float inner_skin_auto = 0.f; bool dual_auto_off = false; uint32_t dual_win_steps = 0, dual_win_prunes = 0;
     bool prune_pending = true;   // the next step-loop force call must prune (after a rebuild / at the start of mdx_step)
     bool prune_latch = false;    // ... latched for the (up to two) launches of that force call
+    bool moved_outside = true;   // something other than the step loop moved atoms in slot space (minimiser, constraint projection):
+                                 // the path accumulators did not see it, the next mdx_step starts with a pruning pass
     uint32_t n_interior = 0;     // decomposed handle: tiles whose lists involve no ghost (0: no split)
     bool tile_split = false;     // tile_order / n_interior describe the current list
     bool want_tile_split = false; uint32_t cap_tile_split = 0;   // set by the decomposition (world > 1, overlap on)
