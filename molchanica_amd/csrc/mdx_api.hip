@@ -15,6 +15,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <unordered_map>
 
 static thread_local std::string g_last_error;
 void mdx_set_error(const std::string& s) { g_last_error = s; }
@@ -141,7 +142,7 @@ static void free_device(mdx_handle* h) {
                     d.cell_count, d.cell_start, d.cell_cursor, d.sorted_orig, d.col_tiles, d.tile_start,
                     d.tile_col, d.scan_tmp, d.cl_lo, d.cl_hi, d.list_counts, d.entry_cnt, d.entry_off,
                     d.mchunk_cnt, d.mchunk_off, d.entries, d.entries_in, d.inner_nch, d.list_cursors, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
-                    d.role_off_s, d.role_rec_s, d.ctl, d.energy,
+                    d.role_off_s, d.role_rec_s, d.role_prm, d.ctl, d.energy,
                     d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.pme_force, d.cons_o, d.cons_s, d.cons_vir, d.vsite_o, d.vsite_s, d.pme_q, d.pme_f,
                     d.pme_theta, d.pme_q2, d.pme_f2, d.scratch4, d.tile_bnd, d.tile_scan, d.tile_order};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -259,13 +260,26 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
         const uint32_t R = cnt[N];
         std::vector<RoleRec> recs(R);
         std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
+        // distinct parameter sets (by bit pattern, per term kind): the records carry an index
+        std::vector<float4> prm_tab;
+        struct PKey { uint32_t k, a, b, c; bool operator==(const PKey& o) const { return k == o.k && a == o.a && b == o.b && c == o.c; } };
+        struct PHash { size_t operator()(const PKey& x) const { uint64_t h = x.k * 0x9E3779B97F4A7C15ull; h = (h ^ x.a) * 0xBF58476D1CE4E5B9ull; h = (h ^ x.b) * 0x94D049BB133111EBull; h = (h ^ x.c) * 0x9E3779B97F4A7C15ull; return (size_t)(h ^ (h >> 29)); } };
+        std::unordered_map<PKey, uint32_t, PHash> prm_index;
+        bool prm_overflow = false;
         auto add_term = [&](const uint32_t* at, int w, uint32_t kind, float p0, float p1, float p2) {
+            const PKey key{kind, f2u(p0), f2u(p1), f2u(p2)};
+            auto it = prm_index.find(key);
+            uint32_t pi;
+            if (it == prm_index.end()) {
+                pi = (uint32_t)prm_tab.size();
+                if (pi >= (1u << 24)) { prm_overflow = true; pi = 0; }
+                else { prm_index.emplace(key, pi); prm_tab.push_back(make_float4(p0, p1, p2, 0.f)); }
+            } else pi = it->second;
             for (int r = 0; r < w; ++r) {
                 RoleRec rec{};
                 int q = 0;
                 for (int k = 0; k < w; ++k) if (k != r) rec.p[q++] = at[k];
-                rec.meta = kind | ((uint32_t)r << 4);
-                rec.prm[0] = p0; rec.prm[1] = p1; rec.prm[2] = p2; rec.prm[3] = 0.f;
+                rec.meta = kind | ((uint32_t)r << 4) | (pi << 8);
                 recs[cur[at[r]]++] = rec;
             }
         };
@@ -294,6 +308,8 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
                         add_term(at, 2, ROLE_EWALD_EXCL, c->coulomb_k * q[i] * q[j], 0.f, 0.f);
                     }
         h->n_roles = R;
+        if (prm_overflow) FAIL(MDX_EPARAM, "more than 16.7 M distinct bonded parameter sets");
+        MDX_TRY(upload_vec(&d.role_prm, prm_tab, st));
         MDX_TRY(upload_vec(&d.role_off_o, cnt, st)); MDX_TRY(upload_vec(&d.role_rec_o, recs, st));
         MDX_TRY(alloc_n(&d.role_rec_s, R));
         HIP_TRY(hipStreamSynchronize(st));

@@ -6,21 +6,21 @@
 //   dihedral E = (barrier_height/divider) [1 + cos(periodicity*phi - phase)]   :474-511
 //
 // Atom-owned gather, no atomics: one lane per slot walks the atom's own list of "roles" (one
-// 32-byte record per (term, atom-of-that-term): the partner slots, the term kind, the atom's
-// position in the term, the parameters), recomputes each term it belongs to and keeps only the
+// 16-byte record per (term, atom-of-that-term): the partner slots, the term kind, the atom's
+// position in the term, the index of its parameter set), recomputes each term it belongs to and keeps only the
 // force on itself.  A bond is evaluated twice, an angle three times, a dihedral four times — the
 // arithmetic is free next to the memory traffic — and in exchange every force component has a
 // single writer: f[slot] += sum is a plain read-modify-write, the result is bitwise reproducible,
 // and the 7 M contended f32 atomics per step of a term-per-lane scatter (0.35 ms on the 1 M-atom
 // water box, 20x the streaming time) are gone.  Role lists live in slot space and are rebuilt at
 // every neighbour rebuild, so a lane's records are contiguous and its partners sit in the same
-// or an adjacent tile (L1/L2 hits).  HBM-bound: ~36 + 32 r B per atom-step, r = roles per atom
+// or an adjacent tile (L1/L2 hits).  HBM-bound: ~36 + 16 r B per atom-step, r = roles per atom
 // (2.33 for water).
 #include "mdx_bonded_dev.h"
 
 struct BondedArgs {
     uint32_t S;
-    const uint32_t* role_off; const RoleRec* roles;
+    const uint32_t* role_off; const RoleRec* roles; const float4* prm;
     const float4* posq; float4* force; double* energy;
     BondedParams p;
     const uint32_t* gate; uint32_t thr_bits;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void bonded_gather_kernel(BondedArgs a) {
             float fx = 0.f, fy = 0.f, fz = 0.f;
             for (uint32_t k = rb + q4; k < re; k += BONDED_LPA) {
                 const RoleRec r = a.roles[k];
-                role_eval<ENERGY>(r, self, a.posq, a.p, fx, fy, fz, en);
+                role_eval<ENERGY>(r, a.prm, self, a.posq, a.p, fx, fy, fz, en);
             }
             fx = quad_xadd<0xB1>(fx); fy = quad_xadd<0xB1>(fy); fz = quad_xadd<0xB1>(fz);   // lane ^ 1
             fx = quad_xadd<0x4E>(fx); fy = quad_xadd<0x4E>(fy); fz = quad_xadd<0x4E>(fz);   // lane ^ 2
@@ -98,7 +98,7 @@ int mdx_launch_bonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32
     if (skip_bonded && !h->pme_on) return MDX_OK;
     if (!h->n_roles) return MDX_OK;
     BondedArgs a{};
-    a.S = h->S; a.role_off = h->d.role_off_s; a.roles = h->d.role_rec_s;
+    a.S = h->S; a.role_off = h->d.role_off_s; a.roles = h->d.role_rec_s; a.prm = h->d.role_prm;
     a.posq = h->d.posq; a.force = h->d.force; a.energy = h->d.energy; a.gate = d_gate; a.thr_bits = thr_bits;
     for (int d = 0; d < 3; ++d) {
         a.p.box[d] = h->per[d] ? (h->box_hi[d] - h->box_lo[d]) : 0.f;

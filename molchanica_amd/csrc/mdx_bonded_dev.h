@@ -23,8 +23,11 @@ struct RoleEnergies { double bond = 0.0, angle = 0.0, dih = 0.0, lj14 = 0.0, c14
 // Adds to (fx, fy, fz) the force of role `r` on its own atom (position `self`).  ENERGY: the term's energy and
 // virial are credited once, by the atom in role 0.
 template <bool ENERGY>
-__device__ __forceinline__ void role_eval(const RoleRec& r, const float4 self, const float4* __restrict__ posq,
+__device__ __forceinline__ void role_eval(const RoleRec& r, const float4* __restrict__ prm_tab, const float4 self,
+                                          const float4* __restrict__ posq,
                                           const BondedParams& p, float& fx, float& fy, float& fz, RoleEnergies& en) {
+    const float4 prm4 = prm_tab[r.meta >> 8];
+    const float prm[3] = {prm4.x, prm4.y, prm4.z};
     double& e_bond = en.bond; double& e_angle = en.angle; double& e_dih = en.dih; double& e_lj14 = en.lj14;
     double& e_c14 = en.c14; double& e_rec = en.rec; double& e_vir = en.vir;
     const uint32_t kind = r.meta & 0xFu, role = (r.meta >> 4) & 0xFu;
@@ -33,9 +36,9 @@ __device__ __forceinline__ void role_eval(const RoleRec& r, const float4 self, c
         const float3 d = mimg(sub3(self, posq[r.p[0]]), p);
         const float r2 = dot3(d, d), rinv = rsqrtf(r2), rr = r2 * rinv, br = p.ewald_beta * rr;
         const float er = erff(br);
-        const float fs = -r.prm[0] * (er * rinv - 1.1283791671f * p.ewald_beta * __expf(-br * br)) * rinv * rinv;
+        const float fs = -prm[0] * (er * rinv - 1.1283791671f * p.ewald_beta * __expf(-br * br)) * rinv * rinv;
         fx += fs * d.x; fy += fs * d.y; fz += fs * d.z;
-        if (ENERGY && role == 0) { e_rec -= (double)(r.prm[0] * er * rinv); e_vir += (double)(fs * r2); }
+        if (ENERGY && role == 0) { e_rec -= (double)(prm[0] * er * rinv); e_vir += (double)(fs * r2); }
         return;
     }
     if (p.skip_bonded) return;
@@ -44,16 +47,16 @@ __device__ __forceinline__ void role_eval(const RoleRec& r, const float4 self, c
         const float r2 = dot3(d, d);
         float fs;
         if (kind == ROLE_BOND) {
-            const float rr = sqrtf(r2), dr = rr - r.prm[1];
-            fs = -2.0f * r.prm[0] * dr / rr;
-            if (ENERGY && role == 0) e_bond += (double)r.prm[0] * dr * dr;
+            const float rr = sqrtf(r2), dr = rr - prm[1];
+            fs = -2.0f * prm[0] * dr / rr;
+            if (ENERGY && role == 0) e_bond += (double)prm[0] * dr * dr;
         } else {   // prm: sigma_ij, 4*scale*eps_ij, scale*ke*qi*qj
             const float rinv = rsqrtf(r2), rinv2 = rinv * rinv;
-            const float s2 = r.prm[0] * r.prm[0] * rinv2, s6 = s2 * s2 * s2;
-            fs = (6.0f * r.prm[1] * s6 * (2.0f * s6 - 1.0f) + r.prm[2] * rinv) * rinv2;
+            const float s2 = prm[0] * prm[0] * rinv2, s6 = s2 * s2 * s2;
+            fs = (6.0f * prm[1] * s6 * (2.0f * s6 - 1.0f) + prm[2] * rinv) * rinv2;
             if (ENERGY && role == 0) {
-                e_lj14 += (double)(r.prm[1] * s6 * (s6 - 1.0f));
-                e_c14 += (double)(r.prm[2] * rinv);
+                e_lj14 += (double)(prm[1] * s6 * (s6 - 1.0f));
+                e_c14 += (double)(prm[2] * rinv);
             }
         }
         fx += fs * d.x; fy += fs * d.y; fz += fs * d.z;
@@ -70,9 +73,9 @@ __device__ __forceinline__ void role_eval(const RoleRec& r, const float4 self, c
         const float ir1 = rsqrtf(dot3(v1, v1)), ir2 = rsqrtf(dot3(v2, v2));
         float cs = dot3(v1, v2) * ir1 * ir2;
         cs = fminf(1.0f, fmaxf(-1.0f, cs));
-        const float th = acosf(cs), dth = th - r.prm[1];
+        const float th = acosf(cs), dth = th - prm[1];
         const float sn = fmaxf(sqrtf(1.0f - cs * cs), 1e-6f);
-        const float de = 2.0f * r.prm[0] * dth;   // dE/dtheta
+        const float de = 2.0f * prm[0] * dth;   // dE/dtheta
         // dtheta/dr_i = -(v2/|v2| - cos v1/|v1|) / (|v1| sin)
         const float ci = de * ir1 / sn, ck = de * ir2 / sn;
         const float3 u1 = scale3(v1, ir1), u2 = scale3(v2, ir2);
@@ -81,7 +84,7 @@ __device__ __forceinline__ void role_eval(const RoleRec& r, const float4 self, c
         if (role == 0) { fx += fi.x; fy += fi.y; fz += fi.z; }
         else if (role == 2) { fx += fk.x; fy += fk.y; fz += fk.z; }
         else { fx -= fi.x + fk.x; fy -= fi.y + fk.y; fz -= fi.z + fk.z; }
-        if (ENERGY && role == 0) e_angle += (double)r.prm[0] * dth * dth;
+        if (ENERGY && role == 0) e_angle += (double)prm[0] * dth * dth;
     } else {   // ROLE_DIHEDRAL: ordered atoms 0-1-2-3, this lane is atom `role`
         const float4 q0 = posq[r.p[0]], q1 = posq[r.p[1]], q2 = posq[r.p[2]];
         const float4 p0 = role == 0 ? self : q0;
@@ -98,8 +101,8 @@ __device__ __forceinline__ void role_eval(const RoleRec& r, const float4 self, c
             const float sinphi = dot3(cross3(B, A), G) * iGn;
             const float phi = atan2f(sinphi, cosphi);
             float sn, cn;
-            sincosf(r.prm[2] * phi - r.prm[1], &sn, &cn);
-            const float de = -r.prm[0] * r.prm[2] * sn;   // dE/dphi
+            sincosf(prm[2] * phi - prm[1], &sn, &cn);
+            const float de = -prm[0] * prm[2] * sn;   // dE/dphi
             const float iA2 = 1.0f / A2, iB2 = 1.0f / B2;
             const float FG = dot3(F, G), HG = dot3(H, G);
             const float ca = -Gn * iA2, cb = Gn * iB2;
@@ -113,7 +116,7 @@ __device__ __forceinline__ void role_eval(const RoleRec& r, const float4 self, c
             fx -= de * (wa * A.x + wb * B.x);
             fy -= de * (wa * A.y + wb * B.y);
             fz -= de * (wa * A.z + wb * B.z);
-            if (ENERGY && role == 0) e_dih += (double)r.prm[0] * (1.0 + (double)cn);
+            if (ENERGY && role == 0) e_dih += (double)prm[0] * (1.0 + (double)cn);
         }
     }
 }

@@ -89,11 +89,13 @@ struct StepCtl {
 
 // One (term, atom-of-that-term) record of the atom-owned bonded gather (mdx_bonded.hip).
 enum { ROLE_BOND = 0, ROLE_ANGLE = 1, ROLE_DIHEDRAL = 2, ROLE_PAIR14 = 3, ROLE_EWALD_EXCL = 4 };
+// 16 bytes: the parameters live in a table of DISTINCT parameter sets (role_prm: a force field has a few hundred; the
+// two of a water box sit in L1), which halves the record stream the gather reads - 2.33 roles per water atom.
 struct __attribute__((aligned(16))) RoleRec {
     uint32_t p[3];   // the term's other atoms, in term order (caller index in *_o, slot in *_s)
-    uint32_t meta;   // kind | role << 4  (role = this atom's position in the term)
-    float prm[4];    // bond: k, r0 | angle: k, theta0 | dihedral: v, phase, n | 1-4: sigma, 4 s eps, s ke qq
+    uint32_t meta;   // kind | role << 4 | parameter-set index << 8   (role = this atom's position in the term)
 };
+// role_prm[index] (float4): bond: k, r0 | angle: k, theta0 | dihedral: v, phase, n | 1-4: sigma, 4 s eps, s ke qq | Ewald exclusion: ke qq
 
 // A cluster of atoms tied by distance constraints (rigid water: 3 atoms / 3 constraints; X-H3: 4 / 3).
 struct __attribute__((aligned(16))) ConsGroup {
@@ -162,6 +164,7 @@ struct DeviceState {
     uint32_t* role_off_o = nullptr; RoleRec* role_rec_o = nullptr;   // [N+1], [R]
     uint32_t* role_cnt_s = nullptr; uint32_t* role_off_s = nullptr;  // [S+1]
     RoleRec*  role_rec_s = nullptr;                                  // [R]
+    float4*   role_prm = nullptr;                                    // distinct parameter sets of the bonded terms
     // SPME (mdx_pme.hip)
     float* pme_q = nullptr; float2* pme_f = nullptr; float* pme_theta = nullptr;
     float* pme_q2 = nullptr; float2* pme_f2 = nullptr;   // alchemical window: the coupled molecule's own mesh
