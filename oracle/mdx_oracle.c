@@ -8,7 +8,14 @@
  * which is absent from /root/reference and cannot be built here (no Rust toolchain), and the
  * reference holds no test or golden vector on this path (src/tests.rs:3-4 is empty).  This
  * restatement is therefore pinned by analytic known-answer tests and self-consistency checks
- * (tests/test_oracle_*.py), not by the reference binary.
+ * (tests/test_oracle_*.py), not by the reference binary - with ONE exception: the pair formulas the
+ * tree itself states in native code.  The reference's own CUDA kernels (src/cuda/cuda.cu + util.cu:
+ * lj_force_kernel, coulomb_force_kernel, lj_V_kernel, min_image) compile with hipcc as they lie into
+ * oracle/_ref/libref_cuda.so (oracle/Makefile target `ref`), run on the MI355X, and this file's LJ
+ * 12-6 force / energy, tgt - src direction, Coulomb form with softening and rint minimum image must
+ * reproduce them (tests/test_gpu_reference_kernels.py).  Everything the absent crate decides alone -
+ * combining rule, 1-4 scaling, k_e, Coulomb treatment at the cutoff, bonded conventions, integrator
+ * order - stays unpinned.
  *
  * What it follows in the reference tree (paths relative to /root/reference):
  *   - LJ 12-6 force/energy form and the `tgt - src` direction convention: src/cuda/util.cu:92-140

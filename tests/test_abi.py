@@ -115,3 +115,16 @@ def test_product_package_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"(import\s+oracle|from\s+oracle|oracle[/.]|liborc|orc_)", txt), \
                     f"{f} reaches into the oracle"
+
+
+def test_reference_kernels_build_from_where_they_lie():
+    """oracle/_ref: the reference's own CUDA pair kernels compiled by hipcc from /root/reference (only where that tree exists)."""
+    from oracle import ref_kernels
+    if not os.path.isdir(ref_kernels.REFERENCE):
+        pytest.skip("no reference tree on this machine: the prebuilt oracle/_ref/libref_cuda.so is what travels")
+    assert ref_kernels.build() is not None
+    l = C.CDLL(ref_kernels.PATH)
+    for name in ("ref_lj_force", "ref_coulomb_force", "ref_lj_V", "ref_min_image"):
+        assert hasattr(l, name)
+    txt = open(os.path.join(ROOT, "oracle", "ref_cuda_host.hip")).read()
+    assert '#include "cuda.cu"' in txt and "__global__ void lj_force_kernel" not in txt, "the reference's kernels are included, never copied"
