@@ -21,7 +21,8 @@ def ref():
     from oracle import ref_kernels
     if not ref_kernels.available():
         ref_kernels.build()
-    assert ref_kernels.available(), "oracle/_ref/libref_cuda.so is missing: build it where /root/reference exists (make -C oracle ref)"
+    if not ref_kernels.available():      # a checkout without the prebuilt object on a machine without the reference tree
+        pytest.skip("oracle/_ref/libref_cuda.so is not here and /root/reference is not either: build it in the build container (make -C oracle ref)")
     return ref_kernels
 
 
