@@ -1067,7 +1067,8 @@ int mdx_rebuild(mdx_handle* h) {
     hipLaunchKernelGGL(build_list_kernel<LB_FILL>, dim3(div_up(T, LB_WAVES)), dim3(LB_WAVES * 64), 0, st, a);
     }
     const bool prune = !std::isinf(h->r_list) && mdx_nb_variant(h) >= 2;   // the whole-tile kernel ignores imask
-    if (prune && T) {
+    static const bool exact_prune = [] { const char* e = std::getenv("MDX_EXACT_PRUNE"); return !(e && e[0] == '0'); }();   // A/B knob
+    if (prune && T && exact_prune) {
         const float rb = a.r_build;
         hipLaunchKernelGGL(prune_list_kernel, dim3(div_up(T, 4)), dim3(256), 0, st, T, rb * rb,
                            h->per[0] ? h->box_hi[0] - h->box_lo[0] : 0.f, h->per[1] ? h->box_hi[1] - h->box_lo[1] : 0.f,
@@ -1087,9 +1088,9 @@ int mdx_rebuild(mdx_handle* h) {
     HIP_TRY(hipGetLastError());
     unsigned long long npairs_pruned = 0;
     HIP_TRY(hipMemcpyAsync(flags, d.flags_dev, sizeof(flags), hipMemcpyDeviceToHost, st));
-    if (prune) HIP_TRY(hipMemcpyAsync(&npairs_pruned, d.pair_count + 1, sizeof(npairs_pruned), hipMemcpyDeviceToHost, st));
+    if (prune && exact_prune) HIP_TRY(hipMemcpyAsync(&npairs_pruned, d.pair_count + 1, sizeof(npairs_pruned), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (prune) npairs = npairs_pruned;
+    if (prune && exact_prune) npairs = npairs_pruned;
     if (flags[0] & 8u) { mdx_set_error("a constrained / virtual-site atom is missing from the local atom set"); return MDX_EPARAM; }
     if (flags[0] & 3u) { mdx_set_error("exclusion table overflow while building the pair list"); return MDX_EPARAM; }
     if (flags[0] & 4u) {

@@ -41,8 +41,10 @@ for world in worlds:
             k_i = st["integ_ms_sum"] / max(st["integ_launches"], 1)
             rebuilds = st1["rebuild_count"] - st0["rebuild_count"]
             print("world %d rank 0 (interior/boundary split %s): owned %d ghost %d tiles %d | pair %.3f ms bonded %.3f integrate %.3f = %.3f ms of kernels | "
-                  "step wall %.3f ms (%d list rebuilds in %d steps at %.2f ms, %d repartitions at %.2f ms incl. their rebuild: %.3f ms per step amortised) -> ceiling %.0f steps/s without wire time | cluster pairs verlet %.1f M inner %.1f M" % (
+                  "step wall %.3f ms (%d list rebuilds in %d steps at %.2f ms, %d repartitions at %.2f ms incl. their rebuild: %.3f ms per step amortised; %.3f ms of the wall is in neither kernels nor list builds) -> ceiling %.0f steps/s without wire time | cluster pairs verlet %.1f M inner %.1f M" % (
                       world, {"1": "on", "0": "off"}.get(overlap, "auto-tuned"), st["n_owned"], st["n_ghost"], st["n_tiles"], k_nb, k_b, k_i, k_nb + k_b + k_i,
                       1e3 * el / steps, rebuilds, steps, rb_ms, st1["repartitions"] - st0["repartitions"], rp_ms,
-                      (rebuilds * rb_ms + (st1["repartitions"] - st0["repartitions"]) * max(rp_ms - rb_ms, 0.0)) / steps, steps / el,
+                      (rebuilds * rb_ms + (st1["repartitions"] - st0["repartitions"]) * max(rp_ms - rb_ms, 0.0)) / steps,
+                      1e3 * el / steps - (k_nb + k_b + k_i) - (rebuilds * rb_ms + (st1["repartitions"] - st0["repartitions"]) * max(rp_ms - rb_ms, 0.0)) / steps,
+                      steps / el,
                       st["n_cluster_pairs"] / 1e6, st["n_inner_cluster_pairs"] / 1e6), flush=True)
