@@ -366,6 +366,10 @@ int mdx_dd_gather_global(mdx_handle* h, bool with_force) {
     hipLaunchKernelGGL(dd_gather_scatter_kernel, dim3(div_up(N, 256)), dim3(256), 0, st, N, R, dd->gat_recv, dd->g_pos, dd->g_vel, dd->g_frc, N,
                        h->d.flags_dev);
     HIP_TRY(hipGetLastError());
+    uint32_t err[4];
+    HIP_TRY(hipMemcpyAsync(err, h->d.flags_dev, sizeof(err), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (err[0] & 2u) FAIL(MDX_EDEVICE, "decomposition: a gathered row carries an atom id outside the system (corrupted message)");
     return MDX_OK;
 }
 
