@@ -138,10 +138,20 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    # Verification aid for 1-GPU boxes: MDX_BENCH_SAME_GPU=1 maps every rank to device 0, uses gloo for the launcher's process
+    # group and the library's shared-memory transport instead of RCCL (which refuses two ranks on one device), so the
+    # complete process-per-rank flow - rendezvous, broadcast of the prepared state, mdx_comm_init*, the decomposed step loop
+    # with its halo exchange, repartition, energy reduction, the JSON line - runs on real kernels.  Never a measurement.
+    same_gpu = os.environ.get("MDX_BENCH_SAME_GPU", "0") == "1"
+    if same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if same_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from molchanica_amd import MdConfig, systems
     from molchanica_amd.md_state import MdState
@@ -173,7 +183,9 @@ def main():
             pos_eq = np.zeros((n_atoms, 3), np.float32); vel_eq = np.zeros((n_atoms, 3), np.float32)
             e_eq = {"temperature": 0.0}
         if world > 1:
-            tp = torch.from_numpy(np.ascontiguousarray(pos_eq)).cuda(); tv = torch.from_numpy(np.ascontiguousarray(vel_eq)).cuda()
+            tp = torch.from_numpy(np.ascontiguousarray(pos_eq)); tv = torch.from_numpy(np.ascontiguousarray(vel_eq))
+            if not same_gpu:
+                tp, tv = tp.cuda(), tv.cuda()
             dist.broadcast(tp, 0); dist.broadcast(tv, 0)
             pos_eq, vel_eq = tp.cpu().numpy(), tv.cpu().numpy()
         system.pos = np.ascontiguousarray(pos_eq, dtype=np.float32)
@@ -195,10 +207,13 @@ def main():
         if rank == 0:
             uid = torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8).clone()
         if world > 1:
-            uid = uid.cuda()
+            uid = uid if same_gpu else uid.cuda()
             dist.broadcast(uid, 0)
             uid = uid.cpu()
-        md.comm_init(bytes(uid.numpy().tobytes()), rank, world)
+        if same_gpu and world > 1:
+            md.comm_init_shm("bench_" + bytes(uid.numpy().tobytes())[:8].hex(), rank, world)
+        else:
+            md.comm_init(bytes(uid.numpy().tobytes()), rank, world)
         info = md.comm_info()
         g = info["grid"]
         parallelism = (f"spatial {g[0]}x{g[1]}x{g[2]} bricks, ghost halo {info['halo']:.1f} A, ncclSend/ncclRecv group per step on a "
@@ -225,7 +240,7 @@ def main():
 
     def max_over_ranks(x):
         if world > 1:
-            t = torch.tensor([x], dtype=torch.float64, device="cuda")
+            t = torch.tensor([x], dtype=torch.float64, device="cpu" if same_gpu else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
         return x

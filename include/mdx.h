@@ -405,6 +405,10 @@ mdx_fabric* mdx_fabric_create(int world);
 void mdx_fabric_destroy(mdx_fabric* f);
 void mdx_fabric_abort(mdx_fabric* f);          /* a rank failed: release everybody who waits for it */
 int mdx_comm_init_fabric(mdx_handle* h, mdx_fabric* f, int rank);
+/* The same decomposition between PROCESSES of one host without RCCL: rows are staged through a POSIX shared-memory segment
+ * `/mdx_<name>` (every rank passes the same name; rank 0 creates it; slots of MDX_SHM_SLOT_MB = 64 MiB per rank).  Not a
+ * performance path - it runs the process-per-rank flow on a box whose single GPU RCCL will not share between two ranks. */
+int mdx_comm_init_shm(mdx_handle* h, const char* name, int rank, int world);
 /* Rank `rank` of `world` with a transport that delivers nothing: what ONE rank of a decomposition costs per step,
  * measured alone on a single GPU (tools/one_rank_profile.py). */
 int mdx_comm_init_null(mdx_handle* h, int rank, int world);

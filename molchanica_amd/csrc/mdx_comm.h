@@ -32,6 +32,7 @@ struct MdxTransport {
 struct mdx_fabric;   // the in-process transport's meeting point (C ABI: mdx_fabric_create / _destroy)
 MdxTransport* mdx_make_rccl_transport(const uint8_t* id128, int rank, int world, int device);    // nullptr + error text on failure
 MdxTransport* mdx_make_fabric_transport(mdx_fabric* f, int rank);
+MdxTransport* mdx_make_shm_transport(const char* name, int rank, int world);   // processes of one host, rows staged through POSIX shared memory
 MdxTransport* mdx_make_null_transport(int rank, int world);   // delivers nothing: one rank of N profiled alone (tools/one_rank_profile.py)
 
 // ---- decomposition state of one handle -------------------------------------------------------------------------

@@ -14,6 +14,13 @@
 // The reference has no multi-device code at all (/root/reference src/util.rs:1086: CudaContext::new(0)).
 #include "mdx_comm.h"
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -248,6 +255,132 @@ struct NullTransport : MdxTransport {
 };
 }  // namespace
 
+// ---- shared-memory transport: ranks are PROCESSES of one host, data is staged through a POSIX shm segment -------------
+// Not a performance path (every row crosses the host twice): it lets the complete multi-process flow - one process per
+// rank, as the driver launches bench.py - run on a box with ONE GPU, where RCCL refuses two ranks per device, and serves
+// hosts without RCCL.  Same interface, same call sequence.
+namespace {
+struct ShmHeader {
+    std::atomic<uint32_t> arrived; std::atomic<uint32_t> generation; std::atomic<uint32_t> aborted; uint32_t world;
+    uint64_t slot_bytes;
+};
+struct ShmSegEntry { int32_t peer; uint32_t nrows; uint64_t offset; };
+struct ShmSlotHead { uint32_t n_entries; uint32_t word; ShmSegEntry e[64]; };
+
+struct ShmTransport : MdxTransport {
+    std::string shm_name; int fd = -1; unsigned char* base = nullptr; size_t total = 0; ShmHeader* hd = nullptr; uint64_t slot_bytes = 0;
+    ~ShmTransport() override {
+        if (base) munmap(base, total);
+        if (fd >= 0) close(fd);
+        if (rank == 0 && !shm_name.empty()) shm_unlink(shm_name.c_str());
+    }
+    const char* name() const override { return "shared memory (host-staged)"; }
+    unsigned char* slot(int q) const { return base + 4096 + (size_t)q * slot_bytes; }
+    int fail(const char* why) { if (hd) hd->aborted.store(1); mdx_set_error(std::string("shared-memory transport: ") + why); return MDX_EDEVICE; }
+    bool barrier() {
+        const uint32_t gen = hd->generation.load();
+        if (hd->arrived.fetch_add(1) + 1 == (uint32_t)world) { hd->arrived.store(0); hd->generation.fetch_add(1); return !hd->aborted.load(); }
+        const auto t0 = std::chrono::steady_clock::now();
+        while (hd->generation.load() == gen) {
+            if (hd->aborted.load()) return false;
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { hd->aborted.store(1); return false; }
+            std::this_thread::yield();
+        }
+        return !hd->aborted.load();
+    }
+    int exchange(const float4* send, const std::vector<MdxSeg>& ssegs, float4* recv, const std::vector<MdxSeg>& rsegs, hipStream_t stream) override {
+        ShmSlotHead* mine = (ShmSlotHead*)slot(rank);
+        if (ssegs.size() > 64) return fail("too many segments");
+        uint64_t off = sizeof(ShmSlotHead);
+        mine->n_entries = (uint32_t)ssegs.size();
+        for (size_t k = 0; k < ssegs.size(); ++k) {
+            const uint64_t bytes = (uint64_t)ssegs[k].nrows * sizeof(float4);
+            if (off + bytes > slot_bytes) return fail("message larger than the shared-memory slot (MDX_SHM_SLOT_MB)");
+            mine->e[k] = {ssegs[k].peer, ssegs[k].nrows, off};
+            if (bytes && hipMemcpyAsync(slot(rank) + off, send + ssegs[k].row0, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return fail("copy failed");
+            off += bytes;
+        }
+        if (hipStreamSynchronize(stream) != hipSuccess) return fail("sync failed");
+        if (!barrier()) return fail("a rank failed or timed out");
+        for (const MdxSeg& r : rsegs) {
+            if (!r.nrows) continue;
+            const ShmSlotHead* ph = (const ShmSlotHead*)slot(r.peer);
+            const ShmSegEntry* src = nullptr;
+            for (uint32_t k = 0; k < ph->n_entries; ++k) if (ph->e[k].peer == rank) { src = &ph->e[k]; break; }
+            if (!src || src->nrows != r.nrows) return fail("send / receive segment mismatch");
+            if (hipMemcpyAsync(recv + r.row0, slot(r.peer) + src->offset, (size_t)r.nrows * sizeof(float4), hipMemcpyHostToDevice, stream) != hipSuccess) return fail("copy failed");
+        }
+        if (hipStreamSynchronize(stream) != hipSuccess) return fail("sync failed");
+        if (!barrier()) return fail("a rank failed or timed out");
+        return MDX_OK;
+    }
+    template <typename T, typename F>
+    int reduce_impl(T* dev, size_t n, hipStream_t stream, F op) {
+        const size_t bytes = n * sizeof(T);
+        if (sizeof(ShmSlotHead) + bytes > slot_bytes) return fail("array larger than the shared-memory slot (MDX_SHM_SLOT_MB)");
+        T* mine = (T*)(slot(rank) + sizeof(ShmSlotHead));
+        if (hipMemcpyAsync(mine, dev, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return fail("copy failed");
+        if (!barrier()) return fail("a rank failed or timed out");
+        std::vector<T> out(n);
+        for (size_t i = 0; i < n; ++i) {
+            T a = ((const T*)(slot(0) + sizeof(ShmSlotHead)))[i];
+            for (int q = 1; q < world; ++q) a = op(a, ((const T*)(slot(q) + sizeof(ShmSlotHead)))[i]);     // rank order: same bits everywhere
+            out[i] = a;
+        }
+        if (!barrier()) return fail("a rank failed or timed out");
+        if (hipMemcpyAsync(dev, out.data(), bytes, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return fail("copy failed");
+        return MDX_OK;
+    }
+    int all_reduce(void* dev, size_t n, int kind, hipStream_t stream) override {
+        if (kind == 0) return reduce_impl((double*)dev, n, stream, [](double a, double b) { return a + b; });
+        return reduce_impl((uint32_t*)dev, n, stream, [](uint32_t a, uint32_t b) { return std::max(a, b); });
+    }
+    int all_reduce_f32(float* dev, size_t n, hipStream_t stream) override { return reduce_impl(dev, n, stream, [](float a, float b) { return a + b; }); }
+    int all_gather_u32(uint32_t mine, uint32_t* all, hipStream_t) override {
+        ((ShmSlotHead*)slot(rank))->word = mine;
+        if (!barrier()) return fail("a rank failed or timed out");
+        for (int q = 0; q < world; ++q) all[q] = ((const ShmSlotHead*)slot(q))->word;
+        if (!barrier()) return fail("a rank failed or timed out");
+        return MDX_OK;
+    }
+};
+}  // namespace
+
+MdxTransport* mdx_make_shm_transport(const char* name, int rank, int world) {
+    ShmTransport* t = new ShmTransport();
+    t->rank = rank; t->world = world; t->shm_name = std::string("/mdx_") + name;
+    size_t slot_mb = 64;
+    if (const char* e = std::getenv("MDX_SHM_SLOT_MB")) slot_mb = (size_t)std::max(1, std::atoi(e));
+    t->slot_bytes = slot_mb << 20;
+    t->total = 4096 + (size_t)world * t->slot_bytes;
+    // rank 0 creates and sizes the segment, the others wait for it to appear at full size
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        t->fd = shm_open(t->shm_name.c_str(), rank == 0 ? (O_CREAT | O_RDWR) : O_RDWR, 0600);
+        if (t->fd >= 0) {
+            if (rank == 0) { if (ftruncate(t->fd, (off_t)t->total) != 0) { mdx_set_error("shared-memory transport: ftruncate failed"); delete t; return nullptr; } break; }
+            struct stat st;
+            if (fstat(t->fd, &st) == 0 && (size_t)st.st_size >= t->total) break;
+            close(t->fd); t->fd = -1;
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) { mdx_set_error("shared-memory transport: the segment never appeared"); delete t; return nullptr; }
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+    }
+    void* m = mmap(nullptr, t->total, PROT_READ | PROT_WRITE, MAP_SHARED, t->fd, 0);
+    if (m == MAP_FAILED) { mdx_set_error("shared-memory transport: mmap failed"); delete t; return nullptr; }
+    t->base = (unsigned char*)m; t->hd = (ShmHeader*)m;
+    if (rank == 0) { t->hd->arrived.store(0); t->hd->generation.store(0); t->hd->aborted.store(0); t->hd->slot_bytes = t->slot_bytes; t->hd->world = (uint32_t)world; }
+    else {
+        const auto t1 = std::chrono::steady_clock::now();
+        while (t->hd->world != (uint32_t)world) {      // rank 0 has not initialised the header yet
+            if (std::chrono::steady_clock::now() - t1 > std::chrono::seconds(60)) { mdx_set_error("shared-memory transport: header never initialised"); delete t; return nullptr; }
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+    }
+    if (!t->barrier()) { mdx_set_error("shared-memory transport: rendezvous failed"); delete t; return nullptr; }
+    return t;
+}
+
 MdxTransport* mdx_make_fabric_transport(mdx_fabric* f, int rank) {
     if (!f || rank < 0 || rank >= f->world) { mdx_set_error("bad fabric / rank"); return nullptr; }
     FabricTransport* t = new FabricTransport();
@@ -278,6 +411,14 @@ extern "C" int mdx_comm_init_fabric(mdx_handle* h, mdx_fabric* f, int rank) {
     const int rc = mdx_dd_attach(h, t);
     if (rc != MDX_OK) f->abort();
     return rc;
+}
+extern "C" int mdx_comm_init_shm(mdx_handle* h, const char* name, int rank, int world) {
+    if (!h || !name || !name[0]) FAIL(MDX_EPARAM, "null argument");
+    if (world < 1 || world > 32 || rank < 0 || rank >= world) FAIL(MDX_EPARAM, "rank / world out of range (world <= 32)");
+    if (h->dd) FAIL(MDX_EPARAM, "the handle is already decomposed");
+    MdxTransport* t = mdx_make_shm_transport(name, rank, world);
+    if (!t) return MDX_EDEVICE;
+    return mdx_dd_attach(h, t);
 }
 extern "C" int mdx_comm_init_null(mdx_handle* h, int rank, int world) {
     if (!h) FAIL(MDX_EPARAM, "null argument");

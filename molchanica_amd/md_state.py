@@ -133,6 +133,7 @@ def load_library():
     lib.mdx_fabric_abort.restype = None
     lib.mdx_comm_init_fabric.argtypes = [H, C.c_void_p, C.c_int]
     lib.mdx_comm_init_null.argtypes = [H, C.c_int, C.c_int]
+    lib.mdx_comm_init_shm.argtypes = [H, C.c_char_p, C.c_int, C.c_int]
     lib.mdx_comm_selftest.argtypes = [H]
     lib.mdx_comm_info.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _u32p, _u32p, _fp]
     _lib = lib
@@ -406,6 +407,10 @@ class MdState:
         """The same decomposition between handles of ONE process (one thread per rank) through an in-process fabric."""
         self._fabric = fabric            # keep it alive as long as the handle
         _check(load_library().mdx_comm_init_fabric(self._h, fabric.ptr, int(rank)))
+
+    def comm_init_shm(self, name: str, rank: int, world: int):
+        """Ranks as processes of one host, rows staged through POSIX shared memory `/mdx_<name>` (no RCCL)."""
+        _check(load_library().mdx_comm_init_shm(self._h, name.encode(), int(rank), int(world)))
 
     def comm_init_null(self, rank: int, world: int):
         """Rank `rank` of `world` with a transport that delivers nothing (one rank's cost measured alone)."""

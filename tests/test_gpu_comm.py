@@ -6,6 +6,7 @@ is the production code: device-side partition (owners, ghosts, image shifts, hal
 the communication stream, the stale flag riding on the halo message, local rebuilds vs repartition, global gathers,
 energy all-reduces, constraint clusters and virtual sites owned as a whole, one thermostat for the whole box."""
 import math
+import os
 import threading
 
 import numpy as np
@@ -297,3 +298,65 @@ def test_rccl_transport_single_rank_selftest():
         assert abs(e["potential"] - e_ref["potential"]) < 1e-2
         md.step(0.0005, None, 20)
         assert md.step_count == 20 and md.positions().shape == (s.n_atoms, 3)
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_process_per_rank_flow_on_one_gpu(n):
+    """The driver's launch line for N > 1 - `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` - with the
+    N processes mapped onto this box's one GPU (MDX_BENCH_SAME_GPU=1: gloo for the launcher's group, the library's
+    shared-memory transport instead of RCCL, which refuses two ranks per device): rendezvous, broadcast of the prepared state,
+    mdx_comm_init_shm, the decomposed step loop below the ABI with halo exchange / repartition / energy reduction across
+    PROCESSES, the tail, the JSON line."""
+    import json, os, socket, subprocess, sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MDX_BENCH_SAME_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "40", "--warmup", "8",
+           "--workload", "dna100k", "--no-cpu-baseline", "--energy-every", "20", "--tail-steps", "60"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == n and j["steps"] == 40 and j["value"] > 0 and j["scaling"] == "strong"
+    assert j["config"]["energy_evaluations_in_timed_region"] == 2 and ("2x1x1" if n == 2 else "2x2x1") in j["config"]["parallelism"]
+    assert 0 < j["config"]["n_owned_rank0"] < j["config"]["n_atoms"] and j["config"]["n_ghost_rank0"] > 0
+    assert j["tail"]["steps"] == 60 and j["tail"]["rebuilds"] >= 1 and j["config"]["repartitions"] >= 1
+
+
+def test_shared_memory_transport_matches_single_gpu():
+    """Two PROCESSES on the one GPU through the shared-memory transport: energies and a 30-step trajectory of the decomposed box
+    equal the single-handle run (the process-level twin of the thread + fabric tests above)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_shm_rank, args=(r, 2, "t%d" % os.getpid(), q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=600) for _ in ps]
+    [p.join(60) for p in ps]
+    assert all(r[1] is None for r in res), [r[1] for r in res]
+    from molchanica_amd.md_state import MdState
+    s = systems.water_box(14, seed=6)
+    with MdState(s, MdConfig(**CFG)) as md:
+        e_ref = md.energy()["potential"]
+        md.step(0.0005, None, 30)
+        p_ref = md.positions()
+    for rank, err, e0, pos in res:
+        assert abs(e0 - e_ref) < 3e-6 * abs(e_ref) + 0.05
+        assert rms_dev(pos, p_ref, np.array(s.box_hi, dtype=np.float64)) < 2e-3
+
+
+def _shm_rank(rank, world, name, q):
+    try:
+        from molchanica_amd.md_state import MdState
+        s = systems.water_box(14, seed=6)
+        with MdState(s, MdConfig(**CFG)) as md:
+            md.comm_init_shm(name, rank, world)
+            md.comm_selftest()
+            e0 = md.energy()["potential"]
+            md.step(0.0005, None, 30)
+            q.put((rank, None, e0, md.positions()))
+    except BaseException as e:   # pragma: no cover
+        q.put((rank, repr(e), None, None))
