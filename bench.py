@@ -216,8 +216,9 @@ def main():
             md.comm_init(bytes(uid.numpy().tobytes()), rank, world)
         info = md.comm_info()
         g = info["grid"]
-        parallelism = (f"spatial {g[0]}x{g[1]}x{g[2]} bricks, ghost halo {info['halo']:.1f} A, ncclSend/ncclRecv group per step on a "
-                       f"communication stream (below the C ABI), stale flag on the halo message, local list rebuilds, then repartition")
+        parallelism = (f"spatial {g[0]}x{g[1]}x{g[2]} bricks, ghost halo {info['halo']:.1f} A, ncclSend/ncclRecv group per step "
+                       f"(below the C ABI), interior tiles beside the message when that measures faster, stale flag on the halo message, "
+                       f"local list rebuilds, then repartition; transport: {'shared memory (verification aid, not a measurement)' if same_gpu and world > 1 else 'RCCL'}")
 
     def sync():
         if world > 1:
