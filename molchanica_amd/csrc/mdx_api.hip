@@ -159,6 +159,7 @@ extern "C" void mdx_destroy(mdx_handle* h) {
     mdx_pme_destroy(h);
     free_device(h);
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
+    if (h->h_rb) (void)hipHostFree(h->h_rb);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }

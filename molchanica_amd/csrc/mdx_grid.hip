@@ -426,6 +426,9 @@ struct ListArgs {
 // mask array with two atomics and writes everything out.  Tiles land in completion order, which nothing depends on
 // (every consumer addresses a tile's list by entry_off[t] and its counts).  A tile that does not fit the LDS buffers, or
 // a list that outgrows the arrays, raises an error bit and the host falls back to count + fill (with larger arrays).
+#ifndef MDX_XCD_SWIZZLE
+#define MDX_XCD_SWIZZLE 1     // 0: A/B build without the XCD-aware tile order of the list kernels
+#endif
 enum { LB_COUNT = 0, LB_FILL = 1, LB_SINGLE = 2 };
 template <int MODE>
 __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
@@ -437,7 +440,8 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     __shared__ uint2 s_plain[SINGLE ? LB_WAVES : 1][SINGLE ? LB_PLAIN : 1];
     __shared__ uint8_t s_mimask[SINGLE ? LB_WAVES : 1][SINGLE ? LB_MAXFLAG : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t t = blockIdx.x * LB_WAVES + wave;
+    const uint32_t per_xcd = gridDim.x >> 3;       // (the grid is a multiple of 8 workgroups) a contiguous eighth of the tiles per XCD
+    const uint32_t t = MDX_XCD_SWIZZLE ? ((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * LB_WAVES + wave : blockIdx.x * LB_WAVES + wave;
     if (t >= a.T) return;
 
     uint32_t* hash = s_hash[wave];
@@ -717,13 +721,19 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
 // the plain run whose mask empties are squeezed out (the run is compacted in place and re-padded); entries of
 // the masked run keep their position, which addresses their exclusion masks.  One wave per tile.
 // ================================================================================================
+#ifndef PRUNE_TRIES
+#define PRUNE_TRIES 1         // quick-accept tries per cluster pair (measured at 1 M atoms: 0 -> 283 us, 1 -> 278, 3 -> 291, 6 -> 314)
+#endif
 __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, float shx, float shy, float shz,
                                                          const float4* __restrict__ posq, ListCounts* __restrict__ counts,
                                                          const uint32_t* __restrict__ entry_off, uint2* __restrict__ entries,
                                                          uint32_t null_cluster, unsigned long long* __restrict__ pair_count) {
     __shared__ float4 s_j[4][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t t = blockIdx.x * 4 + wave;      // one wave per tile: the plain run is compacted in place
+    // one wave per tile (the plain run is compacted in place); a contiguous eighth of the tiles per XCD, as in the pair
+    // kernel: the j-atoms a tile's list names are its spatial neighbours, and each XCD has its own L2
+    const uint32_t per_xcd = gridDim.x >> 3;
+    const uint32_t t = MDX_XCD_SWIZZLE ? ((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * 4 + wave : blockIdx.x * 4 + wave;
     if (t >= T) return;
     const int ii = lane & 7, jj = lane >> 3;
     float xi[8], yi[8], zi[8];
@@ -732,6 +742,16 @@ __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, f
         const float4 p = posq[(size_t)t * MDX_TILE + ci * MDX_CLUSTER + ii];
         xi[ci] = p.x; yi[ci] = p.y; zi[ci] = p.z;
     }
+    // Quick accept before the 64-lane tests: lane (ci = lane & 7, e = lane >> 3) tries a fixed atom pair of cluster
+    // pair (i-cluster ci, entry e); one within r settles that cluster pair for 7 instructions per CHUNK instead of 7 per
+    // cluster pair.  What the try leaves open gets the exact test - the kept set is the same either way.  (The counters
+    // say the pass is bound by VALU + SALU issue - 108 M + 107 M instructions per launch, the scalar half being the
+    // ballot / branch bookkeeping per cluster pair - so more tries cost what they save.)
+    constexpr int NTRY = PRUNE_TRIES;
+    constexpr int TI[6] = {0, 7, 3, 0, 7, 4}, TJ[6] = {0, 7, 4, 7, 0, 3};
+    float4 rep[NTRY ? NTRY : 1];
+#pragma unroll
+    for (int k = 0; k < NTRY; ++k) rep[k] = posq[(size_t)t * MDX_TILE + (lane & 7) * MDX_CLUSTER + TI[k]];
     const ListCounts cnt = counts[t];
     const uint32_t e0 = entry_off[t], nmc = cnt.n_masked >> 3, nchunks = (cnt.n_masked + cnt.n_plain) >> 3;
     uint32_t kept = 0, wcur = 0;                   // wcur: plain entries written back so far
@@ -753,16 +773,27 @@ __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, f
         s_j[wave][lane] = pj;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
         uint32_t newy = ent.y;                     // lanes 8e .. 8e+7 hold entry e
+        unsigned long long acc = 0ull;             // bit e * 8 + ci: cluster pair (ci, e) has an atom pair inside r for sure
+#pragma unroll
+        for (int k = 0; k < NTRY; ++k) {
+            const float4 q = s_j[wave][(lane & ~7) + TJ[k]];
+            const float dx = rep[k].x - q.x, dy = rep[k].y - q.y, dz = rep[k].z - q.z;
+            acc |= __ballot(dx * dx + dy * dy + dz * dz < r2);
+        }
 #pragma unroll 2
         for (int e = 0; e < 8; ++e) {
             const float4 q = s_j[wave][e * 8 + jj];
-            uint32_t any = 0;                      // all eight i-clusters, no branches: eight independent ballots
+            const uint32_t y = __builtin_amdgcn_readlane(ent.y, e * 8);
+            const uint32_t sure = (uint32_t)(acc >> (e * 8)) & 0xFFu;
+            uint32_t any = sure;
+            // only the i-clusters the bounding-box test let through (~5 of 8) and the quick accept left open
+            // (all eight, branch-free: 357 us per rebuild at 1 M atoms; this: 278 us)
 #pragma unroll
             for (int ci = 0; ci < 8; ++ci) {
+                if (!(((y >> 8) & ~sure) & (1u << ci))) continue;
                 const float dx = xi[ci] - q.x, dy = yi[ci] - q.y, dz = zi[ci] - q.z;
                 any |= (__ballot(dx * dx + dy * dy + dz * dz < r2) != 0ull ? 1u : 0u) << ci;
             }
-            const uint32_t y = __builtin_amdgcn_readlane(ent.y, e * 8);
             const uint32_t im = (y >> 8) & any;
             kept += __popc(im & 0xFFu);
             if ((lane >> 3) == e) newy = (y & 0xFFu) | ((im & 0xFFu) << 8);
@@ -946,6 +977,24 @@ int mdx_gather_to_orig(mdx_handle* h, const float4* slot_arr, float4* orig_arr) 
     return MDX_OK;
 }
 
+// The rebuild's host decisions hang on a few device words (tile count, error bits, list cursors, pair counts).  One
+// thread copies them into pinned host memory the device can write: one 3 us launch per synchronisation point instead
+// of two to four pageable hipMemcpyAsync calls of ~25 us each (the rebuild at 1 M atoms spent 0.3 of its 1.36 ms in
+// those copies and the host wake-ups around them).
+struct RbSrc { const uint32_t* p[4]; uint32_t n[4]; };
+__global__ void readback_kernel(RbSrc s, uint32_t* __restrict__ out) {
+    uint32_t k = 0;
+    for (int a = 0; a < 4; ++a)
+        for (uint32_t i = 0; i < s.n[a]; ++i) out[k++] = s.p[a] ? s.p[a][i] : 0u;
+    __threadfence_system();
+}
+static int readback(mdx_handle* h, const RbSrc& s) {
+    if (!h->h_rb) HIP_TRY(hipHostMalloc((void**)&h->h_rb, sizeof(uint32_t) * 32, hipHostMallocDefault));
+    hipLaunchKernelGGL(readback_kernel, dim3(1), dim3(1), 0, h->stream, s, h->h_rb);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MDX_OK;
+}
+
 static float c_inner_skin(const mdx_config& c) { return c.inner_skin == 0.f ? 0.5f : c.inner_skin; }
 
 int mdx_rebuild(mdx_handle* h) {
@@ -976,9 +1025,9 @@ int mdx_rebuild(mdx_handle* h) {
     hipLaunchKernelGGL(cell_sort_kernel, dim3(div_up(h->ncells, 256)), dim3(256), 0, st, d.cell_start,
                        h->ncells, d.pos_orig, d.sorted_orig);
     uint32_t T = 0, flags[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(&T, d.tile_start + h->ncol, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(flags, d.flags_dev, sizeof(flags), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    MDX_TRY(readback(h, RbSrc{{d.tile_start + h->ncol, d.flags_dev, nullptr, nullptr}, {1, 4, 0, 0}}));
+    T = h->h_rb[0];
+    for (int k = 0; k < 4; ++k) flags[k] = h->h_rb[1 + k];
     if (flags[1]) { mdx_set_error("non-finite position at neighbour rebuild"); return MDX_ENAN; }
     if (T + 1 > h->cap_tiles) { mdx_set_error("internal: tile capacity exceeded"); return MDX_EDEVICE; }
     h->T = T;
@@ -1017,64 +1066,58 @@ int mdx_rebuild(mdx_handle* h) {
     // Single pass when the arrays of the previous build are there to be reused (every rebuild but the first): one
     // search of every tile's neighbourhood instead of count + scan + fill.  MDX_LIST_TWO_PASS=1 keeps the two passes.
     static const bool two_pass_env = [] { const char* e = std::getenv("MDX_LIST_TWO_PASS"); return e && e[0] == '1'; }();
-    bool built = false;
+    // The single pass is launched and NOT waited for: the exact pruning, the bonded role lists and the constraint remap
+    // queue up behind it, and its cursors and overflow bits are read at the one synchronisation at the end.  A tile that
+    // did not fit has an empty list (counts 0) by then, so what ran behind it was safe; count + fill then builds afresh.
+    bool speculative = false;
     if (d.entries && d.masks && h->cap_entries && h->cap_mchunks && T && !two_pass_env) {
         if (!d.list_cursors) ALLOC(d.list_cursors, 2);
         HIP_TRY(hipMemsetAsync(d.pair_count, 0, sizeof(unsigned long long) * 2, st));
         HIP_TRY(hipMemsetAsync(d.list_cursors, 0, sizeof(uint32_t) * 2, st));
         a.cursors = d.list_cursors;
         a.cap_entries = (uint32_t)std::min<uint64_t>(h->cap_entries, 0xFFFFFFFFull); a.cap_mchunks = h->cap_mchunks;
-        hipLaunchKernelGGL(build_list_kernel<LB_SINGLE>, dim3(div_up(T, LB_WAVES)), dim3(LB_WAVES * 64), 0, st, a);
-        uint32_t cur[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(&npairs, d.pair_count, sizeof(npairs), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(cur, d.list_cursors, sizeof(cur), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(flags, d.flags_dev, sizeof(flags), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (flags[0] & 1u) { mdx_set_error("exclusion table overflow while building the pair list"); return MDX_EPARAM; }
-        if (flags[0] & (16u | 32u)) {
-            // a tile beyond the LDS buffers, or a list that outgrew the arrays: count + fill below sizes them afresh
-            HIP_TRY(hipMemsetAsync(d.flags_dev, 0, sizeof(uint32_t), st));
-        } else {
-            E = cur[0]; MC = cur[1]; built = true;
-            h->E = E; h->MC = MC;
+        hipLaunchKernelGGL(build_list_kernel<LB_SINGLE>, dim3((div_up(T, LB_WAVES) + 7u) & ~7u), dim3(LB_WAVES * 64), 0, st, a);
+        speculative = true;
+    }
+    auto two_pass = [&]() -> int {
+        HIP_TRY(hipMemsetAsync(d.pair_count, 0, sizeof(unsigned long long) * 2, st));
+        HIP_TRY(hipMemsetAsync(d.entry_cnt + T, 0, sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(d.mchunk_cnt + T, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(build_list_kernel<LB_COUNT>, dim3((div_up(T, LB_WAVES) + 7u) & ~7u), dim3(LB_WAVES * 64), 0, st, a);
+        MDX_TRY(mdx_exclusive_scan_u32(h, d.entry_cnt, d.entry_off, T + 1));
+        MDX_TRY(mdx_exclusive_scan_u32(h, d.mchunk_cnt, d.mchunk_off, T + 1));
+        MDX_TRY(readback(h, RbSrc{{d.flags_dev, d.entry_off + T, d.mchunk_off + T, reinterpret_cast<const uint32_t*>(d.pair_count)}, {4, 1, 1, 2}}));
+        for (int k = 0; k < 4; ++k) flags[k] = h->h_rb[k];
+        E = h->h_rb[4]; MC = h->h_rb[5];
+        npairs = (unsigned long long)h->h_rb[6] | ((unsigned long long)h->h_rb[7] << 32);
+        if (flags[0] & 3u) { mdx_set_error("exclusion table overflow while building the pair list"); return MDX_EPARAM; }
+        if (E > h->cap_entries || !d.entries) {
+            h->cap_entries = (uint64_t)(E * 1.25) + 1024;
+            ALLOC(d.entries, h->cap_entries);
+            ALLOC(d.entries_in, h->cap_entries);   // dual list: the pruning pass of the pair kernel fills it
+            a.entries = d.entries;
         }
-    }
-    if (!built) {
-    HIP_TRY(hipMemsetAsync(d.pair_count, 0, sizeof(unsigned long long) * 2, st));
-    HIP_TRY(hipMemsetAsync(d.entry_cnt + T, 0, sizeof(uint32_t), st));
-    HIP_TRY(hipMemsetAsync(d.mchunk_cnt + T, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL(build_list_kernel<LB_COUNT>, dim3(div_up(T, LB_WAVES)), dim3(LB_WAVES * 64), 0, st, a);
-    MDX_TRY(mdx_exclusive_scan_u32(h, d.entry_cnt, d.entry_off, T + 1));
-    MDX_TRY(mdx_exclusive_scan_u32(h, d.mchunk_cnt, d.mchunk_off, T + 1));
-    HIP_TRY(hipMemcpyAsync(&npairs, d.pair_count, sizeof(npairs), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&E, d.entry_off + T, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&MC, d.mchunk_off + T, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(flags, d.flags_dev, sizeof(flags), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (flags[0]) { mdx_set_error("exclusion table overflow while building the pair list"); return MDX_EPARAM; }
-    if (E > h->cap_entries || !d.entries) {
-        h->cap_entries = (uint64_t)(E * 1.25) + 1024;
-        ALLOC(d.entries, h->cap_entries);
-        ALLOC(d.entries_in, h->cap_entries);   // dual list: the pruning pass of the pair kernel fills it
-        a.entries = d.entries;
-    }
-    if (MC > h->cap_mchunks || !d.masks) {
-        h->cap_mchunks = (uint32_t)(MC * 1.25) + 64;
-        ALLOC(d.masks, (size_t)h->cap_mchunks * 64);
-        a.masks = d.masks;
-    }
-    h->E = E; h->MC = MC;
-    hipLaunchKernelGGL(build_list_kernel<LB_FILL>, dim3(div_up(T, LB_WAVES)), dim3(LB_WAVES * 64), 0, st, a);
-    }
+        if (MC > h->cap_mchunks || !d.masks) {
+            h->cap_mchunks = (uint32_t)(MC * 1.25) + 64;
+            ALLOC(d.masks, (size_t)h->cap_mchunks * 64);
+            a.masks = d.masks;
+        }
+        h->E = E; h->MC = MC;
+        hipLaunchKernelGGL(build_list_kernel<LB_FILL>, dim3((div_up(T, LB_WAVES) + 7u) & ~7u), dim3(LB_WAVES * 64), 0, st, a);
+        return MDX_OK;
+    };
+    if (!speculative) MDX_TRY(two_pass());
     const bool prune = !std::isinf(h->r_list) && mdx_nb_variant(h) >= 2;   // the whole-tile kernel ignores imask
     static const bool exact_prune = [] { const char* e = std::getenv("MDX_EXACT_PRUNE"); return !(e && e[0] == '0'); }();   // A/B knob
-    if (prune && T && exact_prune) {
+    auto launch_prune = [&]() {
+        if (!(prune && T && exact_prune)) return;
         const float rb = a.r_build;
-        hipLaunchKernelGGL(prune_list_kernel, dim3(div_up(T, 4)), dim3(256), 0, st, T, rb * rb,
+        hipLaunchKernelGGL(prune_list_kernel, dim3((div_up(T, 4) + 7u) & ~7u), dim3(256), 0, st, T, rb * rb,
                            h->per[0] ? h->box_hi[0] - h->box_lo[0] : 0.f, h->per[1] ? h->box_hi[1] - h->box_lo[1] : 0.f,
                            h->per[2] ? h->box_hi[2] - h->box_lo[2] : 0.f, d.posq, d.list_counts, d.entry_off, d.entries,
                            a.null_cluster, d.pair_count);
-    }
+    };
+    launch_prune();
 
     // ---- bonded role lists into slot space ----
     if (h->n_roles) {
@@ -1087,9 +1130,33 @@ int mdx_rebuild(mdx_handle* h) {
     MDX_TRY(mdx_remap_constraints(h));
     HIP_TRY(hipGetLastError());
     unsigned long long npairs_pruned = 0;
-    HIP_TRY(hipMemcpyAsync(flags, d.flags_dev, sizeof(flags), hipMemcpyDeviceToHost, st));
-    if (prune && exact_prune) HIP_TRY(hipMemcpyAsync(&npairs_pruned, d.pair_count + 1, sizeof(npairs_pruned), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    auto read_counts = [&]() -> int {
+        MDX_TRY(readback(h, RbSrc{{d.flags_dev, d.list_cursors, reinterpret_cast<const uint32_t*>(d.pair_count), nullptr}, {4, 2, 4, 0}}));
+        for (int k = 0; k < 4; ++k) flags[k] = h->h_rb[k];
+        if (speculative) {
+            E = h->h_rb[4]; MC = h->h_rb[5];
+            npairs = (unsigned long long)h->h_rb[6] | ((unsigned long long)h->h_rb[7] << 32);
+        }
+        npairs_pruned = (unsigned long long)h->h_rb[8] | ((unsigned long long)h->h_rb[9] << 32);
+        return MDX_OK;
+    };
+    MDX_TRY(read_counts());
+    if (speculative) {
+        if (flags[0] & 1u) { mdx_set_error("exclusion table overflow while building the pair list"); return MDX_EPARAM; }
+        if (flags[0] & (16u | 32u)) {
+            // a tile beyond the LDS buffers, or a list that outgrew the arrays: count + fill sizes them afresh
+            // (the role lists and the constraint remap above do not depend on the pair list and stand)
+            const uint32_t keep = flags[0] & ~(16u | 32u);
+            HIP_TRY(hipMemcpyAsync(d.flags_dev, &keep, sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            speculative = false;
+            MDX_TRY(two_pass());
+            launch_prune();
+            MDX_TRY(read_counts());
+        } else {
+            h->E = E; h->MC = MC;
+        }
+    }
     if (prune && exact_prune) npairs = npairs_pruned;
     if (flags[0] & 8u) { mdx_set_error("a constrained / virtual-site atom is missing from the local atom set"); return MDX_EPARAM; }
     if (flags[0] & 3u) { mdx_set_error("exclusion table overflow while building the pair list"); return MDX_EPARAM; }

@@ -277,6 +277,7 @@ struct mdx_handle {
     std::vector<Snapshot> snapshots;
     DeviceState d;
     StepCtl* h_ctl = nullptr;  // pinned
+    uint32_t* h_rb = nullptr;  // pinned, device-visible: the list rebuild's counters land here straight from a kernel
 };
 
 // ---- error plumbing ------------------------------------------------------------------------------

@@ -85,3 +85,32 @@ def test_single_point_and_step_loop(mdx, orc, name):
         md.energy()
         fo2, _ = orc.forces(s, cfg, pos=pos2.astype(np.float64), use_cells=False)
         assert_forces(md.forces(), fo2, orc.cutoff_slack(s, cfg, pos=pos2), name + " after 60 steps")
+
+
+def test_pair_list_outgrows_its_arrays(mdx):
+    """The single-pass list build reuses the arrays of the previous build and runs unwaited-for, with the exact
+    pruning behind it; a list that no longer fits is only noticed at the end of the rebuild, which then sizes the
+    arrays afresh (count + fill) and prunes again.  A dilute argon-like box compressed to 2.4x its density is that
+    case (arrays carry 25 % headroom): forces, energies and list statistics must equal those of a handle created on
+    the compressed box (`md.cell = ...` + new positions, sol_shrinking_box.rs:600-603)."""
+    import dataclasses
+    s = systems.water_box(12, seed=41, spacing=4.2)                # dilute: 5,184 atoms in a 50.4 A box
+    cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, coulomb_mode=1)
+    k = 0.745
+    pos2 = (np.asarray(s.pos, dtype=np.float64) * k).astype(np.float32)   # water geometry shrinks too: no constraints here
+    hi2 = tuple(float(x) * k for x in s.box_hi)
+    s2 = dataclasses.replace(s, pos=pos2, box_hi=hi2)
+    with mdx.MdState(s2, cfg) as ref:
+        e_ref, f_ref, st_ref = ref.energy(), ref.forces().astype(np.float64), ref.stats()
+    with mdx.MdState(s, cfg) as md:
+        md.step(0.0005, None, 3)                                   # a list (and its arrays) of the dilute box exist
+        st0 = md.stats()
+        md.set_cell(s.box_lo, hi2)
+        md.set_positions(pos2)
+        e, f, st = md.energy(), md.forces().astype(np.float64), md.stats()
+    assert st["n_list_entries"] > 1.25 * st0["n_list_entries"] + 1024      # the arrays of the dilute list were too small
+    assert st["n_cluster_pairs"] == st_ref["n_cluster_pairs"] and st["n_list_entries"] == st_ref["n_list_entries"]
+    for key in ("lj", "coulomb", "bond", "angle"):
+        assert abs(e[key] - e_ref[key]) <= 1e-6 * abs(e_ref[key]) + 1e-3, (key, e[key], e_ref[key])
+    rmsf = math.sqrt((f_ref ** 2).sum(1).mean())
+    assert np.abs(f - f_ref).max() <= 2e-4 * rmsf

@@ -92,7 +92,7 @@ if pmc:
     lines.append("")
     lines.append(f"# rocprofv3 --pmc (separate passes; mean per executed dispatch)   ({tag})")
     for k, cs in sorted(pmc.items()):
-        if not (k.startswith("nb_") or k.startswith("bonded") or k.startswith("integrate")):
+        if not k.startswith(("nb_", "bonded", "integrate", "build_list", "prune_list")):
             continue
         lines.append(k)
         for c, (n, tot) in sorted(cs.items()):
