@@ -93,18 +93,26 @@ __global__ void add_ext_kernel(uint32_t S, const uint32_t* __restrict__ orig_of,
     force[s] = f;
 }
 
-int mdx_launch_bonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr_bits) {
+bool mdx_bonded_wanted(const mdx_handle* h) {
     const bool skip_bonded = (h->cfg.overrides & MDX_OVR_BONDED_DISABLED) != 0;
-    if (skip_bonded && !h->pme_on) return MDX_OK;
-    if (!h->n_roles) return MDX_OK;
+    return h->n_roles && !(skip_bonded && !h->pme_on);
+}
+void mdx_fill_bonded_params(const mdx_handle* h, BondedParams& p) {
+    for (int d = 0; d < 3; ++d) {
+        p.box[d] = h->per[d] ? (h->box_hi[d] - h->box_lo[d]) : 0.f;
+        p.inv_box[d] = h->per[d] ? 1.0f / p.box[d] : 0.f;
+    }
+    p.ewald_beta = h->cfg.ewald_alpha;
+    p.skip_bonded = (h->cfg.overrides & MDX_OVR_BONDED_DISABLED) ? 1 : 0;
+}
+
+int mdx_launch_bonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr_bits) {
+    if (h->bonded_fused) { h->bonded_fused = false; return MDX_OK; }   // rode along with the pair launch (small systems)
+    if (!mdx_bonded_wanted(h)) return MDX_OK;
     BondedArgs a{};
     a.S = h->S; a.role_off = h->d.role_off_s; a.roles = h->d.role_rec_s; a.prm = h->d.role_prm;
     a.posq = h->d.posq; a.force = h->d.force; a.energy = h->d.energy; a.gate = d_gate; a.thr_bits = thr_bits;
-    for (int d = 0; d < 3; ++d) {
-        a.p.box[d] = h->per[d] ? (h->box_hi[d] - h->box_lo[d]) : 0.f;
-        a.p.inv_box[d] = h->per[d] ? 1.0f / a.p.box[d] : 0.f;
-    }
-    a.p.ewald_beta = h->cfg.ewald_alpha; a.p.skip_bonded = skip_bonded ? 1 : 0;
+    mdx_fill_bonded_params(h, a.p);
     mdx_prof_begin(h, energy ? 3 : 1);
     const dim3 g((uint32_t)(((size_t)h->S * BONDED_LPA + 255) / 256)), b(256);
     if (energy) hipLaunchKernelGGL(bonded_gather_kernel<true>, g, b, 0, h->stream, a);

@@ -264,6 +264,7 @@ struct mdx_handle {
     int baro_kind = 0; float baro_p0 = 1.f, baro_tau = 5.f, baro_beta = 4.5e-5f; uint32_t baro_every = 25;
     double last_pressure = 0.0, last_mu = 1.0;
     bool force_zeroed = false;   // the integrate pass just enqueued cleared the force array (half-list kernel: skip the fill)
+    bool bonded_fused = false;   // the pair launch just enqueued carried the bonded gather in extra workgroups: skip its own launch
     uint64_t rng_state = 0;
     bool zero_com = false;
     uint32_t snap_every = 0; bool snap_vel = false;
@@ -304,6 +305,8 @@ int mdx_classify_tiles(mdx_handle* h);
 // message is in flight); 2 = its boundary tiles (after the unpack)
 int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr_bits, int part = 0);
 int mdx_launch_bonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr_bits);
+bool mdx_bonded_wanted(const mdx_handle* h);                       // there are bonded roles to evaluate in a force call
+void mdx_fill_bonded_params(const mdx_handle* h, BondedParams& p);
 int mdx_launch_add_ext(mdx_handle* h, const uint32_t* d_gate, uint32_t thr_bits);
 // integration (mode: 0 = half kick + drift, 1 = full kick + drift (also: one leapfrog step), 2 = closing half
 // kick, 3 = one Langevin-middle step: full kick, half drift, friction + noise, half drift)

@@ -32,6 +32,7 @@
 //     a compact spatial region.
 // No MFMA: this is pairwise scalar work.  Roofline: fp32 VALU bound (with the PMC numbers).
 #include "mdx_internal.h"
+#include "mdx_bonded_dev.h"
 #include <algorithm>
 #include <cfloat>
 #include <cstdlib>
@@ -69,6 +70,10 @@ struct NbArgs {
     const uint32_t* tile_order; uint32_t t_first, t_count;
     const uint32_t* prune_flag2;  // boundary launch: the ghosts' prune word (raised by the halo unpack); then only a pass asked for by
                                   // the owned atoms' word clears the owned atoms' path accumulators (the interior lists depend on them)
+    // small systems (DUAL 4): workgroups pair_grid .. of the launch evaluate the bonded gather beside the pair tiles
+    uint32_t pair_grid, b_S;
+    const uint32_t* b_role_off; const RoleRec* b_roles; const float4* b_prm;
+    BondedParams b_p;
 };
 
 enum { CM_SHIFTED = 0, CM_RF = 1, CM_EWALD = 2, CM_SOFT = 3 };
@@ -597,11 +602,39 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
     }
 }
 
+// The bonded gather as extra workgroups of the pair launch (DUAL 4, systems of a few hundred tiles): the pair tiles of
+// such a system fill a fraction of the chip, so the gather's waves run beside them on idle CUs and the step is one
+// launch shorter - at 23 k atoms the separate gather was 9.7 us of kernel and a ~4 us launch gap in a 72 us step.  Four
+// lanes per atom as in bonded_gather_kernel (mdx_bonded.hip); the force leaves through atomics, as the pair kernel's
+// does.  (At 1 M atoms the same arrangement costs more than it hides - the two compete for the memory-side atomic
+// path, DESIGN.md section 4 - so the large-system classes keep the separate launch.)
+__device__ __forceinline__ void bonded_workgroup(const NbArgs& a, uint32_t wg, uint32_t wg_threads) {
+    const uint32_t tid = wg * wg_threads + threadIdx.x;
+    const uint32_t s = tid >> 2, q4 = tid & 3u;
+    if (s >= a.b_S) return;
+    const uint32_t rb = a.b_role_off[s], re = a.b_role_off[s + 1];
+    if (re <= rb) return;      // quad-uniform
+    const float4 self = a.posq[s];
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    RoleEnergies en;
+    for (uint32_t k = rb + q4; k < re; k += 4) {
+        const RoleRec r = a.b_roles[k];
+        role_eval<false>(r, a.b_prm, self, a.posq, a.b_p, fx, fy, fz, en);
+    }
+    fx = dpp_xadd<0xB1>(fx); fy = dpp_xadd<0xB1>(fy); fz = dpp_xadd<0xB1>(fz);   // lane ^ 1
+    fx = dpp_xadd<0x4E>(fx); fy = dpp_xadd<0x4E>(fy); fz = dpp_xadd<0x4E>(fz);   // lane ^ 2
+    if (q4 < 3) {
+        float* const f = reinterpret_cast<float*>(a.force) + (size_t)s * 4;
+        unsafeAtomicAdd(f + q4, q4 == 0 ? fx : (q4 == 1 ? fy : fz));
+    }
+}
+
 template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF, bool ALCH = false, int DUAL = 0>
 __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && NB_HALF_FLUSH) || ENERGY) ? 3 : 4) void nb_cluster_kernel(NbArgs a) {
     if (a.gate && *a.gate > a.thr_bits) return;
     static_assert(DUAL == 0 || (HALF && !ENERGY), "the dual list exists for the half-list force kernel");
     constexpr int BW = WPT > NB_WAVES ? WPT : NB_WAVES;       // waves per workgroup
+    if (DUAL == 4 && blockIdx.x >= a.pair_grid) { bonded_workgroup(a, blockIdx.x - a.pair_grid, BW * 64); return; }
     __shared__ float4 s_xyzq[BW][64];
     __shared__ float2 s_lj[BW][64];
     __shared__ float s_red[WPT > 1 ? BW : 1][3][64];
@@ -613,7 +646,7 @@ __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && N
     } else {
         const bool owned_prune = (a.force_prune | *a.prune_flag) != 0u;
         const bool want_prune = owned_prune || (a.prune_flag2 && *a.prune_flag2 != 0u);
-        if (DUAL == 3) {        // merged launch: the device picks the body
+        if (DUAL >= 3) {        // merged launch: the device picks the body
             if (want_prune) nb_cluster_body<ENERGY, COUL, GEOM, SAMECUT, WPT, HALF, ALCH, 2, BW>(a, owned_prune, s_xyzq, s_lj, s_red, s_ownj, s_g, s_mask);
             else nb_cluster_body<ENERGY, COUL, GEOM, SAMECUT, WPT, HALF, ALCH, 1, BW>(a, owned_prune, s_xyzq, s_lj, s_red, s_ownj, s_g, s_mask);
         } else {
@@ -661,6 +694,12 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
         if (h->alch_on && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true, true>), g, b, 0, h->stream, a); \
         else if (h->alch_on) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, true, true>), g, b, 0, h->stream, a); \
         else if (var == 1) hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, G, S>), g, b, 0, h->stream, a);     \
+        else if (half && a.inner && dual_merged && wpt == 8 && a.b_S && !ENERGY) {                                 \
+            NbArgs af = a; af.pair_grid = grid;                                                                    \
+            const dim3 gf(grid + (uint32_t)(((size_t)a.b_S * 4 + bw * 64 - 1) / (bw * 64)));                       \
+            hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, 4>), gf, b, 0, h->stream, af); \
+            h->bonded_fused = true;                                                                                \
+        }                                                                                                          \
         else if (half && a.inner && dual_merged && wpt == 8) { NB_DUAL(G, S, 3); }                                 \
         else if (half && a.inner) { NB_DUAL(G, S, 1); NB_DUAL(G, S, 2); }                                          \
         else if (half && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true>), g, b, 0, h->stream, a); \
@@ -709,6 +748,14 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
         a.rin2 = rin * rin;
         a.entries_in = h->d.entries_in; a.inner_nch = h->d.inner_nch; a.ref = h->d.ref; a.inner_count = h->d.inner_count;
         // (a launch gated off behind a stale list is followed by a rebuild, which sets prune_pending again)
+    }
+    // small systems: the bonded gather rides along as extra workgroups of the merged dual-list launch (launch_variant
+    // decides; mdx_launch_bonded then finds bonded_fused set).  MDX_FUSE_BONDED=0: A/B knob.
+    static const bool fuse_bonded = [] { const char* e = std::getenv("MDX_FUSE_BONDED"); return !(e && e[0] == '0'); }();
+    h->bonded_fused = false;
+    if (fuse_bonded && a.inner && part == 0 && mdx_bonded_wanted(h) && (!h->profile || h->profile_level == 2)) {
+        a.b_S = h->S; a.b_role_off = h->d.role_off_s; a.b_roles = h->d.role_rec_s; a.b_prm = h->d.role_prm;
+        mdx_fill_bonded_params(h, a.b_p);
     }
     NbParams& p = a.p;
     p.rc2_lj = cut_on(c.lj_cutoff) ? c.lj_cutoff * c.lj_cutoff : FLT_MAX;
