@@ -139,7 +139,7 @@ static void free_device(mdx_handle* h) {
     void* ptrs[] = {d.o_qs, d.o_lj, d.o_invm, d.o_mass, d.o_q, d.o_lj_raw, d.excl_off, d.excl_idx, d.pos_orig,
                     d.vel_orig, d.ext_orig, d.posq, d.lj, d.vel, d.force, d.ref, d.orig_of, d.slot_of, d.gid, d.lflag,
                     d.slot_flags, d.cell_of,
-                    d.cell_count, d.cell_start, d.cell_cursor, d.sorted_orig, d.col_tiles, d.tile_start,
+                    d.cell_count, d.cell_start, d.cell_cursor, d.sorted_orig, d.sorted_tmp, d.col_tiles, d.tile_start,
                     d.tile_col, d.scan_tmp, d.cl_lo, d.cl_hi, d.list_counts, d.entry_cnt, d.entry_off,
                     d.mchunk_cnt, d.mchunk_off, d.entries, d.entries_in, d.inner_nch, d.list_cursors, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
                     d.role_off_s, d.role_rec_s, d.role_prm, d.ctl, d.energy,
@@ -337,7 +337,7 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
         MDX_TRY(upload_vec(&d.gid, gid, st)); MDX_TRY(upload_vec(&d.lflag, lf, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
-    MDX_TRY(alloc_n(&d.slot_of, N)); MDX_TRY(alloc_n(&d.cell_of, N)); MDX_TRY(alloc_n(&d.sorted_orig, N));
+    MDX_TRY(alloc_n(&d.slot_of, N)); MDX_TRY(alloc_n(&d.cell_of, N)); MDX_TRY(alloc_n(&d.sorted_orig, N)); MDX_TRY(alloc_n(&d.sorted_tmp, N));
     MDX_TRY(alloc_n(&d.ctl, 1)); MDX_TRY(alloc_n(&d.energy, EN_COUNT + 8 + MDX_ESTRIDE * MDX_EPART)); MDX_TRY(alloc_n(&d.flags_dev, 4));
     HIP_TRY(hipMemsetAsync(d.ctl, 0, sizeof(StepCtl), st));
     HIP_TRY(hipMemsetAsync(d.energy, 0, sizeof(double) * (EN_COUNT + 8 + MDX_ESTRIDE * MDX_EPART), st));

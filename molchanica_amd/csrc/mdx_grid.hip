@@ -104,9 +104,39 @@ int mdx_exclusive_scan_u32(mdx_handle* h, const uint32_t* in, uint32_t* out, uin
     return mdx_exclusive_scan_u32_ex(h, in, out, n, h->d.scan_tmp);
 }
 
+// Arrays of up to 64 k elements (everything a 23 k-atom system scans): ONE workgroup of 1024 threads walks the array
+// 8192 elements at a time, carrying the running total - one launch instead of three (tile scan, scan of the tile sums,
+// add), which at this size are all launch latency.
+constexpr int SCAN1_THREADS = 1024;
+__global__ __launch_bounds__(SCAN1_THREADS) void scan_one_block_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                                       uint32_t n) {
+    // thread k owns the contiguous segment [k * ipt, (k + 1) * ipt): sums it, the workgroup scans the 1024 sums once,
+    // the thread walks its segment again writing prefixes - two passes of independent loads, one barrier pair
+    __shared__ uint32_t s_wave[SCAN1_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t ipt = (n + SCAN1_THREADS - 1) / SCAN1_THREADS;
+    const uint32_t b = threadIdx.x * ipt, e = min(n, b + ipt);
+    uint32_t sum = 0;
+    for (uint32_t i = b; i < e; ++i) sum += in[i];
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += s_wave[w];
+    uint32_t ex = wbase + inc - sum;
+    for (uint32_t i = b; i < e; ++i) { const uint32_t v = in[i]; out[i] = ex; ex += v; }
+}
+
 int mdx_exclusive_scan_u32_ex(mdx_handle* h, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums) {
     if (n == 0) return MDX_OK;
     uint32_t nb = div_up(n, SCAN_TILE);
+    if (nb > 1 && n <= 65536u) {
+        hipLaunchKernelGGL(scan_one_block_kernel, dim3(1), dim3(SCAN1_THREADS), 0, h->stream, in, out, n);
+        HIP_TRY(hipGetLastError());
+        return MDX_OK;
+    }
     hipLaunchKernelGGL(scan_tile_kernel, dim3(nb), dim3(SCAN_THREADS), 0, h->stream, in, out, sums, n);
     if (nb > 1) {
         hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, h->stream, sums, nb);
@@ -124,6 +154,14 @@ __device__ __forceinline__ float wrap1(float x, float lo, float L) {
     if (t < lo) t += L;
     if (t >= lo + L) t -= L;
     return t;
+}
+
+__global__ void rebuild_clear_kernel(uint32_t* __restrict__ slot_of, uint32_t n_slot_of, uint32_t* __restrict__ cell_count,
+                                     uint32_t* __restrict__ cell_cursor, uint32_t n_cells1, uint32_t* __restrict__ flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_slot_of) slot_of[i] = MDX_INVALID;
+    if (i < n_cells1) { cell_count[i] = 0u; cell_cursor[i] = 0u; }
+    if (i < 4u) flags[i] = 0u;
 }
 
 __global__ void bin_atoms_kernel(float4* __restrict__ pos_orig, uint32_t N, GridParams g,
@@ -173,26 +211,26 @@ __global__ void scatter_kernel(const uint32_t* __restrict__ cell_of, const uint3
     sorted_orig[cell_start[c] + k] = o;
 }
 
-// Insertion sort of every cell's members by (z, atom id): removes the arbitrary order the atomic
-// scatter left, so the whole build is deterministic.  Cells hold a handful of atoms.
-__global__ void cell_sort_kernel(const uint32_t* __restrict__ cell_start, uint32_t ncells,
-                                 const float4* __restrict__ pos_orig, uint32_t* __restrict__ sorted_orig) {
-    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncells) return;
-    uint32_t b = cell_start[c], e = cell_start[c + 1];
-    for (uint32_t i = b + 1; i < e; ++i) {
-        uint32_t oi = sorted_orig[i];
-        float zi = pos_orig[oi].z;
-        uint32_t j = i;
-        while (j > b) {
-            uint32_t oj = sorted_orig[j - 1];
-            float zj = pos_orig[oj].z;
-            if (zj < zi || (zj == zi && oj < oi)) break;
-            sorted_orig[j] = oj;
-            --j;
-        }
-        sorted_orig[j] = oi;
+// Order of every cell's members by (z, atom id): removes the arbitrary order the atomic scatter left, so the whole
+// build is deterministic.  One thread per ATOM counts the members of its cell that come before it and writes itself to
+// that rank - a handful of independent loads per thread.  (One thread per cell running an insertion sort in global
+// memory, a chain of dependent loads per comparison, took 81 us at 1 M atoms and 48 us at 23 k.)
+__global__ void cell_rank_kernel(uint32_t N, const uint32_t* __restrict__ cell_of, const uint32_t* __restrict__ cell_start,
+                                 const float4* __restrict__ pos_orig, const uint32_t* __restrict__ unsorted,
+                                 uint32_t* __restrict__ sorted_orig) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const uint32_t o = unsorted[p];
+    const uint32_t c = cell_of[o];
+    const uint32_t b = cell_start[c], e = cell_start[c + 1];
+    const float z = pos_orig[o].z;
+    uint32_t rank = 0;
+    for (uint32_t j = b; j < e; ++j) {
+        const uint32_t oj = unsorted[j];
+        const float zj = pos_orig[oj].z;
+        rank += (zj < z || (zj == z && oj < o)) ? 1u : 0u;
     }
+    sorted_orig[b + rank] = o;
 }
 
 // ================================================================================================
@@ -333,12 +371,11 @@ __global__ void role_count_kernel(uint32_t S, const uint32_t* __restrict__ orig_
     cnt[s] = n;
 }
 
-__global__ void role_fill_kernel(uint32_t S, const uint32_t* __restrict__ orig_of, const uint32_t* __restrict__ gid,
-                                 const uint8_t* __restrict__ lflag, const uint32_t* __restrict__ slot_of,
-                                 const uint32_t* __restrict__ role_off_o, const RoleRec* __restrict__ rec_o,
-                                 const uint32_t* __restrict__ role_off_s, RoleRec* __restrict__ rec_s,
-                                 uint32_t* __restrict__ err) {
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void role_fill_body(uint32_t s, uint32_t S, const uint32_t* __restrict__ orig_of, const uint32_t* __restrict__ gid,
+                                               const uint8_t* __restrict__ lflag, const uint32_t* __restrict__ slot_of,
+                                               const uint32_t* __restrict__ role_off_o, const RoleRec* __restrict__ rec_o,
+                                               const uint32_t* __restrict__ role_off_s, RoleRec* __restrict__ rec_s,
+                                               uint32_t* __restrict__ err) {
     if (s >= S) return;
     const uint32_t o = orig_of[s];
     if (o == MDX_INVALID || (lflag[o] & 1u)) return;
@@ -355,6 +392,13 @@ __global__ void role_fill_kernel(uint32_t S, const uint32_t* __restrict__ orig_o
         }
         rec_s[w + k] = r;
     }
+}
+__global__ void role_fill_kernel(uint32_t S, const uint32_t* __restrict__ orig_of, const uint32_t* __restrict__ gid,
+                                 const uint8_t* __restrict__ lflag, const uint32_t* __restrict__ slot_of,
+                                 const uint32_t* __restrict__ role_off_o, const RoleRec* __restrict__ rec_o,
+                                 const uint32_t* __restrict__ role_off_s, RoleRec* __restrict__ rec_s,
+                                 uint32_t* __restrict__ err) {
+    role_fill_body(blockIdx.x * blockDim.x + threadIdx.x, S, orig_of, gid, lflag, slot_of, role_off_o, rec_o, role_off_s, rec_s, err);
 }
 
 // ================================================================================================
@@ -419,6 +463,10 @@ struct ListArgs {
     int half;                        // 1: every cluster pair appears in exactly one tile's list
     const uint32_t* cell_start;      // [ncol * nzb + 1]: first sorted atom of every (column, z-bin) cell
     const float4* posq;              // slot-space coordinates, for the exact test of borderline cluster pairs
+    // single pass: workgroups list_grid .. of the launch translate the bonded role lists into slot space (role_fill_body)
+    uint32_t list_grid, rf_S;
+    const uint32_t* rf_role_off_o; const RoleRec* rf_rec_o; const uint32_t* rf_role_off_s; RoleRec* rf_rec_s;
+    const uint8_t* rf_lflag;
 };
 
 // MODE 0: count pass (sizes per tile, then a scan); MODE 1: fill pass; MODE 2: SINGLE pass - the tile's entries are
@@ -440,7 +488,12 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     __shared__ uint2 s_plain[SINGLE ? LB_WAVES : 1][SINGLE ? LB_PLAIN : 1];
     __shared__ uint8_t s_mimask[SINGLE ? LB_WAVES : 1][SINGLE ? LB_MAXFLAG : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t per_xcd = gridDim.x >> 3;       // (the grid is a multiple of 8 workgroups) a contiguous eighth of the tiles per XCD
+    if (SINGLE && blockIdx.x >= a.list_grid) {     // the role lists ride along: independent of the pair list, and this launch leaves CUs idle
+        role_fill_body((blockIdx.x - a.list_grid) * (LB_WAVES * 64) + threadIdx.x, a.rf_S, a.orig_of, a.gid, a.rf_lflag, a.slot_of,
+                       a.rf_role_off_o, a.rf_rec_o, a.rf_role_off_s, a.rf_rec_s, a.err);
+        return;
+    }
+    const uint32_t per_xcd = (SINGLE ? a.list_grid : gridDim.x) >> 3;   // (a multiple of 8 workgroups) a contiguous eighth of the tiles per XCD
     const uint32_t t = MDX_XCD_SWIZZLE ? ((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * LB_WAVES + wave : blockIdx.x * LB_WAVES + wave;
     if (t >= a.T) return;
 
@@ -821,6 +874,93 @@ __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, f
     }
 }
 
+// The same pass for systems of a few hundred tiles, W waves per tile: one wave per tile leaves such a launch at the
+// latency of its longest list (82 us at 23 k atoms, 370 tiles on 1024 SIMDs).  Wave w takes chunks w, w + W, ... and
+// writes the trimmed masks in place; after a workgroup barrier wave 0 squeezes the emptied entries out of the plain
+// run, 64 entries per step.  Same kept set, same layout as prune_list_kernel.
+template <int W>
+__global__ __launch_bounds__(W * 64) void prune_list_mw_kernel(uint32_t T, float r2, float shx, float shy, float shz,
+                                                               const float4* __restrict__ posq, ListCounts* __restrict__ counts,
+                                                               const uint32_t* __restrict__ entry_off, uint2* __restrict__ entries,
+                                                               uint32_t null_cluster, unsigned long long* __restrict__ pair_count) {
+    __shared__ float4 s_j[W][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t t = blockIdx.x;
+    if (t >= T) return;
+    const int ii = lane & 7, jj = lane >> 3;
+    float xi[8], yi[8], zi[8];
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) {
+        const float4 p = posq[(size_t)t * MDX_TILE + ci * MDX_CLUSTER + ii];
+        xi[ci] = p.x; yi[ci] = p.y; zi[ci] = p.z;
+    }
+    const float4 rep = posq[(size_t)t * MDX_TILE + (lane & 7) * MDX_CLUSTER];      // quick accept: atom 0 of i-cluster (lane & 7)
+    const ListCounts cnt = counts[t];
+    const uint32_t e0 = entry_off[t], nchunks = (cnt.n_masked + cnt.n_plain) >> 3;
+    uint32_t kept = 0;
+    uint2 ent_n = make_uint2(null_cluster, 13u);
+    float4 pj_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((uint32_t)wave < nchunks) { ent_n = entries[e0 + wave * 8 + (lane >> 3)]; pj_n = posq[(size_t)ent_n.x * MDX_CLUSTER + (lane & 7)]; }
+    for (uint32_t c = wave; c < nchunks; c += W) {
+        const uint2 ent = ent_n;
+        float4 pj = pj_n;
+        if (c + W < nchunks) {
+            ent_n = entries[e0 + (c + W) * 8 + (lane >> 3)];
+            pj_n = posq[(size_t)ent_n.x * MDX_CLUSTER + (lane & 7)];
+        }
+        const uint32_t code = ent.y & 31u;
+        pj.x += (float)((int)(code % 3u) - 1) * shx;
+        pj.y += (float)((int)((code / 3u) % 3u) - 1) * shy;
+        pj.z += (float)((int)(code / 9u) - 1) * shz;
+        s_j[wave][lane] = pj;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+        uint32_t newy = ent.y;
+        unsigned long long acc;
+        {
+            const float4 q = s_j[wave][lane & ~7];
+            const float dx = rep.x - q.x, dy = rep.y - q.y, dz = rep.z - q.z;
+            acc = __ballot(dx * dx + dy * dy + dz * dz < r2);
+        }
+#pragma unroll 2
+        for (int e = 0; e < 8; ++e) {
+            const float4 q = s_j[wave][e * 8 + jj];
+            const uint32_t y = __builtin_amdgcn_readlane(ent.y, e * 8);
+            const uint32_t sure = (uint32_t)(acc >> (e * 8)) & 0xFFu;
+            uint32_t any = sure;
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci) {
+                if (!(((y >> 8) & ~sure) & (1u << ci))) continue;
+                const float dx = xi[ci] - q.x, dy = yi[ci] - q.y, dz = zi[ci] - q.z;
+                any |= (__ballot(dx * dx + dy * dy + dz * dz < r2) != 0ull ? 1u : 0u) << ci;
+            }
+            const uint32_t im = (y >> 8) & any;
+            kept += __popc(im & 0xFFu);
+            if ((lane >> 3) == e) newy = (y & 0xFFu) | ((im & 0xFFu) << 8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+        if ((lane & 7) == 0 && newy != ent.y) entries[e0 + c * 8 + (lane >> 3)].y = newy;
+    }
+    if (lane == 0 && kept) atomicAdd(pair_count + 1, (unsigned long long)kept);
+    __threadfence_block();
+    __syncthreads();
+    if (wave != 0) return;
+    // plain run: survivors move down (reads of a 64-entry step are complete - the ballot needs them - before its writes,
+    // and the write cursor never passes the read position)
+    uint32_t wcur = 0;
+    uint2* const plain = entries + e0 + cnt.n_masked;
+    for (uint32_t base = 0; base < cnt.n_plain; base += 64) {
+        const uint32_t idx = base + (uint32_t)lane;
+        const uint2 ent = idx < cnt.n_plain ? plain[idx] : make_uint2(null_cluster, 13u);
+        const bool alive = ((ent.y >> 8) & 0xFFu) != 0u;
+        const unsigned long long bal = __ballot(alive);
+        if (alive) plain[wcur + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = ent;
+        wcur += (uint32_t)__popcll(bal);
+    }
+    const uint32_t np_pad = (wcur + 7u) & ~7u;
+    if (lane < (int)(np_pad - wcur)) plain[wcur + lane] = make_uint2(null_cluster, 13u);
+    if (lane == 0) counts[t].n_plain = np_pad;
+}
+
 // ================================================================================================
 // neighbour-list extraction (parity / debugging API): canonical fp32 distances
 // ================================================================================================
@@ -1010,10 +1150,11 @@ int mdx_rebuild(mdx_handle* h) {
     const GridParams g = h->grid;
     hipStream_t st = h->stream;
 
-    HIP_TRY(hipMemsetAsync(d.slot_of, 0xFF, sizeof(uint32_t) * (size_t)h->N, st));
-    HIP_TRY(hipMemsetAsync(d.cell_count, 0, sizeof(uint32_t) * ((size_t)h->ncells + 1), st));
-    HIP_TRY(hipMemsetAsync(d.cell_cursor, 0, sizeof(uint32_t) * ((size_t)h->ncells + 1), st));
-    HIP_TRY(hipMemsetAsync(d.flags_dev, 0, sizeof(uint32_t) * 4, st));
+    {   // slot_of = invalid, cell counters and cursors = 0, error bits = 0: one launch instead of four fills
+        const uint32_t n_max = std::max<uint32_t>(h->N, h->ncells + 1);
+        hipLaunchKernelGGL(rebuild_clear_kernel, dim3(div_up(n_max, 256)), dim3(256), 0, st, d.slot_of, h->N, d.cell_count,
+                           d.cell_cursor, h->ncells + 1, d.flags_dev);
+    }
     hipLaunchKernelGGL(bin_atoms_kernel, dim3(div_up(N, 256)), dim3(256), 0, st, d.pos_orig, N, g, d.cell_of,
                        d.cell_count, d.flags_dev + 1);
     MDX_TRY(mdx_exclusive_scan_u32(h, d.cell_count, d.cell_start, h->ncells + 1));
@@ -1021,9 +1162,9 @@ int mdx_rebuild(mdx_handle* h) {
                        h->ncol, g.nzb, d.col_tiles);
     MDX_TRY(mdx_exclusive_scan_u32(h, d.col_tiles, d.tile_start, h->ncol + 1));
     hipLaunchKernelGGL(scatter_kernel, dim3(div_up(N, 256)), dim3(256), 0, st, d.cell_of, d.cell_start,
-                       d.cell_cursor, d.sorted_orig, N);
-    hipLaunchKernelGGL(cell_sort_kernel, dim3(div_up(h->ncells, 256)), dim3(256), 0, st, d.cell_start,
-                       h->ncells, d.pos_orig, d.sorted_orig);
+                       d.cell_cursor, d.sorted_tmp, N);
+    hipLaunchKernelGGL(cell_rank_kernel, dim3(div_up(N, 256)), dim3(256), 0, st, N, d.cell_of, d.cell_start,
+                       d.pos_orig, d.sorted_tmp, d.sorted_orig);
     uint32_t T = 0, flags[4] = {0, 0, 0, 0};
     MDX_TRY(readback(h, RbSrc{{d.tile_start + h->ncol, d.flags_dev, nullptr, nullptr}, {1, 4, 0, 0}}));
     T = h->h_rb[0];
@@ -1069,14 +1210,25 @@ int mdx_rebuild(mdx_handle* h) {
     // The single pass is launched and NOT waited for: the exact pruning, the bonded role lists and the constraint remap
     // queue up behind it, and its cursors and overflow bits are read at the one synchronisation at the end.  A tile that
     // did not fit has an empty list (counts 0) by then, so what ran behind it was safe; count + fill then builds afresh.
-    bool speculative = false;
+    bool speculative = false, roles_done = false;
     if (d.entries && d.masks && h->cap_entries && h->cap_mchunks && T && !two_pass_env) {
         if (!d.list_cursors) ALLOC(d.list_cursors, 2);
         HIP_TRY(hipMemsetAsync(d.pair_count, 0, sizeof(unsigned long long) * 2, st));
         HIP_TRY(hipMemsetAsync(d.list_cursors, 0, sizeof(uint32_t) * 2, st));
         a.cursors = d.list_cursors;
         a.cap_entries = (uint32_t)std::min<uint64_t>(h->cap_entries, 0xFFFFFFFFull); a.cap_mchunks = h->cap_mchunks;
-        hipLaunchKernelGGL(build_list_kernel<LB_SINGLE>, dim3((div_up(T, LB_WAVES) + 7u) & ~7u), dim3(LB_WAVES * 64), 0, st, a);
+        a.list_grid = (div_up(T, LB_WAVES) + 7u) & ~7u;
+        uint32_t rf_blocks = 0;
+        if (h->n_roles) {      // bonded role lists into slot space: count + scan here, the fill as extra workgroups of the list build
+            hipLaunchKernelGGL(role_count_kernel, dim3(div_up(S + 1, 256)), dim3(256), 0, st, S, d.orig_of, d.gid,
+                               d.lflag, d.role_off_o, d.role_cnt_s);
+            MDX_TRY(mdx_exclusive_scan_u32(h, d.role_cnt_s, d.role_off_s, S + 1));
+            a.rf_S = S; a.rf_role_off_o = d.role_off_o; a.rf_rec_o = d.role_rec_o; a.rf_role_off_s = d.role_off_s;
+            a.rf_rec_s = d.role_rec_s; a.rf_lflag = d.lflag;
+            rf_blocks = div_up(S, LB_WAVES * 64);
+            roles_done = true;
+        }
+        hipLaunchKernelGGL(build_list_kernel<LB_SINGLE>, dim3(a.list_grid + rf_blocks), dim3(LB_WAVES * 64), 0, st, a);
         speculative = true;
     }
     auto two_pass = [&]() -> int {
@@ -1112,15 +1264,19 @@ int mdx_rebuild(mdx_handle* h) {
     auto launch_prune = [&]() {
         if (!(prune && T && exact_prune)) return;
         const float rb = a.r_build;
-        hipLaunchKernelGGL(prune_list_kernel, dim3((div_up(T, 4) + 7u) & ~7u), dim3(256), 0, st, T, rb * rb,
-                           h->per[0] ? h->box_hi[0] - h->box_lo[0] : 0.f, h->per[1] ? h->box_hi[1] - h->box_lo[1] : 0.f,
-                           h->per[2] ? h->box_hi[2] - h->box_lo[2] : 0.f, d.posq, d.list_counts, d.entry_off, d.entries,
-                           a.null_cluster, d.pair_count);
+        const float shx = h->per[0] ? h->box_hi[0] - h->box_lo[0] : 0.f, shy = h->per[1] ? h->box_hi[1] - h->box_lo[1] : 0.f,
+                    shz = h->per[2] ? h->box_hi[2] - h->box_lo[2] : 0.f;
+        if (T < 2048u)          // a few hundred tiles: eight waves per tile (one wave per tile is a 1/3-empty chip waiting for its longest list)
+            hipLaunchKernelGGL(prune_list_mw_kernel<8>, dim3(T), dim3(512), 0, st, T, rb * rb, shx, shy, shz, d.posq, d.list_counts,
+                               d.entry_off, d.entries, a.null_cluster, d.pair_count);
+        else
+            hipLaunchKernelGGL(prune_list_kernel, dim3((div_up(T, 4) + 7u) & ~7u), dim3(256), 0, st, T, rb * rb, shx, shy, shz,
+                               d.posq, d.list_counts, d.entry_off, d.entries, a.null_cluster, d.pair_count);
     };
     launch_prune();
 
     // ---- bonded role lists into slot space ----
-    if (h->n_roles) {
+    if (h->n_roles && !roles_done) {
         hipLaunchKernelGGL(role_count_kernel, dim3(div_up(S + 1, 256)), dim3(256), 0, st, S, d.orig_of, d.gid,
                            d.lflag, d.role_off_o, d.role_cnt_s);
         MDX_TRY(mdx_exclusive_scan_u32(h, d.role_cnt_s, d.role_off_s, S + 1));

@@ -143,6 +143,7 @@ struct DeviceState {
     uint32_t* cell_start = nullptr;   // [ncells+1]
     uint32_t* cell_cursor = nullptr;  // [ncells]
     uint32_t* sorted_orig = nullptr;  // [N]
+    uint32_t* sorted_tmp = nullptr;   // [N] the cells' members as the atomic scatter left them, before the rank sort
     uint32_t* col_tiles = nullptr;    // [ncol+1]
     uint32_t* tile_start = nullptr;   // [ncol+1]
     uint32_t* tile_col = nullptr;     // [T]
