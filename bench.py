@@ -39,7 +39,7 @@ B_ALG_INTEGRATE = 64.0         # R x,v,f (36) + 1/m (4), W x,v (24)
 B_ALG_BONDED_WATER = 52.0      # 36 + 16 t, t = 1 bonded term per atom in flexible water
 B_ALG_STEP_WATER = 170.0       # whole step, water box
 FLOP_PER_PAIR = 45.0
-NB_KERNEL_REV = "r02a"         # revision tag of the default pair kernel the cached PMC traffic figure belongs to
+NB_KERNEL_REV = "r02d"         # revision tag of the default pair kernel the cached PMC traffic figure belongs to
 
 
 def parse():
@@ -210,15 +210,42 @@ def main():
             uid = uid if same_gpu else uid.cuda()
             dist.broadcast(uid, 0)
             uid = uid.cpu()
+        transport = "RCCL"
+        shm_name = "bench_" + bytes(uid.numpy().tobytes())[:8].hex()
         if same_gpu and world > 1:
-            md.comm_init_shm("bench_" + bytes(uid.numpy().tobytes())[:8].hex(), rank, world)
+            md.comm_init_shm(shm_name, rank, world)
+            transport = "shared memory (verification aid, not a measurement)"
         else:
-            md.comm_init(bytes(uid.numpy().tobytes()), rank, world)
+            # RCCL below the C ABI has only ever run with one rank per box before the driver's scaling run.  If its
+            # initialisation or its self-test (one halo-shaped exchange + one all-reduce) fails on ANY rank, every rank
+            # says so on stderr and the run continues over the library's host shared-memory transport - GPU kernels
+            # unchanged, halo through host memory - and the JSON line names the transport it was measured on.
+            err = ""
+            try:
+                md.comm_init(bytes(uid.numpy().tobytes()), rank, world)
+                md.comm_selftest()
+            except Exception as e:  # noqa: BLE001 - reported, never swallowed
+                err = f"{type(e).__name__}: {e}"
+            if world > 1:
+                bad = torch.tensor([1.0 if err else 0.0], device="cuda")
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                if bad.item() > 0:
+                    sys.stderr.write(f"[bench rank {rank}] RCCL transport unusable ({err or 'failed on another rank'}); "
+                                     f"continuing over the shared-memory transport\n")
+                    md.close()
+                    md = MdState(system, cfg, device=local_rank)
+                    md.comm_init_shm(shm_name, rank, world)
+                    transport = "host shared memory (RCCL initialisation failed - see stderr)"
+            elif err:
+                raise SystemExit(err)
+        stepper = lambda k: md.step(args.dt, None, k)
+        stats = md.stats
+        prof = md.profile
         info = md.comm_info()
         g = info["grid"]
         parallelism = (f"spatial {g[0]}x{g[1]}x{g[2]} bricks, ghost halo {info['halo']:.1f} A, ncclSend/ncclRecv group per step "
                        f"(below the C ABI), interior tiles beside the message when that measures faster, stale flag on the halo message, "
-                       f"local list rebuilds, then repartition; transport: {'shared memory (verification aid, not a measurement)' if same_gpu and world > 1 else 'RCCL'}")
+                       f"local list rebuilds, then repartition; transport: {transport}")
 
     def sync():
         if world > 1:

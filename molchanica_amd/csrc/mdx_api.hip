@@ -11,6 +11,7 @@
 // MDX_EDEVICE and the host keeps its own CPU path (src/util.rs:1072-1119 semantics).
 #include "mdx_comm.h"
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cfloat>
 #include <cmath>
@@ -341,7 +342,8 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
     MDX_TRY(alloc_n(&d.ctl, 1)); MDX_TRY(alloc_n(&d.energy, EN_COUNT + 8 + MDX_ESTRIDE * MDX_EPART)); MDX_TRY(alloc_n(&d.flags_dev, 4));
     HIP_TRY(hipMemsetAsync(d.ctl, 0, sizeof(StepCtl), st));
     HIP_TRY(hipMemsetAsync(d.energy, 0, sizeof(double) * (EN_COUNT + 8 + MDX_ESTRIDE * MDX_EPART), st));
-    HIP_TRY(hipHostMalloc((void**)&h->h_ctl, sizeof(StepCtl), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&h->h_ctl, sizeof(StepCtl) + 64, hipHostMallocDefault));   // + the sequence word of ctl_readback_kernel
+    std::memset(h->h_ctl, 0, sizeof(StepCtl) + 64);
     HIP_TRY(hipStreamSynchronize(st));  // host vectors go out of scope
     h->in_slot_space = false; h->list_valid = false; h->forces_valid = false;
     MDX_TRY(mdx_build_constraints(h, s));
@@ -368,6 +370,43 @@ static uint32_t stale_threshold_bits(const mdx_handle* h) {
     if (std::isinf(h->r_list)) return f2u(1.0e29f);  // all pairs listed: never stale (NaN still trips)
     const float half = 0.5f * h->cfg.skin;
     return f2u(half * half);
+}
+
+// End of a chunk: the step-control words reach the host.  A kernel copies them into pinned host memory and writes a
+// sequence word last; the host spins on that word - no runtime call on the wait path (tools/ubench/sync_latency.hip:
+// launch + readback + wait 13 us this way, 18 us with hipStreamSynchronize behind the same kernel, 27 us with a
+// hipMemcpyAsync + hipStreamSynchronize).  One chunk end per 16 steps: 1 % of a 55 us step at 23 k atoms.  Profiled
+// and decomposed handles keep the synchronising copy (their host code after the chunk relies on an idle stream), and
+// so does a wait that lasts longer than 20 ms (a fault then surfaces through hipStreamSynchronize).
+__global__ __launch_bounds__(256) void ctl_readback_kernel(const uint32_t* __restrict__ src, volatile uint32_t* dst, uint32_t nwords,
+                                                           volatile uint32_t* seq_word, uint32_t seq) {
+    for (uint32_t i = threadIdx.x; i < nwords; i += 256) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) *seq_word = seq;
+}
+static int ctl_to_host(mdx_handle* h) {
+    hipStream_t st = h->stream;
+    static const bool spin_ok = [] { const char* e = std::getenv("MDX_CHUNK_SPIN"); return !(e && e[0] == '0'); }();
+    if (!spin_ok || h->profile || h->dd) {
+        HIP_TRY(hipMemcpyAsync(h->h_ctl, h->d.ctl, sizeof(StepCtl), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return MDX_OK;
+    }
+    volatile uint32_t* seq_word = reinterpret_cast<volatile uint32_t*>(reinterpret_cast<char*>(h->h_ctl) + sizeof(StepCtl));
+    const uint32_t seq = ++h->ctl_seq;
+    hipLaunchKernelGGL(ctl_readback_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(h->d.ctl),
+                       reinterpret_cast<volatile uint32_t*>(h->h_ctl), (uint32_t)(sizeof(StepCtl) / 4), seq_word, seq);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0; *seq_word != seq; ++spins) {
+        if ((spins & 0xFFFu) == 0xFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+            HIP_TRY(hipStreamSynchronize(st));
+            if (*seq_word != seq) { mdx_set_error("internal: step-control readback did not arrive"); return MDX_EDEVICE; }
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return MDX_OK;
 }
 
 static int compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint32_t thr) {
@@ -536,8 +575,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         if (fused) MDX_TRY(mdx_launch_integrate(h, 2, dt, &d.ctl->disp2[chunk], nullptr, thr));
         h->prof_tag = -1;
         if (h->dd) h->chunk_s = -1;
-        HIP_TRY(hipMemcpyAsync(h->h_ctl, d.ctl, sizeof(StepCtl), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        MDX_TRY(ctl_to_host(h));
         uint32_t done = chunk;
         int first_stale = 1 << 30;
         for (uint32_t s = 0; s < chunk; ++s)

@@ -117,7 +117,13 @@ __global__ __launch_bounds__(SCAN1_THREADS) void scan_one_block_kernel(const uin
     const uint32_t ipt = (n + SCAN1_THREADS - 1) / SCAN1_THREADS;
     const uint32_t b = threadIdx.x * ipt, e = min(n, b + ipt);
     uint32_t sum = 0;
-    for (uint32_t i = b; i < e; ++i) sum += in[i];
+    for (uint32_t i = b; i < e; i += 8) {          // eight loads in flight (one load per iteration waits ~0.6 us each time)
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (i + k < e) ? in[i + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum += v[k];
+    }
     uint32_t inc = sum;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d); if (lane >= d) inc += t; }
@@ -126,7 +132,13 @@ __global__ __launch_bounds__(SCAN1_THREADS) void scan_one_block_kernel(const uin
     uint32_t wbase = 0;
     for (int w = 0; w < wave; ++w) wbase += s_wave[w];
     uint32_t ex = wbase + inc - sum;
-    for (uint32_t i = b; i < e; ++i) { const uint32_t v = in[i]; out[i] = ex; ex += v; }
+    for (uint32_t i = b; i < e; i += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (i + k < e) ? in[i + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { if (i + k < e) out[i + k] = ex; ex += v[k]; }
+    }
 }
 
 int mdx_exclusive_scan_u32_ex(mdx_handle* h, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums) {

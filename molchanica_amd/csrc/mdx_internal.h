@@ -278,7 +278,8 @@ struct mdx_handle {
     std::vector<uint32_t> h_bond_pairs;  // bonds + constraints as given at creation (pairs), for the donor table
     std::vector<Snapshot> snapshots;
     DeviceState d;
-    StepCtl* h_ctl = nullptr;  // pinned
+    StepCtl* h_ctl = nullptr;  // pinned (+ 64 bytes: the sequence word of the chunk-end readback)
+    uint32_t ctl_seq = 0;
     uint32_t* h_rb = nullptr;  // pinned, device-visible: the list rebuild's counters land here straight from a kernel
 };
 

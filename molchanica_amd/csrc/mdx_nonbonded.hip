@@ -629,12 +629,21 @@ __device__ __forceinline__ void bonded_workgroup(const NbArgs& a, uint32_t wg, u
     }
 }
 
-template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF, bool ALCH = false, int DUAL = 0>
+template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF, bool ALCH = false, int DUAL = 0, bool FB = false>
 __global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && NB_HALF_FLUSH) || ENERGY) ? 3 : 4) void nb_cluster_kernel(NbArgs a) {
     if (a.gate && *a.gate > a.thr_bits) return;
     static_assert(DUAL == 0 || (HALF && !ENERGY), "the dual list exists for the half-list force kernel");
+    static_assert(!FB || DUAL != 0, "the bonded workgroups ride with the dual-list launches");
     constexpr int BW = WPT > NB_WAVES ? WPT : NB_WAVES;       // waves per workgroup
-    if (DUAL == 4 && blockIdx.x >= a.pair_grid) { bonded_workgroup(a, blockIdx.x - a.pair_grid, BW * 64); return; }
+    if ((DUAL == 4 || FB) && blockIdx.x >= a.pair_grid) {
+        // (a twin launch: the bonded workgroups run in whichever of the two the device executes)
+        if (DUAL == 1 || DUAL == 2) {
+            const bool want_prune = (a.force_prune | *a.prune_flag) != 0u || (a.prune_flag2 && *a.prune_flag2 != 0u);
+            if (want_prune != (DUAL == 2)) return;
+        }
+        bonded_workgroup(a, blockIdx.x - a.pair_grid, BW * 64);
+        return;
+    }
     __shared__ float4 s_xyzq[BW][64];
     __shared__ float2 s_lj[BW][64];
     __shared__ float s_red[WPT > 1 ? BW : 1][3][64];
@@ -680,11 +689,19 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
     // ones launch the two flavours back to back and the device runs exactly one (measured: merged +1 % at 23 k atoms,
     // -0.4 % at 1 M, where the merged kernel's 92 SGPRs / 127 VGPRs cost more than the ~4 us twin).  MDX_DUAL_MERGED=0: never merge.
     static const bool dual_merged = [] { const char* e = std::getenv("MDX_DUAL_MERGED"); return !(e && e[0] == '0'); }();
+    static const bool fb_all = [] { const char* e = std::getenv("MDX_FUSE_BONDED"); return e && e[0] == '2'; }();   // A/B: also the twin launches of the large classes
     // dual list: the inner-walk kernel and the pruning kernel back to back, the device runs exactly one of them
 #define NB_DUAL(G, S, D)                                                                                              \
     do {                                                                                                               \
         if (ENERGY) break;                                                                                             \
-        if (wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, D>), g, b, 0, h->stream, a);      \
+        if (fb_all && a.b_S && (wpt == 2 || wpt == 4)) {   /* bonded workgroups behind the pair grid of both twins */  \
+            NbArgs af = a; af.pair_grid = grid;                                                                        \
+            const dim3 gf(grid + (uint32_t)(((size_t)a.b_S * 4 + bw * 64 - 1) / (bw * 64)));                           \
+            if (wpt == 2) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 2, true, false, D, true>), gf, b, 0, h->stream, af); \
+            else hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 4, true, false, D, true>), gf, b, 0, h->stream, af);          \
+            h->bonded_fused = true;                                                                                    \
+        }                                                                                                              \
+        else if (wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, D>), g, b, 0, h->stream, a); \
         else if (wpt == 2) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 2, true, false, D>), g, b, 0, h->stream, a); \
         else if (wpt == 1) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 1, true, false, D>), g, b, 0, h->stream, a); \
         else hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 4, true, false, D>), g, b, 0, h->stream, a);               \
