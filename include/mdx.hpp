@@ -196,6 +196,10 @@ public:
     void comm_init(const std::array<uint8_t, MDX_COMM_ID_BYTES>& id, int rank, int world) { check(mdx_comm_init(h_, id.data(), rank, world)); }
     /// ... or, between handles of ONE process (one thread each), an in-process fabric.
     void comm_init_fabric(mdx_fabric* fabric, int rank) { check(mdx_comm_init_fabric(h_, fabric, rank)); }
+    /// ... or between processes of one host through POSIX shared memory (verification transport: no RCCL, any devices).
+    void comm_init_shm(const std::string& name, int rank, int world) { check(mdx_comm_init_shm(h_, name.c_str(), rank, world)); }
+    /// Collective: every transport entry point once on the real wire, results checked.
+    void comm_selftest() { check(mdx_comm_selftest(h_)); }
 
     /// `snapshot_handlers.memory: Some(every_n)` (src/properties/water_sol.rs:185-189).
     void set_snapshot_cadence(uint32_t every_n, bool with_velocities = false) {
