@@ -191,10 +191,16 @@ __global__ void vsite_construct_kernel(uint32_t n, const VSite* __restrict__ vs,
     const float4 r0 = posq[v.p0], r1 = posq[v.p1], r2 = posq[v.p2];
     const float3 d1 = mimg3(make_float3(r1.x - r0.x, r1.y - r0.y, r1.z - r0.z), p);
     const float3 d2 = mimg3(make_float3(r2.x - r0.x, r2.y - r0.y, r2.z - r0.z), p);
+    // The site goes to the periodic image of r0 + a d1 + b d2 that is nearest to where it is stored now: the pair
+    // list holds ONE image shift per cluster pair, fixed at the rebuild, which wrapped every atom into the box on its
+    // own - a site whose parent sits just across a box face must stay on ITS side of that face, where its cluster's
+    // shifts expect it, as an integrated atom does by moving continuously.  (Placed next to the parent it sat a box
+    // length away from the image the list had paired it with: every water straddling a face fed energy into the box,
+    // 15 kcal/mol/ps per water at 23 k sites.  Minimum image per atom pair, as the oracle has, never sees this.)
     float4 m = posq[v.site];
-    m.x = r0.x + v.a * d1.x + v.b * d2.x;
-    m.y = r0.y + v.a * d1.y + v.b * d2.y;
-    m.z = r0.z + v.a * d1.z + v.b * d2.z;
+    const float3 fresh = make_float3(r0.x + v.a * d1.x + v.b * d2.x, r0.y + v.a * d1.y + v.b * d2.y, r0.z + v.a * d1.z + v.b * d2.z);
+    const float3 back = mimg3(make_float3(m.x - fresh.x, m.y - fresh.y, m.z - fresh.z), p);     // stored - new, minimum image: minus the true move
+    m.x -= back.x; m.y -= back.y; m.z -= back.z;
     posq[v.site] = m;
 }
 

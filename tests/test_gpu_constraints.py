@@ -64,6 +64,66 @@ def test_rigid_water_parity_at_2fs(mdx, orc, model):
     assert rebuilds >= 2
 
 
+@pytest.mark.parametrize("model", ["tip3p_rigid", "opc"])
+def test_rigid_waters_straddling_box_faces(mdx, orc, model):
+    """The state a running box is always in: atoms are wrapped into the cell one by one, so a water near a face has
+    its sites on BOTH sides of it (the lattice the generator starts from never has).  The pair list fixes one image
+    shift per cluster pair at the rebuild; SHAKE moves atoms by corrections and a virtual site must be rebuilt in the
+    periodic image it is stored in, not next to its parent - otherwise every straddling OPC water interacts through the
+    wrong image and the box heats (found in round 2: +15 kcal/mol/ps per water at 23 k sites, invisible to the lattice
+    start of the test above).  Forces, energies, a dt = 2 fs trajectory and energy conservation against the oracle,
+    which takes the minimum image per atom pair."""
+    s = systems.water_box(6, seed=7, rigid=True) if model == "tip3p_rigid" else systems.opc_water_box(6, seed=7)
+    L = np.array(s.box_hi, dtype=np.float64)
+    s.pos = np.mod(np.asarray(s.pos, dtype=np.float64) + 1.25, L).astype(np.float32)     # the last lattice layer now straddles every upper face
+    nsite = 3 if model == "tip3p_rigid" else 4
+    w = s.pos.reshape(-1, nsite, 3)
+    assert (np.abs(w[:, 1:] - w[:, :1]).max(axis=(1, 2)) > 0.5 * L[0]).sum() > 30, "no water straddles a face"
+    cfg = MdConfig(lj_cutoff=8.0, coulomb_cutoff=8.0, skin=1.0, coulomb_mode=1)
+    with mdx.MdState(s, cfg) as md:
+        f, e = md.forces().astype(np.float64), md.energy()
+        x0, v0 = md.positions().astype(np.float64), md.velocities().astype(np.float64)
+        fo, eo = orc.forces(s, cfg, pos=x0)
+        err = np.linalg.norm(f - fo, axis=1)
+        tol = 1e-4 * np.maximum(np.linalg.norm(fo, axis=1), 1.0) + orc.cutoff_slack(s, cfg, pos=x0)
+        assert (err <= tol).all(), float((err / tol).max())
+        for k in ("lj", "coulomb"):
+            assert e[k] == pytest.approx(eo[k], rel=5e-6, abs=2e-2)
+        t0 = e["potential"] + e["kinetic"]
+        md.step(0.002, None, 60)
+        x = md.positions().astype(np.float64)
+        e1 = md.energy()
+        assert md.stats()["rebuild_count"] >= 3        # every rebuild wraps the atoms again
+        assert bond_errors(s, x).max() < 3e-5
+    xo, vo, _ = orc.step(s, cfg, 0.002, 60, pos=x0, vel=v0, use_cells=True)
+    d = x - xo
+    d -= np.round(d / L) * L
+    rms = math.sqrt((d ** 2).sum(1).mean())
+    assert rms < 2e-3, f"trajectory deviates from the oracle: {rms:.2e} A"
+    assert abs(e1["potential"] + e1["kinetic"] - t0) < 0.02 * e["kinetic"], "energy not conserved over 60 steps of NVE"
+
+
+def test_opc_box_conserves_energy_after_equilibration(mdx):
+    """NVE at the reference's default operating point (rigid OPC, dt 2 fs) from an equilibrated, wrapped state: the total
+    energy of 1000 waters may wander by a fraction of a percent of the kinetic energy over 300 steps (it rose by
+    4500 kcal/mol in 200 steps with the virtual sites rebuilt in the wrong image)."""
+    s = systems.opc_water_box(10, seed=5)
+    cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, coulomb_mode=1)
+    with mdx.MdState(s, cfg) as md:
+        md.minimize_energy(200)
+        md.initialize_velocities(300.0, True, seed=1)
+        md.set_thermostat(1, 300.0, 0.02, 1)
+        md.step(0.001, None, 1500)
+        md.set_thermostat(0, 300.0, 0.02, 1)
+        e0 = md.energy()
+        md.step(0.002, None, 300)
+        e1 = md.energy()
+        assert md.stats()["rebuild_count"] >= 10
+    drift = (e1["potential"] + e1["kinetic"]) - (e0["potential"] + e0["kinetic"])
+    assert abs(drift) < 0.01 * e0["kinetic"], f"dE = {drift:.1f} kcal/mol (kinetic {e0['kinetic']:.0f})"
+    assert abs(e1["temperature"] - e0["temperature"]) < 25.0
+
+
 def test_xh_constraints_on_a_solvated_chain(mdx, orc):
     """HydrogenConstraint::Shake on the solute's X-H bonds; input geometry is off the constraint
     lengths by ~2 %, so creation has to project it first."""
