@@ -73,8 +73,14 @@ __device__ __forceinline__ void role_eval(const RoleRec& r, const float4* __rest
         const float ir1 = rsqrtf(dot3(v1, v1)), ir2 = rsqrtf(dot3(v2, v2));
         float cs = dot3(v1, v2) * ir1 * ir2;
         cs = fminf(1.0f, fmaxf(-1.0f, cs));
-        const float th = acosf(cs), dth = th - prm[1];
-        const float sn = fmaxf(sqrtf(1.0f - cs * cs), 1e-6f);
+        // theta from atan2(|v1 x v2|, v1 . v2): in fp32 acos(cs) loses half its digits near a straight angle
+        // (d theta / d cs = -1 / sin theta), and sqrt(1 - cs^2) all of them; GAFF has theta0 = 180 deg (nitriles, alkynes)
+        // and the synthetic helix of config 4 has 177 deg - with acos its angle forces carried ~2 kcal/mol/A of rounding
+        // noise per step and the box heated by 5 % of its kinetic energy per 1000 steps
+        const float3 cr = cross3(v1, v2);
+        const float cl = sqrtf(dot3(cr, cr));
+        const float th = atan2f(cl, dot3(v1, v2)), dth = th - prm[1];
+        const float sn = fmaxf(cl * ir1 * ir2, 1e-6f);
         const float de = 2.0f * prm[0] * dth;   // dE/dtheta
         // dtheta/dr_i = -(v2/|v2| - cos v1/|v1|) / (|v1| sin)
         const float ci = de * ir1 / sn, ck = de * ir2 / sn;
