@@ -1078,7 +1078,8 @@ __global__ void pack_pos_kernel(uint32_t n, const uint32_t* __restrict__ atom_id
 __global__ void unpack_pos_kernel(uint32_t n, const uint32_t* __restrict__ atom_idx, const uint32_t* __restrict__ slot_of,
                                   float4* __restrict__ posq, const float4* __restrict__ in,
                                   const float4* __restrict__ shift, uint32_t* __restrict__ flag_word,
-                                  float4* __restrict__ ref, uint32_t* __restrict__ prune_out, float path_thr) {
+                                  float4* __restrict__ ref, uint32_t* __restrict__ prune_out, float path_thr,
+                                  float gx, float gy, float gz) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t g = atom_idx[i];
@@ -1091,6 +1092,15 @@ __global__ void unpack_pos_kernel(uint32_t n, const uint32_t* __restrict__ atom_
     float4 v = in[i];
     if (shift) { const float4 sh = shift[i]; v.x += sh.x; v.y += sh.y; v.z += sh.z; }
     float4 p = posq[s];
+    // (library-managed decomposition: gx, gy, gz = the global box) The ghost goes to the periodic image of the incoming
+    // position that is nearest to where it stands now.  The message carries the SENDER's coordinates; for an atom the
+    // sender owns through its cluster's anchor while it lies across the periodic face (a straddling rigid water) those
+    // are a box length away from the wrapped coordinate the receiver's image shift was computed for, and an atom that
+    // has drifted out of [lo, lo + L) on its owner is in the same position.  A ghost moves by far less than L / 2 per
+    // message and starts in the right image (the partition places it), so the nearest image is the true one.
+    if (gx > 0.f) v.x -= gx * rintf((v.x - p.x) / gx);
+    if (gy > 0.f) v.y -= gy * rintf((v.y - p.y) / gy);
+    if (gz > 0.f) v.z -= gz * rintf((v.z - p.z) / gz);
     if (ref) {
         const float mx = v.x - p.x, my = v.y - p.y, mz = v.z - p.z;
         const float w = ref[s].w + sqrtf(mx * mx + my * my + mz * mz);
@@ -1225,7 +1235,9 @@ extern "C" int mdx_unpack_positions(mdx_handle* h, const uint32_t* d_gid, uint32
                               dual ? h->d.ref : nullptr,
                               dual ? (mdx_dd_split_now(h) ? &h->d.ctl->prune_ghost[h->chunk_s + 1]
                                                                                                       : &h->d.ctl->prune[h->chunk_s + 1]) : nullptr,
-                              0.5f * h->inner_skin * (1.0f - 1.0e-4f));
+                              0.5f * h->inner_skin * (1.0f - 1.0e-4f),
+                              h->dd ? h->box_hi[0] - h->box_lo[0] : 0.f, h->dd ? h->box_hi[1] - h->box_lo[1] : 0.f,
+                              h->dd ? h->box_hi[2] - h->box_lo[2] : 0.f);
     HIP_TRY(hipGetLastError());
     h->forces_valid = false;
     if (!dual) h->moved_outside = true;     // ghosts moved without feeding their path accumulators
