@@ -21,18 +21,90 @@
 #include "mdx_internal.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <numeric>
 
 #define FAIL(code, msg) do { mdx_set_error(msg); return (code); } while (0)
 static inline unsigned div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
-struct ConsParams { float box[3], inv_box[3]; float tol; int max_iter; };
+struct ConsParams { float box[3], inv_box[3]; float tol; int max_iter; int settle; };
 
 __device__ __forceinline__ float3 mimg3(float3 d, const ConsParams& p) {
     if (p.box[0] > 0.f) d.x -= rintf(d.x * p.inv_box[0]) * p.box[0];
     if (p.box[1] > 0.f) d.y -= rintf(d.y * p.inv_box[1]) * p.box[1];
     if (p.box[2] > 0.f) d.z -= rintf(d.z * p.inv_box[2]) * p.box[2];
     return d;
+}
+
+// ---- rigid three-site water: analytic solution (SETTLE, Miyamoto & Kollman 1992) -----------------------------------
+// A cluster of three atoms with all three distances fixed, two equal legs from atom 0 and equal masses on atoms 1, 2
+// (every rigid water; OPC's M site is a virtual site, not a member) needs no iteration: the constrained triangle is the
+// canonical one rotated by three angles that follow in closed form from the old positions (which satisfy the
+// constraints) and the unconstrained new ones.  The Gauss-Seidel SHAKE sweep it replaces converges linearly (~12 sweeps to
+// 1e-5 in fp32, each a chain of dependent operations): at 1 M sites of rigid OPC the position stage took 82 us and the
+// velocity stage 68 us of a 1.05 ms step.  Other clusters (X-H groups of a solute) keep SHAKE / RATTLE.
+struct Triangle { float l01, l12; bool ok; };
+__device__ __forceinline__ Triangle rigid_triangle(const ConsGroup& cg, const float im[4]) {
+    Triangle t{0.f, 0.f, false};
+    if (cg.natoms != 3 || cg.ncons != 3 || !(im[0] > 0.f) || !(im[1] > 0.f) || im[1] != im[2]) return t;
+    float l01 = 0.f, l02 = 0.f, l12 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int a = min((int)cg.ca[c], (int)cg.cb[c]), b = max((int)cg.ca[c], (int)cg.cb[c]);
+        if (a == 0 && b == 1) l01 = cg.len[c];
+        else if (a == 0 && b == 2) l02 = cg.len[c];
+        else if (a == 1 && b == 2) l12 = cg.len[c];
+    }
+    t.l01 = l01; t.l12 = l12;
+    t.ok = l01 > 0.f && l02 > 0.f && l12 > 0.f && fabsf(l01 - l02) <= 1e-6f * l01 && l12 < 2.0f * l01;
+    return t;
+}
+__device__ __forceinline__ float3 cross3f(float3 a, float3 b) { return make_float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ float dot3f(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float3 unit3f(float3 a) { const float s = rsqrtf(dot3f(a, a)); return make_float3(a.x * s, a.y * s, a.z * s); }
+// xo: old positions (constraints satisfied), xn: unconstrained new positions, both relative to one origin; on success xn
+// holds the constrained positions.  false: degenerate input (a site moved by about a bond length) - the caller iterates.
+__device__ __forceinline__ bool settle_positions(const float3 xo[4], float3 xn[4], const float im[4], const Triangle& t) {
+    const float mO = 1.0f / im[0], mH = 1.0f / im[1], iM = 1.0f / (mO + 2.0f * mH);
+    const float rc = 0.5f * t.l12, hgt = sqrtf(t.l01 * t.l01 - rc * rc), ra = hgt * 2.0f * mH * iM, rb = hgt - ra;
+    const float3 b0 = make_float3(xo[1].x - xo[0].x, xo[1].y - xo[0].y, xo[1].z - xo[0].z);
+    const float3 c0 = make_float3(xo[2].x - xo[0].x, xo[2].y - xo[0].y, xo[2].z - xo[0].z);
+    const float wO = mO * iM, wH = mH * iM;
+    const float3 com = make_float3(wO * xn[0].x + wH * (xn[1].x + xn[2].x), wO * xn[0].y + wH * (xn[1].y + xn[2].y),
+                                   wO * xn[0].z + wH * (xn[1].z + xn[2].z));
+    const float3 a1 = make_float3(xn[0].x - com.x, xn[0].y - com.y, xn[0].z - com.z);
+    const float3 b1 = make_float3(xn[1].x - com.x, xn[1].y - com.y, xn[1].z - com.z);
+    const float3 c1 = make_float3(xn[2].x - com.x, xn[2].y - com.y, xn[2].z - com.z);
+    const float3 ez = unit3f(cross3f(b0, c0));
+    const float3 ex = unit3f(cross3f(a1, ez));
+    const float3 ey = cross3f(ez, ex);
+    const float xb0d = dot3f(b0, ex), yb0d = dot3f(b0, ey), xc0d = dot3f(c0, ex), yc0d = dot3f(c0, ey);
+    const float za1d = dot3f(a1, ez);
+    const float xb1d = dot3f(b1, ex), yb1d = dot3f(b1, ey), zb1d = dot3f(b1, ez);
+    const float xc1d = dot3f(c1, ex), yc1d = dot3f(c1, ey), zc1d = dot3f(c1, ez);
+    const float sinphi = za1d / ra, cp2 = 1.0f - sinphi * sinphi;
+    if (!(cp2 > 1e-6f)) return false;
+    const float cosphi = sqrtf(cp2);
+    const float sinpsi = (zb1d - zc1d) / (2.0f * rc * cosphi), cs2 = 1.0f - sinpsi * sinpsi;
+    if (!(cs2 > 1e-6f)) return false;
+    const float cospsi = sqrtf(cs2);
+    const float ya2d = ra * cosphi, xb2d = -rc * cospsi, t1 = -rb * cosphi, t2 = rc * sinpsi * sinphi;
+    const float yb2d = t1 - t2, yc2d = t1 + t2;
+    const float alpha = xb2d * (xb0d - xc0d) + yb0d * yb2d + yc0d * yc2d;
+    const float beta = xb2d * (yc0d - yb0d) + xb0d * yb2d + xc0d * yc2d;
+    const float gamma = xb0d * yb1d - xb1d * yb0d + xc0d * yc1d - xc1d * yc0d;
+    const float al2be2 = alpha * alpha + beta * beta, disc = al2be2 - gamma * gamma;
+    if (!(disc > 0.f) || !(al2be2 > 0.f)) return false;
+    const float sinthe = (alpha * gamma - beta * sqrtf(disc)) / al2be2, ct2 = 1.0f - sinthe * sinthe;
+    if (!(ct2 > 1e-6f)) return false;
+    const float costhe = sqrtf(ct2);
+    const float xa3 = -ya2d * sinthe, ya3 = ya2d * costhe, za3 = za1d;
+    const float xb3 = xb2d * costhe - yb2d * sinthe, yb3 = xb2d * sinthe + yb2d * costhe, zb3 = zb1d;
+    const float xc3 = -xb2d * costhe - yc2d * sinthe, yc3 = -xb2d * sinthe + yc2d * costhe, zc3 = zc1d;
+    xn[0] = make_float3(com.x + xa3 * ex.x + ya3 * ey.x + za3 * ez.x, com.y + xa3 * ex.y + ya3 * ey.y + za3 * ez.y, com.z + xa3 * ex.z + ya3 * ey.z + za3 * ez.z);
+    xn[1] = make_float3(com.x + xb3 * ex.x + yb3 * ey.x + zb3 * ez.x, com.y + xb3 * ex.y + yb3 * ey.y + zb3 * ez.y, com.z + xb3 * ex.z + yb3 * ey.z + zb3 * ez.z);
+    xn[2] = make_float3(com.x + xc3 * ex.x + yc3 * ey.x + zc3 * ez.x, com.y + xc3 * ex.y + yc3 * ey.y + zc3 * ez.y, com.z + xc3 * ex.z + yc3 * ey.z + zc3 * ez.z);
+    return true;
 }
 
 // ---- SHAKE: positions ---------------------------------------------------------------------------
@@ -70,7 +142,18 @@ __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_gro
         // (kcal/mol/A: im = 418.4/m, and the force acts through the half kick dt/2 and the drift dt) along
         // the OLD bond vector r; its contribution to sum r_i . F_i is G . (r_a - r_b) = 2 gk |r|^2 / dt^2.
         float wc = 0.f;
-        for (int it = 0; it < p.max_iter; ++it) {
+        bool settled = false;
+        if (p.settle && dt != 0.f) {      // (dt = 0 is the projection of caller-supplied geometry: its "old" positions are not on the constraints)
+            const Triangle tri = rigid_triangle(cg, im);
+            if (tri.ok && settle_positions(xo, xn, im, tri)) {
+                settled = true;
+                // the virial sum of the equivalent pair corrections: sum_k g_k |r_k|^2 = sum_i (dx_i / im_i) . x_old_i
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    wc += ((xn[k].x - xs[k].x) * xo[k].x + (xn[k].y - xs[k].y) * xo[k].y + (xn[k].z - xs[k].z) * xo[k].z) / im[k];
+            }
+        }
+        for (int it = 0; it < (settled ? 0 : p.max_iter); ++it) {
             bool done = true;
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
@@ -149,7 +232,47 @@ __global__ __launch_bounds__(128) void constrain_velocities_kernel(uint32_t n_gr
         }
         v0[k] = v[k];
     }
-    for (int it = 0; it < p.max_iter; ++it) {
+    bool solved = false;
+    if (p.settle && rigid_triangle(cg, im).ok) {
+        // three multipliers from one 3 x 3 system: the corrected velocities v_i - im_i sum_k s_ik tau_k r_k must have no
+        // component along any of the three bonds
+        float3 r[3]; float rhs[3]; int ia[3], ib[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ia[c] = cg.ca[c]; ib[c] = cg.cb[c];
+            r[c] = make_float3(x[ia[c]].x - x[ib[c]].x, x[ia[c]].y - x[ib[c]].y, x[ia[c]].z - x[ib[c]].z);
+            rhs[c] = dot3f(r[c], make_float3(v[ia[c]].x - v[ib[c]].x, v[ia[c]].y - v[ib[c]].y, v[ia[c]].z - v[ib[c]].z));
+        }
+        float A[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const float sa = (ia[k] == ia[l] ? 1.f : 0.f) - (ia[k] == ib[l] ? 1.f : 0.f);    // sign of constraint l on atom ia[k]
+                const float sb = (ib[k] == ia[l] ? 1.f : 0.f) - (ib[k] == ib[l] ? 1.f : 0.f);
+                A[k][l] = dot3f(r[k], r[l]) * (im[ia[k]] * sa - im[ib[k]] * sb);
+            }
+        const float det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                          A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+        if (fabsf(det) > 0.f) {
+            const float id = 1.0f / det;
+            float tau[3];
+            tau[0] = id * (rhs[0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (rhs[1] * A[2][2] - A[1][2] * rhs[2]) +
+                           A[0][2] * (rhs[1] * A[2][1] - A[1][1] * rhs[2]));
+            tau[1] = id * (A[0][0] * (rhs[1] * A[2][2] - A[1][2] * rhs[2]) - rhs[0] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                           A[0][2] * (A[1][0] * rhs[2] - rhs[1] * A[2][0]));
+            tau[2] = id * (A[0][0] * (A[1][1] * rhs[2] - rhs[1] * A[2][1]) - A[0][1] * (A[1][0] * rhs[2] - rhs[1] * A[2][0]) +
+                           rhs[0] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int a = ia[c], b = ib[c];
+                v[a].x -= tau[c] * im[a] * r[c].x; v[a].y -= tau[c] * im[a] * r[c].y; v[a].z -= tau[c] * im[a] * r[c].z;
+                v[b].x += tau[c] * im[b] * r[c].x; v[b].y += tau[c] * im[b] * r[c].y; v[b].z += tau[c] * im[b] * r[c].z;
+            }
+            solved = true;
+        }
+    }
+    for (int it = 0; it < (solved ? 0 : p.max_iter); ++it) {
         bool done = true;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
@@ -264,6 +387,8 @@ static ConsParams cons_params(const mdx_handle* h) {
     }
     p.tol = h->cfg.constraint_tol > 0.f ? h->cfg.constraint_tol : 1e-5f;
     p.max_iter = h->cfg.constraint_max_iter ? (int)h->cfg.constraint_max_iter : 64;
+    static const bool settle_env = [] { const char* e = std::getenv("MDX_SETTLE"); return !(e && e[0] == '0'); }();   // A/B knob
+    p.settle = settle_env ? 1 : 0;
     return p;
 }
 
