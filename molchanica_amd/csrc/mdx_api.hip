@@ -543,20 +543,28 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         const uint32_t chunk = std::min(std::min(remaining, h->cfg.chunk_steps), mdx_steps_to_next_event(h));
         const auto t_chunk = std::chrono::steady_clock::now();
         HIP_TRY(hipMemsetAsync(d.ctl, 0, sizeof(StepCtl), st));
-        // Velocity Verlet: without constraints the closing half kick of step s and the opening one of
-        // step s+1 are one pass (mode 1).  With constraints every step is kick-drift-SHAKE-forces-kick-
-        // RATTLE, so the velocity projection sits between the two half kicks exactly as in RATTLE.
+        // Velocity Verlet: the closing half kick of step s and the opening one of step s+1 are one pass (mode 1), with
+        // and without constraints.  RATTLE's velocity projection between the two half kicks removes components along
+        // the bonds at t + dt; left in, they displace the next drift along exactly the directions the next SHAKE corrects
+        // along (the bonds at t + dt are its "old" bonds, the mass weighting is the same), so its multipliers absorb them:
+        // the positions are the same, and SHAKE's dx / dt puts the half-step velocities back on the constraint surface.
+        // The projection therefore runs once, after the closing kick of the chunk, where velocities are read (kinetic
+        // energy, thermostats, download) - two launches per step less at the reference's default operating point.
+        // MDX_RATTLE_EVERY_STEP=1 keeps kick-drift-SHAKE-forces-kick-RATTLE per step for A/B.
         // Leapfrog and Langevin-middle carry half-step velocities: one pass per step (mode 1 / 3), SHAKE
         // folds its correction into them, and there is no closing kick.
+        static const bool rattle_every = [] { const char* e = std::getenv("MDX_RATTLE_EVERY_STEP"); return e && e[0] == '1'; }();
         const int integ = h->integrator;
         const bool vv = integ == MDX_INTEGRATOR_VERLET_VELOCITY;
-        const bool fused = vv && h->n_groups == 0;
+        const bool fused = vv && (h->n_groups == 0 || !rattle_every);
         for (uint32_t s = 0; s < chunk; ++s) {
             h->prof_tag = (int)s;
             h->lang_step = h->step_count + s;
             const int mode = !vv ? (integ == MDX_INTEGRATOR_LANGEVIN_MIDDLE ? 3 : 1) : ((s == 0 || !fused) ? 0 : 1);
             MDX_TRY(mdx_launch_integrate(h, mode, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
+            h->cons_full_kick = vv && mode == 1;
             MDX_TRY(mdx_launch_constrain_positions(h, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
+            h->cons_full_kick = false;
             // Langevin middle: friction and noise sit between the two half drifts, so SHAKE's dx/dt is not an
             // exact velocity projection; RATTLE the half-step velocities (same gate as SHAKE: it belongs to the
             // drift, which has happened even when the step's forces turn out to be gated off)
@@ -572,7 +580,10 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
             }
         }
         h->prof_tag = (int)chunk;
-        if (fused) MDX_TRY(mdx_launch_integrate(h, 2, dt, &d.ctl->disp2[chunk], nullptr, thr));
+        if (fused) {
+            MDX_TRY(mdx_launch_integrate(h, 2, dt, &d.ctl->disp2[chunk], nullptr, thr));
+            MDX_TRY(mdx_launch_constrain_velocities(h, &d.ctl->disp2[chunk], thr));     // (no-op without constraints)
+        }
         h->prof_tag = -1;
         if (h->dd) h->chunk_s = -1;
         MDX_TRY(ctl_to_host(h));

@@ -27,7 +27,7 @@
 #define FAIL(code, msg) do { mdx_set_error(msg); return (code); } while (0)
 static inline unsigned div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
-struct ConsParams { float box[3], inv_box[3]; float tol; int max_iter; int settle; };
+struct ConsParams { float box[3], inv_box[3]; float tol; int max_iter; int settle; float vir_scale; };
 
 __device__ __forceinline__ float3 mimg3(float3 d, const ConsParams& p) {
     if (p.box[0] > 0.f) d.x -= rintf(d.x * p.inv_box[0]) * p.box[0];
@@ -175,7 +175,9 @@ __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_gro
             if (done) break;
         }
         const float idt = dt != 0.f ? 1.0f / dt : 0.f;
-        if (cons_vir) cons_vir[g] = 2.0f * wc * idt * idt;
+        // (vir_scale: 2 when the correction answers the opening half kick alone - a force acting through dt/2 and the
+        // drift - and 1 when kick and drift of a fused step carried the velocity projection with them: through dt)
+        if (cons_vir) cons_vir[g] = p.vir_scale * wc * idt * idt;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k >= (int)cg.natoms) break;
@@ -490,8 +492,10 @@ int mdx_launch_constrain_positions(mdx_handle* h, float dt, const uint32_t* d_ga
                                    uint32_t* d_prune_out) {
     if (!h->n_groups) return MDX_OK;
     if (!h->dual_on) d_prune_out = nullptr;
+    ConsParams cp = cons_params(h);
+    cp.vir_scale = h->cons_full_kick ? 1.0f : 2.0f;
     hipLaunchKernelGGL(constrain_positions_kernel, dim3(div_up(h->n_groups, 128)), dim3(128), 0, h->stream, h->n_groups,
-                       h->d.cons_s, h->d.posq, h->d.vel, h->d.ref, dt, cons_params(h),
+                       h->d.cons_s, h->d.posq, h->d.vel, h->d.ref, dt, cp,
                        dt != 0.f ? h->d.cons_vir : nullptr,   // a dt = 0 projection (new coordinates, rescaled box) keeps the last step's virial
                        d_gate, d_disp_out, thr, d_prune_out, 0.5f * h->inner_skin * (1.0f - 1.0e-4f));
     HIP_TRY(hipGetLastError());

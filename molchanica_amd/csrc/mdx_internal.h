@@ -265,6 +265,7 @@ struct mdx_handle {
     int baro_kind = 0; float baro_p0 = 1.f, baro_tau = 5.f, baro_beta = 4.5e-5f; uint32_t baro_every = 25;
     double last_pressure = 0.0, last_mu = 1.0;
     bool force_zeroed = false;   // the integrate pass just enqueued cleared the force array (half-list kernel: skip the fill)
+    bool cons_full_kick = false; // the SHAKE pass about to be enqueued follows a fused full kick (closing + opening): its corrections are those of a force acting through dt
     bool bonded_fused = false;   // the pair launch just enqueued carried the bonded gather in extra workgroups: skip its own launch
     uint64_t rng_state = 0;
     bool zero_com = false;
