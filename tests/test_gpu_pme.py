@@ -28,9 +28,12 @@ def excluded_pairs(s):
     return pairs
 
 
-@pytest.mark.parametrize("which", ["water", "chain"])
-def test_spme_matches_numpy_restatement_and_ewald(mdx, orc, which):
+@pytest.mark.parametrize("which,side_stream", [("water", "0"), ("chain", "0"), ("chain", "1")])
+def test_spme_matches_numpy_restatement_and_ewald(mdx, orc, which, side_stream, monkeypatch):
+    """side_stream: the reciprocal-space chain beside the pair kernel on its own stream (the default from 65 k atoms up)
+    or on the handle's stream (the default below) - MDX_PME_OVERLAP is read when a handle sets its mesh up."""
     from oracle import pme_ref as P
+    monkeypatch.setenv("MDX_PME_OVERLAP", side_stream)
     s = systems.water_box(6, seed=3) if which == "water" else systems.small_solvated()
     L = float(s.box_hi[0])
     beta, grid = 0.40, (24, 24, 24) if which == "water" else (32, 32, 32)
