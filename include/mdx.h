@@ -348,7 +348,10 @@ int      mdx_flush_snapshot_queues(mdx_handle* h);       /* drop the stored snap
  * [ref: src/md/viewer.rs:374-394, 917-960; src/properties/water_sol.rs:268-300].  Here the system is one flat atom
  * array; the host says where its waters are - n_waters contiguous records of `sites_per_water` atoms in the order
  * O, H0, H1 (, M) starting at first_atom - and the library hands out the reference's views:
- *   mdx_water_download      md.water[i].{o,h0,h1,m}.posit / .force of the current state, [3 n_waters] floats each
+ *   mdx_water_download      md.water[i].{o,h0,h1,m}.posit / .force of the current state, [3 n_waters] floats each; positions
+ *                           come out with every molecule WHOLE (H0, H1, M in the periodic image next to their O: the flat
+ *                           array of mdx_download keeps each atom wrapped into the cell on its own); the same holds for
+ *                           mdx_snapshot_read_water
  *   mdx_snapshot_read_water water_o/h0/h1_posits of stored snapshot k (atom_posits = rows [0, first_atom) of its pos)
  * Hydrogen bonds: the detection rule lives in the absent crates (bio_files::bond_inference::h_bond_geometry_strength);
  * built here, switchable per handle: a hydrogen bound (bond or constraint) to a heavy atom flagged in

@@ -490,6 +490,27 @@ extern "C" int mdx_set_water_layout(mdx_handle* h, uint32_t first_atom, uint32_t
     return MDX_OK;
 }
 
+// The engine keeps every atom wrapped into the cell on its own, so a water near a face has its hydrogens on the far side.
+// The water views hand molecules out WHOLE: H0, H1 (and M) in the periodic image nearest to their oxygen - what a viewer
+// drawing O-H bonds needs (src/md/viewer.rs:378-394) and what a host computing intramolecular geometry expects.
+static void water_make_whole(const mdx_handle* h, const float* o, float* const* sites, uint32_t n_sites) {
+    const bool per_any = h->dd || h->per[0] || h->per[1] || h->per[2];
+    if (!per_any) return;
+    for (int d = 0; d < 3; ++d) {
+        if (!(h->dd || h->per[d])) continue;
+        const float L = h->box_hi[d] - h->box_lo[d];
+        if (!(L > 0.f)) continue;
+        for (uint32_t k = 0; k < n_sites; ++k) {
+            float* s = sites[k];
+            if (!s) continue;
+            for (uint32_t w = 0; w < h->n_waters; ++w) {
+                const float dx = s[3 * (size_t)w + d] - o[3 * (size_t)w + d];
+                s[3 * (size_t)w + d] -= L * std::rint(dx / L);
+            }
+        }
+    }
+}
+
 extern "C" int mdx_water_download(mdx_handle* h, int which, float* o, float* h0, float* h1, float* m) {
     if (!h || !o || !h0 || !h1) FAIL(MDX_EPARAM, "null argument");
     if (!h->n_waters) FAIL(MDX_EPARAM, "no water layout set (mdx_set_water_layout)");
@@ -502,6 +523,7 @@ extern "C" int mdx_water_download(mdx_handle* h, int which, float* o, float* h0,
     for (uint32_t w = 0; w < h->n_waters; ++w)
         for (uint32_t k = 0; k < h->water_sites; ++k)
             if (dst[k]) std::memcpy(dst[k] + 3 * (size_t)w, all.data() + 3 * ((size_t)h->water_first + (size_t)w * h->water_sites + k), 3 * sizeof(float));
+    if (which == MDX_POS) water_make_whole(h, o, dst + 1, h->water_sites - 1);
     return MDX_OK;
 }
 
@@ -533,6 +555,7 @@ extern "C" int mdx_snapshot_read_water(mdx_handle* h, uint32_t k, float* o, floa
     for (uint32_t w = 0; w < h->n_waters; ++w)
         for (uint32_t s3 = 0; s3 < 3; ++s3)
             std::memcpy(dst[s3] + 3 * (size_t)w, sn.pos.data() + 3 * ((size_t)h->water_first + (size_t)w * h->water_sites + s3), 3 * sizeof(float));
+    water_make_whole(h, o, dst + 1, 2);
     return MDX_OK;
 }
 

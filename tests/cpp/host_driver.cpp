@@ -131,10 +131,17 @@ int main() {
         const auto w = moved.water(MDX_POS);
         const auto x = moved.positions();
         expect(w.o.size() == box.sys.n_atoms && w.m.empty(), "md.water views have one row per water (3-site: no M)");
-        bool same = true;
+        // the oxygen is the flat array's; the hydrogens are the flat array's atoms in the periodic image next to their oxygen
+        // (the engine wraps every atom on its own; the views hand molecules out whole)
+        bool same = true, whole = true;
         for (uint32_t i = 0; i < box.sys.n_atoms / 3 && same; ++i)
-            for (int k = 0; k < 3; ++k) same = same && w.o[3 * i + k] == x[9 * i + k] && w.h0[3 * i + k] == x[9 * i + 3 + k] && w.h1[3 * i + k] == x[9 * i + 6 + k];
-        expect(same, "md.water[i].{o,h0,h1}.posit are views over the flat atom array");
+            for (int k = 0; k < 3; ++k) {
+                const float L = box.sys.box_hi[k] - box.sys.box_lo[k];
+                const float d0 = w.h0[3 * i + k] - x[9 * i + 3 + k], d1 = w.h1[3 * i + k] - x[9 * i + 6 + k];
+                same = same && w.o[3 * i + k] == x[9 * i + k] && std::fabs(d0 - L * std::round(d0 / L)) < 1e-4f && std::fabs(d1 - L * std::round(d1 / L)) < 1e-4f;
+                whole = whole && std::fabs(w.h0[3 * i + k] - w.o[3 * i + k]) < 1.3f && std::fabs(w.h1[3 * i + k] - w.o[3 * i + k]) < 1.3f;
+            }
+        expect(same && whole, "md.water[i].{o,h0,h1}.posit are views over the flat atom array, molecules whole");
         const uint64_t rb = moved.stats().rebuild_count;
         std::vector<float> lig(x.begin() + 30, x.begin() + 60);
         for (float& v : lig) v += 0.05f;

@@ -184,6 +184,8 @@ def test_water_views_and_hydrogen_bonds_of_a_snapshot(mdx):
     (src/md/viewer.rs:374-394, 917-960).  Views over the flat atom array, and the library's hydrogen-bond rule against
     a brute-force evaluation of the same rule."""
     s = systems.small_solvated()
+    Lb = np.array(s.box_hi, dtype=np.float64)
+    s.pos = np.mod(np.asarray(s.pos, dtype=np.float64) + 1.25, Lb).astype(np.float32)   # atom-wise wrapped, as a running box is: waters straddle the faces
     cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5)
     n_sol = int(s.mol_start[1])                       # one solute chain, then waters (O, H, H)
     n_w = (s.n_atoms - n_sol) // 3
@@ -198,11 +200,19 @@ def test_water_views_and_hydrogen_bonds_of_a_snapshot(mdx):
         pos, frc = md.positions(), md.forces()
         w, wf = md.water("posit"), md.water("force")
         snaps = md.snapshots
-    assert np.array_equal(w["o"], pos[n_sol::3]) and np.array_equal(w["h0"], pos[n_sol + 1::3]) and np.array_equal(w["h1"], pos[n_sol + 2::3])
+    assert np.array_equal(w["o"], pos[n_sol::3])
+    for key, off in (("h0", 1), ("h1", 2)):          # the same atoms, handed out WHOLE: in the image next to their oxygen
+        dw = w[key].astype(np.float64) - pos[n_sol + off::3]
+        assert np.abs(dw - np.round(dw / Lb) * Lb).max() < 1e-4
+        assert np.linalg.norm(w[key] - w["o"], axis=1).max() < 1.3
+    assert (np.abs(pos[n_sol + 1::3] - pos[n_sol::3]).max(axis=1) > 0.5 * Lb[0]).sum() > 5, "no water straddles a face in the flat array"
     assert np.array_equal(wf["h1"], frc[n_sol + 2::3])
     sn = snaps[-1]
     assert sn["step"] == 10 and sn["atom_posits"].shape == (n_sol, 3) and sn["water_o_posits"].shape == (n_w, 3)
-    assert np.array_equal(sn["water_h0_posits"], sn["all_posits"][n_sol + 1::3])
+    L = np.array(s.box_hi, dtype=np.float64)
+    dh = sn["water_h0_posits"].astype(np.float64) - sn["all_posits"][n_sol + 1::3]
+    assert np.abs(dh - np.round(dh / L) * L).max() < 1e-4      # the same atoms, handed out in the image next to their oxygen
+    assert np.linalg.norm(sn["water_h0_posits"] - sn["water_o_posits"], axis=1).max() < 1.3
     # brute force of the documented rule on the snapshot's coordinates
     P = sn["all_posits"].astype(np.float64)
     L = np.array(s.box_hi, np.float64) - np.array(s.box_lo, np.float64)
