@@ -34,9 +34,10 @@ template <int CTRL>
 __device__ __forceinline__ float quad_xadd(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
-constexpr int BONDED_LPA = 4;
-
-template <bool ENERGY>
+// BONDED_LPA lanes per atom: 4 when the system has chains (above), 2 for mixed and 1 for pure-solvent systems - a flexible
+// water atom has 2.3 roles, so with four lanes per atom most of them only read the offsets and leave (1 M-atom water:
+// 36.6 us with 4 lanes, 30.7 with 2, 27.8 with 1).
+template <bool ENERGY, int BONDED_LPA>
 __global__ __launch_bounds__(256) void bonded_gather_kernel(BondedArgs a) {
     if (a.gate && *a.gate > a.thr_bits) return;
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -51,8 +52,8 @@ __global__ __launch_bounds__(256) void bonded_gather_kernel(BondedArgs a) {
                 const RoleRec r = a.roles[k];
                 role_eval<ENERGY>(r, a.prm, self, a.posq, a.p, fx, fy, fz, en);
             }
-            fx = quad_xadd<0xB1>(fx); fy = quad_xadd<0xB1>(fy); fz = quad_xadd<0xB1>(fz);   // lane ^ 1
-            fx = quad_xadd<0x4E>(fx); fy = quad_xadd<0x4E>(fy); fz = quad_xadd<0x4E>(fz);   // lane ^ 2
+            if (BONDED_LPA >= 2) { fx = quad_xadd<0xB1>(fx); fy = quad_xadd<0xB1>(fy); fz = quad_xadd<0xB1>(fz); }   // lane ^ 1
+            if (BONDED_LPA == 4) { fx = quad_xadd<0x4E>(fx); fy = quad_xadd<0x4E>(fy); fz = quad_xadd<0x4E>(fz); }   // lane ^ 2
             if (q4 == 0) {
                 float4 f = a.force[s];
                 f.x += fx; f.y += fy; f.z += fz;
@@ -114,9 +115,20 @@ int mdx_launch_bonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32
     a.posq = h->d.posq; a.force = h->d.force; a.energy = h->d.energy; a.gate = d_gate; a.thr_bits = thr_bits;
     mdx_fill_bonded_params(h, a.p);
     mdx_prof_begin(h, energy ? 3 : 1);
-    const dim3 g((uint32_t)(((size_t)h->S * BONDED_LPA + 255) / 256)), b(256);
-    if (energy) hipLaunchKernelGGL(bonded_gather_kernel<true>, g, b, 0, h->stream, a);
-    else hipLaunchKernelGGL(bonded_gather_kernel<false>, g, b, 0, h->stream, a);
+    // lanes per atom by the mean role count of the slots (MDX_BONDED_LPA=2|4 forces it for A/B)
+    static const int lpa_env = [] { const char* e = std::getenv("MDX_BONDED_LPA"); return e ? std::atoi(e) : 0; }();
+    const int lpa = (lpa_env == 1 || lpa_env == 2 || lpa_env == 4) ? lpa_env : ((double)h->n_roles < 2.6 * (double)h->S ? 1 : ((double)h->n_roles < 6.0 * (double)h->S ? 2 : 4));
+    const dim3 g((uint32_t)(((size_t)h->S * lpa + 255) / 256)), b(256);
+    if (lpa == 1) {
+        if (energy) hipLaunchKernelGGL((bonded_gather_kernel<true, 1>), g, b, 0, h->stream, a);
+        else hipLaunchKernelGGL((bonded_gather_kernel<false, 1>), g, b, 0, h->stream, a);
+    } else if (lpa == 2) {
+        if (energy) hipLaunchKernelGGL((bonded_gather_kernel<true, 2>), g, b, 0, h->stream, a);
+        else hipLaunchKernelGGL((bonded_gather_kernel<false, 2>), g, b, 0, h->stream, a);
+    } else {
+        if (energy) hipLaunchKernelGGL((bonded_gather_kernel<true, 4>), g, b, 0, h->stream, a);
+        else hipLaunchKernelGGL((bonded_gather_kernel<false, 4>), g, b, 0, h->stream, a);
+    }
     mdx_prof_end(h);
     HIP_TRY(hipGetLastError());
     return MDX_OK;
