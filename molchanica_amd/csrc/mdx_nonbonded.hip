@@ -315,20 +315,25 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
     // the wave index is wave-uniform: say so, and tile number, list bounds and the chunk loop
     // live in SGPRs with scalar branches instead of VGPR compares and exec-mask loops
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int TPB = BW / WPT;                             // tiles per workgroup
+    // BW < WPT: the WPT waves of a tile sit in WPT / BW workgroups (systems of a few hundred tiles: with one workgroup per
+    // tile 370 tiles land on 256 CUs as one or two per CU and the launch lasts as long as the CUs that got two)
+    constexpr int SPLIT = BW < WPT ? WPT / BW : 1;
+    static_assert(SPLIT == 1 || HALF, "a tile split over workgroups returns its i-forces through atomics");
+    constexpr int TPB = SPLIT > 1 ? 1 : BW / WPT;             // tiles per workgroup
     const uint32_t ntiles = a.tile_order ? a.t_count : a.T;   // (a decomposed handle launches its interior and boundary tiles apart)
-    const uint32_t nblocks = (ntiles + TPB - 1) / TPB;
+    const uint32_t nblocks = SPLIT > 1 ? ntiles * SPLIT : (ntiles + TPB - 1) / TPB;
     const uint32_t per_xcd = (nblocks + 7) >> 3;
     // a decomposed rank's tile range is owned bricks (long lists) and halo shells (short lists) in spatial order: a
     // contiguous eighth per XCD would leave whole XCDs with halo tiles only, so there the tiles go round-robin
     const uint32_t blk = a.xcd_interleave ? blockIdx.x : (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (blk >= nblocks) return;                               // whole workgroup
-    const int tib = wave / WPT;                               // tile within the workgroup
-    const int part = wave % WPT;                              // which share of the tile's chunks
-    const bool t_ok = blk * TPB + tib < ntiles;               // (the last workgroup may have a tile too many)
+    const int tib = SPLIT > 1 ? 0 : wave / WPT;               // tile within the workgroup
+    const int part = SPLIT > 1 ? (int)(blk % SPLIT) * BW + wave : wave % WPT;   // which share of the tile's chunks
+    const uint32_t tidx = SPLIT > 1 ? blk / SPLIT : blk * TPB + tib;
+    const bool t_ok = tidx < ntiles;                          // (the last workgroup may have a tile too many)
     if (WPT == 1 && !t_ok) return;
     // a.T = the null tile: empty list, nothing stored
-    const uint32_t t = t_ok ? (a.tile_order ? __builtin_amdgcn_readfirstlane(a.tile_order[a.t_first + blk * TPB + tib]) : blk * TPB + tib) : a.T;
+    const uint32_t t = t_ok ? (a.tile_order ? __builtin_amdgcn_readfirstlane(a.tile_order[a.t_first + tidx]) : tidx) : a.T;
     const int ii = lane & 7, jj = lane >> 3;
 
     float xi[8], yi[8], zi[8], qi[8], sgi[8], epi[8], fx[8], fy[8], fz[8];
@@ -571,11 +576,11 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
     if (WPT > 1) {   // fixed-order sum of the waves' partial forces
         s_red[wave][0][lane] = ox; s_red[wave][1][lane] = oy; s_red[wave][2][lane] = oz;
         __syncthreads();
-        if (part == 0 && t_ok) {
-            const int w0 = tib * WPT;
+        if ((SPLIT > 1 ? wave == 0 : part == 0) && t_ok) {
+            const int w0 = SPLIT > 1 ? 0 : tib * WPT;
             ox = s_red[w0][0][lane]; oy = s_red[w0][1][lane]; oz = s_red[w0][2][lane];
 #pragma unroll
-            for (int w = 1; w < WPT; ++w) { ox += s_red[w0 + w][0][lane]; oy += s_red[w0 + w][1][lane]; oz += s_red[w0 + w][2][lane]; }
+            for (int w = 1; w < (SPLIT > 1 ? BW : WPT); ++w) { ox += s_red[w0 + w][0][lane]; oy += s_red[w0 + w][1][lane]; oz += s_red[w0 + w][2][lane]; }
             if (HALF) { unsafeAtomicAdd(fi, ox); unsafeAtomicAdd(fi + 1, oy); unsafeAtomicAdd(fi + 2, oz); }
             else a.force[t * MDX_TILE + lane] = make_float4(ox, oy, oz, 0.f);
         }
@@ -629,12 +634,12 @@ __device__ __forceinline__ void bonded_workgroup(const NbArgs& a, uint32_t wg, u
     }
 }
 
-template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF, bool ALCH = false, int DUAL = 0, bool FB = false>
-__global__ __launch_bounds__((WPT > NB_WAVES ? WPT : NB_WAVES) * 64, ((HALF && NB_HALF_FLUSH) || ENERGY) ? 3 : 4) void nb_cluster_kernel(NbArgs a) {
+template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF, bool ALCH = false, int DUAL = 0, bool FB = false, int SPLIT = 1>
+__global__ __launch_bounds__((SPLIT > 1 ? WPT / SPLIT : (WPT > NB_WAVES ? WPT : NB_WAVES)) * 64, ((HALF && NB_HALF_FLUSH) || ENERGY) ? 3 : 4) void nb_cluster_kernel(NbArgs a) {
     if (a.gate && *a.gate > a.thr_bits) return;
     static_assert(DUAL == 0 || (HALF && !ENERGY), "the dual list exists for the half-list force kernel");
     static_assert(!FB || DUAL != 0, "the bonded workgroups ride with the dual-list launches");
-    constexpr int BW = WPT > NB_WAVES ? WPT : NB_WAVES;       // waves per workgroup
+    constexpr int BW = SPLIT > 1 ? WPT / SPLIT : (WPT > NB_WAVES ? WPT : NB_WAVES);       // waves per workgroup
     if ((DUAL == 4 || FB) && blockIdx.x >= a.pair_grid) {
         // (a twin launch: the bonded workgroups run in whichever of the two the device executes)
         if (DUAL == 1 || DUAL == 2) {
@@ -689,6 +694,9 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
     // ones launch the two flavours back to back and the device runs exactly one (measured: merged +1 % at 23 k atoms,
     // -0.4 % at 1 M, where the merged kernel's 92 SGPRs / 127 VGPRs cost more than the ~4 us twin).  MDX_DUAL_MERGED=0: never merge.
     static const bool dual_merged = [] { const char* e = std::getenv("MDX_DUAL_MERGED"); return !(e && e[0] == '0'); }();
+    // below ~1000 tiles a tile's eight waves go to two workgroups of four (MDX_TILE_SPLIT=0 / 1 forces)
+    static const int split_env = [] { const char* e = std::getenv("MDX_TILE_SPLIT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    const bool split2 = split_env >= 0 ? split_env == 1 : (a.tile_order ? a.t_count : a.T) < 1024u;
     static const bool fb_all = [] { const char* e = std::getenv("MDX_FUSE_BONDED"); return e && e[0] == '2'; }();   // A/B: also the twin launches of the large classes
     // dual list: the inner-walk kernel and the pruning kernel back to back, the device runs exactly one of them
 #define NB_DUAL(G, S, D)                                                                                              \
@@ -711,6 +719,14 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
         if (h->alch_on && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true, true>), g, b, 0, h->stream, a); \
         else if (h->alch_on) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, true, true>), g, b, 0, h->stream, a); \
         else if (var == 1) hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, G, S>), g, b, 0, h->stream, a);     \
+        else if (half && a.inner && dual_merged && wpt == 8 && split2 && !ENERGY) {   /* a tile = two workgroups of four waves */ \
+            NbArgs af = a;                                                                                         \
+            const uint32_t nb2 = (a.tile_order ? a.t_count : a.T) * 2u;                                            \
+            af.pair_grid = ((nb2 + 7) / 8) * 8;                                                                    \
+            const dim3 gf(af.pair_grid + (a.b_S ? (uint32_t)(((size_t)a.b_S * 4 + 255) / 256) : 0u)), bf(256);     \
+            if (a.b_S) { hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, 4, false, 2>), gf, bf, 0, h->stream, af); h->bonded_fused = true; } \
+            else hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, 3, false, 2>), gf, bf, 0, h->stream, af); \
+        }                                                                                                          \
         else if (half && a.inner && dual_merged && wpt == 8 && a.b_S && !ENERGY) {                                 \
             NbArgs af = a; af.pair_grid = grid;                                                                    \
             const dim3 gf(grid + (uint32_t)(((size_t)a.b_S * 4 + bw * 64 - 1) / (bw * 64)));                       \
