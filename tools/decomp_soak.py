@@ -30,6 +30,11 @@ def case(name, s, cfg, dt, n_eq=2000, n_cmp=40, n_nve=400):
         print(f"   world {world}: e0 diff pot {r0['e0']['potential'] - e0['potential']:8.3f}  rms dev after {n_cmp} steps {rms_dev(r0['pos'], p_ref, L):.2e} A  dE over {n_nve} steps {t(q['e1']) - t(q['e0']):8.2f}  T {q['e1']['temperature']:.1f}  repartitions {q['stats']['repartitions']} local rebuilds {q['stats']['local_rebuilds']}", flush=True)
 
 rf = dict(coulomb_mode=1, lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5)
+if len(sys.argv) > 1 and sys.argv[1] == "water1M":
+    # the headline box at full size on 2 / 4 / 8 virtual ranks (fp32 coordinates in a 217 A box resolve 1.3e-5 A: two runs that
+    # round in different frames drift apart by ~1e-4 A in 60 steps whatever else they do)
+    case("water1M flexible TIP3P, shifted cutoff (bench configuration)", systems.BY_NAME["water1M"](), MdConfig(), 0.0005, n_eq=600, n_cmp=60, n_nve=300)
+    sys.exit(0)
 case("rigid OPC 16k sites RF dt 2 fs", systems.opc_water_box(16, seed=3), MdConfig(**rf), 0.002)
 case("flexible TIP3P 17k RF", systems.water_box(18, seed=5), MdConfig(**rf), 0.0005)
 case("solvated chain 400 RF", systems.small_solvated(n_chain=400, box=44.0), MdConfig(**rf), 0.0005)
