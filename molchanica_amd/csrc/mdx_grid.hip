@@ -236,6 +236,10 @@ __global__ void cell_rank_kernel(uint32_t N, const uint32_t* __restrict__ cell_o
     const uint32_t c = cell_of[o];
     const uint32_t b = cell_start[c], e = cell_start[c + 1];
     const float z = pos_orig[o].z;
+    // (a cell of thousands of members is not a liquid: non-finite coordinates are parked in cell 0 by the binning pass,
+    // which also raises the error the host returns after this kernel - keep the scatter order there instead of counting
+    // n^2 / 2 pairs, which for a box of NaNs would hold the device for minutes)
+    if (e - b > 4096u) { sorted_orig[p] = o; return; }
     uint32_t rank = 0;
     for (uint32_t j = b; j < e; ++j) {
         const uint32_t oj = unsorted[j];
