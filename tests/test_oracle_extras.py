@@ -176,3 +176,27 @@ def test_shrink_cell_rule(orc):
     assert np.allclose(x[0], pos[0], atol=1e-5) and np.allclose(x[1], nlo, atol=1e-4) and np.allclose(x[2], nhi, atol=1e-4)
     nlo2, nhi2, _, shrank2 = orc.shrink_cell_towards(tlo, thi, tlo, thi, 0.5, pos)
     assert not shrank2 and np.allclose(nlo2, tlo) and np.allclose(nhi2, thi)
+
+
+def test_oracle_handles_rigid_waters_wrapped_across_box_faces(orc):
+    """The GPU tests that found the virtual-site and halo image bugs of round 2 lean on the oracle for atom-wise wrapped
+    rigid waters: it takes the minimum image per atom pair and per constraint / site vector, so a water whose sites sit on
+    both sides of a face is the same molecule to it.  Energies and forces are invariant under wrapping, and 150 steps of
+    NVE at dt 2 fs conserve the total energy from the wrapped state."""
+    import numpy as np
+    from molchanica_amd import MdConfig, systems
+    s = systems.opc_water_box(5, seed=21)                         # 125 OPC waters, 15.5 A box
+    L = np.array(s.box_hi, dtype=np.float64)
+    cfg = MdConfig(lj_cutoff=6.0, coulomb_cutoff=6.0, skin=1.0, coulomb_mode=1)
+    x_whole = np.asarray(s.pos, dtype=np.float64) + 1.3
+    x_wrapped = np.mod(x_whole, L)
+    w = x_wrapped.reshape(-1, 4, 3)
+    assert (np.abs(w[:, 1:] - w[:, :1]).max(axis=(1, 2)) > 0.5 * L[0]).sum() >= 10
+    f0, e0 = orc.forces(s, cfg, pos=x_whole)
+    f1, e1 = orc.forces(s, cfg, pos=x_wrapped)
+    # (the oracle decides cut-off membership on canonical fp32 distances: a pair within rounding of the cut-off may flip)
+    assert np.abs(f0 - f1).max() < 1e-3 and abs(e0["potential"] - e1["potential"]) < 1e-2
+    v = np.asarray(s.vel, dtype=np.float64)
+    t0 = e1["potential"] + orc.kinetic(s, v)
+    x, v, e = orc.step(s, cfg, 0.002, 150, pos=x_wrapped, vel=v)
+    assert abs(e["potential"] + orc.kinetic(s, v) - t0) < 0.02 * orc.kinetic(s, v)
