@@ -188,15 +188,18 @@ def test_oracle_handles_rigid_waters_wrapped_across_box_faces(orc):
     s = systems.opc_water_box(5, seed=21)                         # 125 OPC waters, 15.5 A box
     L = np.array(s.box_hi, dtype=np.float64)
     cfg = MdConfig(lj_cutoff=6.0, coulomb_cutoff=6.0, skin=1.0, coulomb_mode=1)
-    x_whole = np.asarray(s.pos, dtype=np.float64) + 1.3
-    x_wrapped = np.mod(x_whole, L)
+    x_rel, v, _ = orc.step_thermo(s, cfg, 0.001, 400, 1, 300.0, 0.02, 1, 0)      # off the random-orientation lattice first
+    x_whole = x_rel + 1.3
+    for k in range(0, x_whole.shape[0], 4):                                       # every water whole, next to its oxygen ...
+        d = x_whole[k + 1:k + 4] - x_whole[k]
+        x_whole[k + 1:k + 4] -= np.round(d / L) * L
+    x_wrapped = np.mod(x_whole, L)                                                # ... and wrapped atom by atom
     w = x_wrapped.reshape(-1, 4, 3)
     assert (np.abs(w[:, 1:] - w[:, :1]).max(axis=(1, 2)) > 0.5 * L[0]).sum() >= 10
     f0, e0 = orc.forces(s, cfg, pos=x_whole)
     f1, e1 = orc.forces(s, cfg, pos=x_wrapped)
     # (the oracle decides cut-off membership on canonical fp32 distances: a pair within rounding of the cut-off may flip)
     assert np.abs(f0 - f1).max() < 1e-3 and abs(e0["potential"] - e1["potential"]) < 1e-2
-    v = np.asarray(s.vel, dtype=np.float64)
     t0 = e1["potential"] + orc.kinetic(s, v)
     x, v, e = orc.step(s, cfg, 0.002, 150, pos=x_wrapped, vel=v)
     assert abs(e["potential"] + orc.kinetic(s, v) - t0) < 0.02 * orc.kinetic(s, v)
