@@ -392,7 +392,7 @@ double   mdx_time_ps(const mdx_handle* h);
  *     mdx_download  gathers the global array on every rank
  * and these three are COLLECTIVE: every rank must make the same calls in the same order.  Constraints, virtual sites,
  * thermostats, every integrator and snapshots work on a decomposed handle (a constraint cluster / virtual-site family is
- * owned as a whole by one rank); the barostat, alchemical windows, external forces, the minimiser, uploads and the SPME
+ * owned as a whole by one rank); the barostat, alchemical windows, the minimiser, uploads and the SPME
  * reciprocal sum are refused (MDX_EPARAM) - configure those, and initial velocities, before joining.
  *
  * mdx_comm_unique_id: rank 0 draws the id (ncclGetUniqueId; librccl is dlopen'd on first use) and hands the 128 bytes

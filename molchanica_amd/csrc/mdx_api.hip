@@ -519,7 +519,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
     // external forces (held constant over the burst)  [ref: src/mol_alignment.rs:318-346]
     const bool had_ext = h->have_ext;
     if (ext_forces) {
-        if (h->n_local != h->N || h->dd) FAIL(MDX_EPARAM, "external forces are not supported on a decomposed handle");
+        if (h->n_local != h->N && !h->dd) FAIL(MDX_EPARAM, "external forces need the library's own decomposition (mdx_comm_init) on a narrowed handle");
         std::vector<float4> e4(h->N);
         for (uint32_t i = 0; i < h->N; ++i)
             e4[i] = make_float4(ext_forces[3 * i], ext_forces[3 * i + 1], ext_forces[3 * i + 2], 0.f);

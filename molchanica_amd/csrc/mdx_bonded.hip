@@ -82,14 +82,17 @@ __global__ __launch_bounds__(256) void bonded_gather_kernel(BondedArgs a) {
     }
 }
 
-__global__ void add_ext_kernel(uint32_t S, const uint32_t* __restrict__ orig_of, const float4* __restrict__ ext,
+// `ext` is in the caller's (global) atom order; `gid` maps a local atom to it (identity on a whole handle).  On a decomposed
+// handle every rank is given the same global array and adds the rows of the atoms it owns (a ghost's force is never used).
+__global__ void add_ext_kernel(uint32_t S, const uint32_t* __restrict__ orig_of, const uint32_t* __restrict__ gid,
+                               const uint8_t* __restrict__ slot_flags, const float4* __restrict__ ext,
                                float4* __restrict__ force, const uint32_t* gate, uint32_t thr_bits) {
     if (gate && *gate > thr_bits) return;
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
     uint32_t o = orig_of[s];
-    if (o == MDX_INVALID) return;
-    float4 f = force[s], e = ext[o];
+    if (o == MDX_INVALID || !(slot_flags[s] & 2u)) return;
+    float4 f = force[s], e = ext[gid[o]];
     f.x += e.x; f.y += e.y; f.z += e.z;
     force[s] = f;
 }
@@ -136,8 +139,8 @@ int mdx_launch_bonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32
 
 int mdx_launch_add_ext(mdx_handle* h, const uint32_t* d_gate, uint32_t thr_bits) {
     if (!h->have_ext) return MDX_OK;
-    hipLaunchKernelGGL(add_ext_kernel, dim3((h->S + 255) / 256), dim3(256), 0, h->stream, h->S, h->d.orig_of,
-                       h->d.ext_orig, h->d.force, d_gate, thr_bits);
+    hipLaunchKernelGGL(add_ext_kernel, dim3((h->S + 255) / 256), dim3(256), 0, h->stream, h->S, h->d.orig_of, h->d.gid,
+                       h->d.slot_flags, h->d.ext_orig, h->d.force, d_gate, thr_bits);
     HIP_TRY(hipGetLastError());
     return MDX_OK;
 }

@@ -524,7 +524,6 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
     if (h->n_local != h->N) { mdx_set_error("the handle already simulates a subset"); return bail(MDX_EPARAM); }
     if (h->alch_on) { mdx_set_error("alchemical windows are not supported on a decomposed handle"); return bail(MDX_EPARAM); }
     if (h->baro_kind) { mdx_set_error("the barostat is not supported on a decomposed handle"); return bail(MDX_EPARAM); }
-    if (h->have_ext) { mdx_set_error("external forces are not supported on a decomposed handle"); return bail(MDX_EPARAM); }
     if (hipSetDevice(h->device) != hipSuccess) { mdx_set_error("hipSetDevice failed"); return bail(MDX_EDEVICE); }
     const uint32_t N = h->N;
     MdxDecomp* dd = new MdxDecomp();

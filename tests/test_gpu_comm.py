@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 CFG = dict(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, chunk_steps=8)
 
 
-def run_ranks(system, cfg, world, n_steps, dt=0.0005, setup=None, want_forces=False):
+def run_ranks(system, cfg, world, n_steps, dt=0.0005, setup=None, want_forces=False, ext=None):
     """-> {rank: results}.  `setup(md)` configures a handle before it joins (thermostat, integrator, ...)."""
     from molchanica_amd.md_state import Fabric, MdState
     fabric = Fabric(world)
@@ -34,7 +34,7 @@ def run_ranks(system, cfg, world, n_steps, dt=0.0005, setup=None, want_forces=Fa
                 info = md.comm_info()
                 e0 = md.energy()
                 f0 = md.forces() if want_forces else None
-                md.step(dt, None, n_steps)
+                md.step(dt, ext, n_steps)
                 res[rank] = dict(pos=md.positions(), vel=md.velocities(), e0=e0, f0=f0, e1=md.energy(), stats=md.stats(),
                                  steps=md.step_count, info=info)
         except BaseException as e:   # pragma: no cover
@@ -92,6 +92,29 @@ def test_ranks_below_the_abi_match_single_gpu(reference, world):
     if world > 1:
         assert all(res[r]["stats"]["n_ghost"] > 0 for r in range(world))
         assert r0["stats"]["repartitions"] >= 2, "the run never repartitioned: migration is not covered"
+
+
+def test_external_forces_on_decomposed_handles():
+    """`md.step(dev, dt, Some(external_forces))` (src/mol_alignment.rs:349-356): every rank is handed the same per-atom array in
+    the caller's order and adds the rows of the atoms it owns."""
+    from molchanica_amd.md_state import MdState
+    s = systems.water_box(14, seed=8)
+    cfg = MdConfig(**CFG)
+    ext = np.zeros((s.n_atoms, 3), np.float32)
+    rng = np.random.default_rng(3)
+    pulled = rng.choice(s.n_atoms, 60, replace=False)
+    ext[pulled] = rng.normal(scale=40.0, size=(60, 3))               # kcal/mol/A: strong enough to show in 25 steps
+    with MdState(s, cfg) as md:
+        md.step(0.0005, ext, 25)
+        p_ref = md.positions().astype(np.float64)
+    with MdState(s, cfg) as md:
+        md.step(0.0005, None, 25)
+        p_free = md.positions().astype(np.float64)
+    L = np.array(s.box_hi, dtype=np.float64)
+    assert rms_dev(p_ref[pulled], p_free[pulled], L) > 1e-2          # the pull does something
+    for world in (2, 8):
+        res = run_ranks(s, cfg, world, 25, ext=ext)
+        assert rms_dev(res[0]["pos"], p_ref, L) < 2e-4, world
 
 
 def test_chain_solute_across_brick_faces():
@@ -278,9 +301,10 @@ def test_refusals_and_errors_on_decomposed_handles():
         with pytest.raises(ParamError):
             md.set_barostat(1, 1.0, 1.0)
         with pytest.raises(ParamError):
-            md.step(0.0005, np.zeros((s.n_atoms, 3), np.float32), 1)
+            md.minimize_energy(10)
+        md.step(0.0005, np.zeros((s.n_atoms, 3), np.float32), 1)   # external forces are served (test above)
         md.step(0.0005, None, 5)                               # a one-rank decomposition just runs
-        assert md.step_count == 5
+        assert md.step_count == 6
     small = systems.water_box(8, seed=1)                       # 24.8 A: too small to cut at rc 9 + skin 1.5
     with MdState(small, MdConfig(**CFG)) as md:
         with pytest.raises(ParamError, match="two images|too small"):
