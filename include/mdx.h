@@ -391,9 +391,10 @@ double   mdx_time_ps(const mdx_handle* h);
  *     mdx_energy    returns the totals of the whole box on every rank
  *     mdx_download  gathers the global array on every rank
  * and these three are COLLECTIVE: every rank must make the same calls in the same order.  Constraints, virtual sites,
- * thermostats, every integrator and snapshots work on a decomposed handle (a constraint cluster / virtual-site family is
- * owned as a whole by one rank); the barostat, alchemical windows, the minimiser, uploads and the SPME
- * reciprocal sum are refused (MDX_EPARAM) - configure those, and initial velocities, before joining.
+ * thermostats, every integrator, external forces, snapshots and the SPME reciprocal sum (a replicated mesh, all-reduced)
+ * work on a decomposed handle (a constraint cluster / virtual-site family is owned as a whole by one rank); the barostat,
+ * alchemical windows, the minimiser and uploads are refused (MDX_EPARAM) - minimise, upload and draw initial velocities
+ * before joining.
  *
  * mdx_comm_unique_id: rank 0 draws the id (ncclGetUniqueId; librccl is dlopen'd on first use) and hands the 128 bytes
  * to the other ranks by whatever means the host has.  mdx_comm_init is ncclCommInitRank + the first partition. */
