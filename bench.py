@@ -151,7 +151,14 @@ def main():
         if same_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # the launcher's group only carries the prepared state, the 128-byte RCCL id and the timing reduction: if its
+            # RCCL backend cannot come up, gloo does the same job (the library's own communicator is initialised separately)
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write(f"[bench rank {rank}] torch.distributed nccl backend failed ({type(e).__name__}: {e}); using gloo for the launcher's group\n")
+                dist.init_process_group("gloo")
+    pg_cpu = same_gpu or (world > 1 and dist.get_backend() == "gloo")    # tensors of the launcher's collectives live on the host
 
     from molchanica_amd import MdConfig, systems
     from molchanica_amd.md_state import MdState
@@ -184,7 +191,7 @@ def main():
             e_eq = {"temperature": 0.0}
         if world > 1:
             tp = torch.from_numpy(np.ascontiguousarray(pos_eq)); tv = torch.from_numpy(np.ascontiguousarray(vel_eq))
-            if not same_gpu:
+            if not pg_cpu:
                 tp, tv = tp.cuda(), tv.cuda()
             dist.broadcast(tp, 0); dist.broadcast(tv, 0)
             pos_eq, vel_eq = tp.cpu().numpy(), tv.cpu().numpy()
@@ -207,7 +214,7 @@ def main():
         if rank == 0:
             uid = torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8).clone()
         if world > 1:
-            uid = uid if same_gpu else uid.cuda()
+            uid = uid if pg_cpu else uid.cuda()
             dist.broadcast(uid, 0)
             uid = uid.cpu()
         transport = "RCCL"
@@ -227,7 +234,7 @@ def main():
             except Exception as e:  # noqa: BLE001 - reported, never swallowed
                 err = f"{type(e).__name__}: {e}"
             if world > 1:
-                bad = torch.tensor([1.0 if err else 0.0], device="cuda")
+                bad = torch.tensor([1.0 if err else 0.0], device="cpu" if pg_cpu else "cuda")
                 dist.all_reduce(bad, op=dist.ReduceOp.MAX)
                 if bad.item() > 0:
                     sys.stderr.write(f"[bench rank {rank}] RCCL transport unusable ({err or 'failed on another rank'}); "
@@ -268,7 +275,7 @@ def main():
 
     def max_over_ranks(x):
         if world > 1:
-            t = torch.tensor([x], dtype=torch.float64, device="cpu" if same_gpu else "cuda")
+            t = torch.tensor([x], dtype=torch.float64, device="cpu" if pg_cpu else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
         return x
