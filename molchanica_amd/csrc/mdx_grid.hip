@@ -421,6 +421,7 @@ __global__ void role_fill_kernel(uint32_t S, const uint32_t* __restrict__ orig_o
 // tile pair list
 // ================================================================================================
 constexpr int LB_WAVES = 4;
+constexpr int LB_REGIONS = 64;   // single-pass build: claim regions of the entry / mask arrays (one cursor line each)
 constexpr int LB_HASH = 1024;
 constexpr int LB_MAXFLAG = 512;
 constexpr int LB_PLAIN = 512;   // single-pass build: plain entries of a tile buffered in LDS before its slice of the list is claimed
@@ -469,8 +470,10 @@ struct ListArgs {
     ListCounts* counts; uint32_t* entry_cnt; uint32_t* mchunk_cnt;
     // fill pass in/out (the single-pass build writes them: a tile claims its slice with two atomics)
     uint32_t* entry_off; uint32_t* mchunk_off;
-    uint32_t* cursors;               // single pass: [0] entries claimed so far, [1] masked chunks claimed so far
-    uint32_t cap_entries, cap_mchunks;
+    // single pass: the entry and mask arrays are cut into n_regions equal regions, tile t claims from region t % n_regions with
+    // ONE returning 64-bit atomic (low word: entries, high word: masked chunks) on that region's own 128-byte line
+    unsigned long long* cursors;
+    uint32_t n_regions, region_cap_e, region_cap_m;
     uint2* entries; unsigned long long* masks;
     uint32_t* err;
     uint32_t null_cluster;
@@ -700,14 +703,17 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
         // claim this tile's slice of the entry array and of the mask array, then drain the LDS buffers into it
         bool fits = nm <= LB_MAXFLAG && np <= LB_PLAIN;
         if (!fits) atomicOr(a.err, 16u);
-        uint32_t eb_claim = 0, mb_claim = 0;
-        if (lane == 0 && fits) {
-            eb_claim = atomicAdd(a.cursors, nm_pad + np_pad);
-            mb_claim = atomicAdd(a.cursors + 1, nm_pad >> 3);
-        }
-        ebase = __shfl(eb_claim, 0); mbase = __shfl(mb_claim, 0);
-        if (fits && (ebase + nm_pad + np_pad > a.cap_entries || mbase + (nm_pad >> 3) > a.cap_mchunks)) {
-            atomicOr(a.err, 32u);      // the host reads the cursors, grows the arrays and repeats
+        // A returning atomic on one address is served every ~35 ns (tools/ubench/grid_barrier.hip): two per tile on one
+        // pair of cursors made 16 k tiles queue for 0.46 ms - the whole duration of this kernel at 1 M atoms, whatever its
+        // occupancy or tile order.  Regions give the claims n_regions lines to land on.
+        const uint32_t reg = t & (a.n_regions - 1u);
+        unsigned long long claim = 0ull;
+        if (lane == 0 && fits)
+            claim = atomicAdd(a.cursors + (size_t)reg * 16, ((unsigned long long)(nm_pad >> 3) << 32) | (unsigned long long)(nm_pad + np_pad));
+        const uint32_t eoff = __shfl((uint32_t)claim, 0), moff = __shfl((uint32_t)(claim >> 32), 0);
+        ebase = reg * a.region_cap_e + eoff; mbase = reg * a.region_cap_m + moff;
+        if (fits && (eoff + nm_pad + np_pad > a.region_cap_e || moff + (nm_pad >> 3) > a.region_cap_m)) {
+            atomicOr(a.err, 32u);      // the host falls back to count + fill, which sizes the arrays afresh
             fits = false;
         }
         if (lane == 0) {
@@ -1151,6 +1157,15 @@ static int readback(mdx_handle* h, const RbSrc& s) {
     return MDX_OK;
 }
 
+// totals of the single-pass build's region cursors (statistics): entries, masked chunks
+__global__ void cursor_sum_kernel(const unsigned long long* __restrict__ cursors, uint32_t* __restrict__ out) {
+    const unsigned long long c = cursors[(size_t)threadIdx.x * 16];
+    uint32_t e = (uint32_t)c, m = (uint32_t)(c >> 32);
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) { e += __shfl_xor(e, k); m += __shfl_xor(m, k); }
+    if (threadIdx.x == 0) { out[0] = e; out[1] = m; }
+}
+
 static float c_inner_skin(const mdx_config& c) { return c.inner_skin == 0.f ? 0.5f : c.inner_skin; }
 
 int mdx_rebuild(mdx_handle* h) {
@@ -1228,11 +1243,14 @@ int mdx_rebuild(mdx_handle* h) {
     // did not fit has an empty list (counts 0) by then, so what ran behind it was safe; count + fill then builds afresh.
     bool speculative = false, roles_done = false;
     if (d.entries && d.masks && h->cap_entries && h->cap_mchunks && T && !two_pass_env) {
-        if (!d.list_cursors) ALLOC(d.list_cursors, 2);
+        if (!d.list_cursors) ALLOC(d.list_cursors, LB_REGIONS * 32 + 2);     // 64 regions x one 128-B line, + the two totals
         HIP_TRY(hipMemsetAsync(d.pair_count, 0, sizeof(unsigned long long) * 2, st));
-        HIP_TRY(hipMemsetAsync(d.list_cursors, 0, sizeof(uint32_t) * 2, st));
-        a.cursors = d.list_cursors;
-        a.cap_entries = (uint32_t)std::min<uint64_t>(h->cap_entries, 0xFFFFFFFFull); a.cap_mchunks = h->cap_mchunks;
+        HIP_TRY(hipMemsetAsync(d.list_cursors, 0, sizeof(uint32_t) * (LB_REGIONS * 32 + 2), st));
+        a.cursors = reinterpret_cast<unsigned long long*>(d.list_cursors);
+        a.n_regions = 1;
+        while (a.n_regions < (uint32_t)LB_REGIONS && a.n_regions * 128u <= T) a.n_regions <<= 1;      // >= 64 tiles per region
+        a.region_cap_e = (uint32_t)(std::min<uint64_t>(h->cap_entries, 0xFFFFFFFFull) / a.n_regions) & ~7u;
+        a.region_cap_m = h->cap_mchunks / a.n_regions;
         a.list_grid = (div_up(T, LB_WAVES) + 7u) & ~7u;
         uint32_t rf_blocks = 0;
         if (h->n_roles) {      // bonded role lists into slot space: count + scan here, the fill as extra workgroups of the list build
@@ -1303,7 +1321,10 @@ int mdx_rebuild(mdx_handle* h) {
     HIP_TRY(hipGetLastError());
     unsigned long long npairs_pruned = 0;
     auto read_counts = [&]() -> int {
-        MDX_TRY(readback(h, RbSrc{{d.flags_dev, d.list_cursors, reinterpret_cast<const uint32_t*>(d.pair_count), nullptr}, {4, 2, 4, 0}}));
+        if (speculative) hipLaunchKernelGGL(cursor_sum_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<const unsigned long long*>(d.list_cursors),
+                                            d.list_cursors + LB_REGIONS * 32);
+        MDX_TRY(readback(h, RbSrc{{d.flags_dev, d.list_cursors ? d.list_cursors + LB_REGIONS * 32 : nullptr,
+                                   reinterpret_cast<const uint32_t*>(d.pair_count), nullptr}, {4, 2, 4, 0}}));
         for (int k = 0; k < 4; ++k) flags[k] = h->h_rb[k];
         if (speculative) {
             E = h->h_rb[4]; MC = h->h_rb[5];

@@ -158,7 +158,7 @@ struct DeviceState {
     uint32_t* mchunk_off = nullptr;     // [T+1]
     uint2*    entries = nullptr;        // [E]
     uint2*    entries_in = nullptr;     // [E] dual list: the inner list (masked run in place, plain run compacted per wave)
-    uint32_t* list_cursors = nullptr;   // [2] single-pass list build: entries / masked chunks claimed so far
+    uint32_t* list_cursors = nullptr;   // single-pass list build: 64 region cursors (u64: entries | masked chunks << 32), one 128-B line each, then the two totals
     uint32_t* inner_nch = nullptr;      // [T*8] dual list: chunk-loop bound per (tile, wave of the tile)
     unsigned long long* masks = nullptr; // [MC*64]
     // bonded terms as per-atom role lists: caller order (static) and slot order (per rebuild)
