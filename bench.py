@@ -39,7 +39,7 @@ B_ALG_INTEGRATE = 64.0         # R x,v,f (36) + 1/m (4), W x,v (24)
 B_ALG_BONDED_WATER = 52.0      # 36 + 16 t, t = 1 bonded term per atom in flexible water
 B_ALG_STEP_WATER = 170.0       # whole step, water box
 FLOP_PER_PAIR = 45.0
-NB_KERNEL_REV = "r02e"         # revision tag of the default pair kernel the cached PMC traffic figure belongs to
+NB_KERNEL_REV = "r02f"         # revision tag of the default pair kernel the cached PMC traffic figure belongs to
 
 
 def parse():
