@@ -419,6 +419,11 @@ int mdx_comm_init_null(mdx_handle* h, int rank, int world);
 /* Diagnostics: every transport entry point of a joined handle on its real wire (send/recv group to every rank incl. itself,
  * the small and the large all-reduce, the word all-gather), results checked.  Collective. */
 int mdx_comm_selftest(mdx_handle* h);
+/* Diagnostics of the error path: issues a send to a rank that does not exist INSIDE a send/recv group.  Returns MDX_OK
+ * when the transport behaved - it reported the failure, closed its group (no later call hangs in an open group) and
+ * refuses further traffic - and MDX_EDEVICE when it did not.  The handle's communicator is unusable afterwards:
+ * destroy the handle.  Not collective (nothing reaches the wire). */
+int mdx_comm_selftest_fault(mdx_handle* h);
 int mdx_comm_info(const mdx_handle* h, int* rank, int* world, int grid[3], uint32_t* n_owned, uint32_t* n_ghost, float* halo);
 
 /* ---- the building blocks underneath (kept for hosts that drive the decomposition themselves, and for the tests) ----

@@ -79,30 +79,54 @@ bool load_rccl() {
 struct RcclTransport : MdxTransport {
     ncclComm_t comm = nullptr;
     uint32_t* d_words = nullptr;   // [world + 1] all-gather scratch
+    bool dead = false;             // a call inside a send/recv group failed: the communicator is not used (or destroyed) again
     ~RcclTransport() override {
-        if (comm) (void)g_rccl.CommDestroy(comm);
+        // a communicator whose group failed may have operations queued that never complete: ncclCommDestroy would wait
+        // for them, so it is abandoned instead (the process is about to report the error and fall back or exit)
+        if (comm && !dead) (void)g_rccl.CommDestroy(comm);
         if (d_words) (void)hipFree(d_words);
     }
     const char* name() const override { return "rccl"; }
     int exchange(const float4* send, const std::vector<MdxSeg>& ssegs, float4* recv, const std::vector<MdxSeg>& rsegs,
                  hipStream_t stream) override {
+        if (dead) FAIL(MDX_EDEVICE, "rccl transport: an earlier send/recv group failed");
         NCCL_TRY(g_rccl.GroupStart());
-        for (const MdxSeg& s : ssegs)
-            if (s.nrows) NCCL_TRY(g_rccl.Send(send + s.row0, (size_t)s.nrows * 4, ncclFloat32, s.peer, comm, stream));
-        for (const MdxSeg& r : rsegs)
-            if (r.nrows) NCCL_TRY(g_rccl.Recv(recv + r.row0, (size_t)r.nrows * 4, ncclFloat32, r.peer, comm, stream));
-        NCCL_TRY(g_rccl.GroupEnd());
+        // Inside the group nothing may return early: a thread that leaves with its group open queues every later RCCL
+        // call - including ncclCommDestroy - into a group that is never closed.  The first error is remembered, the
+        // group is always closed, and the transport is marked dead.
+        int first = ncclSuccess;
+        const char* what = "";
+        for (const MdxSeg& s : ssegs) {
+            if (!s.nrows || first != ncclSuccess) continue;
+            first = g_rccl.Send(send + s.row0, (size_t)s.nrows * 4, ncclFloat32, s.peer, comm, stream);
+            if (first != ncclSuccess) what = "ncclSend";
+        }
+        for (const MdxSeg& r : rsegs) {
+            if (!r.nrows || first != ncclSuccess) continue;
+            first = g_rccl.Recv(recv + r.row0, (size_t)r.nrows * 4, ncclFloat32, r.peer, comm, stream);
+            if (first != ncclSuccess) what = "ncclRecv";
+        }
+        const int end = g_rccl.GroupEnd();
+        if (first == ncclSuccess && end != ncclSuccess) { first = end; what = "ncclGroupEnd"; }
+        if (first != ncclSuccess) {
+            dead = true;
+            mdx_set_error(std::string(what) + " (halo exchange group): " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(first) : "rccl error"));
+            return MDX_EDEVICE;
+        }
         return MDX_OK;
     }
     int all_reduce(void* dev, size_t n, int kind, hipStream_t stream) override {
+        if (dead) FAIL(MDX_EDEVICE, "rccl transport: an earlier send/recv group failed");
         NCCL_TRY(g_rccl.AllReduce(dev, dev, n, kind == 0 ? ncclFloat64 : ncclUint32, kind == 0 ? ncclSum : ncclMax, comm, stream));
         return MDX_OK;
     }
     int all_reduce_f32(float* dev, size_t n, hipStream_t stream) override {
+        if (dead) FAIL(MDX_EDEVICE, "rccl transport: an earlier send/recv group failed");
         NCCL_TRY(g_rccl.AllReduce(dev, dev, n, ncclFloat32, ncclSum, comm, stream));
         return MDX_OK;
     }
     int all_gather_u32(uint32_t mine, uint32_t* all, hipStream_t stream) override {
+        if (dead) FAIL(MDX_EDEVICE, "rccl transport: an earlier send/recv group failed");
         HIP_TRY(hipMemcpyAsync(d_words + world, &mine, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         NCCL_TRY(g_rccl.AllGather(d_words + world, d_words, 1, ncclUint32, comm, stream));
         HIP_TRY(hipMemcpyAsync(all, d_words, sizeof(uint32_t) * world, hipMemcpyDeviceToHost, stream));

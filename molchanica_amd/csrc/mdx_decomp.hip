@@ -636,6 +636,31 @@ __global__ void dd_selftest_fill_kernel(uint32_t n, float4* a, float seed) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = make_float4(seed + (float)i, 2.f * (float)i, -(float)i, 1.f);
 }
+extern "C" int mdx_comm_selftest_fault(mdx_handle* h) {
+    if (!h || !h->dd) FAIL(MDX_EPARAM, "the handle has not joined a communicator");
+    MdxDecomp* dd = h->dd;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = dd->comm_stream;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float4 *a = nullptr;
+    HIP_TRY(hipMalloc((void**)&a, sizeof(float4) * 64));
+    HIP_TRY(hipMemsetAsync(a, 0, sizeof(float4) * 64, st));
+    std::vector<MdxSeg> ss{{dd->world + 3, 0u, 16u}}, rs{{dd->world + 3, 32u, 16u}};   // a peer that does not exist
+    const int rc1 = dd->tr->exchange(a, ss, a, rs, st);
+    if (!dd->tr->delivers()) { (void)hipFree(a); return MDX_OK; }     // (the null transport has no wire to fail on)
+    const std::string first = mdx_last_error();
+    // the group must be closed and the transport must refuse what follows instead of queueing it
+    std::vector<MdxSeg> ok_s{{dd->rank, 0u, 16u}}, ok_r{{dd->rank, 32u, 16u}};
+    const int rc2 = dd->tr->exchange(a, ok_s, a, ok_r, st);
+    const hipError_t sync = hipStreamSynchronize(st);
+    (void)hipFree(a);
+    if (rc1 == MDX_OK) FAIL(MDX_EDEVICE, "selftest_fault: a send to a non-existent rank was accepted");
+    if (rc2 == MDX_OK) FAIL(MDX_EDEVICE, "selftest_fault: the transport kept going after a failed group");
+    if (sync != hipSuccess) FAIL(MDX_EDEVICE, "selftest_fault: the communication stream did not drain");
+    mdx_set_error("selftest_fault: reported as expected: " + first);
+    return MDX_OK;
+}
+
 extern "C" int mdx_comm_selftest(mdx_handle* h) {
     if (!h || !h->dd) FAIL(MDX_EPARAM, "the handle has not joined a communicator");
     MdxDecomp* dd = h->dd;

@@ -131,7 +131,11 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
     const float s2 = sig * sig * rinv2;
     const float s6 = s2 * s2 * s2;
     const float es6 = eps * s6;
+#ifdef NB_EXP_NOLJ
+    const float flj_r2 = 0.f;
+#else
     const float flj_r2 = es6 * (2.0f * s6 - 1.0f);  // 24 eps (2 s12 - s6)      [force * r^2]
+#endif
     const float qq = qi * pj.w;                     // k_e q_i q_j
     float fc_r2;                                    // Coulomb force * r^2
     if (COUL == CM_SHIFTED) fc_r2 = qq * rinv;
@@ -501,7 +505,11 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
                 if (ii < 3) {
                     const float v = ii == 0 ? g[0] : (ii == 1 ? g[1] : g[2]);
                     if (NB_HALF_FLUSH) reinterpret_cast<float*>(sg)[(e * 8 + jj) * 4 + ii] = -v;
+#ifdef NB_EXP_NOATOMIC
+                    else if (v == 1.2345e30f) unsafeAtomicAdd(fbase + (size_t)__builtin_amdgcn_readlane(cur_jc, e * 8) * (MDX_CLUSTER * 4) + jj * 4 + ii, -v);
+#else
                     else unsafeAtomicAdd(fbase + (size_t)__builtin_amdgcn_readlane(cur_jc, e * 8) * (MDX_CLUSTER * 4) + jj * 4 + ii, -v);
+#endif
                 }
             }
         }

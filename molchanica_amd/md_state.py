@@ -135,6 +135,7 @@ def load_library():
     lib.mdx_comm_init_null.argtypes = [H, C.c_int, C.c_int]
     lib.mdx_comm_init_shm.argtypes = [H, C.c_char_p, C.c_int, C.c_int]
     lib.mdx_comm_selftest.argtypes = [H]
+    lib.mdx_comm_selftest_fault.argtypes = [H]
     lib.mdx_comm_info.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _u32p, _u32p, _fp]
     _lib = lib
     return lib
@@ -419,6 +420,11 @@ class MdState:
     def comm_selftest(self):
         """Every transport entry point on the real wire, results checked (collective)."""
         _check(load_library().mdx_comm_selftest(self._h))
+
+    def comm_selftest_fault(self):
+        """Forces a failing call inside a send/recv group and checks that the transport reports it, closes the group and
+        refuses further traffic.  The communicator is unusable afterwards: close the handle."""
+        _check(load_library().mdx_comm_selftest_fault(self._h))
 
     def comm_info(self) -> dict:
         r, w, g = C.c_int(), C.c_int(), (C.c_int * 3)()

@@ -330,6 +330,31 @@ def test_transport_selftest_on_the_fabric(world):
     assert not errs, errs
 
 
+def test_rccl_failed_group_is_reported_not_hung():
+    """A send/recv that fails INSIDE ncclGroupStart / ncclGroupEnd (here: a peer that does not exist) must come back as an
+    error with the group closed: the transport then refuses further traffic and destroying the handle does not wait on an
+    open group (round-2 advisor finding: the early return left the thread's group open)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        from molchanica_amd import MdConfig, systems
+        from molchanica_amd.md_state import MdState, DeviceError, comm_unique_id
+        s = systems.water_box(8, seed=2)
+        cfg = MdConfig(lj_cutoff=7.0, coulomb_cutoff=7.0, skin=1.5)
+        md = MdState(s, cfg)
+        md.comm_init(comm_unique_id(), 0, 1)
+        md.comm_selftest()
+        md.comm_selftest_fault()     # raises unless the transport reported the failure, closed the group, refused the next call
+        print("REPORTED")
+        md.close()
+        print("CLOSED")
+    """) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)   # a hang is the failure mode
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "REPORTED" in r.stdout and "CLOSED" in r.stdout, r.stdout + r.stderr[-2000:]
+
+
 def test_rccl_transport_single_rank_selftest():
     """The RCCL leg itself (dlopen of librccl, ncclGetUniqueId, ncclCommInitRank, the all-reduce and all-gather wrappers)
     with the one rank a single-GPU box allows: a world-1 communicator runs the decomposed step loop and reports totals."""
