@@ -37,6 +37,7 @@ FP32_PEAK_TFLOPS = 157.3
 B_ALG_NONBONDED = 32.0         # R x(12)+q(4)+type(4), W f(12)  per atom per launch
 B_ALG_INTEGRATE = 64.0         # R x,v,f (36) + 1/m (4), W x,v (24)
 B_ALG_BONDED_WATER = 52.0      # 36 + 16 t, t = 1 bonded term per atom in flexible water
+B_ALG_FUSED_WATER = 116.0      # bonded gather + kick + drift as one pass: the two figures above together
 B_ALG_STEP_WATER = 170.0       # whole step, water box
 FLOP_PER_PAIR = 45.0
 NB_KERNEL_REV = "r02f"         # revision tag of the default pair kernel the cached PMC traffic figure belongs to
@@ -53,6 +54,11 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=100, help="steps of the cpu_baseline leg (SURVEY 8d: 100 at the 1 M-atom box)")
     ap.add_argument("--cpu-kind", default="port-production", choices=["port-production", "port"],
                     help="port-production: oracle/cpu_production.c (fp32, half Verlet list reused across steps); port: the fp64 parity oracle")
+    ap.add_argument("--reference-cmd", default="",
+                    help="SURVEY 8d's slot for the real reference: a command line (no shell) that runs --reference-steps MD steps of "
+                         "the same workload on the host CPU (e.g. a headless build of the reference's md loop); it is timed as a "
+                         "child process and reported as cpu_baseline.kind = 'reference' instead of this repo's CPU port")
+    ap.add_argument("--reference-steps", type=int, default=100, help="steps the --reference-cmd run performs")
     ap.add_argument("--tail-steps", type=int, default=-1,
                     help="untimed-for-value tail with natural rebuilds and energies every 100 steps; -1 = 1000 when --steps < 1000, else 0")
     ap.add_argument("--nb-variant", type=int, default=0)
@@ -92,6 +98,23 @@ def cpu_baseline_production(system, cfg, dt, n_steps):
                   f"reused across steps ({builds} list builds incl. the first), Newton-3 pair loop, energies every 100 steps, "
                   f"gcc -O3 -march=native, OpenMP over all host cores, {el:.1f} s",
     }
+
+
+def cpu_baseline_reference(cmd, n_atoms, n_steps):
+    """Times an external reference run (`--reference-cmd`): the command is started as a child process without a
+    shell, and must perform n_steps MD steps of the same workload on the host cores.  Nothing in this repository produces such
+    a binary (the reference's engine is a Rust crate that is not in its tree): the slot is for a maintainer who has one."""
+    import shlex
+    import subprocess
+    argv = shlex.split(cmd)
+    t0 = time.perf_counter()
+    r = subprocess.run(argv, capture_output=True, text=True)
+    el = time.perf_counter() - t0
+    if r.returncode != 0:
+        raise RuntimeError(f"--reference-cmd exited with {r.returncode}: {r.stderr[-400:]}")
+    return {"value": n_atoms * n_steps / el, "unit": "atom-updates/s", "steps_per_s": n_steps / el,
+            "cores": os.cpu_count(), "kind": "reference",
+            "sample": f"{n_steps} steps by the external command {argv[0]!r} (wall time of the child process, start-up included), {el:.1f} s"}
 
 
 def cpu_baseline(system, cfg, dt, n_steps):
@@ -148,16 +171,18 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if same_gpu:
-            dist.init_process_group("gloo")
+        # The launcher's group only carries the prepared state, the 128-byte RCCL id and the timing reduction (the library's
+        # own communicator is initialised separately).  The backend is chosen BEFORE the one init call and alike on every
+        # rank: from MDX_BENCH_PG_BACKEND if set, else "nccl" when torch was built with it, else "gloo".  (A second
+        # init_process_group after a failed one cannot work - the env:// rendezvous is consumed - and a per-rank fallback
+        # could leave the ranks on different backends.)
+        backend = os.environ.get("MDX_BENCH_PG_BACKEND", "")
+        if not backend:
+            backend = "gloo" if (same_gpu or not dist.is_nccl_available()) else "nccl"
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
-            # the launcher's group only carries the prepared state, the 128-byte RCCL id and the timing reduction: if its
-            # RCCL backend cannot come up, gloo does the same job (the library's own communicator is initialised separately)
-            try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            except Exception as e:  # noqa: BLE001
-                sys.stderr.write(f"[bench rank {rank}] torch.distributed nccl backend failed ({type(e).__name__}: {e}); using gloo for the launcher's group\n")
-                dist.init_process_group("gloo")
+            dist.init_process_group(backend)
     pg_cpu = same_gpu or (world > 1 and dist.get_backend() == "gloo")    # tensors of the launcher's collectives live on the host
 
     from molchanica_amd import MdConfig, systems
@@ -313,10 +338,16 @@ def main():
         st_nb = st
     # bonded / integrate kernel times: a short tail outside the timed region with every kernel bracketed
     prof(1)
+    st_pre = stats()
     stepper(48)
     sync()
     st_tail = stats()
     prof(0)
+    # the large classes run bonded gather + kick + drift as ONE pass on 15 steps of a 16-step chunk: its own timer
+    fused_n = st_tail.get("fused_launches", 0) - st_pre.get("fused_launches", 0)
+    fused_ms = (st_tail.get("fused_ms_sum", 0.0) - st_pre.get("fused_ms_sum", 0.0)) / fused_n if fused_n else None
+    streaming_ms_per_step = ((st_tail["bonded_ms_sum"] - st_pre["bonded_ms_sum"]) + (st_tail["integ_ms_sum"] - st_pre["integ_ms_sum"])
+                             + (st_tail.get("fused_ms_sum", 0.0) - st_pre.get("fused_ms_sum", 0.0))) / 48.0
     if args.profile_level == 0:
         st_nb = st_tail
 
@@ -397,20 +428,35 @@ def main():
             "bonded_gather_kernel": ({"bound": "hbm", "bytes_per_atom": B_ALG_BONDED_WATER, "launch_ms": bonded_ms,
                                       "achieved": gbs(B_ALG_BONDED_WATER, bonded_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": gbs(B_ALG_BONDED_WATER, bonded_ms) / HBM_PEAK_GBS}
-                                     if args.workload == "water1M" else {"launch_ms": bonded_ms, "achieved": None})},
+                                     if args.workload == "water1M" else {"launch_ms": bonded_ms, "achieved": None}),
+            # steps 1 .. 15 of a 16-step chunk: bonded gather + full kick + drift in one pass (mdx_integrate.hip); the two
+            # kernels above then run once per chunk (the opening half kick, the chunk's last bonded call, the closing kick)
+            "bonded_integrate_kernel": ({"bound": "hbm", "bytes_per_atom": B_ALG_FUSED_WATER, "launch_ms": fused_ms,
+                                         "achieved": gbs(B_ALG_FUSED_WATER, fused_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": gbs(B_ALG_FUSED_WATER, fused_ms) / HBM_PEAK_GBS, "launches_of_48_steps": fused_n}
+                                        if (fused_ms and args.workload == "water1M") else ({"launch_ms": fused_ms} if fused_ms else None))},
         "valu": {"pair_evals_per_launch": pair_evals,
                  "pair_evals_per_s": pair_evals / (nb_ms * 1e-3) if nb_ms > 0 else 0.0,
                  "algorithmic_tflops": alg_tflops, "peak_tflops": FP32_PEAK_TFLOPS,
                  "frac": alg_tflops / FP32_PEAK_TFLOPS if alg_tflops is not None else None},
         "step_hbm_frac": B_ALG_STEP_WATER * value / (world * HBM_PEAK_GBS * 1e9) if args.workload == "water1M" else None,
-        "kernel_ms": {"nonbonded": nb_ms, "bonded": bonded_ms, "integrate": integ_ms,
+        "kernel_ms": {"nonbonded": nb_ms, "bonded": bonded_ms, "integrate": integ_ms, "bonded_integrate_fused": fused_ms,
+                      "bonded_plus_integrate_per_step": streaming_ms_per_step,
                       "rebuild_total": st_nb["rebuild_ms_sum"] - st0["rebuild_ms_sum"]},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        if args.cpu_kind == "port-production" and not args.pme:
-            out["cpu_baseline"] = cpu_baseline_production(system, cfg, args.dt, args.cpu_steps)
-        else:
-            out["cpu_baseline"] = cpu_baseline(system, cfg, args.dt, min(args.cpu_steps, 10))
+        # the GPU measurement above must reach the driver whatever happens to the CPU leg (a failed -march=native build,
+        # a missing compiler on the box): its failure is reported inside the JSON line, not instead of it
+        try:
+            if args.reference_cmd:
+                out["cpu_baseline"] = cpu_baseline_reference(args.reference_cmd, n_atoms, args.reference_steps)
+            elif args.cpu_kind == "port-production" and not args.pme:
+                out["cpu_baseline"] = cpu_baseline_production(system, cfg, args.dt, args.cpu_steps)
+            else:
+                out["cpu_baseline"] = cpu_baseline(system, cfg, args.dt, min(args.cpu_steps, 10))
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"value": None, "unit": "atom-updates/s", "cores": os.cpu_count(), "kind": args.cpu_kind,
+                                   "sample": None, "error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -187,6 +187,8 @@ typedef struct mdx_stats {
     uint64_t repartitions;      /* times the ranks re-derived owners / ghosts / halo lists from the gathered state */
     uint64_t local_rebuilds;    /* stale lists rebuilt on the unchanged owned + ghost set */
     double   repartition_ms_sum;
+    /* step loop of the large classes: bonded gather + full kick + drift as one pass (not counted under bonded / integ) */
+    double   fused_ms_sum;  uint64_t fused_launches;
 } mdx_stats;
 
 typedef struct mdx_handle mdx_handle;

@@ -16,6 +16,8 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <dlfcn.h>
+#include <mutex>
 #include <unordered_map>
 
 static thread_local std::string g_last_error;
@@ -138,7 +140,7 @@ int mdx_check_box(const mdx_handle* h, const float* lo, const float* hi) { retur
 static void free_device(mdx_handle* h) {
     DeviceState& d = h->d;
     void* ptrs[] = {d.o_qs, d.o_lj, d.o_invm, d.o_mass, d.o_q, d.o_lj_raw, d.excl_off, d.excl_idx, d.pos_orig,
-                    d.vel_orig, d.ext_orig, d.posq, d.lj, d.vel, d.force, d.ref, d.orig_of, d.slot_of, d.gid, d.lflag,
+                    d.vel_orig, d.ext_orig, d.posq, d.posq_alt, d.lj, d.vel, d.force, d.ref, d.orig_of, d.slot_of, d.gid, d.lflag,
                     d.slot_flags, d.cell_of,
                     d.cell_count, d.cell_start, d.cell_cursor, d.sorted_orig, d.sorted_tmp, d.col_tiles, d.tile_start,
                     d.tile_col, d.scan_tmp, d.cl_lo, d.cl_hi, d.list_counts, d.entry_cnt, d.entry_off,
@@ -285,15 +287,19 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
                 recs[cur[at[r]]++] = rec;
             }
         };
+        // an atom's roles are ordered by kind, the expensive kinds first (dihedrals, angles, bonds, 1-4 pairs): the lanes of a
+        // wave walk their lists in step, and role i of neighbouring atoms is then mostly the same kind - in water (angle, bond,
+        // bond) for an oxygen and (angle, bond) for a hydrogen, where (bond, bond, angle) / (bond, angle) made every wave run
+        // both branches at i = 1 and i = 2
+        for (uint32_t k = 0; k < s->n_dihedrals; ++k)
+            add_term(s->dihedral_idx + 4 * k, 4, ROLE_DIHEDRAL, s->dihedral_v[k], s->dihedral_phase[k],
+                     (float)s->dihedral_n[k]);
+        for (uint32_t k = 0; k < s->n_angles; ++k)
+            add_term(s->angle_idx + 3 * k, 3, ROLE_ANGLE, s->angle_k[k], s->angle_theta0[k], 0.f);
         for (uint32_t k = 0; k < s->n_bonds; ++k) {
             if (s->bond_idx[2 * k] == s->bond_idx[2 * k + 1]) FAIL(MDX_EPARAM, "bond of an atom with itself");
             add_term(s->bond_idx + 2 * k, 2, ROLE_BOND, s->bond_k[k], s->bond_r0[k], 0.f);
         }
-        for (uint32_t k = 0; k < s->n_angles; ++k)
-            add_term(s->angle_idx + 3 * k, 3, ROLE_ANGLE, s->angle_k[k], s->angle_theta0[k], 0.f);
-        for (uint32_t k = 0; k < s->n_dihedrals; ++k)
-            add_term(s->dihedral_idx + 4 * k, 4, ROLE_DIHEDRAL, s->dihedral_v[k], s->dihedral_phase[k],
-                     (float)s->dihedral_n[k]);
         for (uint32_t k = 0; k < s->n_pairs14; ++k) {
             const uint32_t a = s->pairs14_idx[2 * k], b = s->pairs14_idx[2 * k + 1];
             const float sa = ljraw[a].x, sb = ljraw[b].x;
@@ -410,6 +416,7 @@ static int ctl_to_host(mdx_handle* h) {
 }
 
 static int compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint32_t thr) {
+    MdxRange range_forces(energy ? "mdx forces+energies" : "mdx forces");
     MDX_TRY(mdx_launch_vsite_construct(h, gate, thr));     // massless sites follow their parents
     bool split = false;
     if (h->dd && h->dd->halo_pending) {                    // decomposed handle, step loop: ghost positions travel now
@@ -429,8 +436,11 @@ static int compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint
             MDX_TRY(rc_int);
             HIP_TRY(hipEventRecord(h->dd->ev_interior, h->dd->side_stream));
         }
-        MDX_TRY(mdx_dd_halo_begin(h));                     // pack + ncclSend/ncclRecv group
-        MDX_TRY(mdx_dd_halo_end(h));                       // unpack: ghost positions, the peers' flag words
+        {
+            MdxRange range_halo("mdx halo exchange");
+            MDX_TRY(mdx_dd_halo_begin(h));                 // pack + ncclSend/ncclRecv group
+            MDX_TRY(mdx_dd_halo_end(h));                   // unpack: ghost positions, the peers' flag words
+        }
     }
     if (h->pme_on && h->pme_overlap) {                     // SPME reciprocal space on its side stream, beside the pair kernel
         MDX_TRY(mdx_pme_fork(h));
@@ -468,6 +478,34 @@ static int ensure_ready(mdx_handle* h) {
     return MDX_OK;
 }
 
+// ---- rocprof markers -------------------------------------------------------------------------
+namespace {
+struct RoctxApi { int state = 0; int (*push)(const char*) = nullptr; int (*pop)() = nullptr; };   // state: 0 unknown, 1 on, 2 off
+RoctxApi g_roctx;
+std::mutex g_roctx_mutex;
+bool roctx_ready() {
+    if (g_roctx.state) return g_roctx.state == 1;
+    std::lock_guard<std::mutex> lk(g_roctx_mutex);
+    if (g_roctx.state) return g_roctx.state == 1;
+    const char* e = std::getenv("MDX_ROCTX");
+    int st = 2;
+    if (e && e[0] == '1') {
+        const char* names[] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"};
+        for (const char* n : names) {
+            void* lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) continue;
+            *(void**)(&g_roctx.push) = dlsym(lib, "roctxRangePushA");
+            *(void**)(&g_roctx.pop) = dlsym(lib, "roctxRangePop");
+            if (g_roctx.push && g_roctx.pop) { st = 1; break; }
+        }
+    }
+    g_roctx.state = st;
+    return st == 1;
+}
+}  // namespace
+void mdx_range_push(const char* name) { if (roctx_ready()) (void)g_roctx.push(name); }
+void mdx_range_pop() { if (roctx_ready()) (void)g_roctx.pop(); }
+
 // ---- profiling -------------------------------------------------------------------------------
 void mdx_prof_begin(mdx_handle* h, int kind) {
     h->prof_open = false;
@@ -495,13 +533,14 @@ void mdx_prof_collect(mdx_handle* h, int first_stale_step) {
         (void)hipEventSynchronize(p.b);
         // launches enqueued behind a stale list were no-ops: the integrate pass of the stale step
         // itself still ran (it detected it), force kernels of that step and everything later did not
-        const bool ran = p.tag < 0 || (p.kind == 2 ? p.tag <= first_stale_step : p.tag < first_stale_step);
+        const bool ran = p.tag < 0 || ((p.kind == 2 || p.kind == 5) ? p.tag <= first_stale_step : p.tag < first_stale_step);
         // (level 2 = "the pair kernel only" covers both halves of a split launch)
         if (ran && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             if (p.kind == 0) { h->stats.nb_ms_sum += ms; h->stats.nb_launches++; }
             else if (p.kind == 4) h->stats.nb_ms_sum += ms;     // the boundary half of a split pair-kernel launch
             else if (p.kind == 1) { h->stats.bonded_ms_sum += ms; h->stats.bonded_launches++; }
             else if (p.kind == 2) { h->stats.integ_ms_sum += ms; h->stats.integ_launches++; }
+            else if (p.kind == 5) { h->stats.fused_ms_sum += ms; h->stats.fused_launches++; }
         }
         h->ev_pool.push_back(p.a); h->ev_pool.push_back(p.b);
     }
@@ -542,6 +581,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         MDX_TRY(ensure_ready(h));   // a barostat application at the last cadence point left the list to rebuild
         const uint32_t chunk = std::min(std::min(remaining, h->cfg.chunk_steps), mdx_steps_to_next_event(h));
         const auto t_chunk = std::chrono::steady_clock::now();
+        MdxRange range_chunk("mdx step chunk");
         HIP_TRY(hipMemsetAsync(d.ctl, 0, sizeof(StepCtl), st));
         // Velocity Verlet: the closing half kick of step s and the opening one of step s+1 are one pass (mode 1), with
         // and without constraints.  RATTLE's velocity projection between the two half kicks removes components along
@@ -557,11 +597,19 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         const int integ = h->integrator;
         const bool vv = integ == MDX_INTEGRATOR_VERLET_VELOCITY;
         const bool fused = vv && (h->n_groups == 0 || !rattle_every);
+        // Large classes: steps 1 .. chunk-1 run bonded gather + full kick + drift as ONE pass over double-buffered positions
+        // (mdx_integrate.hip); the force call in front of such a pass leaves its bonded launch out.  The last force call of
+        // the chunk is complete again (the closing half kick, energies, downloads read the force array).
+        const bool fuse_bi = fused && mdx_bonded_integrate_ok(h);
+        float4* pos_after[MDX_MAX_CHUNK + 1];      // the buffer that holds the positions after step s's drift
         for (uint32_t s = 0; s < chunk; ++s) {
             h->prof_tag = (int)s;
             h->lang_step = h->step_count + s;
             const int mode = !vv ? (integ == MDX_INTEGRATOR_LANGEVIN_MIDDLE ? 3 : 1) : ((s == 0 || !fused) ? 0 : 1);
-            MDX_TRY(mdx_launch_integrate(h, mode, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
+            if (fuse_bi && mode == 1) MDX_TRY(mdx_launch_bonded_integrate(h, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
+            else MDX_TRY(mdx_launch_integrate(h, mode, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
+            pos_after[s] = d.posq;
+            h->bonded_deferred = fuse_bi && s + 1 < chunk;
             h->cons_full_kick = vv && mode == 1;
             MDX_TRY(mdx_launch_constrain_positions(h, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
             h->cons_full_kick = false;
@@ -572,7 +620,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
             h->nb_step = (int)s;      // the pair kernel of this call may walk the inner masks / prune (prune[s + 1])
             if (h->dd) { h->dd->halo_pending = true; h->dd->halo_step = (int)s; h->chunk_s = (int)s; }
             const int frc = compute_forces(h, false, &d.ctl->disp2[s + 1], thr);
-            h->nb_step = -1;
+            h->nb_step = -1; h->bonded_deferred = false;
             MDX_TRY(frc);
             if (vv && !fused) {
                 MDX_TRY(mdx_launch_integrate(h, 2, dt, &d.ctl->disp2[s + 1], nullptr, thr));
@@ -599,6 +647,9 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
                     h->step_count += s;
                     FAIL(MDX_ENAN, "non-finite or runaway coordinates during mdx_step");
                 }
+                // (fused bonded + kick + drift passes swap the two position buffers at every enqueued step, the gated-off
+                // ones included: the state is in the buffer step s's drift wrote)
+                if (fuse_bi && d.posq != pos_after[s]) std::swap(d.posq, d.posq_alt);
                 // the drift of step s happened, its forces did not: rebuild, finish the step.  On a decomposed handle
                 // every rank is here at the same step (the flag rides on the halo message): rebuild locally while the
                 // owned + ghost set is still complete, else repartition - decided alike on every rank

@@ -112,6 +112,7 @@ void mdx_fill_bonded_params(const mdx_handle* h, BondedParams& p) {
 
 int mdx_launch_bonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr_bits) {
     if (h->bonded_fused) { h->bonded_fused = false; return MDX_OK; }   // rode along with the pair launch (small systems)
+    if (h->bonded_deferred && !energy) return MDX_OK;                  // the next step's fused bonded + kick + drift pass evaluates them
     if (!mdx_bonded_wanted(h)) return MDX_OK;
     BondedArgs a{};
     a.S = h->S; a.role_off = h->d.role_off_s; a.roles = h->d.role_rec_s; a.prm = h->d.role_prm;

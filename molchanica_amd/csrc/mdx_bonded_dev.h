@@ -22,18 +22,34 @@ struct RoleEnergies { double bond = 0.0, angle = 0.0, dih = 0.0, lj14 = 0.0, c14
 
 // Adds to (fx, fy, fz) the force of role `r` on its own atom (position `self`).  ENERGY: the term's energy and
 // virial are credited once, by the atom in role 0.
+// role_compute: the arithmetic, with the term's first two partners (q0 = posq[r.p[0]], q1 = posq[r.p[1]]) already loaded -
+// the fused bonded + kick + drift pass issues the partner loads of an atom's first roles together, ahead of the arithmetic.
+template <bool ENERGY>
+__device__ __forceinline__ void role_compute(const RoleRec& r, const float4 prm4, const float4 self, const float4 q0, const float4 q1,
+                                             const float4* __restrict__ posq,
+                                             const BondedParams& p, float& fx, float& fy, float& fz, RoleEnergies& en);
+
 template <bool ENERGY>
 __device__ __forceinline__ void role_eval(const RoleRec& r, const float4* __restrict__ prm_tab, const float4 self,
                                           const float4* __restrict__ posq,
                                           const BondedParams& p, float& fx, float& fy, float& fz, RoleEnergies& en) {
-    const float4 prm4 = prm_tab[r.meta >> 8];
+    const uint32_t kind = r.meta & 0xFu;
+    const float4 q0 = posq[r.p[0]];
+    const float4 q1 = (kind == ROLE_ANGLE || kind == ROLE_DIHEDRAL) ? posq[r.p[1]] : q0;
+    role_compute<ENERGY>(r, prm_tab[r.meta >> 8], self, q0, q1, posq, p, fx, fy, fz, en);
+}
+
+template <bool ENERGY>
+__device__ __forceinline__ void role_compute(const RoleRec& r, const float4 prm4, const float4 self, const float4 q0, const float4 q1,
+                                             const float4* __restrict__ posq,
+                                             const BondedParams& p, float& fx, float& fy, float& fz, RoleEnergies& en) {
     const float prm[3] = {prm4.x, prm4.y, prm4.z};
     double& e_bond = en.bond; double& e_angle = en.angle; double& e_dih = en.dih; double& e_lj14 = en.lj14;
     double& e_c14 = en.c14; double& e_rec = en.rec; double& e_vir = en.vir;
     const uint32_t kind = r.meta & 0xFu, role = (r.meta >> 4) & 0xFu;
     if (kind == ROLE_EWALD_EXCL) {
         // the reciprocal sum includes this excluded / 1-4 pair: take erf(beta r)/r out again
-        const float3 d = mimg(sub3(self, posq[r.p[0]]), p);
+        const float3 d = mimg(sub3(self, q0), p);
         const float r2 = dot3(d, d), rinv = rsqrtf(r2), rr = r2 * rinv, br = p.ewald_beta * rr;
         const float er = erff(br);
         const float fs = -prm[0] * (er * rinv - 1.1283791671f * p.ewald_beta * __expf(-br * br)) * rinv * rinv;
@@ -43,7 +59,7 @@ __device__ __forceinline__ void role_eval(const RoleRec& r, const float4* __rest
     }
     if (p.skip_bonded) return;
     if (kind == ROLE_BOND || kind == ROLE_PAIR14) {
-        const float3 d = mimg(sub3(self, posq[r.p[0]]), p);
+        const float3 d = mimg(sub3(self, q0), p);
         const float r2 = dot3(d, d);
         float fs;
         if (kind == ROLE_BOND) {
@@ -65,7 +81,6 @@ __device__ __forceinline__ void role_eval(const RoleRec& r, const float4* __rest
         if (ENERGY && role == 0) e_vir += (double)(fs * r2);
     } else if (kind == ROLE_ANGLE) {
         // ordered atoms i - j(apex) - k; this lane is atom `role`
-        const float4 q0 = posq[r.p[0]], q1 = posq[r.p[1]];
         const float4 pi = role == 0 ? self : q0;
         const float4 pj = role == 1 ? self : (role == 0 ? q0 : q1);
         const float4 pk = role == 2 ? self : q1;
@@ -92,7 +107,7 @@ __device__ __forceinline__ void role_eval(const RoleRec& r, const float4* __rest
         else { fx -= fi.x + fk.x; fy -= fi.y + fk.y; fz -= fi.z + fk.z; }
         if (ENERGY && role == 0) e_angle += (double)prm[0] * dth * dth;
     } else {   // ROLE_DIHEDRAL: ordered atoms 0-1-2-3, this lane is atom `role`
-        const float4 q0 = posq[r.p[0]], q1 = posq[r.p[1]], q2 = posq[r.p[2]];
+        const float4 q2 = posq[r.p[2]];
         const float4 p0 = role == 0 ? self : q0;
         const float4 p1 = role == 1 ? self : (role == 0 ? q0 : q1);
         const float4 p2 = role == 2 ? self : (role < 2 ? q1 : q2);

@@ -455,6 +455,7 @@ static int dd_repartition(mdx_handle* h) {
 }
 
 int mdx_dd_on_stale(mdx_handle* h) {
+    MdxRange range_stale("mdx decomposed stale list: local rebuild or repartition");
     MdxDecomp* dd = h->dd;
     // The drift (and SHAKE) of the stale step happened, its force call - which starts by constructing the virtual sites -
     // did not: bring the owned sites up to date before their positions travel (gather or halo), or the peers would

@@ -1110,7 +1110,7 @@ static int setup_grid(mdx_handle* h) {
     if (need_tiles > h->cap_tiles) {
         h->cap_tiles = need_tiles;
         const size_t S = (size_t)need_tiles * MDX_TILE, NC = (size_t)need_tiles * MDX_CL_PER_TILE;
-        ALLOC(d.posq, S); ALLOC(d.lj, S); ALLOC(d.vel, S); ALLOC(d.force, S); ALLOC(d.ref, S);
+        ALLOC(d.posq, S); ALLOC(d.lj, S); ALLOC(d.vel, S); ALLOC(d.force, S); ALLOC(d.ref, S); ALLOC(d.posq_alt, S);
         ALLOC(d.orig_of, S); ALLOC(d.slot_flags, S); ALLOC(d.pme_force, S);
         ALLOC(d.role_cnt_s, S + 1); ALLOC(d.role_off_s, S + 1);
         ALLOC(d.tile_col, need_tiles);
@@ -1169,6 +1169,7 @@ __global__ void cursor_sum_kernel(const unsigned long long* __restrict__ cursors
 static float c_inner_skin(const mdx_config& c) { return c.inner_skin == 0.f ? 0.5f : c.inner_skin; }
 
 int mdx_rebuild(mdx_handle* h) {
+    MdxRange range_rebuild("mdx list rebuild");
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profile) {
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));

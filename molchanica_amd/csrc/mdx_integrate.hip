@@ -12,8 +12,10 @@
 // atomicMax (non-negative floats order like their bit patterns).  Downstream kernels gate on
 // that word.
 #include "mdx_internal.h"
+#include "mdx_bonded_dev.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 struct LangevinArgs {
     float a1;          // exp(-gamma dt)
@@ -106,6 +108,82 @@ __global__ __launch_bounds__(256) void integrate_kernel(uint32_t S, float dt, fl
     }
 }
 
+// Bonded gather + full kick + drift in ONE pass (the large classes' step loop: velocity Verlet inside a chunk, no
+// constraints, virtual sites, SPME or external forces, mean role count of a solvent box).  The separate kernels stream
+// posq R + roles R + force RMW (bonded gather), then posq RW + vel RW + force R + zero W + ref RW (kick + drift): 226 B per
+// water atom in two launches.  Fused, the bonded force of an atom never leaves its registers - v += dt/m (f_pair + f_bonded) -
+// and the force array is read once and cleared: ~170 B per atom, one launch.  The gather reads its partners at time t while
+// the drift produces t + dt, so positions are double-buffered: read posq_in, write posq_out, the host swaps the two
+// pointers (slots that are never integrated - static, ghost, dummy - are copied through).  The bonded terms evaluated here
+// are those of the PREVIOUS force call (whose own bonded launch mdx_step left out): positions have not moved since.
+struct FusedArgs {
+    uint32_t S; float dt;
+    const float4* posq_in; float4* posq_out; float4* vel; float4* force; float4* ref;
+    const uint32_t* role_off; const RoleRec* roles; const float4* prm; BondedParams p; uint32_t R;
+    const uint32_t* gate_in; uint32_t* disp_out; uint32_t thr_bits; uint32_t* prune_out; float path_thr;
+};
+template <bool DUAL>
+__global__ __launch_bounds__(256) void bonded_integrate_kernel(FusedArgs a) {
+    const uint32_t gate = a.gate_in ? *a.gate_in : 0u;
+    if (gate > a.thr_bits) {  // list already stale: stay a no-op (positions stay in posq_in: the host does not swap back, see launcher)
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(a.disp_out, gate);
+        return;
+    }
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    float d2 = 0.f, path = 0.f;
+    if (s < a.S) {
+        // three dependent fetches stand between a lane and its bonded force (offsets -> role records -> partner positions):
+        // the offsets go first, the lane's own rows travel beside them, and the first FUSED_PRE records with their
+        // partners are fetched as one batch each (a loop with a data-dependent trip count would take them one round trip
+        // at a time) - a water atom has two or three roles
+        const uint32_t rb = a.role_off[s], re = a.role_off[s + 1];
+        float4 p = a.posq_in[s];
+        float4 v = a.vel[s];
+        if (v.w != 0.f) {   // w = 418.4/m; 0 marks static, ghost and dummy slots
+            float4 f = a.force[s];
+            constexpr int FUSED_PRE = 3;
+            RoleRec rr[FUSED_PRE]; float4 q0[FUSED_PRE], q1[FUSED_PRE], prm[FUSED_PRE];
+#pragma unroll
+            for (int i = 0; i < FUSED_PRE; ++i) rr[i] = a.roles[min(rb + (uint32_t)i, a.R - 1u)];   // (a record past the atom's own list is fetched, never evaluated)
+#pragma unroll
+            for (int i = 0; i < FUSED_PRE; ++i) { q0[i] = a.posq_in[rr[i].p[0]]; q1[i] = a.posq_in[rr[i].p[1]]; prm[i] = a.prm[rr[i].meta >> 8]; }
+            RoleEnergies en;
+#pragma unroll
+            for (int i = 0; i < FUSED_PRE; ++i)
+                if (rb + (uint32_t)i < re) role_compute<false>(rr[i], prm[i], p, q0[i], q1[i], a.posq_in, a.p, f.x, f.y, f.z, en);
+            for (uint32_t k = rb + FUSED_PRE; k < re; ++k) {
+                const RoleRec r = a.roles[k];
+                role_eval<false>(r, a.prm, p, a.posq_in, a.p, f.x, f.y, f.z, en);
+            }
+            const float kdt = a.dt * v.w;
+            v.x += kdt * f.x; v.y += kdt * f.y; v.z += kdt * f.z;
+            const float ox = p.x, oy = p.y, oz = p.z;
+            p.x += a.dt * v.x; p.y += a.dt * v.y; p.z += a.dt * v.z;
+            float4 r = a.ref[s];
+            const float dx = p.x - r.x, dy = p.y - r.y, dz = p.z - r.z;
+            d2 = dx * dx + dy * dy + dz * dz;
+            if (!(d2 < 1.0e30f)) d2 = 3.0e38f;  // NaN/inf -> huge, forces a stop
+            if (DUAL) {
+                const float mx = p.x - ox, my = p.y - oy, mz = p.z - oz;
+                path = r.w + __builtin_sqrtf(mx * mx + my * my + mz * mz);
+                r.w = path;
+                a.ref[s] = r;
+            }
+            a.vel[s] = v;
+        }
+        a.posq_out[s] = p;
+        a.force[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, m));
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(d2) > a.thr_bits) atomicMax(a.disp_out, __float_as_uint(d2));
+    if (DUAL) {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) path = fmaxf(path, __shfl_xor(path, m));
+        if ((threadIdx.x & 63) == 0 && !(path <= a.path_thr)) *a.prune_out = 1u;
+    }
+}
+
 // kinetic energy (kcal/mol) and max |F|^2 over mobile atoms.  Grid-stride over at most 1024 blocks and
 // a block-level reduction through LDS: one pair of atomics per block.  (One per wave - 16 k contended
 // atomics at 1 M atoms - made this pass take 205 us instead of the 15 us its 33 MB of reads need.)
@@ -177,6 +255,36 @@ int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_ga
 #undef INTEG
     mdx_prof_end(h);
     HIP_TRY(hipGetLastError());
+    return MDX_OK;
+}
+
+// MDX_FUSE_BONDED_INTEGRATE=0: A/B knob (the separate bonded gather and kick + drift launches at every step)
+bool mdx_bonded_integrate_ok(const mdx_handle* h) {
+    const char* e = std::getenv("MDX_FUSE_BONDED_INTEGRATE");     // read per chunk, so one process can compare both arrangements
+    const bool on = !(e && e[0] == '0');
+    return on && mdx_nb_variant(h) >= 2 && h->integrator == MDX_INTEGRATOR_VERLET_VELOCITY && h->n_groups == 0 && h->n_vsites == 0 &&
+           !h->pme_on && !h->have_ext && !h->dd && h->n_local == h->N && !h->alch_on && mdx_bonded_wanted(h) && h->T >= 4096u &&
+           (double)h->n_roles < 2.6 * (double)h->S && h->d.posq_alt != nullptr;
+}
+
+int mdx_launch_bonded_integrate(mdx_handle* h, float dt, const uint32_t* d_gate_in, uint32_t* d_disp_out, uint32_t thr_bits,
+                                uint32_t* d_prune_out) {
+    DeviceState& d = h->d;
+    FusedArgs a{};
+    a.S = h->S; a.dt = dt; a.posq_in = d.posq; a.posq_out = d.posq_alt; a.vel = d.vel; a.force = d.force; a.ref = d.ref;
+    a.role_off = d.role_off_s; a.roles = d.role_rec_s; a.prm = d.role_prm; a.R = h->n_roles;
+    mdx_fill_bonded_params(h, a.p);
+    a.gate_in = d_gate_in; a.disp_out = d_disp_out; a.thr_bits = thr_bits; a.prune_out = d_prune_out;
+    a.path_thr = 0.5f * h->inner_skin * (1.0f - 1.0e-4f);
+    const bool dual = h->dual_on && d_prune_out != nullptr;
+    const dim3 g((h->S + 255) / 256), b(256);
+    mdx_prof_begin(h, 5);
+    if (dual) hipLaunchKernelGGL(bonded_integrate_kernel<true>, g, b, 0, h->stream, a);
+    else hipLaunchKernelGGL(bonded_integrate_kernel<false>, g, b, 0, h->stream, a);
+    mdx_prof_end(h);
+    HIP_TRY(hipGetLastError());
+    std::swap(d.posq, d.posq_alt);
+    h->force_zeroed = true;
     return MDX_OK;
 }
 

@@ -132,6 +132,7 @@ struct DeviceState {
     // slot space
     float4* posq = nullptr; float2* lj = nullptr; float4* vel = nullptr; float4* force = nullptr;
     float4* ref = nullptr;
+    float4* posq_alt = nullptr;   // second position buffer: the fused bonded + kick + drift pass reads t, writes t + dt, then the two swap
     uint32_t* orig_of = nullptr;  // [S]  slot -> local atom index (MDX_INVALID for dummies)
     uint32_t* slot_of = nullptr;  // [N]  GLOBAL atom id -> slot (MDX_INVALID when not simulated here)
     uint32_t* gid = nullptr;      // [cap_local] local atom index -> global atom id
@@ -267,6 +268,7 @@ struct mdx_handle {
     bool force_zeroed = false;   // the integrate pass just enqueued cleared the force array (half-list kernel: skip the fill)
     bool cons_full_kick = false; // the SHAKE pass about to be enqueued follows a fused full kick (closing + opening): its corrections are those of a force acting through dt
     bool bonded_fused = false;   // the pair launch just enqueued carried the bonded gather in extra workgroups: skip its own launch
+    bool bonded_deferred = false; // step loop, large classes: the NEXT step's fused bonded + kick + drift pass evaluates the bonded terms of this force call
     uint64_t rng_state = 0;
     bool zero_com = false;
     uint32_t snap_every = 0; bool snap_vel = false;
@@ -315,6 +317,11 @@ int mdx_launch_add_ext(mdx_handle* h, const uint32_t* d_gate, uint32_t thr_bits)
 // kick, 3 = one Langevin-middle step: full kick, half drift, friction + noise, half drift)
 int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_gate_in,
                          uint32_t* d_disp_out, uint32_t thr_bits, uint32_t* d_prune_out = nullptr);
+// one pass for the bonded gather of step s-1's positions, the full kick and the drift of step s (velocity Verlet inside a
+// chunk, no constraints / virtual sites / SPME / external forces, one lane per atom): reads posq, writes posq_alt, swaps
+bool mdx_bonded_integrate_ok(const mdx_handle* h);
+int mdx_launch_bonded_integrate(mdx_handle* h, float dt, const uint32_t* d_gate_in, uint32_t* d_disp_out, uint32_t thr_bits,
+                                uint32_t* d_prune_out);
 int mdx_launch_kinetic(mdx_handle* h);  // energy[EN_KIN], energy[EN_COUNT] = max |F|^2
 int mdx_exclusive_scan_u32(mdx_handle* h, const uint32_t* in, uint32_t* out, uint32_t n);
 int mdx_exclusive_scan_u32_ex(mdx_handle* h, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums);   // caller's scratch: n / 2048 + 1 words
@@ -371,6 +378,18 @@ __host__ __device__ static inline uint64_t mdx_splitmix64(uint64_t* s) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
+
+// rocprof markers: roctxRangePush / roctxRangePop around the phases of the step loop, so that
+// `rocprofv3 --marker-trace` shows rebuild / halo / force phases beside the kernels.  librocprofiler-sdk-roctx (or the older
+// libroctx64) is dlopen'd on first use, only when MDX_ROCTX=1 is set; otherwise - and when neither library is there - the
+// calls are no-ops (one predictable branch).
+void mdx_range_push(const char* name);
+void mdx_range_pop();
+struct MdxRange {
+    explicit MdxRange(const char* name) { mdx_range_push(name); }
+    ~MdxRange() { mdx_range_pop(); }
+    MdxRange(const MdxRange&) = delete; MdxRange& operator=(const MdxRange&) = delete;
+};
 
 // profiling helpers
 void mdx_prof_begin(mdx_handle* h, int kind);

@@ -15,6 +15,7 @@
  *
  * Supported: orthorhombic periodic systems, MDX_COULOMB_SHIFTED / MDX_COULOMB_REACTION, separate LJ / Coulomb
  * cut-offs, exclusions and scaled 1-4 pairs, bonds / angles / dihedrals, static atoms, velocity Verlet.
+ * Refused (NULL / -1): vacuum, Ewald, distance constraints, virtual sites.
  */
 #include <math.h>
 #include <stdint.h>
@@ -90,6 +91,9 @@ static inline int excluded(const prod_t* p, uint32_t i, uint32_t j) {
 
 static prod_t* prod_create(const mdx_system* s, const mdx_config* c) {
     if (!s->periodic || c->coulomb_mode == MDX_COULOMB_EWALD) return NULL;
+    /* rigid molecules and virtual sites are not restated here: timing such a system without them would time a different
+     * system (round-2 advisor finding) */
+    if (s->n_constraints || s->n_vsites) return NULL;
     prod_t* p = (prod_t*)calloc(1, sizeof(prod_t));
     p->s = s; p->c = c; p->N = s->n_atoms; p->T = (int)s->n_lj_types;
     for (int a = 0; a < 3; ++a) { p->L[a] = s->box_hi[a] - s->box_lo[a]; p->invL[a] = 1.0f / p->L[a]; p->lo[a] = s->box_lo[a]; }

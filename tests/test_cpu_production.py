@@ -62,3 +62,16 @@ def test_refuses_what_it_does_not_implement(prod):
         prod.forces(systems.lig50(), MdConfig(lj_cutoff=0.0, coulomb_cutoff=0.0))
     with pytest.raises(ValueError):
         prod.forces(systems.small_solvated(), MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, coulomb_mode=2, ewald_alpha=0.3))
+
+
+def test_rigid_and_virtual_site_systems_are_refused():
+    """The baseline restates neither constraints nor virtual sites: it must refuse such a system instead of timing a different one."""
+    import pytest
+    from molchanica_amd import MdConfig, systems
+    from oracle import cpu_production as cp
+    cfg = MdConfig(lj_cutoff=6.0, coulomb_cutoff=6.0, skin=1.0)
+    for s in (systems.water_box(6, seed=3, rigid=True), systems.opc_water_box(6, seed=3)):
+        with pytest.raises(ValueError):
+            cp.forces(s, cfg)
+        with pytest.raises(ValueError):
+            cp.run(s, cfg, 0.0005, 2)
