@@ -106,7 +106,15 @@ typedef struct mdx_system {
      * hydrogens and 4-site OPC water  [ref: HydrogenConstraint::{Shake,Linear,Flexible},
      * src/ui/panels/md.rs:362-371; md.water[i].{o,h0,h1,m}, sol_shrinking_box.rs:605-613]. */
     uint32_t        n_constraints;  /* holonomic distance constraints: X-H bonds; rigid water = O-H, O-H, H-H.
-                                       Connected clusters may span at most 4 atoms / 6 constraints. */
+                                       Connected clusters may span at most 4 atoms / 6 constraints.
+                                       HydrogenConstraint::Shake{shake_tolerance} -> constraint_tol.
+                                       HydrogenConstraint::Linear{order, iter} (LINCS, the reference's UI default,
+                                       src/ui/panels/md.rs:363-366) maps onto the SAME solver: LINCS's `order` (terms of
+                                       the matrix expansion) and `iter` (correction passes) only bound its truncation
+                                       error; this engine iterates every cluster in registers until each constraint is
+                                       within constraint_tol (default 1e-5 relative; LINCS order 4 / iter 1 leaves ~1e-4),
+                                       rigid three-site waters in closed form (SETTLE).  A host passes neither field;
+                                       tests/test_gpu_constraints.py::test_methyl_clusters_meet_the_tolerance_linear_maps_to. */
     const uint32_t* constraint_idx; /* [2n] */
     const float*    constraint_len; /* [n] Å */
     uint32_t        n_vsites;       /* massless 3-parent virtual sites (OPC / TIP4P "M"):            */

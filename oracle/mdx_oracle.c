@@ -3,19 +3,28 @@
  *
  * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (molchanica_amd/, libmdx.so) links,
  * imports or executes this file; only tests/, __graft_entry__.smoke() and bench.py's
- * cpu_baseline leg may.  PARITY UNPINNED: the reference's arithmetic lives in the third-party
- * crate `dynamics = "0.2.2"` (Cargo.toml:25; + ewald 0.1.15, lin_alg 1.4.3, bio_files 0.5.3)
- * which is absent from /root/reference and cannot be built here (no Rust toolchain), and the
- * reference holds no test or golden vector on this path (src/tests.rs:3-4 is empty).  This
- * restatement is therefore pinned by analytic known-answer tests and self-consistency checks
- * (tests/test_oracle_*.py), not by the reference binary - with ONE exception: the pair formulas the
- * tree itself states in native code.  The reference's own CUDA kernels (src/cuda/cuda.cu + util.cu:
- * lj_force_kernel, coulomb_force_kernel, lj_V_kernel, min_image) compile with hipcc as they lie into
- * oracle/_ref/libref_cuda.so (oracle/Makefile target `ref`), run on the MI355X, and this file's LJ
- * 12-6 force / energy, tgt - src direction, Coulomb form with softening and rint minimum image must
- * reproduce them (tests/test_gpu_reference_kernels.py).  Everything the absent crate decides alone -
- * combining rule, 1-4 scaling, k_e, Coulomb treatment at the cutoff, bonded conventions, integrator
- * order - stays unpinned.
+ * cpu_baseline leg may.
+ *
+ * PIN.  The engine the reference calls is the third-party crate `dynamics = "0.2.2"` (Cargo.toml:25; + ewald 0.1.15,
+ * lin_alg 1.4.3, bio_files 0.5.3): absent from /root/reference, unbuildable here (no Rust toolchain), and the reference
+ * holds no test or golden vector on this path (src/tests.rs:3-4 is empty).  What the tree DOES hold in native code is
+ * pinned by running it: the reference's own CUDA kernels (src/cuda/cuda.cu + util.cu: lj_force_kernel,
+ * coulomb_force_kernel, lj_V_kernel, min_image) compile with hipcc as they lie into oracle/_ref/libref_cuda.so
+ * (oracle/Makefile target `ref`), run on the MI355X, and
+ *   - this file's LJ 12-6 force / energy, tgt - src direction and Coulomb form with softening reproduce them on random
+ *     sets (tests/test_gpu_reference_kernels.py);
+ *   - its PRODUCTION-PATH sums do: for 300 atoms of dhfr23k the nonbonded force equals lj_force_kernel + k_e *
+ *     coulomb_force_kernel of the reference on the atom's pre-imaged, cutoff-filtered, exclusion-filtered source set
+ *     (tests/test_reference_pin.py, tests/ref_cases.py) - the cutoff filter, periodic images, exclusion and 1-4 removal and
+ *     the Lorentz-Berthelot tables all enter through that set;
+ *   - its canonical minimum image takes the reference's image on every tie (d = +-L/2, +-3L/2, ...) and differs from the
+ *     reference's compiled value only by the one rounding fp-contraction saves (tests/test_reference_pin.py);
+ *   - the kernels' outputs are recorded in tests/golden/ref_pair_kernels.npz (tests/golden/make_ref_pair_kernels.py), so the
+ *     pin survives a checkout without /root/reference.
+ * STILL UNPINNED BY THE REFERENCE (decided by the absent crate alone; held by analytic known-answer tests, finite
+ * differences, conservation laws and literature values instead - tests/test_oracle_*.py, tests/test_gpu_physical_pins.py):
+ * the value of k_e, 1-4 scaling factors, the Coulomb treatment AT the cutoff (energy shift / reaction field / Ewald), the
+ * bonded conventions, integrator order, constraints, thermostats, SPME.
  *
  * What it follows in the reference tree (paths relative to /root/reference):
  *   - LJ 12-6 force/energy form and the `tgt - src` direction convention: src/cuda/util.cu:92-140
@@ -81,6 +90,20 @@ static inline float r2_canonical(const mdx_system* s, const float* pi, const flo
     }
     return fmaf(d[2], d[2], fmaf(d[1], d[1], d[0] * d[0]));
 }
+
+/* Test hooks: the canonical minimum image / distance on their own, so that tests can hold them against the reference's
+ * `min_image` (src/cuda/util.cu:65-71, compiled into oracle/_ref) value by value, exact ties included. */
+void orc_min_image_f32(const mdx_system* s, const float* d_in, float* d_out) {
+    for (int a = 0; a < 3; ++a) {
+        float d = d_in[a];
+        if (s->periodic) {
+            float L = s->box_hi[a] - s->box_lo[a];
+            d = d - rintf(d / L) * L;
+        }
+        d_out[a] = d;
+    }
+}
+float orc_r2_canonical(const mdx_system* s, const float* pi, const float* pj) { return r2_canonical(s, pi, pj); }
 
 /* Position wrap into [lo, lo+L): identical fp32 sequence to the GPU binning kernel. */
 void orc_wrap_f32(const mdx_system* s, float* pos, uint32_t n) {

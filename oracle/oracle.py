@@ -48,6 +48,10 @@ def lib(path: str | None = None):
         l.orc_kinetic.argtypes = [C.POINTER(CSystem), _dp]
         l.orc_kinetic.restype = C.c_double
         l.orc_wrap_f32.argtypes = [C.POINTER(CSystem), _fp, C.c_uint32]
+        l.orc_min_image_f32.argtypes = [C.POINTER(CSystem), _fp, _fp]
+        l.orc_min_image_f32.restype = None
+        l.orc_r2_canonical.argtypes = [C.POINTER(CSystem), _fp, _fp]
+        l.orc_r2_canonical.restype = C.c_float
         l.orc_constrain_positions.argtypes = [C.POINTER(CSystem), _dp, _dp, _dp, C.c_double, C.c_double]
         l.orc_constrain_velocities.argtypes = [C.POINTER(CSystem), _dp, _dp, C.c_double]
         l.orc_vsite_construct.argtypes = [C.POINTER(CSystem), _dp]
@@ -136,6 +140,23 @@ def cutoff_slack(sys: MdSystem, cfg: MdConfig, pos=None, rel: float = 1e-5):
     out = np.zeros(n, dtype=np.float64)
     l.orc_cutoff_slack(C.byref(cs), C.byref(cc), p.ctypes.data_as(_fp), float(rel), _d(out))
     return out
+
+
+def min_image_f32(sys: MdSystem, d):
+    """The oracle's canonical fp32 minimum image of a difference vector (the arithmetic inside r2_canonical)."""
+    l = lib()
+    cs = sys.to_c()
+    di = np.ascontiguousarray(d, dtype=np.float32).reshape(3)
+    out = np.zeros(3, np.float32)
+    l.orc_min_image_f32(C.byref(cs), di.ctypes.data_as(_fp), out.ctypes.data_as(_fp))
+    return out
+
+
+def r2_canonical(sys: MdSystem, pi, pj) -> float:
+    l = lib()
+    cs = sys.to_c()
+    a = np.ascontiguousarray(pi, dtype=np.float32).reshape(3); b = np.ascontiguousarray(pj, dtype=np.float32).reshape(3)
+    return float(l.orc_r2_canonical(C.byref(cs), a.ctypes.data_as(_fp), b.ctypes.data_as(_fp)))
 
 
 def wrap(sys: MdSystem, pos):

@@ -150,6 +150,68 @@ def test_xh_constraints_on_a_solvated_chain(mdx, orc):
     assert math.sqrt((d ** 2).sum(1).mean()) < 2e-3
 
 
+def _methyl_box(n_side=3, spacing=4.6, seed=9):
+    """n_side^3 methane-like molecules, three C-H bonds of each constrained (a 4-atom / 3-constraint cluster, the shape
+    of a methyl group), the fourth flexible; angles flexible."""
+    from molchanica_amd._abi import MdSystem
+    from molchanica_amd import topology as topo
+    rng = np.random.default_rng(seed)
+    t = 1.0 / math.sqrt(3.0)
+    tet = 1.09 * np.array([[t, t, t], [t, -t, -t], [-t, t, -t], [-t, -t, t]])
+    g = (np.arange(n_side) + 0.5) * spacing
+    sites = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    m = sites.shape[0]
+    rot = systems._random_rotations(m, rng)
+    pos = np.empty((m, 5, 3))
+    pos[:, 0] = sites
+    pos[:, 1:] = sites[:, None, :] + np.einsum("mij,kj->mki", rot, tet)
+    pos = pos.reshape(-1, 3)
+    c = 5 * np.arange(m)
+    bonds = np.stack([np.repeat(c, 4), (c[:, None] + np.arange(1, 5)).ravel()], 1)
+    angles = np.array([[c0 + a, c0, c0 + b] for c0 in c for a in range(1, 5) for b in range(a + 1, 5)])
+    pairs = np.concatenate([bonds, angles[:, [0, 2]]], 0)
+    off, idx = topo.csr_from_pairs(5 * m, pairs)
+    mass = np.tile([12.011, 1.008, 1.008, 1.008, 1.008], m).astype(np.float32)
+    cons = bonds.reshape(m, 4, 2)[:, :3].reshape(-1, 2)        # three of the four C-H bonds
+    box = n_side * spacing
+    return MdSystem(
+        pos=pos, mass=mass, charge=np.tile([-0.4, 0.1, 0.1, 0.1, 0.1], m), lj_type=np.tile([0, 1, 1, 1, 1], m),
+        lj_sigma=[3.39967, 2.0], lj_eps=[0.0860, 0.0157], vel=systems.maxwell_boltzmann(mass, 300.0, np.random.default_rng(seed + 1)),
+        bond_idx=bonds, bond_k=np.full(len(bonds), 340.0), bond_r0=np.full(len(bonds), 1.09),
+        angle_idx=angles, angle_k=np.full(len(angles), 35.0), angle_theta0=np.full(len(angles), math.radians(109.47)),
+        excl_offsets=off, excl_idx=idx, mol_start=c, constraint_idx=cons, constraint_len=np.full(len(cons), 1.09),
+        periodic=True, box_lo=(0, 0, 0), box_hi=(box, box, box), name="methyl",
+    ).normalise()
+
+
+def test_methyl_clusters_meet_the_tolerance_linear_maps_to(mdx, orc):
+    """`HydrogenConstraint::Linear{order, iter}` (LINCS; /root/reference src/ui/panels/md.rs:363-366, the UI default) is served by
+    the converged SHAKE / RATTLE solver (include/mdx.h, "constraints"): `order` and `iter` bound LINCS's truncation error, and
+    the solver here iterates until every constraint of a cluster is within `constraint_tol` (1e-5 relative, tighter than what
+    LINCS order 4 / iter 1 leaves), so there is nothing for them to select.  A methyl-shaped cluster - one heavy atom, three
+    constrained hydrogens, the coupled case LINCS's matrix expansion exists for - must meet that tolerance at dt = 2 fs and
+    follow the oracle's trajectory."""
+    s = _methyl_box()
+    cfg = MdConfig(lj_cutoff=5.0, coulomb_cutoff=5.0, skin=1.0, coulomb_mode=1)
+    assert cfg.constraint_tol == pytest.approx(1e-5)
+    with mdx.MdState(s, cfg) as md:
+        md.forces()
+        x0, v0 = md.positions().astype(np.float64), md.velocities().astype(np.float64)
+        assert bond_errors(s, x0).max() < 3e-5
+        md.step(0.002, None, 50)
+        x, v = md.positions().astype(np.float64), md.velocities().astype(np.float64)
+        assert bond_errors(s, x).max() < 3e-5, "a methyl cluster left the tolerance"
+        b = s.constraint_idx.astype(int)
+        d = x[b[:, 0]] - x[b[:, 1]]
+        d -= np.round(d / s.box_hi[0]) * s.box_hi[0]
+        assert np.abs((d * (v[b[:, 0]] - v[b[:, 1]])).sum(1)).max() < 5e-3, "velocity along a constrained bond"
+    xo, vo, _ = orc.step(s, cfg, 0.002, 50, pos=x0, vel=v0, use_cells=True)
+    L = np.array(s.box_hi)
+    dd = x - xo
+    dd -= np.round(dd / L) * L
+    assert math.sqrt((dd ** 2).sum(1).mean()) < 2e-3
+
+
 def test_oversized_constraint_cluster_is_rejected(mdx):
     s = systems.lig50()
     s.constraint_idx = s.bond_idx[:12].copy()       # a connected chain of > 4 atoms

@@ -3,7 +3,8 @@
 The reference holds NO test, fixture or golden vector on the MD path (src/tests.rs:3-4 is an
 empty `fn test_basic_forces() {}`) and its engine crate cannot be built here, so
 the oracle is pinned by analytic known-answer tests (K1-K7) and self-consistency checks (V1-V5).
-Parity is therefore "unpinned" in the judge's sense; these tests are what stands in.
+The pair arithmetic the reference's tree states in native code is pinned by running it (tests/test_reference_pin.py,
+tests/test_gpu_reference_kernels.py); for everything the absent crate decides alone these tests are what stands in.
 """
 import math
 
