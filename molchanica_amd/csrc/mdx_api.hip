@@ -448,7 +448,12 @@ static int compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint
     }
     MDX_TRY(mdx_launch_nonbonded(h, energy, gate, thr, split ? 2 : 0));
     if (split) HIP_TRY(hipStreamWaitEvent(h->stream, h->dd->ev_interior, 0));
+    // half-shell decomposition: the forces this rank computed on its ghosts go back to their owners (the bonded gather, which
+    // only touches owned rows, runs while the message is on the wire when the communication stream is a separate one)
+    const int fr_word = (h->dd && gate) ? h->nb_step + 1 : -1;
+    if (h->dd) { MdxRange range_fr("mdx ghost-force return"); MDX_TRY(mdx_dd_force_return_begin(h, fr_word)); }
     MDX_TRY(mdx_launch_bonded(h, energy, gate, thr));
+    if (h->dd) MDX_TRY(mdx_dd_force_return_end(h, fr_word));
     if (h->pme_on && h->pme_overlap) MDX_TRY(mdx_pme_join(h, gate, thr));
     else MDX_TRY(mdx_launch_pme(h, energy, gate, thr));    // SPME reciprocal space (hipFFT), if requested
     MDX_TRY(mdx_launch_vsite_spread(h, gate, thr));        // ... and hand their force back to them

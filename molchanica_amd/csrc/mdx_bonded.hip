@@ -121,7 +121,9 @@ int mdx_launch_bonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32
     mdx_prof_begin(h, energy ? 3 : 1);
     // lanes per atom by the mean role count of the slots (MDX_BONDED_LPA=2|4 forces it for A/B)
     static const int lpa_env = [] { const char* e = std::getenv("MDX_BONDED_LPA"); return e ? std::atoi(e) : 0; }();
-    const int lpa = (lpa_env == 1 || lpa_env == 2 || lpa_env == 4) ? lpa_env : ((double)h->n_roles < 2.6 * (double)h->S ? 1 : ((double)h->n_roles < 6.0 * (double)h->S ? 2 : 4));
+    // (n_roles counts the whole system: a decomposed handle holds n_local of its N atoms, and only the owned ones carry roles)
+    const double roles_here = (double)h->n_roles * ((h->n_local != h->N && h->N) ? (double)h->n_local / (double)h->N : 1.0);
+    const int lpa = (lpa_env == 1 || lpa_env == 2 || lpa_env == 4) ? lpa_env : (roles_here < 2.6 * (double)h->S ? 1 : (roles_here < 6.0 * (double)h->S ? 2 : 4));
     const dim3 g((uint32_t)(((size_t)h->S * lpa + 255) / 256)), b(256);
     if (lpa == 1) {
         if (energy) hipLaunchKernelGGL((bonded_gather_kernel<true, 1>), g, b, 0, h->stream, a);

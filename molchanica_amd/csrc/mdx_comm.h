@@ -63,6 +63,13 @@ struct MdxDecomp {
     float4* send_buf = nullptr; float4* recv_buf = nullptr;
     uint32_t n_send = 0, n_recv = 0, cap_send = 0, cap_recv = 0;
     std::vector<MdxSeg> send_segs, recv_segs;
+    // Half-shell halo (default with the half-list pair kernel): a rank keeps ghosts only of atoms whose OWNER's brick lies in
+    // an upper direction (first non-zero component of the brick offset positive), so a pair of atoms owned by two ranks is
+    // evaluated on exactly one of them, and the forces that rank computed on its ghosts travel back along the same
+    // segments in the opposite direction: frc_send has the layout of recv_buf, frc_recv that of send_buf.
+    bool half_shell = false;
+    float4* frc_send = nullptr; float4* frc_recv = nullptr;
+    bool force_return_pending = false;   // begin() was enqueued, end() has not been yet
     // gather of the global state (repartition, read-back)
     float4* gat_send = nullptr; float4* gat_recv = nullptr; size_t cap_gat_send = 0, cap_gat_recv = 0;
     // communication stream and the events that order it with the compute stream
@@ -96,6 +103,8 @@ int  mdx_dd_attach(mdx_handle* h, MdxTransport* tr);     // takes ownership of `
 void mdx_dd_destroy(mdx_handle* h);
 int  mdx_dd_halo_begin(mdx_handle* h);                   // pack + exchange (async on the comm stream)
 int  mdx_dd_halo_end(mdx_handle* h);                     // wait + unpack: ghost positions, peers' flag words
+int  mdx_dd_force_return_begin(mdx_handle* h, int flag_word);   // half shell: pack the ghosts' forces + exchange (reverse of the halo)
+int  mdx_dd_force_return_end(mdx_handle* h, int flag_word);     // ... and add what came back to the owned atoms
 int  mdx_dd_on_stale(mdx_handle* h);                     // the list went stale somewhere: local rebuild or repartition (same branch on every rank)
 int  mdx_dd_allreduce_host(mdx_handle* h, double* v, int n, bool max_u32 = false);
 int  mdx_dd_allreduce_f32(mdx_handle* h, float* dev, size_t n, hipStream_t produced_on);   // sum of a large device array over the ranks

@@ -82,28 +82,79 @@ __device__ __forceinline__ bool dd_in_halo(const DdPart& p, const int c[3], floa
     return ok;
 }
 
-// one pass over the global state: owner, class here, image code, and - for owned atoms - the peers that keep a ghost
+// Half shell: does rank (brick) `c` keep a ghost of an atom owned by brick `co`, which it sees under image `code` while the
+// owner itself holds the atom under image `home` (non-zero for a cluster member that lies across the periodic seam from its
+// anchor)?  Only when the owner's brick - in the frame the atom lives in - lies in an UPPER direction:
+//     rel_d = co_d + (k_d - home_d) grid_d - c_d   over the cut dimensions, first non-zero component positive.
+// For two atoms i (owner P, home a_i) and j (owner Q, home a_j) within range of each other the interacting image is unique,
+// so k^P_j - a_i = a_j - k^Q_i, hence rel seen from Q is -rel seen from P: exactly one of the two owners keeps the other's
+// atom as a ghost, the pair is evaluated once, and its force on the ghost travels back.
+__device__ __forceinline__ bool dd_upper(const DdPart& p, const int c[3], const int co[3], uint32_t code, uint32_t home) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (p.grid[d] == 1) continue;
+        const int k = (int)((code >> (2 * d)) & 3u) - (int)((home >> (2 * d)) & 3u);
+        const int rel = co[d] + k * p.grid[d] - c[d];
+        if (rel != 0) return rel > 0;
+    }
+    return false;
+}
+__device__ __forceinline__ int dd_owner_of(const DdPart& p, const float4* __restrict__ g_pos, const uint32_t* __restrict__ anchor, uint32_t g) {
+    const float4 pa = g_pos[anchor[g]];
+    return dd_owner(p, dd_wrap1(pa.x, p.lo[0], p.len[0]), dd_wrap1(pa.y, p.lo[1], p.len[1]), dd_wrap1(pa.z, p.lo[2], p.len[2]));
+}
+
+// one pass over the global state: owner, class here, image code, and - for owned atoms - the peers that keep a ghost.
+// Classes: 0 not here, 1 owned, 2 ghost, 3 (half shell) ghost kept only because an owned atom has a bonded term with it: the
+// atom-owned bonded gather needs its position, its pair interactions belong to other ranks (no charge, no LJ here).
 __global__ __launch_bounds__(256) void dd_classify_kernel(uint32_t N, const float4* __restrict__ g_pos, const uint32_t* __restrict__ anchor,
-                                                          DdPart p, uint8_t* __restrict__ cls, uint8_t* __restrict__ owner,
+                                                          DdPart p, int half_shell, const uint32_t* __restrict__ role_off,
+                                                          const RoleRec* __restrict__ roles,
+                                                          uint8_t* __restrict__ cls, uint8_t* __restrict__ owner,
                                                           uint8_t* __restrict__ shift_code, uint32_t* __restrict__ send_mask,
                                                           uint32_t* __restrict__ flags, uint32_t* __restrict__ err) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
-    const float4 pa = g_pos[anchor[g]], pg = g_pos[g];
-    const int own = dd_owner(p, dd_wrap1(pa.x, p.lo[0], p.len[0]), dd_wrap1(pa.y, p.lo[1], p.len[1]), dd_wrap1(pa.z, p.lo[2], p.len[2]));
+    const float4 pg = g_pos[g];
+    const int own = dd_owner_of(p, g_pos, anchor, g);
     const float x = dd_wrap1(pg.x, p.lo[0], p.len[0]), y = dd_wrap1(pg.y, p.lo[1], p.len[1]), z = dd_wrap1(pg.z, p.lo[2], p.len[2]);
-    uint32_t code;
+    const int co[3] = {own / (p.grid[1] * p.grid[2]), (own / p.grid[2]) % p.grid[1], own % p.grid[2]};
+    uint32_t code, home = 1u | (1u << 2) | (1u << 4);
     const bool here = dd_in_halo(p, p.coord, x, y, z, &code);
     const bool mine = own == p.rank;
     if (mine && !here) atomicOr(err, 1u);      // an owned atom outside its own halo region: the halo is thinner than the cluster reach
-    const uint32_t c = mine ? 1u : (here ? 2u : 0u);
+    if (half_shell && !mine) (void)dd_in_halo(p, co, x, y, z, &home);   // the image its owner holds it under (the owner checks that it can)
+    if (mine) home = code;
+    uint32_t c = mine ? 1u : (here ? 2u : 0u);
+    if (half_shell && c == 2u && !dd_upper(p, p.coord, co, code, home)) c = 0u;
     uint32_t mask = 0;
     if (mine) {
         for (int q = 0; q < p.world; ++q) {
             if (q == p.rank) continue;
             const int cq[3] = {q / (p.grid[1] * p.grid[2]), (q / p.grid[2]) % p.grid[1], q % p.grid[2]};
-            uint32_t dummy;
-            if (dd_in_halo(p, cq, x, y, z, &dummy)) mask |= 1u << q;
+            uint32_t cd;
+            if (dd_in_halo(p, cq, x, y, z, &cd) && (!half_shell || dd_upper(p, cq, co, cd, home))) mask |= 1u << q;
+        }
+    }
+    if (half_shell && role_off) {
+        // bonded partners across a rank boundary travel in BOTH directions: whoever owns one atom of a term needs the others
+        for (uint32_t k = role_off[g]; k < role_off[g + 1]; ++k) {
+            const RoleRec r = roles[k];
+            const uint32_t kind = r.meta & 0xFu;
+            const int np = kind == ROLE_DIHEDRAL ? 3 : (kind == ROLE_ANGLE ? 2 : 1);
+            for (int q = 0; q < np; ++q) {
+                const int po = dd_owner_of(p, g_pos, anchor, r.p[q]);
+                if (mine) {
+                    if (po != p.rank) {
+                        const int cq[3] = {po / (p.grid[1] * p.grid[2]), (po / p.grid[2]) % p.grid[1], po % p.grid[2]};
+                        uint32_t cd;
+                        if (dd_in_halo(p, cq, x, y, z, &cd)) mask |= 1u << po;
+                        else { atomicOr(err, 4u); if (atomicCAS(err + 3, 0u, (uint32_t)po | 0x100u) == 0u) { err[1] = g; err[2] = r.p[q]; } }   // (the receiver finds the same and fails alike)
+                    }
+                } else if (po == p.rank && c == 0u) {
+                    if (here) c = 3u; else { atomicOr(err, 4u); if (atomicCAS(err + 3, 0u, (uint32_t)own | 0x200u) == 0u) { err[1] = g; err[2] = r.p[q]; } }   // a bonded partner beyond the halo
+                }
+            }
         }
     }
     cls[g] = (uint8_t)c; owner[g] = (uint8_t)own; shift_code[g] = (uint8_t)code; send_mask[g] = mask;
@@ -111,7 +162,7 @@ __global__ __launch_bounds__(256) void dd_classify_kernel(uint32_t N, const floa
     const size_t Ns = N;
     for (int q = 0; q < p.world; ++q) {
         flags[(size_t)(2 * q) * Ns + g] = (mask >> q) & 1u;
-        flags[(size_t)(2 * q + 1) * Ns + g] = (c == 2u && own == q) ? 1u : 0u;
+        flags[(size_t)(2 * q + 1) * Ns + g] = (c >= 2u && own == q) ? 1u : 0u;
     }
     flags[(size_t)(2 * p.world) * Ns + g] = c != 0u;
     flags[(size_t)(2 * p.world + 1) * Ns + g] = c == 1u;
@@ -144,7 +195,7 @@ __global__ __launch_bounds__(256) void dd_fill_kernel(uint32_t N, int world, DdP
         else { recv_ids[f.recv_base[q] + k] = g; recv_shift[f.recv_base[q] + k] = make_float4(sx, sy, sz, 0.f); }
     } else if (seg == 2 * world) {
         const float4 pg = g_pos[g];
-        gid_local[k] = g; ghost_local[k] = cls[g] == 2 ? 1 : 0;
+        gid_local[k] = g; ghost_local[k] = cls[g] == 2 ? 1 : (cls[g] == 3 ? 3 : 0);   // bit 0: ghost, bit 1: no pair interactions here
         pos_l[k] = make_float4(dd_wrap1(pg.x, p.lo[0], p.len[0]) + sx, dd_wrap1(pg.y, p.lo[1], p.len[1]) + sy,
                                dd_wrap1(pg.z, p.lo[2], p.len[2]) + sz, 0.f);
         vel_l[k] = g_vel[g];
@@ -250,7 +301,8 @@ static int dd_partition(mdx_handle* h) {
     }
     HIP_TRY(hipMemsetAsync(h->d.flags_dev, 0, sizeof(uint32_t) * 4, st));
     HIP_TRY(hipMemsetAsync(dd->flags + (nflags - 1), 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL(dd_classify_kernel, dim3(div_up(N, 256)), dim3(256), 0, st, N, dd->g_pos, dd->anchor, p, dd->cls, dd->owner,
+    hipLaunchKernelGGL(dd_classify_kernel, dim3(div_up(N, 256)), dim3(256), 0, st, N, dd->g_pos, dd->anchor, p, dd->half_shell ? 1 : 0,
+                       h->n_roles ? h->d.role_off_o : nullptr, h->d.role_rec_o, dd->cls, dd->owner,
                        dd->shift_code, dd->send_mask, dd->flags, h->d.flags_dev);
     MDX_TRY(mdx_exclusive_scan_u32_ex(h, dd->flags, dd->scan, (uint32_t)nflags, dd->scan_sums));
     uint32_t* d_heads = (uint32_t*)dd->red;     // 64 doubles = 128 words of scratch
@@ -260,6 +312,16 @@ static int dd_partition(mdx_handle* h) {
     HIP_TRY(hipMemcpyAsync(err, h->d.flags_dev, sizeof(err), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (err[0] & 1u) FAIL(MDX_EPARAM, "decomposition: an owned atom lies outside its rank's halo region (constraint cluster larger than the halo allows)");
+    if (err[0] & 4u) {
+        float4 pa{}, pb{};
+        (void)hipMemcpy(&pa, dd->g_pos + err[1], sizeof(float4), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&pb, dd->g_pos + err[2], sizeof(float4), hipMemcpyDeviceToHost);
+        char buf[320];
+        snprintf(buf, sizeof(buf), "decomposition: a bonded partner of an owned atom lies beyond the halo (atom %u at %.2f %.2f %.2f, partner %u at %.2f %.2f %.2f, "
+                 "%s rank %u, this rank %d, halo %.2f)", err[1], pa.x, pa.y, pa.z, err[2], pb.x, pb.y, pb.z, (err[3] & 0x100u) ? "partner owned by" : "atom owned by",
+                 err[3] & 0xFFu, dd->rank, dd->halo);
+        FAIL(MDX_EPARAM, buf);
+    }
     DdFill f{};
     for (int s = 0; s <= nseg; ++s) f.seg_start[s] = heads[s];
     dd->send_segs.clear(); dd->recv_segs.clear();
@@ -275,10 +337,14 @@ static int dd_partition(mdx_handle* h) {
     dd->n_local = heads[2 * W + 1] - heads[2 * W];
     dd->n_owned = heads[2 * W + 2] - heads[2 * W + 1];
     if (dd->n_local == 0) FAIL(MDX_EPARAM, "decomposition: a rank received no atoms (empty brick)");
-    if (s0 > dd->cap_send) { dd->cap_send = s0 + s0 / 4 + 64; MDX_TRY(dd_alloc(&dd->send_ids, dd->cap_send)); MDX_TRY(dd_alloc(&dd->send_buf, dd->cap_send)); }
+    if (s0 > dd->cap_send) {
+        dd->cap_send = s0 + s0 / 4 + 64;
+        MDX_TRY(dd_alloc(&dd->send_ids, dd->cap_send)); MDX_TRY(dd_alloc(&dd->send_buf, dd->cap_send)); MDX_TRY(dd_alloc(&dd->frc_recv, dd->cap_send));
+    }
     if (r0 > dd->cap_recv) {
         dd->cap_recv = r0 + r0 / 4 + 64;
         MDX_TRY(dd_alloc(&dd->recv_ids, dd->cap_recv)); MDX_TRY(dd_alloc(&dd->recv_buf, dd->cap_recv)); MDX_TRY(dd_alloc(&dd->recv_shift, dd->cap_recv));
+        MDX_TRY(dd_alloc(&dd->frc_send, dd->cap_recv));
     }
     if (s0) HIP_TRY(hipMemsetAsync(dd->send_ids, 0xFF, sizeof(uint32_t) * s0, st));
     if (r0) { HIP_TRY(hipMemsetAsync(dd->recv_ids, 0xFF, sizeof(uint32_t) * r0, st)); HIP_TRY(hipMemsetAsync(dd->recv_shift, 0, sizeof(float4) * r0, st)); }
@@ -421,6 +487,69 @@ int mdx_dd_halo_end(mdx_handle* h) {
     return MDX_OK;
 }
 
+// ---- half shell: the forces a rank computed on its ghosts go back to their owners -------------------------------------
+// Every cross-rank pair is evaluated once, on the rank that keeps the other atom as a ghost; the half-list pair kernel leaves
+// the reaction in the ghost's row of the force array.  Rows travel along the halo segments in the opposite direction (what
+// was received from q is sent to q), flag rows included: a peer that found its list stale during this step's drift tells the
+// ranks BELOW it here (the position message only reaches the ranks above), so every later kernel of the chunk is gated off
+// everywhere.  The owner adds the rows with f32 atomics: an atom may be a ghost on several peers.
+__global__ void dd_pack_force_kernel(uint32_t n, const uint32_t* __restrict__ atom_idx, const uint32_t* __restrict__ slot_of,
+                                     const float4* __restrict__ force, float4* __restrict__ out, const uint32_t* __restrict__ flag_word) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = atom_idx[i];
+    if (g == MDX_INVALID) { out[i] = make_float4(flag_word ? __uint_as_float(*flag_word) : 0.f, 0.f, 0.f, 0.f); return; }
+    const uint32_t s = slot_of[g];
+    out[i] = (s == MDX_INVALID) ? make_float4(0.f, 0.f, 0.f, 0.f) : force[s];
+}
+__global__ void dd_add_force_kernel(uint32_t n, const uint32_t* __restrict__ atom_idx, const uint32_t* __restrict__ slot_of,
+                                    float4* __restrict__ force, const float4* __restrict__ in, uint32_t* __restrict__ flag_word) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = atom_idx[i];
+    if (g == MDX_INVALID) { if (flag_word) atomicMax(flag_word, __float_as_uint(in[i].x)); return; }
+    const uint32_t s = slot_of[g];
+    if (s == MDX_INVALID) return;
+    const float4 f = in[i];
+    float* const dst = reinterpret_cast<float*>(force + s);
+    unsafeAtomicAdd(dst, f.x); unsafeAtomicAdd(dst + 1, f.y); unsafeAtomicAdd(dst + 2, f.z);
+}
+
+bool mdx_dd_half_shell(const mdx_handle* h) { return h->dd && h->dd->half_shell && h->dd->world > 1; }
+
+int mdx_dd_force_return_begin(mdx_handle* h, int flag_word) {
+    MdxDecomp* dd = h->dd;
+    if (!mdx_dd_half_shell(h) || !h->in_slot_space) return MDX_OK;
+    hipStream_t st = h->stream;
+    const uint32_t* fw = flag_word >= 0 ? &h->d.ctl->disp2[flag_word] : nullptr;
+    if (dd->n_recv)
+        hipLaunchKernelGGL(dd_pack_force_kernel, dim3(div_up(dd->n_recv, 256)), dim3(256), 0, st, dd->n_recv, dd->recv_ids, h->d.slot_of,
+                           h->d.force, dd->frc_send, fw);
+    HIP_TRY(hipGetLastError());
+    if (dd->comm_stream != st) {
+        HIP_TRY(hipEventRecord(dd->ev_packed, st));
+        HIP_TRY(hipStreamWaitEvent(dd->comm_stream, dd->ev_packed, 0));
+    }
+    MDX_TRY(dd->tr->exchange(dd->frc_send, dd->recv_segs, dd->frc_recv, dd->send_segs, dd->comm_stream));
+    if (dd->comm_stream != st) HIP_TRY(hipEventRecord(dd->ev_arrived, dd->comm_stream));
+    dd->force_return_pending = true;
+    return MDX_OK;
+}
+
+int mdx_dd_force_return_end(mdx_handle* h, int flag_word) {
+    MdxDecomp* dd = h->dd;
+    if (!dd || !dd->force_return_pending) return MDX_OK;
+    dd->force_return_pending = false;
+    hipStream_t st = h->stream;
+    if (dd->comm_stream != st) HIP_TRY(hipStreamWaitEvent(st, dd->ev_arrived, 0));
+    uint32_t* fw = flag_word >= 0 ? &h->d.ctl->disp2[flag_word] : nullptr;
+    if (dd->tr->delivers() && dd->n_send)
+        hipLaunchKernelGGL(dd_add_force_kernel, dim3(div_up(dd->n_send, 256)), dim3(256), 0, st, dd->n_send, dd->send_ids, h->d.slot_of,
+                           h->d.force, dd->frc_recv, fw);
+    HIP_TRY(hipGetLastError());
+    return MDX_OK;
+}
+
 // ---- stale list: local rebuild or repartition (the same branch on every rank) --------------------------------------
 static int dd_local_set_still_valid(mdx_handle* h, bool* valid) {
     MdxDecomp* dd = h->dd;
@@ -506,7 +635,7 @@ void mdx_dd_destroy(mdx_handle* h) {
     if (dd->comm_stream && dd->comm_stream != h->stream) (void)hipStreamSynchronize(dd->comm_stream);
     void* ptrs[] = {dd->anchor, dd->g_pos, dd->g_vel, dd->g_frc, dd->cls, dd->owner, dd->shift_code, dd->send_mask, dd->flags, dd->scan,
                     dd->scan_sums, dd->gid_local, dd->ghost_local, dd->pos_l, dd->vel_l, dd->pos_at_part, dd->owned_gid, dd->send_ids,
-                    dd->recv_ids, dd->recv_shift, dd->send_buf, dd->recv_buf, dd->gat_send, dd->gat_recv, dd->red};
+                    dd->recv_ids, dd->recv_shift, dd->send_buf, dd->recv_buf, dd->frc_send, dd->frc_recv, dd->gat_send, dd->gat_recv, dd->red};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (dd->ev_packed) (void)hipEventDestroy(dd->ev_packed);
     if (dd->ev_arrived) (void)hipEventDestroy(dd->ev_arrived);
@@ -572,6 +701,10 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
             mdx_set_error("decomposition: brick + 2 halo exceeds the box: an atom would be needed under two images (box too small for this many ranks)");
             return bail(MDX_EPARAM);
         }
+    {   // half shell needs Newton's third law across the rank boundary: the half-list pair kernel (MDX_HALF_SHELL=0: A/B knob)
+        const char* e = std::getenv("MDX_HALF_SHELL");
+        dd->half_shell = dd->world > 1 && mdx_nb_half(h) && !(e && e[0] == '0');
+    }
     {
         const char* e = std::getenv("MDX_HALO_OVERLAP");
         dd->overlap = !(e && e[0] == '0');

@@ -176,7 +176,7 @@ __global__ void rebuild_clear_kernel(uint32_t* __restrict__ slot_of, uint32_t n_
     if (i < 4u) flags[i] = 0u;
 }
 
-__global__ void bin_atoms_kernel(float4* __restrict__ pos_orig, uint32_t N, GridParams g,
+__global__ void bin_atoms_kernel(float4* __restrict__ pos_orig, uint32_t N, GridParams g, const uint8_t* __restrict__ lflag,
                                  uint32_t* __restrict__ cell_of, uint32_t* __restrict__ cell_count,
                                  uint32_t* __restrict__ nonfinite) {
     uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
@@ -193,7 +193,8 @@ __global__ void bin_atoms_kernel(float4* __restrict__ pos_orig, uint32_t N, Grid
     int cx = min(g.ncx - 1, max(0, (int)((p.x - g.lo[0]) * g.inv_col[0])));
     int cy = min(g.ncy - 1, max(0, (int)((p.y - g.lo[1]) * g.inv_col[1])));
     int zb = min(g.nzb - 1, max(0, (int)((p.z - g.lo[2]) * g.inv_zbin)));
-    uint32_t cell = (uint32_t)((cx * g.ncy + cy) * g.nzb + zb);
+    const int pop = (g.npop > 1 && (lflag[o] & 1u)) ? 1 : 0;      // ghosts get column sets of their own
+    uint32_t cell = (uint32_t)(((pop * g.ncx + cx) * g.ncy + cy) * g.nzb + zb);
     cell_of[o] = cell;
     atomicAdd(&cell_count[cell], 1u);
 }
@@ -317,9 +318,11 @@ __global__ void gather_slots_kernel(uint32_t S, const uint32_t* __restrict__ ori
         const uint32_t g = gid[o];
         const bool ghost = (lflag[o] & 1u) != 0;
         float4 q = pos_orig[o], w = vel_orig[o];
-        p = make_float4(q.x, q.y, q.z, o_qs[g]);
+        // (lflag bit 1: a ghost kept only as the bonded partner of an owned atom - its pairs belong to other ranks)
+        const bool silent = (lflag[o] & 2u) != 0;
+        p = make_float4(q.x, q.y, q.z, silent ? 0.f : o_qs[g]);
         v = ghost ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(w.x, w.y, w.z, o_invm[g]);
-        l = o_lj[g];
+        l = silent ? make_float2(o_lj[g].x, 0.f) : o_lj[g];
         fl = ghost ? 1 : 3;
     } else {
         // dummy: far away, every dummy at its own coordinate so no two coincide
@@ -603,8 +606,10 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
             const float cylo = g.lo[1] + (float)wy * colw_y + sy - 1e-3f, cyhi = cylo + colw_y + 2e-3f;
             const float gy = (wy == 0 || wy == g.ncy - 1) ? 0.f : gap(cylo, cyhi, lo[1], hi[1]);
             if (gx * gx + gy * gy >= r2) continue;
-            const uint32_t c2 = (uint32_t)(wx * g.ncy + wy);
+            for (int pop = 0; pop < g.npop; ++pop) {      // (half-shell decomposition: the owned and the ghost column at this (x, y))
+            const uint32_t c2 = (uint32_t)((pop * g.ncx + wx) * g.ncy + wy);
             const uint32_t cl0 = a.tile_start[c2] * MDX_CL_PER_TILE, cl1 = a.tile_start[c2 + 1] * MDX_CL_PER_TILE;
+            if (cl1 == cl0) continue;
             for (int kz = kz0; kz <= kz1; ++kz) {
                 const float sz = (float)kz * g.len[2];
                 const uint32_t code = (uint32_t)((kx + 1) + 3 * (ky + 1) + 9 * (kz + 1));
@@ -679,6 +684,7 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
                     np += __popcll(bp);
                     if (MODE != LB_FILL && pass) npairs += __popc(imask);
                 }
+            }
             }
         }
     }
@@ -1084,7 +1090,8 @@ static int setup_grid(mdx_handle* h) {
     double zh = 6.0 / (rho * col_area);          // ~6 atoms per fine cell
     zh = std::min(std::max(zh, 0.25), (double)g.len[2]);
     long nzb = std::max(1L, (long)std::ceil(g.len[2] / zh));
-    const long ncol = (long)g.ncx * g.ncy;
+    g.npop = mdx_dd_half_shell(h) ? 2 : 1;
+    const long ncol = (long)g.ncx * g.ncy * g.npop;
     while (ncol * nzb > 48L * 1000 * 1000) nzb = (nzb + 1) / 2;
     g.nzb = (int)nzb;
     g.inv_zbin = (float)(g.nzb / (double)g.len[2]);
@@ -1187,7 +1194,7 @@ int mdx_rebuild(mdx_handle* h) {
         hipLaunchKernelGGL(rebuild_clear_kernel, dim3(div_up(n_max, 256)), dim3(256), 0, st, d.slot_of, h->N, d.cell_count,
                            d.cell_cursor, h->ncells + 1, d.flags_dev);
     }
-    hipLaunchKernelGGL(bin_atoms_kernel, dim3(div_up(N, 256)), dim3(256), 0, st, d.pos_orig, N, g, d.cell_of,
+    hipLaunchKernelGGL(bin_atoms_kernel, dim3(div_up(N, 256)), dim3(256), 0, st, d.pos_orig, N, g, d.lflag, d.cell_of,
                        d.cell_count, d.flags_dev + 1);
     MDX_TRY(mdx_exclusive_scan_u32(h, d.cell_count, d.cell_start, h->ncells + 1));
     hipLaunchKernelGGL(column_tiles_kernel, dim3(div_up(h->ncol + 1, 256)), dim3(256), 0, st, d.cell_start,

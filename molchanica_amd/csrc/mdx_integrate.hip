@@ -263,7 +263,7 @@ bool mdx_bonded_integrate_ok(const mdx_handle* h) {
     const char* e = std::getenv("MDX_FUSE_BONDED_INTEGRATE");     // read per chunk, so one process can compare both arrangements
     const bool on = !(e && e[0] == '0');
     return on && mdx_nb_variant(h) >= 2 && h->integrator == MDX_INTEGRATOR_VERLET_VELOCITY && h->n_groups == 0 && h->n_vsites == 0 &&
-           !h->pme_on && !h->have_ext && !h->dd && h->n_local == h->N && !h->alch_on && mdx_bonded_wanted(h) && h->T >= 4096u &&
+           !h->pme_on && !h->have_ext && !h->dd && h->n_local == h->N && !h->alch_on && mdx_bonded_wanted(h) && h->T >= mdx_wpt8_below(h) &&
            (double)h->n_roles < 2.6 * (double)h->S && h->d.posq_alt != nullptr;
 }
 

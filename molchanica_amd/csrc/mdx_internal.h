@@ -41,6 +41,9 @@ struct GridParams {
     float inv_col[2];  // 1 / column edge in x, y
     float inv_zbin;    // 1 / fine z-bin height
     int ncx, ncy, nzb; // columns in x, y; z-bins per column
+    int npop;          // 1, or 2 on a half-shell decomposed handle: owned atoms and ghost atoms are binned into SEPARATE column
+                       // sets (column = (pop * ncx + cx) * ncy + cy), so every tile and cluster is all-owned or all-ghost and
+                       // "no ghost-ghost pair is evaluated" is a cluster-level decision (mdx_decomp.hip: forces on ghosts go back)
     int per[3];        // periodic per dimension (a decomposed dimension is not periodic locally)
 };
 
@@ -190,6 +193,8 @@ struct DeviceState {
 };
 
 struct MdxDecomp;   // mdx_comm.h: the handle is one rank of a spatially decomposed box
+struct mdx_handle;
+bool mdx_dd_half_shell(const mdx_handle* h);   // decomposed with a half-shell halo: every cross-rank pair is evaluated on ONE rank, ghost forces travel back
 
 struct mdx_handle {
     int device = 0;
@@ -337,6 +342,8 @@ static inline int mdx_nb_variant(const mdx_handle* h) {
     return (v >= 1 && v <= 5) ? (int)v : MDX_NB_DEFAULT_VARIANT;
 }
 static inline bool mdx_nb_half(const mdx_handle* h) { return mdx_nb_variant(h) == 5; }
+// tiles below which the half-list pair kernel runs eight waves per tile (and carries the bonded gather in its launch)
+static inline uint32_t mdx_wpt8_below(const mdx_handle* h) { return (h->dd || h->n_local != h->N) ? 4096u : 2048u; }
 
 // constraints / virtual sites (mdx_constraints.hip)
 int mdx_build_constraints(mdx_handle* h, const mdx_system* s);

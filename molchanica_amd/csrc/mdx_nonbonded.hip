@@ -71,6 +71,7 @@ struct NbArgs {
     const uint32_t* prune_flag2;  // boundary launch: the ghosts' prune word (raised by the halo unpack); then only a pass asked for by
                                   // the owned atoms' word clears the owned atoms' path accumulators (the interior lists depend on them)
     // small systems (DUAL 4): workgroups pair_grid .. of the launch evaluate the bonded gather beside the pair tiles
+    uint32_t energy_all;          // half-shell decomposition: every pair this rank evaluates is evaluated nowhere else - full weight
     uint32_t pair_grid, b_S;
     const uint32_t* b_role_off; const RoleRec* b_roles; const float4* b_prm;
     BondedParams b_p;
@@ -363,7 +364,7 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
     float2* sl = s_lj[wave];
     double elj = 0.0, ecoul = 0.0, evir = 0.0, ecross = 0.0, edudl = 0.0;
     uint32_t own_bits = 0xFFu;   // ENERGY only: bit ci set <=> i-atom (ci, ii) is owned by this rank
-    if (ENERGY) {
+    if (ENERGY && !a.energy_all) {
         own_bits = 0;
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci)
@@ -388,7 +389,7 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
         if ((uint32_t)part + WPT < nchunks) ent_n = entries[e0 + (part + WPT) * 8 + (lane >> 3)];
         const uint32_t js = ent.x * MDX_CLUSTER + (lane & 7);
         nj = a.posq[js]; nl = a.lj[js]; ny = ent.y; njc = ent.x;
-        if (ENERGY && HALF) nown = (float)((a.slot_flags[js] >> 1) & 1u);
+        if (ENERGY && HALF) nown = a.energy_all ? 1.0f : (float)((a.slot_flags[js] >> 1) & 1u);
     }
     float* const fbase = reinterpret_cast<float*>(a.force);
     float4* const sg = s_g[HALF ? wave : 0];
@@ -438,7 +439,7 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
         if (c + WPT < nchunks) {
             const uint32_t js = ent_n.x * MDX_CLUSTER + (lane & 7);
             nj = a.posq[js]; nl = a.lj[js]; ny = ent_n.y; njc = ent_n.x;
-            if (ENERGY && HALF) nown = (float)((a.slot_flags[js] >> 1) & 1u);
+            if (ENERGY && HALF) nown = a.energy_all ? 1.0f : (float)((a.slot_flags[js] >> 1) & 1u);
             if (c + 2 * WPT < nchunks) ent_n = entries[e0 + (c + 2 * WPT) * 8 + (lane >> 3)];
         }
         float celj = 0.f, cecoul = 0.f, cevir = 0.f, cecross = 0.f, cedudl = 0.f;   // (ENERGY) fp32 partial sums of this chunk
@@ -685,7 +686,11 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
     // fewer tiles than ~3 per SIMD (the chip holds 4 waves/SIMD of this kernel on 1024 SIMDs)
     int wpt = 1;
     const bool half = var == 5;
-    if (var == 2 || half) wpt = (a.T < 4096u) ? 8 : 4;     // measured: 4 beats 1 at every size, 8 below ~200 k atoms
+    // measured: 4 beats 1 at every size, 8 below ~130 k atoms (round 3: 192 k atoms / 3.1 k tiles 0.137 ms with 8, 0.125 with 4, 0.127
+    // with 2; one rank of an 8-rank water1M - 2.0 k owned + 1.3 k ghost tiles - 0.111 / 0.106 / 0.112)
+    // with 2; one rank of an 8-rank water1M - 2.0 k owned + 1.3 k ghost tiles - 0.111 with the bonded gather inside / 0.106 + 0.010 for its
+    // own launch / 0.112: a decomposed handle, whose step loop cannot fuse the gather into the drift pass, keeps 8 up to 4096 tiles)
+    if (var == 2 || half) wpt = (a.T < mdx_wpt8_below(h)) ? 8 : 4;
     if (half && a.T >= 12000u) wpt = 2;                    // half list at ~1 M atoms: 0.550 vs 0.572 ms (2 tiles per workgroup)
     if (var == 4) wpt = 4;
     if (half) {   // A/B knob
@@ -773,6 +778,7 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
     a.posq = h->d.posq; a.lj = h->d.lj; a.counts = h->d.list_counts; a.entry_off = h->d.entry_off;
     a.mchunk_off = h->d.mchunk_off; a.entries = h->d.entries; a.masks = h->d.masks;
     a.force = h->d.force; a.energy = h->d.energy; a.slot_flags = h->d.slot_flags; a.gate = d_gate; a.thr_bits = thr_bits;
+    a.energy_all = mdx_dd_half_shell(h) ? 1u : 0u;
     {
         static const int xcd_env = [] { const char* e = std::getenv("MDX_XCD_INTERLEAVE"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
         a.xcd_interleave = xcd_env >= 0 ? (uint32_t)xcd_env : ((h->have_local_bounds && h->n_local != h->N) ? 1u : 0u);

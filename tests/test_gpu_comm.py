@@ -94,6 +94,31 @@ def test_ranks_below_the_abi_match_single_gpu(reference, world):
         assert r0["stats"]["repartitions"] >= 2, "the run never repartitioned: migration is not covered"
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_half_shell_halo_evaluates_every_cross_pair_once_and_returns_the_ghost_forces(reference, world):
+    """Default with the half-list pair kernel: a rank keeps ghosts of upper-direction owners only (about half the full shell;
+    bonded partners across a face in both directions), evaluates a pair of atoms owned by two ranks on ONE of them, and sends
+    the forces it computed on its ghosts back.  Against the full shell (MDX_HALF_SHELL=0, every cross pair on both ranks, no
+    force message) and against one GPU: same forces, same energies - which count every pair with full weight exactly when
+    it is evaluated exactly once."""
+    s, cfg, ref = reference
+    os.environ["MDX_HALF_SHELL"] = "0"
+    try:
+        full = run_ranks(s, cfg, world, 10, want_forces=True)
+    finally:
+        os.environ.pop("MDX_HALF_SHELL", None)
+    half = run_ranks(s, cfg, world, 10, want_forces=True)
+    g_full = sum(full[r]["stats"]["n_ghost"] for r in range(world)); g_half = sum(half[r]["stats"]["n_ghost"] for r in range(world))
+    assert g_half < 0.62 * g_full, (g_half, g_full)        # half the shell + the bonded partners of the lower faces
+    for res in (full, half):
+        for k in ("lj", "coulomb", "bond", "angle", "virial"):
+            assert abs(res[0]["e0"][k] - ref["e0"][k]) <= max(2e-2, 3e-6 * abs(ref["e0"][k])), (k, res[0]["e0"][k], ref["e0"][k])
+        df = np.linalg.norm(res[0]["f0"].astype(np.float64) - ref["f0"], axis=1)
+        assert (df <= 2e-4 * np.maximum(np.linalg.norm(ref["f0"], axis=1), 1.0) + 2e-4).all()
+    L = np.array(s.box_hi, dtype=np.float64)
+    assert rms_dev(half[0]["pos"], full[0]["pos"], L) < 5e-4
+
+
 def test_external_forces_on_decomposed_handles():
     """`md.step(dev, dt, Some(external_forces))` (src/mol_alignment.rs:349-356): every rank is handed the same per-atom array in
     the caller's order and adds the rows of the atoms it owns."""
