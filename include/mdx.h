@@ -435,6 +435,13 @@ int mdx_comm_selftest(mdx_handle* h);
  * destroy the handle.  Not collective (nothing reaches the wire). */
 int mdx_comm_selftest_fault(mdx_handle* h);
 int mdx_comm_info(const mdx_handle* h, int* rank, int* world, int grid[3], uint32_t* n_owned, uint32_t* n_ghost, float* halo);
+/* Diagnostics: what the partition kernels derived at the last (re)partition, per GLOBAL atom - class here (0 absent, 1 owned,
+ * 2 ghost, 3 ghost kept only as a bonded partner), owning rank, image code ((kx+1) | (ky+1) << 2 | (kz+1) << 4) and, for owned
+ * atoms, the bit set of ranks that keep a copy - and the two halo lists (global atom ids in message order, 0xFFFFFFFF = a
+ * peer segment's flag row).  Any pointer may be NULL.  tests/test_gpu_partition_spec.py holds them against the executable
+ * specification tests/decomp_spec.py. */
+int mdx_comm_debug_partition(mdx_handle* h, uint8_t* cls, uint8_t* owner, uint8_t* image_code, uint32_t* send_mask /* [N] each */,
+                             uint32_t* n_send, uint32_t* n_recv, uint32_t* send_ids, uint32_t* recv_ids, uint32_t capacity);
 
 /* ---- the building blocks underneath (kept for hosts that drive the decomposition themselves, and for the tests) ----
  * One handle per GPU/rank, created from the GLOBAL system (static per-atom data and topology are

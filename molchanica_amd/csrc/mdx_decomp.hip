@@ -764,6 +764,30 @@ extern "C" int mdx_comm_info(const mdx_handle* h, int* rank, int* world, int gri
     return MDX_OK;
 }
 
+extern "C" int mdx_comm_debug_partition(mdx_handle* h, uint8_t* cls, uint8_t* owner, uint8_t* image_code, uint32_t* send_mask,
+                                        uint32_t* n_send, uint32_t* n_recv, uint32_t* send_ids, uint32_t* recv_ids, uint32_t capacity) {
+    if (!h || !h->dd) FAIL(MDX_EPARAM, "the handle has not joined a communicator");
+    MdxDecomp* dd = h->dd;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const uint32_t N = h->N;
+    if (cls) HIP_TRY(hipMemcpy(cls, dd->cls, N, hipMemcpyDeviceToHost));
+    if (owner) HIP_TRY(hipMemcpy(owner, dd->owner, N, hipMemcpyDeviceToHost));
+    if (image_code) HIP_TRY(hipMemcpy(image_code, dd->shift_code, N, hipMemcpyDeviceToHost));
+    if (send_mask) HIP_TRY(hipMemcpy(send_mask, dd->send_mask, sizeof(uint32_t) * N, hipMemcpyDeviceToHost));
+    if (n_send) *n_send = dd->n_send;
+    if (n_recv) *n_recv = dd->n_recv;
+    if (send_ids && dd->n_send) {
+        if (capacity < dd->n_send) FAIL(MDX_EPARAM, "capacity below n_send");
+        HIP_TRY(hipMemcpy(send_ids, dd->send_ids, sizeof(uint32_t) * dd->n_send, hipMemcpyDeviceToHost));
+    }
+    if (recv_ids && dd->n_recv) {
+        if (capacity < dd->n_recv) FAIL(MDX_EPARAM, "capacity below n_recv");
+        HIP_TRY(hipMemcpy(recv_ids, dd->recv_ids, sizeof(uint32_t) * dd->n_recv, hipMemcpyDeviceToHost));
+    }
+    return MDX_OK;
+}
+
 // Exercises every transport entry point of a joined handle on the wire it really has - including, with one rank, RCCL's
 // send/recv to self inside a group - and checks the results: what a single-GPU box can verify of the RCCL leg.
 __global__ void dd_selftest_fill_kernel(uint32_t n, float4* a, float seed) {

@@ -136,6 +136,7 @@ def load_library():
     lib.mdx_comm_init_shm.argtypes = [H, C.c_char_p, C.c_int, C.c_int]
     lib.mdx_comm_selftest.argtypes = [H]
     lib.mdx_comm_selftest_fault.argtypes = [H]
+    lib.mdx_comm_debug_partition.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _u32p, _u32p, C.c_void_p, C.c_void_p, C.c_uint32]
     lib.mdx_comm_info.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _u32p, _u32p, _fp]
     _lib = lib
     return lib
@@ -426,13 +427,26 @@ class MdState:
         refuses further traffic.  The communicator is unusable afterwards: close the handle."""
         _check(load_library().mdx_comm_selftest_fault(self._h))
 
+    def comm_debug_partition(self, n_atoms: int) -> dict:
+        """What the partition kernels derived at the last (re)partition (diagnostics; see include/mdx.h)."""
+        cls = np.zeros(n_atoms, np.uint8); owner = np.zeros(n_atoms, np.uint8); code = np.zeros(n_atoms, np.uint8)
+        mask = np.zeros(n_atoms, np.uint32)
+        ns, nr = C.c_uint32(), C.c_uint32()
+        lib = load_library()
+        _check(lib.mdx_comm_debug_partition(self._h, cls.ctypes.data, owner.ctypes.data, code.ctypes.data, mask.ctypes.data,
+                                            C.byref(ns), C.byref(nr), None, None, 0))
+        sid = np.zeros(max(ns.value, 1), np.uint32); rid = np.zeros(max(nr.value, 1), np.uint32)
+        _check(lib.mdx_comm_debug_partition(self._h, None, None, None, None, C.byref(ns), C.byref(nr), sid.ctypes.data, rid.ctypes.data,
+                                            max(ns.value, nr.value, 1)))
+        return dict(cls=cls, owner=owner, image_code=code, send_mask=mask, send_ids=sid[:ns.value], recv_ids=rid[:nr.value])
+
     def comm_info(self) -> dict:
         r, w, g = C.c_int(), C.c_int(), (C.c_int * 3)()
         no, ng, halo = C.c_uint32(), C.c_uint32(), C.c_float()
         _check(load_library().mdx_comm_info(self._h, C.byref(r), C.byref(w), g, C.byref(no), C.byref(ng), C.byref(halo)))
         return dict(rank=r.value, world=w.value, grid=tuple(g), n_owned=no.value, n_ghost=ng.value, halo=halo.value)
 
-    # -- multi-GPU plumbing (raw device pointers; used by molchanica_amd.decomp) -------------------
+    # -- multi-GPU plumbing (raw device pointers; the building blocks for hosts that drive a decomposition themselves; tests/decomp_spec.py does) -------------------
     def set_local_atoms(self, n_local, d_gid, d_ghost, d_pos4, d_vel4, lo, hi, periodic_mask: int):
         _check(load_library().mdx_set_local_atoms(
             self._h, int(n_local), C.c_void_p(d_gid), C.c_void_p(d_ghost), C.c_void_p(d_pos4), C.c_void_p(d_vel4),

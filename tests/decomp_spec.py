@@ -1,4 +1,15 @@
-"""Spatial domain decomposition of one periodic box over the GPUs of a node.
+"""EXECUTABLE SPECIFICATION of the spatial decomposition (tests only).
+
+The product's decomposition lives below the C ABI (molchanica_amd/csrc/mdx_decomp.hip, mdx_comm.hip: `mdx_comm_init`); this
+file is its statement in plain torch, kept under tests/ for two jobs:
+  * `Partition` - bricks, owners, halo membership, image shifts, the half-shell rule and the bonded-partner rule - is what
+    tests/test_gpu_partition_spec.py holds the device kernels of mdx_decomp.hip against, atom by atom, at 2 / 4 / 8 ranks;
+  * `DecomposedMd` - the round-1 host-driven step loop over the ABI's building blocks (mdx_set_local_atoms, mdx_chunk_*,
+    mdx_pack/unpack_positions: still public, for hosts that drive a decomposition themselves) - runs under `gloo` with a numpy
+    engine double in tests/test_decomp_gloo.py (world 2 and 4 on CPU: rendezvous, repartition, halo lists, stale-flag
+    protocol of THIS driver, full-shell halo) and on the HIP engine in tests/test_gpu_decomp.py.
+What the gloo test does NOT cover: the C++ transports, the half-shell force return and the device partition kernels - those
+are tests/test_gpu_comm.py and tests/test_gpu_partition_spec.py.
 
 The reference is single-device (`CudaContext::new(0)`, /root/reference src/util.rs:1086; no
 NCCL/MPI anywhere in the tree), so this is new capability layered on the same C ABI:
@@ -7,22 +18,13 @@ NCCL/MPI anywhere in the tree), so this is new capability layered on the same C 
     wrap every rank of a 2x2x2 grid has exactly 7 distinct peers = the 7 xGMI links of an MI355X);
   * a rank integrates the atoms it OWNS (those inside its brick at the last repartition) and
     keeps GHOST copies of every other atom within `halo = cutoff + skin` of the brick, already
-    shifted into its own frame — a decomposed dimension is therefore not periodic locally, a
+    shifted into its own frame - a decomposed dimension is therefore not periodic locally, a
     dimension that is not cut stays periodic inside the engine;
-  * every step: drift -> 1-word all-reduce(max) of the rebuild flag -> ONE batched group of
-    point-to-point sends/receives of ghost positions (ncclGroupStart / ncclSend / ncclRecv per
-    peer / ncclGroupEnd via `batch_isend_irecv`), packed and unpacked by index-list kernels on the
-    engine's stream -> forces.  Pair forces are evaluated full-list on owned tiles only, so no
-    force message ever travels back;
-  * when any rank's list goes stale, all ranks repartition: owned state is scattered into a
-    zero-filled global array and summed with one all-reduce (each row is non-zero on exactly one
-    rank, so the sum is exact), every rank re-derives owners, ghosts, image shifts and the
-    send/receive index lists from the same data with the same arithmetic — the lists agree by
-    construction, sorted by global atom id, and no index list is ever exchanged.  Static per-atom
-    data and topology are replicated on every GPU (288 GB of HBM make that free at these sizes).
-
-All partition / list logic is plain torch and device-agnostic: under `gloo` on CPU it is exercised
-by tests/test_decomp_gloo.py with a test-double engine; in production the engine is the HIP library.
+  * (DecomposedMd) every step: drift -> 1-word all-reduce(max) of the rebuild flag -> ONE batched group of
+    point-to-point sends/receives of ghost positions, packed and unpacked by index-list kernels on the
+    engine's stream -> forces, full shell: no force message travels back;
+  * when any rank's list goes stale, all ranks repartition from the same gathered data with the same arithmetic - the
+    lists agree by construction, sorted by global atom id, and no index list is ever exchanged.
 """
 from __future__ import annotations
 
@@ -32,7 +34,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from ._abi import MdConfig, MdSystem
+from molchanica_amd._abi import MdConfig, MdSystem
 
 GRIDS = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
 
@@ -102,7 +104,9 @@ class Partition:
         """-> (mask [N] bool: atom is simulated by `rank` (owned or ghost), shift [N,3] image shift
         that moves the atom into rank's frame)."""
         dev = pos_wrapped.device
-        blo, bhi = self.brick(rank)
+        # brick faces and the widened interval in fp32, operation by operation as dd_in_halo (mdx_decomp.hip) evaluates them
+        f32 = np.float32
+        c = self.coords(rank)
         mask = torch.ones(pos_wrapped.shape[0], dtype=torch.bool, device=dev)
         shift = torch.zeros_like(pos_wrapped)
         for d in range(3):
@@ -110,7 +114,10 @@ class Partition:
                 continue
             x = pos_wrapped[:, d]
             L = float(self.len[d])
-            lo_h, hi_h = blo[d] - self.halo, bhi[d] + self.halo
+            lo32, len32 = f32(self.lo[d]), f32(self.len[d])
+            blo = f32(lo32 + f32(f32(len32 * f32(c[d])) / f32(self.grid[d])))
+            bhi = f32(lo32 + f32(f32(len32 * f32(c[d] + 1)) / f32(self.grid[d])))
+            lo_h, hi_h = float(f32(blo - f32(self.halo))), float(f32(bhi + f32(self.halo)))
             any_k = torch.zeros_like(mask)
             sh = torch.zeros_like(x)
             for k in (-1.0, 0.0, 1.0):
@@ -121,6 +128,60 @@ class Partition:
             mask &= any_k
             shift[:, d] = sh
         return mask, shift
+
+    # ---- the rules mdx_decomp.hip adds (dd_classify_kernel), restated ---------------------------------------------------
+    def image_codes(self, rank: int, pos_wrapped: torch.Tensor):
+        """-> (here [N] bool, k [N,3] int: the image (-1, 0, +1 per cut dimension, the FIRST that fits) under which the atom
+        lies inside `rank`'s brick widened by the halo)."""
+        mask, shift = self.local_mask_and_shift(rank, pos_wrapped)
+        k = torch.zeros(pos_wrapped.shape, dtype=torch.int64)
+        for d in range(3):
+            if self.grid[d] > 1:
+                k[:, d] = torch.round(shift[:, d] / float(self.len[d])).to(torch.int64)
+        return mask, k
+
+    def classify(self, rank: int, pos_wrapped: torch.Tensor, owner: torch.Tensor, half_shell: bool, role_partners=None):
+        """Class of every atom on `rank`: 0 not here, 1 owned, 2 ghost, 3 ghost kept only as the bonded partner of an owned atom.
+        Half shell: a ghost is kept only if its OWNER's brick - in the frame the atom lives in: its image here minus the image its
+        owner holds it under - lies in an upper direction (first non-zero component of  c_owner + (k_here - k_home) grid - c_rank
+        positive).  role_partners: list of (atom, partner) pairs of the bonded terms (both directions)."""
+        n = pos_wrapped.shape[0]
+        here, k_here = self.image_codes(rank, pos_wrapped)
+        cls = torch.where(owner == rank, 1, torch.where(here, 2, 0)).to(torch.int64)
+        if half_shell:
+            k_home = torch.zeros_like(k_here)
+            for q in range(self.world):
+                sel = owner == q
+                if sel.any():
+                    _, kq = self.image_codes(q, pos_wrapped)
+                    k_home[sel] = kq[sel]
+            cr = torch.tensor(self.coords(rank))
+            g = torch.tensor(self.grid)
+            co = torch.stack([owner // (self.grid[1] * self.grid[2]), (owner // self.grid[2]) % self.grid[1], owner % self.grid[2]], 1)
+            rel = co + (k_here - k_home) * g - cr
+            rel[:, [d for d in range(3) if self.grid[d] == 1]] = 0
+            upper = torch.zeros(n, dtype=torch.bool); decided = torch.zeros(n, dtype=torch.bool)
+            for d in range(3):
+                nz = (rel[:, d] != 0) & ~decided
+                upper |= nz & (rel[:, d] > 0)
+                decided |= nz
+            cls = torch.where((cls == 2) & ~upper, 0, cls)
+            if role_partners is not None and len(role_partners):
+                a, b = role_partners[:, 0], role_partners[:, 1]
+                need = (owner[b] == rank) & (owner[a] != rank)          # atom a shares a term with an atom this rank owns
+                wanted = torch.zeros(n, dtype=torch.bool); wanted[a[need]] = True
+                cls = torch.where(wanted & (cls == 0) & here, 3, cls)
+        return cls, k_here
+
+    def send_mask(self, rank: int, pos_wrapped: torch.Tensor, owner: torch.Tensor, half_shell: bool, role_partners=None):
+        """For the atoms `rank` owns: bit q <=> rank q keeps a copy (the mirror image of classify on q)."""
+        m = torch.zeros(pos_wrapped.shape[0], dtype=torch.int64)
+        for q in range(self.world):
+            if q == rank:
+                continue
+            cls_q, _ = self.classify(q, pos_wrapped, owner, half_shell, role_partners)
+            m |= ((cls_q >= 2) & (owner == rank)).to(torch.int64) << q
+        return m
 
     def local_bounds(self, rank: int, pad: float = 1.0):
         blo, bhi = self.brick(rank)

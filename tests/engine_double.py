@@ -1,4 +1,4 @@
-"""CPU test double of the engine interface molchanica_amd.decomp.DecomposedMd drives.
+"""CPU test double of the engine interface tests.decomp_spec.DecomposedMd drives.
 
 Pure numpy, fp64: non-bonded LJ + shifted-cutoff Coulomb by brute force over the LOCAL atom set
 (minimum image only in the dimensions that are periodic locally), velocity-Verlet kick/drift and

@@ -1,5 +1,10 @@
-"""Multi-rank path on CPU: partition invariants, and 2-/4-rank `gloo` runs of DecomposedMd (with the
-numpy engine double) that must reproduce the 1-rank trajectory.  Nothing here touches a GPU."""
+"""Multi-rank path on CPU: partition invariants, and 2-/4-rank `gloo` runs of tests/decomp_spec.py's DecomposedMd (with the
+numpy engine double) that must reproduce the 1-rank trajectory.  Nothing here touches a GPU.
+
+What this covers: the world-2 / world-4 rendezvous over `gloo`, the partition RULES (owners, halo membership, image shifts -
+the same `Partition` class tests/test_gpu_partition_spec.py holds the device kernels of mdx_decomp.hip against), the
+repartition and stale-flag protocol of the Python driver.  What it does not: the product's own step loop, transports and
+half-shell force return, which live below the C ABI and need a GPU (tests/test_gpu_comm.py)."""
 import os
 import socket
 
@@ -10,7 +15,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from molchanica_amd import MdConfig, MdSystem
-from molchanica_amd.decomp import DecomposedMd, DistComm, Partition, ThreadComm, process_grid
+from tests.decomp_spec import DecomposedMd, DistComm, Partition, ThreadComm, process_grid
 
 
 def charged_fluid(n=360, box=30.0, seed=0):

@@ -17,7 +17,7 @@ CFG = dict(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, chunk_steps=8)
 
 
 def run_ranks(system, cfg, world, n_steps, dt=0.0005):
-    from molchanica_amd.decomp import DecomposedMd, ThreadComm
+    from tests.decomp_spec import DecomposedMd, ThreadComm
     shared = ThreadComm.Shared(world)
     res, errs = {}, []
 
