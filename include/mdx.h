@@ -401,10 +401,14 @@ double   mdx_time_ps(const mdx_handle* h);
  *     mdx_energy    returns the totals of the whole box on every rank
  *     mdx_download  gathers the global array on every rank
  * and these three are COLLECTIVE: every rank must make the same calls in the same order.  Constraints, virtual sites,
- * thermostats, every integrator, external forces, snapshots and the SPME reciprocal sum (a replicated mesh, all-reduced)
- * work on a decomposed handle (a constraint cluster / virtual-site family is owned as a whole by one rank); the barostat,
- * alchemical windows, the minimiser and uploads are refused (MDX_EPARAM) - minimise, upload and draw initial velocities
- * before joining.
+ * thermostats, every integrator, external forces, snapshots, the SPME reciprocal sum (a replicated mesh, all-reduced), the
+ * barostat (the all-reduced pressure gives every rank the same scale factor; the gathered state and the box are scaled alike,
+ * then the ranks repartition), mdx_minimize_energy (collective: all-reduced energies and largest force drive ONE step-length
+ * control; the accepted state is the gathered global positions) and alchemical windows (cutoff and SPME) work on a decomposed
+ * handle (a constraint cluster / virtual-site family is owned as a whole by one rank).  The halo is a HALF shell when the
+ * half-list pair kernel runs (the default): a pair of atoms owned by two ranks is evaluated on one of them and the force on
+ * the ghost travels back in a second send/recv group per step.  Uploads (mdx_upload*, mdx_set_box, mdx_shrink_cell_towards,
+ * mdx_initialize_velocities) are refused (MDX_EPARAM): the state is distributed - set it before joining.
  *
  * mdx_comm_unique_id: rank 0 draws the id (ncclGetUniqueId; librccl is dlopen'd on first use) and hands the 128 bytes
  * to the other ranks by whatever means the host has.  mdx_comm_init is ncclCommInitRank + the first partition. */

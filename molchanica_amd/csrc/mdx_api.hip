@@ -748,10 +748,10 @@ int mdx_energy_impl(mdx_handle* h, mdx_energies* out) {
     if (h->dd) {   // every rank evaluated its share (a pair's energy is split between the owners of its atoms): sum them
         double v[EN_COUNT + 2];
         for (int k = 0; k < EN_COUNT; ++k) v[k] = e[k];
-        v[EN_COUNT] = u_cross;
-        MDX_TRY(mdx_dd_allreduce_host(h, v, EN_COUNT + 1));
+        v[EN_COUNT] = u_cross; v[EN_COUNT + 1] = du_dl;
+        MDX_TRY(mdx_dd_allreduce_host(h, v, EN_COUNT + 2));
         for (int k = 0; k < EN_COUNT; ++k) e[k] = v[k];
-        u_cross = v[EN_COUNT];
+        u_cross = v[EN_COUNT]; du_dl = v[EN_COUNT + 1];
         uint32_t mfb; std::memcpy(&mfb, &e[EN_COUNT], 4);
         double mv = (double)mfb;
         MDX_TRY(mdx_dd_allreduce_host(h, &mv, 1, true));
@@ -1193,9 +1193,9 @@ int mdx_set_local_atoms_impl(mdx_handle* h, uint32_t n_local, const uint32_t* d_
                              int32_t periodic) {
     if (n_local == 0 || n_local > h->N) FAIL(MDX_EPARAM, "n_local must be in 1..n_atoms (each atom at most once)");
     if (h->pme_on && !h->dd) FAIL(MDX_EPARAM, "the SPME reciprocal sum needs the library's own decomposition (mdx_comm_init): here each rank would spread only its own charges");
-    if (h->alch_on) FAIL(MDX_EPARAM, "alchemical windows are not supported on a decomposed handle");
+    if (h->alch_on && !h->dd) FAIL(MDX_EPARAM, "alchemical windows need the library's own decomposition (mdx_comm_init)");
     if (h->integrator != MDX_INTEGRATOR_VERLET_VELOCITY && !h->dd) FAIL(MDX_EPARAM, "only velocity Verlet is supported when the host drives the decomposition itself (mdx_comm_init handles every integrator)");
-    if (h->baro_kind) FAIL(MDX_EPARAM, "the barostat is not supported on a decomposed handle");
+    if (h->baro_kind && !h->dd) FAIL(MDX_EPARAM, "the barostat needs the library's own decomposition (mdx_comm_init)");
     HIP_TRY(hipSetDevice(h->device));
     int per[3];
     decode_periodic(periodic, per);

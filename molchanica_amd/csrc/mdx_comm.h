@@ -110,3 +110,6 @@ int  mdx_dd_allreduce_host(mdx_handle* h, double* v, int n, bool max_u32 = false
 int  mdx_dd_allreduce_f32(mdx_handle* h, float* dev, size_t n, hipStream_t produced_on);   // sum of a large device array over the ranks
 int  mdx_dd_download(mdx_handle* h, int which, float* dst);   // collective: the global array on every rank
 int  mdx_dd_gather_global(mdx_handle* h, bool with_force);    // g_pos / g_vel (/ g_frc) <- all ranks' owned atoms
+int  mdx_dd_rescale_box(mdx_handle* h, const float hi[3], float mu);   // barostat: scale the gathered state about box_lo, new box, repartition
+int  mdx_dd_save_global(mdx_handle* h, float4* backup);      // minimiser: the accepted state (gathered global positions) ...
+int  mdx_dd_restore_global(mdx_handle* h, const float4* backup);   // ... and back to it (repartition from the copy)

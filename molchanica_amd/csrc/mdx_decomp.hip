@@ -648,12 +648,79 @@ void mdx_dd_destroy(mdx_handle* h) {
     h->dd = nullptr;
 }
 
+// bricks from the handle's box; the halo: ghosts are kept out to r_list + margin (+ ext), atoms may then drift margin / 2
+// before a rank can miss a neighbour (both again whenever the box changes: the barostat)
+static void dd_set_bricks(mdx_handle* h) {
+    MdxDecomp* dd = h->dd;
+    for (int d = 0; d < 3; ++d) {
+        dd->box_lo[d] = h->box_lo[d]; dd->box_len[d] = h->box_hi[d] - h->box_lo[d];
+        dd->brick_lo[d] = dd->box_lo[d] + dd->box_len[d] * (float)dd->coord[d] / (float)dd->grid[d];
+        dd->brick_hi[d] = dd->box_lo[d] + dd->box_len[d] * (float)(dd->coord[d] + 1) / (float)dd->grid[d];
+    }
+}
+static int dd_set_halo(mdx_handle* h) {
+    MdxDecomp* dd = h->dd;
+    double room = 4.4;
+    for (int d = 0; d < 3; ++d)
+        if (dd->grid[d] > 1) room = std::min(room, (double)dd->box_len[d] * (1.0 - 1.0 / dd->grid[d]) / 2.0 - dd->r_list - dd->ext - 0.01);
+    {
+        const char* e = std::getenv("MDX_HALO_MARGIN");
+        if (e) room = std::min(room, std::max(0.0, std::atof(e)));
+    }
+    dd->margin = (float)std::max(0.0, room);
+    dd->halo = dd->r_list + dd->margin + dd->ext;
+    for (int d = 0; d < 3; ++d)
+        if (dd->grid[d] > 1 && dd->box_len[d] / dd->grid[d] + 2.0f * dd->halo > dd->box_len[d] + 1e-3f)
+            FAIL(MDX_EPARAM, "decomposition: brick + 2 halo exceeds the box: an atom would be needed under two images (box too small for this many ranks)");
+    return MDX_OK;
+}
+
+// ---- what the single-GPU workflows do between steps, on a decomposed handle ---------------------------------------------
+// Barostat (BarostatCfg, /root/reference src/properties/crystal.rs:312-315): the pressure is all-reduced, so every rank
+// computes the same mu; the gathered global coordinates are scaled about box_lo on every rank alike, the box, the bricks and
+// the halo follow, and the ranks repartition from that state.
+__global__ void dd_scale_global_kernel(uint32_t N, float4* __restrict__ g_pos, DdPart p, float mu) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float4 q = g_pos[i];
+    q.x = p.lo[0] + mu * (dd_wrap1(q.x, p.lo[0], p.len[0]) - p.lo[0]);
+    q.y = p.lo[1] + mu * (dd_wrap1(q.y, p.lo[1], p.len[1]) - p.lo[1]);
+    q.z = p.lo[2] + mu * (dd_wrap1(q.z, p.lo[2], p.len[2]) - p.lo[2]);
+    g_pos[i] = q;
+}
+int mdx_dd_rescale_box(mdx_handle* h, const float hi[3], float mu) {
+    MdxDecomp* dd = h->dd;
+    MDX_TRY(mdx_dd_gather_global(h, false));
+    hipLaunchKernelGGL(dd_scale_global_kernel, dim3(div_up(h->N, 256)), dim3(256), 0, h->stream, h->N, dd->g_pos, make_part(dd), mu);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int d = 0; d < 3; ++d) h->box_hi[d] = hi[d];
+    dd_set_bricks(h);
+    MDX_TRY(dd_set_halo(h));
+    MDX_TRY(mdx_pme_setup(h));          // mesh spacing and theta(m) follow the box
+    h->list_valid = false; h->forces_valid = false;
+    MDX_TRY(dd_partition(h));
+    MDX_TRY(mdx_rebuild(h));
+    return MDX_OK;
+}
+// Minimiser: the accepted state is kept as a copy of the gathered global arrays; a refused move goes back to it.
+int mdx_dd_save_global(mdx_handle* h, float4* backup /* [N] device */) {
+    MDX_TRY(mdx_dd_gather_global(h, false));
+    HIP_TRY(hipMemcpyAsync(backup, h->dd->g_pos, sizeof(float4) * (size_t)h->N, hipMemcpyDeviceToDevice, h->stream));
+    return MDX_OK;
+}
+int mdx_dd_restore_global(mdx_handle* h, const float4* backup) {
+    HIP_TRY(hipMemcpyAsync(h->dd->g_pos, backup, sizeof(float4) * (size_t)h->N, hipMemcpyDeviceToDevice, h->stream));
+    h->list_valid = false; h->forces_valid = false;
+    MDX_TRY(dd_partition(h));
+    MDX_TRY(mdx_rebuild(h));
+    return MDX_OK;
+}
+
 int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
     auto bail = [&](int rc) { std::string keep = mdx_last_error(); if (!h->dd) delete tr; else mdx_dd_destroy(h); mdx_set_error(keep); return rc; };
     if (!(h->per[0] && h->per[1] && h->per[2])) { mdx_set_error("spatial decomposition needs a fully periodic box"); return bail(MDX_EPARAM); }
     if (h->n_local != h->N) { mdx_set_error("the handle already simulates a subset"); return bail(MDX_EPARAM); }
-    if (h->alch_on) { mdx_set_error("alchemical windows are not supported on a decomposed handle"); return bail(MDX_EPARAM); }
-    if (h->baro_kind) { mdx_set_error("the barostat is not supported on a decomposed handle"); return bail(MDX_EPARAM); }
     if (hipSetDevice(h->device) != hipSuccess) { mdx_set_error("hipSetDevice failed"); return bail(MDX_EDEVICE); }
     const uint32_t N = h->N;
     MdxDecomp* dd = new MdxDecomp();
@@ -661,11 +728,7 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
     h->dd = dd;
     process_grid(dd->world, dd->grid);
     dd->coord[0] = dd->rank / (dd->grid[1] * dd->grid[2]); dd->coord[1] = (dd->rank / dd->grid[2]) % dd->grid[1]; dd->coord[2] = dd->rank % dd->grid[2];
-    for (int d = 0; d < 3; ++d) {
-        dd->box_lo[d] = h->box_lo[d]; dd->box_len[d] = h->box_hi[d] - h->box_lo[d];
-        dd->brick_lo[d] = dd->box_lo[d] + dd->box_len[d] * (float)dd->coord[d] / (float)dd->grid[d];
-        dd->brick_hi[d] = dd->box_lo[d] + dd->box_len[d] * (float)(dd->coord[d] + 1) / (float)dd->grid[d];
-    }
+    dd_set_bricks(h);
     dd->r_list = h->r_list;
     if (std::isinf(dd->r_list)) { mdx_set_error("spatial decomposition needs finite cut-offs"); return bail(MDX_EPARAM); }
     // ownership anchors and the reach of a constraint cluster / virtual-site family from its anchor
@@ -686,21 +749,7 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
     }
     if (!h->h_vsites.empty() && h->h_groups.empty()) ext = std::max(ext, 2.0);   // flexible parents: a bond length of room
     dd->ext = (float)(ext * 1.05 + (ext > 0.0 ? 0.05 : 0.0));
-    // ghosts are kept out to r_list + margin (+ ext): atoms may then drift margin/2 before a rank can miss a neighbour
-    double room = 4.4;
-    for (int d = 0; d < 3; ++d)
-        if (dd->grid[d] > 1) room = std::min(room, (double)dd->box_len[d] * (1.0 - 1.0 / dd->grid[d]) / 2.0 - dd->r_list - dd->ext - 0.01);
-    {
-        const char* e = std::getenv("MDX_HALO_MARGIN");
-        if (e) room = std::min(room, std::max(0.0, std::atof(e)));
-    }
-    dd->margin = (float)std::max(0.0, room);
-    dd->halo = dd->r_list + dd->margin + dd->ext;
-    for (int d = 0; d < 3; ++d)
-        if (dd->grid[d] > 1 && dd->box_len[d] / dd->grid[d] + 2.0f * dd->halo > dd->box_len[d] + 1e-3f) {
-            mdx_set_error("decomposition: brick + 2 halo exceeds the box: an atom would be needed under two images (box too small for this many ranks)");
-            return bail(MDX_EPARAM);
-        }
+    if (dd_set_halo(h) != MDX_OK) return bail(MDX_EPARAM);
     {   // half shell needs Newton's third law across the rank boundary: the half-list pair kernel (MDX_HALF_SHELL=0: A/B knob)
         const char* e = std::getenv("MDX_HALF_SHELL");
         dd->half_shell = dd->world > 1 && mdx_nb_half(h) && !(e && e[0] == '0');

@@ -97,12 +97,12 @@ __global__ __launch_bounds__(256) void min_move_kernel(uint32_t S, float4* __res
 __global__ __launch_bounds__(256) void ext_work_kernel(uint32_t N, const uint32_t* __restrict__ slot_of,
                                                        const float4* __restrict__ posq, const float4* __restrict__ accepted,
                                                        const float4* __restrict__ ext, float lx, float ly, float lz,
-                                                       double* __restrict__ out) {
+                                                       double* __restrict__ out, const uint8_t* __restrict__ slot_flags) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     double w = 0.0;
     if (i < N) {
         const uint32_t s = slot_of[i];
-        if (s != MDX_INVALID) {
+        if (s != MDX_INVALID && (!slot_flags || (slot_flags[s] & 2u))) {      // (decomposed: every atom is counted by its owner)
             const float4 p = posq[s], a = accepted[i], f = ext[i];
             float dx = p.x - a.x, dy = p.y - a.y, dz = p.z - a.z;
             if (lx > 0.f) dx -= rintf(dx / lx) * lx;
@@ -196,7 +196,17 @@ static int apply_barostat(mdx_handle* h, double dt_couple) {
     if (mu == 1.0) return MDX_OK;
     float hi[3];
     for (int d = 0; d < 3; ++d) hi[d] = h->box_lo[d] + (float)mu * (h->box_hi[d] - h->box_lo[d]);
+    if (h->dd) {      // (the global box is periodic in every dimension whatever the local region is)
+        for (int d = 0; d < 3; ++d)
+            if (hi[d] - h->box_lo[d] < 2.0f * h->r_list) FAIL(MDX_EPARAM, "box edge shorter than 2*(cutoff+skin): minimum image is not unique");
+    } else
     MDX_TRY(mdx_check_box(h, h->box_lo, hi));   // refuse BEFORE touching the state (box < 2 (rc + skin): stop, cf. sol_shrinking_box.rs guards)
+    if (h->dd) {      // decomposed: the same mu on every rank (the pressure is all-reduced); scale the gathered state, repartition
+        MDX_TRY(mdx_dd_rescale_box(h, hi, (float)mu));
+        if (h->n_groups) h->cons_dirty = true;
+        h->last_pressure = e.pressure; h->last_mu = mu;
+        return MDX_OK;
+    }
     MDX_TRY(mdx_unsort_state(h));
     hipLaunchKernelGGL(scale_positions_kernel, dim3(div_up(h->n_local, 256)), dim3(256), 0, h->stream, h->n_local,
                        h->d.pos_orig, h->box_lo[0], h->box_lo[1], h->box_lo[2], (float)mu);
@@ -413,7 +423,7 @@ extern "C" int mdx_configure_alchemical_window(mdx_handle* h, uint32_t mol_index
     if (on) {
         if (!(lambda <= 1.0)) FAIL(MDX_EPARAM, "lambda must lie in [0, 1] (negative switches the window off)");
         if (h->mol_start.empty() || mol_index >= h->mol_start.size()) FAIL(MDX_EPARAM, "molecule index out of range (mol_start missing?)");
-        if (h->dd || h->n_local != h->N) FAIL(MDX_EPARAM, "alchemical windows are not supported on a decomposed handle");
+        if (!h->dd && h->n_local != h->N) FAIL(MDX_EPARAM, "alchemical windows need the library's own decomposition (mdx_comm_init) on a narrowed handle");
     }
     const uint32_t lo = on ? h->mol_start[mol_index] : 0;
     const uint32_t hi = on ? (mol_index + 1 < h->mol_start.size() ? h->mol_start[mol_index + 1] : h->N) : 0;
@@ -440,8 +450,9 @@ extern "C" int mdx_set_barostat(mdx_handle* h, int kind, float pressure_target_b
     if (!h) FAIL(MDX_EPARAM, "null handle");
     if (kind < 0 || kind > 1) FAIL(MDX_EPARAM, "unknown barostat kind");
     if (kind) {
-        if (!h->periodic || !(h->per[0] && h->per[1] && h->per[2])) FAIL(MDX_EPARAM, "the barostat needs a fully periodic box");
-        if (h->dd || h->n_local != h->N) FAIL(MDX_EPARAM, "the barostat is not supported on a decomposed handle");
+        // (a decomposed handle is periodic as a whole: only its local region is not, in the cut dimensions)
+        if (!h->dd && (!h->periodic || !(h->per[0] && h->per[1] && h->per[2]))) FAIL(MDX_EPARAM, "the barostat needs a fully periodic box");
+        if (!h->dd && h->n_local != h->N) FAIL(MDX_EPARAM, "the barostat needs the library's own decomposition (mdx_comm_init) on a narrowed handle");
         if (!(tau_ps > 0.f) || every_n_steps == 0 || !std::isfinite(pressure_target_bar))
             FAIL(MDX_EPARAM, "barostat needs a finite target, tau > 0 and a coupling interval >= 1 step");
     }
@@ -616,18 +627,30 @@ static constexpr double MDX_MIN_MAX_STEP = 0.2;
 extern "C" int mdx_minimize_energy(mdx_handle* h, uint32_t max_iters, const float* ext_forces, float f_tol,
                                    mdx_energies* final_e, uint32_t* iters_done) {
     if (!h) FAIL(MDX_EPARAM, "null handle");
-    if (h->dd || h->n_local != h->N) FAIL(MDX_EPARAM, "minimize_energy on a decomposed handle");
+    if (!h->dd && h->n_local != h->N) FAIL(MDX_EPARAM, "minimize_energy needs the library's own decomposition (mdx_comm_init) on a narrowed handle");
+    // Decomposed handle (collective: every rank makes the call; /root/reference src/properties/sol_shrinking_box.rs:962 reaches the
+    // minimiser through the same MdState): every rank moves the atoms it owns along their forces with the SAME step length -
+    // energies and the largest force are all-reduced, so accept / refuse and the step-length control take the same branch
+    // everywhere; ghost positions follow by halo message before each evaluation; "some atom left the list's reach" is an
+    // all-reduced word and then handled like a stale list of the step loop (local rebuild or repartition); the accepted state is
+    // a copy of the gathered global positions, and a refused move repartitions from it.
+    const bool dd = h->dd != nullptr;
     HIP_TRY(hipSetDevice(h->device));
     MDX_TRY(mdx_step(h, 0.f, ext_forces, 0));      // installs / clears the external forces
     hipStream_t st = h->stream;
     float4* backup = nullptr;                          // accepted positions, caller order
     HIP_TRY(hipMalloc((void**)&backup, sizeof(float4) * (size_t)h->N));
     auto done = [&](int rc) { (void)hipFree(backup); return rc; };
+    auto evaluate = [&](mdx_energies* e) -> int {
+        if (dd && h->dd->world > 1 && h->in_slot_space) { h->dd->halo_pending = true; h->dd->halo_step = -1; }
+        return mdx_energy_impl(h, e);
+    };
+    auto save = [&]() -> int { return dd ? mdx_dd_save_global(h, backup) : mdx_gather_to_orig(h, h->d.posq, backup); };
 
     mdx_energies cur{};
-    int rc = mdx_energy_impl(h, &cur);
+    int rc = evaluate(&cur);
     if (rc != MDX_OK) return done(rc);
-    rc = mdx_gather_to_orig(h, h->d.posq, backup);
+    rc = save();
     if (rc != MDX_OK) return done(rc);
     double hstep = 0.01;
     uint32_t it = 0;
@@ -641,15 +664,19 @@ extern "C" int mdx_minimize_energy(mdx_handle* h, uint32_t max_iters, const floa
         uint32_t flag = 0;
         if (hipMemcpyAsync(&flag, &h->d.ctl->disp2[1], sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) { mdx_set_error("HIP error in minimiser"); return done(MDX_EDEVICE); }
-        if (flag > thr) h->list_valid = false;     // moved more than skin/2 since the last rebuild
+        if (dd) { double fv = (double)flag; rc = mdx_dd_allreduce_host(h, &fv, 1, true); if (rc != MDX_OK) return done(rc); flag = (uint32_t)fv; }
         h->forces_valid = false; h->moved_outside = true;
+        if (flag > thr) {                            // moved more than skin/2 since the last rebuild
+            h->list_valid = false;
+            if (dd) { rc = mdx_dd_on_stale(h); if (rc != MDX_OK) return done(rc); }
+        }
         if (h->n_groups) {                           // keep constrained bonds at their length
             if (!h->list_valid) { rc = mdx_rebuild(h); if (rc != MDX_OK) return done(rc); }
             rc = mdx_launch_constrain_positions(h, 0.f, nullptr, nullptr, 0);
             if (rc != MDX_OK) return done(rc);
         }
         mdx_energies trial{};
-        rc = mdx_energy_impl(h, &trial);
+        rc = evaluate(&trial);
         ++it;
         if (rc == MDX_ENAN) { trial.potential = INFINITY; rc = MDX_OK; }
         if (rc != MDX_OK) return done(rc);
@@ -659,28 +686,36 @@ extern "C" int mdx_minimize_energy(mdx_handle* h, uint32_t max_iters, const floa
         double ext_work = 0.0;
         if (h->have_ext && std::isfinite(trial.potential)) {
             double* wdev = h->d.energy + EN_COUNT + 1;      // the momentum scratch words
+            const bool px = dd || h->per[0], py = dd || h->per[1], pz = dd || h->per[2];
             if (hipMemsetAsync(wdev, 0, sizeof(double), st) != hipSuccess) return done(MDX_EDEVICE);
             hipLaunchKernelGGL(ext_work_kernel, dim3(div_up(h->N, 256)), dim3(256), 0, st, h->N, h->d.slot_of, h->d.posq,
-                               backup, h->d.ext_orig, h->per[0] ? h->box_hi[0] - h->box_lo[0] : 0.f,
-                               h->per[1] ? h->box_hi[1] - h->box_lo[1] : 0.f, h->per[2] ? h->box_hi[2] - h->box_lo[2] : 0.f, wdev);
+                               backup, h->d.ext_orig, px ? h->box_hi[0] - h->box_lo[0] : 0.f,
+                               py ? h->box_hi[1] - h->box_lo[1] : 0.f, pz ? h->box_hi[2] - h->box_lo[2] : 0.f, wdev,
+                               dd ? h->d.slot_flags : nullptr);
             if (hipMemcpyAsync(&ext_work, wdev, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess) { mdx_set_error("HIP error in minimiser"); return done(MDX_EDEVICE); }
+            if (dd) { rc = mdx_dd_allreduce_host(h, &ext_work, 1); if (rc != MDX_OK) return done(rc); }
         }
         if (trial.potential - ext_work < cur.potential) {
             cur = trial;
             hstep = std::min(hstep * 1.2, MDX_MIN_MAX_STEP);
-            rc = mdx_gather_to_orig(h, h->d.posq, backup);
+            rc = save();
             if (rc != MDX_OK) return done(rc);
         } else {
             hstep *= 0.5;
             // undo: accepted positions back into the caller-order staging, velocities kept
-            rc = mdx_unsort_state(h);
-            if (rc != MDX_OK) return done(rc);
-            if (hipMemcpyAsync(h->d.pos_orig, backup, sizeof(float4) * (size_t)h->N, hipMemcpyDeviceToDevice, st) != hipSuccess)
-                return done(MDX_EDEVICE);
-            h->list_valid = false; h->forces_valid = false;
+            if (dd) {
+                rc = mdx_dd_restore_global(h, backup);
+                if (rc != MDX_OK) return done(rc);
+            } else {
+                rc = mdx_unsort_state(h);
+                if (rc != MDX_OK) return done(rc);
+                if (hipMemcpyAsync(h->d.pos_orig, backup, sizeof(float4) * (size_t)h->N, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                    return done(MDX_EDEVICE);
+                h->list_valid = false; h->forces_valid = false;
+            }
             mdx_energies again{};
-            rc = mdx_energy_impl(h, &again);          // forces at the accepted point (the sort order changed)
+            rc = evaluate(&again);          // forces at the accepted point (the sort order changed)
             if (rc != MDX_OK) return done(rc);
             cur.max_force = again.max_force;
         }

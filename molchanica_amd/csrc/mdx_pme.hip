@@ -237,7 +237,7 @@ template <bool ENERGY>
 __global__ __launch_bounds__(256) void pme_solve2_kernel(size_t n, int K1, int K2, int K3h, int K3, float3 inv_len,
                                                          float pi2_over_beta2, float2* __restrict__ F, float2* __restrict__ G,
                                                          const float* __restrict__ theta, double* energy, double asc,
-                                                         const uint32_t* gate, uint32_t thr) {
+                                                         const uint32_t* gate, uint32_t thr, double escale) {
     if (gate && *gate > thr) return;
     double e = 0.0, w = 0.0, ex = 0.0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -268,7 +268,9 @@ __global__ __launch_bounds__(256) void pme_solve2_kernel(size_t n, int K1, int K
         __syncthreads();
         if (threadIdx.x == 0) {
             e = s_e[0] + s_e[1] + s_e[2] + s_e[3]; w = s_w[0] + s_w[1] + s_w[2] + s_w[3]; ex = s_x[0] + s_x[1] + s_x[2] + s_x[3];
-            if (e != 0.0) { atomicAdd(&energy[EN_RECIP], e); atomicAdd(&energy[EN_VIRIAL], w); }
+            // (decomposed handle: every rank solves the same replicated mesh and the energies are summed over the ranks
+            // afterwards - escale = 1 / world; the dU/dlambda word is not part of that sum)
+            if (e != 0.0) { atomicAdd(&energy[EN_RECIP], e * escale); atomicAdd(&energy[EN_VIRIAL], w * escale); }
             if (ex != 0.0) atomicAdd(&energy[EN_COUNT + 5], -ex);     // dU/dlambda of the reciprocal sum
         }
     }
@@ -521,9 +523,9 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
     const float pb = (float)(M_PI * M_PI / ((double)h->cfg.ewald_alpha * h->cfg.ewald_alpha));
     if (alch) {
         if (energy) hipLaunchKernelGGL(pme_solve2_kernel<true>, gs, dim3(256), 0, st, p->n_cplx, h->pme_K[0], h->pme_K[1], K3h, h->pme_K[2],
-                                       inv_len, pb, h->d.pme_f, h->d.pme_f2, h->d.pme_theta, h->d.energy, (double)asc, d_gate, thr);
+                                       inv_len, pb, h->d.pme_f, h->d.pme_f2, h->d.pme_theta, h->d.energy, (double)asc, d_gate, thr, escale);
         else hipLaunchKernelGGL(pme_solve2_kernel<false>, gs, dim3(256), 0, st, p->n_cplx, h->pme_K[0], h->pme_K[1], K3h, h->pme_K[2],
-                                inv_len, pb, h->d.pme_f, h->d.pme_f2, h->d.pme_theta, h->d.energy, (double)asc, d_gate, thr);
+                                inv_len, pb, h->d.pme_f, h->d.pme_f2, h->d.pme_theta, h->d.energy, (double)asc, d_gate, thr, escale);
         if (p->exec_c2r(p->inv, (hipfftComplex*)h->d.pme_f2, h->d.pme_q2) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecC2R failed");
     } else {
         if (energy) hipLaunchKernelGGL(pme_solve_kernel<true>, gs, dim3(256), 0, st, p->n_cplx, h->pme_K[0], h->pme_K[1], K3h,

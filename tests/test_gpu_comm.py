@@ -323,10 +323,17 @@ def test_refusals_and_errors_on_decomposed_handles():
         md.comm_init_fabric(Fabric(1), 0)
         with pytest.raises(ParamError):
             md.comm_init_fabric(Fabric(1), 0)                 # already decomposed
+        # uploads are what is still refused: the state of a decomposed handle is distributed (set it before joining)
         with pytest.raises(ParamError):
-            md.set_barostat(1, 1.0, 1.0)
+            md.set_positions(s.pos)
         with pytest.raises(ParamError):
-            md.minimize_energy(10)
+            md.set_velocities(np.zeros((s.n_atoms, 3), np.float32))
+        with pytest.raises(ParamError):
+            md.set_positions_range(0, s.pos[:3])
+        with pytest.raises(ParamError):
+            md.set_cell(s.box_lo, s.box_hi)
+        with pytest.raises(ParamError):
+            md.initialize_velocities(300.0)
         md.step(0.0005, np.zeros((s.n_atoms, 3), np.float32), 1)   # external forces are served (test above)
         md.step(0.0005, None, 5)                               # a one-rank decomposition just runs
         assert md.step_count == 6
@@ -334,6 +341,111 @@ def test_refusals_and_errors_on_decomposed_handles():
     with MdState(small, MdConfig(**CFG)) as md:
         with pytest.raises(ParamError, match="two images|too small"):
             md.comm_init_fabric(Fabric(2), 0)
+
+
+def _run_ranks_fn(system, cfg, world, fn):
+    """Every rank: create, join, run fn(md) -> result."""
+    from molchanica_amd.md_state import Fabric, MdState
+    fabric = Fabric(world)
+    res, errs = {}, []
+
+    def run(rank):
+        try:
+            with MdState(system, cfg) as md:
+                md.comm_init_fabric(fabric, rank)
+                res[rank] = fn(md)
+        except BaseException as e:   # pragma: no cover
+            errs.append(e); fabric.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join() for t in th]
+    if errs:
+        raise errs[0]
+    return res
+
+
+def test_barostat_on_decomposed_handles():
+    """`barostat_cfg: Some(BarostatCfg{..})` (/root/reference src/properties/crystal.rs:312-315) on 4 ranks: the all-reduced
+    pressure gives every rank the same mu, the gathered coordinates and the box are scaled alike, the ranks repartition.
+    Box edge, pressure and trajectory against one GPU."""
+    from molchanica_amd.md_state import MdState
+    s = systems.water_box(16, seed=4, rigid=True)
+    cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, coulomb_mode=1)
+
+    def run(md):
+        md.set_thermostat(2, 300.0, 0.1, 5, seed=7)
+        md.set_barostat(1, 1.0, 0.5, every_n_steps=5)
+        e0 = md.energy()
+        md.step(0.002, None, 40)
+        return dict(cell=md.cell(), pos=md.positions(), e0=e0, e1=md.energy())
+    with MdState(s, cfg) as md:
+        ref = run(md)
+    res = _run_ranks_fn(s, cfg, 4, run)
+    r0 = res[0]
+    assert abs(r0["e0"]["pressure"] - ref["e0"]["pressure"]) <= 2e-3 * max(abs(ref["e0"]["pressure"]), 100.0), (r0["e0"]["pressure"], ref["e0"]["pressure"])
+    assert abs(r0["e0"]["virial"] - ref["e0"]["virial"]) <= 2e-5 * abs(ref["e0"]["virial"]) + 0.5
+    edge, edge_ref = r0["cell"][1][0] - r0["cell"][0][0], ref["cell"][1][0] - ref["cell"][0][0]
+    assert edge_ref != pytest.approx(s.box_hi[0], abs=1e-4), "the barostat never moved the box"
+    assert edge == pytest.approx(edge_ref, abs=2e-4)
+    for r in range(1, 4):
+        assert np.array_equal(np.asarray(res[r]["cell"]), np.asarray(r0["cell"])) and np.array_equal(res[r]["pos"], r0["pos"])
+    L = np.array([edge_ref] * 3)
+    assert rms_dev(r0["pos"], ref["pos"], L) < 5e-3
+
+
+def test_minimiser_on_decomposed_handles():
+    """`md.minimize_energy(dev, iters, None)` (/root/reference src/properties/sol_shrinking_box.rs:962) on 4 ranks: the same
+    steepest-descent path as one GPU - all-reduced energies and largest force drive one step-length control."""
+    from molchanica_amd.md_state import MdState
+    s = systems.water_box(14, seed=6)
+    cfg = MdConfig(**CFG)
+
+    def run(md):
+        e0 = md.energy()
+        out = md.minimize_energy(16)        # crosses a list rebuild / repartition (a move beyond skin / 2)
+        mid = dict(e=md.energy(), pos=md.positions())
+        md.minimize_energy(24)
+        return dict(e0=e0, out=out, mid=mid, e1=md.energy(), pos=md.positions(), stats=md.stats())
+    with MdState(s, cfg) as md:
+        ref = run(md)
+    res = _run_ranks_fn(s, cfg, 4, run)
+    r0 = res[0]
+    assert ref["e1"]["potential"] < ref["e0"]["potential"] - 100.0
+    assert r0["out"][1] == 16
+    # the same path while no accept / refuse decision is marginal (16 iterations: 16.6 k -> -8.9 k kcal/mol) ...
+    assert r0["mid"]["e"]["potential"] == pytest.approx(ref["mid"]["e"]["potential"], rel=3e-5, abs=0.5)
+    L = np.array(s.box_hi, dtype=np.float64)
+    assert rms_dev(r0["mid"]["pos"], ref["mid"]["pos"], L) < 2e-3
+    # ... and the same basin afterwards (a step whose energy change is within the f32 summation noise may be taken on one
+    # side and halved on the other: steepest descent then follows a neighbouring path, on one GPU from run to run as well)
+    assert r0["e1"]["potential"] == pytest.approx(ref["e1"]["potential"], rel=2e-2)
+    assert r0["stats"]["repartitions"] >= 2
+    for r in range(1, 4):
+        assert np.array_equal(res[r]["pos"], r0["pos"])
+
+
+def test_alchemical_window_on_decomposed_handles():
+    """`md.configure_alchemical_window(dev, 0, lambda)` (/root/reference src/properties/water_sol.rs:556) on 4 ranks, cutoff and
+    SPME Coulomb: energies, dH/dlambda, the coupled interaction and a short trajectory against one GPU."""
+    from molchanica_amd.md_state import MdState
+    s = systems.small_solvated(box=44.0, n_chain=40)
+    for mode, extra in ((1, {}), (2, dict(ewald_alpha=0.35, overrides=0))):
+        cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, coulomb_mode=mode, **extra)
+
+        def run(md):
+            md.configure_alchemical_window(0, 0.35)
+            e0 = md.energy()
+            md.step(0.0005, None, 20)
+            return dict(e0=e0, e1=md.energy(), pos=md.positions())
+        with MdState(s, cfg) as md:
+            ref = run(md)
+        res = _run_ranks_fn(s, cfg, 4, run)
+        r0 = res[0]
+        for k in ("potential", "dh_dlambda", "coupled_interaction", "lj", "coulomb"):
+            tol = max(5e-2, 3e-5 * abs(ref["e0"][k]))
+            assert abs(r0["e0"][k] - ref["e0"][k]) <= tol, (mode, k, r0["e0"][k], ref["e0"][k])
+        assert abs(ref["e0"]["dh_dlambda"]) > 1.0
+        L = np.array(s.box_hi, dtype=np.float64)
+        assert rms_dev(r0["pos"], ref["pos"], L) < 2e-3
 
 
 @pytest.mark.parametrize("world", [1, 4])
