@@ -287,16 +287,19 @@ namespace {
 struct ShmHeader {
     std::atomic<uint32_t> arrived; std::atomic<uint32_t> generation; std::atomic<uint32_t> aborted; uint32_t world;
     uint64_t slot_bytes;
+    std::atomic<uint32_t> magic;     // SHM_READY once rank 0 has initialised everything above (written last, release); SHM_DEAD: a leftover
 };
+constexpr uint32_t SHM_READY = 0x4D445852u, SHM_DEAD = 0xDEADDEADu;
 struct ShmSegEntry { int32_t peer; uint32_t nrows; uint64_t offset; };
 struct ShmSlotHead { uint32_t n_entries; uint32_t word; ShmSegEntry e[64]; };
 
 struct ShmTransport : MdxTransport {
     std::string shm_name; int fd = -1; unsigned char* base = nullptr; size_t total = 0; ShmHeader* hd = nullptr; uint64_t slot_bytes = 0;
+    bool unlinked = false;
     ~ShmTransport() override {
         if (base) munmap(base, total);
         if (fd >= 0) close(fd);
-        if (rank == 0 && !shm_name.empty()) shm_unlink(shm_name.c_str());
+        if (rank == 0 && !shm_name.empty() && !unlinked) shm_unlink(shm_name.c_str());
     }
     const char* name() const override { return "shared memory (host-staged)"; }
     unsigned char* slot(int q) const { return base + 4096 + (size_t)q * slot_bytes; }
@@ -377,32 +380,56 @@ MdxTransport* mdx_make_shm_transport(const char* name, int rank, int world) {
     if (const char* e = std::getenv("MDX_SHM_SLOT_MB")) slot_mb = (size_t)std::max(1, std::atoi(e));
     t->slot_bytes = slot_mb << 20;
     t->total = 4096 + (size_t)world * t->slot_bytes;
-    // rank 0 creates and sizes the segment, the others wait for it to appear at full size
+    // Rank 0 creates the segment afresh: a leftover of the same name (a crashed run, a reused pid in a test's name) is first
+    // poisoned - a rank that attached to it fails its rendezvous instead of waiting on stale counters - then unlinked, and
+    // the new one is opened O_EXCL.  Readiness is ONE word written last (release); the others take nothing from the header
+    // before they have seen it (acquire).  Once every rank has mapped it the name is unlinked: the mappings stay valid and
+    // nothing is left in /dev/shm if the run dies later (round-2 advisor finding).
     const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-        t->fd = shm_open(t->shm_name.c_str(), rank == 0 ? (O_CREAT | O_RDWR) : O_RDWR, 0600);
-        if (t->fd >= 0) {
-            if (rank == 0) { if (ftruncate(t->fd, (off_t)t->total) != 0) { mdx_set_error("shared-memory transport: ftruncate failed"); delete t; return nullptr; } break; }
+    auto expired = [&](int secs) { return std::chrono::steady_clock::now() - t0 > std::chrono::seconds(secs); };
+    auto unmap = [&]() { if (t->base) munmap(t->base, t->total); t->base = nullptr; t->hd = nullptr; if (t->fd >= 0) close(t->fd); t->fd = -1; };
+    if (rank == 0) {
+        int old = shm_open(t->shm_name.c_str(), O_RDWR, 0600);
+        if (old >= 0) {
             struct stat st;
-            if (fstat(t->fd, &st) == 0 && (size_t)st.st_size >= t->total) break;
-            close(t->fd); t->fd = -1;
+            if (fstat(old, &st) == 0 && (size_t)st.st_size >= sizeof(ShmHeader)) {
+                void* om = mmap(nullptr, sizeof(ShmHeader), PROT_READ | PROT_WRITE, MAP_SHARED, old, 0);
+                if (om != MAP_FAILED) { ShmHeader* oh = (ShmHeader*)om; oh->magic.store(SHM_DEAD); oh->aborted.store(1); munmap(om, sizeof(ShmHeader)); }
+            }
+            close(old);
+            shm_unlink(t->shm_name.c_str());
         }
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) { mdx_set_error("shared-memory transport: the segment never appeared"); delete t; return nullptr; }
-        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        t->fd = shm_open(t->shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (t->fd < 0) { mdx_set_error("shared-memory transport: cannot create the segment (another run with the same name?)"); delete t; return nullptr; }
+        if (ftruncate(t->fd, (off_t)t->total) != 0) { mdx_set_error("shared-memory transport: ftruncate failed"); shm_unlink(t->shm_name.c_str()); delete t; return nullptr; }
+        void* m = mmap(nullptr, t->total, PROT_READ | PROT_WRITE, MAP_SHARED, t->fd, 0);
+        if (m == MAP_FAILED) { mdx_set_error("shared-memory transport: mmap failed"); shm_unlink(t->shm_name.c_str()); delete t; return nullptr; }
+        t->base = (unsigned char*)m; t->hd = (ShmHeader*)m;
+        t->hd->arrived.store(0); t->hd->generation.store(0); t->hd->aborted.store(0); t->hd->slot_bytes = t->slot_bytes; t->hd->world = (uint32_t)world;
+        t->hd->magic.store(SHM_READY, std::memory_order_release);
+        if (!t->barrier()) { mdx_set_error("shared-memory transport: rendezvous failed"); shm_unlink(t->shm_name.c_str()); t->unlinked = true; delete t; return nullptr; }
+        shm_unlink(t->shm_name.c_str()); t->unlinked = true;       // every rank has it mapped
+        return t;
     }
-    void* m = mmap(nullptr, t->total, PROT_READ | PROT_WRITE, MAP_SHARED, t->fd, 0);
-    if (m == MAP_FAILED) { mdx_set_error("shared-memory transport: mmap failed"); delete t; return nullptr; }
-    t->base = (unsigned char*)m; t->hd = (ShmHeader*)m;
-    if (rank == 0) { t->hd->arrived.store(0); t->hd->generation.store(0); t->hd->aborted.store(0); t->hd->slot_bytes = t->slot_bytes; t->hd->world = (uint32_t)world; }
-    else {
-        const auto t1 = std::chrono::steady_clock::now();
-        while (t->hd->world != (uint32_t)world) {      // rank 0 has not initialised the header yet
-            if (std::chrono::steady_clock::now() - t1 > std::chrono::seconds(60)) { mdx_set_error("shared-memory transport: header never initialised"); delete t; return nullptr; }
-            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    for (;;) {      // ranks > 0: attach to a READY segment of the right shape; a poisoned or half-built one is tried again
+        if (expired(60)) { mdx_set_error("shared-memory transport: the segment never appeared"); delete t; return nullptr; }
+        t->fd = shm_open(t->shm_name.c_str(), O_RDWR, 0600);
+        struct stat st;
+        if (t->fd < 0 || fstat(t->fd, &st) != 0 || (size_t)st.st_size < t->total) { unmap(); std::this_thread::sleep_for(std::chrono::milliseconds(5)); continue; }
+        void* m = mmap(nullptr, t->total, PROT_READ | PROT_WRITE, MAP_SHARED, t->fd, 0);
+        if (m == MAP_FAILED) { mdx_set_error("shared-memory transport: mmap failed"); delete t; return nullptr; }
+        t->base = (unsigned char*)m; t->hd = (ShmHeader*)m;
+        bool ready = false;
+        for (int spin = 0; spin < 400 && !ready; ++spin) {          // up to ~2 s for rank 0 to finish this segment's header
+            const uint32_t mg = t->hd->magic.load(std::memory_order_acquire);
+            if (mg == SHM_READY) ready = true;
+            else if (mg == SHM_DEAD) break;
+            else std::this_thread::sleep_for(std::chrono::milliseconds(5));
         }
+        if (ready && t->hd->world == (uint32_t)world && t->hd->slot_bytes == t->slot_bytes && t->barrier()) return t;
+        unmap();                                                     // a leftover that rank 0 has poisoned (or is about to): look again
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
     }
-    if (!t->barrier()) { mdx_set_error("shared-memory transport: rendezvous failed"); delete t; return nullptr; }
-    return t;
 }
 
 MdxTransport* mdx_make_fabric_transport(mdx_fabric* f, int rank) {

@@ -1273,6 +1273,11 @@ int mdx_rebuild(mdx_handle* h) {
         hipLaunchKernelGGL(build_list_kernel<LB_SINGLE>, dim3(a.list_grid + rf_blocks), dim3(LB_WAVES * 64), 0, st, a);
         speculative = true;
     }
+    // A region of the single-pass build fills at cap / n_regions, which an imbalance between the regions reaches before the
+    // totals reach cap: while a list grows (equilibration, a shrinking box, an inhomogeneous solute) every rebuild would then
+    // run the speculative pass AND count + fill with the arrays unchanged.  After such an overflow the arrays are sized with
+    // half as much room again as the list needs, so the overflow is paid once (round-2 advisor finding).
+    bool grow_for_regions = false;
     auto two_pass = [&]() -> int {
         HIP_TRY(hipMemsetAsync(d.pair_count, 0, sizeof(unsigned long long) * 2, st));
         HIP_TRY(hipMemsetAsync(d.entry_cnt + T, 0, sizeof(uint32_t), st));
@@ -1285,14 +1290,14 @@ int mdx_rebuild(mdx_handle* h) {
         E = h->h_rb[4]; MC = h->h_rb[5];
         npairs = (unsigned long long)h->h_rb[6] | ((unsigned long long)h->h_rb[7] << 32);
         if (flags[0] & 3u) { mdx_set_error("exclusion table overflow while building the pair list"); return MDX_EPARAM; }
-        if (E > h->cap_entries || !d.entries) {
-            h->cap_entries = (uint64_t)(E * 1.25) + 1024;
+        if (E > h->cap_entries || !d.entries || (grow_for_regions && (double)h->cap_entries < 1.5 * (double)E)) {
+            h->cap_entries = (uint64_t)(E * (grow_for_regions ? 1.5 : 1.25)) + 1024;
             ALLOC(d.entries, h->cap_entries);
             ALLOC(d.entries_in, h->cap_entries);   // dual list: the pruning pass of the pair kernel fills it
             a.entries = d.entries;
         }
-        if (MC > h->cap_mchunks || !d.masks) {
-            h->cap_mchunks = (uint32_t)(MC * 1.25) + 64;
+        if (MC > h->cap_mchunks || !d.masks || (grow_for_regions && (double)h->cap_mchunks < 1.5 * (double)MC)) {
+            h->cap_mchunks = (uint32_t)(MC * (grow_for_regions ? 1.5 : 1.25)) + 64;
             ALLOC(d.masks, (size_t)h->cap_mchunks * 64);
             a.masks = d.masks;
         }
@@ -1351,6 +1356,7 @@ int mdx_rebuild(mdx_handle* h) {
             HIP_TRY(hipMemcpyAsync(d.flags_dev, &keep, sizeof(uint32_t), hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));
             speculative = false;
+            grow_for_regions = (flags[0] & 32u) != 0;
             MDX_TRY(two_pass());
             launch_prune();
             MDX_TRY(read_counts());
