@@ -40,7 +40,7 @@ B_ALG_BONDED_WATER = 52.0      # 36 + 16 t, t = 1 bonded term per atom in flexib
 B_ALG_FUSED_WATER = 116.0      # bonded gather + kick + drift as one pass: the two figures above together
 B_ALG_STEP_WATER = 170.0       # whole step, water box
 FLOP_PER_PAIR = 45.0
-NB_KERNEL_REV = "r02f"         # revision tag of the default pair kernel the cached PMC traffic figure belongs to
+NB_KERNEL_REV = "r03a"         # revision tag of the default pair kernel the cached PMC traffic figure belongs to
 
 
 def parse():
@@ -91,12 +91,16 @@ def cpu_baseline_production(system, cfg, dt, n_steps):
     _, _, _, builds = cp.run(system, cfg, dt, n_steps, energy_every=100, native=True)
     el = time.perf_counter() - t0
     n = system.n_atoms
+    cores = int(lib.cpu_prod_max_threads())
+    pairs = int(lib.cpu_prod_last_pairs())
     return {
         "value": n * n_steps / el, "unit": "atom-updates/s", "steps_per_s": n_steps / el,
-        "cores": int(lib.cpu_prod_max_threads()), "kind": "port-production",
+        "cores": cores, "kind": "port-production", "list_pairs_per_s_per_core": pairs / el / max(cores, 1),
         "sample": f"{n_steps} velocity-Verlet steps of the same {n}-atom box, fp32, cell search -> half Verlet list (rc + skin) "
-                  f"reused across steps ({builds} list builds incl. the first), Newton-3 pair loop, energies every 100 steps, "
-                  f"gcc -O3 -march=native, OpenMP over all host cores, {el:.1f} s",
+                  f"reused across steps ({builds} list builds incl. the first), Newton-3 pair loop over a static, contiguous "
+                  f"partition of the rows (block-private force accumulation), energies every 100 steps, "
+                  f"gcc -O3 -march=native, OpenMP over all host cores, {el:.1f} s: {pairs / el / max(cores, 1) / 1e6:.1f} M list pairs/s/core "
+                  f"(list builds included in the time)",
     }
 
 

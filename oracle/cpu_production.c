@@ -47,6 +47,10 @@ typedef struct {
     float *xref;
     /* per-thread force buffers, tracked in blocks */
     int nthreads; float **fb; uint8_t **touched; uint32_t nblk;
+    /* static partition of the pair rows: thread t owns rows [row_lo[t], row_lo[t+1]) - equal PAIR counts, contiguous in the
+     * (spatially coherent) atom order, so the j atoms it writes to lie in one window of blocks [blk_lo[t], blk_hi[t]) */
+    uint32_t *row_lo; uint32_t *blk_lo, *blk_hi;
+    uint64_t pairs_evaluated;
     uint32_t rebuilds;
 } prod_t;
 
@@ -58,6 +62,8 @@ static int thread_count(void) {
 #endif
 }
 int cpu_prod_max_threads(void) { return thread_count(); }
+static uint64_t g_last_pairs = 0;   /* list pairs evaluated by the last cpu_prod_run (all force passes) */
+uint64_t cpu_prod_last_pairs(void) { return g_last_pairs; }
 
 static int cmp_u32(const void* a, const void* b) {
     uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
@@ -128,6 +134,9 @@ static prod_t* prod_create(const mdx_system* s, const mdx_config* c) {
         p->fb[t] = (float*)calloc((size_t)p->nblk * BLK * 3, sizeof(float));   /* pages are committed when first touched */
         p->touched[t] = (uint8_t*)calloc(p->nblk, 1);
     }
+    p->row_lo = (uint32_t*)calloc((size_t)p->nthreads + 1, sizeof(uint32_t));
+    p->blk_lo = (uint32_t*)calloc((size_t)p->nthreads, sizeof(uint32_t));
+    p->blk_hi = (uint32_t*)calloc((size_t)p->nthreads, sizeof(uint32_t));
     return p;
 }
 
@@ -135,7 +144,7 @@ static void prod_destroy(prod_t* p) {
     if (!p) return;
     for (int t = 0; t < p->nthreads; ++t) { free(p->fb[t]); free(p->touched[t]); }
     free(p->fb); free(p->touched); free(p->c12); free(p->c6); free(p->qs); free(p->invm);
-    free(p->ex_off); free(p->ex_idx); free(p->nl_off); free(p->nl_idx); free(p->xref); free(p);
+    free(p->ex_off); free(p->ex_idx); free(p->nl_off); free(p->nl_idx); free(p->xref); free(p->row_lo); free(p->blk_lo); free(p->blk_hi); free(p);
 }
 
 /* ---- cell search -> half Verlet list ------------------------------------------------------------------------ */
@@ -236,6 +245,24 @@ static void prod_rebuild(prod_t* p, const float* x) {
         }
     }
     free(sx); free(sy); free(sz);
+    {   /* rows -> threads by equal pair counts; the window of blocks each thread's rows write to (j > i: it starts at its first row) */
+        const uint64_t tot = p->nl_off[N];
+        uint32_t r = 0;
+        for (int t = 0; t < p->nthreads; ++t) {
+            p->row_lo[t] = r;
+            const uint64_t goal = tot * (uint64_t)(t + 1) / (uint64_t)p->nthreads;
+            while (r < N && p->nl_off[r + 1] <= goal) ++r;
+            if (t == p->nthreads - 1) r = N;
+        }
+        p->row_lo[p->nthreads] = N;
+#pragma omp parallel for schedule(static, 1)
+        for (int t = 0; t < p->nthreads; ++t) {
+            const uint32_t a = p->row_lo[t], b = p->row_lo[t + 1];
+            uint32_t mx = b ? b - 1 : 0;
+            for (uint64_t k = p->nl_off[a]; k < p->nl_off[b]; ++k) if (p->nl_idx[k] > mx) mx = p->nl_idx[k];
+            p->blk_lo[t] = a / BLK; p->blk_hi[t] = (a < b) ? mx / BLK + 1 : a / BLK;
+        }
+    }
     memcpy(p->xref, x, sizeof(float) * 3 * (size_t)N);
     free(start); free(cell); free(items);
     p->rebuilds++;
@@ -262,8 +289,15 @@ static inline __attribute__((always_inline)) void pair_rows(prod_t* p, const flo
         const int tid = 0;
 #endif
         float* fb = p->fb[tid]; uint8_t* tb = p->touched[tid];
-#pragma omp for schedule(dynamic, 512)
-        for (uint32_t i = 0; i < N; ++i) {
+        /* (the team may be smaller than the partition was built for: a thread then takes every nthreads-th share) */
+#ifdef _OPENMP
+        const int team = omp_get_num_threads();
+#else
+        const int team = 1;
+#endif
+        for (int share = tid; share < p->nthreads; share += team) {
+        for (uint32_t bb = p->blk_lo[share]; bb < p->blk_hi[share]; ++bb) tb[bb] = 1;
+        for (uint32_t i = p->row_lo[share]; i < p->row_lo[share + 1]; ++i) {
             const uint64_t a = p->nl_off[i], b = p->nl_off[i + 1];
             if (a == b) continue;
             const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2], qi = p->qs[i];
@@ -292,11 +326,11 @@ static inline __attribute__((always_inline)) void pair_rows(prod_t* p, const flo
                 fb[3 * j] -= gx; fb[3 * j + 1] -= gy; fb[3 * j + 2] -= gz;     /* j is unique within a row */
             }
             fb[3 * i] += fx; fb[3 * i + 1] += fy; fb[3 * i + 2] += fz;
-            touch(tb, i);
-            for (uint32_t k = 0; k < cnt; ++k) touch(tb, nl[k]);
             e_lj += elj; e_c += ec;
         }
+        }
     }
+    p->pairs_evaluated += p->nl_off[N];
     if (want_e) { en[PE_LJ] += e_lj; en[PE_COUL] += e_c; }
 }
 
@@ -472,6 +506,7 @@ int cpu_prod_run(const mdx_system* s, const mdx_config* c, float* x, float* v, f
         if (want_e) e[PE_KIN] = ke;
     }
     if (en) memcpy(en, e, sizeof(e));
+    g_last_pairs = p->pairs_evaluated;
     const int rb = (int)p->rebuilds;
     free(f);
     prod_destroy(p);

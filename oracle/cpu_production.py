@@ -43,6 +43,7 @@ def lib(native: bool = False):
         l.cpu_prod_forces.argtypes = [C.POINTER(CSystem), C.POINTER(CConfig), _fp, _fp, _dp]
         l.cpu_prod_run.argtypes = [C.POINTER(CSystem), C.POINTER(CConfig), _fp, _fp, C.c_float, C.c_uint32, C.c_uint32, _dp]
         l.cpu_prod_max_threads.restype = C.c_int
+        l.cpu_prod_last_pairs.restype = C.c_uint64
         _libs[native] = l
     return _libs[native]
 
