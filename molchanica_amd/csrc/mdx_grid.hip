@@ -427,7 +427,7 @@ constexpr int LB_WAVES = 4;
 constexpr int LB_REGIONS = 64;   // single-pass build: claim regions of the entry / mask arrays (one cursor line each)
 constexpr int LB_HASH = 1024;
 constexpr int LB_MAXFLAG = 512;
-constexpr int LB_PLAIN = 512;   // single-pass build: plain entries of a tile buffered in LDS before its slice of the list is claimed
+constexpr int LB_PLAIN = 1024;  // single-pass build: plain entries of a tile buffered in LDS before its slice of the list is claimed
 
 __device__ __forceinline__ uint32_t hash_u32(uint32_t k) { return (k * 2654435761u) >> 22; }  // 10 bits
 
@@ -1357,6 +1357,8 @@ int mdx_rebuild(mdx_handle* h) {
             HIP_TRY(hipStreamSynchronize(st));
             speculative = false;
             grow_for_regions = (flags[0] & 32u) != 0;
+            if (std::getenv("MDX_LIST_DEBUG")) fprintf(stderr, "[mdx] single-pass list build fell back: flags %u, T %u, E %u MC %u, cap_e %llu cap_m %u regions %u\n",
+                                                       flags[0], T, E, MC, (unsigned long long)h->cap_entries, h->cap_mchunks, a.n_regions);
             MDX_TRY(two_pass());
             launch_prune();
             MDX_TRY(read_counts());

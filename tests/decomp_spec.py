@@ -298,7 +298,7 @@ class HipEngine:
     """Adapter: torch tensors -> device pointers of the C ABI (molchanica_amd.md_state.MdState)."""
 
     def __init__(self, system: MdSystem, cfg: MdConfig, device: int):
-        from .md_state import MdState
+        from molchanica_amd.md_state import MdState
         self.md = MdState(system, cfg, device)
         self.device = torch.device("cuda", device)
         self.stream = torch.cuda.ExternalStream(self.md.stream_ptr(), device=self.device)
