@@ -40,7 +40,7 @@ B_ALG_BONDED_WATER = 52.0      # 36 + 16 t, t = 1 bonded term per atom in flexib
 B_ALG_FUSED_WATER = 116.0      # bonded gather + kick + drift as one pass: the two figures above together
 B_ALG_STEP_WATER = 170.0       # whole step, water box
 FLOP_PER_PAIR = 45.0
-NB_KERNEL_REV = "r03a"         # revision tag of the default pair kernel the cached PMC traffic figure belongs to
+NB_KERNEL_REV = "r03b"         # revision tag of the default pair kernel the cached PMC traffic figure belongs to
 
 
 def parse():

@@ -427,7 +427,9 @@ constexpr int LB_WAVES = 4;
 constexpr int LB_REGIONS = 64;   // single-pass build: claim regions of the entry / mask arrays (one cursor line each)
 constexpr int LB_HASH = 1024;
 constexpr int LB_MAXFLAG = 512;
-constexpr int LB_PLAIN = 1024;  // single-pass build: plain entries of a tile buffered in LDS before its slice of the list is claimed
+constexpr int LB_PLAIN = 512;   // single-pass build: plain entries of a tile buffered in LDS before its slice of the list is claimed
+constexpr int LB_PLAIN_DD = 1024;   // ... on a half-shell decomposed handle, whose ghost columns at the rim of the halo are slivers with tall tiles
+                                    // (32 KB more LDS per workgroup: with it for everybody the 1 M-atom list build went 0.37 -> 0.43 ms)
 
 __device__ __forceinline__ uint32_t hash_u32(uint32_t k) { return (k * 2654435761u) >> 22; }  // 10 bits
 
@@ -500,14 +502,14 @@ struct ListArgs {
 #define MDX_XCD_SWIZZLE 1     // 0: A/B build without the XCD-aware tile order of the list kernels
 #endif
 enum { LB_COUNT = 0, LB_FILL = 1, LB_SINGLE = 2 };
-template <int MODE>
+template <int MODE, int PLAINCAP = LB_PLAIN>
 __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     constexpr bool FILL = MODE != LB_COUNT;        // entries are produced (to memory, or to LDS first)
     constexpr bool SINGLE = MODE == LB_SINGLE;
     __shared__ uint32_t s_hash[LB_WAVES][LB_HASH];
     __shared__ uint32_t s_fl[LB_WAVES][LB_MAXFLAG];
     __shared__ float s_ibb[LB_WAVES][MDX_CL_PER_TILE][6];
-    __shared__ uint2 s_plain[SINGLE ? LB_WAVES : 1][SINGLE ? LB_PLAIN : 1];
+    __shared__ uint2 s_plain[SINGLE ? LB_WAVES : 1][SINGLE ? PLAINCAP : 1];
     __shared__ uint8_t s_mimask[SINGLE ? LB_WAVES : 1][SINGLE ? LB_MAXFLAG : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (SINGLE && blockIdx.x >= a.list_grid) {     // the role lists ride along: independent of the pair list, and this launch leaves CUs idle
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
                         } else if (pass) {
                             uint32_t k = np + __popcll(bp & lt_mask);
                             if (!SINGLE) a.entries[ebase + nm_pad_total + k] = ent;
-                            else if (k < LB_PLAIN) s_plain[wave][k] = ent;
+                            else if (k < PLAINCAP) s_plain[wave][k] = ent;
                         }
                     }
                     nm += __popcll(bm);
@@ -707,7 +709,7 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     uint32_t mbase = 0;
     if (SINGLE) {
         // claim this tile's slice of the entry array and of the mask array, then drain the LDS buffers into it
-        bool fits = nm <= LB_MAXFLAG && np <= LB_PLAIN;
+        bool fits = nm <= LB_MAXFLAG && np <= PLAINCAP;
         if (!fits) atomicOr(a.err, 16u);
         // A returning atomic on one address is served every ~35 ns (tools/ubench/grid_barrier.hip): two per tile on one
         // pair of cursors made 16 k tiles queue for 0.46 ms - the whole duration of this kernel at 1 M atoms, whatever its
@@ -1270,7 +1272,8 @@ int mdx_rebuild(mdx_handle* h) {
             rf_blocks = div_up(S, LB_WAVES * 64);
             roles_done = true;
         }
-        hipLaunchKernelGGL(build_list_kernel<LB_SINGLE>, dim3(a.list_grid + rf_blocks), dim3(LB_WAVES * 64), 0, st, a);
+        if (g.npop > 1) hipLaunchKernelGGL((build_list_kernel<LB_SINGLE, LB_PLAIN_DD>), dim3(a.list_grid + rf_blocks), dim3(LB_WAVES * 64), 0, st, a);
+        else hipLaunchKernelGGL(build_list_kernel<LB_SINGLE>, dim3(a.list_grid + rf_blocks), dim3(LB_WAVES * 64), 0, st, a);
         speculative = true;
     }
     // A region of the single-pass build fills at cap / n_regions, which an imbalance between the regions reaches before the

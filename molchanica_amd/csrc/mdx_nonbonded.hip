@@ -36,6 +36,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstdlib>
+#include <type_traits>
 
 #define WAVE_LDS_SYNC()                                        \
     do {                                                       \
@@ -44,6 +45,13 @@
     } while (0)
 
 constexpr int NB_WAVES = 4;
+#ifndef NB_ASM_PAIR
+#define NB_ASM_PAIR 0     // 1: the default flavour's pair evaluation is the hand-written block pair_eval_asm (v_cmpx exec handling):
+                          // measured round 3 - inner-list walk 0.4566 / 0.4517 ms against 0.4565 / 0.4572 with the compiler's
+                          // v_cmp + s_and_saveexec + s_cbranch_execz + s_or, pruning pass SLOWER (no early-out for the 40 % of its
+                          // cluster pairs without a lane in range): 0.4936 vs 0.4809 ms per step.  Two scalar instructions fewer per
+                          // cluster pair buy nothing; kept as an A/B arm (make EXTRA=-DNB_ASM_PAIR=1), parity-tested once
+#endif
 #ifndef NB_HALF_FLUSH
 #define NB_HALF_FLUSH 0   // 1: j-forces leave once per chunk from LDS; 0: one 24-lane atomic per entry
 #endif
@@ -179,6 +187,74 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
         }
         if (evir) *evir += fs * r2;   // r_ij . F_ij of the pair (fs = 0 outside the cutoffs)
     }
+}
+
+// The force-only pair evaluation of the default flavour (shifted-cutoff Coulomb, Lorentz-Berthelot, one cutoff, half list) as ONE
+// block of hand-written gfx950 instructions (round 3).  Same arithmetic, instruction for instruction, as hipcc's code for
+// pair_eval<..., BRANCHY, HALF>; what differs is the exec-mask handling.  The compiler brackets the in-range part with
+//     v_cmp_gt_f32 vcc / s_and_saveexec_b64 / s_cbranch_execz ... s_or_b64 exec
+// and this loop is issue-bound with scalar instructions costing as much as vector ones (65 M SALU are
+// 17 % of the launch).  Here v_cmpx_gt_f32 narrows EXEC itself and one s_mov_b64 restores it: one scalar instruction per cluster
+// pair instead of three.  Preconditions, all true in nb_cluster_body's entry loop: EXEC is all ones on entry (whole waves, no
+// divergent region around the call); nothing after the block reads VCC.  Hazards: the only EXEC write by a VALU instruction is
+// the v_cmpx, and 21 VALU instructions separate it from whatever follows the block (DPP and v_readlane want 5 / 4 wait states
+// after a VALU write of EXEC; an s_mov of EXEC needs none); the first use of the v_rsq result is four instructions behind it.  BIAS: the masked chunks' NaN-coded exclusion
+// bit enters r^2 as the addend of the first FMA.  R2OUT: the pruning pass wants r^2 (of every lane, in range or not).
+template <bool BIAS, bool R2OUT>
+__device__ __forceinline__ void pair_eval_asm(float xi, float yi, float zi, float qi, float sgi, float epi, const float4 pj,
+                                              const float2 lj, float rc2, float bias, float& fx, float& fy, float& fz,
+                                              float& g0, float& g1, float& g2, float& r2_out) {
+    float dx, dy, dz, r2, t1, t2, t3, t4;
+    if (BIAS) {
+        asm volatile(
+            "v_sub_f32 %[dy], %[yi], %[yj]\n\t"
+            "v_sub_f32 %[dx], %[xi], %[xj]\n\t"
+            "v_fma_f32 %[r2], %[dy], %[dy], %[bias]\n\t"
+            "v_sub_f32 %[dz], %[zi], %[zj]\n\t"
+            "v_fmac_f32 %[r2], %[dx], %[dx]\n\t"
+            "v_fmac_f32 %[r2], %[dz], %[dz]\n\t"
+            : [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [r2] "=&v"(r2)
+            : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [xj] "v"(pj.x), [yj] "v"(pj.y), [zj] "v"(pj.z), [bias] "v"(bias));
+    } else {
+        asm volatile(
+            "v_sub_f32 %[dy], %[yi], %[yj]\n\t"
+            "v_sub_f32 %[dx], %[xi], %[xj]\n\t"
+            "v_mul_f32 %[r2], %[dy], %[dy]\n\t"
+            "v_sub_f32 %[dz], %[zi], %[zj]\n\t"
+            "v_fmac_f32 %[r2], %[dx], %[dx]\n\t"
+            "v_fmac_f32 %[r2], %[dz], %[dz]\n\t"
+            : [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [r2] "=&v"(r2)
+            : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [xj] "v"(pj.x), [yj] "v"(pj.y), [zj] "v"(pj.z));
+    }
+    if (R2OUT) r2_out = r2;
+    asm volatile(
+        "v_cmpx_gt_f32 vcc, %[rc2], %[r2]\n\t"            // EXEC &= (r^2 < rc^2); a NaN r^2 (excluded pair) fails
+        "v_rsq_f32 %[r2], %[r2]\n\t"                      // 1 / r
+        "v_add_f32 %[t1], %[sgi], %[ljx]\n\t"             // sigma_ij = sigma_i / 2 + sigma_j / 2
+        "v_mul_f32 %[t1], %[t1], %[t1]\n\t"
+        "v_mul_f32 %[t2], %[epi], %[ljy]\n\t"             // 24 eps_ij
+        "v_mul_f32 %[t3], %[r2], %[r2]\n\t"               // 1 / r^2
+        "v_mul_f32 %[t1], %[t1], %[t3]\n\t"               // s2 = sigma^2 / r^2
+        "v_mul_f32 %[t4], %[t1], %[t1]\n\t"
+        "v_mul_f32 %[t1], %[t1], %[t4]\n\t"               // s6
+        "v_mul_f32 %[t2], %[t2], %[t1]\n\t"               // 24 eps s6
+        "v_fma_f32 %[t1], %[t1], 2.0, -1.0\n\t"           // 2 s6 - 1
+        "v_mul_f32 %[t1], %[t2], %[t1]\n\t"               // LJ force * r^2
+        "v_mul_f32 %[t2], %[qi], %[qj]\n\t"               // k_e q_i q_j
+        "v_fmac_f32 %[t1], %[t2], %[r2]\n\t"              // + Coulomb force * r^2
+        "v_mul_f32 %[t1], %[t3], %[t1]\n\t"               // fs = (...) / r^2
+        "v_fmac_f32 %[fx], %[dx], %[t1]\n\t"
+        "v_fmac_f32 %[fy], %[dy], %[t1]\n\t"
+        "v_fmac_f32 %[fz], %[dz], %[t1]\n\t"
+        "v_fmac_f32 %[g0], %[dx], %[t1]\n\t"
+        "v_fmac_f32 %[g1], %[dy], %[t1]\n\t"
+        "v_fmac_f32 %[g2], %[dz], %[t1]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        : [fx] "+v"(fx), [fy] "+v"(fy), [fz] "+v"(fz), [g0] "+v"(g0), [g1] "+v"(g1), [g2] "+v"(g2), [r2] "+v"(r2),
+          [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4)
+        : [rc2] "s"(rc2), [sgi] "v"(sgi), [epi] "v"(epi), [ljx] "v"(lj.x), [ljy] "v"(lj.y), [qi] "v"(qi), [qj] "v"(pj.w),
+          [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz)
+        : "vcc");
 }
 
 template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, bool MASKED>
@@ -414,9 +490,14 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
     // (HALF) retire the prologue's loads here: the loop then never waits at its top, where the
     // atomics of the previous chunk are still in flight
     if (HALF && NB_HALF_FLUSH) __builtin_amdgcn_s_waitcnt(0x0F70);
-    for (uint32_t c = part; c < nchunks; c += WPT) {
+    const float rc2_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.p.rc2_lj)));   // an SGPR operand of v_cmpx
+    // The chunk loop exists twice (round 3): the masked chunks at the head of the wave's share, then the plain ones - see the
+    // entry loop.  The software pipeline's state (nj, nl, ny, njc, ent_n, nmq) carries over from the first loop into the second.
+    auto chunk_pass = [&](auto masked_tag, const uint32_t c_begin, const uint32_t c_end) __attribute__((always_inline)) {
+    constexpr bool MASKED_CHUNK = decltype(masked_tag)::value;
+    for (uint32_t c = c_begin; c < c_end; c += WPT) {
         const uint32_t cur_y = ny, cur_jc = njc;
-        const bool masked = c < nmc;
+        constexpr bool masked = MASKED_CHUNK;
         if (masked) s_mask[wave][lane] = nmq;                   // read back a byte per entry: two VGPRs fewer
         if (ENERGY && HALF) s_ownj[wave][lane] = nown;
         if (HALF && NB_HALF_FLUSH) {
@@ -444,7 +525,10 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
         }
         float celj = 0.f, cecoul = 0.f, cevir = 0.f, cecross = 0.f, cedudl = 0.f;   // (ENERGY) fp32 partial sums of this chunk
         uint32_t newy = cur_y & 0xFFu;                                // (pruning launch) this lane's entry word with the inner mask
-        // entry loop: each entry's j record is read from LDS where it is needed (any look-ahead measured slower)
+        // entry loop: each entry's j record is read from LDS where it is needed (any look-ahead measured slower).
+        // Two copies of it (round 3, NB_SPLIT_MASKED): exclusion bits only exist in the masked chunks at the head of a tile's list;
+        // the plain chunks (90-95 %) run a body without the per-pair v_bfe_i32 that turns a mask bit into the NaN addend of r^2
+        // (one VALU instruction of ~29 per cluster pair; 16 k extra bytes of code).
 #pragma unroll 1
         for (int e = 0; e < 8; ++e) {
             const float4 pj = sx[e * 8 + jj];
@@ -452,9 +536,8 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
             const uint32_t im = (__builtin_amdgcn_readlane(cur_y, e * 8) >> 8) & 0xFFu;  // wave-uniform
             if (im == 0) continue;
             uint32_t newm = 0;
-            // exclusion bits only exist in masked chunks; elsewhere the (uniform) imask bit suffices
             // (as EXCLUDED bits: bit ci set <=> this lane's pair with i-cluster ci is masked out)
-            const int x8 = masked ? (int)(~(uint32_t)reinterpret_cast<const uint8_t*>(&s_mask[wave][lane])[e]) : 0;
+            const int x8 = MASKED_CHUNK ? (int)(~(uint32_t)reinterpret_cast<const uint8_t*>(&s_mask[wave][lane])[e]) : 0;
             float g[3] = {0.f, 0.f, 0.f};
             float wj = 0.f;
             if (ENERGY && HALF) wj = 0.5f * s_ownj[wave][e * 8 + jj];
@@ -463,9 +546,14 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
                 if (im & (1u << ci)) {
                     float e1 = 0.f, e2 = 0.f, e3 = 0.f, e4 = 0.f, e5 = 0.f;
                     // 0.0f or NaN: sign-extend bit ci of the exclusion byte over the word (one v_bfe_i32)
-                    const float bias = __int_as_float((x8 << (31 - ci)) >> 31);
+                    const float bias = MASKED_CHUNK ? __int_as_float((x8 << (31 - ci)) >> 31) : 0.f;
                     float r2v = 0.f;
-                    pair_eval<ENERGY, COUL, GEOM, SAMECUT, true, HALF, ALCH, true>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci],
+                    constexpr bool ASM_PAIR = NB_ASM_PAIR && !ENERGY && COUL == CM_SHIFTED && !GEOM && SAMECUT && HALF && !ALCH;
+                    if constexpr (ASM_PAIR)
+                        pair_eval_asm<MASKED_CHUNK, prune>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci], pj, lj, rc2_s, bias, fx[ci], fy[ci], fz[ci],
+                                                           g[0], g[1], g[2], r2v);
+                    else
+                    pair_eval<ENERGY, COUL, GEOM, SAMECUT, true, HALF, ALCH, MASKED_CHUNK>(xi[ci], yi[ci], zi[ci], qi[ci], sgi[ci], epi[ci],
                                                                              pj, lj, true, a.p, fx[ci], fy[ci],
                                                                              fz[ci], e1, e2, g, ENERGY ? &e3 : nullptr,
                                                                              (ENERGY && ALCH) ? &e4 : nullptr, bias,
@@ -547,6 +635,15 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
             }
         }
     }
+    };
+#ifndef NB_SPLIT_MASKED
+#define NB_SPLIT_MASKED 1
+#endif
+    if (NB_SPLIT_MASKED) {
+        const uint32_t c_mid = c_first < nchunks ? c_first : nchunks;      // this wave's first plain chunk
+        chunk_pass(std::true_type{}, (uint32_t)part, c_mid);
+        chunk_pass(std::false_type{}, c_mid, nchunks);
+    } else chunk_pass(std::true_type{}, (uint32_t)part, nchunks);
     // sum the eight j-lanes of every i-atom (lanes ii, ii+8, ..., ii+56), then lane (ii, jj) keeps
     // i-cluster ci == jj: slot tile*64 + jj*8 + ii == tile*64 + lane, a coalesced store.
     float ox = 0.f, oy = 0.f, oz = 0.f;
