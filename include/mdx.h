@@ -444,6 +444,11 @@ int mdx_comm_info(const mdx_handle* h, int* rank, int* world, int grid[3], uint3
  * atoms, the bit set of ranks that keep a copy - and the two halo lists (global atom ids in message order, 0xFFFFFFFF = a
  * peer segment's flag row).  Any pointer may be NULL.  tests/test_gpu_partition_spec.py holds them against the executable
  * specification tests/decomp_spec.py. */
+/* Diagnostics of the reciprocal-space mesh of a decomposed handle: slab_on = 1 when the mesh is cut into x-slabs (one per rank:
+ * block -> slab redistribution, 2-D FFT + transpose + 1-D FFT; mdx_pme.hip), 0 when it is replicated and all-reduced (fallback: mesh
+ * edges not divisible by the rank count, alchemical window, MDX_PME_SLAB=0); bytes this rank SENDS per force call for the
+ * real-space mesh (charges to the slab owners + potential back to the block owners) and for the two FFT transposes. */
+int mdx_pme_info(const mdx_handle* h, int* slab_on, uint64_t* mesh_bytes_sent, uint64_t* transpose_bytes_sent, uint64_t* replicated_mesh_bytes);
 int mdx_comm_debug_partition(mdx_handle* h, uint8_t* cls, uint8_t* owner, uint8_t* image_code, uint32_t* send_mask /* [N] each */,
                              uint32_t* n_send, uint32_t* n_recv, uint32_t* send_ids, uint32_t* recv_ids, uint32_t capacity);
 

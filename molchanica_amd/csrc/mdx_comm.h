@@ -108,6 +108,8 @@ int  mdx_dd_force_return_end(mdx_handle* h, int flag_word);     // ... and add w
 int  mdx_dd_on_stale(mdx_handle* h);                     // the list went stale somewhere: local rebuild or repartition (same branch on every rank)
 int  mdx_dd_allreduce_host(mdx_handle* h, double* v, int n, bool max_u32 = false);
 int  mdx_dd_allreduce_f32(mdx_handle* h, float* dev, size_t n, hipStream_t produced_on);   // sum of a large device array over the ranks
+int  mdx_dd_exchange(mdx_handle* h, const float4* send, const std::vector<MdxSeg>& ssegs, float4* recv, const std::vector<MdxSeg>& rsegs,
+                     hipStream_t produced_on);                // one send/recv group, ordered against `produced_on`
 int  mdx_dd_download(mdx_handle* h, int which, float* dst);   // collective: the global array on every rank
 int  mdx_dd_gather_global(mdx_handle* h, bool with_force);    // g_pos / g_vel (/ g_frc) <- all ranks' owned atoms
 int  mdx_dd_rescale_box(mdx_handle* h, const float hi[3], float mu);   // barostat: scale the gathered state about box_lo, new box, repartition

@@ -395,6 +395,20 @@ int mdx_dd_allreduce_f32(mdx_handle* h, float* dev, size_t n, hipStream_t produc
     return MDX_OK;
 }
 
+// A send/recv group on the handle's communication stream, consuming data produced on `produced_on` and producing data that
+// stream consumes (the slab-decomposed SPME chain: mesh redistribution and FFT transposes).
+int mdx_dd_exchange(mdx_handle* h, const float4* send, const std::vector<MdxSeg>& ssegs, float4* recv, const std::vector<MdxSeg>& rsegs,
+                    hipStream_t produced_on) {
+    MdxDecomp* dd = h->dd;
+    if (dd->comm_stream == produced_on) return dd->tr->exchange(send, ssegs, recv, rsegs, produced_on);
+    HIP_TRY(hipEventRecord(dd->ev_packed, produced_on));
+    HIP_TRY(hipStreamWaitEvent(dd->comm_stream, dd->ev_packed, 0));
+    MDX_TRY(dd->tr->exchange(send, ssegs, recv, rsegs, dd->comm_stream));
+    HIP_TRY(hipEventRecord(dd->ev_arrived, dd->comm_stream));
+    HIP_TRY(hipStreamWaitEvent(produced_on, dd->ev_arrived, 0));
+    return MDX_OK;
+}
+
 int mdx_dd_gather_global(mdx_handle* h, bool with_force) {
     MdxDecomp* dd = h->dd;
     hipStream_t st = h->stream;

@@ -43,6 +43,23 @@ struct PmePlan {
     bool have_plans = false;
     PmeDev dev{};
     size_t n_real = 0, n_cplx = 0;
+    // ---- slab-decomposed mesh of a decomposed handle (round 3; see "Slab-decomposed SPME" below) ----
+    decltype(&hipfftPlanMany) plan_many = nullptr;
+    decltype(&hipfftExecC2C) exec_c2c = nullptr;
+    struct Group { int peer; int a_lo, a_cnt; uint32_t row0, nrows; };     // x-planes [a_lo, a_lo + a_cnt) of a block, for one slab owner
+    struct Slab {
+        bool on = false;
+        int W = 1, rank = 0, nx = 0, ny = 0;                 // planes / rows of the mesh per rank
+        int b0[32][3], nb[32][3];                            // every rank's spread block: origin (unwrapped mesh index) and extent
+        std::vector<Group> out_groups;                       // my block, cut by slab owner (ascending a)
+        std::vector<Group> in_groups;                        // the blocks of all ranks, the part inside my slab (by source rank, ascending a)
+        std::vector<MdxSeg> s_out, r_in, s_tr, r_tr;         // segments of the redistribution (charges out; potential back = reversed) and of the transposes
+        float *slab_real = nullptr; float2 *slab_cplx = nullptr, *tr = nullptr;
+        float4 *buf_a = nullptr, *buf_b = nullptr; size_t cap_a = 0, cap_b = 0;    // staging of the redistribution / transposes
+        hipfftHandle fwd2d{}, inv2d{}, fft1d{};
+        bool have_plans = false;
+        size_t max_out = 0, max_in = 0;                     // largest group (cells) of either list
+    } slab;
 };
 
 __device__ __forceinline__ void bspline4(float w, float* m, float* d) {
@@ -283,12 +300,12 @@ __global__ __launch_bounds__(256) void pme_gather_kernel(uint32_t S, const float
                                                          const float* __restrict__ phi, float4* __restrict__ force,
                                                          const uint32_t* gate, uint32_t thr,
                                                          const float* __restrict__ phi2 = nullptr, const float2* __restrict__ lj = nullptr,
-                                                         float asc = 1.f) {
+                                                         float asc = 1.f, uint32_t need = 1u) {
     if (gate && *gate > thr) return;
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
     const float4 p = posq[s];
-    if (!(slot_flags[s] & 1u) || p.w == 0.f) {
+    if ((slot_flags[s] & need) != need || p.w == 0.f) {      // need = 3: owned atoms only (slab-decomposed mesh: the canvas holds this rank's block)
         if (SEPARATE) force[s] = make_float4(0.f, 0.f, 0.f, 0.f);   // nothing to add for this slot
         return;
     }
@@ -340,6 +357,108 @@ __global__ __launch_bounds__(256) void pme_add_force_kernel(uint32_t S, float4* 
     force[s] = f;
 }
 
+// ---- Slab-decomposed SPME (decomposed handles, round 3) ------------------------------------------------------------------
+// The first decomposed form all-reduced a replicated mesh (55 MB per rank and step at 240^3) and ran the whole FFT on every rank.
+// Now the mesh is cut into x-slabs, one per rank (K1 / W planes):
+//   spread     into the full-size canvas as before, but only a rank's own block is ever touched: its brick widened by the
+//              drift margin and the spline support (block(q) is a pure function of the decomposition, every rank knows all);
+//   charges    my block, cut by slab owner, travels to the owners in ONE send/recv group; an owner adds what arrives
+//              (blocks overlap at their margins) into its slab;
+//   FFT        2-D R2C on the slab's planes (batched hipFFT) -> transpose group: rank q receives the rows y in its y-slab from
+//              everybody and lays them out with x fastest -> 1-D C2C along x (unit stride);
+//   solve      theta(m) on the transposed slab; every rank sums the energy and virial of ITS part (no 1 / W factor any more);
+//   back       1-D inverse, transpose group, 2-D C2R: the convolved potential on the slab's planes;
+//   potential  the reverse of `charges`: every block's cells go back to the block's rank, which writes them into its canvas;
+//   gather     as before, owned atoms only.
+// Per rank and step at 240^3 on 8 ranks: 2 x ~9 MB of real mesh (block minus the part that stays) + 2 x 6.1 MB of transposes,
+// against 55 MB in and out of an all-reduce; FFT work per rank 1 / W.  Falls back to the replicated mesh when K1 or K2 is not a
+// multiple of W, a block would wrap onto itself, or an alchemical window is on (two meshes).
+// One launch moves all the groups of a direction: blockIdx.y = the group (x-planes [a_lo, a_lo + a_cnt) of the block of rank q).
+// MODE 0: slab[i - i0][j][k] += buf (charges arriving at their slab owner; blocks overlap at their margins: atomic add);
+//      1: mesh[i][j][k] = buf (potential arriving at the block's rank, mesh = its canvas, i0 = 0);
+//      2: buf = slab[i - i0][j][k] (potential leaving the slab owner);  3: buf = mesh[i][j][k] (charges leaving the canvas)
+constexpr int PME_MAX_GROUPS = 48;
+struct PmeGroupTab {
+    int n;
+    int q[PME_MAX_GROUPS], a_lo[PME_MAX_GROUPS], a_cnt[PME_MAX_GROUPS]; uint32_t row0[PME_MAX_GROUPS];
+    int b0[32][3], nb[32][3];
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void pme_block_move_kernel(PmeGroupTab t, int K1, int K2, int K3, int i0, float* __restrict__ mesh,
+                                                             float4* __restrict__ buf) {
+    const int g = blockIdx.y;
+    const int q = t.q[g], nby = t.nb[q][1], nbz = t.nb[q][2];
+    const size_t n = (size_t)t.a_cnt[g] * nby * nbz;
+    float* const b = reinterpret_cast<float*>(buf + t.row0[g]);
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % (size_t)nbz), bb = (int)((e / (size_t)nbz) % (size_t)nby), a = t.a_lo[g] + (int)(e / ((size_t)nbz * nby));
+        int i = (t.b0[q][0] + a) % K1; if (i < 0) i += K1;
+        int j = (t.b0[q][1] + bb) % K2; if (j < 0) j += K2;
+        int k = (t.b0[q][2] + c) % K3; if (k < 0) k += K3;
+        const size_t at = ((size_t)(i - i0) * K2 + j) * K3 + k;
+        if (MODE == 0) atomicAdd(&mesh[at], b[e]);
+        else if (MODE == 1) mesh[at] = b[e];
+        else b[e] = mesh[at];
+    }
+}
+// The transposes go through staging buffers of W blocks of blk = nx ny K3h complex numbers each, padded to whole float4 rows
+// (blk_pad).  SLAB side: slab_cplx [nx][K2][K3h] <-> block q holds the rows y in [q ny, (q+1) ny) as [x][y_loc][k].  LINE side:
+// tr [ny][K3h][K1] (x fastest: a strided 1-D hipFFT over [K1][ny][K3h] took 54 us at 200^3 where the unit-stride one takes a
+// few) <-> block s holds the planes x in [s nx, (s+1) nx) as [x_loc][y_loc][k].  TO_BUF: mesh -> buffer.
+template <bool SLAB_SIDE, bool TO_BUF>
+__global__ __launch_bounds__(256) void pme_transpose_kernel(size_t n, int nx, int ny, int K2, int K3h, size_t blk, size_t blk_pad,
+                                                            float2* __restrict__ mesh, float2* __restrict__ buf) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    size_t o;
+    if (SLAB_SIDE) {
+        const int k = (int)(e % (size_t)K3h), y = (int)((e / (size_t)K3h) % (size_t)K2), x = (int)(e / ((size_t)K3h * K2));
+        const int q = y / ny, yl = y - q * ny;
+        o = (size_t)q * blk_pad + ((size_t)x * ny + yl) * K3h + k;
+    } else {      // e runs over tr in ITS order, x fastest: [y_loc][k][x] - the lines along x are contiguous for the 1-D transform
+        const int K1 = (int)(n / ((size_t)ny * K3h));
+        const int x = (int)(e % (size_t)K1), k = (int)((e / (size_t)K1) % (size_t)K3h), yl = (int)(e / ((size_t)K1 * K3h));
+        const int sidx = x / nx, xl = x - sidx * nx;
+        o = (size_t)sidx * blk_pad + ((size_t)xl * ny + yl) * K3h + k;
+    }
+    if (TO_BUF) buf[o] = mesh[e]; else mesh[e] = buf[o];
+}
+template <bool ENERGY>
+__global__ __launch_bounds__(256) void pme_solve_slab_kernel(size_t n, int K1, int K2, int K3h, int K3, int ny, int y0, float3 inv_len,
+                                                             float pi2_over_beta2, float2* __restrict__ F,
+                                                             const float* __restrict__ theta, double* energy,
+                                                             const uint32_t* gate, uint32_t thr) {
+    if (gate && *gate > thr) return;
+    double e = 0.0, w = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int k1 = (int)(i % (size_t)K1), k3 = (int)((i / (size_t)K1) % (size_t)K3h), k2 = y0 + (int)(i / ((size_t)K1 * K3h));      // tr is [y_loc][k][x]
+        const float t = theta[((size_t)k1 * K2 + k2) * K3h + k3];
+        float2 f = F[i];
+        if (ENERGY) {
+            const float mult = (k3 == 0 || (2 * k3 == K3)) ? 1.0f : 2.0f;
+            const double ei = 0.5 * (double)(mult * t * (f.x * f.x + f.y * f.y));
+            const float m1 = (float)(k1 <= K1 / 2 ? k1 : k1 - K1) * inv_len.x;
+            const float m2 = (float)(k2 <= K2 / 2 ? k2 : k2 - K2) * inv_len.y;
+            const float m3 = (float)k3 * inv_len.z;
+            e += ei;
+            w += ei * (1.0 - 2.0 * (double)(pi2_over_beta2 * (m1 * m1 + m2 * m2 + m3 * m3)));
+        }
+        f.x *= t; f.y *= t;
+        F[i] = f;
+    }
+    if (ENERGY) {
+        __shared__ double s_e[4], s_w[4];
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) { e += __shfl_xor(e, m); w += __shfl_xor(w, m); }
+        if ((threadIdx.x & 63) == 0) { s_e[threadIdx.x >> 6] = e; s_w[threadIdx.x >> 6] = w; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            e = s_e[0] + s_e[1] + s_e[2] + s_e[3]; w = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+            if (e != 0.0) { atomicAdd(&energy[EN_RECIP], e); atomicAdd(&energy[EN_VIRIAL], w); }
+        }
+    }
+}
+
 // ---- host -------------------------------------------------------------------------------------------
 static int good_size(double min_n) {
     for (int n = std::max(8, (int)std::ceil(min_n));; ++n) {
@@ -360,6 +479,7 @@ static std::vector<double> bspline_moduli4(int K) {
     return b2;
 }
 
+static void pme_slab_free(PmePlan* p);
 void mdx_pme_destroy(mdx_handle* h) {
     if (h->stream_pme) {
         (void)hipStreamSynchronize(h->stream_pme);
@@ -370,9 +490,160 @@ void mdx_pme_destroy(mdx_handle* h) {
     PmePlan* p = (PmePlan*)h->pme_plan;
     if (!p) return;
     if (p->have_plans) { p->destroy(p->fwd); p->destroy(p->inv); }
+    pme_slab_free(p);
     if (p->lib) dlclose(p->lib);
     delete p;
     h->pme_plan = nullptr;
+}
+
+static void pme_slab_free(PmePlan* p) {
+    PmePlan::Slab& sl = p->slab;
+    if (sl.have_plans) { p->destroy(sl.fwd2d); p->destroy(sl.inv2d); p->destroy(sl.fft1d); sl.have_plans = false; }
+    for (void** q : {(void**)&sl.slab_real, (void**)&sl.slab_cplx, (void**)&sl.tr, (void**)&sl.buf_a, (void**)&sl.buf_b})
+        if (*q) { (void)hipFree(*q); *q = nullptr; }
+    sl.cap_a = sl.cap_b = 0; sl.on = false;
+}
+
+// Geometry, message lists, buffers and plans of the slab-decomposed mesh; called at every mdx_pme_setup (attach, box change).
+// MDX_PME_SLAB=0 keeps the replicated mesh (A/B).
+static int pme_slab_setup(mdx_handle* h, PmePlan* p) {
+    PmePlan::Slab& sl = p->slab;
+    pme_slab_free(p);
+    MdxDecomp* dd = h->dd;
+    const char* e = std::getenv("MDX_PME_SLAB");
+    if (!dd || dd->world < 2 || dd->world > 32 || (e && e[0] == '0') || !p->plan_many || !p->exec_c2c) return MDX_OK;
+    const int W = dd->world, K1 = h->pme_K[0], K2 = h->pme_K[1], K3 = h->pme_K[2], K3h = K3 / 2 + 1;
+    if (K1 % W || K2 % W) return MDX_OK;
+    const int nx = K1 / W, ny = K2 / W;
+    sl.W = W; sl.rank = dd->rank; sl.nx = nx; sl.ny = ny;
+    const int K[3] = {K1, K2, K3};
+    // every rank's spread block: its brick widened by what an owned atom may have drifted since the partition (margin), the
+    // reach of a cluster from its anchor (ext) and the spline support (3 cells below, 1 above the atom's cell)
+    const double pad = (double)dd->margin + (double)dd->ext + 1.0;
+    for (int q = 0; q < W; ++q) {
+        const int cq[3] = {q / (dd->grid[1] * dd->grid[2]), (q / dd->grid[2]) % dd->grid[1], q % dd->grid[2]};
+        for (int d = 0; d < 3; ++d) {
+            const double L = (double)h->box_hi[d] - (double)h->box_lo[d], hc = L / K[d];
+            if (dd->grid[d] == 1) { sl.b0[q][d] = 0; sl.nb[q][d] = K[d]; continue; }
+            const double blo = L * cq[d] / dd->grid[d], bhi = L * (cq[d] + 1) / dd->grid[d];
+            const int lo = (int)std::floor((blo - pad) / hc) - 3, end = (int)std::floor((bhi + pad) / hc) + 2;
+            sl.b0[q][d] = lo; sl.nb[q][d] = end - lo;
+            if (sl.nb[q][d] >= K[d] - (d == 0 ? nx : 0)) { sl.b0[q][d] = 0; sl.nb[q][d] = K[d]; }   // (a block that nearly wraps: take the whole dimension)
+        }
+    }
+    // cut every block by slab owner: runs of consecutive x-planes that belong to the same slab
+    auto groups_of = [&](int q) {
+        std::vector<PmePlan::Group> g;
+        for (int a = 0; a < sl.nb[q][0]; ++a) {
+            int i = (sl.b0[q][0] + a) % K1; if (i < 0) i += K1;
+            const int owner = i / nx;
+            if (!g.empty() && g.back().peer == owner && g.back().a_lo + g.back().a_cnt == a) g.back().a_cnt++;
+            else g.push_back({owner, a, 1, 0u, 0u});
+        }
+        for (auto& x : g) x.nrows = (uint32_t)(((size_t)x.a_cnt * sl.nb[q][1] * sl.nb[q][2] + 3) / 4);
+        return g;
+    };
+    sl.out_groups = groups_of(sl.rank);
+    uint32_t r = 0;
+    for (auto& g : sl.out_groups) { g.row0 = r; r += g.nrows; sl.s_out.push_back({g.peer, g.row0, g.nrows}); }
+    const size_t rows_out = r;
+    r = 0;
+    for (int q = 0; q < W; ++q)
+        for (auto g : groups_of(q))
+            if (g.peer == sl.rank) { g.peer = q; g.row0 = r; r += g.nrows; sl.in_groups.push_back(g); sl.r_in.push_back({q, g.row0, g.nrows}); }
+    const size_t rows_in = r;
+    if (sl.out_groups.size() > (size_t)PME_MAX_GROUPS || sl.in_groups.size() > (size_t)PME_MAX_GROUPS) { pme_slab_free(p); return MDX_OK; }
+    sl.max_out = sl.max_in = 0;
+    for (const auto& g : sl.out_groups) sl.max_out = std::max(sl.max_out, (size_t)g.a_cnt * sl.nb[sl.rank][1] * sl.nb[sl.rank][2]);
+    for (const auto& g : sl.in_groups) sl.max_in = std::max(sl.max_in, (size_t)g.a_cnt * sl.nb[g.peer][1] * sl.nb[g.peer][2]);
+    const size_t blk_rows = ((size_t)nx * ny * K3h + 1) / 2, tr_rows = blk_rows * W;      // (blocks padded to whole float4 rows)
+    for (int q = 0; q < W; ++q) { sl.s_tr.push_back({q, (uint32_t)(q * blk_rows), (uint32_t)blk_rows}); sl.r_tr.push_back({q, (uint32_t)(q * blk_rows), (uint32_t)blk_rows}); }
+    sl.cap_a = std::max(rows_out, tr_rows) + 4; sl.cap_b = std::max(rows_in, tr_rows) + 4;
+    HIP_TRY(hipMalloc((void**)&sl.buf_a, sizeof(float4) * sl.cap_a)); HIP_TRY(hipMalloc((void**)&sl.buf_b, sizeof(float4) * sl.cap_b));
+    HIP_TRY(hipMalloc((void**)&sl.slab_real, sizeof(float) * (size_t)nx * K2 * K3));
+    HIP_TRY(hipMalloc((void**)&sl.slab_cplx, sizeof(float2) * (size_t)nx * K2 * K3h));
+    HIP_TRY(hipMalloc((void**)&sl.tr, sizeof(float2) * (size_t)K1 * ny * K3h));
+    int n2[2] = {K2, K3};
+    int n1[1] = {K1};
+    int emb1[1] = {K1};
+    if (p->plan_many(&sl.fwd2d, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_R2C, nx) != HIPFFT_SUCCESS ||
+        p->plan_many(&sl.inv2d, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_C2R, nx) != HIPFFT_SUCCESS ||
+        p->plan_many(&sl.fft1d, 1, n1, emb1, 1, K1, emb1, 1, K1, HIPFFT_C2C, ny * K3h) != HIPFFT_SUCCESS)
+        FAIL(MDX_EDEVICE, "hipfftPlanMany failed (slab-decomposed SPME)");
+    sl.have_plans = true;
+    p->set_stream(sl.fwd2d, h->stream); p->set_stream(sl.inv2d, h->stream); p->set_stream(sl.fft1d, h->stream);
+    sl.on = true;
+    return MDX_OK;
+}
+
+// The reciprocal-space chain on the slab-decomposed mesh (the canvas h->d.pme_q holds this rank's spread charges on entry and
+// the convolved potential over this rank's block on return).
+static int pme_slab_chain(mdx_handle* h, PmePlan* p, bool energy, const uint32_t* d_gate, uint32_t thr) {
+    PmePlan::Slab& sl = p->slab;
+    hipStream_t st = h->stream;
+    const int K1 = h->pme_K[0], K2 = h->pme_K[1], K3 = h->pme_K[2], K3h = K3 / 2 + 1, nx = sl.nx, ny = sl.ny, me = sl.rank;
+    auto blocks = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    float* canvas = h->d.pme_q;
+    auto table = [&](const std::vector<PmePlan::Group>& gs, bool mine) {
+        PmeGroupTab t{};
+        t.n = (int)gs.size();
+        for (int k = 0; k < t.n; ++k) { t.q[k] = mine ? me : gs[k].peer; t.a_lo[k] = gs[k].a_lo; t.a_cnt[k] = gs[k].a_cnt; t.row0[k] = gs[k].row0; }
+        for (int q = 0; q < sl.W; ++q) for (int d = 0; d < 3; ++d) { t.b0[q][d] = sl.b0[q][d]; t.nb[q][d] = sl.nb[q][d]; }
+        return t;
+    };
+    const PmeGroupTab t_out = table(sl.out_groups, true), t_in = table(sl.in_groups, false);
+    auto grid2 = [](size_t n_max, int n_groups) { return dim3((unsigned)std::min<size_t>((n_max + 255) / 256, 4096), (unsigned)n_groups); };
+    // charges: my block -> the slab owners
+    hipLaunchKernelGGL(pme_block_move_kernel<3>, grid2(sl.max_out, t_out.n), dim3(256), 0, st, t_out, K1, K2, K3, 0, canvas, sl.buf_a);
+    MDX_TRY(mdx_dd_exchange(h, sl.buf_a, sl.s_out, sl.buf_b, sl.r_in, st));
+    HIP_TRY(hipMemsetAsync(sl.slab_real, 0, sizeof(float) * (size_t)nx * K2 * K3, st));
+    hipLaunchKernelGGL(pme_block_move_kernel<0>, grid2(sl.max_in, t_in.n), dim3(256), 0, st, t_in, K1, K2, K3, me * nx, sl.slab_real, sl.buf_b);
+    // forward transform: planes, transpose, lines
+    if (p->exec_r2c(sl.fwd2d, sl.slab_real, (hipfftComplex*)sl.slab_cplx) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecR2C failed (slab)");
+    const size_t n_sl = (size_t)nx * K2 * K3h, blk = (size_t)nx * ny * K3h, blk_pad = (blk + 1) & ~(size_t)1;
+    hipLaunchKernelGGL((pme_transpose_kernel<true, true>), blocks(n_sl), dim3(256), 0, st, n_sl, nx, ny, K2, K3h, blk, blk_pad, sl.slab_cplx, (float2*)sl.buf_a);
+    MDX_TRY(mdx_dd_exchange(h, sl.buf_a, sl.s_tr, sl.buf_b, sl.r_tr, st));
+    hipLaunchKernelGGL((pme_transpose_kernel<false, false>), blocks(n_sl), dim3(256), 0, st, n_sl, nx, ny, K2, K3h, blk, blk_pad, sl.tr, (float2*)sl.buf_b);
+    if (p->exec_c2c(sl.fft1d, (hipfftComplex*)sl.tr, (hipfftComplex*)sl.tr, HIPFFT_FORWARD) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecC2C failed (slab)");
+    // theta(m), energy and virial of this rank's part of reciprocal space
+    const size_t n_tr = (size_t)K1 * ny * K3h;
+    const dim3 gs((unsigned)std::min<size_t>((n_tr + 255) / 256, energy ? 1024 : (size_t)1 << 30));
+    const float3 inv_len = make_float3(p->dev.inv_len[0], p->dev.inv_len[1], p->dev.inv_len[2]);
+    const float pb = (float)(M_PI * M_PI / ((double)h->cfg.ewald_alpha * h->cfg.ewald_alpha));
+    if (energy) hipLaunchKernelGGL(pme_solve_slab_kernel<true>, gs, dim3(256), 0, st, n_tr, K1, K2, K3h, K3, ny, me * ny, inv_len, pb, sl.tr, h->d.pme_theta,
+                                   h->d.energy, d_gate, thr);
+    else hipLaunchKernelGGL(pme_solve_slab_kernel<false>, gs, dim3(256), 0, st, n_tr, K1, K2, K3h, K3, ny, me * ny, inv_len, pb, sl.tr, h->d.pme_theta,
+                            h->d.energy, d_gate, thr);
+    // back: lines, transpose, planes
+    if (p->exec_c2c(sl.fft1d, (hipfftComplex*)sl.tr, (hipfftComplex*)sl.tr, HIPFFT_BACKWARD) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecC2C failed (slab)");
+    hipLaunchKernelGGL((pme_transpose_kernel<false, true>), blocks(n_sl), dim3(256), 0, st, n_sl, nx, ny, K2, K3h, blk, blk_pad, sl.tr, (float2*)sl.buf_a);
+    MDX_TRY(mdx_dd_exchange(h, sl.buf_a, sl.s_tr, sl.buf_b, sl.r_tr, st));
+    hipLaunchKernelGGL((pme_transpose_kernel<true, false>), blocks(n_sl), dim3(256), 0, st, n_sl, nx, ny, K2, K3h, blk, blk_pad, sl.slab_cplx, (float2*)sl.buf_b);
+    if (p->exec_c2r(sl.inv2d, (hipfftComplex*)sl.slab_cplx, sl.slab_real) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecC2R failed (slab)");
+    // potential: every block's cells back to the block's rank
+    hipLaunchKernelGGL(pme_block_move_kernel<2>, grid2(sl.max_in, t_in.n), dim3(256), 0, st, t_in, K1, K2, K3, me * nx, sl.slab_real, sl.buf_b);
+    MDX_TRY(mdx_dd_exchange(h, sl.buf_b, sl.r_in, sl.buf_a, sl.s_out, st));
+    hipLaunchKernelGGL(pme_block_move_kernel<1>, grid2(sl.max_out, t_out.n), dim3(256), 0, st, t_out, K1, K2, K3, 0, canvas, sl.buf_a);
+    HIP_TRY(hipGetLastError());
+    return MDX_OK;
+}
+
+extern "C" int mdx_pme_info(const mdx_handle* h, int* slab_on, uint64_t* mesh_bytes_sent, uint64_t* transpose_bytes_sent, uint64_t* replicated_mesh_bytes) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    const PmePlan* p = (const PmePlan*)h->pme_plan;
+    if (!h->pme_on || !p) FAIL(MDX_EPARAM, "the handle has no reciprocal-space sum");
+    const PmePlan::Slab& sl = p->slab;
+    uint64_t mesh = 0, tr = 0;
+    if (sl.on) {
+        for (const auto& g : sl.out_groups) if (g.peer != sl.rank) mesh += (uint64_t)g.nrows * 16u;      // charges out
+        for (const auto& g : sl.in_groups) if (g.peer != sl.rank) mesh += (uint64_t)g.nrows * 16u;       // potential back
+        tr = 2ull * (uint64_t)(sl.W - 1) * (((uint64_t)sl.nx * sl.ny * (h->pme_K[2] / 2 + 1) + 1) / 2 * 16ull);
+    }
+    if (slab_on) *slab_on = sl.on ? 1 : 0;
+    if (mesh_bytes_sent) *mesh_bytes_sent = mesh;
+    if (transpose_bytes_sent) *transpose_bytes_sent = tr;
+    if (replicated_mesh_bytes) *replicated_mesh_bytes = (uint64_t)p->n_real * 4ull;
+    return MDX_OK;
 }
 
 int mdx_pme_setup(mdx_handle* h) {
@@ -398,6 +669,8 @@ int mdx_pme_setup(mdx_handle* h) {
         p->exec_c2r = (decltype(p->exec_c2r))dlsym(p->lib, "hipfftExecC2R");
         p->set_stream = (decltype(p->set_stream))dlsym(p->lib, "hipfftSetStream");
         p->destroy = (decltype(p->destroy))dlsym(p->lib, "hipfftDestroy");
+        p->plan_many = (decltype(p->plan_many))dlsym(p->lib, "hipfftPlanMany");
+        p->exec_c2c = (decltype(p->exec_c2c))dlsym(p->lib, "hipfftExecC2C");
         if (!p->plan3d || !p->exec_r2c || !p->exec_c2r || !p->set_stream || !p->destroy)
             FAIL(MDX_EDEVICE, "hipFFT symbols missing");
     }
@@ -467,6 +740,7 @@ int mdx_pme_setup(mdx_handle* h) {
     // constants of the Ewald sum (charges: the ones the pair loop uses, i.e. bonded_only atoms carry none)
     h->ewald_self = -(double)c.coulomb_k * beta / std::sqrt(M_PI) * h->sum_q2;
     h->ewald_background = -M_PI * (double)c.coulomb_k * h->total_charge * h->total_charge / (2.0 * V * beta * beta);
+    MDX_TRY(pme_slab_setup(h, p));
     return MDX_OK;
 }
 
@@ -503,6 +777,21 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
     }
     const float asc = (float)(1.0 - h->alch_lambda);
     static const bool per_atom_spread = [] { const char* e = std::getenv("MDX_PME_SPREAD_PER_ATOM"); return e && e[0] == '1'; }();
+    if (p->slab.on && !alch) {      // decomposed handle: x-slabs of the mesh, one per rank (above)
+        float* Q = h->d.pme_q;
+        HIP_TRY(hipMemsetAsync(Q, 0, sizeof(float) * p->n_real, st));
+        if (per_atom_spread || !h->in_slot_space)
+            hipLaunchKernelGGL(pme_spread_kernel, dim3(div_up(h->S * 16u, 256)), dim3(256), 0, st, h->S, h->d.posq,
+                               h->d.slot_flags, p->dev, Q, d_gate, thr, need, h->d.lj, 0);
+        else
+            hipLaunchKernelGGL(pme_spread_tile_kernel, dim3(h->T), dim3(256), 0, st, h->T, h->d.posq, h->d.slot_flags, p->dev,
+                               Q, d_gate, thr, need, h->d.lj, 0);
+        MDX_TRY(pme_slab_chain(h, p, energy, d_gate, thr));
+        hipLaunchKernelGGL(pme_gather_kernel<false>, dim3(div_up(h->S, 256)), dim3(256), 0, st, h->S, h->d.posq, h->d.slot_flags,
+                           p->dev, h->d.pme_q, h->d.force, d_gate, thr, nullptr, h->d.lj, 1.f, 3u);
+        HIP_TRY(hipGetLastError());
+        return MDX_OK;
+    }
     for (int grp = 0; grp < (alch ? 2 : 1); ++grp) {
         float* Q = grp ? h->d.pme_q2 : h->d.pme_q;
         const int sel = alch ? grp + 1 : 0;

@@ -136,6 +136,7 @@ def load_library():
     lib.mdx_comm_init_shm.argtypes = [H, C.c_char_p, C.c_int, C.c_int]
     lib.mdx_comm_selftest.argtypes = [H]
     lib.mdx_comm_selftest_fault.argtypes = [H]
+    lib.mdx_pme_info.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.mdx_comm_debug_partition.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _u32p, _u32p, C.c_void_p, C.c_void_p, C.c_uint32]
     lib.mdx_comm_info.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _u32p, _u32p, _fp]
     _lib = lib
@@ -439,6 +440,12 @@ class MdState:
         _check(lib.mdx_comm_debug_partition(self._h, None, None, None, None, C.byref(ns), C.byref(nr), sid.ctypes.data, rid.ctypes.data,
                                             max(ns.value, nr.value, 1)))
         return dict(cls=cls, owner=owner, image_code=code, send_mask=mask, send_ids=sid[:ns.value], recv_ids=rid[:nr.value])
+
+    def pme_info(self) -> dict:
+        """Is the reciprocal-space mesh of this (decomposed) handle slab-decomposed, and what it sends per force call."""
+        on, a, b, c = C.c_int(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(load_library().mdx_pme_info(self._h, C.byref(on), C.byref(a), C.byref(b), C.byref(c)))
+        return dict(slab_on=bool(on.value), mesh_bytes_sent=a.value, transpose_bytes_sent=b.value, replicated_mesh_bytes=c.value)
 
     def comm_info(self) -> dict:
         r, w, g = C.c_int(), C.c_int(), (C.c_int * 3)()

@@ -32,6 +32,8 @@ def run_ranks(system, cfg, world, n_steps, dt=0.0005, setup=None, want_forces=Fa
                     setup(md)
                 md.comm_init_fabric(fabric, rank)
                 info = md.comm_info()
+                if cfg.coulomb_mode == 2 and not (cfg.overrides & 0x8):
+                    info["pme"] = md.pme_info()
                 e0 = md.energy()
                 f0 = md.forces() if want_forces else None
                 md.step(dt, ext, n_steps)
@@ -272,14 +274,28 @@ def test_default_operating_point_on_decomposed_handles(world):
     assert sum(res[r]["stats"]["n_owned"] for r in range(world)) == s.n_atoms
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_spme_on_decomposed_handles(world):
-    """Ewald Coulomb with the SPME reciprocal sum (the reference's default Coulomb, README.md:240) on a decomposed box:
-    every rank spreads the charges it owns, the charge meshes are summed over the ranks (replicated mesh), every rank
-    solves it and interpolates the forces of its own atoms; the reciprocal energy is reported once."""
+@pytest.mark.parametrize("slab", [True, False])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_spme_on_decomposed_handles(world, slab):
+    """Ewald Coulomb with the SPME reciprocal sum (the reference's default Coulomb, README.md:240) on a decomposed box.
+    slab (the default): the mesh is cut into x-slabs, one per rank - every rank spreads the charges it owns into its own block,
+    blocks travel to the slab owners, the FFT is 2-D on the planes + a transpose group + 1-D along x, every rank sums the
+    reciprocal energy of its part, the potential goes back block by block (mdx_pme.hip, "Slab-decomposed SPME").
+    not slab (MDX_PME_SLAB=0, the round-2 form): a replicated mesh, all-reduced, solved on every rank."""
     from molchanica_amd.md_state import MdState
-    s = systems.small_solvated(n_chain=400, box=44.0)
-    cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, chunk_steps=8, coulomb_mode=2, ewald_alpha=0.35, overrides=0)
+    s = systems.small_solvated(n_chain=400, box=44.0) if world < 8 else systems.small_solvated(n_chain=400, box=56.0)
+    cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, chunk_steps=8, coulomb_mode=2, ewald_alpha=0.35, overrides=0,
+                   pme_grid=(48, 48, 48) if world < 8 else (64, 64, 64))
+    if not slab:
+        os.environ["MDX_PME_SLAB"] = "0"
+    try:
+        _spme_decomposed_body(s, cfg, world, slab)
+    finally:
+        os.environ.pop("MDX_PME_SLAB", None)
+
+
+def _spme_decomposed_body(s, cfg, world, slab):
+    from molchanica_amd.md_state import MdState
     with MdState(s, cfg) as md:
         e_ref = md.energy()
         f_ref = md.forces().astype(np.float64)
@@ -293,8 +309,12 @@ def test_spme_on_decomposed_handles(world):
         assert abs(r0["e0"][k] - e_ref[k]) <= max(5e-2, 1e-5 * abs(e_ref[k])), (k, r0["e0"][k], e_ref[k])
     df = np.linalg.norm(r0["f0"].astype(np.float64) - f_ref, axis=1)
     assert (df <= 3e-4 * np.maximum(np.linalg.norm(f_ref, axis=1), 1.0) + 3e-4).all(), float(df.max())
-    assert rms_dev(r0["pos"], p_ref, 44.0) < 2e-3
+    assert rms_dev(r0["pos"], p_ref, np.array(s.box_hi, dtype=np.float64)) < 2e-3
     assert abs(r0["e1"]["potential"] - e1_ref["potential"]) < 2e-4 * s.n_atoms
+    pme = r0["info"]["pme"]
+    assert pme["slab_on"] == slab
+    if slab:      # what a rank sends per force call stays below the replicated mesh an all-reduce moves in and out
+        assert 0 < pme["mesh_bytes_sent"] + pme["transpose_bytes_sent"] < 2 * pme["replicated_mesh_bytes"]
 
 
 @pytest.mark.parametrize("kind", [1, 2])
