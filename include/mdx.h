@@ -401,7 +401,7 @@ double   mdx_time_ps(const mdx_handle* h);
  *     mdx_energy    returns the totals of the whole box on every rank
  *     mdx_download  gathers the global array on every rank
  * and these three are COLLECTIVE: every rank must make the same calls in the same order.  Constraints, virtual sites,
- * thermostats, every integrator, external forces, snapshots, the SPME reciprocal sum (a replicated mesh, all-reduced), the
+ * thermostats, every integrator, external forces, snapshots, the SPME reciprocal sum (the mesh cut into x-slabs, one per rank: see mdx_pme_info), the
  * barostat (the all-reduced pressure gives every rank the same scale factor; the gathered state and the box are scaled alike,
  * then the ranks repartition), mdx_minimize_energy (collective: all-reduced energies and largest force drive ONE step-length
  * control; the accepted state is the gathered global positions) and alchemical windows (cutoff and SPME) work on a decomposed
