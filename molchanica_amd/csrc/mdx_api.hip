@@ -584,7 +584,17 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
     uint32_t remaining = n_steps;
     while (remaining) {
         MDX_TRY(ensure_ready(h));   // a barostat application at the last cadence point left the list to rebuild
-        const uint32_t chunk = std::min(std::min(remaining, h->cfg.chunk_steps), mdx_steps_to_next_event(h));
+        uint32_t chunk = std::min(std::min(remaining, h->cfg.chunk_steps), mdx_steps_to_next_event(h));
+        // The host enqueues a chunk blind; behind the step at which the list goes stale every launch of the chunk is gated off
+        // (~4 us each, three per step at 1 M atoms: ~8 steps' worth per rebuild with fixed chunks of 16).  Rebuild-free
+        // stretches are regular (thermal motion against a fixed skin), so a chunk is cut to end just behind the step the
+        // stretch is expected to end at: mean + mean absolute deviation + 1.  MDX_CHUNK_PREDICT=0: fixed chunks (A/B).
+        static const bool chunk_predict = [] { const char* e = std::getenv("MDX_CHUNK_PREDICT"); return !(e && e[0] == '0'); }();
+        if (chunk_predict && h->stretch_samples >= 3 && chunk > 4) {
+            const float left = h->stretch_mean + h->stretch_dev + 1.0f - (float)h->steps_since_rebuild;
+            const uint32_t want = left > 4.0f ? (uint32_t)std::ceil(left) : 4u;
+            chunk = std::min(chunk, want);
+        }
         const auto t_chunk = std::chrono::steady_clock::now();
         MdxRange range_chunk("mdx step chunk");
         HIP_TRY(hipMemsetAsync(d.ctl, 0, sizeof(StepCtl), st));
@@ -641,6 +651,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         if (h->dd) h->chunk_s = -1;
         MDX_TRY(ctl_to_host(h));
         uint32_t done = chunk;
+        bool stale_hit = false;
         int first_stale = 1 << 30;
         for (uint32_t s = 0; s < chunk; ++s)
             if (h->h_ctl->disp2[s + 1] > thr) { first_stale = (int)s; break; }
@@ -659,9 +670,22 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
                 // every rank is here at the same step (the flag rides on the halo message): rebuild locally while the
                 // owned + ghost set is still complete, else repartition - decided alike on every rank
                 h->list_valid = false;
+                const float len = (float)(h->steps_since_rebuild + s + 1);   // (mdx_rebuild restarts the count)
                 if (h->dd) { h->chunk_s = -1; MDX_TRY(mdx_dd_on_stale(h)); }
                 else MDX_TRY(mdx_rebuild(h));
-                MDX_TRY(compute_forces(h, false, nullptr, 0));
+                {   // length of the stretch that just ended (running mean and mean absolute deviation)
+                    if (h->stretch_samples == 0) { h->stretch_mean = len; h->stretch_dev = 2.0f; }
+                    else {
+                        h->stretch_dev += 0.25f * (std::fabs(len - h->stretch_mean) - h->stretch_dev);
+                        h->stretch_mean += 0.25f * (len - h->stretch_mean);
+                    }
+                    ++h->stretch_samples;
+                    stale_hit = true;
+                }
+                h->nb_post_rebuild = true;       // dual list: this force call is the pruning pass over the new list
+                const int frc = compute_forces(h, false, nullptr, 0);
+                h->nb_post_rebuild = false;
+                MDX_TRY(frc);
                 if (vv) {
                     MDX_TRY(mdx_launch_integrate(h, 2, dt, nullptr, nullptr, thr));
                     MDX_TRY(mdx_launch_constrain_velocities(h, nullptr, 0));
@@ -710,6 +734,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
                 }
             }
         }
+        h->steps_since_rebuild = stale_hit ? 0u : h->steps_since_rebuild + done;
         h->forces_valid = true;
         h->step_count += done;
         h->time_ps += (double)dt * done;

@@ -427,6 +427,7 @@ constexpr int LB_WAVES = 4;
 constexpr int LB_REGIONS = 64;   // single-pass build: claim regions of the entry / mask arrays (one cursor line each)
 constexpr int LB_HASH = 1024;
 constexpr int LB_MAXFLAG = 512;
+constexpr int LB_CAND = 256;     // candidate j-tiles buffered between the two phases of the neighbourhood search
 constexpr int LB_PLAIN = 512;   // single-pass build: plain entries of a tile buffered in LDS before its slice of the list is claimed
 constexpr int LB_PLAIN_DD = 1024;   // ... on a half-shell decomposed handle, whose ghost columns at the rim of the halo are slivers with tall tiles
                                     // (32 KB more LDS per workgroup: with it for everybody the 1 M-atom list build went 0.37 -> 0.43 ms)
@@ -511,6 +512,7 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     __shared__ float s_ibb[LB_WAVES][MDX_CL_PER_TILE][6];
     __shared__ uint2 s_plain[SINGLE ? LB_WAVES : 1][SINGLE ? PLAINCAP : 1];
     __shared__ uint8_t s_mimask[SINGLE ? LB_WAVES : 1][SINGLE ? LB_MAXFLAG : 1];
+    __shared__ uint32_t s_cand[LB_WAVES][LB_CAND];   // candidate j-tiles of the neighbourhood search: tile | image code << 27
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (SINGLE && blockIdx.x >= a.list_grid) {     // the role lists ride along: independent of the pair list, and this launch leaves CUs idle
         role_fill_body((blockIdx.x - a.list_grid) * (LB_WAVES * 64) + threadIdx.x, a.rf_S, a.orig_of, a.gid, a.rf_lflag, a.slot_of,
@@ -594,102 +596,130 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     }
     const float colw_x = 1.0f / g.inv_col[0], colw_y = 1.0f / g.inv_col[1];
 
-    for (int ix = ix0; ix <= ix1; ++ix) {
-        const int kx = g.per[0] ? floor_div(ix, g.ncx) : 0;
-        const int wx = ix - kx * g.ncx;
-        const float sx = (float)kx * g.len[0];
-        // column slab distance in x (column interval, slightly widened)
-        const float cxlo = g.lo[0] + (float)wx * colw_x + sx - 1e-3f, cxhi = cxlo + colw_x + 2e-3f;
-        const float gx = (wx == 0 || wx == g.ncx - 1) ? 0.f : gap(cxlo, cxhi, lo[0], hi[0]);
-        for (int iy = iy0; iy <= iy1; ++iy) {
-            const int ky = g.per[1] ? floor_div(iy, g.ncy) : 0;
-            const int wy = iy - ky * g.ncy;
-            const float sy = (float)ky * g.len[1];
+    // The neighbourhood is searched in two phases (round 3; it was one loop nest over columns, images and z-windows whose every
+    // iteration began with a chain of dependent loads - tile_start, cell_start, then the cluster boxes - for a window of ~4 tiles,
+    // i.e. 32 of 64 lanes, half of which the half list's parity rule then sent idle: 0.37 ms at 1 M atoms, all of it latency).
+    // (A) one lane per (column, population, z-image): the lanes look their columns' z-windows up together - one round trip -
+    //     and the candidate j-tiles this tile owns (parity rule) are compacted into LDS, image code attached;
+    // (B) eight candidate tiles per pass, lane = j-cluster: the bounding-box tests as before, every lane busy.
+    const int nxr = ix1 - ix0 + 1, nyr = iy1 - iy0 + 1, nkz = kz1 - kz0 + 1;
+    const uint32_t ncombo = (uint32_t)(nxr * nyr * g.npop * nkz);
+    uint32_t* const cand = s_cand[wave];
+    uint32_t nc = 0;
+    auto drain = [&]() {
+        WAVE_LDS_SYNC();
+        for (uint32_t base = 0; base < nc; base += 8) {
+            const uint32_t k = base + (uint32_t)(lane >> 3);
+            bool pass = false, have = k < nc;
+            uint32_t imask = 0, jc = 0, code = 13u;
+            if (have) {
+                const uint32_t cd = cand[k];
+                const uint32_t Jt = cd & 0x7FFFFFFu;
+                code = cd >> 27;
+                jc = Jt * MDX_CL_PER_TILE + (uint32_t)(lane & 7);
+                const float sx = (float)((int)(code % 3u) - 1) * g.len[0], sy = (float)((int)((code / 3u) % 3u) - 1) * g.len[1],
+                            sz = (float)((int)(code / 9u) - 1) * g.len[2];
+                float4 jl = a.cl_lo[jc], jh = a.cl_hi[jc];
+                jl.x += sx; jh.x += sx; jl.y += sy; jh.y += sy; jl.z += sz; jh.z += sz;
+                float dx = gap(jl.x, jh.x, lo[0], hi[0]);
+                float dy = gap(jl.y, jh.y, lo[1], hi[1]);
+                float dz = gap(jl.z, jh.z, lo[2], hi[2]);
+                if (jl.w > 0.f && dx * dx + dy * dy + dz * dz < r2) {
+#pragma unroll
+                    for (int ci = 0; ci < MDX_CL_PER_TILE; ++ci) {
+                        const float* b = s_ibb[wave][ci];
+                        float ex = gap(jl.x, jh.x, b[0], b[3]);
+                        float ey = gap(jl.y, jh.y, b[1], b[4]);
+                        float ez = gap(jl.z, jh.z, b[2], b[5]);
+                        if (ex * ex + ey * ey + ez * ez < r2) imask |= 1u << ci;
+                    }
+                    if (a.half) {
+                        // one owner per pair.  Different tiles: by the parity of I + J (balances
+                        // the lists).  Same tile: the lower cluster owns (ci, cj); a cluster's
+                        // pair with itself is kept and its mask holds the j > i triangle; its
+                        // pair with its own periodic image goes to the "positive" image code.
+                        if (Jt == t) {
+                            const uint32_t cj = jc % MDX_CL_PER_TILE;
+                            const uint32_t self = (code >= 13u) ? 1u : 0u;
+                            imask &= ((1u << cj) - 1u) | (self << cj);
+                        }
+                        if (jh.w <= 0.f) imask &= i_owned;   // neither side owned here: not ours
+                    }
+                    pass = imask != 0;
+                }
+            }
+            const bool flagged = pass && hash_contains(hash, jc);
+            const unsigned long long bm = __ballot(flagged), bp = __ballot(pass && !flagged);
+            if (FILL) {
+                const uint2 ent = make_uint2(jc, code | (imask << 8));
+                if (flagged) {
+                    uint32_t kk = nm + __popcll(bm & lt_mask);
+                    if (!SINGLE) a.entries[ebase + kk] = ent;
+                    if (kk < LB_MAXFLAG) { fl[kk] = jc | (code << 27); if (SINGLE) s_mimask[wave][kk] = (uint8_t)imask; }
+                } else if (pass) {
+                    uint32_t kk = np + __popcll(bp & lt_mask);
+                    if (!SINGLE) a.entries[ebase + nm_pad_total + kk] = ent;
+                    else if (kk < PLAINCAP) s_plain[wave][kk] = ent;
+                }
+            }
+            nm += __popcll(bm);
+            np += __popcll(bp);
+            if (MODE != LB_FILL && pass) npairs += __popc(imask);
+        }
+        WAVE_LDS_SYNC();
+        nc = 0;
+    };
+    for (uint32_t q0 = 0; q0 < ncombo; q0 += 64) {
+        // (A) this lane's column, population and z-image; its window of tiles [tA, tB)
+        uint32_t tA = 0, tB = 0, code = 13u;
+        const uint32_t q = q0 + (uint32_t)lane;
+        if (q < ncombo) {
+            const int kz = kz0 + (int)(q % (uint32_t)nkz);
+            const int pop = (int)((q / (uint32_t)nkz) % (uint32_t)g.npop);
+            const int iy = iy0 + (int)((q / (uint32_t)(nkz * g.npop)) % (uint32_t)nyr);
+            const int ix = ix0 + (int)(q / (uint32_t)(nkz * g.npop * nyr));
+            const int kx = g.per[0] ? floor_div(ix, g.ncx) : 0, ky = g.per[1] ? floor_div(iy, g.ncy) : 0;
+            const int wx = ix - kx * g.ncx, wy = iy - ky * g.ncy;
+            const float sx = (float)kx * g.len[0], sy = (float)ky * g.len[1], sz = (float)kz * g.len[2];
+            // column slab distance in x and y (column interval, slightly widened)
+            const float cxlo = g.lo[0] + (float)wx * colw_x + sx - 1e-3f, cxhi = cxlo + colw_x + 2e-3f;
+            const float gx = (wx == 0 || wx == g.ncx - 1) ? 0.f : gap(cxlo, cxhi, lo[0], hi[0]);
             const float cylo = g.lo[1] + (float)wy * colw_y + sy - 1e-3f, cyhi = cylo + colw_y + 2e-3f;
             const float gy = (wy == 0 || wy == g.ncy - 1) ? 0.f : gap(cylo, cyhi, lo[1], hi[1]);
-            if (gx * gx + gy * gy >= r2) continue;
-            for (int pop = 0; pop < g.npop; ++pop) {      // (half-shell decomposition: the owned and the ghost column at this (x, y))
-            const uint32_t c2 = (uint32_t)((pop * g.ncx + wx) * g.ncy + wy);
-            const uint32_t cl0 = a.tile_start[c2] * MDX_CL_PER_TILE, cl1 = a.tile_start[c2 + 1] * MDX_CL_PER_TILE;
-            if (cl1 == cl0) continue;
-            for (int kz = kz0; kz <= kz1; ++kz) {
-                const float sz = (float)kz * g.len[2];
-                const uint32_t code = (uint32_t)((kx + 1) + 3 * (ky + 1) + 9 * (kz + 1));
+            if (gx * gx + gy * gy < r2) {
+                const uint32_t c2 = (uint32_t)((pop * g.ncx + wx) * g.ncy + wy);
+                const uint32_t t0 = a.tile_start[c2], t1 = a.tile_start[c2 + 1];
+                code = (uint32_t)((kx + 1) + 3 * (ky + 1) + 9 * (kz + 1));
+                tA = t0; tB = t1;
                 // A column's tiles are consecutive z-ranges of its z-sorted atoms: only the tiles that hold
                 // atoms of the z-bins within r of this tile can contribute (a 217 A column is 25 tiles tall,
                 // the window ~4), so look the window up in the cell table instead of testing every cluster.
-                uint32_t clA = cl0, clB = cl1;
-                if (r < 1.0e30f) {
+                if (r < 1.0e30f && t1 > t0) {
                     int zb0 = (int)floorf((lo[2] - r - sz - g.lo[2]) * g.inv_zbin) - 1;
                     int zb1 = (int)floorf((hi[2] + r - sz - g.lo[2]) * g.inv_zbin) + 1;
-                    if (zb1 < 0 || zb0 >= g.nzb) continue;
-                    zb0 = max(zb0, 0); zb1 = min(zb1, g.nzb - 1);
-                    const uint32_t* cs = a.cell_start + (size_t)c2 * g.nzb;
-                    const uint32_t aA = cs[zb0] - cs[0], aB = cs[zb1 + 1] - cs[0];
-                    if (aB <= aA) continue;
-                    clA = cl0 + (aA / MDX_TILE) * MDX_CL_PER_TILE;
-                    clB = min(cl1, cl0 + ((aB + MDX_TILE - 1) / MDX_TILE) * MDX_CL_PER_TILE);
-                }
-                for (uint32_t base = clA; base < clB; base += 64) {
-                    const uint32_t jc = base + lane;
-                    bool pass = false;
-                    uint32_t imask = 0;
-                    // half list: a tile pair has one owner, decided by the parity of I + J - test that first,
-                    // it spares the non-owner the bounding-box arithmetic
-                    const uint32_t Jt = jc / MDX_CL_PER_TILE;
-                    const bool mine = !a.half || Jt == t || ((t < Jt) == (((t + Jt) & 1u) == 0u));
-                    if (jc < clB && mine) {
-                        float4 jl = a.cl_lo[jc], jh = a.cl_hi[jc];
-                        jl.x += sx; jh.x += sx; jl.y += sy; jh.y += sy; jl.z += sz; jh.z += sz;
-                        float dx = gap(jl.x, jh.x, lo[0], hi[0]);
-                        float dy = gap(jl.y, jh.y, lo[1], hi[1]);
-                        float dz = gap(jl.z, jh.z, lo[2], hi[2]);
-                        if (jl.w > 0.f && dx * dx + dy * dy + dz * dz < r2) {
-#pragma unroll
-                            for (int ci = 0; ci < MDX_CL_PER_TILE; ++ci) {
-                                const float* b = s_ibb[wave][ci];
-                                float ex = gap(jl.x, jh.x, b[0], b[3]);
-                                float ey = gap(jl.y, jh.y, b[1], b[4]);
-                                float ez = gap(jl.z, jh.z, b[2], b[5]);
-                                if (ex * ex + ey * ey + ez * ez < r2) imask |= 1u << ci;
-                            }
-                            if (a.half) {
-                                // one owner per pair.  Different tiles: by the parity of I + J (balances
-                                // the lists).  Same tile: the lower cluster owns (ci, cj); a cluster's
-                                // pair with itself is kept and its mask holds the j > i triangle; its
-                                // pair with its own periodic image goes to the "positive" image code.
-                                if (Jt == t) {
-                                    const uint32_t cj = jc % MDX_CL_PER_TILE;
-                                    const uint32_t self = (code >= 13u) ? 1u : 0u;
-                                    imask &= ((1u << cj) - 1u) | (self << cj);
-                                }
-                                if (jh.w <= 0.f) imask &= i_owned;   // neither side owned here: not ours
-                            }
-                            pass = imask != 0;
-                        }
+                    if (zb1 < 0 || zb0 >= g.nzb) tB = tA;
+                    else {
+                        zb0 = max(zb0, 0); zb1 = min(zb1, g.nzb - 1);
+                        const uint32_t* cs = a.cell_start + (size_t)c2 * g.nzb;
+                        const uint32_t aA = cs[zb0] - cs[0], aB = cs[zb1 + 1] - cs[0];
+                        if (aB <= aA) tB = tA;
+                        else { tA = t0 + aA / MDX_TILE; tB = min(t1, t0 + (aB + MDX_TILE - 1) / MDX_TILE); }
                     }
-                    const bool flagged = pass && hash_contains(hash, jc);
-                    const unsigned long long bm = __ballot(flagged), bp = __ballot(pass && !flagged);
-                    if (FILL) {
-                        const uint2 ent = make_uint2(jc, code | (imask << 8));
-                        if (flagged) {
-                            uint32_t k = nm + __popcll(bm & lt_mask);
-                            if (!SINGLE) a.entries[ebase + k] = ent;
-                            if (k < LB_MAXFLAG) { fl[k] = jc | (code << 27); if (SINGLE) s_mimask[wave][k] = (uint8_t)imask; }
-                        } else if (pass) {
-                            uint32_t k = np + __popcll(bp & lt_mask);
-                            if (!SINGLE) a.entries[ebase + nm_pad_total + k] = ent;
-                            else if (k < PLAINCAP) s_plain[wave][k] = ent;
-                        }
-                    }
-                    nm += __popcll(bm);
-                    np += __popcll(bp);
-                    if (MODE != LB_FILL && pass) npairs += __popc(imask);
                 }
-            }
             }
         }
+        // compact the windows' tiles into the candidate buffer, one tile per lane and round.  Half list: a tile pair has one
+        // owner, decided by the parity of I + J - tested here, it spares the non-owner the bounding-box pass altogether
+        for (uint32_t k = 0; __any(tA + k < tB); ++k) {
+            const uint32_t Jt = tA + k;
+            const bool mine = Jt < tB && (!a.half || Jt == t || ((t < Jt) == (((t + Jt) & 1u) == 0u)));
+            const unsigned long long bc = __ballot(mine);
+            if (mine) cand[nc + __popcll(bc & lt_mask)] = Jt | (code << 27);
+            nc += __popcll(bc);
+            if (nc > LB_CAND - 64) drain();
+        }
     }
+    drain();
     const uint32_t nm_pad = (nm + 7) & ~7u, np_pad = (np + 7) & ~7u;
     if (nm > LB_MAXFLAG) atomicOr(a.err, SINGLE ? 16u : 2u);
     if (MODE != LB_FILL) {
@@ -1381,7 +1411,7 @@ int mdx_rebuild(mdx_handle* h) {
     if (h->want_tile_split && mdx_nb_variant(h) >= 2) MDX_TRY(mdx_classify_tiles(h));
     h->list_valid = true;
     h->forces_valid = false;
-    h->rebuild_count++;
+    h->rebuild_count++; h->steps_since_rebuild = 0;
     // dual pair list: the step loop of a half-list run walks a rolling-pruned inner list.  What moves an atom inside
     // the step loop feeds its path accumulator: the drift pass, SHAKE, and - for the ghosts of a decomposed handle - the
     // halo unpack; a virtual site inside the triangle of its parents never moves further than they do (anything else

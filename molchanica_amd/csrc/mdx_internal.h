@@ -251,6 +251,10 @@ struct mdx_handle {
     bool tile_split = false;     // tile_order / n_interior describe the current list
     bool want_tile_split = false; uint32_t cap_tile_split = 0;   // set by the decomposition (world > 1, overlap on)
     int nb_step = -1;            // chunk step of the force call being enqueued (-1: not from the step loop -> outer masks)
+    bool nb_post_rebuild = false;   // the force call that finishes a step behind a list rebuild: it is the pruning pass itself
+    // step loop: length of the rebuild-free stretches (steps), so that a chunk ends near the step the list is expected to go
+    // stale at instead of enqueueing up to chunk_steps - 1 launches the device then gates off
+    uint32_t steps_since_rebuild = 0, stretch_samples = 0; float stretch_mean = 0.f, stretch_dev = 0.f;
     int chunk_s = -1;            // decomposed driver: chunk step whose drift has been enqueued (its prune word is shared by the halo unpack)
     // state flags
     bool list_valid = false;    // spatial caches match the slot-space state

@@ -844,7 +844,7 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
             h->bonded_fused = true;                                                                                \
         }                                                                                                          \
         else if (half && a.inner && dual_merged && wpt == 8) { NB_DUAL(G, S, 3); }                                 \
-        else if (half && a.inner) { NB_DUAL(G, S, 1); NB_DUAL(G, S, 2); }                                          \
+        else if (half && a.inner) { if (!a.force_prune) NB_DUAL(G, S, 1); NB_DUAL(G, S, 2); }   /* (a pass the host forces: no twin) */ \
         else if (half && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true>), g, b, 0, h->stream, a); \
         else if (half && wpt == 2) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 2, true>), g, b, 0, h->stream, a); \
         else if (half && wpt == 1) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 1, true>), g, b, 0, h->stream, a); \
@@ -882,12 +882,15 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
     }
     // dual list: only force calls of the step loop (nb_step >= 0) use the inner masks; everything else - energies, the
     // minimiser, the first evaluation after a rebuild - walks the plain list, which is always valid
-    a.inner = (h->dual_on && !h->alch_on && !energy && h->nb_step >= 0 && d_gate != nullptr) ? 1u : 0u;
+    // ... except the one that finishes the step behind a rebuild (nb_post_rebuild): that one IS the pruning pass (round 3: it
+    // used to walk the plain list, 514 us at 1 M atoms, and the next step pruned, 604; now 604 here and 445 there)
+    const bool step_call = h->nb_step >= 0 && d_gate != nullptr;
+    a.inner = (h->dual_on && !h->alch_on && !energy && (step_call || (h->nb_post_rebuild && h->prune_pending))) ? 1u : 0u;
     if (a.inner) {
         if (part != 2) { h->prune_latch = h->prune_pending; h->prune_pending = false; }   // one decision for both halves of a split launch
         a.force_prune = h->prune_latch ? 1u : 0u;
-        a.prune_flag = &h->d.ctl->prune[h->nb_step + 1];
-        a.prune_flag2 = part == 2 ? &h->d.ctl->prune_ghost[h->nb_step + 1] : nullptr;
+        a.prune_flag = &h->d.ctl->prune[step_call ? h->nb_step + 1 : 0];   // (word 0 is never raised: the drift of step s writes s + 1)
+        a.prune_flag2 = (part == 2 && step_call) ? &h->d.ctl->prune_ghost[h->nb_step + 1] : nullptr;
         const float rin = std::max(cut_on(c.lj_cutoff) ? c.lj_cutoff : 0.f, cut_on(c.coulomb_cutoff) ? c.coulomb_cutoff : 0.f) + h->inner_skin;
         a.rin2 = rin * rin;
         a.entries_in = h->d.entries_in; a.inner_nch = h->d.inner_nch; a.ref = h->d.ref; a.inner_count = h->d.inner_count;
