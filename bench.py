@@ -292,11 +292,13 @@ def main():
         """n steps with energies every --energy-every steps -> number of energy evaluations."""
         n_e = 0
         if args.energy_every > 0:
+            # energies at the steps whose absolute count is a multiple of the cadence - the steps the library was told about
+            # (mdx_set_energy_cadence: they are evaluated with the forces of those steps, not by a second evaluation)
             done = 0
             while done < n:
-                k = min(args.energy_every, n - done)
+                k = min(args.energy_every - md.step_count % args.energy_every, n - done)
                 stepper(k); done += k
-                if done % args.energy_every == 0:
+                if md.step_count % args.energy_every == 0:
                     md.energy(); n_e += 1
         else:
             stepper(n)
@@ -309,6 +311,8 @@ def main():
             return float(t.item())
         return x
 
+    if args.energy_every > 0:
+        md.set_energy_cadence(args.energy_every)
     stepper(args.warmup)
     if world > 1 and args.profile_level == 2:
         # decomposed runs are timed in their production arrangement: the event brackets would switch the interior /

@@ -197,6 +197,9 @@ typedef struct mdx_stats {
     double   repartition_ms_sum;
     /* step loop of the large classes: bonded gather + full kick + drift as one pass (not counted under bonded / integ) */
     double   fused_ms_sum;  uint64_t fused_launches;
+    /* energies: force calls of the energy flavour enqueued so far (one the device gated off behind a stale list counts), and mdx_energy / snapshot / barostat reads served by the evaluation
+     * the step loop made at a cadence step (mdx_set_energy_cadence) instead of one of their own */
+    uint64_t energy_evaluations, energies_from_step_loop;
 } mdx_stats;
 
 typedef struct mdx_handle mdx_handle;
@@ -344,6 +347,14 @@ int mdx_set_barostat(mdx_handle* h, int kind, float pressure_target_bar, float t
 int mdx_set_thermostat(mdx_handle* h, int kind, float temp_target, float tau_ps, uint32_t every_n_steps,
                        uint64_t seed);
 int mdx_set_zero_com_drift(mdx_handle* h, int enable);   /* removed at the thermostat cadence (or every 100 steps) */
+/* Energies at a cadence.  The reference reads them at the ratio of its snapshot handlers (`SnapshotHandlers`, /root/reference
+ * src/md/mod.rs:121-122; src/properties/water_sol.rs:185-189), i.e. the caller knows in advance at which steps it will ask.  Told
+ * that cadence, mdx_step evaluates the energies as part of the force call that ends every step whose count is a multiple of
+ * `every_n_steps` (the energy flavour of the same kernels, on the same positions), and mdx_energy called at such a step
+ * returns them without a second evaluation; at any other step, or after anything has changed the state, mdx_energy evaluates
+ * afresh as before.  The snapshot cadence and the barostat's coupling interval get the same treatment by themselves.
+ * 0 = off (default). */
+int mdx_set_energy_cadence(mdx_handle* h, uint32_t every_n_steps);
 /* In-memory snapshots every `every_n` steps: time, step, energies, positions (and velocities). */
 int      mdx_set_snapshot_cadence(mdx_handle* h, uint32_t every_n, int with_velocities);
 uint32_t mdx_snapshot_count(const mdx_handle* h);

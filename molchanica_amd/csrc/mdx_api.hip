@@ -417,6 +417,7 @@ static int ctl_to_host(mdx_handle* h) {
 
 static int compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint32_t thr) {
     MdxRange range_forces(energy ? "mdx forces+energies" : "mdx forces");
+    if (energy) h->stats.energy_evaluations++;
     MDX_TRY(mdx_launch_vsite_construct(h, gate, thr));     // massless sites follow their parents
     bool split = false;
     if (h->dd && h->dd->halo_pending) {                    // decomposed handle, step loop: ghost positions travel now
@@ -616,6 +617,10 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         // (mdx_integrate.hip); the force call in front of such a pass leaves its bonded launch out.  The last force call of
         // the chunk is complete again (the closing half kick, energies, downloads read the force array).
         const bool fuse_bi = fused && mdx_bonded_integrate_ok(h);
+        // energies are read after this chunk (cadence, snapshot, barostat): its last force call evaluates them
+        const bool want_e = mdx_energy_wanted_at(h, h->step_count + chunk);
+        h->e_cache_valid = false; h->e_pending = false;
+        const size_t e_bytes = sizeof(double) * (EN_COUNT + 8 + MDX_ESTRIDE * MDX_EPART);
         float4* pos_after[MDX_MAX_CHUNK + 1];      // the buffer that holds the positions after step s's drift
         for (uint32_t s = 0; s < chunk; ++s) {
             h->prof_tag = (int)s;
@@ -634,7 +639,9 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
             if (integ == MDX_INTEGRATOR_LANGEVIN_MIDDLE) MDX_TRY(mdx_launch_constrain_velocities(h, &d.ctl->disp2[s], thr));
             h->nb_step = (int)s;      // the pair kernel of this call may walk the inner masks / prune (prune[s + 1])
             if (h->dd) { h->dd->halo_pending = true; h->dd->halo_step = (int)s; h->chunk_s = (int)s; }
-            const int frc = compute_forces(h, false, &d.ctl->disp2[s + 1], thr);
+            const bool e_now = want_e && s + 1 == chunk;
+            if (e_now) HIP_TRY(hipMemsetAsync(d.energy, 0, e_bytes, st));
+            const int frc = compute_forces(h, e_now, &d.ctl->disp2[s + 1], thr);
             h->nb_step = -1; h->bonded_deferred = false;
             MDX_TRY(frc);
             if (vv && !fused) {
@@ -682,8 +689,10 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
                     ++h->stretch_samples;
                     stale_hit = true;
                 }
-                h->nb_post_rebuild = true;       // dual list: this force call is the pruning pass over the new list
-                const int frc = compute_forces(h, false, nullptr, 0);
+                const bool e_now = want_e && s + 1 == chunk;
+                if (e_now) HIP_TRY(hipMemsetAsync(d.energy, 0, e_bytes, st));
+                h->nb_post_rebuild = !e_now;     // dual list: this force call is the pruning pass over the new list
+                const int frc = compute_forces(h, e_now, nullptr, 0);
                 h->nb_post_rebuild = false;
                 MDX_TRY(frc);
                 if (vv) {
@@ -736,6 +745,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         }
         h->steps_since_rebuild = stale_hit ? 0u : h->steps_since_rebuild + done;
         h->forces_valid = true;
+        h->e_pending = want_e && done == chunk;
         h->step_count += done;
         h->time_ps += (double)dt * done;
         remaining -= done;
@@ -750,15 +760,41 @@ extern "C" uint64_t mdx_step_count(const mdx_handle* h) { return h ? h->step_cou
 
 extern "C" int mdx_energy(mdx_handle* h, mdx_energies* out) { return mdx_energy_impl(h, out); }
 
+static int energy_tail(mdx_handle* h, mdx_energies* out);
+
+int mdx_finalize_energy_cache(mdx_handle* h) {
+    if (!h->e_pending) return MDX_OK;
+    h->e_pending = false;
+    if (!h->forces_valid || !h->list_valid || h->cons_dirty) return MDX_OK;   // something moved the atoms since: evaluate afresh when asked
+    // (the thermostat's own kinetic-energy launch added into the same word; the force maximum next to it is idempotent)
+    HIP_TRY(hipMemsetAsync(h->d.energy + EN_KIN, 0, sizeof(double), h->stream));
+    MDX_TRY(energy_tail(h, &h->e_cache));
+    h->e_cache_valid = true; h->e_cache_step = h->step_count;
+    return MDX_OK;
+}
+
 int mdx_energy_impl(mdx_handle* h, mdx_energies* out) {
     if (!h || !out) FAIL(MDX_EPARAM, "null argument");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->e_cache_valid && h->e_cache_step == h->step_count && h->forces_valid && h->list_valid && !h->cons_dirty) {
+        *out = h->e_cache;      // the step loop evaluated them with the forces of this step (mdx_set_energy_cadence)
+        h->stats.energies_from_step_loop++;
+        return MDX_OK;
+    }
     if (!h->list_valid) MDX_TRY(mdx_rebuild(h));
     if (h->cons_dirty) MDX_TRY(ensure_ready(h));
     hipStream_t st = h->stream;
     HIP_TRY(hipMemsetAsync(h->d.energy, 0, sizeof(double) * (EN_COUNT + 8 + MDX_ESTRIDE * MDX_EPART), st));
     MDX_TRY(compute_forces(h, true, nullptr, 0));
     h->forces_valid = true;
+    MDX_TRY(energy_tail(h, out));
+    if (h->profile) mdx_prof_collect(h);
+    return MDX_OK;
+}
+
+// kinetic energy + constraint virial behind a force call of the energy flavour, read-back, totals
+static int energy_tail(mdx_handle* h, mdx_energies* out) {
+    hipStream_t st = h->stream;
     MDX_TRY(mdx_launch_kinetic(h));
     MDX_TRY(mdx_launch_constraint_virial(h));   // SHAKE forces of the last step (0 after a dt = 0 projection)
     double e[EN_COUNT + 8 + MDX_ESTRIDE * MDX_EPART];
@@ -769,7 +805,6 @@ int mdx_energy_impl(mdx_handle* h, mdx_energies* out) {
         const double* q = e + EN_COUNT + 8 + MDX_ESTRIDE * k;
         e[EN_LJ] += q[0]; e[EN_COUL] += q[1]; e[EN_VIRIAL] += q[2]; u_cross += q[3]; du_dl += q[4];
     }
-    if (h->profile) mdx_prof_collect(h);
     if (h->dd) {   // every rank evaluated its share (a pair's energy is split between the owners of its atoms): sum them
         double v[EN_COUNT + 2];
         for (int k = 0; k < EN_COUNT; ++k) v[k] = e[k];
@@ -988,6 +1023,7 @@ extern "C" int mdx_download(mdx_handle* h, int which, float* dst) {
 
 extern "C" int mdx_upload(mdx_handle* h, int which, const float* src) {
     if (!h || !src) FAIL(MDX_EPARAM, "null argument");
+    h->e_cache_valid = false; h->e_pending = false;
     if (which != MDX_POS && which != MDX_VEL) FAIL(MDX_EPARAM, "only MDX_POS and MDX_VEL can be uploaded");
     HIP_TRY(hipSetDevice(h->device));
     if (h->dd || h->n_local != h->N) FAIL(MDX_EPARAM, "mdx_upload on a decomposed handle");
@@ -1039,6 +1075,7 @@ __global__ __launch_bounds__(256) void pose_update_kernel(uint32_t first, uint32
 
 extern "C" int mdx_upload_range(mdx_handle* h, int which, uint32_t first, uint32_t count, const float* src) {
     if (!h || (count && !src)) FAIL(MDX_EPARAM, "null argument");
+    h->e_cache_valid = false; h->e_pending = false;
     if (which != MDX_POS && which != MDX_VEL) FAIL(MDX_EPARAM, "only MDX_POS and MDX_VEL can be uploaded");
     if (h->dd || h->n_local != h->N) FAIL(MDX_EPARAM, "mdx_upload_range on a decomposed handle");
     if ((uint64_t)first + count > h->N) FAIL(MDX_EPARAM, "atom range out of bounds");

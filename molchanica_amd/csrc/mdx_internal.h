@@ -251,6 +251,10 @@ struct mdx_handle {
     bool tile_split = false;     // tile_order / n_interior describe the current list
     bool want_tile_split = false; uint32_t cap_tile_split = 0;   // set by the decomposition (world > 1, overlap on)
     int nb_step = -1;            // chunk step of the force call being enqueued (-1: not from the step loop -> outer masks)
+    // Energies at a cadence (mdx_set_energy_cadence, snapshots, the barostat): the force call that ends such a step runs the
+    // energy flavour of the kernels (e_pending: its sums sit in d.energy), mdx_finalize_energy_cache adds the kinetic energy and
+    // the constraint virial behind the thermostat and keeps the result; mdx_energy at that step returns it.
+    uint32_t energy_every = 0; bool e_pending = false, e_cache_valid = false; uint64_t e_cache_step = 0; mdx_energies e_cache{};
     bool nb_post_rebuild = false;   // the force call that finishes a step behind a list rebuild: it is the pruning pass itself
     // step loop: length of the rebuild-free stretches (steps), so that a chunk ends near the step the list is expected to go
     // stale at instead of enqueueing up to chunk_steps - 1 launches the device then gates off
@@ -373,6 +377,8 @@ int mdx_ensure_ready(mdx_handle* h);
 int mdx_energy_impl(mdx_handle* h, mdx_energies* out);
 int mdx_after_steps(mdx_handle* h, float dt, uint32_t done);      // thermostat / COM / snapshots at their cadence
 uint32_t mdx_steps_to_next_event(const mdx_handle* h);            // chunk lengths stop at these boundaries
+bool mdx_energy_wanted_at(const mdx_handle* h, uint64_t step);    // does something read the energies after step `step`?
+int mdx_finalize_energy_cache(mdx_handle* h);                     // e_pending -> e_cache (kinetic energy, constraint virial, read-back)
 int mdx_launch_scale_velocities(mdx_handle* h, float lambda, const double* com_v_or_null);
 int mdx_launch_momentum(mdx_handle* h);                           // energy[EN_COUNT+1..] <- sum m v (3 doubles) + mass
 

@@ -93,6 +93,7 @@ def load_library():
     lib.mdx_get_box.argtypes = [H, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.mdx_set_zero_com_drift.argtypes = [H, C.c_int]
     lib.mdx_set_snapshot_cadence.argtypes = [H, C.c_uint32, C.c_int]
+    lib.mdx_set_energy_cadence.argtypes = [H, C.c_uint32]
     lib.mdx_snapshot_count.argtypes = [H]
     lib.mdx_snapshot_count.restype = C.c_uint32
     lib.mdx_snapshot_read.argtypes = [H, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
@@ -315,6 +316,11 @@ class MdState:
 
     def set_zero_com_drift(self, enable: bool = True):
         _check(load_library().mdx_set_zero_com_drift(self._h, int(enable)))
+
+    def set_energy_cadence(self, every_n: int):
+        """The caller will read `energy()` after every `every_n`-th step (the ratio of the reference's snapshot handlers,
+        src/md/mod.rs:121-122): the step loop then evaluates the energies with the forces of those steps."""
+        _check(load_library().mdx_set_energy_cadence(self._h, int(every_n)))
 
     def set_snapshot_cadence(self, every_n: int, with_velocities: bool = False):
         """`snapshot_handlers.memory: Some(every_n)` (water_sol.rs:185-189)."""
