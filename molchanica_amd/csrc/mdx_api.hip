@@ -147,7 +147,7 @@ static void free_device(mdx_handle* h) {
                     d.mchunk_cnt, d.mchunk_off, d.entries, d.entries_in, d.inner_nch, d.list_cursors, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
                     d.role_off_s, d.role_rec_s, d.role_prm, d.ctl, d.energy,
                     d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.pme_force, d.cons_o, d.cons_s, d.cons_vir, d.vsite_o, d.vsite_s, d.pme_q, d.pme_f,
-                    d.pme_theta, d.pme_q2, d.pme_f2, d.scratch4, d.tile_bnd, d.tile_scan, d.tile_order};
+                    d.pme_theta, d.pme_q2, d.pme_f2, d.scratch4, d.tile_bnd, d.tile_scan, d.tile_order, d.tile_lpt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = DeviceState{};
 }

@@ -608,18 +608,30 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     uint32_t nc = 0;
     auto drain = [&]() {
         WAVE_LDS_SYNC();
+        // (the boxes of the next eight candidate tiles are fetched while this pass tests its own)
+        uint32_t cd_n = 0; float4 jl_n = make_float4(0.f, 0.f, 0.f, 0.f), jh_n = jl_n;
+        if ((uint32_t)(lane >> 3) < nc) {
+            cd_n = cand[lane >> 3];
+            const uint32_t jn = (cd_n & 0x7FFFFFFu) * MDX_CL_PER_TILE + (uint32_t)(lane & 7);
+            jl_n = a.cl_lo[jn]; jh_n = a.cl_hi[jn];
+        }
         for (uint32_t base = 0; base < nc; base += 8) {
             const uint32_t k = base + (uint32_t)(lane >> 3);
             bool pass = false, have = k < nc;
             uint32_t imask = 0, jc = 0, code = 13u;
+            const uint32_t cd = cd_n;
+            float4 jl = jl_n, jh = jh_n;
+            if (k + 8 < nc) {
+                cd_n = cand[k + 8];
+                const uint32_t jn = (cd_n & 0x7FFFFFFu) * MDX_CL_PER_TILE + (uint32_t)(lane & 7);
+                jl_n = a.cl_lo[jn]; jh_n = a.cl_hi[jn];
+            }
             if (have) {
-                const uint32_t cd = cand[k];
                 const uint32_t Jt = cd & 0x7FFFFFFu;
                 code = cd >> 27;
                 jc = Jt * MDX_CL_PER_TILE + (uint32_t)(lane & 7);
                 const float sx = (float)((int)(code % 3u) - 1) * g.len[0], sy = (float)((int)((code / 3u) % 3u) - 1) * g.len[1],
                             sz = (float)((int)(code / 9u) - 1) * g.len[2];
-                float4 jl = a.cl_lo[jc], jh = a.cl_hi[jc];
                 jl.x += sx; jh.x += sx; jl.y += sy; jh.y += sy; jl.z += sz; jh.z += sz;
                 float dx = gap(jl.x, jh.x, lo[0], hi[0]);
                 float dy = gap(jl.y, jh.y, lo[1], hi[1]);
@@ -868,16 +880,19 @@ __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, f
     const ListCounts cnt = counts[t];
     const uint32_t e0 = entry_off[t], nmc = cnt.n_masked >> 3, nchunks = (cnt.n_masked + cnt.n_plain) >> 3;
     uint32_t kept = 0, wcur = 0;                   // wcur: plain entries written back so far
-    // prefetch chunk 0
-    uint2 ent_n = make_uint2(null_cluster, 13u);
+    // two-deep prefetch, as in the pair kernel: the entries of chunk c + 2 and the atoms of chunk c + 1 are in flight while
+    // chunk c is tested (one-deep, the atom load waited for the entry load it depends on at the top of every chunk)
+    uint2 ent_n = make_uint2(null_cluster, 13u), ent_nn = make_uint2(null_cluster, 13u);
     float4 pj_n = make_float4(0.f, 0.f, 0.f, 0.f);
     if (nchunks) { ent_n = entries[e0 + (lane >> 3)]; pj_n = posq[(size_t)ent_n.x * MDX_CLUSTER + (lane & 7)]; }
+    if (nchunks > 1) ent_nn = entries[e0 + 8 + (lane >> 3)];
     for (uint32_t c = 0; c < nchunks; ++c) {
         const uint2 ent = ent_n;
         float4 pj = pj_n;
         if (c + 1 < nchunks) {
-            ent_n = entries[e0 + (c + 1) * 8 + (lane >> 3)];
+            ent_n = ent_nn;
             pj_n = posq[(size_t)ent_n.x * MDX_CLUSTER + (lane & 7)];
+            if (c + 2 < nchunks) ent_nn = entries[e0 + (c + 2) * 8 + (lane >> 3)];
         }
         const uint32_t code = ent.y & 31u;
         pj.x += (float)((int)(code % 3u) - 1) * shx;
@@ -1408,7 +1423,16 @@ int mdx_rebuild(mdx_handle* h) {
     }
 
     h->tile_split = false; h->n_interior = 0;
-    if (h->want_tile_split && mdx_nb_variant(h) >= 2) MDX_TRY(mdx_classify_tiles(h));
+    {
+        // longest lists first where a launch is only a few rounds of waves (MDX_TILE_LPT=0 / 1 forces it off / on for A/B)
+        static const int lpt_env = [] { const char* e = std::getenv("MDX_TILE_LPT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+        // default: every decomposed handle (owned bricks and halo shells: its lists differ by an order of magnitude), and
+        // single-device systems below the size at which a contiguous eighth of the tiles per XCD starts to matter
+        const bool want = lpt_env >= 0 ? lpt_env == 1 : ((h->dd || h->n_local != h->N) || (T >= 512u && T < 12000u));
+        h->tile_lpt_on = false;
+        if (h->want_tile_split && mdx_nb_variant(h) >= 2) MDX_TRY(mdx_classify_tiles(h, want));
+        if (want && mdx_nb_variant(h) >= 2) MDX_TRY(mdx_order_tiles_by_length(h));
+    }
     h->list_valid = true;
     h->forces_valid = false;
     h->rebuild_count++; h->steps_since_rebuild = 0;
@@ -1433,6 +1457,34 @@ int mdx_rebuild(mdx_handle* h) {
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
     return MDX_OK;
+}
+
+// ---- tiles by decreasing list length ------------------------------------------------------------------------------------
+// A launch of a few thousand tiles is 2-3 rounds of waves per SIMD; in spatial order the long lists (owned bricks, box
+// interior) and the short ones (halo shells, faces of a non-periodic system) come in runs, and the launch ends when the
+// last long list does.  Longest first is the classic list-scheduling order: the short lists fill the tail.  A counting
+// sort over the chunk count (129 buckets), one small launch per rebuild.
+constexpr uint32_t LPT_BUCKETS = 129;
+// One workgroup, LDS histogram and cursors (atomics on a hundred global words would queue: a returning atomic on one address is
+// served every ~35 ns, tools/ubench/grid_barrier.hip - 70 us for the fullest bucket of a 9 k-tile launch).
+// is_int (may be null): the interior / boundary split of a decomposed handle - interior tiles first, each part by length.
+__global__ __launch_bounds__(1024) void lpt_order_kernel(uint32_t T, const ListCounts* __restrict__ counts, const uint32_t* __restrict__ is_int,
+                                                         uint32_t* __restrict__ order) {
+    __shared__ uint32_t s_hist[2 * LPT_BUCKETS], s_cur[2 * LPT_BUCKETS];
+    for (uint32_t b = threadIdx.x; b < 2 * LPT_BUCKETS; b += blockDim.x) s_hist[b] = 0;
+    __syncthreads();
+    auto bucket = [&](uint32_t t) {
+        const uint32_t nch = (counts[t].n_masked + counts[t].n_plain) >> 3;
+        return ((is_int && !is_int[t]) ? LPT_BUCKETS : 0u) + LPT_BUCKETS - 1u - min(nch, LPT_BUCKETS - 1u);   // bucket 0 = the longest lists
+    };
+    for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) atomicAdd(&s_hist[bucket(t)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t b = 0; b < 2 * LPT_BUCKETS; ++b) { s_cur[b] = run; run += s_hist[b]; }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) order[atomicAdd(&s_cur[bucket(t)], 1u)] = t;
 }
 
 // ---- decomposed handle: interior / boundary tiles ---------------------------------------------------------------------
@@ -1466,7 +1518,7 @@ __global__ void tile_order_kernel(uint32_t T, const uint32_t* __restrict__ is_in
     order[is_int[t] ? scan[t] : n_int + (t - scan[t])] = t;
 }
 
-int mdx_classify_tiles(mdx_handle* h) {
+int mdx_classify_tiles(mdx_handle* h, bool by_length) {
     DeviceState& d = h->d;
     const uint32_t T = h->T;
     hipStream_t st = h->stream;
@@ -1480,11 +1532,28 @@ int mdx_classify_tiles(mdx_handle* h) {
     hipLaunchKernelGGL(tile_class_kernel, dim3(div_up(T, 4)), dim3(256), 0, st, T, d.slot_flags, d.list_counts, d.entry_off, d.entries,
                        d.tile_bnd);
     MDX_TRY(mdx_exclusive_scan_u32(h, d.tile_bnd, d.tile_scan, T + 1));
-    hipLaunchKernelGGL(tile_order_kernel, dim3(div_up(T, 256)), dim3(256), 0, st, T, d.tile_bnd, d.tile_scan, d.tile_order);
+    if (by_length) hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, T, d.list_counts, d.tile_bnd, d.tile_order);
+    else hipLaunchKernelGGL(tile_order_kernel, dim3(div_up(T, 256)), dim3(256), 0, st, T, d.tile_bnd, d.tile_scan, d.tile_order);
     uint32_t n_int = 0;
     HIP_TRY(hipMemcpyAsync(&n_int, d.tile_scan + T, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     h->n_interior = n_int; h->tile_split = true;
+    return MDX_OK;
+}
+
+int mdx_order_tiles_by_length(mdx_handle* h) {
+    DeviceState& d = h->d;
+    const uint32_t T = h->T;
+    hipStream_t st = h->stream;
+    h->tile_lpt_on = false;
+    if (!T) return MDX_OK;
+    if (!d.tile_lpt || d.cap_tile_lpt < T) {
+        d.cap_tile_lpt = h->cap_tiles + 1;
+        ALLOC(d.tile_lpt, d.cap_tile_lpt);
+    }
+    hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, T, d.list_counts, (const uint32_t*)nullptr, d.tile_lpt);
+    HIP_TRY(hipGetLastError());
+    h->tile_lpt_on = true;
     return MDX_OK;
 }
 

@@ -189,6 +189,8 @@ struct DeviceState {
     uint32_t* tile_bnd = nullptr;  // [T+1] decomposed handle: 1 <=> the tile holds a ghost or lists a cluster that does
     uint32_t* tile_scan = nullptr; // [T+1]
     uint32_t* tile_order = nullptr;// [T] interior tiles first (launched while the halo message is in flight), then boundary tiles
+    uint32_t* tile_lpt = nullptr;  // [T] tiles by decreasing list length (mid-size launches: longest lists first)
+    uint32_t cap_tile_lpt = 0;
     float4*  scratch4 = nullptr;   // [cap_scratch4] caller-order scratch (force read-back)
 };
 
@@ -249,6 +251,7 @@ struct mdx_handle {
                                  // the path accumulators did not see it, the next mdx_step starts with a pruning pass
     uint32_t n_interior = 0;     // decomposed handle: tiles whose lists involve no ghost (0: no split)
     bool tile_split = false;     // tile_order / n_interior describe the current list
+    bool tile_lpt_on = false;    // tile_lpt describes the current list
     bool want_tile_split = false; uint32_t cap_tile_split = 0;   // set by the decomposition (world > 1, overlap on)
     int nb_step = -1;            // chunk step of the force call being enqueued (-1: not from the step loop -> outer masks)
     // Energies at a cadence (mdx_set_energy_cadence, snapshots, the barostat): the force call that ends such a step runs the
@@ -317,7 +320,8 @@ int mdx_rebuild(mdx_handle* h);
 int mdx_unsort_state(mdx_handle* h);  // slot space -> pos_orig / vel_orig
 int mdx_gather_to_orig(mdx_handle* h, const float4* slot_arr, float4* orig_arr);
 int mdx_extract_neighbors(mdx_handle* h, uint32_t* offsets, uint32_t* idx);
-int mdx_classify_tiles(mdx_handle* h);
+int mdx_classify_tiles(mdx_handle* h, bool by_length);
+int mdx_order_tiles_by_length(mdx_handle* h);   // tile_lpt: longest lists first
 // forces
 // part: 0 = every tile; 1 = the interior tiles of a decomposed handle (no ghost in their lists: they run while the halo
 // message is in flight); 2 = its boundary tiles (after the unpack)
@@ -351,7 +355,13 @@ static inline int mdx_nb_variant(const mdx_handle* h) {
 }
 static inline bool mdx_nb_half(const mdx_handle* h) { return mdx_nb_variant(h) == 5; }
 // tiles below which the half-list pair kernel runs eight waves per tile (and carries the bonded gather in its launch)
-static inline uint32_t mdx_wpt8_below(const mdx_handle* h) { return (h->dd || h->n_local != h->N) ? 4096u : 2048u; }
+// (round 3: a decomposed handle used to keep eight up to 4096 tiles; with its tiles launched longest list first, four waves
+// per tile and a bonded launch of its own are faster there too: rank 0 of 8 of the 1 M-atom box 0.108 -> 0.089 + 0.009 ms)
+static inline uint32_t mdx_wpt8_below(const mdx_handle* h) {
+    static const int env = [] { const char* e = std::getenv("MDX_WPT8_BELOW"); return e ? std::atoi(e) : -1; }();
+    (void)h;
+    return env >= 0 ? (uint32_t)env : 2048u;
+}
 
 // constraints / virtual sites (mdx_constraints.hip)
 int mdx_build_constraints(mdx_handle* h, const mdx_system* s);

@@ -872,6 +872,7 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
         a.t_first = part == 1 ? 0u : h->n_interior;
         a.t_count = part == 1 ? h->n_interior : h->T - h->n_interior;
     }
+    if (part == 0 && h->tile_lpt_on) { a.tile_order = h->d.tile_lpt; a.t_first = 0; a.t_count = h->T; }   // longest lists first
     a.posq = h->d.posq; a.lj = h->d.lj; a.counts = h->d.list_counts; a.entry_off = h->d.entry_off;
     a.mchunk_off = h->d.mchunk_off; a.entries = h->d.entries; a.masks = h->d.masks;
     a.force = h->d.force; a.energy = h->d.energy; a.slot_flags = h->d.slot_flags; a.gate = d_gate; a.thr_bits = thr_bits;
@@ -879,6 +880,7 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
     {
         static const int xcd_env = [] { const char* e = std::getenv("MDX_XCD_INTERLEAVE"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
         a.xcd_interleave = xcd_env >= 0 ? (uint32_t)xcd_env : ((h->have_local_bounds && h->n_local != h->N) ? 1u : 0u);
+        if (part == 0 && h->tile_lpt_on) a.xcd_interleave = 1u;    // (an order by length has no spatial runs to keep on one XCD)
     }
     // dual list: only force calls of the step loop (nb_step >= 0) use the inner masks; everything else - energies, the
     // minimiser, the first evaluation after a rebuild - walks the plain list, which is always valid
