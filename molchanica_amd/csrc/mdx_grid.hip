@@ -424,15 +424,31 @@ __global__ void role_fill_kernel(uint32_t S, const uint32_t* __restrict__ orig_o
 // tile pair list
 // ================================================================================================
 constexpr int LB_WAVES = 4;
+// Statistics (cluster pairs built / kept) are summed into 64 partial counters, a 128-byte line each, by tile number: one 64-bit
+// atomic per tile on ONE address is served every ~15 ns even when nobody waits for its result - 16 k tiles = 0.25 ms, which is
+// what BOTH list kernels took at 1 M atoms whatever else was done to them.  Totals: pair_sum_kernel -> pair_count[PC_TOTAL ..].
+constexpr uint32_t PC_PARTS = 64, PC_STRIDE = 16, PC_TOTAL = PC_PARTS * PC_STRIDE;
+__device__ __forceinline__ unsigned long long* pc_slot(unsigned long long* base, uint32_t t, uint32_t which) {
+    return base + (size_t)(t & (PC_PARTS - 1u)) * PC_STRIDE + which;
+}
 constexpr int LB_REGIONS = 64;   // single-pass build: claim regions of the entry / mask arrays (one cursor line each)
-constexpr int LB_HASH = 1024;
-constexpr int LB_MAXFLAG = 512;
+#ifndef LB_HASH_SIZE
+#define LB_HASH_SIZE 1024
+#endif
+#ifndef LB_MAXFLAG_SIZE
+#define LB_MAXFLAG_SIZE 512
+#endif
+#ifndef LB_PLAIN_SIZE
+#define LB_PLAIN_SIZE 512
+#endif
+constexpr int LB_HASH = LB_HASH_SIZE;
+constexpr int LB_MAXFLAG = LB_MAXFLAG_SIZE;
 constexpr int LB_CAND = 256;     // candidate j-tiles buffered between the two phases of the neighbourhood search
-constexpr int LB_PLAIN = 512;   // single-pass build: plain entries of a tile buffered in LDS before its slice of the list is claimed
+constexpr int LB_PLAIN = LB_PLAIN_SIZE;   // single-pass build: plain entries of a tile buffered in LDS before its slice of the list is claimed
 constexpr int LB_PLAIN_DD = 1024;   // ... on a half-shell decomposed handle, whose ghost columns at the rim of the halo are slivers with tall tiles
                                     // (32 KB more LDS per workgroup: with it for everybody the 1 M-atom list build went 0.37 -> 0.43 ms)
 
-__device__ __forceinline__ uint32_t hash_u32(uint32_t k) { return (k * 2654435761u) >> 22; }  // 10 bits
+__device__ __forceinline__ uint32_t hash_u32(uint32_t k) { return ((k * 2654435761u) >> 22) & (uint32_t)(LB_HASH - 1); }  // 10 bits, cut to the table
 
 __device__ __forceinline__ bool hash_insert(uint32_t* tab, uint32_t key) {
     uint32_t hpos = hash_u32(key);
@@ -740,7 +756,7 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     }
     if (MODE == LB_COUNT) {
         if (lane == 0) {
-            atomicAdd(a.pair_count, (unsigned long long)npairs);
+            atomicAdd(pc_slot(a.pair_count, t, 0), (unsigned long long)npairs);
             a.counts[t].n_masked = nm_pad;
             a.counts[t].n_plain = np_pad;
             a.entry_cnt[t] = nm_pad + np_pad;
@@ -771,7 +787,7 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
             a.counts[t].n_plain = fits ? np_pad : 0u;
             a.entry_off[t] = fits ? ebase : 0u;
             a.mchunk_off[t] = fits ? mbase : 0u;
-            if (fits) atomicAdd(a.pair_count, (unsigned long long)npairs);
+            if (fits) atomicAdd(pc_slot(a.pair_count, t, 0), (unsigned long long)npairs);
         }
         if (!fits) return;
         nm_pad_total = nm_pad;
@@ -945,7 +961,7 @@ __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, f
     if (lane < (int)(np_pad - wcur)) entries[e0 + cnt.n_masked + wcur + lane] = make_uint2(null_cluster, 13u);
     if (lane == 0) {
         counts[t].n_plain = np_pad;
-        if (kept) atomicAdd(pair_count + 1, (unsigned long long)kept);
+        if (kept) atomicAdd(pc_slot(pair_count, t, 1), (unsigned long long)kept);
     }
 }
 
@@ -1015,7 +1031,7 @@ __global__ __launch_bounds__(W * 64) void prune_list_mw_kernel(uint32_t T, float
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
         if ((lane & 7) == 0 && newy != ent.y) entries[e0 + c * 8 + (lane >> 3)].y = newy;
     }
-    if (lane == 0 && kept) atomicAdd(pair_count + 1, (unsigned long long)kept);
+    if (lane == 0 && kept) atomicAdd(pc_slot(pair_count, t, 1), (unsigned long long)kept);
     __threadfence_block();
     __syncthreads();
     if (wave != 0) return;
@@ -1220,6 +1236,13 @@ __global__ void cursor_sum_kernel(const unsigned long long* __restrict__ cursors
     if (threadIdx.x == 0) { out[0] = e; out[1] = m; }
 }
 
+__global__ void pair_sum_kernel(unsigned long long* __restrict__ pc) {      // one wave
+    unsigned long long a = pc[(size_t)threadIdx.x * PC_STRIDE], b = pc[(size_t)threadIdx.x * PC_STRIDE + 1];
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) { a += __shfl_xor(a, k); b += __shfl_xor(b, k); }
+    if (threadIdx.x == 0) { pc[PC_TOTAL] = a; pc[PC_TOTAL + 1] = b; }
+}
+
 static float c_inner_skin(const mdx_config& c) { return c.inner_skin == 0.f ? 0.5f : c.inner_skin; }
 
 int mdx_rebuild(mdx_handle* h) {
@@ -1286,7 +1309,7 @@ int mdx_rebuild(mdx_handle* h) {
     a.half = mdx_nb_half(h) ? 1 : 0;
     a.cell_start = d.cell_start;
     a.posq = d.posq;
-    if (!d.pair_count) ALLOC(d.pair_count, 2);
+    if (!d.pair_count) ALLOC(d.pair_count, PC_TOTAL + 2);
     a.pair_count = d.pair_count;
     uint32_t E = 0, MC = 0;
     unsigned long long npairs = 0;
@@ -1299,7 +1322,7 @@ int mdx_rebuild(mdx_handle* h) {
     bool speculative = false, roles_done = false;
     if (d.entries && d.masks && h->cap_entries && h->cap_mchunks && T && !two_pass_env) {
         if (!d.list_cursors) ALLOC(d.list_cursors, LB_REGIONS * 32 + 2);     // 64 regions x one 128-B line, + the two totals
-        HIP_TRY(hipMemsetAsync(d.pair_count, 0, sizeof(unsigned long long) * 2, st));
+        HIP_TRY(hipMemsetAsync(d.pair_count, 0, sizeof(unsigned long long) * (PC_TOTAL + 2), st));
         HIP_TRY(hipMemsetAsync(d.list_cursors, 0, sizeof(uint32_t) * (LB_REGIONS * 32 + 2), st));
         a.cursors = reinterpret_cast<unsigned long long*>(d.list_cursors);
         a.n_regions = 1;
@@ -1327,13 +1350,14 @@ int mdx_rebuild(mdx_handle* h) {
     // half as much room again as the list needs, so the overflow is paid once (round-2 advisor finding).
     bool grow_for_regions = false;
     auto two_pass = [&]() -> int {
-        HIP_TRY(hipMemsetAsync(d.pair_count, 0, sizeof(unsigned long long) * 2, st));
+        HIP_TRY(hipMemsetAsync(d.pair_count, 0, sizeof(unsigned long long) * (PC_TOTAL + 2), st));
         HIP_TRY(hipMemsetAsync(d.entry_cnt + T, 0, sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(d.mchunk_cnt + T, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(build_list_kernel<LB_COUNT>, dim3((div_up(T, LB_WAVES) + 7u) & ~7u), dim3(LB_WAVES * 64), 0, st, a);
         MDX_TRY(mdx_exclusive_scan_u32(h, d.entry_cnt, d.entry_off, T + 1));
         MDX_TRY(mdx_exclusive_scan_u32(h, d.mchunk_cnt, d.mchunk_off, T + 1));
-        MDX_TRY(readback(h, RbSrc{{d.flags_dev, d.entry_off + T, d.mchunk_off + T, reinterpret_cast<const uint32_t*>(d.pair_count)}, {4, 1, 1, 2}}));
+        hipLaunchKernelGGL(pair_sum_kernel, dim3(1), dim3(64), 0, st, d.pair_count);
+        MDX_TRY(readback(h, RbSrc{{d.flags_dev, d.entry_off + T, d.mchunk_off + T, reinterpret_cast<const uint32_t*>(d.pair_count + PC_TOTAL)}, {4, 1, 1, 2}}));
         for (int k = 0; k < 4; ++k) flags[k] = h->h_rb[k];
         E = h->h_rb[4]; MC = h->h_rb[5];
         npairs = (unsigned long long)h->h_rb[6] | ((unsigned long long)h->h_rb[7] << 32);
@@ -1384,8 +1408,9 @@ int mdx_rebuild(mdx_handle* h) {
     auto read_counts = [&]() -> int {
         if (speculative) hipLaunchKernelGGL(cursor_sum_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<const unsigned long long*>(d.list_cursors),
                                             d.list_cursors + LB_REGIONS * 32);
+        hipLaunchKernelGGL(pair_sum_kernel, dim3(1), dim3(64), 0, st, d.pair_count);
         MDX_TRY(readback(h, RbSrc{{d.flags_dev, d.list_cursors ? d.list_cursors + LB_REGIONS * 32 : nullptr,
-                                   reinterpret_cast<const uint32_t*>(d.pair_count), nullptr}, {4, 2, 4, 0}}));
+                                   reinterpret_cast<const uint32_t*>(d.pair_count + PC_TOTAL), nullptr}, {4, 2, 4, 0}}));
         for (int k = 0; k < 4; ++k) flags[k] = h->h_rb[k];
         if (speculative) {
             E = h->h_rb[4]; MC = h->h_rb[5];
