@@ -740,6 +740,16 @@ __device__ __forceinline__ void bonded_workgroup(const NbArgs& a, uint32_t wg, u
     }
 }
 
+#ifndef NB_MERGED_NOINLINE
+#define NB_MERGED_NOINLINE 0
+#endif
+template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF, bool ALCH, int DUAL, int BW>
+__device__ __attribute__((noinline)) void nb_cluster_body_call(const NbArgs& a, const bool owned_prune, float4 (*s_xyzq)[64], float2 (*s_lj)[64],
+                                                               float (*s_red)[3][64], float (*s_ownj)[64], float4 (*s_g)[64],
+                                                               unsigned long long (*s_mask)[64]) {
+    nb_cluster_body<ENERGY, COUL, GEOM, SAMECUT, WPT, HALF, ALCH, DUAL, BW>(a, owned_prune, s_xyzq, s_lj, s_red, s_ownj, s_g, s_mask);
+}
+
 template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF, bool ALCH = false, int DUAL = 0, bool FB = false, int SPLIT = 1>
 __global__ __launch_bounds__((SPLIT > 1 ? WPT / SPLIT : (WPT > NB_WAVES ? WPT : NB_WAVES)) * 64, ((HALF && NB_HALF_FLUSH) || ENERGY) ? 3 : 4) void nb_cluster_kernel(NbArgs a) {
     if (a.gate && *a.gate > a.thr_bits) return;
@@ -767,8 +777,14 @@ __global__ __launch_bounds__((SPLIT > 1 ? WPT / SPLIT : (WPT > NB_WAVES ? WPT : 
         const bool owned_prune = (a.force_prune | *a.prune_flag) != 0u;
         const bool want_prune = owned_prune || (a.prune_flag2 && *a.prune_flag2 != 0u);
         if (DUAL >= 3) {        // merged launch: the device picks the body
+#if NB_MERGED_NOINLINE
+            // (experiment: the two bodies as real functions, so that each keeps the register allocation of its stand-alone kernel)
+            if (want_prune) nb_cluster_body_call<ENERGY, COUL, GEOM, SAMECUT, WPT, HALF, ALCH, 2, BW>(a, owned_prune, s_xyzq, s_lj, s_red, s_ownj, s_g, s_mask);
+            else nb_cluster_body_call<ENERGY, COUL, GEOM, SAMECUT, WPT, HALF, ALCH, 1, BW>(a, owned_prune, s_xyzq, s_lj, s_red, s_ownj, s_g, s_mask);
+#else
             if (want_prune) nb_cluster_body<ENERGY, COUL, GEOM, SAMECUT, WPT, HALF, ALCH, 2, BW>(a, owned_prune, s_xyzq, s_lj, s_red, s_ownj, s_g, s_mask);
             else nb_cluster_body<ENERGY, COUL, GEOM, SAMECUT, WPT, HALF, ALCH, 1, BW>(a, owned_prune, s_xyzq, s_lj, s_red, s_ownj, s_g, s_mask);
+#endif
         } else {
             if (want_prune != (DUAL == 2)) return;
             nb_cluster_body<ENERGY, COUL, GEOM, SAMECUT, WPT, HALF, ALCH, DUAL == 2 ? 2 : 1, BW>(a, owned_prune, s_xyzq, s_lj, s_red, s_ownj, s_g, s_mask);
@@ -800,10 +816,13 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
     const uint32_t grid = ((nblocks + 7) / 8) * 8;
     if (nblocks == 0) return;
     dim3 g(grid), b(bw * 64);
-    // Small systems (8 waves per tile) launch ONE kernel that picks the inner-walk or the pruning body on the device; larger
-    // ones launch the two flavours back to back and the device runs exactly one (measured: merged +1 % at 23 k atoms,
-    // -0.4 % at 1 M, where the merged kernel's 92 SGPRs / 127 VGPRs cost more than the ~4 us twin).  MDX_DUAL_MERGED=0: never merge.
+    // ONE kernel picks the inner-walk or the pruning body on the device (round 2 measured the merged launch at +1 % for 23 k atoms
+    // and -0.4 % at 1 M, and launched the two flavours back to back for the large classes, the device running exactly one; since
+    // the chunk loop exists twice the merged kernel is faster there too: the gated-off twin was ~5 us of a 550 us step).
+    // MDX_DUAL_MERGED=0: never merge; 1: the eight-waves-per-tile class only.
     static const bool dual_merged = [] { const char* e = std::getenv("MDX_DUAL_MERGED"); return !(e && e[0] == '0'); }();
+    // (round 3, after the two chunk loops: merged wins at every size - water1M 1812 -> 1827 steps/s; MDX_DUAL_MERGED=1: small class only)
+    static const bool merge_all = [] { const char* e = std::getenv("MDX_DUAL_MERGED"); return !(e && (e[0] == '0' || e[0] == '1')); }();
     // below ~1000 tiles a tile's eight waves go to two workgroups of four (MDX_TILE_SPLIT=0 / 1 forces)
     static const int split_env = [] { const char* e = std::getenv("MDX_TILE_SPLIT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     const bool split2 = split_env >= 0 ? split_env == 1 : (a.tile_order ? a.t_count : a.T) < 1024u;
@@ -843,7 +862,7 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
             hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, 4>), gf, b, 0, h->stream, af); \
             h->bonded_fused = true;                                                                                \
         }                                                                                                          \
-        else if (half && a.inner && dual_merged && wpt == 8) { NB_DUAL(G, S, 3); }                                 \
+        else if (half && a.inner && dual_merged && (wpt == 8 || merge_all)) { NB_DUAL(G, S, 3); }                  \
         else if (half && a.inner) { if (!a.force_prune) NB_DUAL(G, S, 1); NB_DUAL(G, S, 2); }   /* (a pass the host forces: no twin) */ \
         else if (half && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true>), g, b, 0, h->stream, a); \
         else if (half && wpt == 2) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 2, true>), g, b, 0, h->stream, a); \
