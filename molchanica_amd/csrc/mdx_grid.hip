@@ -110,34 +110,59 @@ int mdx_exclusive_scan_u32(mdx_handle* h, const uint32_t* in, uint32_t* out, uin
 constexpr int SCAN1_THREADS = 1024;
 __global__ __launch_bounds__(SCAN1_THREADS) void scan_one_block_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                                        uint32_t n) {
-    // thread k owns the contiguous segment [k * ipt, (k + 1) * ipt): sums it, the workgroup scans the 1024 sums once,
-    // the thread walks its segment again writing prefixes - two passes of independent loads, one barrier pair
+    // Wave w owns the contiguous range [w * cw, (w + 1) * cw), cw a multiple of 256, and reads it as 16-byte vectors, lane after
+    // lane (coalesced: one 1-KB request per instruction), ALL of it before anything else - up to 16 loads in flight, the data
+    // stays in registers.  The waves' totals meet in LDS once; then every wave scans its registers and writes.  (Round 2's form
+    // gave thread k the segment [k * ipt, (k + 1) * ipt): 64 cache lines per load instruction, two passes of ~1 us round
+    // trips - 29 us for the 60 k cells of a 23 k-atom system, 5 us now.)
     __shared__ uint32_t s_wave[SCAN1_THREADS / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t ipt = (n + SCAN1_THREADS - 1) / SCAN1_THREADS;
-    const uint32_t b = threadIdx.x * ipt, e = min(n, b + ipt);
+    constexpr int NW = SCAN1_THREADS / 64, MAXIT = 16;                 // NW * MAXIT * 256 = 65536 elements
+    const uint32_t cw = ((n + NW * 256u - 1u) / (NW * 256u)) * 256u;
+    const uint32_t b = wave * cw, e = min(n, b + cw);
+    const bool vec = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0u;
+    uint4 v[MAXIT];
     uint32_t sum = 0;
-    for (uint32_t i = b; i < e; i += 8) {          // eight loads in flight (one load per iteration waits ~0.6 us each time)
-        uint32_t v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = (i + k < e) ? in[i + k] : 0u;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) sum += v[k];
+    for (int it = 0; it < MAXIT; ++it) {
+        const uint32_t i = b + (uint32_t)it * 256u + (uint32_t)lane * 4u;
+        uint4 x = make_uint4(0u, 0u, 0u, 0u);
+        if ((uint32_t)it * 256u < cw) {
+            if (vec && i + 3u < e) x = *reinterpret_cast<const uint4*>(in + i);
+            else {
+                if (i < e) x.x = in[i];
+                if (i + 1u < e) x.y = in[i + 1u];
+                if (i + 2u < e) x.z = in[i + 2u];
+                if (i + 3u < e) x.w = in[i + 3u];
+            }
+        }
+        v[it] = x;
+        sum += x.x + x.y + x.z + x.w;
     }
-    uint32_t inc = sum;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d); if (lane >= d) inc += t; }
-    if (lane == 63) s_wave[wave] = inc;
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+    if (lane == 0) s_wave[wave] = sum;
     __syncthreads();
-    uint32_t wbase = 0;
-    for (int w = 0; w < wave; ++w) wbase += s_wave[w];
-    uint32_t ex = wbase + inc - sum;
-    for (uint32_t i = b; i < e; i += 8) {
-        uint32_t v[8];
+    uint32_t carry = 0;
+    for (int w = 0; w < wave; ++w) carry += s_wave[w];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = (i + k < e) ? in[i + k] : 0u;
+    for (int it = 0; it < MAXIT; ++it) {
+        if ((uint32_t)it * 256u >= cw) break;
+        const uint32_t i = b + (uint32_t)it * 256u + (uint32_t)lane * 4u;
+        const uint4 x = v[it];
+        const uint32_t t = x.x + x.y + x.z + x.w;
+        uint32_t inc = t;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { if (i + k < e) out[i + k] = ex; ex += v[k]; }
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(inc, d); if (lane >= d) inc += u; }
+        const uint32_t e0 = carry + inc - t, e1 = e0 + x.x, e2 = e1 + x.y, e3 = e2 + x.z;
+        if (vec && i + 3u < e) *reinterpret_cast<uint4*>(out + i) = make_uint4(e0, e1, e2, e3);
+        else {
+            if (i < e) out[i] = e0;
+            if (i + 1u < e) out[i + 1u] = e1;
+            if (i + 2u < e) out[i + 2u] = e2;
+            if (i + 3u < e) out[i + 3u] = e3;
+        }
+        carry += __shfl(inc, 63);
     }
 }
 
@@ -443,6 +468,7 @@ constexpr int LB_REGIONS = 64;   // single-pass build: claim regions of the entr
 #endif
 constexpr int LB_HASH = LB_HASH_SIZE;
 constexpr int LB_MAXFLAG = LB_MAXFLAG_SIZE;
+constexpr int LB_SPC = 4;        // excluded partners per atom whose slots are kept in registers between the two uses
 constexpr int LB_CAND = 256;     // candidate j-tiles buffered between the two phases of the neighbourhood search
 constexpr int LB_PLAIN = LB_PLAIN_SIZE;   // single-pass build: plain entries of a tile buffered in LDS before its slice of the list is claimed
 constexpr int LB_PLAIN_DD = 1024;   // ... on a half-shell decomposed handle, whose ghost columns at the rim of the halo are slivers with tall tiles
@@ -580,9 +606,20 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     if (lane < MDX_CL_PER_TILE) ok_ins &= hash_insert(hash, t * MDX_CL_PER_TILE + lane);
     uint32_t eb = 0, ee = 0;
     if (myo != MDX_INVALID) { const uint32_t mg = a.gid[myo]; eb = a.excl_off[mg]; ee = a.excl_off[mg + 1]; }
-    for (uint32_t k = eb; k < ee; ++k) {
+    // the slots of this lane's first LB_SPC excluded partners stay in registers: the mask phase below needs them again for every
+    // masked chunk, and re-reading excl_idx -> slot_of there cost two dependent round trips per partner and chunk (a protein
+    // tile: ~12 partners x ~5 chunks); unrolled, the loads of this first pass are independent of one another as well
+    uint32_t spc[LB_SPC];
+#pragma unroll
+    for (int q = 0; q < LB_SPC; ++q) spc[q] = (eb + q < ee) ? a.excl_idx[eb + q] : MDX_INVALID;
+#pragma unroll
+    for (int q = 0; q < LB_SPC; ++q) if (spc[q] != MDX_INVALID) spc[q] = a.slot_of[spc[q]];
+#pragma unroll
+    for (int q = 0; q < LB_SPC; ++q)
+        if (spc[q] != MDX_INVALID) ok_ins &= hash_insert(hash, spc[q] >> 3);   // absent partner: beyond the halo, out of range
+    for (uint32_t k = eb + LB_SPC; k < ee; ++k) {
         const uint32_t sp = a.slot_of[a.excl_idx[k]];
-        if (sp != MDX_INVALID) ok_ins &= hash_insert(hash, sp >> 3);   // absent partner: beyond the halo, out of range
+        if (sp != MDX_INVALID) ok_ins &= hash_insert(hash, sp >> 3);
     }
     if (!ok_ins) atomicOr(a.err, 1u);
     WAVE_LDS_SYNC();
@@ -827,7 +864,15 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
                                                                           : (1ull << (myslot & 7));
                     m &= ~(gone << (8 * e));
                 }
-            for (uint32_t k = eb; k < ee; ++k) {
+#pragma unroll
+            for (int q = 0; q < LB_SPC; ++q) {
+                const uint32_t sp = spc[q];
+                if (sp == MDX_INVALID) continue;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (jcs[e] == (sp >> 3)) m &= ~(1ull << (8 * e + (sp & 7)));
+            }
+            for (uint32_t k = eb + LB_SPC; k < ee; ++k) {
                 uint32_t sp = a.slot_of[a.excl_idx[k]];
                 if (sp == MDX_INVALID) continue;
 #pragma unroll
