@@ -193,7 +193,7 @@ def main():
     from molchanica_amd.md_state import MdState
 
     system = systems.BY_NAME[args.workload]()
-    cfg = MdConfig(nb_variant=args.nb_variant, skin=args.skin, chunk_steps=args.chunk_steps or 16, inner_skin=args.inner_skin)  # rc 10 Å (LJ & Coulomb), skin 2 Å, shifted cutoff Coulomb
+    cfg = MdConfig(nb_variant=args.nb_variant, skin=args.skin, chunk_steps=args.chunk_steps, inner_skin=args.inner_skin)  # rc 10 Å (LJ & Coulomb), skin 2 Å, shifted cutoff Coulomb
     if args.pme:
         cfg = MdConfig(nb_variant=args.nb_variant, coulomb_mode=2, ewald_alpha=0.3, overrides=0, inner_skin=args.inner_skin)
     n_atoms = system.n_atoms

@@ -136,7 +136,8 @@ typedef struct mdx_config {
     int32_t  combining_rule;   /* MDX_COMBINE_*                                                   */
     uint32_t overrides;        /* MDX_OVR_* bit set                                               */
     float    softening_sq;     /* Å², added to r² in the Coulomb force (src/cuda/util.cu:9 uses 1e-6); default 0 */
-    uint32_t chunk_steps;      /* steps enqueued between host checks of the rebuild flag (default 16) */
+    uint32_t chunk_steps;      /* steps enqueued between host checks of the rebuild flag (mdx_config_default: 16; 0 = the
+                                * library chooses by system size: 48 below 131 k atoms, else 16) */
     uint32_t nb_variant;       /* pair kernel (A/B knob): 0 = library default (5); 1 = whole-tile, full list; 2 = cluster-masked, full
                                   list, bitwise reproducible; 3/4 = 2 with 1/4 waves per tile; 5 = cluster-masked, HALF list, the
                                   reaction force written back with f32 atomics (fastest; last bits vary run to run) */

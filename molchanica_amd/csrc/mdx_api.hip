@@ -170,7 +170,9 @@ extern "C" void mdx_destroy(mdx_handle* h) {
 static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx_handle* h) {
     const uint32_t N = s->n_atoms;
     h->N = N; h->cfg = *c; h->device = device;
-    if (h->cfg.chunk_steps == 0) h->cfg.chunk_steps = 16;
+    // 0 = the library chooses: a chunk costs one host synchronisation (~15 us), which is 2 % of a 50 us step at 16 steps per
+    // chunk; the chunk-length prediction (mdx_step) keeps longer chunks from running far past a stale list
+    if (h->cfg.chunk_steps == 0) h->cfg.chunk_steps = N < 131072u ? 48u : 16u;
     if (h->cfg.chunk_steps > MDX_MAX_CHUNK) h->cfg.chunk_steps = MDX_MAX_CHUNK;
     decode_periodic(s->periodic, h->per);
     h->periodic = h->per[0] || h->per[1] || h->per[2];

@@ -21,6 +21,8 @@
 //            their mask bit (24 % of them), the plain run is compacted in place
 //   remap    bonded index lists caller order -> slot order
 #include "mdx_internal.h"
+#include <atomic>
+#include <chrono>
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -1259,16 +1261,28 @@ int mdx_gather_to_orig(mdx_handle* h, const float4* slot_arr, float4* orig_arr) 
 // of two to four pageable hipMemcpyAsync calls of ~25 us each (the rebuild at 1 M atoms spent 0.3 of its 1.36 ms in
 // those copies and the host wake-ups around them).
 struct RbSrc { const uint32_t* p[4]; uint32_t n[4]; };
-__global__ void readback_kernel(RbSrc s, uint32_t* __restrict__ out) {
+__global__ void readback_kernel(RbSrc s, volatile uint32_t* out, uint32_t seq) {
     uint32_t k = 0;
     for (int a = 0; a < 4; ++a)
         for (uint32_t i = 0; i < s.n[a]; ++i) out[k++] = s.p[a] ? s.p[a][i] : 0u;
     __threadfence_system();
+    out[31] = seq;      // the host spins on this word (a stream synchronisation costs ~5 us more: tools/ubench/sync_latency.hip)
 }
 static int readback(mdx_handle* h, const RbSrc& s) {
-    if (!h->h_rb) HIP_TRY(hipHostMalloc((void**)&h->h_rb, sizeof(uint32_t) * 32, hipHostMallocDefault));
-    hipLaunchKernelGGL(readback_kernel, dim3(1), dim3(1), 0, h->stream, s, h->h_rb);
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (!h->h_rb) { HIP_TRY(hipHostMalloc((void**)&h->h_rb, sizeof(uint32_t) * 32, hipHostMallocDefault)); h->h_rb[31] = 0u; }
+    static const bool spin_ok = [] { const char* e = std::getenv("MDX_CHUNK_SPIN"); return !(e && e[0] == '0'); }();
+    const uint32_t seq = ++h->rb_seq;
+    hipLaunchKernelGGL(readback_kernel, dim3(1), dim3(1), 0, h->stream, s, (volatile uint32_t*)h->h_rb, seq);
+    if (!spin_ok || h->profile) { HIP_TRY(hipStreamSynchronize(h->stream)); return MDX_OK; }
+    volatile uint32_t* seq_word = (volatile uint32_t*)h->h_rb + 31;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0; *seq_word != seq; ++spins) {
+        if ((spins & 0xFFFu) == 0xFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
+            HIP_TRY(hipStreamSynchronize(h->stream));       // (an error on the stream, or a very long queue: wait the ordinary way)
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
     return MDX_OK;
 }
 

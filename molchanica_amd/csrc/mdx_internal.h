@@ -300,6 +300,7 @@ struct mdx_handle {
     StepCtl* h_ctl = nullptr;  // pinned (+ 64 bytes: the sequence word of the chunk-end readback)
     uint32_t ctl_seq = 0;
     uint32_t* h_rb = nullptr;  // pinned, device-visible: the list rebuild's counters land here straight from a kernel
+    uint32_t rb_seq = 0;        // sequence number of the last read-back (word 31 of h_rb: the host spins on it)
 };
 
 // ---- error plumbing ------------------------------------------------------------------------------
