@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256) void bonded_integrate_kernel(FusedArgs a) {
             constexpr int FUSED_PRE = 3;
             RoleRec rr[FUSED_PRE]; float4 q0[FUSED_PRE], q1[FUSED_PRE], prm[FUSED_PRE];
 #pragma unroll
-            for (int i = 0; i < FUSED_PRE; ++i) rr[i] = a.roles[min(rb + (uint32_t)i, a.R - 1u)];   // (a record past the atom's own list is fetched, never evaluated)
+            for (int i = 0; i < FUSED_PRE; ++i)      // (past the atom's own list: a null record - slot 0, parameter set 0 - fetched, never evaluated)
+                rr[i] = (rb + (uint32_t)i < re) ? a.roles[rb + (uint32_t)i] : RoleRec{{0u, 0u, 0u}, 0u};
 #pragma unroll
             for (int i = 0; i < FUSED_PRE; ++i) { q0[i] = a.posq_in[rr[i].p[0]]; q1[i] = a.posq_in[rr[i].p[1]]; prm[i] = a.prm[rr[i].meta >> 8]; }
             RoleEnergies en;
@@ -262,9 +263,15 @@ int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_ga
 bool mdx_bonded_integrate_ok(const mdx_handle* h) {
     const char* e = std::getenv("MDX_FUSE_BONDED_INTEGRATE");     // read per chunk, so one process can compare both arrangements
     const bool on = !(e && e[0] == '0');
+    // decomposed handles (round 3): ghost slots carry w = 0 and are copied through, the halo unpack writes into the buffer the
+    // pass has just filled; MDX_FUSE_BONDED_INTEGRATE_DD=0 keeps the separate launches there
+    static const bool dd_env = [] { const char* x = std::getenv("MDX_FUSE_BONDED_INTEGRATE_DD"); return !(x && x[0] == '0'); }();
+    const bool dd_ok = dd_env && h->dd != nullptr;
+    // (n_roles counts the whole system; a decomposed handle holds n_local of its N atoms)
+    const double roles_here = (double)h->n_roles * ((h->n_local != h->N && h->N) ? (double)h->n_local / (double)h->N : 1.0);
     return on && mdx_nb_variant(h) >= 2 && h->integrator == MDX_INTEGRATOR_VERLET_VELOCITY && h->n_groups == 0 && h->n_vsites == 0 &&
-           !h->pme_on && !h->have_ext && !h->dd && h->n_local == h->N && !h->alch_on && mdx_bonded_wanted(h) && h->T >= mdx_wpt8_below(h) &&
-           (double)h->n_roles < 2.6 * (double)h->S && h->d.posq_alt != nullptr;
+           !h->pme_on && !h->have_ext && (dd_ok || (!h->dd && h->n_local == h->N)) && !h->alch_on && mdx_bonded_wanted(h) && h->T >= mdx_wpt8_below(h) &&
+           roles_here < 2.6 * (double)h->S && h->d.posq_alt != nullptr;
 }
 
 int mdx_launch_bonded_integrate(mdx_handle* h, float dt, const uint32_t* d_gate_in, uint32_t* d_disp_out, uint32_t thr_bits,

@@ -79,3 +79,53 @@ def test_fused_pass_against_the_oracle(big_water):
     d -= np.rint(d / box) * box
     assert np.sqrt((d ** 2).sum(1).mean()) < 2e-4, np.sqrt((d ** 2).sum(1).mean())
     assert np.abs(d).max() < 5e-3
+
+
+def test_fused_pass_on_decomposed_handles(big_water):
+    """Two ranks of the 273 k-atom box hold ~2.6 k tiles each - the class in which a decomposed handle's step loop runs the fused
+    pass too (ghost slots are copied through; the halo unpack writes into the buffer the pass has just filled).  With the
+    deterministic full-list kernel and reaction field the two ranks follow the single-device run, with the pass and with the
+    separate launches (MDX_FUSE_BONDED_INTEGRATE_DD, read at library load: the separate arm is the per-chunk knob)."""
+    import threading
+    from molchanica_amd.md_state import Fabric, MdState
+    box = np.asarray(big_water.box_hi, np.float64) - np.asarray(big_water.box_lo, np.float64)
+    cfg = MdConfig(skin=2.0, nb_variant=2, coulomb_mode=1)
+    with MdState(big_water, cfg) as md:
+        md.step(0.0005, None, 40)
+        ref_pos, ref_e = md.positions(), md.energy()
+
+    def ranks(fused):
+        os.environ["MDX_FUSE_BONDED_INTEGRATE"] = "1" if fused else "0"
+        fabric = Fabric(2)
+        res, errs = {}, []
+
+        def run(rank):
+            try:
+                with MdState(big_water, cfg) as md:
+                    md.comm_init_fabric(fabric, rank)
+                    md.step(0.0005, None, 24)
+                    md.profile(1)                      # (the per-kernel brackets count the fused launches)
+                    md.step(0.0005, None, 16)
+                    md.profile(0)
+                    res[rank] = (md.positions(), md.energy(), md.stats())
+            except BaseException as e:   # pragma: no cover
+                errs.append(e)
+                fabric.abort()
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        os.environ.pop("MDX_FUSE_BONDED_INTEGRATE", None)
+        if errs:
+            raise errs[0]
+        return res
+
+    for fused in (True, False):
+        res = ranks(fused)
+        for r in (0, 1):
+            pos, e, st = res[r]
+            assert st["n_tiles"] >= 2048                      # the rank is in the class that fuses
+            assert (st["fused_launches"] > 0) == fused
+            mx, rms = _dev(pos, ref_pos, box)
+            assert rms < 5e-5 and mx < 5e-3, (fused, r, mx, rms)
+            assert abs(e["potential"] - ref_e["potential"]) < 5e-5 * abs(ref_e["potential"])
