@@ -40,7 +40,7 @@ B_ALG_BONDED_WATER = 52.0      # 36 + 16 t, t = 1 bonded term per atom in flexib
 B_ALG_FUSED_WATER = 116.0      # bonded gather + kick + drift as one pass: the two figures above together
 B_ALG_STEP_WATER = 170.0       # whole step, water box
 FLOP_PER_PAIR = 45.0
-NB_KERNEL_REV = "r03b"         # revision tag of the default pair kernel the cached PMC traffic figure belongs to
+NB_KERNEL_REV = "r03e"         # revision tag of the default pair kernel the cached PMC traffic figure belongs to
 
 
 def parse():
@@ -400,7 +400,7 @@ def main():
         kernel = "nb_tile_kernel"
     elif dual:
         kernel = (f"nb_cluster_kernel: {100 * (1 - prune_frac):.0f} % inner-list walks + {100 * prune_frac:.0f} % pruning passes "
-                  f"(the no-op twin of each launch pair is inside the bracket)")
+                  f"(one merged launch per step: the device picks the body)")
     else:
         kernel = "nb_cluster_kernel (plain Verlet list)"
     out = {
