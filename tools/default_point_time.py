@@ -8,12 +8,13 @@ from molchanica_amd.md_state import MdState
 n_side = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 inner = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0      # dual-list buffer (0 = library default 0.5 A)
 skin = float(sys.argv[3]) if len(sys.argv) > 3 else 2.0
+pre = int(sys.argv[4]) if len(sys.argv) > 4 else 300         # untimed steps at the operating point (the library's dual-list tuning settles within ~1500)
 s = systems.opc_water_box(n_side, seed=5)
 for name, cfg in (("SPME", MdConfig(coulomb_mode=2, ewald_alpha=0.3, overrides=0, inner_skin=inner, skin=skin)), ("cutoff (reaction field)", MdConfig(coulomb_mode=1, inner_skin=inner, skin=skin))):
     with MdState(s, cfg) as md:
         md.minimize_energy(100); md.initialize_velocities(300.0, True, seed=1)
         md.set_thermostat(1, 300.0, 0.02, 1); md.step(0.001, None, 1500)       # untimed: the random-orientation lattice relaxes
-        md.set_thermostat(2, 300.0, 0.1, 10, seed=2); md.step(0.002, None, 300)
+        md.set_thermostat(2, 300.0, 0.1, 10, seed=2); md.step(0.002, None, pre)
         t = time.perf_counter(); n = 500; md.step(0.002, None, n); e = md.energy(); el = time.perf_counter() - t
         st = md.stats()
         print("inner_skin %.1f skin %.1f | OPC %d sites, dt 2 fs, %s: %.0f steps/s = %.1f ns/day  (T %.0f K, %d list rebuilds, %d pruning passes, inner/verlet cluster pairs %.2f)" % (
