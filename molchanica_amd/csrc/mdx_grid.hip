@@ -1509,13 +1509,17 @@ int mdx_rebuild(mdx_handle* h) {
     h->tile_split = false; h->n_interior = 0;
     {
         // longest lists first where a launch is only a few rounds of waves (MDX_TILE_LPT=0 / 1 forces it off / on for A/B)
-        static const int lpt_env = [] { const char* e = std::getenv("MDX_TILE_LPT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+        static const int lpt_env = [] { const char* e = std::getenv("MDX_TILE_LPT"); return e ? (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)) : -1; }();
         // default: every decomposed handle (owned bricks and halo shells: its lists differ by an order of magnitude), and
         // single-device systems below the size at which a contiguous eighth of the tiles per XCD starts to matter
-        const bool want = lpt_env >= 0 ? lpt_env == 1 : ((h->dd || h->n_local != h->N) || (T >= 512u && T < 12000u));
+        // (later in round 3: single-device systems of every size from 512 tiles on, ordered by length inside each XCD's contiguous
+        // range - water1M 1832 -> 1853 steps/s, against 1843-1849 with the round-robin order; MDX_TILE_LPT=1 / 2 force either)
+        const bool decomposed = h->dd || h->n_local != h->N;
+        const bool want = lpt_env >= 0 ? lpt_env >= 1 : (decomposed || T >= 512u);
+        const bool grouped = lpt_env >= 0 ? lpt_env == 2 : !decomposed;
         h->tile_lpt_on = false;
         if (h->want_tile_split && mdx_nb_variant(h) >= 2) MDX_TRY(mdx_classify_tiles(h, want));
-        if (want && mdx_nb_variant(h) >= 2) MDX_TRY(mdx_order_tiles_by_length(h));
+        if (want && mdx_nb_variant(h) >= 2) MDX_TRY(mdx_order_tiles_by_length(h, grouped));
     }
     h->list_valid = true;
     h->forces_valid = false;
@@ -1552,20 +1556,24 @@ constexpr uint32_t LPT_BUCKETS = 129;
 // One workgroup, LDS histogram and cursors (atomics on a hundred global words would queue: a returning atomic on one address is
 // served every ~35 ns, tools/ubench/grid_barrier.hip - 70 us for the fullest bucket of a 9 k-tile launch).
 // is_int (may be null): the interior / boundary split of a decomposed handle - interior tiles first, each part by length.
+// group_tiles > 0 (large single-device systems): the order is by length INSIDE each of the eight contiguous tile ranges the pair
+// kernel hands to the eight XCDs (group_tiles tiles each), so a range stays on its XCD's L2 and still runs longest list first.
 __global__ __launch_bounds__(1024) void lpt_order_kernel(uint32_t T, const ListCounts* __restrict__ counts, const uint32_t* __restrict__ is_int,
-                                                         uint32_t* __restrict__ order) {
-    __shared__ uint32_t s_hist[2 * LPT_BUCKETS], s_cur[2 * LPT_BUCKETS];
-    for (uint32_t b = threadIdx.x; b < 2 * LPT_BUCKETS; b += blockDim.x) s_hist[b] = 0;
+                                                         uint32_t* __restrict__ order, uint32_t group_tiles) {
+    constexpr uint32_t NB = 8 * LPT_BUCKETS;
+    __shared__ uint32_t s_hist[NB], s_cur[NB];
+    for (uint32_t b = threadIdx.x; b < NB; b += blockDim.x) s_hist[b] = 0;
     __syncthreads();
     auto bucket = [&](uint32_t t) {
         const uint32_t nch = (counts[t].n_masked + counts[t].n_plain) >> 3;
-        return ((is_int && !is_int[t]) ? LPT_BUCKETS : 0u) + LPT_BUCKETS - 1u - min(nch, LPT_BUCKETS - 1u);   // bucket 0 = the longest lists
+        const uint32_t major = group_tiles ? min(t / group_tiles, 7u) : ((is_int && !is_int[t]) ? 1u : 0u);
+        return major * LPT_BUCKETS + LPT_BUCKETS - 1u - min(nch, LPT_BUCKETS - 1u);   // bucket 0 = the longest lists
     };
     for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) atomicAdd(&s_hist[bucket(t)], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t run = 0;
-        for (uint32_t b = 0; b < 2 * LPT_BUCKETS; ++b) { s_cur[b] = run; run += s_hist[b]; }
+        for (uint32_t b = 0; b < NB; ++b) { s_cur[b] = run; run += s_hist[b]; }
     }
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) order[atomicAdd(&s_cur[bucket(t)], 1u)] = t;
@@ -1616,7 +1624,7 @@ int mdx_classify_tiles(mdx_handle* h, bool by_length) {
     hipLaunchKernelGGL(tile_class_kernel, dim3(div_up(T, 4)), dim3(256), 0, st, T, d.slot_flags, d.list_counts, d.entry_off, d.entries,
                        d.tile_bnd);
     MDX_TRY(mdx_exclusive_scan_u32(h, d.tile_bnd, d.tile_scan, T + 1));
-    if (by_length) hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, T, d.list_counts, d.tile_bnd, d.tile_order);
+    if (by_length) hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, T, d.list_counts, d.tile_bnd, d.tile_order, 0u);
     else hipLaunchKernelGGL(tile_order_kernel, dim3(div_up(T, 256)), dim3(256), 0, st, T, d.tile_bnd, d.tile_scan, d.tile_order);
     uint32_t n_int = 0;
     HIP_TRY(hipMemcpyAsync(&n_int, d.tile_scan + T, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -1625,7 +1633,7 @@ int mdx_classify_tiles(mdx_handle* h, bool by_length) {
     return MDX_OK;
 }
 
-int mdx_order_tiles_by_length(mdx_handle* h) {
+int mdx_order_tiles_by_length(mdx_handle* h, bool grouped) {
     DeviceState& d = h->d;
     const uint32_t T = h->T;
     hipStream_t st = h->stream;
@@ -1635,9 +1643,14 @@ int mdx_order_tiles_by_length(mdx_handle* h) {
         d.cap_tile_lpt = h->cap_tiles + 1;
         ALLOC(d.tile_lpt, d.cap_tile_lpt);
     }
-    hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, T, d.list_counts, (const uint32_t*)nullptr, d.tile_lpt);
+    uint32_t group_tiles = 0;
+    if (grouped) {      // the pair kernel's XCD ranges: ceil(workgroups / 8) workgroups of TPB tiles each (mdx_nonbonded.hip)
+        const uint32_t wpt = (uint32_t)mdx_nb_wpt_half(h, T), tpb = std::max(wpt, 4u) / wpt;
+        group_tiles = (((T + tpb - 1) / tpb + 7) >> 3) * tpb;
+    }
+    hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, T, d.list_counts, (const uint32_t*)nullptr, d.tile_lpt, group_tiles);
     HIP_TRY(hipGetLastError());
-    h->tile_lpt_on = true;
+    h->tile_lpt_on = true; h->tile_lpt_grouped = grouped;
     return MDX_OK;
 }
 

@@ -252,6 +252,7 @@ struct mdx_handle {
     uint32_t n_interior = 0;     // decomposed handle: tiles whose lists involve no ghost (0: no split)
     bool tile_split = false;     // tile_order / n_interior describe the current list
     bool tile_lpt_on = false;    // tile_lpt describes the current list
+    bool tile_lpt_grouped = false;   // ... ordered by length inside each XCD's contiguous range (no round-robin over the XCDs then)
     bool want_tile_split = false; uint32_t cap_tile_split = 0;   // set by the decomposition (world > 1, overlap on)
     int nb_step = -1;            // chunk step of the force call being enqueued (-1: not from the step loop -> outer masks)
     // Energies at a cadence (mdx_set_energy_cadence, snapshots, the barostat): the force call that ends such a step runs the
@@ -322,7 +323,7 @@ int mdx_unsort_state(mdx_handle* h);  // slot space -> pos_orig / vel_orig
 int mdx_gather_to_orig(mdx_handle* h, const float4* slot_arr, float4* orig_arr);
 int mdx_extract_neighbors(mdx_handle* h, uint32_t* offsets, uint32_t* idx);
 int mdx_classify_tiles(mdx_handle* h, bool by_length);
-int mdx_order_tiles_by_length(mdx_handle* h);   // tile_lpt: longest lists first
+int mdx_order_tiles_by_length(mdx_handle* h, bool grouped);   // tile_lpt: longest lists first
 // forces
 // part: 0 = every tile; 1 = the interior tiles of a decomposed handle (no ghost in their lists: they run while the halo
 // message is in flight); 2 = its boundary tiles (after the unpack)
@@ -362,6 +363,14 @@ static inline uint32_t mdx_wpt8_below(const mdx_handle* h) {
     static const int env = [] { const char* e = std::getenv("MDX_WPT8_BELOW"); return e ? std::atoi(e) : -1; }();
     (void)h;
     return env >= 0 ? (uint32_t)env : 2048u;
+}
+
+// waves per tile of the half-list pair kernel for a list of T tiles (MDX_WPT: A/B knob)
+static inline int mdx_nb_wpt_half(const mdx_handle* h, uint32_t T) {
+    static const int env = [] { const char* e = std::getenv("MDX_WPT"); return (e && (e[0] == '1' || e[0] == '2' || e[0] == '4' || e[0] == '8')) ? e[0] - '0' : 0; }();
+    if (env) return env;
+    if (T >= 12000u) return 2;                     // half list at ~1 M atoms: 0.550 vs 0.572 ms (2 tiles per workgroup)
+    return T < mdx_wpt8_below(h) ? 8 : 4;
 }
 
 // constraints / virtual sites (mdx_constraints.hip)

@@ -803,13 +803,9 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
     // with 2; one rank of an 8-rank water1M - 2.0 k owned + 1.3 k ghost tiles - 0.111 / 0.106 / 0.112)
     // with 2; one rank of an 8-rank water1M - 2.0 k owned + 1.3 k ghost tiles - 0.111 with the bonded gather inside / 0.106 + 0.010 for its
     // own launch / 0.112: a decomposed handle, whose step loop cannot fuse the gather into the drift pass, keeps 8 up to 4096 tiles)
-    if (var == 2 || half) wpt = (a.T < mdx_wpt8_below(h)) ? 8 : 4;
-    if (half && a.T >= 12000u) wpt = 2;                    // half list at ~1 M atoms: 0.550 vs 0.572 ms (2 tiles per workgroup)
+    if (var == 2) wpt = (a.T < mdx_wpt8_below(h)) ? 8 : 4;
+    if (half) wpt = mdx_nb_wpt_half(h, a.T);               // (shared with the tile order of the list rebuild: mdx_internal.h)
     if (var == 4) wpt = 4;
-    if (half) {   // A/B knob
-        const char* e = std::getenv("MDX_WPT");
-        if (e && (e[0] == '1' || e[0] == '2' || e[0] == '4' || e[0] == '8')) wpt = e[0] - '0';
-    }
     const uint32_t bw = std::max(wpt, NB_WAVES);
     const uint32_t tpb = (var == 1) ? NB_WAVES : bw / wpt;
     const uint32_t nblocks = ((a.tile_order ? a.t_count : a.T) + tpb - 1) / tpb;
@@ -899,7 +895,7 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
     {
         static const int xcd_env = [] { const char* e = std::getenv("MDX_XCD_INTERLEAVE"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
         a.xcd_interleave = xcd_env >= 0 ? (uint32_t)xcd_env : ((h->have_local_bounds && h->n_local != h->N) ? 1u : 0u);
-        if (part == 0 && h->tile_lpt_on) a.xcd_interleave = 1u;    // (an order by length has no spatial runs to keep on one XCD)
+        if (part == 0 && h->tile_lpt_on && !h->tile_lpt_grouped) a.xcd_interleave = 1u;    // (an order by length has no spatial runs to keep on one XCD)
     }
     // dual list: only force calls of the step loop (nb_step >= 0) use the inner masks; everything else - energies, the
     // minimiser, the first evaluation after a rebuild - walks the plain list, which is always valid
