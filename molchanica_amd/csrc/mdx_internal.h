@@ -369,7 +369,14 @@ static inline uint32_t mdx_wpt8_below(const mdx_handle* h) {
 static inline int mdx_nb_wpt_half(const mdx_handle* h, uint32_t T) {
     static const int env = [] { const char* e = std::getenv("MDX_WPT"); return (e && (e[0] == '1' || e[0] == '2' || e[0] == '4' || e[0] == '8')) ? e[0] - '0' : 0; }();
     if (env) return env;
-    if (T >= 12000u) return 2;                     // half list at ~1 M atoms: 0.550 vs 0.572 ms (2 tiles per workgroup)
+    // With the tiles launched longest list first (round 3) fewer waves per tile win further down than before: one wave from
+    // 12 k tiles on (water1M: pair launch 0.464 -> 0.458 ms, 1844 -> 1870 steps/s; it was two), two from 3 k tiles on for a
+    // single-device list (375 k atoms 0.213 -> 0.197 ms, 585 k atoms 0.312 -> 0.289; it was four up to 12 k tiles)
+    const bool decomposed = h->dd || h->n_local != h->N;
+    // (a decomposed rank - owned bricks and halo shells, very uneven lists - keeps four up to 8 k tiles: rank 0 of 4, 5.5 k tiles,
+    // 0.155 ms with four against 0.180 with two; rank 0 of 2, 9.4 k tiles, 0.285 with four against 0.257 with two)
+    if (T >= 12000u) return decomposed ? 2 : 1;
+    if (T >= (decomposed ? 8000u : 3000u)) return 2;
     return T < mdx_wpt8_below(h) ? 8 : 4;
 }
 
