@@ -1645,7 +1645,7 @@ int mdx_order_tiles_by_length(mdx_handle* h, bool grouped) {
     }
     uint32_t group_tiles = 0;
     if (grouped) {      // the pair kernel's XCD ranges: ceil(workgroups / 8) workgroups of TPB tiles each (mdx_nonbonded.hip)
-        const uint32_t wpt = (uint32_t)mdx_nb_wpt_half(h, T), tpb = std::max(wpt, 4u) / wpt;
+        const uint32_t wpt = (uint32_t)mdx_nb_wpt_half(h, T), tpb = std::max(wpt, (uint32_t)MDX_NB_WAVES) / wpt;
         group_tiles = (((T + tpb - 1) / tpb + 7) >> 3) * tpb;
     }
     hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, T, d.list_counts, (const uint32_t*)nullptr, d.tile_lpt, group_tiles);

@@ -365,6 +365,13 @@ static inline uint32_t mdx_wpt8_below(const mdx_handle* h) {
     return env >= 0 ? (uint32_t)env : 2048u;
 }
 
+// Least number of waves in a workgroup of the cluster pair kernel: with w waves per tile a workgroup holds max(w, this) waves,
+// i.e. max(1, this / w) tiles.  It was 4 (a workgroup of 256 threads: two or four tiles at one or two waves per tile); measured at
+// the end of round 3 with one wave per tile at water1M: 4 -> 0.4600 ms per pair launch, 2 -> 0.4560, 8 -> 0.4753, 1 -> 0.4487 - a
+// one-wave workgroup has no barrier, frees its slot the moment its tile is done and is dispatched one tile at a time.
+#ifndef MDX_NB_WAVES
+#define MDX_NB_WAVES 1
+#endif
 // waves per tile of the half-list pair kernel for a list of T tiles (MDX_WPT: A/B knob)
 static inline int mdx_nb_wpt_half(const mdx_handle* h, uint32_t T) {
     static const int env = [] { const char* e = std::getenv("MDX_WPT"); return (e && (e[0] == '1' || e[0] == '2' || e[0] == '4' || e[0] == '8')) ? e[0] - '0' : 0; }();

@@ -44,7 +44,7 @@
         __builtin_amdgcn_wave_barrier();                       \
     } while (0)
 
-constexpr int NB_WAVES = 4;
+constexpr int NB_WAVES = MDX_NB_WAVES;      // least waves per workgroup (mdx_internal.h)
 #ifndef NB_ASM_PAIR
 #define NB_ASM_PAIR 0     // 1: the default flavour's pair evaluation is the hand-written block pair_eval_asm (v_cmpx exec handling):
                           // measured round 3 - inner-list walk 0.4566 / 0.4517 ms against 0.4565 / 0.4572 with the compiler's
