@@ -667,14 +667,15 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         if (h->profile) mdx_prof_collect(h, first_stale);
         for (uint32_t s = 0; s < chunk; ++s) {
             if (h->h_ctl->disp2[s + 1] > thr) {
+                // (fused bonded + kick + drift passes swap the two position buffers at every enqueued step, the gated-off
+                // ones included: the state is in the buffer step s's drift wrote - also for a caller that downloads the
+                // coordinates to look at a runaway step)
+                if (fuse_bi && d.posq != pos_after[s]) std::swap(d.posq, d.posq_alt);
                 if (u2f(h->h_ctl->disp2[s + 1]) > 1.0e29f) {
                     h->forces_valid = false; h->list_valid = false;
                     h->step_count += s;
                     FAIL(MDX_ENAN, "non-finite or runaway coordinates during mdx_step");
                 }
-                // (fused bonded + kick + drift passes swap the two position buffers at every enqueued step, the gated-off
-                // ones included: the state is in the buffer step s's drift wrote)
-                if (fuse_bi && d.posq != pos_after[s]) std::swap(d.posq, d.posq_alt);
                 // the drift of step s happened, its forces did not: rebuild, finish the step.  On a decomposed handle
                 // every rank is here at the same step (the flag rides on the halo message): rebuild locally while the
                 // owned + ghost set is still complete, else repartition - decided alike on every rank

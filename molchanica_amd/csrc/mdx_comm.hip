@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256) void fabric_sum_kernel(size_t n, SumPtrs src, 
 struct FabricTransport : MdxTransport {
     mdx_fabric* f = nullptr;
     float* tmp = nullptr; size_t cap_tmp = 0;
+    bool dead = false;      // an exchange named a peer outside the communicator: refused before the barrier, nothing is queued again
     ~FabricTransport() override { if (tmp) (void)hipFree(tmp); }
     int all_reduce_f32(float* dev, size_t n, hipStream_t stream) override {
         if (n > cap_tmp) {
@@ -229,6 +230,9 @@ struct FabricTransport : MdxTransport {
     int fail() { f->abort(); FAIL(MDX_EDEVICE, "in-process fabric: a rank failed or aborted"); }
     int exchange(const float4* send, const std::vector<MdxSeg>& ssegs, float4* recv, const std::vector<MdxSeg>& rsegs,
                  hipStream_t stream) override {
+        if (dead) FAIL(MDX_EDEVICE, "in-process fabric: an earlier exchange was refused");
+        for (const MdxSeg& s : ssegs) if (s.peer < 0 || s.peer >= world) { dead = true; FAIL(MDX_EDEVICE, "in-process fabric: send segment names a peer outside the communicator"); }
+        for (const MdxSeg& r : rsegs) if (r.peer < 0 || r.peer >= world) { dead = true; FAIL(MDX_EDEVICE, "in-process fabric: receive segment names a peer outside the communicator"); }
         if (hipStreamSynchronize(stream) != hipSuccess) return fail();   // my rows are complete
         f->post[rank].send = send; f->post[rank].ssegs = &ssegs;
         if (!f->barrier()) return fail();
@@ -296,6 +300,7 @@ struct ShmSlotHead { uint32_t n_entries; uint32_t word; ShmSegEntry e[64]; };
 struct ShmTransport : MdxTransport {
     std::string shm_name; int fd = -1; unsigned char* base = nullptr; size_t total = 0; ShmHeader* hd = nullptr; uint64_t slot_bytes = 0;
     bool unlinked = false;
+    bool dead = false;
     ~ShmTransport() override {
         if (base) munmap(base, total);
         if (fd >= 0) close(fd);
@@ -316,6 +321,10 @@ struct ShmTransport : MdxTransport {
         return !hd->aborted.load();
     }
     int exchange(const float4* send, const std::vector<MdxSeg>& ssegs, float4* recv, const std::vector<MdxSeg>& rsegs, hipStream_t stream) override {
+        // a peer outside the communicator is refused before the barrier (nobody would arrive) and before slot() is indexed with it
+        if (dead) { mdx_set_error("shared-memory transport: an earlier exchange was refused"); return MDX_EDEVICE; }
+        for (const MdxSeg& s : ssegs) if (s.peer < 0 || s.peer >= world) { dead = true; mdx_set_error("shared-memory transport: send segment names a peer outside the communicator"); return MDX_EDEVICE; }
+        for (const MdxSeg& r : rsegs) if (r.peer < 0 || r.peer >= world) { dead = true; mdx_set_error("shared-memory transport: receive segment names a peer outside the communicator"); return MDX_EDEVICE; }
         ShmSlotHead* mine = (ShmSlotHead*)slot(rank);
         if (ssegs.size() > 64) return fail("too many segments");
         uint64_t off = sizeof(ShmSlotHead);

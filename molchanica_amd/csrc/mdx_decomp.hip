@@ -809,6 +809,12 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
     DD_TRY(dd_partition(h));
     DD_TRY(mdx_rebuild(h));
     h->forces_valid = false;
+    // Every enqueued step of a decomposed handle issues a halo group and a force-return group, so all ranks must cut their chunks
+    // alike.  The chunk-length predictor of mdx_step works from the handle's own history of rebuild-free stretches: a rank that
+    // stepped before it joined (equilibration on the handle it later decomposes) would cut differently from its peers.  From here on
+    // every rank sees the same stale steps (the flag rides on the messages), so the statistics start afresh and stay in step.
+    h->steps_since_rebuild = 0; h->stretch_samples = 0; h->stretch_mean = 0.f; h->stretch_dev = 0.f;
+    h->dual_win_steps = 0; h->dual_win_prunes = 0;
 #undef DD_TRY
 #undef DD_HIP
     return MDX_OK;
@@ -867,8 +873,10 @@ extern "C" int mdx_comm_selftest_fault(mdx_handle* h) {
     HIP_TRY(hipMalloc((void**)&a, sizeof(float4) * 64));
     HIP_TRY(hipMemsetAsync(a, 0, sizeof(float4) * 64, st));
     std::vector<MdxSeg> ss{{dd->world + 3, 0u, 16u}}, rs{{dd->world + 3, 32u, 16u}};   // a peer that does not exist
-    const int rc1 = dd->tr->exchange(a, ss, a, rs, st);
     if (!dd->tr->delivers()) { (void)hipFree(a); return MDX_OK; }     // (the null transport has no wire to fail on)
+    // Not collective: every transport refuses a peer outside the communicator BEFORE it meets the others (mdx_comm.hip: the
+    // fabric and shared-memory transports check their segments ahead of their barrier), so no rank waits for one that never comes
+    const int rc1 = dd->tr->exchange(a, ss, a, rs, st);
     const std::string first = mdx_last_error();
     // the group must be closed and the transport must refuse what follows instead of queueing it
     std::vector<MdxSeg> ok_s{{dd->rank, 0u, 16u}}, ok_r{{dd->rank, 32u, 16u}};

@@ -125,7 +125,8 @@ struct FusedArgs {
 template <bool DUAL>
 __global__ __launch_bounds__(256) void bonded_integrate_kernel(FusedArgs a) {
     const uint32_t gate = a.gate_in ? *a.gate_in : 0u;
-    if (gate > a.thr_bits) {  // list already stale: stay a no-op (positions stay in posq_in: the host does not swap back, see launcher)
+    if (gate > a.thr_bits) {  // list already stale: stay a no-op.  Positions stay in posq_in; the launcher has swapped the host's pointers
+                              // all the same (it enqueues blind), so mdx_step points d.posq back at the buffer the stale step's drift wrote
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(a.disp_out, gate);
         return;
     }

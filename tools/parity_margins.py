@@ -1,0 +1,62 @@
+"""What the parity tests' tolerances leave in hand, measured: for BASELINE configs C1-C5 the worst per-atom force error as a
+multiple of SURVEY 8(c)'s 1e-4 * max(|F|, 1) (no RMS floor), the RMS ratio, the relative error of every energy term, and the
+100-step trajectory deviation of dhfr23k (C2) under reaction field and under the shifted cutoff.  The numbers the tests quote
+come from here.  Usage (through gpurun): python tools/parity_margins.py [c1 c2 c3 c4 c5 traj]"""
+import math, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from molchanica_amd import systems, MdConfig
+from molchanica_amd.md_state import MdState
+from oracle import oracle as orc
+
+TERMS = ("bond", "angle", "dihedral", "lj", "coulomb", "lj14", "coulomb14")
+NOCUT = dict(lj_cutoff=0.0, coulomb_cutoff=0.0)
+want = set(sys.argv[1:]) or {"c1", "c2", "c3", "c4", "c5", "traj"}
+
+
+def single_point(name, s, cfg, use_cells, rel=1e-5):
+    with MdState(s, cfg) as md:
+        pos = md.positions(); f = md.forces().astype(np.float64); e = md.energy()
+    fo, eo = orc.forces(s, cfg, pos=pos.astype(np.float64), use_cells=use_cells)
+    slack = orc.cutoff_slack(s, cfg, pos=pos, rel=rel) if s.periodic else np.zeros(s.n_atoms)
+    err = np.linalg.norm(f - fo, axis=1)
+    fn = np.linalg.norm(fo, axis=1)
+    tol = 1e-4 * np.maximum(fn, 1.0) + slack
+    ratio = err / tol
+    clean = slack == 0
+    rms = math.sqrt(np.mean(err[clean] ** 2)) / math.sqrt(np.mean((fo[clean] ** 2).sum(1)))
+    f_rms = math.sqrt(np.mean((fo ** 2).sum(1)))
+    w = int(np.argmax(ratio))
+    print(f"{name}: N {s.n_atoms}  worst |dF| / (1e-4 max(|F|,1) + cutoff slack) = {ratio.max():.3f} (atom {w}: |F| {fn[w]:.3f}, |dF| {err[w]:.2e}; "
+          f"atoms above 1.0: {int((ratio > 1).sum())}, above 0.5: {int((ratio > 0.5).sum())})  RMS ratio {rms:.2e} (limit 2e-5)  F_rms {f_rms:.2f}  "
+          f"max |dF| / F_rms {err.max() / f_rms:.2e}", flush=True)
+    out = []
+    for k in TERMS:
+        d = abs(e[k] - eo[k])
+        out.append(f"{k} {d / max(abs(eo[k]), 1e-30):.1e} (abs {d:.1e} of {eo[k]:.6g})")
+    print("    energy rel errors: " + "; ".join(out), flush=True)
+
+
+if "c1" in want: single_point("C1 lig50", systems.lig50(), MdConfig(**NOCUT), False)
+if "c2" in want:
+    single_point("C2 dhfr23k", systems.dhfr23k(), MdConfig(), True)
+    single_point("small_solvated rc9", systems.small_solvated(), MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5), False)
+if "c3" in want: single_point("C3 complex50k", systems.complex50k(), MdConfig(), True)
+if "c4" in want: single_point("C4 dna100k", systems.dna100k(), MdConfig(), True)
+if "c5" in want: single_point("C5 water1M", systems.water1m(), MdConfig(), True, rel=4e-5)
+if "traj" in want:
+    s = systems.dhfr23k()
+    L = np.array(s.box_hi) - np.array(s.box_lo)
+    for mode in (1, 0):
+        cfg = MdConfig(coulomb_mode=mode)
+        with MdState(s, cfg) as md:
+            x0, v0 = md.positions().astype(np.float64), md.velocities().astype(np.float64)
+            md.step(0.0005, None, 100)
+            xg, vg = md.positions().astype(np.float64), md.velocities().astype(np.float64)
+            rb = md.stats()["rebuild_count"]
+        t = time.time()
+        xo, vo, _ = orc.step(s, cfg, 0.0005, 100, pos=x0, vel=v0, use_cells=True)
+        d = xg - xo; d -= np.round(d / L) * L
+        per = np.sqrt((d ** 2).sum(1))
+        print(f"C2 dhfr23k 100-step trajectory, coulomb_mode {mode}: RMS deviation {math.sqrt((per ** 2).mean()):.2e} A, max {per.max():.2e} A, "
+              f"velocity RMS {math.sqrt(((vg - vo) ** 2).sum(1).mean()):.2e} A/ps, {rb} list builds, oracle {time.time() - t:.0f} s", flush=True)
