@@ -40,7 +40,18 @@ B_ALG_BONDED_WATER = 52.0      # 36 + 16 t, t = 1 bonded term per atom in flexib
 B_ALG_FUSED_WATER = 116.0      # bonded gather + kick + drift as one pass: the two figures above together
 B_ALG_STEP_WATER = 170.0       # whole step, water box
 FLOP_PER_PAIR = 45.0
-NB_KERNEL_REV = "r03e"         # revision tag of the default pair kernel the cached PMC traffic figure belongs to
+def _nb_kernel_rev():
+    """Revision of the default pair kernel = a hash of its sources: the cached PMC traffic figure (profiles/nb_traffic.json,
+    written by tools/summarize_rocprof.py with the hash of the tree it was measured on) is quoted only while it matches."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("mdx_nonbonded.hip", "mdx_internal.h"):
+        with open(os.path.join(ROOT, "molchanica_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
+NB_KERNEL_REV = _nb_kernel_rev()
 
 
 def parse():
@@ -266,8 +277,9 @@ def main():
                 bad = torch.tensor([1.0 if err else 0.0], device="cpu" if pg_cpu else "cuda")
                 dist.all_reduce(bad, op=dist.ReduceOp.MAX)
                 if bad.item() > 0:
-                    sys.stderr.write(f"[bench rank {rank}] RCCL transport unusable ({err or 'failed on another rank'}); "
-                                     f"continuing over the shared-memory transport\n")
+                    sys.stderr.write(f"[bench rank {rank} of {world}, device {local_rank}] RCCL transport unusable: "
+                                     f"{err or 'no error on this rank (another rank failed)'}; continuing over the shared-memory transport\n")
+                    sys.stderr.flush()
                     md.close()
                     md = MdState(system, cfg, device=local_rank)
                     md.comm_init_shm(shm_name, rank, world)
@@ -359,8 +371,44 @@ def main():
     if args.profile_level == 0:
         st_nb = st_tail
 
+    # Decomposed runs: where the step time goes, rank by rank (mdx_comm_diag): 48 more steps with every phase of the step
+    # bracketed in its production arrangement (profile level 3), outside the timed region.
+    multi = None
+    if world > 1 or args.decomposed:
+        prof(3)
+        t_d = time.perf_counter()
+        stepper(48)
+        sync()
+        wall_d = (time.perf_counter() - t_d) / 48 * 1e3
+        mine = md.comm_diag()
+        prof(0)
+        mine["step_wall_ms_profiled"] = wall_d
+        mine["phase_ms_per_step"] = {k: v / 48.0 for k, v in mine.pop("phase_ms_sum").items()}
+        gpu_sum = sum(mine["phase_ms_per_step"].values())
+        mine["gpu_phases_ms_per_step"] = gpu_sum
+        mine["host_and_idle_ms_per_step"] = wall_d - gpu_sum      # (phases on two streams overlap when the split is on: may be negative)
+        per_rank = [mine]
+        if world > 1:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+        multi = {"rccl_world": mine["rccl_comm_count"], "rccl_version": mine["rccl_version"], "transport": mine["transport"],
+                 "halo_bytes_per_step_per_rank": [r["halo_bytes_per_step"] for r in per_rank],
+                 "n_owned": [r["n_owned"] for r in per_rank], "n_ghost": [r["n_ghost"] for r in per_rank],
+                 "repartitions": [r["repartitions"] for r in per_rank], "local_rebuilds": [r["local_rebuilds"] for r in per_rank],
+                 "overlap_split_kept": [r["overlap_split"] for r in per_rank],
+                 "phase_ms_per_step": {k: [round(r["phase_ms_per_step"][k], 5) for r in per_rank] for k in mine["phase_ms_per_step"]},
+                 "step_wall_ms_profiled": [round(r["step_wall_ms_profiled"], 5) for r in per_rank],
+                 "host_and_idle_ms_per_step": [round(r["host_and_idle_ms_per_step"], 5) for r in per_rank],
+                 "note": "GPU time between HIP events per phase, 48 untimed steps at profile level 3 (production arrangement); "
+                         "halo_wire / force_wire = the ncclSend/ncclRecv group incl. waiting for the peers; pair = whole launch or interior half"}
+
     steps_per_s = args.steps / el
     value = n_atoms * steps_per_s
+    # Whether one of the ~0.6 ms list rebuilds (one per ~25 steps) lands in a 20-step timed window is a coin flip worth 5 % of
+    # `value`.  Two figures beside it that do not depend on the coin: the rate with the window's rebuild time taken out, and
+    # that rate with the rebuild cost of a long run (the tail's, per step) put back in.
+    rb_ms_timed = st["rebuild_ms_sum"] - st0["rebuild_ms_sum"]
+    ms_no_rb = (1e3 * el - rb_ms_timed) / args.steps
     nb_launches = st_nb["nb_launches"]
     nb_ms = st_nb["nb_ms_sum"] / max(nb_launches, 1)
     bonded_ms = st_tail["bonded_ms_sum"] / max(st_tail["bonded_launches"], 1)
@@ -409,6 +457,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,   # the ONE 1M-atom box at every N (BASELINE.json)
         "dtype": "f32", "data": "synthetic",
+        "value_no_rebuild": n_atoms * 1e3 / ms_no_rb if (ms_no_rb > 0 and args.profile_level) else None,
+        "value_with_amortised_rebuild": (n_atoms * 1e3 / (ms_no_rb + (tail["rebuild_ms_per_step_amortised"] if tail else rb_ms_timed / args.steps))
+                                         if (ms_no_rb > 0 and args.profile_level) else None),
         "steps_per_s_1000": tail["steps_per_s"] if tail else steps_per_s,
         "rebuild_ms_per_step_amortised": (tail["rebuild_ms_per_step_amortised"] if tail
                                           else (st["rebuild_ms_sum"] - st0["rebuild_ms_sum"]) / args.steps),
@@ -448,6 +499,7 @@ def main():
                  "algorithmic_tflops": alg_tflops, "peak_tflops": FP32_PEAK_TFLOPS,
                  "frac": alg_tflops / FP32_PEAK_TFLOPS if alg_tflops is not None else None},
         "step_hbm_frac": B_ALG_STEP_WATER * value / (world * HBM_PEAK_GBS * 1e9) if args.workload == "water1M" else None,
+        "multi_gpu": multi,
         "kernel_ms": {"nonbonded": nb_ms, "bonded": bonded_ms, "integrate": integ_ms, "bonded_integrate_fused": fused_ms,
                       "bonded_plus_integrate_per_step": streaming_ms_per_step,
                       "rebuild_total": st_nb["rebuild_ms_sum"] - st0["rebuild_ms_sum"]},

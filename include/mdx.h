@@ -261,6 +261,7 @@ uint64_t mdx_step_count(const mdx_handle* h);
  * (offsets[N] = total), then again with idx sized offsets[N]. */
 int mdx_neighbor_list(mdx_handle* h, uint32_t* offsets /* [N+1] */, uint32_t* idx /* or NULL */);
 
+/* (enable 3, decomposed handles: every phase of the step in its production arrangement - see mdx_comm_diag) */
 /* Kernel timing with HIP events on the library's stream; mdx_get_stats reads the sums.  enable: 0 off, 1 every
  * step kernel, 2 the pair kernel only (each event pair is two extra packets in the queue: level 2 disturbs the
  * step loop least). */
@@ -451,6 +452,33 @@ int mdx_comm_selftest(mdx_handle* h);
  * destroy the handle.  Not collective (nothing reaches the wire). */
 int mdx_comm_selftest_fault(mdx_handle* h);
 int mdx_comm_info(const mdx_handle* h, int* rank, int* world, int grid[3], uint32_t* n_owned, uint32_t* n_ghost, float* halo);
+
+/* Where a decomposed step spends its time and what it moves: what a reader of one multi-GPU bench line needs to tell the
+ * wire from the kernels.  Phase times are GPU time between HIP events on the stream each phase runs on, summed while
+ * mdx_profile(h, 3) is on - level 3 keeps the production arrangement (interior tiles beside the message, fused passes) and
+ * brackets every phase; phase_n counts the brackets.  The halo "wire" phase is the ncclSend/ncclRecv group (or the other
+ * transports' copies): it includes waiting for the peers to arrive.  Not collective. */
+#define MDX_DIAG_PHASES 10
+enum { MDX_PHASE_HALO_PACK = 0, MDX_PHASE_HALO_WIRE = 1, MDX_PHASE_HALO_UNPACK = 2, MDX_PHASE_FORCE_PACK = 3,
+       MDX_PHASE_FORCE_WIRE = 4, MDX_PHASE_FORCE_ADD = 5, MDX_PHASE_PAIR = 6 /* whole launch, or the interior half */,
+       MDX_PHASE_PAIR_BOUNDARY = 7, MDX_PHASE_BONDED = 8 /* + the fused bonded + kick + drift pass */, MDX_PHASE_INTEGRATE = 9 };
+typedef struct mdx_comm_diag {
+    char     transport[64];          /* "rccl", "in-process fabric", "shared memory (host-staged)", "null (delivers nothing)" */
+    int32_t  rank, world, grid[3];
+    int32_t  rccl_version;           /* ncclGetVersion (e.g. 22606), 0 on the other transports */
+    int32_t  rccl_comm_count;        /* ncclCommCount of this handle's communicator: must equal world */
+    int32_t  half_shell;             /* 1: every cross-rank pair on one rank, ghost forces travel back */
+    int32_t  overlap_split;          /* interior / boundary split of the pair kernel: 1 kept, 0 dropped, -1 still measuring */
+    int32_t  comm_stream_separate;   /* 1: RCCL calls on their own stream (MDX_COMM_STREAM=1) */
+    int32_t  pad0;
+    uint32_t n_owned, n_ghost, n_tiles, n_interior_tiles;
+    uint32_t halo_rows_out, halo_rows_in;     /* float4 rows per position message, flag rows included */
+    uint64_t halo_bytes_per_step;    /* positions out + in, plus the force rows back and forth with the half shell */
+    uint64_t repartitions, local_rebuilds;
+    double   repartition_ms_sum;
+    double   phase_ms[MDX_DIAG_PHASES]; uint64_t phase_n[MDX_DIAG_PHASES];
+} mdx_comm_diag;
+int mdx_comm_diag_read(mdx_handle* h, mdx_comm_diag* out);
 /* Diagnostics: what the partition kernels derived at the last (re)partition, per GLOBAL atom - class here (0 absent, 1 owned,
  * 2 ghost, 3 ghost kept only as a bonded partner), owning rank, image code ((kx+1) | (ky+1) << 2 | (kz+1) << 4) and, for owned
  * atoms, the bit set of ranks that keep a copy - and the two halo lists (global atom ids in message order, 0xFFFFFFFF = a

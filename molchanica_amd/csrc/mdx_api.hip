@@ -147,7 +147,7 @@ static void free_device(mdx_handle* h) {
                     d.mchunk_cnt, d.mchunk_off, d.entries, d.entries_in, d.inner_nch, d.list_cursors, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
                     d.role_off_s, d.role_rec_s, d.role_prm, d.ctl, d.energy,
                     d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.pme_force, d.cons_o, d.cons_s, d.cons_vir, d.vsite_o, d.vsite_s, d.pme_q, d.pme_f,
-                    d.pme_theta, d.pme_q2, d.pme_f2, d.scratch4, d.tile_bnd, d.tile_scan, d.tile_order, d.tile_lpt};
+                    d.pme_theta, d.pme_q2, d.pme_f2, d.scratch4, d.tile_bnd, d.tile_scan, d.tile_order, d.tile_lpt, d.rb_ctl, d.scan_chain};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = DeviceState{};
 }
@@ -515,25 +515,26 @@ void mdx_range_push(const char* name) { if (roctx_ready()) (void)g_roctx.push(na
 void mdx_range_pop() { if (roctx_ready()) (void)g_roctx.pop(); }
 
 // ---- profiling -------------------------------------------------------------------------------
-void mdx_prof_begin(mdx_handle* h, int kind) {
+void mdx_prof_begin(mdx_handle* h, int kind, hipStream_t st) {
     h->prof_open = false;
     if (!h->profile) return;
     if (h->profile_level == 2 && kind != 0 && kind != 4) return;   // pair kernel of the step loop only
+    if (kind >= 6 && h->profile_level != 3) return;                // the phases of a decomposed step: level 3
     h->prof_open = true;
     mdx_handle::EvPair p{};
-    p.kind = kind; p.tag = h->prof_tag;
+    p.kind = kind; p.tag = h->prof_tag; p.st = st ? st : h->stream;
     hipEvent_t* ev[2] = {&p.a, &p.b};
     for (auto e : ev) {
         if (!h->ev_pool.empty()) { *e = h->ev_pool.back(); h->ev_pool.pop_back(); }
         else (void)hipEventCreate(e);
     }
-    (void)hipEventRecord(p.a, h->stream);
+    (void)hipEventRecord(p.a, p.st);
     h->ev_pending.push_back(p);
 }
 void mdx_prof_end(mdx_handle* h) {
     if (!h->profile || !h->prof_open || h->ev_pending.empty()) return;
     h->prof_open = false;
-    (void)hipEventRecord(h->ev_pending.back().b, h->stream);
+    (void)hipEventRecord(h->ev_pending.back().b, h->ev_pending.back().st);
 }
 void mdx_prof_collect(mdx_handle* h, int first_stale_step) {
     for (auto& p : h->ev_pending) {
@@ -549,6 +550,15 @@ void mdx_prof_collect(mdx_handle* h, int first_stale_step) {
             else if (p.kind == 1) { h->stats.bonded_ms_sum += ms; h->stats.bonded_launches++; }
             else if (p.kind == 2) { h->stats.integ_ms_sum += ms; h->stats.integ_launches++; }
             else if (p.kind == 5) { h->stats.fused_ms_sum += ms; h->stats.fused_launches++; }
+            if (h->dd && h->profile_level == 3) {      // mdx_comm_diag: phase by phase
+                int ph = -1;
+                if (p.kind >= 6 && p.kind <= 11) ph = p.kind - 6;
+                else if (p.kind == 0) ph = MDX_PHASE_PAIR;
+                else if (p.kind == 4) ph = MDX_PHASE_PAIR_BOUNDARY;
+                else if (p.kind == 1 || p.kind == 5) ph = MDX_PHASE_BONDED;
+                else if (p.kind == 2) ph = MDX_PHASE_INTEGRATE;
+                if (ph >= 0) { h->dd->phase_ms[ph] += ms; h->dd->phase_n[ph]++; }
+            }
         }
         h->ev_pool.push_back(p.a); h->ev_pool.push_back(p.b);
     }
@@ -1166,6 +1176,7 @@ extern "C" int mdx_profile(mdx_handle* h, int enable) {
         h->stats.nb_ms_sum = h->stats.bonded_ms_sum = h->stats.integ_ms_sum = 0.0;
         h->stats.rebuild_ms_sum = h->stats.wall_ms_sum = 0.0;
         h->stats.nb_launches = h->stats.bonded_launches = h->stats.integ_launches = 0;
+        if (h->dd) for (int k = 0; k < MDX_DIAG_PHASES; ++k) { h->dd->phase_ms[k] = 0.0; h->dd->phase_n[k] = 0; }
     }
     return MDX_OK;
 }
@@ -1282,6 +1293,7 @@ int mdx_set_local_atoms_impl(mdx_handle* h, uint32_t n_local, const uint32_t* d_
     h->periodic = per[0] || per[1] || per[2];
     h->have_local_bounds = true;
     h->in_slot_space = false; h->list_valid = false; h->forces_valid = false;
+    h->slot_of_clean = false;      // atoms that left the local set still have their old slots in d.slot_of
     return MDX_OK;
 }
 

@@ -27,6 +27,8 @@ struct MdxTransport {
     virtual int all_gather_u32(uint32_t mine, uint32_t* all, hipStream_t stream) = 0;
     virtual const char* name() const = 0;
     virtual bool delivers() const { return true; }   // false: the null transport (peers' rows never arrive)
+    // RCCL only: ncclGetVersion and ncclCommCount of this handle's communicator (0, 0 elsewhere) - for mdx_comm_diag
+    virtual void wire_info(int* version, int* comm_count) const { *version = 0; *comm_count = 0; }
 };
 
 struct mdx_fabric;   // the in-process transport's meeting point (C ABI: mdx_fabric_create / _destroy)
@@ -89,12 +91,14 @@ struct MdxDecomp {
     // statistics
     uint64_t repartitions = 0, local_rebuilds = 0; uint32_t local_rebuilds_since = 0;
     double repartition_ms = 0.0;
+    // mdx_profile(h, 3): GPU time of the phases of a decomposed step, in the production arrangement (mdx_comm_diag)
+    double phase_ms[MDX_DIAG_PHASES] = {}; uint64_t phase_n[MDX_DIAG_PHASES] = {};
 };
 
 // Is the pair kernel of this step-loop force call launched as interior + boundary halves?  ONE predicate for everybody who
 // must agree on it: the launch itself, and the halo unpack (which then raises the ghosts' own prune word).
 static inline bool mdx_dd_split_now(const mdx_handle* h) {
-    return h->dd && h->tile_split && h->dd->overlap && h->dd->world > 1 && mdx_nb_variant(h) >= 2 && !h->pme_on && !h->profile;
+    return h->dd && h->tile_split && h->dd->overlap && h->dd->world > 1 && mdx_nb_variant(h) >= 2 && !h->pme_on && (!h->profile || h->profile_level == 3);
 }
 
 int  mdx_set_local_atoms_impl(mdx_handle* h, uint32_t n_local, const uint32_t* d_gid, const uint8_t* d_ghost, const float* d_pos4,

@@ -46,6 +46,8 @@ struct RcclApi {
     int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
+    int (*CommCount)(const ncclComm_t, int*) = nullptr;
 };
 RcclApi g_rccl;
 std::mutex g_rccl_mutex;
@@ -63,6 +65,8 @@ bool load_rccl() {
     SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv")
     SYM(AllReduce, "ncclAllReduce") SYM(AllGather, "ncclAllGather") SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+    *(void**)(&a.GetVersion) = dlsym(lib, "ncclGetVersion");      // (diagnostics only: absent symbols read as 0)
+    *(void**)(&a.CommCount) = dlsym(lib, "ncclCommCount");
     g_rccl = a;
     return true;
 }
@@ -87,6 +91,11 @@ struct RcclTransport : MdxTransport {
         if (d_words) (void)hipFree(d_words);
     }
     const char* name() const override { return "rccl"; }
+    void wire_info(int* version, int* comm_count) const override {
+        *version = 0; *comm_count = 0;
+        if (g_rccl.GetVersion) (void)g_rccl.GetVersion(version);
+        if (g_rccl.CommCount && comm && !dead) (void)g_rccl.CommCount(comm, comm_count);
+    }
     int exchange(const float4* send, const std::vector<MdxSeg>& ssegs, float4* recv, const std::vector<MdxSeg>& rsegs,
                  hipStream_t stream) override {
         if (dead) FAIL(MDX_EDEVICE, "rccl transport: an earlier send/recv group failed");
@@ -94,23 +103,28 @@ struct RcclTransport : MdxTransport {
         // Inside the group nothing may return early: a thread that leaves with its group open queues every later RCCL
         // call - including ncclCommDestroy - into a group that is never closed.  The first error is remembered, the
         // group is always closed, and the transport is marked dead.
-        int first = ncclSuccess;
+        int first = ncclSuccess, bad_peer = -1; uint32_t bad_rows = 0;
         const char* what = "";
         for (const MdxSeg& s : ssegs) {
             if (!s.nrows || first != ncclSuccess) continue;
             first = g_rccl.Send(send + s.row0, (size_t)s.nrows * 4, ncclFloat32, s.peer, comm, stream);
-            if (first != ncclSuccess) what = "ncclSend";
+            if (first != ncclSuccess) { what = "ncclSend"; bad_peer = s.peer; bad_rows = s.nrows; }
         }
         for (const MdxSeg& r : rsegs) {
             if (!r.nrows || first != ncclSuccess) continue;
             first = g_rccl.Recv(recv + r.row0, (size_t)r.nrows * 4, ncclFloat32, r.peer, comm, stream);
-            if (first != ncclSuccess) what = "ncclRecv";
+            if (first != ncclSuccess) { what = "ncclRecv"; bad_peer = r.peer; bad_rows = r.nrows; }
         }
         const int end = g_rccl.GroupEnd();
         if (first == ncclSuccess && end != ncclSuccess) { first = end; what = "ncclGroupEnd"; }
         if (first != ncclSuccess) {
             dead = true;
-            mdx_set_error(std::string(what) + " (halo exchange group): " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(first) : "rccl error"));
+            // rank, peer and call: the first real multi-rank run happens on a box nobody watches
+            char where[160];
+            std::snprintf(where, sizeof(where), "rank %d of %d: %s%s%s (send/recv group of %zu + %zu segments", rank, world, what,
+                          bad_peer >= 0 ? " peer " : "", bad_peer >= 0 ? std::to_string(bad_peer).c_str() : "", ssegs.size(), rsegs.size());
+            mdx_set_error(std::string(where) + (bad_peer >= 0 ? ", " + std::to_string(bad_rows) + " float4 rows" : std::string()) + "): " +
+                          (g_rccl.GetErrorString ? g_rccl.GetErrorString(first) : "rccl error"));
             return MDX_EDEVICE;
         }
         return MDX_OK;

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 
 #define FAIL(code, msg) do { mdx_set_error(msg); return (code); } while (0)
@@ -481,12 +482,18 @@ int mdx_dd_halo_begin(mdx_handle* h) {
     MdxDecomp* dd = h->dd;
     if (dd->world == 1) return MDX_OK;
     const int fw = dd->halo_step >= 0 ? dd->halo_step + 1 : -1;
-    MDX_TRY(mdx_pack_positions(h, dd->send_ids, dd->n_send, (float*)dd->send_buf, fw));
+    mdx_prof_begin(h, 6);
+    const int rc_pack = mdx_pack_positions(h, dd->send_ids, dd->n_send, (float*)dd->send_buf, fw);
+    mdx_prof_end(h);
+    MDX_TRY(rc_pack);
     if (dd->comm_stream != h->stream) {
         HIP_TRY(hipEventRecord(dd->ev_packed, h->stream));
         HIP_TRY(hipStreamWaitEvent(dd->comm_stream, dd->ev_packed, 0));
     }
-    MDX_TRY(dd->tr->exchange(dd->send_buf, dd->send_segs, dd->recv_buf, dd->recv_segs, dd->comm_stream));
+    mdx_prof_begin(h, 7, dd->comm_stream);
+    const int rc_x = dd->tr->exchange(dd->send_buf, dd->send_segs, dd->recv_buf, dd->recv_segs, dd->comm_stream);
+    mdx_prof_end(h);
+    MDX_TRY(rc_x);
     if (dd->comm_stream != h->stream) HIP_TRY(hipEventRecord(dd->ev_arrived, dd->comm_stream));
     return MDX_OK;
 }
@@ -496,8 +503,12 @@ int mdx_dd_halo_end(mdx_handle* h) {
     if (dd->world == 1) return MDX_OK;
     const int fw = dd->halo_step >= 0 ? dd->halo_step + 1 : -1;
     if (dd->comm_stream != h->stream) HIP_TRY(hipStreamWaitEvent(h->stream, dd->ev_arrived, 0));
-    if (dd->tr->delivers())
-        MDX_TRY(mdx_unpack_positions(h, dd->recv_ids, dd->n_recv, (const float*)dd->recv_buf, (const float*)dd->recv_shift, fw));
+    if (dd->tr->delivers()) {
+        mdx_prof_begin(h, 8);
+        const int rc_u = mdx_unpack_positions(h, dd->recv_ids, dd->n_recv, (const float*)dd->recv_buf, (const float*)dd->recv_shift, fw);
+        mdx_prof_end(h);
+        MDX_TRY(rc_u);
+    }
     return MDX_OK;
 }
 
@@ -536,15 +547,20 @@ int mdx_dd_force_return_begin(mdx_handle* h, int flag_word) {
     if (!mdx_dd_half_shell(h) || !h->in_slot_space) return MDX_OK;
     hipStream_t st = h->stream;
     const uint32_t* fw = flag_word >= 0 ? &h->d.ctl->disp2[flag_word] : nullptr;
+    mdx_prof_begin(h, 9);
     if (dd->n_recv)
         hipLaunchKernelGGL(dd_pack_force_kernel, dim3(div_up(dd->n_recv, 256)), dim3(256), 0, st, dd->n_recv, dd->recv_ids, h->d.slot_of,
                            h->d.force, dd->frc_send, fw);
+    mdx_prof_end(h);
     HIP_TRY(hipGetLastError());
     if (dd->comm_stream != st) {
         HIP_TRY(hipEventRecord(dd->ev_packed, st));
         HIP_TRY(hipStreamWaitEvent(dd->comm_stream, dd->ev_packed, 0));
     }
-    MDX_TRY(dd->tr->exchange(dd->frc_send, dd->recv_segs, dd->frc_recv, dd->send_segs, dd->comm_stream));
+    mdx_prof_begin(h, 10, dd->comm_stream);
+    const int rc_x = dd->tr->exchange(dd->frc_send, dd->recv_segs, dd->frc_recv, dd->send_segs, dd->comm_stream);
+    mdx_prof_end(h);
+    MDX_TRY(rc_x);
     if (dd->comm_stream != st) HIP_TRY(hipEventRecord(dd->ev_arrived, dd->comm_stream));
     dd->force_return_pending = true;
     return MDX_OK;
@@ -557,9 +573,12 @@ int mdx_dd_force_return_end(mdx_handle* h, int flag_word) {
     hipStream_t st = h->stream;
     if (dd->comm_stream != st) HIP_TRY(hipStreamWaitEvent(st, dd->ev_arrived, 0));
     uint32_t* fw = flag_word >= 0 ? &h->d.ctl->disp2[flag_word] : nullptr;
-    if (dd->tr->delivers() && dd->n_send)
+    if (dd->tr->delivers() && dd->n_send) {
+        mdx_prof_begin(h, 11);
         hipLaunchKernelGGL(dd_add_force_kernel, dim3(div_up(dd->n_send, 256)), dim3(256), 0, st, dd->n_send, dd->send_ids, h->d.slot_of,
                            h->d.force, dd->frc_recv, fw);
+        mdx_prof_end(h);
+    }
     HIP_TRY(hipGetLastError());
     return MDX_OK;
 }
@@ -830,6 +849,30 @@ extern "C" int mdx_comm_info(const mdx_handle* h, int* rank, int* world, int gri
     if (n_owned) *n_owned = dd ? dd->n_owned : h->N;
     if (n_ghost) *n_ghost = dd ? dd->n_local - dd->n_owned : 0;
     if (halo) *halo = dd ? dd->halo : 0.f;
+    return MDX_OK;
+}
+
+extern "C" int mdx_comm_diag_read(mdx_handle* h, mdx_comm_diag* out) {
+    if (!h || !out) FAIL(MDX_EPARAM, "null argument");
+    if (!h->dd) FAIL(MDX_EPARAM, "the handle has not joined a communicator");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    mdx_prof_collect(h);
+    const MdxDecomp* dd = h->dd;
+    std::memset(out, 0, sizeof(*out));
+    std::snprintf(out->transport, sizeof(out->transport), "%s", dd->tr->name());
+    out->rank = dd->rank; out->world = dd->world;
+    for (int d = 0; d < 3; ++d) out->grid[d] = dd->grid[d];
+    dd->tr->wire_info(&out->rccl_version, &out->rccl_comm_count);
+    out->half_shell = mdx_dd_half_shell(h) ? 1 : 0;
+    out->overlap_split = dd->world > 1 ? (dd->tune_phase < 2 ? -1 : (dd->overlap ? 1 : 0)) : 0;
+    out->comm_stream_separate = dd->comm_stream != h->stream ? 1 : 0;
+    out->n_owned = dd->n_owned; out->n_ghost = dd->n_local - dd->n_owned;
+    out->n_tiles = h->T; out->n_interior_tiles = h->tile_split ? h->n_interior : 0;
+    out->halo_rows_out = dd->n_send; out->halo_rows_in = dd->n_recv;
+    out->halo_bytes_per_step = (uint64_t)(dd->n_send + dd->n_recv) * sizeof(float4) * (mdx_dd_half_shell(h) ? 2u : 1u);
+    out->repartitions = dd->repartitions; out->local_rebuilds = dd->local_rebuilds; out->repartition_ms_sum = dd->repartition_ms;
+    for (int k = 0; k < MDX_DIAG_PHASES; ++k) { out->phase_ms[k] = dd->phase_ms[k]; out->phase_n[k] = dd->phase_n[k]; }
     return MDX_OK;
 }
 

@@ -64,10 +64,13 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
     return base + inc - v;
 }
 
+// n_dev (may be null): the element count is still on the device (fused rebuild: the launch covers an upper bound n, the
+// elements beyond *n_dev count as zero and are not written)
 __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_kernel(const uint32_t* __restrict__ in,
                                                                  uint32_t* __restrict__ out,
-                                                                 uint32_t* __restrict__ tile_sums, uint32_t n) {
+                                                                 uint32_t* __restrict__ tile_sums, uint32_t n, const uint32_t* __restrict__ n_dev) {
     __shared__ uint32_t s_wave[SCAN_THREADS / 64];
+    if (n_dev) n = min(n, *n_dev);
     const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS], sum = 0;
 #pragma unroll
@@ -97,7 +100,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_sums_kernel(uint32_t* __res
     }
 }
 
-__global__ void scan_add_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ sums, uint32_t n) {
+__global__ void scan_add_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ sums, uint32_t n, const uint32_t* __restrict__ n_dev) {
+    if (n_dev) n = min(n, *n_dev);
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] += sums[i / SCAN_TILE];
 }
@@ -110,14 +114,18 @@ int mdx_exclusive_scan_u32(mdx_handle* h, const uint32_t* in, uint32_t* out, uin
 // 8192 elements at a time, carrying the running total - one launch instead of three (tile scan, scan of the tile sums,
 // add), which at this size are all launch latency.
 constexpr int SCAN1_THREADS = 1024;
-__global__ __launch_bounds__(SCAN1_THREADS) void scan_one_block_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                                       uint32_t n) {
-    // Wave w owns the contiguous range [w * cw, (w + 1) * cw), cw a multiple of 256, and reads it as 16-byte vectors, lane after
-    // lane (coalesced: one 1-KB request per instruction), ALL of it before anything else - up to 16 loads in flight, the data
-    // stays in registers.  The waves' totals meet in LDS once; then every wave scans its registers and writes.  (Round 2's form
-    // gave thread k the segment [k * ipt, (k + 1) * ipt): 64 cache lines per load instruction, two passes of ~1 us round
-    // trips - 29 us for the 60 k cells of a 23 k-atom system, 5 us now.)
-    __shared__ uint32_t s_wave[SCAN1_THREADS / 64];
+constexpr uint32_t SCAN1_WINDOW = 65536u;
+// Exclusive scan of n <= 65536 elements by the whole 1024-thread workgroup, starting from `carry_in`; returns the running
+// total behind the window (the same value in every thread).  zero_in: the input is cleared behind the read (the cell
+// histogram of the fused rebuild is left ready for the next one).
+// Wave w owns the contiguous range [w * cw, (w + 1) * cw), cw a multiple of 256, and reads it as 16-byte vectors, lane after
+// lane (coalesced: one 1-KB request per instruction), ALL of it before anything else - up to 16 loads in flight, the data
+// stays in registers.  The waves' totals meet in LDS once; then every wave scans its registers and writes.  (Round 2's form
+// gave thread k the segment [k * ipt, (k + 1) * ipt): 64 cache lines per load instruction, two passes of ~1 us round
+// trips - 29 us for the 60 k cells of a 23 k-atom system, 5 us now.)
+template <typename CarryFn>
+__device__ __forceinline__ uint32_t scan_window_1024(const uint32_t* in, uint32_t* __restrict__ out, uint32_t n, CarryFn carry_of,
+                                                     uint32_t* s_wave /* [16] */, uint32_t* zero_in) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NW = SCAN1_THREADS / 64, MAXIT = 16;                 // NW * MAXIT * 256 = 65536 elements
     const uint32_t cw = ((n + NW * 256u - 1u) / (NW * 256u)) * 256u;
@@ -145,8 +153,10 @@ __global__ __launch_bounds__(SCAN1_THREADS) void scan_one_block_kernel(const uin
     for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
     if (lane == 0) s_wave[wave] = sum;
     __syncthreads();
-    uint32_t carry = 0;
-    for (int w = 0; w < wave; ++w) carry += s_wave[w];
+    uint32_t below = 0, local_total = 0;
+    for (int w = 0; w < NW; ++w) { const uint32_t x = s_wave[w]; if (w < wave) below += x; local_total += x; }
+    const uint32_t carry_in = carry_of(local_total);      // (a chained window waits for its predecessor here: contains a barrier)
+    uint32_t carry = carry_in + below;
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
         if ((uint32_t)it * 256u >= cw) break;
@@ -157,32 +167,90 @@ __global__ __launch_bounds__(SCAN1_THREADS) void scan_one_block_kernel(const uin
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(inc, d); if (lane >= d) inc += u; }
         const uint32_t e0 = carry + inc - t, e1 = e0 + x.x, e2 = e1 + x.y, e3 = e2 + x.z;
-        if (vec && i + 3u < e) *reinterpret_cast<uint4*>(out + i) = make_uint4(e0, e1, e2, e3);
-        else {
-            if (i < e) out[i] = e0;
-            if (i + 1u < e) out[i + 1u] = e1;
-            if (i + 2u < e) out[i + 2u] = e2;
-            if (i + 3u < e) out[i + 3u] = e3;
+        if (vec && i + 3u < e) {
+            *reinterpret_cast<uint4*>(out + i) = make_uint4(e0, e1, e2, e3);
+            if (zero_in) *reinterpret_cast<uint4*>(zero_in + i) = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            if (i < e) { out[i] = e0; if (zero_in) zero_in[i] = 0u; }
+            if (i + 1u < e) { out[i + 1u] = e1; if (zero_in) zero_in[i + 1u] = 0u; }
+            if (i + 2u < e) { out[i + 2u] = e2; if (zero_in) zero_in[i + 2u] = 0u; }
+            if (i + 3u < e) { out[i + 3u] = e3; if (zero_in) zero_in[i + 3u] = 0u; }
         }
         carry += __shfl(inc, 63);
     }
+    __syncthreads();      // s_wave is free again
+    return carry_in + local_total;
 }
 
-int mdx_exclusive_scan_u32_ex(mdx_handle* h, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums) {
+// Windows of 65536 elements CHAINED over the workgroups of one launch: workgroup w scans window w; it has its window in
+// registers and its local total before it needs the running total of the windows in front, which it takes from workgroup
+// w - 1 through a word in memory ((generation << 32) | inclusive total: no reset between launches) - a hop of ~1-2 us.
+// The grid is at most a few dozen workgroups, all resident at once, so the spin cannot starve its predecessor.
+struct ScanChain { unsigned long long* carry; uint32_t gen; };
+__device__ __forceinline__ uint32_t chained_carry(const ScanChain& ch, uint32_t w, uint32_t local_total, uint32_t* s_bcast) {
+    if (threadIdx.x == 0) {
+        uint32_t c = 0;
+        if (w > 0) {
+            unsigned long long x;
+            do { x = __hip_atomic_load(ch.carry + (w - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if ((uint32_t)(x >> 32) != ch.gen) __builtin_amdgcn_s_sleep(1); }
+            while ((uint32_t)(x >> 32) != ch.gen);
+            c = (uint32_t)x;
+        }
+        __hip_atomic_store(ch.carry + w, ((unsigned long long)ch.gen << 32) | (unsigned long long)(c + local_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_bcast = c;
+    }
+    __syncthreads();
+    return *s_bcast;
+}
+__global__ __launch_bounds__(SCAN1_THREADS) void scan_chained_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n,
+                                                                     const uint32_t* __restrict__ n_dev, ScanChain ch) {
+    __shared__ uint32_t s_wave[SCAN1_THREADS / 64];
+    __shared__ uint32_t s_bcast;
+    if (n_dev) n = min(n, *n_dev);
+    const uint32_t w = blockIdx.x, w0 = w * SCAN1_WINDOW;
+    const uint32_t nw = w0 < n ? min(SCAN1_WINDOW, n - w0) : 0u;       // (a window behind the end still hands the total on)
+    (void)scan_window_1024(in + w0, out + w0, nw, [&](uint32_t tot) { return chained_carry(ch, w, tot, &s_bcast); }, s_wave, nullptr);
+}
+
+__global__ __launch_bounds__(SCAN1_THREADS) void scan_one_block_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                                       uint32_t n, const uint32_t* __restrict__ n_dev) {
+    __shared__ uint32_t s_wave[SCAN1_THREADS / 64];
+    if (n_dev) n = min(n, *n_dev);
+    (void)scan_window_1024(in, out, n, [](uint32_t) { return 0u; }, s_wave, nullptr);
+}
+
+static int scan_chain_of(mdx_handle* h, ScanChain* ch) {
+    if (!h->d.scan_chain) { HIP_TRY(hipMalloc((void**)&h->d.scan_chain, sizeof(unsigned long long) * 64)); HIP_TRY(hipMemsetAsync(h->d.scan_chain, 0, sizeof(unsigned long long) * 64, h->stream)); }
+    ch->carry = h->d.scan_chain; ch->gen = ++h->scan_gen;
+    return MDX_OK;
+}
+static int scan_u32_dev_n(mdx_handle* h, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums, const uint32_t* n_dev) {
     if (n == 0) return MDX_OK;
     uint32_t nb = div_up(n, SCAN_TILE);
-    if (nb > 1 && n <= 65536u) {
-        hipLaunchKernelGGL(scan_one_block_kernel, dim3(1), dim3(SCAN1_THREADS), 0, h->stream, in, out, n);
+    if (nb > 1 && n <= SCAN1_WINDOW) {
+        hipLaunchKernelGGL(scan_one_block_kernel, dim3(1), dim3(SCAN1_THREADS), 0, h->stream, in, out, n, n_dev);
         HIP_TRY(hipGetLastError());
         return MDX_OK;
     }
-    hipLaunchKernelGGL(scan_tile_kernel, dim3(nb), dim3(SCAN_THREADS), 0, h->stream, in, out, sums, n);
+    // up to eight windows: one launch of chained windows (a 200 k-atom rank's role offsets: three ~5 us launches -> one of ~8 us);
+    // beyond that the chain of hops costs what the three-launch form's bandwidth does
+    static const bool chain_ok = [] { const char* e = std::getenv("MDX_SCAN_CHAINED"); return !(e && e[0] == '0'); }();
+    if (chain_ok && n > SCAN1_WINDOW && n <= 8u * SCAN1_WINDOW) {
+        ScanChain ch; MDX_TRY(scan_chain_of(h, &ch));
+        hipLaunchKernelGGL(scan_chained_kernel, dim3(div_up(n, SCAN1_WINDOW)), dim3(SCAN1_THREADS), 0, h->stream, in, out, n, n_dev, ch);
+        HIP_TRY(hipGetLastError());
+        return MDX_OK;
+    }
+    hipLaunchKernelGGL(scan_tile_kernel, dim3(nb), dim3(SCAN_THREADS), 0, h->stream, in, out, sums, n, n_dev);
     if (nb > 1) {
         hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, h->stream, sums, nb);
-        hipLaunchKernelGGL(scan_add_kernel, dim3(div_up(n, 256)), dim3(256), 0, h->stream, out, sums, n);
+        hipLaunchKernelGGL(scan_add_kernel, dim3(div_up(n, 256)), dim3(256), 0, h->stream, out, sums, n, n_dev);
     }
     HIP_TRY(hipGetLastError());
     return MDX_OK;
+}
+int mdx_exclusive_scan_u32_ex(mdx_handle* h, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums) {
+    return scan_u32_dev_n(h, in, out, n, sums, nullptr);
 }
 
 // ================================================================================================
@@ -534,6 +602,9 @@ struct ListArgs {
     const float4* posq;              // slot-space coordinates, for the exact test of borderline cluster pairs
     // single pass: workgroups list_grid .. of the launch translate the bonded role lists into slot space (role_fill_body)
     uint32_t list_grid, rf_S;
+    // fused rebuild: the tile count is still on the device when this kernel is launched (for an upper bound of tiles):
+    // rb_ctl[0] = T; null_cluster and rf_S follow from it
+    const uint32_t* T_dev;
     const uint32_t* rf_role_off_o; const RoleRec* rf_rec_o; const uint32_t* rf_role_off_s; RoleRec* rf_rec_s;
     const uint8_t* rf_lflag;
 };
@@ -558,6 +629,10 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     __shared__ uint8_t s_mimask[SINGLE ? LB_WAVES : 1][SINGLE ? LB_MAXFLAG : 1];
     __shared__ uint32_t s_cand[LB_WAVES][LB_CAND];   // candidate j-tiles of the neighbourhood search: tile | image code << 27
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (SINGLE && a.T_dev) {                       // (fused rebuild: launched for an upper bound of tiles, the count read here)
+        const uint32_t T = __builtin_amdgcn_readfirstlane(*a.T_dev);
+        a.T = T; a.null_cluster = T * MDX_CL_PER_TILE; a.rf_S = (T + 1u) * MDX_TILE;
+    }
     if (SINGLE && blockIdx.x >= a.list_grid) {     // the role lists ride along: independent of the pair list, and this launch leaves CUs idle
         role_fill_body((blockIdx.x - a.list_grid) * (LB_WAVES * 64) + threadIdx.x, a.rf_S, a.orig_of, a.gid, a.rf_lflag, a.slot_of,
                        a.rf_role_off_o, a.rf_rec_o, a.rf_role_off_s, a.rf_rec_s, a.err);
@@ -912,12 +987,24 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
 #ifndef PRUNE_TRIES
 #define PRUNE_TRIES 1         // quick-accept tries per cluster pair (measured at 1 M atoms: 0 -> 283 us, 1 -> 278, 3 -> 291, 6 -> 314)
 #endif
+// rb_ctl (fused rebuild; may be null): [0] the tile count, still on the device when this launch (for an upper bound of tiles)
+// is enqueued, [1] the first ghost tile.  tile_int (may be null; half-shell decomposed handle: owned and ghost atoms sit in
+// separate column populations, so every tile from rb_ctl[1] on is all-ghost): 1 <=> the tile is owned and no entry that
+// SURVIVES this pass names a ghost cluster - everything its pair evaluation reads is owned by this rank, it may run before
+// the halo message has arrived.  (It was a pass of its own over the finished list, tile_class_kernel, + a scan + a host copy.)
 __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, float shx, float shy, float shz,
                                                          const float4* __restrict__ posq, ListCounts* __restrict__ counts,
                                                          const uint32_t* __restrict__ entry_off, uint2* __restrict__ entries,
-                                                         uint32_t null_cluster, unsigned long long* __restrict__ pair_count) {
+                                                         uint32_t null_cluster, unsigned long long* __restrict__ pair_count,
+                                                         const uint32_t* __restrict__ rb_ctl, uint32_t* __restrict__ tile_int) {
     __shared__ float4 s_j[4][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t first_ghost_cluster = 0xFFFFFFFFu;
+    if (rb_ctl) {
+        T = __builtin_amdgcn_readfirstlane(rb_ctl[0]); null_cluster = T * MDX_CL_PER_TILE;
+        first_ghost_cluster = __builtin_amdgcn_readfirstlane(rb_ctl[1]) * MDX_CL_PER_TILE;
+    }
+    bool ghost_hit = false;
     // one wave per tile (the plain run is compacted in place); a contiguous eighth of the tiles per XCD, as in the pair
     // kernel: the j-atoms a tile's list names are its spatial neighbours, and each XCD has its own L2
     const uint32_t per_xcd = gridDim.x >> 3;
@@ -990,6 +1077,7 @@ __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, f
             if ((lane >> 3) == e) newy = (y & 0xFFu) | ((im & 0xFFu) << 8);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+        ghost_hit |= ((newy >> 8) & 0xFFu) != 0u && ent.x >= first_ghost_cluster && ent.x < null_cluster;
         if (c < nmc) {
             // masked run: per-lane exclusion masks are addressed by chunk position, entries stay where they are
             if ((lane & 7) == 0 && newy != ent.y) entries[e0 + c * 8 + (lane >> 3)].y = newy;
@@ -1006,9 +1094,11 @@ __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, f
     }
     const uint32_t np_pad = (wcur + 7u) & ~7u;
     if (lane < (int)(np_pad - wcur)) entries[e0 + cnt.n_masked + wcur + lane] = make_uint2(null_cluster, 13u);
+    const bool any_ghost = __any(ghost_hit);
     if (lane == 0) {
         counts[t].n_plain = np_pad;
         if (kept) atomicAdd(pc_slot(pair_count, t, 1), (unsigned long long)kept);
+        if (tile_int) tile_int[t] = (!any_ghost && t * MDX_CL_PER_TILE < first_ghost_cluster) ? 1u : 0u;
     }
 }
 
@@ -1020,11 +1110,21 @@ template <int W>
 __global__ __launch_bounds__(W * 64) void prune_list_mw_kernel(uint32_t T, float r2, float shx, float shy, float shz,
                                                                const float4* __restrict__ posq, ListCounts* __restrict__ counts,
                                                                const uint32_t* __restrict__ entry_off, uint2* __restrict__ entries,
-                                                               uint32_t null_cluster, unsigned long long* __restrict__ pair_count) {
+                                                               uint32_t null_cluster, unsigned long long* __restrict__ pair_count,
+                                                               const uint32_t* __restrict__ rb_ctl, uint32_t* __restrict__ tile_int) {
     __shared__ float4 s_j[W][64];
+    __shared__ uint32_t s_ghost;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t first_ghost_cluster = 0xFFFFFFFFu;
+    if (rb_ctl) {      // (see prune_list_kernel)
+        T = __builtin_amdgcn_readfirstlane(rb_ctl[0]); null_cluster = T * MDX_CL_PER_TILE;
+        first_ghost_cluster = __builtin_amdgcn_readfirstlane(rb_ctl[1]) * MDX_CL_PER_TILE;
+    }
     const uint32_t t = blockIdx.x;
     if (t >= T) return;
+    if (threadIdx.x == 0) s_ghost = 0u;
+    if (tile_int) __syncthreads();
+    bool ghost_hit = false;
     const int ii = lane & 7, jj = lane >> 3;
     float xi[8], yi[8], zi[8];
 #pragma unroll
@@ -1077,11 +1177,14 @@ __global__ __launch_bounds__(W * 64) void prune_list_mw_kernel(uint32_t T, float
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
         if ((lane & 7) == 0 && newy != ent.y) entries[e0 + c * 8 + (lane >> 3)].y = newy;
+        ghost_hit |= ((newy >> 8) & 0xFFu) != 0u && ent.x >= first_ghost_cluster && ent.x < null_cluster;
     }
     if (lane == 0 && kept) atomicAdd(pc_slot(pair_count, t, 1), (unsigned long long)kept);
+    if (tile_int && __any(ghost_hit) && lane == 0) atomicOr(&s_ghost, 1u);
     __threadfence_block();
     __syncthreads();
     if (wave != 0) return;
+    if (tile_int && lane == 0) tile_int[t] = (s_ghost == 0u && t * MDX_CL_PER_TILE < first_ghost_cluster) ? 1u : 0u;
     // plain run: survivors move down (reads of a 64-entry step are complete - the ballot needs them - before its writes,
     // and the write cursor never passes the read position)
     uint32_t wcur = 0;
@@ -1209,6 +1312,7 @@ static int setup_grid(mdx_handle* h) {
     DeviceState& d = h->d;
     if (new_ncells > h->ncells || !d.cell_count) {
         ALLOC(d.cell_count, (size_t)new_ncells + 1);
+        h->cell_count_clean = false;
         ALLOC(d.cell_start, (size_t)new_ncells + 1);
         ALLOC(d.cell_cursor, (size_t)new_ncells + 1);
     }
@@ -1304,6 +1408,452 @@ __global__ void pair_sum_kernel(unsigned long long* __restrict__ pc) {      // o
 
 static float c_inner_skin(const mdx_config& c) { return c.inner_skin == 0.f ? 0.5f : c.inner_skin; }
 
+// ================================================================================================
+// Fused list rebuild (round 4).  The chain above is ~28 launches with three host synchronisation points (the tile count,
+// the list totals, the interior-tile count of a decomposed handle); at 1 M atoms its small kernels are a third of the
+// rebuild, and for one rank of an 8-GPU run - 200 k atoms - launch latency and host round trips are most of it (0.49 ms of
+// which the two list kernels are 0.1).  Here the tile count never leaves the device until the end:
+//   prep      (atom)   slot space -> caller order (positions, velocities), wrap, cell id, histogram - the atomicAdd's return
+//                      value is the atom's arrival rank in its cell, so the scatter below needs no cursor
+//   gridscan  (1 workgroup) exclusive scan of the cell histogram (which it leaves zeroed for the next rebuild), tiles per
+//                      column, their scan, tile -> column, T; clears the list cursors, the statistics and the error bits
+//   scatter, rank (atom)   cell members in arrival order, then in (z, atom id) order: deterministic
+//   assign    (wave = tile, launched for an upper bound of tiles) the 64 atoms of a tile, bitonic sub-sort, slot-space arrays,
+//                      cluster bounding boxes and the slots' bonded-role counts - assign + gather + bbox + role count in one
+//   role scan (1 or 3 launches, length read on the device)
+//   list      build_list_kernel<LB_SINGLE> as before, role fill in its extra workgroups; T read on the device
+//   prune     as before; on a half-shell decomposed handle it also says which tiles are interior
+//   finish    (1 workgroup) tiles by list length (inside the pair kernel's XCD ranges, or interior first), totals, and the
+//                      one read-back into pinned host memory the host spins on
+// = 9-11 launches, one host wait.  Anything unusual (first build, vacuum systems, overflow of the list arrays, more than a
+// million cells, MDX_REBUILD_FUSED=0) takes the chain above.
+// ================================================================================================
+constexpr uint32_t LPT_BUCKETS = 129;      // tiles by list length: a counting sort over the chunk count (lpt_order_kernel below)
+enum { RB_T = 0, RB_T_OWN = 1, RB_NONFINITE = 2, RB_N_INT = 3, RB_SCAN_N = 4, RB_WORDS = 8 };
+
+template <bool UNSORT>
+__global__ __launch_bounds__(256) void rb_prep_kernel(uint32_t N, GridParams g, const uint32_t* __restrict__ gid, const uint32_t* __restrict__ slot_of,
+                                                      const float4* __restrict__ posq, const float4* __restrict__ vel,
+                                                      float4* __restrict__ pos_orig, float4* __restrict__ vel_orig,
+                                                      const uint8_t* __restrict__ lflag, uint32_t* __restrict__ cell_of,
+                                                      uint32_t* __restrict__ cell_k, uint32_t* __restrict__ cell_count,
+                                                      uint32_t* __restrict__ rb_ctl) {
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= N) return;
+    float4 p;
+    if (UNSORT) { const uint32_t sl = slot_of[gid[o]]; p = posq[sl]; vel_orig[o] = vel[sl]; }
+    else p = pos_orig[o];
+    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {
+        rb_ctl[RB_NONFINITE] = 1u;
+        p.x = g.lo[0]; p.y = g.lo[1]; p.z = g.lo[2];
+    }
+    if (g.per[0]) p.x = wrap1(p.x, g.lo[0], g.len[0]);
+    if (g.per[1]) p.y = wrap1(p.y, g.lo[1], g.len[1]);
+    if (g.per[2]) p.z = wrap1(p.z, g.lo[2], g.len[2]);
+    pos_orig[o] = p;
+    const int cx = min(g.ncx - 1, max(0, (int)((p.x - g.lo[0]) * g.inv_col[0])));
+    const int cy = min(g.ncy - 1, max(0, (int)((p.y - g.lo[1]) * g.inv_col[1])));
+    const int zb = min(g.nzb - 1, max(0, (int)((p.z - g.lo[2]) * g.inv_zbin)));
+    const int pop = (g.npop > 1 && (lflag[o] & 1u)) ? 1 : 0;      // ghosts get column sets of their own
+    const uint32_t cell = (uint32_t)(((pop * g.ncx + cx) * g.ncy + cy) * g.nzb + zb);
+    cell_of[o] = cell;
+    cell_k[o] = atomicAdd(&cell_count[cell], 1u);
+}
+
+struct GridScanArgs {
+    uint32_t ncells, ncol, first_ghost_col; int nzb;
+    uint32_t* cell_count; uint32_t* cell_start; uint32_t* tile_start; uint32_t* tile_col;
+    uint32_t* rb_ctl; uint32_t* flags; unsigned long long* pair_count; uint32_t* list_cursors;
+    ScanChain chain;
+};
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t* s_wave, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN1_THREADS / 64; ++w) { const uint32_t x = s_wave[w]; if (w < wave) base += x; tot += x; }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+__global__ __launch_bounds__(SCAN1_THREADS) void rb_gridscan_kernel(GridScanArgs a) {
+    __shared__ uint32_t s_wave[SCAN1_THREADS / 64];
+    __shared__ uint32_t s_bcast;
+    // (the histogram has ncells + 1 words, the last one always zero: cell_start[ncells] is the atom count)
+    const uint32_t n = a.ncells + 1u, w = blockIdx.x, w0 = w * SCAN1_WINDOW, nwin = gridDim.x;
+    (void)scan_window_1024(a.cell_count + w0, a.cell_start + w0, min(SCAN1_WINDOW, n - w0),
+                           [&](uint32_t tot) { return chained_carry(a.chain, w, tot, &s_bcast); }, s_wave, a.cell_count + w0);
+    // every window's offsets must have landed before the columns are counted: the workgroups tick a generation-stamped word
+    // each (release), the last one waits for all of them (acquire) and does the rest alone
+    // (the hand-off forms of MI355X_MICROARCH.md, "inter-workgroup visibility": plain stores -> barrier -> one lane's agent
+    // release -> drained -> relaxed agent flag; the consumer polls relaxed, then ONE agent acquire, barrier, plain loads)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.chain.carry + 32 + w, (unsigned long long)a.chain.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (w + 1 != nwin) return;
+    if (threadIdx.x < nwin) {
+        while (__hip_atomic_load(a.chain.carry + 32 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)a.chain.gen) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    // tiles per column and their running sum
+    uint32_t run = 0;
+    for (uint32_t c0 = 0; c0 < a.ncol; c0 += SCAN1_THREADS) {
+        const uint32_t c = c0 + threadIdx.x;
+        uint32_t nt = 0, tot;
+        if (c < a.ncol)
+            nt = (a.cell_start[(size_t)(c + 1) * a.nzb] - a.cell_start[(size_t)c * a.nzb] + MDX_TILE - 1) / MDX_TILE;
+        const uint32_t ex = block_exclusive_scan_1024(nt, s_wave, &tot);
+        if (c < a.ncol) {
+            a.tile_start[c] = run + ex;
+            for (uint32_t t = 0; t < nt; ++t) a.tile_col[run + ex + t] = c;
+            if (c == a.first_ghost_col) a.rb_ctl[RB_T_OWN] = run + ex;
+        }
+        run += tot;
+    }
+    if (threadIdx.x == 0) {
+        a.tile_start[a.ncol] = run;
+        a.rb_ctl[RB_T] = run;
+        if (a.first_ghost_col >= a.ncol) a.rb_ctl[RB_T_OWN] = run;
+        a.rb_ctl[RB_SCAN_N] = (run + 1u) * MDX_TILE + 1u;
+    }
+    if (threadIdx.x < 4) a.flags[threadIdx.x] = 0u;
+    for (uint32_t i = threadIdx.x; i < PC_TOTAL + 2u; i += SCAN1_THREADS) a.pair_count[i] = 0ull;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)LB_REGIONS * 32u + 2u; i += SCAN1_THREADS) a.list_cursors[i] = 0u;
+}
+
+__global__ __launch_bounds__(256) void rb_scatter_kernel(uint32_t N, const uint32_t* __restrict__ cell_of, const uint32_t* __restrict__ cell_k,
+                                                         const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ sorted_tmp) {
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= N) return;
+    sorted_tmp[cell_start[cell_of[o]] + cell_k[o]] = o;
+}
+
+struct AssignArgs {
+    const uint32_t* rb_ctl; int nzb;
+    const uint32_t* tile_col; const uint32_t* tile_start; const uint32_t* cell_start; const uint32_t* sorted_orig;
+    const float4* pos_orig; const float4* vel_orig; const uint32_t* gid; const uint8_t* lflag;
+    const float* o_qs; const float2* o_lj; const float* o_invm;
+    uint32_t* orig_of; uint32_t* slot_of;
+    float4* posq; float2* lj; float4* vel; float4* ref; float4* force; uint8_t* slot_flags;
+    float4* cl_lo; float4* cl_hi;
+    const uint32_t* role_off_o; uint32_t* role_cnt_s;     // null without bonded roles
+};
+__global__ __launch_bounds__(256) void rb_assign_kernel(AssignArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t T = __builtin_amdgcn_readfirstlane(a.rb_ctl[RB_T]);
+    const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (t > T) return;
+    uint32_t o = MDX_INVALID;
+    float x = FLT_MAX, y = FLT_MAX, z = FLT_MAX;
+    if (t < T) {       // (tile T is the null tile: all dummies)
+        const uint32_t c = a.tile_col[t];
+        const uint32_t a0 = a.cell_start[(size_t)c * a.nzb] + (t - a.tile_start[c]) * MDX_TILE;
+        const uint32_t aend = a.cell_start[(size_t)(c + 1) * a.nzb];
+        const uint32_t p = a0 + lane;
+        if (p < aend) { o = a.sorted_orig[p]; const float4 q = a.pos_orig[o]; x = q.x; y = q.y; z = q.z; }
+        // halves by y, quarters by x, eighths (clusters) by z
+        bitonic_group<64>(y, x, z, o, lane);
+        bitonic_group<32>(x, y, z, o, lane);
+        bitonic_group<16>(z, x, y, o, lane);
+    }
+    const uint32_t s = t * MDX_TILE + lane;
+    a.orig_of[s] = o;
+    float4 p, v; float2 l;
+    uint8_t fl = 0;
+    uint32_t nrole = 0;
+    const bool valid = o != MDX_INVALID;
+    if (valid) {
+        const uint32_t g = a.gid[o];
+        a.slot_of[g] = s;
+        const uint8_t lf = a.lflag[o];
+        const bool ghost = (lf & 1u) != 0, silent = (lf & 2u) != 0;   // (bit 1: kept only as the bonded partner of an owned atom)
+        const float4 q = a.pos_orig[o], w = a.vel_orig[o];
+        p = make_float4(q.x, q.y, q.z, silent ? 0.f : a.o_qs[g]);
+        v = ghost ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(w.x, w.y, w.z, a.o_invm[g]);
+        l = silent ? make_float2(a.o_lj[g].x, 0.f) : a.o_lj[g];
+        fl = ghost ? 1 : 3;
+        if (a.role_off_o && !ghost) nrole = a.role_off_o[g + 1] - a.role_off_o[g];
+    } else {
+        // dummy: far away, every dummy at its own coordinate so no two coincide
+        const float d = MDX_DUMMY_BASE + MDX_DUMMY_STEP * (float)(s & 0xFFFFF);
+        p = make_float4(d, d + 17.0f * (float)(s >> 20), d, 0.f);
+        v = make_float4(0.f, 0.f, 0.f, 0.f);
+        l = make_float2(0.f, 0.f);
+    }
+    a.posq[s] = p; a.vel[s] = v; a.lj[s] = l; a.ref[s] = make_float4(p.x, p.y, p.z, 0.f);
+    a.force[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    a.slot_flags[s] = fl;
+    if (a.role_cnt_s) {
+        a.role_cnt_s[s] = nrole;
+        if (t == T && lane == 0) a.role_cnt_s[(T + 1u) * MDX_TILE] = 0u;     // the scan's trailing element
+    }
+    // cluster bounding boxes: eight consecutive lanes
+    float lo[3] = {valid ? p.x : 3.0e38f, valid ? p.y : 3.0e38f, valid ? p.z : 3.0e38f};
+    float hi[3] = {valid ? p.x : -3.0e38f, valid ? p.y : -3.0e38f, valid ? p.z : -3.0e38f};
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { lo[d] = fminf(lo[d], __shfl_xor(lo[d], m)); hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], m)); }
+    const unsigned long long bv = __ballot(valid), bo = __ballot((fl & 2u) != 0);
+    if ((lane & 7) == 0) {
+        const uint32_t c = t * MDX_CL_PER_TILE + (uint32_t)(lane >> 3);
+        a.cl_lo[c] = make_float4(lo[0], lo[1], lo[2], (float)__popcll((bv >> lane) & 0xFFull));
+        a.cl_hi[c] = make_float4(hi[0], hi[1], hi[2], (float)__popcll((bo >> lane) & 0xFFull));   // .w: atoms this rank owns (half list)
+    }
+}
+
+struct FinishArgs {
+    uint32_t* rb_ctl; const ListCounts* counts;
+    uint32_t* tile_lpt; uint32_t lpt_grouped; WptRule rule;      // tile_lpt: tiles by list length (grouped: inside each XCD range of the pair kernel)
+    const uint32_t* tile_int; uint32_t* tile_order;              // tile_order: interior tiles first, either part by length
+    const unsigned long long* cursors; unsigned long long* pair_count; const uint32_t* flags;
+    volatile uint32_t* host; uint32_t seq;
+};
+__global__ __launch_bounds__(1024) void rb_finish_kernel(FinishArgs a) {
+    constexpr uint32_t NB = 8 * LPT_BUCKETS;
+    __shared__ uint32_t s_hist[NB], s_cur[NB], s_scan[16];
+    __shared__ uint32_t s_nint;
+    const uint32_t T = a.rb_ctl[RB_T];
+    if (threadIdx.x == 0) s_nint = 0u;
+    for (int pass = 0; pass < 2; ++pass) {
+        uint32_t* const order = pass == 0 ? a.tile_lpt : a.tile_order;
+        if (!order) continue;           // (uniform)
+        uint32_t group_tiles = 0;
+        if (pass == 0 && a.lpt_grouped) {      // the pair kernel's XCD ranges: ceil(workgroups / 8) workgroups of TPB tiles each (mdx_nonbonded.hip)
+            const uint32_t wpt = (uint32_t)mdx_wpt_rule(a.rule, T), tpb = max(wpt, (uint32_t)MDX_NB_WAVES) / wpt;
+            group_tiles = (((T + tpb - 1u) / tpb + 7u) >> 3) * tpb;
+        }
+        for (uint32_t b = threadIdx.x; b < NB; b += blockDim.x) s_hist[b] = 0;
+        __syncthreads();
+        auto bucket = [&](uint32_t t) {
+            const uint32_t nch = (a.counts[t].n_masked + a.counts[t].n_plain) >> 3;
+            const uint32_t major = pass == 0 ? (group_tiles ? min(t / group_tiles, 7u) : 0u) : (a.tile_int[t] ? 0u : 1u);
+            return major * LPT_BUCKETS + LPT_BUCKETS - 1u - min(nch, LPT_BUCKETS - 1u);   // bucket 0 = the longest lists
+        };
+        for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) atomicAdd(&s_hist[bucket(t)], 1u);
+        __syncthreads();
+        {   // exclusive prefix over the NB = 1032 buckets, two per thread (one thread walking them took ~20 us of LDS round trips)
+            const uint32_t b0 = 2u * threadIdx.x, h0 = b0 < NB ? s_hist[b0] : 0u, h1 = b0 + 1u < NB ? s_hist[b0 + 1u] : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_exclusive_scan_1024(h0 + h1, s_scan, &tot);
+            if (b0 < NB) s_cur[b0] = ex;
+            if (b0 + 1u < NB) s_cur[b0 + 1u] = ex + h0;
+            __syncthreads();
+            if (pass == 1 && threadIdx.x == 0) s_nint = s_cur[LPT_BUCKETS];      // interior tiles = everything in front of major 1
+        }
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) order[atomicAdd(&s_cur[bucket(t)], 1u)] = t;
+        __syncthreads();
+    }
+    if (threadIdx.x < 64) {      // one wave: totals of the region cursors and of the spread statistics, then the read-back
+        const unsigned long long c = a.cursors[(size_t)threadIdx.x * 16];
+        uint32_t e = (uint32_t)c, m = (uint32_t)(c >> 32);
+        unsigned long long pa = a.pair_count[(size_t)threadIdx.x * PC_STRIDE], pb = a.pair_count[(size_t)threadIdx.x * PC_STRIDE + 1];
+#pragma unroll
+        for (int k = 32; k > 0; k >>= 1) { e += __shfl_xor(e, k); m += __shfl_xor(m, k); pa += __shfl_xor(pa, k); pb += __shfl_xor(pb, k); }
+        if (threadIdx.x == 0) {
+            a.pair_count[PC_TOTAL] = pa; a.pair_count[PC_TOTAL + 1] = pb;
+            a.rb_ctl[RB_N_INT] = s_nint;
+            a.host[0] = T; a.host[1] = a.rb_ctl[RB_T_OWN]; a.host[2] = a.rb_ctl[RB_NONFINITE]; a.host[3] = s_nint;
+            for (int k = 0; k < 4; ++k) a.host[4 + k] = a.flags[k];
+            a.host[8] = e; a.host[9] = m;
+            a.host[10] = (uint32_t)pa; a.host[11] = (uint32_t)(pa >> 32); a.host[12] = (uint32_t)pb; a.host[13] = (uint32_t)(pb >> 32);
+            a.rb_ctl[RB_NONFINITE] = 0u;
+            __threadfence_system();
+            a.host[31] = a.seq;      // the host spins on this word
+        }
+    }
+}
+
+
+static int spin_on_readback(mdx_handle* h, uint32_t seq) {
+    static const bool spin_ok = [] { const char* e = std::getenv("MDX_CHUNK_SPIN"); return !(e && e[0] == '0'); }();
+    if (!spin_ok || h->profile) { HIP_TRY(hipStreamSynchronize(h->stream)); return MDX_OK; }
+    volatile uint32_t* seq_word = (volatile uint32_t*)h->h_rb + 31;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0; *seq_word != seq; ++spins) {
+        if ((spins & 0xFFFu) == 0xFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
+            HIP_TRY(hipStreamSynchronize(h->stream));       // (an error on the stream, or a very long queue: wait the ordinary way)
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return MDX_OK;
+}
+
+struct RebuildResult { uint32_t T = 0, E = 0, MC = 0, n_interior = 0; unsigned long long npairs = 0; bool ordered = false, classified = false; };
+
+// which tile orders the rebuild produces (shared by both chains)
+struct TileOrderPlan { bool lpt, grouped, split; };
+static TileOrderPlan tile_order_plan(const mdx_handle* h, uint32_t T) {
+    // longest lists first where a launch is only a few rounds of waves (MDX_TILE_LPT=0 / 1 forces it off / on for A/B)
+    static const int lpt_env = [] { const char* e = std::getenv("MDX_TILE_LPT"); return e ? (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)) : -1; }();
+    // default: every decomposed handle (owned bricks and halo shells: its lists differ by an order of magnitude), and
+    // single-device systems below the size at which a contiguous eighth of the tiles per XCD starts to matter
+    // (later in round 3: single-device systems of every size from 512 tiles on, ordered by length inside each XCD's contiguous
+    // range - water1M 1832 -> 1853 steps/s, against 1843-1849 with the round-robin order; MDX_TILE_LPT=1 / 2 force either)
+    const bool decomposed = h->dd || h->n_local != h->N;
+    TileOrderPlan p;
+    p.lpt = (lpt_env >= 0 ? lpt_env >= 1 : (decomposed || T >= 512u)) && mdx_nb_variant(h) >= 2;
+    p.grouped = lpt_env >= 0 ? lpt_env == 2 : !decomposed;
+    p.split = h->want_tile_split && mdx_nb_variant(h) >= 2;
+    return p;
+}
+
+// *fell_back = true: nothing was decided here (the list outgrew its arrays, or a tile its LDS buffers): the caller runs the
+// unfused chain, which sizes the arrays afresh.  The slot-space state is complete either way.
+static int rebuild_fast(mdx_handle* h, RebuildResult* res, bool* fell_back) {
+    DeviceState& d = h->d;
+    hipStream_t st = h->stream;
+    const uint32_t N = h->n_local;
+    const GridParams g = h->grid;
+    *fell_back = false;
+    if (!d.rb_ctl) { ALLOC(d.rb_ctl, RB_WORDS); HIP_TRY(hipMemsetAsync(d.rb_ctl, 0, sizeof(uint32_t) * RB_WORDS, st)); }
+    if (!d.pair_count) ALLOC(d.pair_count, PC_TOTAL + 2);
+    if (!d.list_cursors) ALLOC(d.list_cursors, LB_REGIONS * 32 + 2);
+    if (!h->h_rb) { HIP_TRY(hipHostMalloc((void**)&h->h_rb, sizeof(uint32_t) * 32, hipHostMallocDefault)); h->h_rb[31] = 0u; }
+    if (!h->cell_count_clean) { HIP_TRY(hipMemsetAsync(d.cell_count, 0, sizeof(uint32_t) * ((size_t)h->ncells + 1), st)); h->cell_count_clean = true; }
+    if (!h->slot_of_clean) { HIP_TRY(hipMemsetAsync(d.slot_of, 0xFF, sizeof(uint32_t) * (size_t)h->N, st)); h->slot_of_clean = true; }
+    const uint32_t T_bound = N / MDX_TILE + h->ncol + 1;        // sum over columns of ceil(n / 64) <= N / 64 + ncol
+    if (T_bound + 1 > h->cap_tiles) { mdx_set_error("internal: tile capacity exceeded"); return MDX_EDEVICE; }
+    const TileOrderPlan plan = tile_order_plan(h, T_bound);
+    const bool prune = !std::isinf(h->r_list) && mdx_nb_variant(h) >= 2;
+    static const bool exact_prune = [] { const char* e = std::getenv("MDX_EXACT_PRUNE"); return !(e && e[0] == '0'); }();
+    // interior / boundary tiles come out of the pruning pass when owned and ghost atoms sit in separate column populations
+    const bool classify_here = plan.split && plan.lpt && g.npop > 1 && prune && exact_prune;
+    if (plan.lpt && (!d.tile_lpt || d.cap_tile_lpt < T_bound)) { d.cap_tile_lpt = h->cap_tiles + 1; ALLOC(d.tile_lpt, d.cap_tile_lpt); }
+    if (classify_here && (!d.tile_bnd || h->cap_tile_split < T_bound + 1)) {
+        h->cap_tile_split = h->cap_tiles + 1;
+        ALLOC(d.tile_bnd, h->cap_tile_split); ALLOC(d.tile_scan, h->cap_tile_split); ALLOC(d.tile_order, h->cap_tile_split);
+    }
+
+    // ---- prep: caller-order positions (wrapped) and velocities, cells ----
+    if (h->in_slot_space)
+        hipLaunchKernelGGL(rb_prep_kernel<true>, dim3(div_up(N, 256)), dim3(256), 0, st, N, g, d.gid, d.slot_of, d.posq, d.vel, d.pos_orig,
+                           d.vel_orig, d.lflag, d.cell_of, d.sorted_orig, d.cell_count, d.rb_ctl);
+    else
+        hipLaunchKernelGGL(rb_prep_kernel<false>, dim3(div_up(N, 256)), dim3(256), 0, st, N, g, d.gid, d.slot_of, d.posq, d.vel, d.pos_orig,
+                           d.vel_orig, d.lflag, d.cell_of, d.sorted_orig, d.cell_count, d.rb_ctl);
+    h->in_slot_space = false;
+    {
+        GridScanArgs ga{};
+        ga.ncells = h->ncells; ga.ncol = h->ncol; ga.nzb = g.nzb;
+        ga.first_ghost_col = g.npop > 1 ? (uint32_t)(g.ncx * g.ncy) : 0xFFFFFFFFu;
+        ga.cell_count = d.cell_count; ga.cell_start = d.cell_start; ga.tile_start = d.tile_start; ga.tile_col = d.tile_col;
+        ga.rb_ctl = d.rb_ctl; ga.flags = d.flags_dev; ga.pair_count = d.pair_count; ga.list_cursors = d.list_cursors;
+        MDX_TRY(scan_chain_of(h, &ga.chain));
+        hipLaunchKernelGGL(rb_gridscan_kernel, dim3(div_up(h->ncells + 1, SCAN1_WINDOW)), dim3(SCAN1_THREADS), 0, st, ga);
+    }
+    hipLaunchKernelGGL(rb_scatter_kernel, dim3(div_up(N, 256)), dim3(256), 0, st, N, d.cell_of, d.sorted_orig, d.cell_start, d.sorted_tmp);
+    hipLaunchKernelGGL(cell_rank_kernel, dim3(div_up(N, 256)), dim3(256), 0, st, N, d.cell_of, d.cell_start, d.pos_orig, d.sorted_tmp, d.sorted_orig);
+    {
+        AssignArgs aa{};
+        aa.rb_ctl = d.rb_ctl; aa.nzb = g.nzb; aa.tile_col = d.tile_col; aa.tile_start = d.tile_start; aa.cell_start = d.cell_start;
+        aa.sorted_orig = d.sorted_orig; aa.pos_orig = d.pos_orig; aa.vel_orig = d.vel_orig; aa.gid = d.gid; aa.lflag = d.lflag;
+        aa.o_qs = d.o_qs; aa.o_lj = d.o_lj; aa.o_invm = d.o_invm; aa.orig_of = d.orig_of; aa.slot_of = d.slot_of;
+        aa.posq = d.posq; aa.lj = d.lj; aa.vel = d.vel; aa.ref = d.ref; aa.force = d.force; aa.slot_flags = d.slot_flags;
+        aa.cl_lo = d.cl_lo; aa.cl_hi = d.cl_hi;
+        aa.role_off_o = h->n_roles ? d.role_off_o : nullptr; aa.role_cnt_s = h->n_roles ? d.role_cnt_s : nullptr;
+        hipLaunchKernelGGL(rb_assign_kernel, dim3(div_up(T_bound + 1, 4)), dim3(256), 0, st, aa);
+    }
+    h->in_slot_space = true;
+    const uint32_t S_bound = (T_bound + 1) * MDX_TILE;
+    if (h->n_roles) MDX_TRY(scan_u32_dev_n(h, d.role_cnt_s, d.role_off_s, S_bound + 1, d.scan_tmp, d.rb_ctl + RB_SCAN_N));
+
+    // ---- pair list: single pass, then the exact pruning ----
+    ListArgs a{};
+    a.T = T_bound; a.T_dev = d.rb_ctl + RB_T; a.g = g;
+    a.r_build = std::isinf(h->r_list) ? h->r_list : h->r_list * (1.0f + 1e-5f) + 1e-4f;
+    a.tile_col = d.tile_col; a.tile_start = d.tile_start; a.cl_lo = d.cl_lo; a.cl_hi = d.cl_hi;
+    a.orig_of = d.orig_of; a.slot_of = d.slot_of; a.gid = d.gid; a.slot_flags = d.slot_flags;
+    a.excl_off = d.excl_off; a.excl_idx = d.excl_idx;
+    a.counts = d.list_counts; a.entry_cnt = d.entry_cnt; a.mchunk_cnt = d.mchunk_cnt;
+    a.entry_off = d.entry_off; a.mchunk_off = d.mchunk_off; a.entries = d.entries; a.masks = d.masks;
+    a.err = d.flags_dev; a.null_cluster = T_bound * MDX_CL_PER_TILE;
+    a.mask_layout = mdx_nb_variant(h) >= 2 ? 2 : 1;
+    a.half = mdx_nb_half(h) ? 1 : 0;
+    a.cell_start = d.cell_start; a.posq = d.posq; a.pair_count = d.pair_count;
+    a.cursors = reinterpret_cast<unsigned long long*>(d.list_cursors);
+    a.n_regions = 1;
+    while (a.n_regions < (uint32_t)LB_REGIONS && a.n_regions * 128u <= T_bound) a.n_regions <<= 1;      // >= 64 tiles per region
+    a.region_cap_e = (uint32_t)(std::min<uint64_t>(h->cap_entries, 0xFFFFFFFFull) / a.n_regions) & ~7u;
+    a.region_cap_m = h->cap_mchunks / a.n_regions;
+    a.list_grid = (div_up(T_bound, LB_WAVES) + 7u) & ~7u;
+    uint32_t rf_blocks = 0;
+    if (h->n_roles) {
+        a.rf_S = S_bound; a.rf_role_off_o = d.role_off_o; a.rf_rec_o = d.role_rec_o; a.rf_role_off_s = d.role_off_s;
+        a.rf_rec_s = d.role_rec_s; a.rf_lflag = d.lflag;
+        rf_blocks = div_up(S_bound, LB_WAVES * 64);
+    }
+    if (g.npop > 1) hipLaunchKernelGGL((build_list_kernel<LB_SINGLE, LB_PLAIN_DD>), dim3(a.list_grid + rf_blocks), dim3(LB_WAVES * 64), 0, st, a);
+    else hipLaunchKernelGGL(build_list_kernel<LB_SINGLE>, dim3(a.list_grid + rf_blocks), dim3(LB_WAVES * 64), 0, st, a);
+    if (prune && exact_prune) {
+        const float rb = a.r_build;
+        const float shx = h->per[0] ? h->box_hi[0] - h->box_lo[0] : 0.f, shy = h->per[1] ? h->box_hi[1] - h->box_lo[1] : 0.f,
+                    shz = h->per[2] ? h->box_hi[2] - h->box_lo[2] : 0.f;
+        uint32_t* const tint = classify_here ? d.tile_bnd : nullptr;
+        // One wave per tile is a launch as long as its longest list: one rank of 8 of the 1 M-atom box - 3.3 k tiles, the owned ones
+        // with ~150 chunks - took 233 us where the whole box, five times the work, takes 256.  Eight waves per tile up to
+        // MDX_PRUNE_MW_BELOW tiles (the unfused chain keeps its 2048)
+        static const uint32_t mw_below = [] { const char* e = std::getenv("MDX_PRUNE_MW_BELOW"); return e ? (uint32_t)std::atoi(e) : 12000u; }();
+        if (T_bound < mw_below)
+            hipLaunchKernelGGL(prune_list_mw_kernel<8>, dim3(T_bound), dim3(512), 0, st, T_bound, rb * rb, shx, shy, shz, d.posq, d.list_counts,
+                               d.entry_off, d.entries, a.null_cluster, d.pair_count, (const uint32_t*)d.rb_ctl, tint);
+        else
+            hipLaunchKernelGGL(prune_list_kernel, dim3((div_up(T_bound, 4) + 7u) & ~7u), dim3(256), 0, st, T_bound, rb * rb, shx, shy, shz,
+                               d.posq, d.list_counts, d.entry_off, d.entries, a.null_cluster, d.pair_count, (const uint32_t*)d.rb_ctl, tint);
+    }
+    MDX_TRY(mdx_remap_constraints(h));
+    // ---- finish: tile orders, totals, the one read-back ----
+    const uint32_t seq = ++h->rb_seq;
+    {
+        FinishArgs fa{};
+        fa.rb_ctl = d.rb_ctl; fa.counts = d.list_counts;
+        fa.tile_lpt = plan.lpt ? d.tile_lpt : nullptr; fa.lpt_grouped = plan.grouped ? 1u : 0u; fa.rule = mdx_wpt_rule_of(h);
+        fa.tile_int = classify_here ? d.tile_bnd : nullptr; fa.tile_order = classify_here ? d.tile_order : nullptr;
+        fa.cursors = reinterpret_cast<const unsigned long long*>(d.list_cursors); fa.pair_count = d.pair_count; fa.flags = d.flags_dev;
+        fa.host = (volatile uint32_t*)h->h_rb; fa.seq = seq;
+        hipLaunchKernelGGL(rb_finish_kernel, dim3(1), dim3(1024), 0, st, fa);
+    }
+    HIP_TRY(hipGetLastError());
+    MDX_TRY(spin_on_readback(h, seq));
+    const uint32_t T = h->h_rb[0];
+    uint32_t flags[4];
+    for (int k = 0; k < 4; ++k) flags[k] = h->h_rb[4 + k];
+    if (h->h_rb[2]) { h->cell_count_clean = false; mdx_set_error("non-finite position at neighbour rebuild"); return MDX_ENAN; }
+    if (T > T_bound) { mdx_set_error("internal: tile count beyond its bound"); return MDX_EDEVICE; }
+    h->T = T; h->S = (T + 1) * MDX_TILE;
+    if (flags[0] & 1u) { mdx_set_error("exclusion table overflow while building the pair list"); return MDX_EPARAM; }
+    if (flags[0] & (16u | 32u)) {      // a tile beyond the LDS buffers, or a list that outgrew the arrays: the unfused chain sizes them afresh
+        if (std::getenv("MDX_LIST_DEBUG")) fprintf(stderr, "[mdx] fused list rebuild fell back: flags %u, T %u, cap_e %llu cap_m %u regions %u\n",
+                                                   flags[0], T, (unsigned long long)h->cap_entries, h->cap_mchunks, a.n_regions);
+        *fell_back = true;
+        return MDX_OK;
+    }
+    if (flags[0] & 8u) { mdx_set_error("a constrained / virtual-site atom is missing from the local atom set"); return MDX_EPARAM; }
+    if (flags[0] & 2u) { mdx_set_error("exclusion table overflow while building the pair list"); return MDX_EPARAM; }
+    if (flags[0] & 4u) { mdx_set_error("a bonded partner of an owned atom is missing from the local atom set (halo too thin)"); return MDX_EPARAM; }
+    res->T = T; res->E = h->h_rb[8]; res->MC = h->h_rb[9];
+    const unsigned long long built = (unsigned long long)h->h_rb[10] | ((unsigned long long)h->h_rb[11] << 32);
+    const unsigned long long kept = (unsigned long long)h->h_rb[12] | ((unsigned long long)h->h_rb[13] << 32);
+    res->npairs = (prune && exact_prune) ? kept : built;
+    h->E = res->E; h->MC = res->MC;
+    res->ordered = true;
+    h->tile_lpt_on = plan.lpt; h->tile_lpt_grouped = plan.grouped;
+    h->tile_split = false; h->n_interior = 0;
+    if (classify_here) { h->tile_split = true; h->n_interior = h->h_rb[3]; res->classified = true; }
+    return MDX_OK;
+}
+
+
 int mdx_rebuild(mdx_handle* h) {
     MdxRange range_rebuild("mdx list rebuild");
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1311,13 +1861,31 @@ int mdx_rebuild(mdx_handle* h) {
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, h->stream));
     }
-    MDX_TRY(mdx_unsort_state(h));  // dynamic state -> caller-order staging
-    MDX_TRY(setup_grid(h));
     DeviceState& d = h->d;
+    // Every rebuild but a handle's first (and a few unusual ones) takes the fused chain above: MDX_REBUILD_FUSED=0 for A/B.
+    static const bool fused_env = [] { const char* e = std::getenv("MDX_REBUILD_FUSED"); return !(e && e[0] == '0'); }();
+    static const bool two_pass_env0 = [] { const char* e = std::getenv("MDX_LIST_TWO_PASS"); return e && e[0] == '1'; }();
+    bool fast = fused_env && !two_pass_env0 && d.entries && d.masks && h->cap_entries && h->cap_mchunks && h->T > 0 && h->n_local > 0;
+    for (int k = 0; k < 3; ++k) if (!h->per[k] && !h->have_local_bounds) fast = false;      // (a vacuum system: the grid follows the atoms' bounding box)
+    if (!fast) MDX_TRY(mdx_unsort_state(h));  // dynamic state -> caller-order staging
+    MDX_TRY(setup_grid(h));
+    if (fast && (size_t)h->ncells + 1 > ((size_t)1 << 21)) { fast = false; MDX_TRY(mdx_unsort_state(h)); }   // (the grid scan is a chain of at most 32 windows)
     const uint32_t N = h->n_local;   // atoms simulated here (all of them on a single GPU)
     const GridParams g = h->grid;
     hipStream_t st = h->stream;
-
+    RebuildResult res;
+    bool fast_done = false;
+    if (fast) {
+        bool fell_back = false;
+        MDX_TRY(rebuild_fast(h, &res, &fell_back));
+        fast_done = !fell_back;
+        if (fell_back) MDX_TRY(mdx_unsort_state(h));
+    }
+    uint32_t E = res.E, MC = res.MC;
+    unsigned long long npairs = res.npairs;
+    const bool prune = !std::isinf(h->r_list) && mdx_nb_variant(h) >= 2;   // the whole-tile kernel ignores imask
+    if (!fast_done) {
+    h->cell_count_clean = false;     // (this chain leaves the histogram behind)
     {   // slot_of = invalid, cell counters and cursors = 0, error bits = 0: one launch instead of four fills
         const uint32_t n_max = std::max<uint32_t>(h->N, h->ncells + 1);
         hipLaunchKernelGGL(rebuild_clear_kernel, dim3(div_up(n_max, 256)), dim3(256), 0, st, d.slot_of, h->N, d.cell_count,
@@ -1333,6 +1901,7 @@ int mdx_rebuild(mdx_handle* h) {
                        d.cell_cursor, d.sorted_tmp, N);
     hipLaunchKernelGGL(cell_rank_kernel, dim3(div_up(N, 256)), dim3(256), 0, st, N, d.cell_of, d.cell_start,
                        d.pos_orig, d.sorted_tmp, d.sorted_orig);
+    h->slot_of_clean = true;
     uint32_t T = 0, flags[4] = {0, 0, 0, 0};
     MDX_TRY(readback(h, RbSrc{{d.tile_start + h->ncol, d.flags_dev, nullptr, nullptr}, {1, 4, 0, 0}}));
     T = h->h_rb[0];
@@ -1370,8 +1939,7 @@ int mdx_rebuild(mdx_handle* h) {
     a.posq = d.posq;
     if (!d.pair_count) ALLOC(d.pair_count, PC_TOTAL + 2);
     a.pair_count = d.pair_count;
-    uint32_t E = 0, MC = 0;
-    unsigned long long npairs = 0;
+    E = 0; MC = 0; npairs = 0;
     // Single pass when the arrays of the previous build are there to be reused (every rebuild but the first): one
     // search of every tile's neighbourhood instead of count + scan + fill.  MDX_LIST_TWO_PASS=1 keeps the two passes.
     static const bool two_pass_env = [] { const char* e = std::getenv("MDX_LIST_TWO_PASS"); return e && e[0] == '1'; }();
@@ -1437,7 +2005,6 @@ int mdx_rebuild(mdx_handle* h) {
         return MDX_OK;
     };
     if (!speculative) MDX_TRY(two_pass());
-    const bool prune = !std::isinf(h->r_list) && mdx_nb_variant(h) >= 2;   // the whole-tile kernel ignores imask
     static const bool exact_prune = [] { const char* e = std::getenv("MDX_EXACT_PRUNE"); return !(e && e[0] == '0'); }();   // A/B knob
     auto launch_prune = [&]() {
         if (!(prune && T && exact_prune)) return;
@@ -1446,10 +2013,10 @@ int mdx_rebuild(mdx_handle* h) {
                     shz = h->per[2] ? h->box_hi[2] - h->box_lo[2] : 0.f;
         if (T < 2048u)          // a few hundred tiles: eight waves per tile (one wave per tile is a 1/3-empty chip waiting for its longest list)
             hipLaunchKernelGGL(prune_list_mw_kernel<8>, dim3(T), dim3(512), 0, st, T, rb * rb, shx, shy, shz, d.posq, d.list_counts,
-                               d.entry_off, d.entries, a.null_cluster, d.pair_count);
+                               d.entry_off, d.entries, a.null_cluster, d.pair_count, (const uint32_t*)nullptr, (uint32_t*)nullptr);
         else
             hipLaunchKernelGGL(prune_list_kernel, dim3((div_up(T, 4) + 7u) & ~7u), dim3(256), 0, st, T, rb * rb, shx, shy, shz,
-                               d.posq, d.list_counts, d.entry_off, d.entries, a.null_cluster, d.pair_count);
+                               d.posq, d.list_counts, d.entry_off, d.entries, a.null_cluster, d.pair_count, (const uint32_t*)nullptr, (uint32_t*)nullptr);
     };
     launch_prune();
 
@@ -1506,20 +2073,19 @@ int mdx_rebuild(mdx_handle* h) {
         return MDX_EPARAM;
     }
 
-    h->tile_split = false; h->n_interior = 0;
+    res.T = T;
+    }   // (the unfused chain)
+    const uint32_t T = h->T, S = h->S, NC = (T + 1) * MDX_CL_PER_TILE;
     {
-        // longest lists first where a launch is only a few rounds of waves (MDX_TILE_LPT=0 / 1 forces it off / on for A/B)
-        static const int lpt_env = [] { const char* e = std::getenv("MDX_TILE_LPT"); return e ? (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)) : -1; }();
-        // default: every decomposed handle (owned bricks and halo shells: its lists differ by an order of magnitude), and
-        // single-device systems below the size at which a contiguous eighth of the tiles per XCD starts to matter
-        // (later in round 3: single-device systems of every size from 512 tiles on, ordered by length inside each XCD's contiguous
-        // range - water1M 1832 -> 1853 steps/s, against 1843-1849 with the round-robin order; MDX_TILE_LPT=1 / 2 force either)
-        const bool decomposed = h->dd || h->n_local != h->N;
-        const bool want = lpt_env >= 0 ? lpt_env >= 1 : (decomposed || T >= 512u);
-        const bool grouped = lpt_env >= 0 ? lpt_env == 2 : !decomposed;
-        h->tile_lpt_on = false;
-        if (h->want_tile_split && mdx_nb_variant(h) >= 2) MDX_TRY(mdx_classify_tiles(h, want));
-        if (want && mdx_nb_variant(h) >= 2) MDX_TRY(mdx_order_tiles_by_length(h, grouped));
+        const TileOrderPlan plan = tile_order_plan(h, T);
+        if (!res.classified) {
+            h->tile_split = false; h->n_interior = 0;
+            if (plan.split) MDX_TRY(mdx_classify_tiles(h, plan.lpt));
+        }
+        if (!res.ordered) {
+            h->tile_lpt_on = false;
+            if (plan.lpt) MDX_TRY(mdx_order_tiles_by_length(h, plan.grouped));
+        }
     }
     h->list_valid = true;
     h->forces_valid = false;
@@ -1552,7 +2118,6 @@ int mdx_rebuild(mdx_handle* h) {
 // interior) and the short ones (halo shells, faces of a non-periodic system) come in runs, and the launch ends when the
 // last long list does.  Longest first is the classic list-scheduling order: the short lists fill the tail.  A counting
 // sort over the chunk count (129 buckets), one small launch per rebuild.
-constexpr uint32_t LPT_BUCKETS = 129;
 // One workgroup, LDS histogram and cursors (atomics on a hundred global words would queue: a returning atomic on one address is
 // served every ~35 ns, tools/ubench/grid_barrier.hip - 70 us for the fullest bucket of a 9 k-tile launch).
 // is_int (may be null): the interior / boundary split of a decomposed handle - interior tiles first, each part by length.

@@ -192,6 +192,11 @@ struct DeviceState {
     uint32_t* tile_lpt = nullptr;  // [T] tiles by decreasing list length (mid-size launches: longest lists first)
     uint32_t cap_tile_lpt = 0;
     float4*  scratch4 = nullptr;   // [cap_scratch4] caller-order scratch (force read-back)
+    // fused list rebuild (mdx_grid.hip, rebuild_fast): the tile count and friends stay on the device until the ONE read-back at
+    // the end of the chain.  [0] T, [1] first ghost tile (= T without separate ghost columns), [2] non-finite coordinate seen,
+    // [3] interior tiles, [4] S + 1 = (T + 1) * 64 + 1 (length of the role-count scan)
+    uint32_t* rb_ctl = nullptr;
+    unsigned long long* scan_chain = nullptr;   // [64] chained-window scans: (generation << 32) | running total per window, then the windows' done ticks
 };
 
 struct MdxDecomp;   // mdx_comm.h: the handle is one rank of a spatially decomposed box
@@ -272,7 +277,7 @@ struct mdx_handle {
     uint64_t step_count = 0, rebuild_count = 0;
     // profiling
     bool profile = false; int profile_level = 0; bool prof_open = false;
-    struct EvPair { hipEvent_t a, b; int kind; int tag; };
+    struct EvPair { hipEvent_t a, b; int kind; int tag; hipStream_t st; };
     int prof_tag = -1;       // chunk step of the launches being enqueued (-1: ungated)
     std::vector<EvPair> ev_pending;
     std::vector<hipEvent_t> ev_pool;
@@ -302,6 +307,9 @@ struct mdx_handle {
     uint32_t ctl_seq = 0;
     uint32_t* h_rb = nullptr;  // pinned, device-visible: the list rebuild's counters land here straight from a kernel
     uint32_t rb_seq = 0;        // sequence number of the last read-back (word 31 of h_rb: the host spins on it)
+    uint32_t scan_gen = 0;           // generation stamp of the chained scans (no reset between launches)
+    bool cell_count_clean = false;   // fused rebuild: d.cell_count is all zero (the grid-scan kernel zeroes what it has consumed)
+    bool slot_of_clean = false;      // ... and d.slot_of holds no slot of an atom that has left the local set
 };
 
 // ---- error plumbing ------------------------------------------------------------------------------
@@ -372,20 +380,27 @@ static inline uint32_t mdx_wpt8_below(const mdx_handle* h) {
 #ifndef MDX_NB_WAVES
 #define MDX_NB_WAVES 1
 #endif
-// waves per tile of the half-list pair kernel for a list of T tiles (MDX_WPT: A/B knob)
-static inline int mdx_nb_wpt_half(const mdx_handle* h, uint32_t T) {
-    static const int env = [] { const char* e = std::getenv("MDX_WPT"); return (e && (e[0] == '1' || e[0] == '2' || e[0] == '4' || e[0] == '8')) ? e[0] - '0' : 0; }();
-    if (env) return env;
+// waves per tile of the half-list pair kernel for a list of T tiles (MDX_WPT: A/B knob).  The rule is evaluated on the host
+// (launch geometry) AND on the device (the fused list rebuild orders the tiles by length inside the pair kernel's XCD ranges
+// before the host knows T), so it is one __host__ __device__ function of a small parameter block.
+struct WptRule { int env; uint32_t wpt8_below; int decomposed; };
+__host__ __device__ static inline int mdx_wpt_rule(const WptRule& r, uint32_t T) {
+    if (r.env) return r.env;
     // With the tiles launched longest list first (round 3) fewer waves per tile win further down than before: one wave from
     // 12 k tiles on (water1M: pair launch 0.464 -> 0.458 ms, 1844 -> 1870 steps/s; it was two), two from 3 k tiles on for a
     // single-device list (375 k atoms 0.213 -> 0.197 ms, 585 k atoms 0.312 -> 0.289; it was four up to 12 k tiles)
-    const bool decomposed = h->dd || h->n_local != h->N;
     // (a decomposed rank - owned bricks and halo shells, very uneven lists - keeps four up to 8 k tiles: rank 0 of 4, 5.5 k tiles,
     // 0.155 ms with four against 0.180 with two; rank 0 of 2, 9.4 k tiles, 0.285 with four against 0.257 with two)
-    if (T >= 12000u) return decomposed ? 2 : 1;
-    if (T >= (decomposed ? 8000u : 3000u)) return 2;
-    return T < mdx_wpt8_below(h) ? 8 : 4;
+    if (T >= 12000u) return r.decomposed ? 2 : 1;
+    if (T >= (r.decomposed ? 8000u : 3000u)) return 2;
+    return T < r.wpt8_below ? 8 : 4;
 }
+static inline WptRule mdx_wpt_rule_of(const mdx_handle* h) {
+    static const int env = [] { const char* e = std::getenv("MDX_WPT"); return (e && (e[0] == '1' || e[0] == '2' || e[0] == '4' || e[0] == '8')) ? e[0] - '0' : 0; }();
+    WptRule r; r.env = env; r.wpt8_below = mdx_wpt8_below(h); r.decomposed = (h->dd || h->n_local != h->N) ? 1 : 0;
+    return r;
+}
+static inline int mdx_nb_wpt_half(const mdx_handle* h, uint32_t T) { return mdx_wpt_rule(mdx_wpt_rule_of(h), T); }
 
 // constraints / virtual sites (mdx_constraints.hip)
 int mdx_build_constraints(mdx_handle* h, const mdx_system* s);
@@ -443,6 +458,9 @@ struct MdxRange {
 };
 
 // profiling helpers
-void mdx_prof_begin(mdx_handle* h, int kind);
+// kinds: 0 pair kernel (whole / interior half), 1 bonded, 2 integrate, 3 energy flavour, 4 pair kernel boundary half, 5 fused bonded +
+// kick + drift; profile level 3 (a decomposed step in its production arrangement, phase by phase) adds 6 halo pack, 7 halo wire,
+// 8 halo unpack, 9 ghost-force pack, 10 ghost-force wire, 11 ghost-force add.  st: the stream the work goes to (default: h->stream)
+void mdx_prof_begin(mdx_handle* h, int kind, hipStream_t st = nullptr);
 void mdx_prof_end(mdx_handle* h);
 void mdx_prof_collect(mdx_handle* h, int first_stale_step = 1 << 30);

@@ -17,7 +17,7 @@ import os
 
 import numpy as np
 
-from ._abi import (CHBond, CConfig, CEnergies, CStats, CSystem, FORCE, MDX_EDEVICE, MDX_ENAN, MDX_EOOM,
+from ._abi import (CCommDiag, CHBond, CConfig, CEnergies, CStats, CSystem, FORCE, MDX_EDEVICE, MDX_ENAN, MDX_EOOM,
                    MDX_EPARAM, MDX_OK, POS, VEL, MdConfig, MdSystem)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -139,6 +139,7 @@ def load_library():
     lib.mdx_comm_selftest_fault.argtypes = [H]
     lib.mdx_pme_info.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.mdx_comm_debug_partition.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _u32p, _u32p, C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.mdx_comm_diag_read.argtypes = [H, C.POINTER(CCommDiag)]
     lib.mdx_comm_info.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _u32p, _u32p, _fp]
     _lib = lib
     return lib
@@ -393,7 +394,8 @@ class MdState:
 
     # -- profiling ---------------------------------------------------------------------------
     def profile(self, enable=True):
-        """0/False off, 1/True every step kernel, 2 the pair kernel only."""
+        """0/False off, 1/True every step kernel, 2 the pair kernel only, 3 (decomposed handles) every phase of the step in its
+        production arrangement (comm_diag reads the sums)."""
         _check(load_library().mdx_profile(self._h, int(enable)))
 
     def stats(self) -> dict:
@@ -452,6 +454,14 @@ class MdState:
         on, a, b, c = C.c_int(), C.c_uint64(), C.c_uint64(), C.c_uint64()
         _check(load_library().mdx_pme_info(self._h, C.byref(on), C.byref(a), C.byref(b), C.byref(c)))
         return dict(slab_on=bool(on.value), mesh_bytes_sent=a.value, transpose_bytes_sent=b.value, replicated_mesh_bytes=c.value)
+
+    def comm_diag(self) -> dict:
+        """mdx_comm_diag_read: transport, RCCL version / communicator size, owned / ghost atoms, halo bytes per step, repartitions,
+        whether the interior / boundary split was kept, and - summed while profile(3) is on - the GPU time of every phase of the
+        decomposed step."""
+        d = CCommDiag()
+        _check(load_library().mdx_comm_diag_read(self._h, C.byref(d)))
+        return d.as_dict()
 
     def comm_info(self) -> dict:
         r, w, g = C.c_int(), C.c_int(), (C.c_int * 3)()

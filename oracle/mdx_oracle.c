@@ -50,7 +50,10 @@
 #define ACC_CONV 418.4          /* kcal/mol/Å/Da -> Å/ps² */
 #define KB_KCAL  0.0019872041   /* kcal/mol/K */
 
-enum { E_BOND, E_ANGLE, E_DIHEDRAL, E_LJ, E_COUL, E_LJ14, E_COUL14, E_KIN, E_VIRIAL, E_CROSS, E_DUDL, E_N };
+/* E_GLJ / E_GCOUL: the GROSS pair sums, sum over pairs of |e_pair| - the scale the fp32 rounding of the engine's pair terms acts on
+ * (the net Coulomb energy of a neutral liquid is a difference of terms a thousand times larger); the parity tests' energy
+ * tolerance for the pair sums is stated against them */
+enum { E_BOND, E_ANGLE, E_DIHEDRAL, E_LJ, E_COUL, E_LJ14, E_COUL14, E_KIN, E_VIRIAL, E_CROSS, E_DUDL, E_GLJ, E_GCOUL, E_N };
 /* E_CROSS: unscaled non-bonded energy between the alchemical molecule and the rest (0 without a window), at the soft-core
  * distance when the soft core is on.  E_DUDL: dU/dlambda of the window (= -E_CROSS for linear coupling). */
 /* E_VIRIAL: W = sum_i r_i . F_i of the internal forces (pairs, 1-4, bonds; angle and dihedral terms are
@@ -512,11 +515,11 @@ int orc_forces(const mdx_system* s, const mdx_config* c, const double* x_in, con
     if (use_cells && !(cut_lj && cut_c)) use_cells = 0;
 
     grid_t g; if (use_cells) g = build_grid(s, x, rmax);
-    double e_lj = 0.0, e_c = 0.0, w_nb = 0.0, e_x = 0.0, e_dl = 0.0;
+    double e_lj = 0.0, e_c = 0.0, w_nb = 0.0, e_x = 0.0, e_dl = 0.0, g_lj = 0.0, g_c = 0.0;
     const int alch = g_alch_lambda >= 0.0;
     const double asc = alch ? 1.0 - g_alch_lambda : 1.0;
 
-#pragma omp parallel for schedule(dynamic, 64) reduction(+ : e_lj, e_c, w_nb, e_x, e_dl)
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : e_lj, e_c, w_nb, e_x, e_dl, g_lj, g_c)
     for (uint32_t i = 0; i < N; ++i) {
         if (!nb_active(s, i)) continue;
         double fi[3] = { 0, 0, 0 };
@@ -570,11 +573,13 @@ int orc_forces(const mdx_system* s, const mdx_config* c, const double* x_in, con
                 }
                 fi[0] += fs * d[0]; fi[1] += fs * d[1]; fi[2] += fs * d[2];
                 e_lj += 0.5 * el; e_c += 0.5 * ec; w_nb += 0.5 * fs * r2;
+                g_lj += 0.5 * fabs(el); g_c += 0.5 * fabs(ec);
             }
         }
         f[3*i] = fi[0]; f[3*i+1] = fi[1]; f[3*i+2] = fi[2];
     }
     en[E_LJ] = e_lj; en[E_COUL] = e_c; en[E_VIRIAL] = w_nb; en[E_CROSS] = e_x; en[E_DUDL] = e_dl;
+    en[E_GLJ] = g_lj; en[E_GCOUL] = g_c;
     bonded_forces(s, c, x, f, en);
     orc_vsite_spread(s, f);
     if (ext) for (uint32_t i = 0; i < 3 * N; ++i) f[i] += ext[i];

@@ -12,7 +12,7 @@ import numpy as np
 from molchanica_amd._abi import CConfig, CSystem, MdConfig, MdSystem
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ENERGY_NAMES = ("bond", "angle", "dihedral", "lj", "coulomb", "lj14", "coulomb14", "kinetic", "virial", "cross", "dudl")
+ENERGY_NAMES = ("bond", "angle", "dihedral", "lj", "coulomb", "lj14", "coulomb14", "kinetic", "virial", "cross", "dudl", "gross_lj", "gross_coulomb")
 BAR_PER_KCAL_MOL_A3 = 69476.95
 
 _dp = C.POINTER(C.c_double)

@@ -49,7 +49,7 @@ def test_forces_energies_and_dh_dlambda_match_the_oracle(mdx, orc, lam, alpha):
         orc.set_alchemical(0, 0, -1.0)
         orc.set_softcore(0.0)
     assert_forces(f, fo, slack, f"alchemical lambda={lam} alpha={alpha}")
-    assert_energies(e, eo, s.n_atoms * 200, f"alchemical lambda={lam} alpha={alpha}")
+    assert_energies(e, eo, f"alchemical lambda={lam} alpha={alpha}", rel=2e-5)   # (the soft-core radius goes through v_log / v_exp: 1e-6 relative per cross pair)
     scale = abs(eo["lj"]) + abs(eo["coulomb"]) + abs(eo["cross"]) + abs(eo["dudl"])
     assert e["dh_dlambda"] == pytest.approx(eo["dudl"], abs=2e-5 * scale + 0.02)
     assert e["coupled_interaction"] == pytest.approx((1 - lam) * eo["cross"], abs=2e-5 * scale + 0.02)

@@ -121,6 +121,41 @@ def test_half_shell_halo_evaluates_every_cross_pair_once_and_returns_the_ghost_f
     assert rms_dev(half[0]["pos"], full[0]["pos"], L) < 5e-4
 
 
+def test_c5_water1m_on_eight_ranks_follows_one_gpu():
+    """BASELINE config 5 in the north star's arrangement: the 1,029,000-atom box on 2 x 2 x 2 ranks (virtual ranks of the one
+    MI355X, in-process fabric; the production partition, halo, force return, local rebuilds and repartitions) against the
+    same box on one GPU, from a prepared state (relaxed, 300 K, atoms wrapped one by one - a running box, not the generator's
+    lattice of whole molecules).  60 steps: <= 2e-4 A RMS - fp32 coordinates in a 217 A box resolve 1.3e-5 A, and the two runs
+    round in different frames (measured 1.0e-4, profiles/r02_decomp_soak_water1M.txt) - and every energy term of the start
+    to 1e-6 (the fp64 all-reduce of eight ranks' sums against one device's)."""
+    import dataclasses
+    from molchanica_amd.md_state import MdState
+    s = systems.water1m()
+    cfg = MdConfig()
+    with MdState(s, cfg) as md:
+        md.minimize_energy(100); md.initialize_velocities(300.0, True, seed=105)
+        md.set_thermostat(1, 300.0, 0.02, 1); md.step(0.0005, None, 300); md.set_thermostat(0, 300.0, 0.02, 1)
+        pos, vel = md.positions(), md.velocities()
+    s2 = dataclasses.replace(s, pos=pos, vel=vel)
+    with MdState(s2, cfg) as md:
+        e_ref = md.energy()
+        md.step(0.0005, None, 60)
+        p_ref = md.positions().astype(np.float64)
+        rb_ref = md.stats()["rebuild_count"]
+    res = run_ranks(s2, cfg, 8, 60)
+    r0 = res[0]
+    L = np.array(s.box_hi, dtype=np.float64)
+    for k in ("lj", "coulomb", "bond", "angle", "kinetic", "potential"):
+        assert abs(r0["e0"][k] - e_ref[k]) <= max(5e-2, 1e-6 * abs(e_ref[k])), (k, r0["e0"][k], e_ref[k])
+    dev = rms_dev(r0["pos"], p_ref, L)
+    assert dev <= 2e-4, f"8 ranks deviate from one GPU by {dev:.2e} A after 60 steps"
+    assert sum(res[r]["stats"]["n_owned"] for r in range(8)) == s.n_atoms
+    assert all(res[r]["stats"]["n_ghost"] > 50_000 for r in range(8))
+    assert rb_ref >= 2 and r0["stats"]["local_rebuilds"] + r0["stats"]["repartitions"] >= 3, "no list rebuild under way: the comparison would not cover one"
+    for r in range(1, 8):
+        assert np.array_equal(res[r]["pos"], r0["pos"]), "ranks disagree on the gathered global state"
+
+
 def test_external_forces_on_decomposed_handles():
     """`md.step(dev, dt, Some(external_forces))` (src/mol_alignment.rs:349-356): every rank is handed the same per-atom array in
     the caller's order and adds the rows of the atoms it owns."""
@@ -556,6 +591,17 @@ def test_bench_process_per_rank_flow_on_one_gpu(n):
     assert j["config"]["energy_evaluations_in_timed_region"] == 2 and ("2x1x1" if n == 2 else "2x2x1") in j["config"]["parallelism"]
     assert 0 < j["config"]["n_owned_rank0"] < j["config"]["n_atoms"] and j["config"]["n_ghost_rank0"] > 0
     assert j["tail"]["steps"] == 60 and j["tail"]["rebuilds"] >= 1 and j["config"]["repartitions"] >= 1
+    # the line says where the step time went, rank by rank (mdx_comm_diag through bench.py): a reader of one SCALE line can
+    # tell the wire from the kernels
+    m = j["multi_gpu"]
+    assert m["transport"].startswith("shared memory") and m["rccl_world"] == 0       # (this run's wire is not RCCL, and says so)
+    assert len(m["n_owned"]) == n and sum(m["n_owned"]) == j["config"]["n_atoms"] and all(g > 0 for g in m["n_ghost"])
+    assert all(b > 0 for b in m["halo_bytes_per_step_per_rank"]) and len(m["overlap_split_kept"]) == n
+    ph = m["phase_ms_per_step"]
+    for k in ("halo_pack", "halo_wire", "halo_unpack", "force_pack", "force_wire", "force_add", "pair", "bonded", "integrate"):
+        assert len(ph[k]) == n and all(v >= 0.0 for v in ph[k]), (k, ph[k])
+    assert all(v > 0.0 for v in ph["pair"]) and all(v > 0.0 for v in ph["halo_wire"]) and all(w > 0 for w in m["step_wall_ms_profiled"])
+    assert j["value_no_rebuild"] is None or j["value_no_rebuild"] >= j["value"] * 0.999
 
 
 def test_shared_memory_transport_matches_single_gpu():

@@ -33,8 +33,10 @@ def single_point(name, s, cfg, use_cells, rel=1e-5):
     out = []
     for k in TERMS:
         d = abs(e[k] - eo[k])
-        out.append(f"{k} {d / max(abs(eo[k]), 1e-30):.1e} (abs {d:.1e} of {eo[k]:.6g})")
-    print("    energy rel errors: " + "; ".join(out), flush=True)
+        g = eo.get("gross_" + k, 0.0)
+        tol = max(1e-3, 2e-6 * abs(eo[k]) + {"lj": 1e-6, "coulomb": 1e-8}.get(k, 0.0) * g)
+        out.append(f"{k} {d / max(abs(eo[k]), 1e-30):.1e} (abs {d:.1e} of {eo[k]:.6g}" + (f", gross {g:.4g}: {d / g:.1e} of it" if g else "") + f"; {d / tol:.2f} of the test's tolerance)")
+    print("    energy errors: " + "; ".join(out), flush=True)
 
 
 if "c1" in want: single_point("C1 lig50", systems.lig50(), MdConfig(**NOCUT), False)
