@@ -262,6 +262,21 @@ uint64_t mdx_step_count(const mdx_handle* h);
 int mdx_neighbor_list(mdx_handle* h, uint32_t* offsets /* [N+1] */, uint32_t* idx /* or NULL */);
 
 /* (enable 3, decomposed handles: every phase of the step in its production arrangement - see mdx_comm_diag) */
+/* HydrogenConstraint::{Flexible, Shake{shake_tolerance}, Linear{order, iter}} as the reference's UI hands it over
+ * [ref: src/ui/panels/md.rs:362-371; LINCS_ORDER_DEFAULT, LINCS_ITER_DEFAULT, SHAKE_TOL_DEFAULT of the dynamics crate].
+ * The constraints themselves are part of mdx_system; this call tells the solver how hard to work:
+ *   MDX_HC_SHAKE   constraint_tol = shake_tolerance (relative; <= 0 keeps the configured one)
+ *   MDX_HC_LINEAR  LINCS's order (terms of its matrix expansion) and iter (correction passes) bound a truncation error; this
+ *                  engine solves every cluster in registers to a tolerance instead, so the pair is MAPPED: the tolerance
+ *                  becomes min(configured, 10^-(order/2 + iter + 1)) - order 4 / iter 1 -> 1e-4, never looser than LINCS
+ *                  itself would leave - and the mapping is written to mdx_constraint_description (nothing is ignored
+ *                  silently)
+ *   MDX_HC_FLEXIBLE refused (MDX_EPARAM) on a system created with constraints: build it without them. */
+enum { MDX_HC_FLEXIBLE = 0, MDX_HC_SHAKE = 1, MDX_HC_LINEAR = 2 };
+int mdx_set_hydrogen_constraint(mdx_handle* h, int kind, uint32_t lincs_order, uint32_t lincs_iter, float shake_tolerance);
+/* One line: solver per cluster kind, tolerance in force, and how a Linear{order, iter} request was mapped. */
+const char* mdx_constraint_description(mdx_handle* h);
+
 /* Kernel timing with HIP events on the library's stream; mdx_get_stats reads the sums.  enable: 0 off, 1 every
  * step kernel, 2 the pair kernel only (each event pair is two extra packets in the queue: level 2 disturbs the
  * step loop least). */

@@ -383,9 +383,10 @@ static uint32_t stale_threshold_bits(const mdx_handle* h) {
 // End of a chunk: the step-control words reach the host.  A kernel copies them into pinned host memory and writes a
 // sequence word last; the host spins on that word - no runtime call on the wait path (tools/ubench/sync_latency.hip:
 // launch + readback + wait 13 us this way, 18 us with hipStreamSynchronize behind the same kernel, 27 us with a
-// hipMemcpyAsync + hipStreamSynchronize).  One chunk end per 16 steps: 1 % of a 55 us step at 23 k atoms.  Profiled
-// and decomposed handles keep the synchronising copy (their host code after the chunk relies on an idle stream), and
-// so does a wait that lasts longer than 20 ms (a fault then surfaces through hipStreamSynchronize).
+// hipMemcpyAsync + hipStreamSynchronize).  One chunk end per 16 steps: 1 % of a 55 us step at 23 k atoms.  Decomposed
+// handles keep the synchronising copy (their host code after the chunk relies on an idle stream), and so does a wait that
+// lasts longer than 20 ms (a fault then surfaces through hipStreamSynchronize).  (Round 4: profiled handles spin too - the
+// event pairs are read after the wait, when all of them have completed.)
 __global__ __launch_bounds__(256) void ctl_readback_kernel(const uint32_t* __restrict__ src, volatile uint32_t* dst, uint32_t nwords,
                                                            volatile uint32_t* seq_word, uint32_t seq) {
     for (uint32_t i = threadIdx.x; i < nwords; i += 256) dst[i] = src[i];
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(256) void ctl_readback_kernel(const uint32_t* __res
 static int ctl_to_host(mdx_handle* h) {
     hipStream_t st = h->stream;
     static const bool spin_ok = [] { const char* e = std::getenv("MDX_CHUNK_SPIN"); return !(e && e[0] == '0'); }();
-    if (!spin_ok || h->profile || h->dd) {
+    if (!spin_ok || h->dd) {
         HIP_TRY(hipMemcpyAsync(h->h_ctl, h->d.ctl, sizeof(StepCtl), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         return MDX_OK;

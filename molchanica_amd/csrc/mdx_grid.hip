@@ -1676,7 +1676,7 @@ __global__ __launch_bounds__(1024) void rb_finish_kernel(FinishArgs a) {
 
 static int spin_on_readback(mdx_handle* h, uint32_t seq) {
     static const bool spin_ok = [] { const char* e = std::getenv("MDX_CHUNK_SPIN"); return !(e && e[0] == '0'); }();
-    if (!spin_ok || h->profile) { HIP_TRY(hipStreamSynchronize(h->stream)); return MDX_OK; }
+    if (!spin_ok) { HIP_TRY(hipStreamSynchronize(h->stream)); return MDX_OK; }
     volatile uint32_t* seq_word = (volatile uint32_t*)h->h_rb + 31;
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t spins = 0; *seq_word != seq; ++spins) {

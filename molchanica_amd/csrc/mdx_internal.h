@@ -221,6 +221,7 @@ struct mdx_handle {
     uint32_t n_roles = 0;
     uint32_t n_groups = 0, n_cons = 0, n_vsites = 0;   // constraint clusters / constraints / virtual sites
     std::vector<ConsGroup> h_groups; std::vector<VSite> h_vsites;   // host copies (caller order): ownership anchors of a decomposition
+    int hc_kind = 1; uint32_t hc_order = 0, hc_iter = 0; std::string hc_text;   // mdx_set_hydrogen_constraint: what the host asked for
     bool cons_dirty = false;                           // positions were set from outside: project them once
     bool vsites_convex = true;                         // every virtual site lies inside the triangle of its parents
     // SPME

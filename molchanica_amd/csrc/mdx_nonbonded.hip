@@ -917,7 +917,7 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
     // decides; mdx_launch_bonded then finds bonded_fused set).  MDX_FUSE_BONDED=0: A/B knob.
     static const bool fuse_bonded = [] { const char* e = std::getenv("MDX_FUSE_BONDED"); return !(e && e[0] == '0'); }();
     h->bonded_fused = false;
-    if (fuse_bonded && a.inner && part == 0 && mdx_bonded_wanted(h) && !h->bonded_deferred && (!h->profile || h->profile_level == 2)) {
+    if (fuse_bonded && a.inner && part == 0 && mdx_bonded_wanted(h) && !h->bonded_deferred && (!h->profile || h->profile_level >= 2)) {
         a.b_S = h->S; a.b_role_off = h->d.role_off_s; a.b_roles = h->d.role_rec_s; a.b_prm = h->d.role_prm;
         mdx_fill_bonded_params(h, a.b_p);
     }

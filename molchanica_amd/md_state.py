@@ -139,6 +139,9 @@ def load_library():
     lib.mdx_comm_selftest_fault.argtypes = [H]
     lib.mdx_pme_info.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.mdx_comm_debug_partition.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _u32p, _u32p, C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.mdx_set_hydrogen_constraint.argtypes = [H, C.c_int, C.c_uint32, C.c_uint32, C.c_float]
+    lib.mdx_constraint_description.argtypes = [H]
+    lib.mdx_constraint_description.restype = C.c_char_p
     lib.mdx_comm_diag_read.argtypes = [H, C.POINTER(CCommDiag)]
     lib.mdx_comm_info.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _u32p, _u32p, _fp]
     _lib = lib
@@ -454,6 +457,14 @@ class MdState:
         on, a, b, c = C.c_int(), C.c_uint64(), C.c_uint64(), C.c_uint64()
         _check(load_library().mdx_pme_info(self._h, C.byref(on), C.byref(a), C.byref(b), C.byref(c)))
         return dict(slab_on=bool(on.value), mesh_bytes_sent=a.value, transpose_bytes_sent=b.value, replicated_mesh_bytes=c.value)
+
+    def set_hydrogen_constraint(self, kind: str, order: int = 4, iters: int = 1, shake_tolerance: float = 0.0) -> str:
+        """HydrogenConstraint::{Flexible, Shake{shake_tolerance}, Linear{order, iter}} (src/ui/panels/md.rs:362-371) -> the
+        solver's description of what it will do (how Linear was mapped)."""
+        k = {"flexible": 0, "shake": 1, "linear": 2}[kind.lower()]
+        lib = load_library()
+        _check(lib.mdx_set_hydrogen_constraint(self._h, k, int(order), int(iters), float(shake_tolerance)))
+        return lib.mdx_constraint_description(self._h).decode()
 
     def comm_diag(self) -> dict:
         """mdx_comm_diag_read: transport, RCCL version / communicator size, owned / ghost atoms, halo bytes per step, repartitions,

@@ -32,6 +32,8 @@ def build(native: bool = False) -> str:
     path, src = os.path.join(_HERE, target), os.path.join(_HERE, "cpu_production.c")
     if (not os.path.exists(path)) or os.path.getmtime(path) < os.path.getmtime(src):
         arch = "-march=native" if native else ""
+        # (no -ffast-math: linking it into a shared object switches the whole process to flush-to-zero; the SIMD loops are
+        # `omp simd` loops and vectorise without it)
         subprocess.check_call(f"gcc -O3 {arch} -fno-math-errno -fno-trapping-math -fPIC -shared -fopenmp -std=c11 "
                               f"{src} -o {path} -lm", shell=True)
     return path

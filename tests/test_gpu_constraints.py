@@ -212,6 +212,25 @@ def test_methyl_clusters_meet_the_tolerance_linear_maps_to(mdx, orc):
     assert math.sqrt((dd ** 2).sum(1).mean()) < 2e-3
 
 
+def test_hydrogen_constraint_kinds_are_mapped_not_ignored(mdx):
+    """`HydrogenConstraint::{Shake{shake_tolerance}, Linear{order, iter}, Flexible}` as the UI hands it over
+    (/root/reference src/ui/panels/md.rs:362-371): Shake sets the tolerance, Linear is MAPPED onto the converged solver with a
+    tolerance no looser than LINCS would leave and says so, Flexible is refused on a system that was built with constraints."""
+    s = _methyl_box()
+    cfg = MdConfig(lj_cutoff=5.0, coulomb_cutoff=5.0, skin=1.0, coulomb_mode=1, constraint_tol=1e-3)
+    with mdx.MdState(s, cfg) as md:
+        text = md.set_hydrogen_constraint("linear", order=4, iters=1)
+        assert "Linear{order 4, iter 1}" in text and "1.0e-04" in text, text
+        md.forces(); md.step(0.002, None, 30)
+        assert bond_errors(s, md.positions().astype(np.float64)).max() < 3e-4
+        text = md.set_hydrogen_constraint("shake", shake_tolerance=1e-6)
+        assert "1.0e-06" in text
+        md.step(0.002, None, 10)
+        assert bond_errors(s, md.positions().astype(np.float64)).max() < 5e-6
+        with pytest.raises(mdx.ParamError, match="Flexible"):
+            md.set_hydrogen_constraint("flexible")
+
+
 def test_oversized_constraint_cluster_is_rejected(mdx):
     s = systems.lig50()
     s.constraint_idx = s.bond_idx[:12].copy()       # a connected chain of > 4 atoms
