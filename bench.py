@@ -98,6 +98,19 @@ def cpu_baseline_production(system, cfg, dt, n_steps):
     same system, the half Verlet list reused until an atom has moved skin/2 (first build included)."""
     from oracle import cpu_production as cp
     lib = cp.lib(native=True)
+    # cores the process may really use: the scheduler affinity, cut by a cgroup CPU quota (the GPU boxes show 256 logical CPUs
+    # and grant 16 CPUs' worth of time: 128 OpenMP threads on that are 16 cores, eight-fold oversubscribed)
+    usable = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(per) + 0.5))
+    except Exception:
+        pass
+    if quota:
+        usable = min(usable, quota)
+    lib.cpu_prod_set_threads(int(usable))
     t0 = time.perf_counter()
     _, _, _, builds = cp.run(system, cfg, dt, n_steps, energy_every=100, native=True)
     el = time.perf_counter() - t0
@@ -111,10 +124,12 @@ def cpu_baseline_production(system, cfg, dt, n_steps):
         "value": n * n_steps / el, "unit": "atom-updates/s", "steps_per_s": n_steps / el,
         "cores": cores, "kind": "port-production", "list_pairs_per_s_per_core": pairs / el / max(cores, 1),
         "lane_pairs_per_s_per_core": lanes / el / max(cores, 1),
+        "cpu_quota": quota, "logical_cpus": os.cpu_count(),
         "sample": f"{n_steps} velocity-Verlet steps of the same {n}-atom box, fp32, SIMD cluster-pair loop (clusters of 8 atoms, "
                   f"structure-of-arrays, per-entry periodic shift, j-forces of an entry in registers; `omp simd`, gcc -O3 -march=native), "
                   f"half cluster-pair list (rc + skin) reused across steps ({builds} list builds incl. the first), Newton-3 with "
-                  f"thread-private force buffers, energies every 100 steps, OpenMP over all host cores, {el:.1f} s: "
+                  f"thread-private force buffers, energies every 100 steps, OpenMP over the {cores} CPUs this process may use "
+                  f"({os.cpu_count()} logical CPUs shown, cgroup quota {quota}), {el:.1f} s: "
                   f"{pairs / el / max(cores, 1) / 1e6:.1f} M list pairs/s/core (atom pairs inside the list radius; "
                   f"{lanes / el / max(cores, 1) / 1e6:.0f} M lane pairs/s/core evaluated; list builds included in the time)",
     }

@@ -386,10 +386,12 @@ static uint32_t stale_threshold_bits(const mdx_handle* h) {
 // hipMemcpyAsync + hipStreamSynchronize).  One chunk end per 16 steps: 1 % of a 55 us step at 23 k atoms.  Decomposed
 // handles keep the synchronising copy (their host code after the chunk relies on an idle stream), and so does a wait that
 // lasts longer than 20 ms (a fault then surfaces through hipStreamSynchronize).  (Round 4: profiled handles spin too - the
-// event pairs are read after the wait, when all of them have completed.)
+// event pairs are read after the wait, when all of them have completed - and so do decomposed ones, with the drift probe of
+// mdx_dd_chunk_end_probe in the same read-back; MDX_DD_CHUNK_SPIN=0 restores their synchronising copy.)
 __global__ __launch_bounds__(256) void ctl_readback_kernel(const uint32_t* __restrict__ src, volatile uint32_t* dst, uint32_t nwords,
-                                                           volatile uint32_t* seq_word, uint32_t seq) {
+                                                           volatile uint32_t* seq_word, uint32_t seq, const uint32_t* __restrict__ extra) {
     for (uint32_t i = threadIdx.x; i < nwords; i += 256) dst[i] = src[i];
+    if (threadIdx.x == 0 && extra) seq_word[1] = *extra;      // (decomposed handle: the drift probe's word, next to the sequence word)
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) *seq_word = seq;
@@ -397,24 +399,31 @@ __global__ __launch_bounds__(256) void ctl_readback_kernel(const uint32_t* __res
 static int ctl_to_host(mdx_handle* h) {
     hipStream_t st = h->stream;
     static const bool spin_ok = [] { const char* e = std::getenv("MDX_CHUNK_SPIN"); return !(e && e[0] == '0'); }();
-    if (!spin_ok || h->dd) {
+    static const bool dd_spin = [] { const char* e = std::getenv("MDX_DD_CHUNK_SPIN"); return !(e && e[0] == '0'); }();
+    const uint32_t* probe = nullptr;
+    if (h->dd) MDX_TRY(mdx_dd_chunk_end_probe(h, &probe));
+    if (!spin_ok || (h->dd && !dd_spin)) {
         HIP_TRY(hipMemcpyAsync(h->h_ctl, h->d.ctl, sizeof(StepCtl), hipMemcpyDeviceToHost, st));
+        if (probe) HIP_TRY(hipMemcpyAsync(&h->dd->spec_bits, probe, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (probe) h->dd->spec_valid = true;
         return MDX_OK;
     }
     volatile uint32_t* seq_word = reinterpret_cast<volatile uint32_t*>(reinterpret_cast<char*>(h->h_ctl) + sizeof(StepCtl));
     const uint32_t seq = ++h->ctl_seq;
     hipLaunchKernelGGL(ctl_readback_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(h->d.ctl),
-                       reinterpret_cast<volatile uint32_t*>(h->h_ctl), (uint32_t)(sizeof(StepCtl) / 4), seq_word, seq);
+                       reinterpret_cast<volatile uint32_t*>(h->h_ctl), (uint32_t)(sizeof(StepCtl) / 4), seq_word, seq, probe);
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t spins = 0; *seq_word != seq; ++spins) {
-        if ((spins & 0xFFFu) == 0xFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+        if ((spins & 0xFFFu) == 0xFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(h->dd ? 2000 : 20)) {
             HIP_TRY(hipStreamSynchronize(st));
             if (*seq_word != seq) { mdx_set_error("internal: step-control readback did not arrive"); return MDX_EDEVICE; }
             break;
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    if (probe) { h->dd->spec_bits = seq_word[1]; h->dd->spec_valid = true; }
+    // (a decomposed handle's host code behind the chunk - transports, collectives - synchronises the stream itself where it needs to)
     return MDX_OK;
 }
 
@@ -479,6 +488,11 @@ static int ensure_ready(mdx_handle* h) {
         MDX_TRY(mdx_launch_constrain_positions(h, 0.f, nullptr, nullptr, 0));
         MDX_TRY(mdx_launch_constrain_velocities(h, nullptr, 0));
         h->cons_dirty = false; h->forces_valid = false; h->moved_outside = true;
+        if (h->dd && h->dd->world > 1) {     // the owners projected their clusters: the ghost copies follow by message
+            h->dd->halo_step = -1;
+            MDX_TRY(mdx_dd_halo_begin(h));
+            MDX_TRY(mdx_dd_halo_end(h));
+        }
     }
     if (!h->forces_valid) {
         MDX_TRY(compute_forces(h, false, nullptr, 0));
@@ -717,6 +731,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
                 break;
             }
         }
+        if (h->dd) h->dd->spec_valid = false;      // (the chunk-end drift probe speaks for the state at THIS chunk's end only)
         // Dual list, library-default buffer: keep the pruning passes rare enough to pay.  A pass costs +15 % over the plain
         // list and an inner-list step saves 15 %, so above ~45 % passes the dual list loses.  Long steps (dt = 2 fs with
         // constraints moves atoms four times as far per step as the 0.5 fs of flexible water) hit the 0.25 A path budget
@@ -1046,16 +1061,21 @@ extern "C" int mdx_upload(mdx_handle* h, int which, const float* src) {
     h->e_cache_valid = false; h->e_pending = false;
     if (which != MDX_POS && which != MDX_VEL) FAIL(MDX_EPARAM, "only MDX_POS and MDX_VEL can be uploaded");
     HIP_TRY(hipSetDevice(h->device));
-    if (h->dd || h->n_local != h->N) FAIL(MDX_EPARAM, "mdx_upload on a decomposed handle");
+    if (!h->dd && h->n_local != h->N) FAIL(MDX_EPARAM, "mdx_upload on a handle narrowed by mdx_set_local_atoms (the host that drives the decomposition owns the state)");
     const uint32_t N = h->N;
     for (size_t k = 0; k < 3 * (size_t)N; ++k)
         if (!std::isfinite(src[k])) FAIL(MDX_EPARAM, "non-finite value in upload");
-    MDX_TRY(mdx_unsort_state(h));  // keep the other array: both now live in caller-order staging
     std::vector<float4> b(N);
     for (uint32_t i = 0; i < N; ++i) {
         b[i] = make_float4(src[3 * i], src[3 * i + 1], src[3 * i + 2], 0.f);
         if (which == MDX_VEL && (h->flags[i] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST))) b[i] = make_float4(0, 0, 0, 0);
     }
+    if (h->dd) {      // joined handle: collective, every rank passes the same array (mdx_decomp.hip)
+        MDX_TRY(mdx_dd_upload(h, which, 0, N, b.data()));
+        if (h->n_groups) h->cons_dirty = true;
+        return MDX_OK;
+    }
+    MDX_TRY(mdx_unsort_state(h));  // keep the other array: both now live in caller-order staging
     HIP_TRY(hipMemcpyAsync(which == MDX_POS ? h->d.pos_orig : h->d.vel_orig, b.data(), sizeof(float4) * N,
                            hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1097,7 +1117,7 @@ extern "C" int mdx_upload_range(mdx_handle* h, int which, uint32_t first, uint32
     if (!h || (count && !src)) FAIL(MDX_EPARAM, "null argument");
     h->e_cache_valid = false; h->e_pending = false;
     if (which != MDX_POS && which != MDX_VEL) FAIL(MDX_EPARAM, "only MDX_POS and MDX_VEL can be uploaded");
-    if (h->dd || h->n_local != h->N) FAIL(MDX_EPARAM, "mdx_upload_range on a decomposed handle");
+    if (!h->dd && h->n_local != h->N) FAIL(MDX_EPARAM, "mdx_upload_range on a handle narrowed by mdx_set_local_atoms");
     if ((uint64_t)first + count > h->N) FAIL(MDX_EPARAM, "atom range out of bounds");
     if (count == 0) return MDX_OK;
     HIP_TRY(hipSetDevice(h->device));
@@ -1108,6 +1128,11 @@ extern "C" int mdx_upload_range(mdx_handle* h, int which, uint32_t first, uint32
     for (uint32_t k = 0; k < count; ++k) {
         b[k] = make_float4(src[3 * k], src[3 * k + 1], src[3 * k + 2], 0.f);
         if (which == MDX_VEL && (h->flags[first + k] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST))) b[k] = make_float4(0, 0, 0, 0);
+    }
+    if (h->dd) {      // joined handle: collective (the moved rows may change owner: gather, overwrite, repartition)
+        MDX_TRY(mdx_dd_upload(h, which, first, count, b.data()));
+        if (h->n_groups) h->cons_dirty = true;
+        return MDX_OK;
     }
     const bool keep_list = which == MDX_POS && h->in_slot_space && h->list_valid && !std::isinf(h->r_list);
     if (!keep_list) {
@@ -1141,10 +1166,13 @@ extern "C" int mdx_upload_range(mdx_handle* h, int which, uint32_t first, uint32
 
 extern "C" int mdx_set_box(mdx_handle* h, const float lo[3], const float hi[3]) {
     if (!h || !lo || !hi) FAIL(MDX_EPARAM, "null argument");
-    if (h->dd) FAIL(MDX_EPARAM, "mdx_set_box on a decomposed handle");
-    if (!h->periodic) FAIL(MDX_EPARAM, "mdx_set_box on a non-periodic system");
-    MDX_TRY(check_box(h->per, lo, hi, &h->cfg));
+    if (!h->periodic && !h->dd) FAIL(MDX_EPARAM, "mdx_set_box on a non-periodic system");
+    {   // (a rank of a fully cut box is not periodic locally: the box is still the global, fully periodic one)
+        const int per_all[3] = {1, 1, 1};
+        MDX_TRY(check_box(h->dd ? per_all : h->per, lo, hi, &h->cfg));
+    }
     HIP_TRY(hipSetDevice(h->device));
+    if (h->dd) { h->e_cache_valid = false; h->e_pending = false; return mdx_dd_set_box(h, lo, hi, nullptr, nullptr); }
     MDX_TRY(mdx_unsort_state(h));
     for (int d = 0; d < 3; ++d) { h->box_lo[d] = lo[d]; h->box_hi[d] = hi[d]; }
     h->list_valid = false; h->forces_valid = false;

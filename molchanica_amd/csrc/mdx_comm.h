@@ -88,6 +88,11 @@ struct MdxDecomp {
     int tune_phase = 0;                // 0: measuring with the split, 1: without, 2: decided
     double tune_ms[2] = {0.0, 0.0}; uint32_t tune_steps[2] = {0, 0}; uint32_t tune_chunks = 0;
     double* red = nullptr;             // [64] device scratch of the small all-reduces
+    // chunk end (step loop): the largest displacement since the last repartition is measured and all-reduced BEHIND the chunk's
+    // last kernel, every chunk, and comes back with the step-control words - a stale list then needs no second round trip to
+    // decide between a local rebuild and a repartition (it was: drift kernel, all-reduce, copy, synchronise - ~80 us per rebuild)
+    uint32_t* drift_bits = nullptr;    // [2] device
+    bool spec_valid = false; uint32_t spec_bits = 0;
     // statistics
     uint64_t repartitions = 0, local_rebuilds = 0; uint32_t local_rebuilds_since = 0;
     double repartition_ms = 0.0;
@@ -109,6 +114,7 @@ int  mdx_dd_halo_begin(mdx_handle* h);                   // pack + exchange (asy
 int  mdx_dd_halo_end(mdx_handle* h);                     // wait + unpack: ghost positions, peers' flag words
 int  mdx_dd_force_return_begin(mdx_handle* h, int flag_word);   // half shell: pack the ghosts' forces + exchange (reverse of the halo)
 int  mdx_dd_force_return_end(mdx_handle* h, int flag_word);     // ... and add what came back to the owned atoms
+int  mdx_dd_chunk_end_probe(mdx_handle* h, const uint32_t** word_out);   // enqueue the speculative drift probe; *word_out: the device word to read back
 int  mdx_dd_on_stale(mdx_handle* h);                     // the list went stale somewhere: local rebuild or repartition (same branch on every rank)
 int  mdx_dd_allreduce_host(mdx_handle* h, double* v, int n, bool max_u32 = false);
 int  mdx_dd_allreduce_f32(mdx_handle* h, float* dev, size_t n, hipStream_t produced_on);   // sum of a large device array over the ranks
@@ -117,5 +123,9 @@ int  mdx_dd_exchange(mdx_handle* h, const float4* send, const std::vector<MdxSeg
 int  mdx_dd_download(mdx_handle* h, int which, float* dst);   // collective: the global array on every rank
 int  mdx_dd_gather_global(mdx_handle* h, bool with_force);    // g_pos / g_vel (/ g_frc) <- all ranks' owned atoms
 int  mdx_dd_rescale_box(mdx_handle* h, const float hi[3], float mu);   // barostat: scale the gathered state about box_lo, new box, repartition
+// host mutation of a joined handle (collective: every rank passes the same data) - md.atoms[i].posit = ..; md.rebuild_spatial_caches()
+// (/root/reference src/properties/sol_shrinking_box.rs:599-632), the docking pose loop (src/docking/mod.rs:235)
+int  mdx_dd_upload(mdx_handle* h, int which, uint32_t first, uint32_t count, const float4* host_rows);
+int  mdx_dd_set_box(mdx_handle* h, const float lo[3], const float hi[3], const float* centre_or_null, const float* mu_or_null);
 int  mdx_dd_save_global(mdx_handle* h, float4* backup);      // minimiser: the accepted state (gathered global positions) ...
 int  mdx_dd_restore_global(mdx_handle* h, const float4* backup);   // ... and back to it (repartition from the copy)

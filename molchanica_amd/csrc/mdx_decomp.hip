@@ -236,26 +236,33 @@ __global__ __launch_bounds__(256) void dd_gather_scatter_kernel(uint32_t n, int 
     if (rows == 3) g_frc[g] = in[(size_t)rows * k + 2];
 }
 
-// largest squared displacement of a local atom since the last repartition (uncut dimensions stay periodic inside the engine)
+// largest squared displacement of a local atom since the last repartition (uncut dimensions stay periodic inside the engine).
+// Grid-stride over at most 64 workgroups, one atomic per workgroup: one per wave - 3.2 k contended atomics for one rank of 8 of
+// the 1 M-atom box - made this a 32 us kernel (it streams 8 MB)
 __global__ __launch_bounds__(256) void dd_drift_kernel(uint32_t n_local, const uint32_t* __restrict__ gid_local, const uint32_t* __restrict__ slot_of,
                                                        const float4* __restrict__ posq, const float4* __restrict__ pos_at_part, DdPart p,
                                                        uint32_t* __restrict__ out_bits) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    float d2 = 0.f;
-    if (i < n_local) {
+    __shared__ float s_max[4];
+    float d2m = 0.f;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_local; i += gridDim.x * blockDim.x) {
         const uint32_t s = slot_of[gid_local[i]];
-        if (s != MDX_INVALID) {
-            const float4 a = posq[s], b = pos_at_part[i];
-            float d[3] = {a.x - b.x, a.y - b.y, a.z - b.z};
+        if (s == MDX_INVALID) continue;
+        const float4 a = posq[s], b = pos_at_part[i];
+        float d[3] = {a.x - b.x, a.y - b.y, a.z - b.z};
 #pragma unroll
-            for (int k = 0; k < 3; ++k) if (p.grid[k] == 1) d[k] -= rintf(d[k] / p.len[k]) * p.len[k];
-            d2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-            if (!(d2 < 1.0e30f)) d2 = 3.0e38f;
-        }
+        for (int k = 0; k < 3; ++k) if (p.grid[k] == 1) d[k] -= rintf(d[k] / p.len[k]) * p.len[k];
+        float d2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        if (!(d2 < 1.0e30f)) d2 = 3.0e38f;
+        d2m = fmaxf(d2m, d2);
     }
 #pragma unroll
-    for (int m = 32; m > 0; m >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, m));
-    if ((threadIdx.x & 63) == 0 && d2 > 0.f) atomicMax(out_bits, __float_as_uint(d2));
+    for (int m = 32; m > 0; m >>= 1) d2m = fmaxf(d2m, __shfl_xor(d2m, m));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = d2m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        d2m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+        if (d2m > 0.f) atomicMax(out_bits, __float_as_uint(d2m));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -584,25 +591,53 @@ int mdx_dd_force_return_end(mdx_handle* h, int flag_word) {
 }
 
 // ---- stale list: local rebuild or repartition (the same branch on every rank) --------------------------------------
+static int dd_enqueue_drift_probe(mdx_handle* h, uint32_t* bits) {
+    MdxDecomp* dd = h->dd;
+    hipStream_t st = h->stream;
+    HIP_TRY(hipMemsetAsync(bits, 0, sizeof(uint32_t), st));
+    if (h->in_slot_space)
+        hipLaunchKernelGGL(dd_drift_kernel, dim3(std::min(div_up(dd->n_local, 256), 64u)), dim3(256), 0, st, dd->n_local, dd->gid_local, h->d.slot_of,
+                           h->d.posq, dd->pos_at_part, make_part(dd), bits);
+    MDX_TRY(dd_comm_enter(h));
+    MDX_TRY(dd->tr->all_reduce(bits, 1, 1, dd->comm_stream));
+    MDX_TRY(dd_comm_leave(h));
+    return MDX_OK;
+}
+static bool dd_drift_allows_local_rebuild(const MdxDecomp* dd, uint32_t bits) {
+    float d2; std::memcpy(&d2, &bits, 4);
+    return dd->margin > 0.f && dd->local_rebuilds_since < 256 && std::sqrt(d2) <= 0.5f * dd->margin - 0.05f;
+}
+
+// Step loop, end of every chunk of a decomposed handle: the probe rides behind the chunk's kernels (a ~5 us kernel and a one-word
+// all-reduce every ~16 steps) and its word reaches the host with the step-control block.  Skipped with virtual sites: their
+// positions at the stale step are only constructed by mdx_dd_on_stale.
+int mdx_dd_chunk_end_probe(mdx_handle* h, const uint32_t** word_out) {
+    MdxDecomp* dd = h->dd;
+    *word_out = nullptr;
+    dd->spec_valid = false;
+    static const bool on = [] { const char* e = std::getenv("MDX_DD_SPEC_PROBE"); return !(e && e[0] == '0'); }();
+    if (!on || dd->world == 1 || h->n_vsites || !h->in_slot_space) return MDX_OK;
+    if (!dd->drift_bits) { HIP_TRY(hipMalloc((void**)&dd->drift_bits, 16)); }
+    MDX_TRY(dd_enqueue_drift_probe(h, dd->drift_bits));
+    *word_out = dd->drift_bits;
+    return MDX_OK;
+}
+
 static int dd_local_set_still_valid(mdx_handle* h, bool* valid) {
     MdxDecomp* dd = h->dd;
     *valid = true;
     if (dd->world == 1) return MDX_OK;
-    *valid = false;
-    if (dd->margin <= 0.f || dd->local_rebuilds_since >= 256) { /* still a collective below: every rank takes this path alike */ }
-    hipStream_t st = h->stream;
+    if (dd->spec_valid) {      // measured and all-reduced behind the chunk that went stale: the same word on every rank
+        dd->spec_valid = false;
+        *valid = dd_drift_allows_local_rebuild(dd, dd->spec_bits);
+        return MDX_OK;
+    }
     uint32_t* bits = (uint32_t*)dd->red;
-    HIP_TRY(hipMemsetAsync(bits, 0, sizeof(uint32_t), st));
-    if (h->in_slot_space)
-        hipLaunchKernelGGL(dd_drift_kernel, dim3(div_up(dd->n_local, 256)), dim3(256), 0, st, dd->n_local, dd->gid_local, h->d.slot_of,
-                           h->d.posq, dd->pos_at_part, make_part(dd), bits);
-    MDX_TRY(dd_comm_enter(h));
-    MDX_TRY(dd->tr->all_reduce(bits, 1, 1, dd->comm_stream));
+    MDX_TRY(dd_enqueue_drift_probe(h, bits));
     uint32_t b = 0;
-    HIP_TRY(hipMemcpyAsync(&b, bits, sizeof(uint32_t), hipMemcpyDeviceToHost, dd->comm_stream));
-    HIP_TRY(hipStreamSynchronize(dd->comm_stream));
-    float d2; std::memcpy(&d2, &b, 4);
-    *valid = dd->margin > 0.f && dd->local_rebuilds_since < 256 && std::sqrt(d2) <= 0.5f * dd->margin - 0.05f;
+    HIP_TRY(hipMemcpyAsync(&b, bits, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *valid = dd_drift_allows_local_rebuild(dd, b);
     return MDX_OK;
 }
 
@@ -668,7 +703,7 @@ void mdx_dd_destroy(mdx_handle* h) {
     if (dd->comm_stream && dd->comm_stream != h->stream) (void)hipStreamSynchronize(dd->comm_stream);
     void* ptrs[] = {dd->anchor, dd->g_pos, dd->g_vel, dd->g_frc, dd->cls, dd->owner, dd->shift_code, dd->send_mask, dd->flags, dd->scan,
                     dd->scan_sums, dd->gid_local, dd->ghost_local, dd->pos_l, dd->vel_l, dd->pos_at_part, dd->owned_gid, dd->send_ids,
-                    dd->recv_ids, dd->recv_shift, dd->send_buf, dd->recv_buf, dd->frc_send, dd->frc_recv, dd->gat_send, dd->gat_recv, dd->red};
+                    dd->recv_ids, dd->recv_shift, dd->send_buf, dd->recv_buf, dd->frc_send, dd->frc_recv, dd->gat_send, dd->gat_recv, dd->red, dd->drift_bits};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (dd->ev_packed) (void)hipEventDestroy(dd->ev_packed);
     if (dd->ev_arrived) (void)hipEventDestroy(dd->ev_arrived);
@@ -736,6 +771,52 @@ int mdx_dd_rescale_box(mdx_handle* h, const float hi[3], float mu) {
     MDX_TRY(mdx_rebuild(h));
     return MDX_OK;
 }
+// Host mutation of a joined handle.  The state is distributed, so a write goes through the replicated global arrays: gather what
+// the ranks hold, overwrite the rows the caller names (every rank is handed the same rows: the call is collective, like
+// mdx_step with external forces), and re-derive owners, ghosts and halo lists from the result - a repartition, ~1 ms at 1 M
+// atoms.  Correct for every caller the reference has (box packing moves atoms between MD phases, the docking loop between
+// single points); a pose loop that wants the single-GPU latency keeps its handle undecomposed.
+int mdx_dd_upload(mdx_handle* h, int which, uint32_t first, uint32_t count, const float4* host_rows) {
+    MdxDecomp* dd = h->dd;
+    MDX_TRY(mdx_dd_gather_global(h, false));
+    float4* dst = (which == MDX_POS ? dd->g_pos : dd->g_vel) + first;
+    HIP_TRY(hipMemcpyAsync(dst, host_rows, sizeof(float4) * (size_t)count, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->list_valid = false; h->forces_valid = false;
+    MDX_TRY(dd_partition(h));
+    MDX_TRY(mdx_rebuild(h));
+    h->moved_outside = true; h->prune_pending = true;
+    return MDX_OK;
+}
+
+__global__ void dd_scale_about_kernel(uint32_t N, float4* __restrict__ g_pos, float cx, float cy, float cz, float mx, float my, float mz) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float4 q = g_pos[i];      // (an affine map commutes with the periodic images: an atom held in its owner's frame stays consistent)
+    q.x = cx + mx * (q.x - cx); q.y = cy + my * (q.y - cy); q.z = cz + mz * (q.z - cz);
+    g_pos[i] = q;
+}
+// SimBox::new + rebuild on every rank alike; with centre / mu the gathered coordinates follow affinely first (shrink_cell_towards)
+int mdx_dd_set_box(mdx_handle* h, const float lo[3], const float hi[3], const float* centre_or_null, const float* mu_or_null) {
+    MdxDecomp* dd = h->dd;
+    MDX_TRY(mdx_dd_gather_global(h, false));
+    if (centre_or_null && mu_or_null) {
+        hipLaunchKernelGGL(dd_scale_about_kernel, dim3(div_up(h->N, 256)), dim3(256), 0, h->stream, h->N, dd->g_pos, centre_or_null[0],
+                           centre_or_null[1], centre_or_null[2], mu_or_null[0], mu_or_null[1], mu_or_null[2]);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int d = 0; d < 3; ++d) { h->box_lo[d] = lo[d]; h->box_hi[d] = hi[d]; }
+    dd_set_bricks(h);
+    MDX_TRY(dd_set_halo(h));
+    MDX_TRY(mdx_pme_setup(h));          // mesh spacing and theta(m) follow the box
+    h->list_valid = false; h->forces_valid = false;
+    MDX_TRY(dd_partition(h));
+    MDX_TRY(mdx_rebuild(h));
+    h->moved_outside = true; h->prune_pending = true;
+    return MDX_OK;
+}
+
 // Minimiser: the accepted state is kept as a copy of the gathered global arrays; a refused move goes back to it.
 int mdx_dd_save_global(mdx_handle* h, float4* backup /* [N] device */) {
     MDX_TRY(mdx_dd_gather_global(h, false));

@@ -234,8 +234,9 @@ __global__ void scale_positions_about_kernel(uint32_t N, float4* __restrict__ po
 extern "C" int mdx_shrink_cell_towards(mdx_handle* h, const float target_lo[3], const float target_hi[3],
                                        float shrink_per_step, int* shrank_out) {
     if (!h || !target_lo || !target_hi) FAIL(MDX_EPARAM, "null argument");
-    if (!h->periodic || !(h->per[0] && h->per[1] && h->per[2])) FAIL(MDX_EPARAM, "shrink_cell_towards needs a fully periodic box");
-    if (h->dd || h->n_local != h->N) FAIL(MDX_EPARAM, "shrink_cell_towards is not supported on a decomposed handle");
+    // (a rank of a cut box is not periodic locally in the cut dimensions: a joined handle's box is the global, fully periodic one)
+    if (!h->dd && (!h->periodic || !(h->per[0] && h->per[1] && h->per[2]))) FAIL(MDX_EPARAM, "shrink_cell_towards needs a fully periodic box");
+    if (!h->dd && h->n_local != h->N) FAIL(MDX_EPARAM, "shrink_cell_towards on a handle narrowed by mdx_set_local_atoms");
     if (!(shrink_per_step >= 0.f) || !std::isfinite(shrink_per_step)) FAIL(MDX_EPARAM, "shrink_per_step must be >= 0");
     float lo[3], hi[3], c[3], mu[3];
     bool shrank = false;
@@ -251,6 +252,14 @@ extern "C" int mdx_shrink_cell_towards(mdx_handle* h, const float target_lo[3], 
     if (shrank_out) *shrank_out = shrank ? 1 : 0;
     if (!shrank) return MDX_OK;
     HIP_TRY(hipSetDevice(h->device));
+    if (h->dd) {      // joined handle (collective): the same rule on every rank, the gathered coordinates follow, the ranks repartition
+        for (int d = 0; d < 3; ++d)
+            if (hi[d] - lo[d] < 2.0f * h->r_list) FAIL(MDX_EPARAM, "box edge shorter than 2*(cutoff+skin): minimum image is not unique");
+        h->e_cache_valid = false; h->e_pending = false;
+        MDX_TRY(mdx_dd_set_box(h, lo, hi, c, mu));
+        if (h->n_groups) h->cons_dirty = true;
+        return MDX_OK;
+    }
     MDX_TRY(mdx_check_box(h, lo, hi));   // refuse BEFORE touching the state (an edge below 2 (rc + skin))
     MDX_TRY(mdx_unsort_state(h));
     hipLaunchKernelGGL(scale_positions_about_kernel, dim3(div_up(h->n_local, 256)), dim3(256), 0, h->stream, h->n_local,
@@ -614,7 +623,9 @@ extern "C" int mdx_initialize_velocities(mdx_handle* h, float temperature, int z
     if (!h) FAIL(MDX_EPARAM, "null handle");
     if (!(temperature >= 0.f) || !std::isfinite(temperature)) FAIL(MDX_EPARAM, "temperature must be >= 0");
     h->e_cache_valid = false; h->e_pending = false;
-    if (h->dd || h->n_local != h->N) FAIL(MDX_EPARAM, "initialize_velocities on a decomposed handle (draw them before mdx_comm_init)");
+    // (joined handle: every rank draws the same stream - it is keyed by the seed and the atom's index - and mdx_upload, collective
+    // there, hands every owner its rows)
+    if (!h->dd && h->n_local != h->N) FAIL(MDX_EPARAM, "initialize_velocities on a handle narrowed by mdx_set_local_atoms");
     const uint32_t N = h->N;
     std::vector<float> v(3 * (size_t)N);
     std::vector<double> vd(3 * (size_t)N);

@@ -226,6 +226,8 @@ struct mdx_handle {
     bool vsites_convex = true;                         // every virtual site lies inside the triangle of its parents
     // SPME
     bool pme_on = false; int pme_K[3] = {0, 0, 0}; void* pme_plan = nullptr;  // opaque PmePlan
+    // the charge mesh is cleared BEHIND the chain that dirtied it (mdx_pme.hip), not in front of the next one
+    bool pme_canvas_clean = false, pme_canvas2_clean = false, pme_clear_pending = false;
     bool pme_overlap = false; hipStream_t stream_pme = nullptr; hipEvent_t ev_pme_fork = nullptr, ev_pme_join = nullptr;
     double ewald_self = 0.0, ewald_background = 0.0; double total_charge = 0.0, sum_q2 = 0.0;
     uint32_t n_mobile = 0;

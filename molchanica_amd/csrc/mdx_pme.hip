@@ -694,6 +694,7 @@ int mdx_pme_setup(mdx_handle* h) {
         for (void** q : {(void**)&h->d.pme_q, (void**)&h->d.pme_f, (void**)&h->d.pme_theta, (void**)&h->d.pme_q2, (void**)&h->d.pme_f2})
             if (*q) { (void)hipFree(*q); *q = nullptr; }
         HIP_TRY(hipMalloc((void**)&h->d.pme_q, sizeof(float) * p->n_real));
+        h->pme_canvas_clean = false; h->pme_canvas2_clean = false; h->pme_clear_pending = false;
         HIP_TRY(hipMalloc((void**)&h->d.pme_f, sizeof(float2) * p->n_cplx));
         HIP_TRY(hipMalloc((void**)&h->d.pme_theta, sizeof(float) * p->n_cplx));
         for (int d = 0; d < 3; ++d) h->pme_K[d] = K[d];
@@ -707,7 +708,11 @@ int mdx_pme_setup(mdx_handle* h) {
         const int env = e ? (e[0] == '0' ? 0 : 1) : -1;
         h->pme_overlap = !h->dd && (env >= 0 ? env == 1 : h->N >= 65536u);
         if (h->pme_overlap && !h->stream_pme) {
-            HIP_TRY(hipStreamCreateWithFlags(&h->stream_pme, hipStreamNonBlocking));
+            // (MDX_PME_PRIORITY=1: the chain's stream above the handle's - A/B; round 3 measured it 3 % slower)
+            static const bool prio = [] { const char* e = std::getenv("MDX_PME_PRIORITY"); return e && e[0] == '1'; }();
+            int lo_p = 0, hi_p = 0;
+            if (prio && hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) == hipSuccess) HIP_TRY(hipStreamCreateWithPriority(&h->stream_pme, hipStreamNonBlocking, hi_p));
+            else HIP_TRY(hipStreamCreateWithFlags(&h->stream_pme, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&h->ev_pme_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&h->ev_pme_join, hipEventDisableTiming));
         }
@@ -747,6 +752,21 @@ int mdx_pme_setup(mdx_handle* h) {
 // With h->pme_overlap the whole chain (spread, FFT, solve, FFT, gather) runs on a SIDE stream, forked before the pair
 // kernel and joined after the bonded gather (mdx_pme_fork / mdx_pme_join around them in compute_forces): the pair kernel
 // is VALU-bound, this chain is atomics- and bandwidth-bound.  The gather then writes to pme_force, added at the join.
+// The charge mesh must be zero when the spread starts.  Clearing it in FRONT of the spread put a 32 MB fill (200^3) at the head
+// of the reciprocal-space chain, on the side stream, where it competes with the pair kernel for the whole chip: the trace of the
+// reference's default operating point (1 M sites) showed it at ~0.45 ms per step - as long as spread and both FFTs together.  It
+// now runs BEHIND the chain that dirtied the mesh, after the event the step joins on: the fill overlaps the step's light tail
+// (bonded terms, constraints, the next drift) and the next chain starts on a clean mesh.
+static int pme_clear_behind(mdx_handle* h, hipStream_t st) {
+    if (!h->pme_clear_pending) return MDX_OK;
+    h->pme_clear_pending = false;
+    PmePlan* p = (PmePlan*)h->pme_plan;
+    HIP_TRY(hipMemsetAsync(h->d.pme_q, 0, sizeof(float) * p->n_real, st));
+    h->pme_canvas_clean = true;
+    if (h->alch_on && h->d.pme_q2) { HIP_TRY(hipMemsetAsync(h->d.pme_q2, 0, sizeof(float) * p->n_real, st)); h->pme_canvas2_clean = true; }
+    return MDX_OK;
+}
+
 int mdx_pme_fork(mdx_handle* h) {
     if (!h->pme_on || !h->pme_overlap) return MDX_OK;
     HIP_TRY(hipEventRecord(h->ev_pme_fork, h->stream));
@@ -757,6 +777,7 @@ int mdx_pme_join(mdx_handle* h, const uint32_t* d_gate, uint32_t thr) {
     if (!h->pme_on || !h->pme_overlap) return MDX_OK;
     HIP_TRY(hipEventRecord(h->ev_pme_join, h->stream_pme));
     HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_pme_join, 0));
+    MDX_TRY(pme_clear_behind(h, h->stream_pme));       // (behind the join event: the step does not wait for it)
     hipLaunchKernelGGL(pme_add_force_kernel, dim3(div_up(h->S, 256)), dim3(256), 0, h->stream, h->S, h->d.force,
                        h->d.pme_force, d_gate, thr);
     HIP_TRY(hipGetLastError());
@@ -773,13 +794,15 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
     const bool alch = h->alch_on;      // two meshes: environment in pme_q / pme_f, coupled molecule in pme_q2 / pme_f2
     if (alch && !h->d.pme_q2) {
         HIP_TRY(hipMalloc((void**)&h->d.pme_q2, sizeof(float) * p->n_real));
+        h->pme_canvas2_clean = false;
         HIP_TRY(hipMalloc((void**)&h->d.pme_f2, sizeof(float2) * p->n_cplx));
     }
     const float asc = (float)(1.0 - h->alch_lambda);
     static const bool per_atom_spread = [] { const char* e = std::getenv("MDX_PME_SPREAD_PER_ATOM"); return e && e[0] == '1'; }();
     if (p->slab.on && !alch) {      // decomposed handle: x-slabs of the mesh, one per rank (above)
         float* Q = h->d.pme_q;
-        HIP_TRY(hipMemsetAsync(Q, 0, sizeof(float) * p->n_real, st));
+        if (!h->pme_canvas_clean) HIP_TRY(hipMemsetAsync(Q, 0, sizeof(float) * p->n_real, st));
+        h->pme_canvas_clean = false;
         if (per_atom_spread || !h->in_slot_space)
             hipLaunchKernelGGL(pme_spread_kernel, dim3(div_up(h->S * 16u, 256)), dim3(256), 0, st, h->S, h->d.posq,
                                h->d.slot_flags, p->dev, Q, d_gate, thr, need, h->d.lj, 0);
@@ -790,12 +813,16 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
         hipLaunchKernelGGL(pme_gather_kernel<false>, dim3(div_up(h->S, 256)), dim3(256), 0, st, h->S, h->d.posq, h->d.slot_flags,
                            p->dev, h->d.pme_q, h->d.force, d_gate, thr, nullptr, h->d.lj, 1.f, 3u);
         HIP_TRY(hipGetLastError());
+        h->pme_clear_pending = true;
+        if (!h->pme_overlap) MDX_TRY(pme_clear_behind(h, st));
         return MDX_OK;
     }
     for (int grp = 0; grp < (alch ? 2 : 1); ++grp) {
         float* Q = grp ? h->d.pme_q2 : h->d.pme_q;
         const int sel = alch ? grp + 1 : 0;
-        HIP_TRY(hipMemsetAsync(Q, 0, sizeof(float) * p->n_real, st));
+        bool& clean = grp ? h->pme_canvas2_clean : h->pme_canvas_clean;
+        if (!clean) HIP_TRY(hipMemsetAsync(Q, 0, sizeof(float) * p->n_real, st));
+        clean = false;
         if (per_atom_spread || !h->in_slot_space)
             hipLaunchKernelGGL(pme_spread_kernel, dim3(div_up(h->S * 16u, 256)), dim3(256), 0, st, h->S, h->d.posq,
                                h->d.slot_flags, p->dev, Q, d_gate, thr, need, h->d.lj, sel);
@@ -831,5 +858,7 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
         hipLaunchKernelGGL(pme_gather_kernel<false>, dim3(div_up(h->S, 256)), dim3(256), 0, st, h->S, h->d.posq, h->d.slot_flags,
                            p->dev, h->d.pme_q, h->d.force, d_gate, thr, phi2, h->d.lj, asc);
     HIP_TRY(hipGetLastError());
+    h->pme_clear_pending = true;
+    if (!h->pme_overlap) MDX_TRY(pme_clear_behind(h, st));      // (on the handle's own stream: still behind the gather)
     return MDX_OK;
 }

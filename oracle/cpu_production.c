@@ -82,6 +82,14 @@ static int thread_count(void) {
 #endif
 }
 int cpu_prod_max_threads(void) { return thread_count(); }
+/* the host may be allowed fewer CPUs than it shows (a cgroup quota): bench.py sets the team to what it may really use */
+void cpu_prod_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 static uint64_t g_last_pairs = 0, g_last_lane_pairs = 0;   /* list pairs (atom pairs inside the list radius) evaluated by the last cpu_prod_run (all force passes); lane pairs of the cluster loop */
 uint64_t cpu_prod_last_pairs(void) { return g_last_pairs; }
 uint64_t cpu_prod_last_lane_pairs(void) { return g_last_lane_pairs; }

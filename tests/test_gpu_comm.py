@@ -378,17 +378,14 @@ def test_refusals_and_errors_on_decomposed_handles():
         md.comm_init_fabric(Fabric(1), 0)
         with pytest.raises(ParamError):
             md.comm_init_fabric(Fabric(1), 0)                 # already decomposed
-        # uploads are what is still refused: the state of a decomposed handle is distributed (set it before joining)
+        # (round 4: uploads, set_cell, shrink_cell_towards and initialize_velocities are served on a joined handle - the test
+        # below; what stays refused is nonsense input)
         with pytest.raises(ParamError):
-            md.set_positions(s.pos)
+            md.set_positions(np.full((s.n_atoms, 3), np.nan, np.float32))
         with pytest.raises(ParamError):
-            md.set_velocities(np.zeros((s.n_atoms, 3), np.float32))
+            md.set_positions_range(s.n_atoms - 1, s.pos[:3])        # range out of bounds
         with pytest.raises(ParamError):
-            md.set_positions_range(0, s.pos[:3])
-        with pytest.raises(ParamError):
-            md.set_cell(s.box_lo, s.box_hi)
-        with pytest.raises(ParamError):
-            md.initialize_velocities(300.0)
+            md.set_cell(s.box_lo, tuple(0.4 * np.array(s.box_hi)))  # shorter than 2 (rc + skin)
         md.step(0.0005, np.zeros((s.n_atoms, 3), np.float32), 1)   # external forces are served (test above)
         md.step(0.0005, None, 5)                               # a one-rank decomposition just runs
         assert md.step_count == 6
@@ -396,6 +393,56 @@ def test_refusals_and_errors_on_decomposed_handles():
     with MdState(small, MdConfig(**CFG)) as md:
         with pytest.raises(ParamError, match="two images|too small"):
             md.comm_init_fabric(Fabric(2), 0)
+
+
+def test_host_mutation_on_decomposed_handles():
+    """`md.atoms[i].posit = ..; md.rebuild_spatial_caches()` and friends on N GPUs (/root/reference
+    src/properties/sol_shrinking_box.rs:599-632, :962-995; the docking pose loop src/docking/mod.rs:235): uploads of
+    positions / velocities, pose updates of an atom range, set_cell, shrink_cell_towards and initialize_velocities on a
+    joined handle are collective calls and leave the box in the state the same calls leave ONE GPU in - every energy term,
+    the gathered forces, and a trajectory from there."""
+    from molchanica_amd.md_state import MdState
+    s = systems.small_solvated(n_chain=300, box=44.0)
+    cfg = MdConfig(**CFG)
+    lig = slice(20, 70)
+    rng = np.random.default_rng(11)
+    poses = [(rng.normal(0, 0.4, 3) + rng.normal(0, 0.02, (50, 3))).astype(np.float32) for _ in range(3)]
+    L = np.array(s.box_hi, dtype=np.float64)
+
+    def script(md):
+        out = []
+        p0 = md.positions()
+        for dp in poses:                                   # pose after pose: only the 50 "ligand" atoms move
+            q = p0[lig] + dp
+            md.set_positions_range(lig.start, q)
+            out.append(("pose", md.energy(), md.forces().astype(np.float64)))
+        p = md.positions()
+        md.set_positions((p * np.float32(0.995)).astype(np.float32))     # the caller scales, then tells the cell (SimBox::new + rebuild)
+        md.set_cell((0, 0, 0), tuple(L * 0.995))
+        out.append(("set_cell", md.energy(), md.forces().astype(np.float64)))
+        shrank = md.shrink_cell_towards((0, 0, 0), tuple(L * 0.98), 0.05)
+        assert shrank
+        out.append(("shrink", md.energy(), md.forces().astype(np.float64)))
+        md.initialize_velocities(250.0, True, seed=7)
+        v = md.velocities()
+        md.set_velocities((v * np.float32(0.5)).astype(np.float32))
+        md.step(0.0005, None, 20)
+        out.append(("steps", md.energy(), md.positions().astype(np.float64)))
+        return out
+
+    with MdState(s, cfg) as md:
+        ref = script(md)
+    res = _run_ranks_fn(s, cfg, 4, script)
+    for r in range(4):
+        for (name, e1, a1), (_, e0, a0) in zip(res[r], ref):
+            for k in ("lj", "coulomb", "bond", "angle", "dihedral", "lj14", "coulomb14", "kinetic"):
+                assert abs(e1[k] - e0[k]) <= max(2e-2, 3e-6 * abs(e0[k])), (r, name, k, e1[k], e0[k])
+            if name == "steps":
+                Ls = L * 0.995 - 0.05       # (the cell after set_cell and one shrink step)
+                assert rms_dev(a1, a0, Ls) < 2e-3, (r, name)
+            else:
+                df = np.linalg.norm(a1 - a0, axis=1)
+                assert (df <= 2e-4 * np.maximum(np.linalg.norm(a0, axis=1), 1.0) + 2e-4).all(), (r, name, float(df.max()))
 
 
 def _run_ranks_fn(system, cfg, world, fn):

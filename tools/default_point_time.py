@@ -10,7 +10,9 @@ inner = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0      # dual-list buffer
 skin = float(sys.argv[3]) if len(sys.argv) > 3 else 2.0
 pre = int(sys.argv[4]) if len(sys.argv) > 4 else 300         # untimed steps at the operating point (the library's dual-list tuning settles within ~1500)
 s = systems.opc_water_box(n_side, seed=5)
-for name, cfg in (("SPME", MdConfig(coulomb_mode=2, ewald_alpha=0.3, overrides=0, inner_skin=inner, skin=skin)), ("cutoff (reaction field)", MdConfig(coulomb_mode=1, inner_skin=inner, skin=skin))):
+cases = (("SPME", MdConfig(coulomb_mode=2, ewald_alpha=0.3, overrides=0, inner_skin=inner, skin=skin)), ("cutoff (reaction field)", MdConfig(coulomb_mode=1, inner_skin=inner, skin=skin)))
+if os.environ.get("DP_ONLY") == "spme": cases = cases[:1]
+for name, cfg in cases:
     with MdState(s, cfg) as md:
         md.minimize_energy(100); md.initialize_velocities(300.0, True, seed=1)
         md.set_thermostat(1, 300.0, 0.02, 1); md.step(0.001, None, 1500)       # untimed: the random-orientation lattice relaxes
