@@ -127,7 +127,9 @@ typedef struct mdx_system {
 typedef struct mdx_config {
     float    lj_cutoff;        /* Å; <=0 or inf: no cutoff (vacuum only)       [ref: md.rs:252-261] */
     float    coulomb_cutoff;   /* Å                                                               */
-    float    skin;             /* Å Verlet buffer; lists rebuilt when max displacement > skin/2   */
+    float    skin;             /* Å Verlet buffer; lists rebuilt when max displacement > skin/2.  0 (periodic, single device) = the
+                                  library chooses: it starts at 2 Å and walks to the skin with the best MEASURED step rate (fewer
+                                  rebuilds against more listed pairs; forces do not depend on it).  mdx_get_skin reads it.   */
     float    coulomb_k;        /* 332.0637 kcal·Å/(mol·e²)                                        */
     float    scale14_lj;       /* 0.5     (Amber 1/2.0)                                           */
     float    scale14_coulomb;  /* 0.8333… (Amber 1/1.2)                                           */
@@ -282,6 +284,8 @@ const char* mdx_constraint_description(mdx_handle* h);
  * step loop least). */
 int mdx_profile(mdx_handle* h, int enable);
 int mdx_get_stats(mdx_handle* h, mdx_stats* out);
+/* The Verlet skin in force, and whether the library is still tuning it (mdx_config.skin == 0). */
+int mdx_get_skin(const mdx_handle* h, float* skin, int* tuning);
 
 /* ---- callers either side of `step` -----------------------------------------------
  * The reference reaches these through the same MdState: `md.minimize_energy(dev, iters, ext)`

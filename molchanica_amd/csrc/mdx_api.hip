@@ -180,7 +180,13 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
     MDX_TRY(check_box(h->per, h->box_lo, h->box_hi, c));
     h->n_local = N; h->cap_local = N;
     const bool all_cut = cut_on(c->lj_cutoff) && cut_on(c->coulomb_cutoff);
-    h->r_list = all_cut ? std::max(c->lj_cutoff, c->coulomb_cutoff) + c->skin : INFINITY;
+    if (c->skin == 0.f && all_cut && h->periodic) {      // the library chooses (and tunes, mdx_step): start from the usual 2 A, or what the box allows
+        float s0 = 2.0f;
+        for (int d = 0; d < 3; ++d)
+            if (h->per[d]) s0 = std::min(s0, 0.5f * (h->box_hi[d] - h->box_lo[d]) - std::max(c->lj_cutoff, c->coulomb_cutoff) - 0.01f);
+        if (s0 >= 0.5f) { h->cfg.skin = s0; h->skin_tune.on = true; h->skin_tune.base_skin = s0; MDX_TRY(check_box(h->per, h->box_lo, h->box_hi, &h->cfg)); }
+    }
+    h->r_list = all_cut ? std::max(c->lj_cutoff, c->coulomb_cutoff) + h->cfg.skin : INFINITY;
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) FAIL(MDX_EDEVICE, "no HIP device available");
@@ -580,6 +586,59 @@ void mdx_prof_collect(mdx_handle* h, int first_stale_step) {
     h->ev_pending.clear();
 }
 
+// mdx_config.skin == 0: the Verlet skin is the library's to choose.  A larger skin means fewer list rebuilds and more listed
+// pairs on every step; where the balance lies depends on the time step, the temperature and on what else the step holds (at the
+// reference's default operating point - rigid water, dt 2 fs - the list goes stale every 4-5 steps at 2 A).  No model: the step
+// rate is MEASURED over windows of >= 12 rebuilds (>= 400 steps) at the current skin, then at 0.5 A less; while that is > 3 %
+// faster the walk goes on downwards in 0.25 A steps (not below 0.75 A), else it tries upwards in 0.5 A steps while the box
+// allows (edge >= 2 (cutoff + skin)); the best stays.  Forces do not depend on the skin, so nothing but speed changes.  Single
+// device only: ranks of a decomposed handle would have to agree, and their clocks do not.
+static void skin_apply(mdx_handle* h, float s) {
+    h->cfg.skin = s;
+    h->r_list = std::max(h->cfg.lj_cutoff, h->cfg.coulomb_cutoff) + s;
+    h->list_valid = false;
+    h->inner_skin_auto = 0.f; h->dual_auto_off = false; h->dual_win_steps = 0; h->dual_win_prunes = 0;
+    h->stretch_samples = 0;
+    h->skin_tune.win_steps = 0; h->skin_tune.win_rebuilds = 0; h->skin_tune.skip_rebuilds = 2;     // (the first lists at a new radius may regrow their arrays)
+}
+static bool skin_fits(const mdx_handle* h, float s) {
+    for (int d = 0; d < 3; ++d)
+        if (h->per[d] && h->box_hi[d] - h->box_lo[d] < 2.0f * (std::max(h->cfg.lj_cutoff, h->cfg.coulomb_cutoff) + s)) return false;
+    return true;
+}
+static void skin_autotune(mdx_handle* h, uint32_t done, bool stale_hit) {
+    mdx_handle::SkinTune& t = h->skin_tune;
+    const auto now = std::chrono::steady_clock::now();
+    if (t.phase == 0) {      // warm-up: lists, arrays and the dual-list tuning settle
+        t.warm_steps += done;
+        if (t.warm_steps >= 200) { t.phase = 1; t.win_steps = 0; t.win_rebuilds = 0; t.skip_rebuilds = 1; }
+        return;
+    }
+    if (t.skip_rebuilds) { if (stale_hit && --t.skip_rebuilds == 0) { t.t0 = now; t.win_steps = 0; t.win_rebuilds = 0; } return; }
+    t.win_steps += done; t.win_rebuilds += stale_hit ? 1u : 0u;
+    if (!((t.win_rebuilds >= 12 && t.win_steps >= 400 && stale_hit) || t.win_steps >= 6000)) return;     // (windows end ON a rebuild: whole stretches)
+    const double rate = (double)t.win_steps / std::chrono::duration<double>(now - t.t0).count();
+    const float cur = h->cfg.skin;
+    auto finish = [&]() { t.phase = 4; if (h->cfg.skin != t.best_skin) skin_apply(h, t.best_skin); };
+    if (t.phase == 1) {
+        t.base_rate = t.best_rate = rate; t.base_skin = t.best_skin = cur;
+        if (cur - 0.5f >= 0.75f) { t.phase = 2; skin_apply(h, cur - 0.5f); }
+        else if (skin_fits(h, cur + 0.5f)) { t.phase = 3; skin_apply(h, cur + 0.5f); }
+        else t.phase = 4;
+    } else if (t.phase == 2) {
+        if (rate > t.best_rate * 1.03) {
+            t.best_rate = rate; t.best_skin = cur;
+            if (cur - 0.25f >= 0.75f) skin_apply(h, cur - 0.25f); else finish();
+        } else if (t.best_skin == t.base_skin && skin_fits(h, t.base_skin + 0.5f)) { t.phase = 3; skin_apply(h, t.base_skin + 0.5f); }
+        else finish();
+    } else if (t.phase == 3) {
+        if (rate > t.best_rate * 1.03) {
+            t.best_rate = rate; t.best_skin = cur;
+            if (skin_fits(h, cur + 0.5f) && cur + 0.5f <= 4.0f) skin_apply(h, cur + 0.5f); else finish();
+        } else finish();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32_t n_steps) {
     if (!h) FAIL(MDX_EPARAM, "null handle");
@@ -608,7 +667,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
     // inner list.  Otherwise the inner list of the last call is still exact and a 10-step GUI burst does not pay a pruning
     // pass (+0.17 ms at 1 M atoms) at its start.
     if (h->moved_outside) { h->prune_pending = true; h->moved_outside = false; }
-    const uint32_t thr = stale_threshold_bits(h);
+    uint32_t thr = stale_threshold_bits(h);      // (the skin tuning below may change it between chunks)
     uint32_t remaining = n_steps;
     while (remaining) {
         MDX_TRY(ensure_ready(h));   // a barostat application at the last cadence point left the list to rebuild
@@ -778,6 +837,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
                 }
             }
         }
+        if (h->skin_tune.on && h->skin_tune.phase < 4 && !h->dd) { skin_autotune(h, done, stale_hit); thr = stale_threshold_bits(h); }
         h->steps_since_rebuild = stale_hit ? 0u : h->steps_since_rebuild + done;
         h->forces_valid = true;
         h->e_pending = want_e && done == chunk;
@@ -1207,6 +1267,13 @@ extern "C" int mdx_profile(mdx_handle* h, int enable) {
         h->stats.nb_launches = h->stats.bonded_launches = h->stats.integ_launches = 0;
         if (h->dd) for (int k = 0; k < MDX_DIAG_PHASES; ++k) { h->dd->phase_ms[k] = 0.0; h->dd->phase_n[k] = 0; }
     }
+    return MDX_OK;
+}
+
+extern "C" int mdx_get_skin(const mdx_handle* h, float* skin, int* tuning) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    if (skin) *skin = h->cfg.skin;
+    if (tuning) *tuning = (h->skin_tune.on && h->skin_tune.phase < 4) ? 1 : 0;
     return MDX_OK;
 }
 

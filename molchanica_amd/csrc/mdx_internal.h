@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <chrono>
 #include <string>
 #include <vector>
 #include "../../include/mdx.h"
@@ -227,7 +228,7 @@ struct mdx_handle {
     // SPME
     bool pme_on = false; int pme_K[3] = {0, 0, 0}; void* pme_plan = nullptr;  // opaque PmePlan
     // the charge mesh is cleared BEHIND the chain that dirtied it (mdx_pme.hip), not in front of the next one
-    bool pme_canvas_clean = false, pme_canvas2_clean = false, pme_clear_pending = false;
+    bool pme_canvas_clean = false, pme_canvas2_clean = false, pme_clear_pending = false, pme_block_spread_used = false, pme_spread_main = false;
     bool pme_overlap = false; hipStream_t stream_pme = nullptr; hipEvent_t ev_pme_fork = nullptr, ev_pme_join = nullptr;
     double ewald_self = 0.0, ewald_background = 0.0; double total_charge = 0.0, sum_q2 = 0.0;
     uint32_t n_mobile = 0;
@@ -271,6 +272,14 @@ struct mdx_handle {
     // step loop: length of the rebuild-free stretches (steps), so that a chunk ends near the step the list is expected to go
     // stale at instead of enqueueing up to chunk_steps - 1 launches the device then gates off
     uint32_t steps_since_rebuild = 0, stretch_samples = 0; float stretch_mean = 0.f, stretch_dev = 0.f;
+    // Verlet skin chosen by the library (mdx_config.skin == 0): hill-climb on the measured step rate over windows of several
+    // rebuilds (mdx_step).  The skin only decides which pairs are LISTED; forces and trajectories do not depend on it.
+    struct SkinTune {
+        bool on = false; int phase = 0;          // 0 warm-up, 1 measuring the base, 2 walking down, 3 walking up, 4 done
+        float base_skin = 2.f, best_skin = 2.f, trial = 2.f; double base_rate = 0.0, best_rate = 0.0;
+        uint32_t win_steps = 0, win_rebuilds = 0, skip_rebuilds = 0, warm_steps = 0;
+        std::chrono::steady_clock::time_point t0;
+    } skin_tune;
     int chunk_s = -1;            // decomposed driver: chunk step whose drift has been enqueued (its prune word is shared by the halo unpack)
     // state flags
     bool list_valid = false;    // spatial caches match the slot-space state

@@ -204,6 +204,121 @@ __global__ __launch_bounds__(256) void pme_spread_tile_kernel(uint32_t T, const 
     }
 }
 
+// Block-owned spread (round 4; single-GPU periodic handles in slot space: the default there).  The tile kernel above still ends in
+// ~2200 memory-side f32 atomics per tile - 36 M per step at 1 M sites, 0.14 ms at the rate gfx950 retires them, 0.22-0.29 ms
+// measured - and needs a cleared mesh.  Here a workgroup OWNS a 16^3 block of mesh points: it finds the tiles whose atoms can
+// reach the block (the tile / column / z-bin tables of the list build, widened by what atoms may have moved since), walks
+// them 64 atoms at a time with the tile kernel's lane mapping (atom = tid >> 2, y offset = tid & 3, 4 x 4 points each),
+// accumulates only the points inside its block in LDS, and STORES the block - every mesh point is written exactly once per
+// step by plain coalesced stores: no global atomic, no fill.  The spline weights of an atom are evaluated by every block its
+// support touches (2-3 on average): arithmetic, not memory.
+constexpr int PME_BB = 16;                 // owned block edge (mesh points)
+constexpr int PME_BB_MAXTILES = 512;       // candidate tiles of a block (a 19 A cube + drift holds ~40)
+struct PmeBlockArgs {
+    uint32_t T; int nbk[3];                // tiles; blocks per dimension
+    GridParams g; const uint32_t* tile_start; const uint32_t* cell_start;
+    float reach;                           // how far an atom may be from where the rebuild binned it (A)
+    const float4* posq; const uint8_t* slot_flags; const float2* lj; PmeDev pg; float* Q;
+    const uint32_t* gate; uint32_t thr; uint32_t need; int sel;
+    uint32_t* err;
+};
+__global__ __launch_bounds__(256) void pme_spread_block_kernel(PmeBlockArgs a) {
+    if (a.gate && *a.gate > a.thr) return;
+    __shared__ float s_q[PME_BB * PME_BB * PME_BB];
+    __shared__ uint32_t s_tiles[PME_BB_MAXTILES];
+    __shared__ uint32_t s_nt;
+    const int tid = threadIdx.x;
+    const int bz = blockIdx.x % a.nbk[2], by = (blockIdx.x / a.nbk[2]) % a.nbk[1], bx = blockIdx.x / (a.nbk[2] * a.nbk[1]);
+    const int b0[3] = {bx * PME_BB, by * PME_BB, bz * PME_BB};
+    for (int k = tid; k < PME_BB * PME_BB * PME_BB; k += 256) s_q[k] = 0.f;
+    if (tid == 0) s_nt = 0u;
+    __syncthreads();
+    // ---- candidate tiles: columns and z-bins that can hold an atom whose 4-point support touches the block ----
+    // an atom at mesh coordinate u touches points floor(u) - 3 .. floor(u): it reaches the block for u in [b0, b0 + BB + 3)
+    const GridParams& g = a.g;
+    float lo_a[3], hi_a[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        lo_a[d] = a.pg.lo[d] + (float)b0[d] / a.pg.scale[d] - a.reach;
+        hi_a[d] = a.pg.lo[d] + (float)(b0[d] + PME_BB + 3) / a.pg.scale[d] + a.reach;
+    }
+    int ix0 = (int)floorf((lo_a[0] - g.lo[0]) * g.inv_col[0]), ix1 = (int)floorf((hi_a[0] - g.lo[0]) * g.inv_col[0]);
+    int iy0 = (int)floorf((lo_a[1] - g.lo[1]) * g.inv_col[1]), iy1 = (int)floorf((hi_a[1] - g.lo[1]) * g.inv_col[1]);
+    if (ix1 - ix0 + 1 > g.ncx) { ix0 = 0; ix1 = g.ncx - 1; }        // every column once
+    if (iy1 - iy0 + 1 > g.ncy) { iy0 = 0; iy1 = g.ncy - 1; }
+    int zb0 = (int)floorf((lo_a[2] - g.lo[2]) * g.inv_zbin) - 1, zb1 = (int)floorf((hi_a[2] - g.lo[2]) * g.inv_zbin) + 1;
+    const bool zall = zb1 - zb0 + 1 >= g.nzb;
+    const int nxr = ix1 - ix0 + 1, nyr = iy1 - iy0 + 1;
+    for (int c = tid; c < nxr * nyr; c += 256) {
+        int wx = (ix0 + c / nyr) % g.ncx; if (wx < 0) wx += g.ncx;
+        int wy = (iy0 + c % nyr) % g.ncy; if (wy < 0) wy += g.ncy;
+        const uint32_t col = (uint32_t)(wx * g.ncy + wy);
+        const uint32_t t0 = a.tile_start[col], t1 = a.tile_start[col + 1];
+        if (t1 <= t0) continue;
+        uint32_t rA = t0, rB = t1, sA = 0, sB = 0;            // two tile ranges (the z-window may wrap around the box)
+        if (!zall) {
+            const uint32_t* cs = a.cell_start + (size_t)col * g.nzb;
+            auto range = [&](int z0, int z1, uint32_t* ta, uint32_t* tb) {
+                const uint32_t aA = cs[z0] - cs[0], aB = cs[z1 + 1] - cs[0];
+                if (aB <= aA) { *ta = 0; *tb = 0; return; }
+                *ta = t0 + aA / MDX_TILE; *tb = min(t1, t0 + (aB + MDX_TILE - 1) / MDX_TILE);
+            };
+            range(max(zb0, 0), min(zb1, g.nzb - 1), &rA, &rB);
+            if (zb0 < 0) range(zb0 + g.nzb, g.nzb - 1, &sA, &sB);
+            else if (zb1 >= g.nzb) range(0, zb1 - g.nzb, &sA, &sB);
+            if (sB > sA && rB > rA && sA < rB && rA < sB) { rA = min(rA, sA); rB = max(rB, sB); sA = sB = 0; }    // overlapping: one range
+        }
+        const uint32_t n = (rB - rA) + (sB - sA);
+        if (!n) continue;
+        const uint32_t at = atomicAdd(&s_nt, n);
+        if (at + n > (uint32_t)PME_BB_MAXTILES) { atomicOr(a.err, 64u); continue; }
+        uint32_t w = at;
+        for (uint32_t t = rA; t < rB; ++t) s_tiles[w++] = t;
+        for (uint32_t t = sA; t < sB; ++t) s_tiles[w++] = t;
+    }
+    __syncthreads();
+    const uint32_t nt = min(s_nt, (uint32_t)PME_BB_MAXTILES);
+    const int atom = tid >> 2, b = tid & 3;
+    for (uint32_t it = 0; it < nt; ++it) {
+        const uint32_t slot = s_tiles[it] * MDX_TILE + (uint32_t)atom;
+        const float4 p = a.posq[slot];
+        const bool live = ((a.slot_flags[slot] & a.need) == a.need) && p.w != 0.f &&
+                          (!a.sel || ((__float_as_int(a.lj[slot].y) < 0) == (a.sel == 2)));
+        if (!live) continue;
+        int k0[3]; float w[3];
+        mesh_coords(p, a.pg, k0, w);                        // wrapped: k0 = floor(u) - 3 in [-3, K - 3]
+        // this lane's y point, and which of the four x / z points fall into the block
+        int ly = k0[1] + b; if (ly < 0) ly += a.pg.K[1];
+        ly -= b0[1];
+        if ((unsigned)ly >= (unsigned)PME_BB) continue;
+        int lx[4], lz[4]; bool anyx = false, anyz = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int kx = k0[0] + q; if (kx < 0) kx += a.pg.K[0];
+            int kz = k0[2] + q; if (kz < 0) kz += a.pg.K[2];
+            lx[q] = kx - b0[0]; lz[q] = kz - b0[2];
+            anyx |= (unsigned)lx[q] < (unsigned)PME_BB; anyz |= (unsigned)lz[q] < (unsigned)PME_BB;
+        }
+        if (!anyx || !anyz) continue;
+        float mx[4], my[4], mz[4], dd[4];
+        bspline4(w[0], mx, dd); bspline4(w[1], my, dd); bspline4(w[2], mz, dd);
+        const float qy = p.w * my[b];
+#pragma unroll
+        for (int qa = 0; qa < 4; ++qa) {
+            if ((unsigned)lx[qa] >= (unsigned)PME_BB) continue;
+#pragma unroll
+            for (int qc = 0; qc < 4; ++qc)
+                if ((unsigned)lz[qc] < (unsigned)PME_BB) atomicAdd(&s_q[(lx[qa] * PME_BB + ly) * PME_BB + lz[qc]], qy * mx[qa] * mz[qc]);
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < PME_BB * PME_BB * PME_BB; k += 256) {
+        const int lz = k % PME_BB, ly = (k / PME_BB) % PME_BB, lx = k / (PME_BB * PME_BB);
+        const int kx = b0[0] + lx, ky = b0[1] + ly, kz = b0[2] + lz;
+        if (kx < a.pg.K[0] && ky < a.pg.K[1] && kz < a.pg.K[2]) a.Q[((size_t)kx * a.pg.K[1] + ky) * a.pg.K[2] + kz] = s_q[k];
+    }
+}
+
 template <bool ENERGY>
 __global__ __launch_bounds__(256) void pme_solve_kernel(size_t n, int K1, int K2, int K3h, int K3, float3 inv_len,
                                                         float pi2_over_beta2, float2* __restrict__ F,
@@ -705,8 +820,12 @@ int mdx_pme_setup(mdx_handle* h) {
         // more than running it beside the pair kernel hides (23 k sites: 5730 steps/s on one stream, 4920 on two;
         // 131 k sites: 2410 / 2560) - small systems keep everything on the handle's stream.  MDX_PME_OVERLAP=1 / 0 forces.
         const char* const e = std::getenv("MDX_PME_OVERLAP");      // read at every setup: a test can choose per handle
-        const int env = e ? (e[0] == '0' ? 0 : 1) : -1;
-        h->pme_overlap = !h->dd && (env >= 0 ? env == 1 : h->N >= 65536u);
+        const int env = e ? (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)) : -1;
+        h->pme_overlap = !h->dd && (env >= 0 ? env >= 1 : h->N >= 65536u);
+        // MDX_PME_OVERLAP=2 (A/B): the charge spread stays on the handle's stream, in FRONT of the pair kernel, and only the rest
+        // of the chain (FFTs, solve, gather) runs beside it: spread and pair kernel both live on the LDS pipeline (ds_add_f32 /
+        // the staged j-atoms) and run no faster side by side than one after the other
+        h->pme_spread_main = h->pme_overlap && env == 2;
         if (h->pme_overlap && !h->stream_pme) {
             // (MDX_PME_PRIORITY=1: the chain's stream above the handle's - A/B; round 3 measured it 3 % slower)
             static const bool prio = [] { const char* e = std::getenv("MDX_PME_PRIORITY"); return e && e[0] == '1'; }();
@@ -760,6 +879,8 @@ int mdx_pme_setup(mdx_handle* h) {
 static int pme_clear_behind(mdx_handle* h, hipStream_t st) {
     if (!h->pme_clear_pending) return MDX_OK;
     h->pme_clear_pending = false;
+    if (h->pme_block_spread_used) return MDX_OK;       // the block-owned spread stores every point: nothing to clear
+    if (h->pme_spread_main) return MDX_OK;             // (the spread runs on the handle's stream: it clears in front of itself, alone on the chip)
     PmePlan* p = (PmePlan*)h->pme_plan;
     HIP_TRY(hipMemsetAsync(h->d.pme_q, 0, sizeof(float) * p->n_real, st));
     h->pme_canvas_clean = true;
@@ -787,7 +908,7 @@ int mdx_pme_join(mdx_handle* h, const uint32_t* d_gate, uint32_t thr) {
 int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr) {
     if (!h->pme_on) return MDX_OK;
     PmePlan* p = (PmePlan*)h->pme_plan;
-    hipStream_t st = h->pme_overlap ? h->stream_pme : h->stream;
+    hipStream_t st = h->pme_overlap ? h->stream_pme : h->stream;      // (non-const: MDX_PME_OVERLAP=2 spreads on the handle's stream)
     const int K3h = h->pme_K[2] / 2 + 1;
     const uint32_t need = h->dd ? 3u : 1u;              // decomposed: every rank spreads the charges it OWNS ...
     const double escale = h->dd ? 1.0 / (double)h->dd->world : 1.0;
@@ -821,6 +942,29 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
         float* Q = grp ? h->d.pme_q2 : h->d.pme_q;
         const int sel = alch ? grp + 1 : 0;
         bool& clean = grp ? h->pme_canvas2_clean : h->pme_canvas_clean;
+        const hipStream_t st_chain = st;
+        const bool spread_main = h->pme_overlap && h->pme_spread_main;
+        if (spread_main) st = h->stream;
+        // block-owned spread (MDX_PME_SPREAD_BLOCK=1; measured round 4 and NOT the default): every mesh point is stored by the
+        // workgroup that owns it - no clear, no global atomics - and yet no faster: 317 us per launch against the tile kernel's 293
+        // at 1 M sites (both are bound by their per-workgroup chain of LDS phases, not by the memory-side atomics), and slower on small
+        // meshes (a 56^3 mesh is 64 blocks)
+        static const bool block_env = [] { const char* e = std::getenv("MDX_PME_SPREAD_BLOCK"); return e && e[0] == '1'; }();
+        const bool block_spread = block_env && !per_atom_spread && h->in_slot_space && !h->dd && h->n_local == h->N &&
+                                  h->per[0] && h->per[1] && h->per[2] && h->grid.npop == 1 && std::isfinite(h->r_list);
+        if (block_spread) {
+            PmeBlockArgs ba{};
+            ba.T = h->T; ba.g = h->grid; ba.tile_start = h->d.tile_start; ba.cell_start = h->d.cell_start;
+            for (int d = 0; d < 3; ++d) ba.nbk[d] = (h->pme_K[d] + PME_BB - 1) / PME_BB;
+            // since the rebuild binned it an atom has moved at most skin / 2 (the stale trigger) + what one step adds before the
+            // trigger is read + a constraint projection / a virtual site's reach from its parents
+            ba.reach = 0.5f * h->cfg.skin + 0.75f;
+            ba.posq = h->d.posq; ba.slot_flags = h->d.slot_flags; ba.lj = h->d.lj; ba.pg = p->dev; ba.Q = Q;
+            ba.gate = d_gate; ba.thr = thr; ba.need = need; ba.sel = sel; ba.err = h->d.flags_dev;
+            hipLaunchKernelGGL(pme_spread_block_kernel, dim3((unsigned)(ba.nbk[0] * ba.nbk[1] * ba.nbk[2])), dim3(256), 0, st, ba);
+            clean = false; h->pme_block_spread_used = true;
+        } else {
+        h->pme_block_spread_used = false;
         if (!clean) HIP_TRY(hipMemsetAsync(Q, 0, sizeof(float) * p->n_real, st));
         clean = false;
         if (per_atom_spread || !h->in_slot_space)
@@ -829,6 +973,12 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
         else
             hipLaunchKernelGGL(pme_spread_tile_kernel, dim3(h->T), dim3(256), 0, st, h->T, h->d.posq, h->d.slot_flags, p->dev,
                                Q, d_gate, thr, need, h->d.lj, sel);
+        }
+        if (spread_main) {      // the rest of the chain leaves for the side stream here
+            HIP_TRY(hipEventRecord(h->ev_pme_fork, h->stream));
+            HIP_TRY(hipStreamWaitEvent(st_chain, h->ev_pme_fork, 0));
+            st = st_chain;
+        }
         // decomposed handle: the meshes are summed over the ranks - a replicated mesh, every rank then solves it and
         // interpolates the forces of its own atoms (the all-reduce is ungated: a collective must be entered by every rank alike)
         if (h->dd && h->dd->world > 1) MDX_TRY(mdx_dd_allreduce_f32(h, Q, p->n_real, st));

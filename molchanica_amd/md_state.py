@@ -83,6 +83,7 @@ def load_library():
     lib.mdx_neighbor_list.argtypes = [H, _u32p, _u32p]
     lib.mdx_profile.argtypes = [H, C.c_int]
     lib.mdx_get_stats.argtypes = [H, C.POINTER(CStats)]
+    lib.mdx_get_skin.argtypes = [H, _fp, C.POINTER(C.c_int)]
     lib.mdx_minimize_energy.argtypes = [H, C.c_uint32, _fp, C.c_float, C.POINTER(CEnergies), _u32p]
     lib.mdx_initialize_velocities.argtypes = [H, C.c_float, C.c_int, C.c_uint64]
     lib.mdx_set_thermostat.argtypes = [H, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_uint64]
@@ -405,6 +406,12 @@ class MdState:
         s = CStats()
         _check(load_library().mdx_get_stats(self._h, C.byref(s)))
         return s.as_dict()
+
+    def skin(self):
+        """-> (Verlet skin in force, still tuning?)  (MdConfig.skin == 0 lets the library choose it)."""
+        v, t = C.c_float(), C.c_int()
+        _check(load_library().mdx_get_skin(self._h, C.byref(v), C.byref(t)))
+        return float(v.value), bool(t.value)
 
     def computation_time(self) -> float:
         """`md.computation_time()` (src/md/mod.rs:740-743): ms spent inside step calls."""

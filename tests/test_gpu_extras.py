@@ -280,3 +280,28 @@ def test_shrink_cell_towards_matches_the_oracle(mdx, orc):
         with pytest.raises(mdx.ParamError):
             md.shrink_cell_towards(c - 5.0, c + 5.0, 20.0)
         assert np.allclose(np.asarray(md.cell()[1]) - np.asarray(md.cell()[0]), 26.0, atol=1e-3)
+
+
+def test_library_chosen_verlet_skin(mdx):
+    """`MdConfig.skin = 0`: the library starts at 2 A (or what the box allows) and walks to the skin with the best measured step
+    rate (mdx_step, skin_autotune).  The skin only decides which pairs are LISTED: the dynamics must be those of a fixed-skin
+    run - same energy conservation, same temperature - whatever the tuner does, and the tuning must end."""
+    s = systems.water_box(10, seed=3)              # 31 A box: room for skins up to ~4 A at rc 7
+    base = dict(lj_cutoff=7.0, coulomb_cutoff=7.0, coulomb_mode=1)
+    out = {}
+    for name, skin in (("fixed", 1.5), ("auto", 0.0)):
+        with mdx.MdState(s, MdConfig(skin=skin, **base)) as md:
+            md.minimize_energy(50); md.initialize_velocities(300.0, True, seed=4)
+            md.step(0.0005, None, 200)
+            e0 = md.energy()
+            md.step(0.0005, None, 9000)
+            e1 = md.energy()
+            out[name] = (e0, e1, md.skin(), md.stats()["rebuild_count"])
+    (e0f, e1f, _, _), (e0a, e1a, (skin_a, tuning), rb_a) = out["fixed"], out["auto"]
+    assert not tuning, "the skin tuning never finished"
+    assert 0.75 <= skin_a <= 4.0 and abs(skin_a * 4 - round(skin_a * 4)) < 1e-4, skin_a      # a multiple of 0.25 A inside its range
+    assert rb_a > 10
+    tot = lambda e: e["potential"] + e["kinetic"]
+    drift_f, drift_a = abs(tot(e1f) - tot(e0f)) / s.n_atoms, abs(tot(e1a) - tot(e0a)) / s.n_atoms
+    assert drift_a < max(2.0 * drift_f, 2e-3), (drift_a, drift_f)
+    assert abs(e1a["temperature"] - e1f["temperature"]) < 25.0
