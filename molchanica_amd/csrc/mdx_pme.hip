@@ -963,6 +963,15 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
             ba.gate = d_gate; ba.thr = thr; ba.need = need; ba.sel = sel; ba.err = h->d.flags_dev;
             hipLaunchKernelGGL(pme_spread_block_kernel, dim3((unsigned)(ba.nbk[0] * ba.nbk[1] * ba.nbk[2])), dim3(256), 0, st, ba);
             clean = false; h->pme_block_spread_used = true;
+            // (A/B arm: a block whose candidate-tile table overflows - 512 entries, ~40-120 in use - raises bit 64 and spreads an
+            // incomplete block; MDX_PME_DEBUG=1 waits for the launch and turns that into an error)
+            static const bool dbg = [] { const char* e = std::getenv("MDX_PME_DEBUG"); return e && e[0] == '1'; }();
+            if (dbg) {
+                uint32_t fl = 0;
+                HIP_TRY(hipMemcpyAsync(&fl, h->d.flags_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                if (fl & 64u) FAIL(MDX_EDEVICE, "block-owned PME spread: candidate-tile table overflow");
+            }
         } else {
         h->pme_block_spread_used = false;
         if (!clean) HIP_TRY(hipMemsetAsync(Q, 0, sizeof(float) * p->n_real, st));

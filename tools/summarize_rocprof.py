@@ -92,7 +92,7 @@ if pmc:
     lines.append("")
     lines.append(f"# rocprofv3 --pmc (separate passes; mean per executed dispatch)   ({tag})")
     for k, cs in sorted(pmc.items()):
-        if not k.startswith(("nb_", "bonded", "integrate", "build_list", "prune_list")):
+        if not k.startswith(("nb_", "bonded", "integrate", "build_list", "prune_list", "rb_")):
             continue
         lines.append(k)
         for c, (n, tot) in sorted(cs.items()):
