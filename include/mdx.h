@@ -508,6 +508,10 @@ int mdx_comm_diag_read(mdx_handle* h, mdx_comm_diag* out);
  * edges not divisible by the rank count, alchemical window, MDX_PME_SLAB=0); bytes this rank SENDS per force call for the
  * real-space mesh (charges to the slab owners + potential back to the block owners) and for the two FFT transposes. */
 int mdx_pme_info(const mdx_handle* h, int* slab_on, uint64_t* mesh_bytes_sent, uint64_t* transpose_bytes_sent, uint64_t* replicated_mesh_bytes);
+/* Diagnostic of the charge spread of a single-GPU handle (mesh cut into bricks, one bucket of atoms per brick; mdx_pme.hip): the
+ * number of atoms, summed over all force calls so far, that did not fit their brick's bucket and went through the overflow list
+ * (correct, slower).  0 on a handle without SPME or with another spread.  Waits for the device. */
+int mdx_pme_brick_overflows(mdx_handle* h, uint64_t* n);
 int mdx_comm_debug_partition(mdx_handle* h, uint8_t* cls, uint8_t* owner, uint8_t* image_code, uint32_t* send_mask /* [N] each */,
                              uint32_t* n_send, uint32_t* n_recv, uint32_t* send_ids, uint32_t* recv_ids, uint32_t capacity);
 

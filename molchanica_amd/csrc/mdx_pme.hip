@@ -32,6 +32,12 @@ struct PmeDev {
     int K[3];
 };
 
+struct PmeBrickGeom {
+    int nb[3];                             // bricks per dimension; brick i of dimension d starts at (i * K[d]) / nb[d]
+    int cb[3];                             // canvas extent = largest brick of the dimension + 3
+    uint32_t nbricks, cap, stride;         // bucket capacity (records), canvas stride in scratch (floats)
+};
+
 struct PmePlan {
     void* lib = nullptr;
     decltype(&hipfftPlan3d) plan3d = nullptr;
@@ -43,6 +49,13 @@ struct PmePlan {
     bool have_plans = false;
     PmeDev dev{};
     size_t n_real = 0, n_cplx = 0;
+    // ---- brick spread (single-GPU handles; see "Brick spread" below) ----
+    struct Brick {
+        bool on = false;
+        PmeBrickGeom g{};
+        float4* rec = nullptr; uint32_t* code = nullptr; uint32_t* count = nullptr; uint32_t* ovf = nullptr; int* scratch = nullptr;
+        uint32_t ovf_S = 0;
+    } brick;
     // ---- slab-decomposed mesh of a decomposed handle (round 3; see "Slab-decomposed SPME" below) ----
     decltype(&hipfftPlanMany) plan_many = nullptr;
     decltype(&hipfftExecC2C) exec_c2c = nullptr;
@@ -120,25 +133,32 @@ __global__ __launch_bounds__(256) void pme_spread_kernel(uint32_t S, const float
 }
 
 // Tile-local spread (default).  The 64 atoms of a tile sit in an ~8.6 A brick, i.e. they touch a block of about
-// 13^3 mesh points: one workgroup per tile accumulates the tile's 64 x 64 contributions in an LDS block with
-// ds_add_f32 and flushes each touched point ONCE with a global atomic - ~2200 memory-side atomics per tile instead
+// 13^3 mesh points: one workgroup per tile accumulates the tile's 64 x 64 contributions in an LDS block (fixed point,
+// see PME_FIX below) and flushes each touched point ONCE with a global atomic - ~2200 memory-side atomics per tile instead
 // of 4096, in rows of consecutive floats.  (The memory side retires ~250 G f32 atomics/s: the 66 M adds of the
 // per-atom kernel above cannot take less than 0.26 ms at 1 M atoms, and took 0.68.)  Mesh indices are kept
 // unwrapped inside the block - an atom that has drifted across the box face since the last rebuild is still a
 // neighbour of the rest of its tile - and wrapped at the flush; an atom whose footprint does not fit the block
 // (a sparse tile) falls back to direct atomics.
+// gfx950 retires ds_add_f32 at ONE lane per three clocks and CU - 0.33 lane-adds per clock whatever the addresses, against 10 per
+// clock for ds_add_u32 (tools/ubench/lds_atomic_rate.hip, profiles/r04_lds_atomic_rate_ubench.txt): the LDS canvases of the charge
+// spread therefore accumulate in 32-bit fixed point, 2^-25 e per count.  A mesh point holds the charge of the handful of atoms
+// whose 4^3 support covers it (|sum| < 2 e in condensed matter; the format holds +-64 e), the rounding of one contribution
+// (1.5e-8 e) is that of an fp32 value near 0.25 e, and - integer adds commute - the sum no longer depends on the order of the lanes.
+constexpr float PME_FIX = 33554432.0f;             // 2^25
+constexpr float PME_UNFIX = 1.0f / 33554432.0f;
 constexpr int PME_TB = 14;    // LDS block edge in mesh points
 __global__ __launch_bounds__(256) void pme_spread_tile_kernel(uint32_t T, const float4* __restrict__ posq,
                                                               const uint8_t* __restrict__ slot_flags, PmeDev g,
                                                               float* __restrict__ Q, const uint32_t* gate, uint32_t thr, uint32_t need,
                                                               const float2* __restrict__ lj, int sel) {
     if (gate && *gate > thr) return;
-    __shared__ float s_q[PME_TB * PME_TB * PME_TB];
+    __shared__ int s_q[PME_TB * PME_TB * PME_TB];
     __shared__ int s_org[3];
     const uint32_t t = blockIdx.x;
     if (t >= T) return;
     const int tid = threadIdx.x;
-    for (int k = tid; k < PME_TB * PME_TB * PME_TB; k += 256) s_q[k] = 0.f;
+    for (int k = tid; k < PME_TB * PME_TB * PME_TB; k += 256) s_q[k] = 0;
     // atom a = tid >> 2 of the tile; its quarter q4 = tid & 3 of the 16 (y, z) offset pairs
     const int atom = tid >> 2, q4 = tid & 3;
     const uint32_t slot = t * MDX_TILE + atom;
@@ -180,7 +200,7 @@ __global__ __launch_bounds__(256) void pme_spread_tile_kernel(uint32_t T, const 
             for (int c = 0; c < 4; ++c) {
                 const float v = p.w * mx[a] * my[b] * mz[c];
                 if (fits) {
-                    atomicAdd(&s_q[((lx + a) * PME_TB + (ly + b)) * PME_TB + (lz + c)], v);
+                    atomicAdd(&s_q[((lx + a) * PME_TB + (ly + b)) * PME_TB + (lz + c)], __float2int_rn(v * PME_FIX));
                 } else {
                     int kx = (k0[0] + a) % g.K[0]; if (kx < 0) kx += g.K[0];
                     int ky = (k0[1] + b) % g.K[1]; if (ky < 0) ky += g.K[1];
@@ -193,8 +213,9 @@ __global__ __launch_bounds__(256) void pme_spread_tile_kernel(uint32_t T, const 
     __syncthreads();
     if (ox == 0x3fffffff) return;      // no live atom in the tile
     for (int k = tid; k < PME_TB * PME_TB * PME_TB; k += 256) {
-        const float v = s_q[k];
-        if (v != 0.f) {
+        const int vi = s_q[k];
+        if (vi != 0) {
+            const float v = (float)vi * PME_UNFIX;
             const int lz = k % PME_TB, ly = (k / PME_TB) % PME_TB, lx = k / (PME_TB * PME_TB);
             int kx = (ox + lx) % g.K[0]; if (kx < 0) kx += g.K[0];
             int ky = (oy + ly) % g.K[1]; if (ky < 0) ky += g.K[1];
@@ -204,118 +225,200 @@ __global__ __launch_bounds__(256) void pme_spread_tile_kernel(uint32_t T, const 
     }
 }
 
-// Block-owned spread (round 4; single-GPU periodic handles in slot space: the default there).  The tile kernel above still ends in
-// ~2200 memory-side f32 atomics per tile - 36 M per step at 1 M sites, 0.14 ms at the rate gfx950 retires them, 0.22-0.29 ms
-// measured - and needs a cleared mesh.  Here a workgroup OWNS a 16^3 block of mesh points: it finds the tiles whose atoms can
-// reach the block (the tile / column / z-bin tables of the list build, widened by what atoms may have moved since), walks
-// them 64 atoms at a time with the tile kernel's lane mapping (atom = tid >> 2, y offset = tid & 3, 4 x 4 points each),
-// accumulates only the points inside its block in LDS, and STORES the block - every mesh point is written exactly once per
-// step by plain coalesced stores: no global atomic, no fill.  The spline weights of an atom are evaluated by every block its
-// support touches (2-3 on average): arithmetic, not memory.
-constexpr int PME_BB = 16;                 // owned block edge (mesh points)
-constexpr int PME_BB_MAXTILES = 512;       // candidate tiles of a block (a 19 A cube + drift holds ~40)
-struct PmeBlockArgs {
-    uint32_t T; int nbk[3];                // tiles; blocks per dimension
-    GridParams g; const uint32_t* tile_start; const uint32_t* cell_start;
-    float reach;                           // how far an atom may be from where the rebuild binned it (A)
-    const float4* posq; const uint8_t* slot_flags; const float2* lj; PmeDev pg; float* Q;
+// Brick spread (round 4; the default of single-GPU handles).  The tile kernel above still ends in ~2200 memory-side f32 atomics
+// per tile - 36 M per step at 1 M sites, 0.22-0.29 ms - and needs a cleared mesh (a 32 MB fill per step at 200^3).  Here the
+// mesh is cut into bricks of 8..16 points per dimension and the spread becomes four launches without one global f32 atomic:
+//   bin      every charged atom computes its mesh cell and spline fractions once and drops a 20-byte record {w, q, cell} into the
+//            bucket of the brick that holds its cell (rank inside the bucket: one wave-aggregated atomicAdd per brick and wave);
+//   canvas   one workgroup per brick accumulates its bucket (fixed point, ds_add_u32: see PME_FIX) in an LDS canvas of (B + 3)^3
+//            points - the brick plus the three planes below it that the order-4 support of its atoms reaches - and STORES it;
+//   combine  every mesh point is the sum of the 1..8 canvases that cover it, stored once: no fill, no atomics - and, the sums
+//            being integer, a mesh that is bitwise the same from run to run;
+//   overflow atoms beyond a bucket's capacity (0.25 atoms per cubic Angstrom; liquid water holds 0.10) are listed by slot and added
+//            with global atomics behind the combine pass - in practice an empty launch.
+// A first attempt at an atomic-free spread ("block-owned": each workgroup walked every tile that could reach its 16^3 block,
+// MDX_PME_SPREAD_BLOCK, removed) spent 317 us at 1 M sites: 40 dependent global loads in a row per workgroup and six atoms read
+// for every one that landed.  Buckets make the canvas pass read exactly its own atoms, in independent 64-atom batches.
+constexpr int PME_CB_MAX = 19;             // canvas edge: at most 16 + 3 points
+constexpr size_t PME_BRICK_MIN_MESH = (size_t)1 << 20;      // mesh points from which the brick spread is the default
+struct PmeBrickArgs {
+    uint32_t S; const float4* posq; const uint8_t* slot_flags; const float2* lj; PmeDev pg; PmeBrickGeom bg;
+    float4* rec; uint32_t* code; uint32_t* count;      // count[nbricks]; [nbricks] = overflow slots of this step; [nbricks + 1] = of all steps
+    uint32_t* ovf; int* scratch; float* Q;
     const uint32_t* gate; uint32_t thr; uint32_t need; int sel;
-    uint32_t* err;
 };
-__global__ __launch_bounds__(256) void pme_spread_block_kernel(PmeBlockArgs a) {
+__device__ __forceinline__ int pme_brick_start(int i, int K, int nb) { return (i * K) / nb; }
+__device__ __forceinline__ int pme_brick_of(int k, int K, int nb) { return ((k + 1) * nb - 1) / K; }
+
+__global__ __launch_bounds__(256) void pme_bin_kernel(PmeBrickArgs a) {
     if (a.gate && *a.gate > a.thr) return;
-    __shared__ float s_q[PME_BB * PME_BB * PME_BB];
-    __shared__ uint32_t s_tiles[PME_BB_MAXTILES];
-    __shared__ uint32_t s_nt;
-    const int tid = threadIdx.x;
-    const int bz = blockIdx.x % a.nbk[2], by = (blockIdx.x / a.nbk[2]) % a.nbk[1], bx = blockIdx.x / (a.nbk[2] * a.nbk[1]);
-    const int b0[3] = {bx * PME_BB, by * PME_BB, bz * PME_BB};
-    for (int k = tid; k < PME_BB * PME_BB * PME_BB; k += 256) s_q[k] = 0.f;
-    if (tid == 0) s_nt = 0u;
-    __syncthreads();
-    // ---- candidate tiles: columns and z-bins that can hold an atom whose 4-point support touches the block ----
-    // an atom at mesh coordinate u touches points floor(u) - 3 .. floor(u): it reaches the block for u in [b0, b0 + BB + 3)
-    const GridParams& g = a.g;
-    float lo_a[3], hi_a[3];
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = false;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s < a.S) {
+        p = a.posq[s];
+        live = ((a.slot_flags[s] & a.need) == a.need) && p.w != 0.f && (!a.sel || ((__float_as_int(a.lj[s].y) < 0) == (a.sel == 2)));
+    }
+    int k0[3] = {0, 0, 0}; float w[3] = {0.f, 0.f, 0.f};
+    uint32_t id = 0xffffffffu, cell = 0u;
+    if (live) {
+        mesh_coords(p, a.pg, k0, w);                // the very expression the gather uses: k0 = floor(u) - 3
+        int bi[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        lo_a[d] = a.pg.lo[d] + (float)b0[d] / a.pg.scale[d] - a.reach;
-        hi_a[d] = a.pg.lo[d] + (float)(b0[d] + PME_BB + 3) / a.pg.scale[d] + a.reach;
-    }
-    int ix0 = (int)floorf((lo_a[0] - g.lo[0]) * g.inv_col[0]), ix1 = (int)floorf((hi_a[0] - g.lo[0]) * g.inv_col[0]);
-    int iy0 = (int)floorf((lo_a[1] - g.lo[1]) * g.inv_col[1]), iy1 = (int)floorf((hi_a[1] - g.lo[1]) * g.inv_col[1]);
-    if (ix1 - ix0 + 1 > g.ncx) { ix0 = 0; ix1 = g.ncx - 1; }        // every column once
-    if (iy1 - iy0 + 1 > g.ncy) { iy0 = 0; iy1 = g.ncy - 1; }
-    int zb0 = (int)floorf((lo_a[2] - g.lo[2]) * g.inv_zbin) - 1, zb1 = (int)floorf((hi_a[2] - g.lo[2]) * g.inv_zbin) + 1;
-    const bool zall = zb1 - zb0 + 1 >= g.nzb;
-    const int nxr = ix1 - ix0 + 1, nyr = iy1 - iy0 + 1;
-    for (int c = tid; c < nxr * nyr; c += 256) {
-        int wx = (ix0 + c / nyr) % g.ncx; if (wx < 0) wx += g.ncx;
-        int wy = (iy0 + c % nyr) % g.ncy; if (wy < 0) wy += g.ncy;
-        const uint32_t col = (uint32_t)(wx * g.ncy + wy);
-        const uint32_t t0 = a.tile_start[col], t1 = a.tile_start[col + 1];
-        if (t1 <= t0) continue;
-        uint32_t rA = t0, rB = t1, sA = 0, sB = 0;            // two tile ranges (the z-window may wrap around the box)
-        if (!zall) {
-            const uint32_t* cs = a.cell_start + (size_t)col * g.nzb;
-            auto range = [&](int z0, int z1, uint32_t* ta, uint32_t* tb) {
-                const uint32_t aA = cs[z0] - cs[0], aB = cs[z1 + 1] - cs[0];
-                if (aB <= aA) { *ta = 0; *tb = 0; return; }
-                *ta = t0 + aA / MDX_TILE; *tb = min(t1, t0 + (aB + MDX_TILE - 1) / MDX_TILE);
-            };
-            range(max(zb0, 0), min(zb1, g.nzb - 1), &rA, &rB);
-            if (zb0 < 0) range(zb0 + g.nzb, g.nzb - 1, &sA, &sB);
-            else if (zb1 >= g.nzb) range(0, zb1 - g.nzb, &sA, &sB);
-            if (sB > sA && rB > rA && sA < rB && rA < sB) { rA = min(rA, sA); rB = max(rB, sB); sA = sB = 0; }    // overlapping: one range
+        for (int d = 0; d < 3; ++d) {
+            const int fl = k0[d] + 3;
+            bi[d] = pme_brick_of(fl, a.pg.K[d], a.bg.nb[d]);
+            cell |= (uint32_t)(fl - pme_brick_start(bi[d], a.pg.K[d], a.bg.nb[d])) << (8 * d);
         }
-        const uint32_t n = (rB - rA) + (sB - sA);
-        if (!n) continue;
-        const uint32_t at = atomicAdd(&s_nt, n);
-        if (at + n > (uint32_t)PME_BB_MAXTILES) { atomicOr(a.err, 64u); continue; }
-        uint32_t w = at;
-        for (uint32_t t = rA; t < rB; ++t) s_tiles[w++] = t;
-        for (uint32_t t = sA; t < sB; ++t) s_tiles[w++] = t;
+        id = (uint32_t)((bi[0] * a.bg.nb[1] + bi[1]) * a.bg.nb[2] + bi[2]);
+    }
+    // rank inside the bucket: the lanes of a wave that share a brick take consecutive places behind ONE atomic
+    const int lane = threadIdx.x & 63;
+    uint32_t rank = 0u;
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t lid = (uint32_t)__shfl((int)id, leader);
+        const unsigned long long same = __ballot(live && id == lid);
+        uint32_t base = 0u;
+        if (lane == leader) base = atomicAdd(a.count + lid, (uint32_t)__popcll(same));
+        base = (uint32_t)__shfl((int)base, leader);
+        if (live && id == lid) rank = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    if (!live) return;
+    if (rank < a.bg.cap) {
+        const size_t at = (size_t)id * a.bg.cap + rank;
+        a.rec[at] = make_float4(w[0], w[1], w[2], p.w);
+        a.code[at] = cell;
+    } else {
+        a.ovf[atomicAdd(a.count + a.bg.nbricks, 1u)] = s;      // (the list holds S slots: it cannot overflow)
+    }
+}
+
+__global__ __launch_bounds__(256) void pme_canvas_kernel(PmeBrickArgs a) {
+    if (a.gate && *a.gate > a.thr) return;
+    __shared__ int s_q[PME_CB_MAX * PME_CB_MAX * PME_CB_MAX];
+    const int tid = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    const int cb1 = a.bg.cb[1], cb2 = a.bg.cb[2];
+    const uint32_t vol = a.bg.stride;
+    for (uint32_t k = tid; k < vol; k += 256) s_q[k] = 0;
+    __syncthreads();
+    const uint32_t n = min(a.count[b], a.bg.cap);
+    const float4* rec = a.rec + (size_t)b * a.bg.cap;
+    const uint32_t* code = a.code + (size_t)b * a.bg.cap;
+    // 64 atoms per pass: atom = tid >> 2, this lane's y offset = tid & 3, 4 x 4 (x, z) points each
+    const int yb = tid & 3;
+    for (uint32_t i = tid >> 2; i < n; i += 64) {
+        const float4 r = rec[i];
+        const uint32_t c = code[i];
+        const int lx = (int)(c & 255u), ly = (int)((c >> 8) & 255u), lz = (int)((c >> 16) & 255u);
+        float mx[4], my[4], mz[4], dd[4];
+        bspline4(r.x, mx, dd); bspline4(r.y, my, dd); bspline4(r.z, mz, dd);
+        const float qy = r.w * my[yb] * PME_FIX;
+        int* row = s_q + ((size_t)lx * cb1 + (ly + yb)) * cb2 + lz;     // canvas origin = brick start - 3: cell l holds points l .. l + 3
+#pragma unroll
+        for (int qa = 0; qa < 4; ++qa) {
+#pragma unroll
+            for (int qc = 0; qc < 4; ++qc) atomicAdd(row + (size_t)qa * cb1 * cb2 + qc, __float2int_rn(qy * mx[qa] * mz[qc]));
+        }
     }
     __syncthreads();
-    const uint32_t nt = min(s_nt, (uint32_t)PME_BB_MAXTILES);
-    const int atom = tid >> 2, b = tid & 3;
-    for (uint32_t it = 0; it < nt; ++it) {
-        const uint32_t slot = s_tiles[it] * MDX_TILE + (uint32_t)atom;
-        const float4 p = a.posq[slot];
-        const bool live = ((a.slot_flags[slot] & a.need) == a.need) && p.w != 0.f &&
-                          (!a.sel || ((__float_as_int(a.lj[slot].y) < 0) == (a.sel == 2)));
-        if (!live) continue;
+    // scratch is ONE padded mesh, the canvases tiled in it brick by brick: a (kx, ky) row of the combine pass then reads one
+    // contiguous run per covering (x, y) canvas pair instead of a 64-byte piece per brick
+    const int cb0 = a.bg.cb[0];
+    const int bz = (int)(b % (uint32_t)a.bg.nb[2]), by = (int)((b / (uint32_t)a.bg.nb[2]) % (uint32_t)a.bg.nb[1]), bx = (int)(b / (uint32_t)(a.bg.nb[2] * a.bg.nb[1]));
+    const size_t PY = (size_t)a.bg.nb[1] * cb1, PZ = (size_t)a.bg.nb[2] * cb2;
+    int* out = a.scratch + ((size_t)bx * cb0 * PY + (size_t)by * cb1) * PZ + (size_t)bz * cb2;
+    for (uint32_t k = tid; k < vol; k += 256) {
+        const uint32_t cz = k % (uint32_t)cb2, cy = (k / (uint32_t)cb2) % (uint32_t)cb1, cx = k / (uint32_t)(cb2 * cb1);
+        out[((size_t)cx * PY + cy) * PZ + cz] = s_q[k];
+    }
+}
+
+// mesh point (kx, ky, kz): the canvas of its own brick holds it at local + 3; when it lies in the top three planes of its brick
+// in a dimension, the next brick's canvas (periodic) holds it too, in its bottom three planes
+__global__ __launch_bounds__(256) void pme_combine_kernel(PmeBrickArgs a, size_t n_real) {
+    if (a.gate && *a.gate > a.thr) return;
+    if (blockIdx.x * 256u + threadIdx.x < a.bg.nbricks) a.count[blockIdx.x * 256u + threadIdx.x] = 0u;      // the buckets are spent: empty for the next step
+    // one WAVE per (kx, ky) row of the mesh: the x / y bricks are the same for the whole row (scalar); a lane takes four kz at a
+    // time and issues all their loads before it adds (a pass with one load in flight per lane ran at 1.4 TB/s: latency)
+    const int K1 = a.pg.K[1], K2 = a.pg.K[2];
+    const uint32_t rowi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (rowi >= (uint32_t)(a.pg.K[0] * K1)) return;
+    const int lane = threadIdx.x & 63;
+    const int kxy[2] = {(int)(rowi / (unsigned)K1), (int)(rowi % (unsigned)K1)};
+    int br[2][2], cc[2][2], nn[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const int K = a.pg.K[d], nb = a.bg.nb[d];
+        const int b = pme_brick_of(kxy[d], K, nb);
+        const int s0 = pme_brick_start(b, K, nb), s1 = pme_brick_start(b + 1, K, nb);
+        const int l = kxy[d] - s0;
+        br[d][0] = b; cc[d][0] = l + 3; nn[d] = 1; br[d][1] = b; cc[d][1] = 0;
+        if (l >= s1 - s0 - 3) { br[d][1] = b + 1 == nb ? 0 : b + 1; cc[d][1] = l - (s1 - s0) + 3; nn[d] = 2; }
+    }
+    const int nbz = a.bg.nb[2], cb0 = a.bg.cb[0], cb1 = a.bg.cb[1], cb2 = a.bg.cb[2];
+    const size_t PY = (size_t)a.bg.nb[1] * cb1, PZ = (size_t)nbz * cb2;
+    float* const qrow = a.Q + (size_t)rowi * K2;
+    for (int kz0 = 0; kz0 < K2; kz0 += 256) {
+        int i0[4], i1[4]; bool ok[4], two[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kz = kz0 + lane + 64 * j;
+            ok[j] = kz < K2;
+            const int kc = ok[j] ? kz : 0;
+            const int bz = pme_brick_of(kc, K2, nbz);
+            const int s0 = pme_brick_start(bz, K2, nbz), s1 = pme_brick_start(bz + 1, K2, nbz);
+            const int l = kc - s0;
+            two[j] = l >= s1 - s0 - 3;
+            i0[j] = bz * cb2 + l + 3;
+            i1[j] = two[j] ? (bz + 1 == nbz ? 0 : bz + 1) * cb2 + l - (s1 - s0) + 3 : i0[j];
+        }
+        int v[4] = {0, 0, 0, 0};      // fixed point: the sum is exact and does not depend on which workgroup finished first
+        for (int ix = 0; ix < nn[0]; ++ix)
+            for (int iy = 0; iy < nn[1]; ++iy) {
+                const int* row = a.scratch + ((size_t)(br[0][ix] * cb0 + cc[0][ix]) * PY + (size_t)(br[1][iy] * cb1 + cc[1][iy])) * PZ;
+                int p0[4], p1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { p0[j] = row[i0[j]]; p1[j] = row[i1[j]]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += p0[j] + (two[j] ? p1[j] : 0);
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (ok[j]) qrow[kz0 + lane + 64 * j] = (float)v[j] * PME_UNFIX;
+    }
+}
+
+// atoms that did not fit their bucket (listed by slot): the per-atom form, with global atomics, behind the combine pass; resets the
+// overflow count.  One workgroup; 16 lanes per atom as in pme_spread_kernel.
+__global__ __launch_bounds__(256) void pme_overflow_kernel(PmeBrickArgs a) {
+    if (a.gate && *a.gate > a.thr) return;
+    const uint32_t n_all = a.count[a.bg.nbricks];
+    if (n_all == 0u) return;
+    const uint32_t n = n_all;
+    const int tid = threadIdx.x, b = (tid >> 2) & 3, c = tid & 3;
+    for (uint32_t i = tid >> 4; i < n; i += 16) {
+        const float4 p = a.posq[a.ovf[i]];
         int k0[3]; float w[3];
-        mesh_coords(p, a.pg, k0, w);                        // wrapped: k0 = floor(u) - 3 in [-3, K - 3]
-        // this lane's y point, and which of the four x / z points fall into the block
-        int ly = k0[1] + b; if (ly < 0) ly += a.pg.K[1];
-        ly -= b0[1];
-        if ((unsigned)ly >= (unsigned)PME_BB) continue;
-        int lx[4], lz[4]; bool anyx = false, anyz = false;
+        mesh_coords(p, a.pg, k0, w);
+        float mx[4], my[4], mz[4], dd[4];
+        bspline4(w[0], mx, dd); bspline4(w[1], my, dd); bspline4(w[2], mz, dd);
+        int ky = k0[1] + b; if (ky < 0) ky += a.pg.K[1];
+        int kz = k0[2] + c; if (kz < 0) kz += a.pg.K[2];
+        const float qbc = p.w * my[b] * mz[c];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             int kx = k0[0] + q; if (kx < 0) kx += a.pg.K[0];
-            int kz = k0[2] + q; if (kz < 0) kz += a.pg.K[2];
-            lx[q] = kx - b0[0]; lz[q] = kz - b0[2];
-            anyx |= (unsigned)lx[q] < (unsigned)PME_BB; anyz |= (unsigned)lz[q] < (unsigned)PME_BB;
-        }
-        if (!anyx || !anyz) continue;
-        float mx[4], my[4], mz[4], dd[4];
-        bspline4(w[0], mx, dd); bspline4(w[1], my, dd); bspline4(w[2], mz, dd);
-        const float qy = p.w * my[b];
-#pragma unroll
-        for (int qa = 0; qa < 4; ++qa) {
-            if ((unsigned)lx[qa] >= (unsigned)PME_BB) continue;
-#pragma unroll
-            for (int qc = 0; qc < 4; ++qc)
-                if ((unsigned)lz[qc] < (unsigned)PME_BB) atomicAdd(&s_q[(lx[qa] * PME_BB + ly) * PME_BB + lz[qc]], qy * mx[qa] * mz[qc]);
+            atomicAdd(a.Q + ((size_t)kx * a.pg.K[1] + ky) * a.pg.K[2] + kz, qbc * mx[q]);
         }
     }
     __syncthreads();
-    for (int k = tid; k < PME_BB * PME_BB * PME_BB; k += 256) {
-        const int lz = k % PME_BB, ly = (k / PME_BB) % PME_BB, lx = k / (PME_BB * PME_BB);
-        const int kx = b0[0] + lx, ky = b0[1] + ly, kz = b0[2] + lz;
-        if (kx < a.pg.K[0] && ky < a.pg.K[1] && kz < a.pg.K[2]) a.Q[((size_t)kx * a.pg.K[1] + ky) * a.pg.K[2] + kz] = s_q[k];
+    if (tid == 0) {
+        a.count[a.bg.nbricks] = 0u;
+        a.count[a.bg.nbricks + 1] += n_all;      // how many atoms ever took this path (diagnostic: mdx_pme_brick_overflows)
     }
 }
 
@@ -595,6 +698,68 @@ static std::vector<double> bspline_moduli4(int K) {
 }
 
 static void pme_slab_free(PmePlan* p);
+static void pme_brick_free(PmePlan* p) {
+    for (void** q : {(void**)&p->brick.rec, (void**)&p->brick.code, (void**)&p->brick.count, (void**)&p->brick.ovf, (void**)&p->brick.scratch})
+        if (*q) { (void)hipFree(*q); *q = nullptr; }
+    p->brick.on = false;
+}
+
+// Brick geometry of a mesh: ceil(K / edge) bricks per dimension, brick i starting at floor(i K / n) - sizes differ by at most one
+// point and lie in [edge / 2, edge] (K >= 8), so the support of an atom (3 points below its cell) never reaches past the
+// neighbouring brick.  MDX_PME_SPREAD_BRICK=0 keeps the tile kernel; MDX_PME_BRICK_EDGE = 8..16; MDX_PME_BRICK_CAP forces a
+// bucket capacity (tests use it to drive atoms through the overflow list).
+static int pme_brick_setup(mdx_handle* h, PmePlan* p) {
+    pme_brick_free(p);
+    const char* const oe = std::getenv("MDX_PME_SPREAD_BRICK");       // (read at every setup: a test can choose per handle)
+    if ((oe && oe[0] == '0') || h->dd || h->n_local != h->N) return MDX_OK;
+    const char* ee = std::getenv("MDX_PME_BRICK_EDGE");
+    const size_t n_real = p->n_real;
+    // small meshes keep the tile kernel (fill + one launch against four launches: 6.9 k against 6.1 k steps/s at 23 k sites, 56^3);
+    // MDX_PME_SPREAD_BRICK=1 forces the bricks
+    if (!(oe && oe[0] == '1') && n_real < PME_BRICK_MIN_MESH) return MDX_OK;
+    int edge = ee ? std::atoi(ee) : (n_real >= (size_t)1 << 21 ? 16 : 8);      // small meshes: more, smaller workgroups
+    edge = std::min(16, std::max(8, edge));
+    PmeBrickGeom& g = p->brick.g;
+    double vol_cell = 1.0;
+    for (int d = 0; d < 3; ++d) {
+        const int K = h->pme_K[d];
+        g.nb[d] = (K + edge - 1) / edge;
+        int bmax = 0;
+        for (int i = 0; i < g.nb[d]; ++i) bmax = std::max(bmax, ((i + 1) * K) / g.nb[d] - (i * K) / g.nb[d]);
+        g.cb[d] = bmax + 3;
+        if (g.cb[d] > PME_CB_MAX) FAIL(MDX_EDEVICE, "PME brick larger than its canvas");
+        vol_cell *= ((double)h->box_hi[d] - (double)h->box_lo[d]) / K;
+    }
+    g.nbricks = (uint32_t)(g.nb[0] * g.nb[1] * g.nb[2]);
+    g.stride = (uint32_t)(g.cb[0] * g.cb[1] * g.cb[2]);
+    // capacity of a bucket: 0.25 charged atoms per cubic Angstrom of the largest brick (liquid water: 0.10), a multiple of 64
+    const double bvol = vol_cell * (g.cb[0] - 3) * (g.cb[1] - 3) * (g.cb[2] - 3);
+    uint32_t cap = (uint32_t)std::ceil(0.25 * bvol);
+    g.cap = (std::min<uint32_t>(std::max<uint32_t>(cap, 1u), h->N + 63u) + 63u) & ~63u;
+    if (const char* ce = std::getenv("MDX_PME_BRICK_CAP")) g.cap = (uint32_t)std::max(1, std::atoi(ce));
+    HIP_TRY(hipMalloc((void**)&p->brick.rec, sizeof(float4) * (size_t)g.nbricks * g.cap));
+    HIP_TRY(hipMalloc((void**)&p->brick.code, sizeof(uint32_t) * (size_t)g.nbricks * g.cap));
+    HIP_TRY(hipMalloc((void**)&p->brick.count, sizeof(uint32_t) * ((size_t)g.nbricks + 2)));
+    HIP_TRY(hipMemset(p->brick.count, 0, sizeof(uint32_t) * ((size_t)g.nbricks + 2)));
+    HIP_TRY(hipMalloc((void**)&p->brick.ovf, sizeof(uint32_t) * ((size_t)h->N + 64)));
+    HIP_TRY(hipMalloc((void**)&p->brick.scratch, sizeof(int) * (size_t)g.nbricks * g.stride));
+    p->brick.on = true;
+    return MDX_OK;
+}
+
+// atoms that ever went through the overflow list of the brick spread (a diagnostic; synchronises)
+extern "C" int mdx_pme_brick_overflows(mdx_handle* h, uint64_t* n) {
+    if (!h || !n) return MDX_EPARAM;
+    *n = 0;
+    PmePlan* p = (PmePlan*)h->pme_plan;
+    if (!p || !p->brick.on) return MDX_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t v = 0;
+    HIP_TRY(hipMemcpy(&v, p->brick.count + p->brick.g.nbricks + 1, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *n = v;
+    return MDX_OK;
+}
+
 void mdx_pme_destroy(mdx_handle* h) {
     if (h->stream_pme) {
         (void)hipStreamSynchronize(h->stream_pme);
@@ -606,6 +771,7 @@ void mdx_pme_destroy(mdx_handle* h) {
     if (!p) return;
     if (p->have_plans) { p->destroy(p->fwd); p->destroy(p->inv); }
     pme_slab_free(p);
+    pme_brick_free(p);
     if (p->lib) dlclose(p->lib);
     delete p;
     h->pme_plan = nullptr;
@@ -814,6 +980,7 @@ int mdx_pme_setup(mdx_handle* h) {
         HIP_TRY(hipMalloc((void**)&h->d.pme_theta, sizeof(float) * p->n_cplx));
         for (int d = 0; d < 3; ++d) h->pme_K[d] = K[d];
     }
+    if (regrid || !((PmePlan*)h->pme_plan)->brick.on) MDX_TRY(pme_brick_setup(h, p));     // (bucket capacity follows the box: set_box re-runs this)
     {   // side stream of the reciprocal-space chain (MDX_PME_OVERLAP=0: everything on the handle's stream; a decomposed
         // handle keeps the chain on its own stream: the mesh all-reduce sits inside it)
         // Below ~65 k atoms the chain's kernels are a few microseconds each and the two cross-stream event hops cost
@@ -879,7 +1046,7 @@ int mdx_pme_setup(mdx_handle* h) {
 static int pme_clear_behind(mdx_handle* h, hipStream_t st) {
     if (!h->pme_clear_pending) return MDX_OK;
     h->pme_clear_pending = false;
-    if (h->pme_block_spread_used) return MDX_OK;       // the block-owned spread stores every point: nothing to clear
+    if (h->pme_block_spread_used) return MDX_OK;       // the brick spread stores every point: nothing to clear
     if (h->pme_spread_main) return MDX_OK;             // (the spread runs on the handle's stream: it clears in front of itself, alone on the chip)
     PmePlan* p = (PmePlan*)h->pme_plan;
     HIP_TRY(hipMemsetAsync(h->d.pme_q, 0, sizeof(float) * p->n_real, st));
@@ -945,33 +1112,17 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
         const hipStream_t st_chain = st;
         const bool spread_main = h->pme_overlap && h->pme_spread_main;
         if (spread_main) st = h->stream;
-        // block-owned spread (MDX_PME_SPREAD_BLOCK=1; measured round 4 and NOT the default): every mesh point is stored by the
-        // workgroup that owns it - no clear, no global atomics - and yet no faster: 317 us per launch against the tile kernel's 293
-        // at 1 M sites (both are bound by their per-workgroup chain of LDS phases, not by the memory-side atomics), and slower on small
-        // meshes (a 56^3 mesh is 64 blocks)
-        static const bool block_env = [] { const char* e = std::getenv("MDX_PME_SPREAD_BLOCK"); return e && e[0] == '1'; }();
-        const bool block_spread = block_env && !per_atom_spread && h->in_slot_space && !h->dd && h->n_local == h->N &&
-                                  h->per[0] && h->per[1] && h->per[2] && h->grid.npop == 1 && std::isfinite(h->r_list);
-        if (block_spread) {
-            PmeBlockArgs ba{};
-            ba.T = h->T; ba.g = h->grid; ba.tile_start = h->d.tile_start; ba.cell_start = h->d.cell_start;
-            for (int d = 0; d < 3; ++d) ba.nbk[d] = (h->pme_K[d] + PME_BB - 1) / PME_BB;
-            // since the rebuild binned it an atom has moved at most skin / 2 (the stale trigger) + what one step adds before the
-            // trigger is read + a constraint projection / a virtual site's reach from its parents
-            ba.reach = 0.5f * h->cfg.skin + 0.75f;
-            ba.posq = h->d.posq; ba.slot_flags = h->d.slot_flags; ba.lj = h->d.lj; ba.pg = p->dev; ba.Q = Q;
-            ba.gate = d_gate; ba.thr = thr; ba.need = need; ba.sel = sel; ba.err = h->d.flags_dev;
-            hipLaunchKernelGGL(pme_spread_block_kernel, dim3((unsigned)(ba.nbk[0] * ba.nbk[1] * ba.nbk[2])), dim3(256), 0, st, ba);
+        if (p->brick.on && !per_atom_spread && !h->dd) {
+            // brick spread: every mesh point is stored once by the combine pass - no clear, no global f32 atomics
+            PmeBrickArgs ba{};
+            ba.S = h->S; ba.posq = h->d.posq; ba.slot_flags = h->d.slot_flags; ba.lj = h->d.lj; ba.pg = p->dev; ba.bg = p->brick.g;
+            ba.rec = p->brick.rec; ba.code = p->brick.code; ba.count = p->brick.count; ba.ovf = p->brick.ovf;
+            ba.scratch = p->brick.scratch; ba.Q = Q; ba.gate = d_gate; ba.thr = thr; ba.need = need; ba.sel = sel;
+            hipLaunchKernelGGL(pme_bin_kernel, dim3(div_up(h->S, 256)), dim3(256), 0, st, ba);
+            hipLaunchKernelGGL(pme_canvas_kernel, dim3(ba.bg.nbricks), dim3(256), 0, st, ba);
+            hipLaunchKernelGGL(pme_combine_kernel, dim3((unsigned)((h->pme_K[0] * h->pme_K[1] + 3) / 4)), dim3(256), 0, st, ba, p->n_real);
+            hipLaunchKernelGGL(pme_overflow_kernel, dim3(1), dim3(256), 0, st, ba);
             clean = false; h->pme_block_spread_used = true;
-            // (A/B arm: a block whose candidate-tile table overflows - 512 entries, ~40-120 in use - raises bit 64 and spreads an
-            // incomplete block; MDX_PME_DEBUG=1 waits for the launch and turns that into an error)
-            static const bool dbg = [] { const char* e = std::getenv("MDX_PME_DEBUG"); return e && e[0] == '1'; }();
-            if (dbg) {
-                uint32_t fl = 0;
-                HIP_TRY(hipMemcpyAsync(&fl, h->d.flags_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                if (fl & 64u) FAIL(MDX_EDEVICE, "block-owned PME spread: candidate-tile table overflow");
-            }
         } else {
         h->pme_block_spread_used = false;
         if (!clean) HIP_TRY(hipMemsetAsync(Q, 0, sizeof(float) * p->n_real, st));

@@ -139,6 +139,7 @@ def load_library():
     lib.mdx_comm_selftest.argtypes = [H]
     lib.mdx_comm_selftest_fault.argtypes = [H]
     lib.mdx_pme_info.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.mdx_pme_brick_overflows.argtypes = [H, C.POINTER(C.c_uint64)]
     lib.mdx_comm_debug_partition.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _u32p, _u32p, C.c_void_p, C.c_void_p, C.c_uint32]
     lib.mdx_set_hydrogen_constraint.argtypes = [H, C.c_int, C.c_uint32, C.c_uint32, C.c_float]
     lib.mdx_constraint_description.argtypes = [H]
@@ -464,6 +465,12 @@ class MdState:
         on, a, b, c = C.c_int(), C.c_uint64(), C.c_uint64(), C.c_uint64()
         _check(load_library().mdx_pme_info(self._h, C.byref(on), C.byref(a), C.byref(b), C.byref(c)))
         return dict(slab_on=bool(on.value), mesh_bytes_sent=a.value, transpose_bytes_sent=b.value, replicated_mesh_bytes=c.value)
+
+    def pme_brick_overflows(self) -> int:
+        """Atoms (summed over all force calls) that went through the overflow list of the brick spread."""
+        n = C.c_uint64()
+        _check(load_library().mdx_pme_brick_overflows(self._h, C.byref(n)))
+        return int(n.value)
 
     def set_hydrogen_constraint(self, kind: str, order: int = 4, iters: int = 1, shake_tolerance: float = 0.0) -> str:
         """HydrogenConstraint::{Flexible, Shake{shake_tolerance}, Linear{order, iter}} (src/ui/panels/md.rs:362-371) -> the

@@ -72,6 +72,34 @@ def test_spme_matches_numpy_restatement_and_ewald(mdx, orc, which, side_stream, 
     assert abs((e20["potential"] + e20["kinetic"]) - (e_full["potential"] + e_full["kinetic"])) / s.n_atoms < 0.05
 
 
+@pytest.mark.parametrize("grid,edge,cap", [((24, 24, 24), None, None), ((50, 36, 30), "16", None), ((50, 36, 30), "11", None),
+                                           ((27, 20, 45), "8", None), ((32, 32, 32), None, "8"), ((16, 8, 12), "16", "8")])
+def test_brick_spread_equals_the_tile_spread(mdx, grid, edge, cap, monkeypatch):
+    """The charge spread of a single-GPU handle (mdx_pme.hip "Brick spread": bin -> canvas -> combine, no global atomics) against
+    the tile kernel it replaced, on meshes whose edges the bricks do not divide, with every brick edge, and with buckets so small
+    that most atoms travel through the overflow list."""
+    s = systems.small_solvated()
+    base = dict(lj_cutoff=8.0, coulomb_cutoff=8.0, skin=1.0, coulomb_mode=_abi.COULOMB_EWALD, ewald_alpha=0.4, overrides=0, pme_grid=grid)
+    out = {}
+    for arm in ("tile", "brick"):
+        monkeypatch.setenv("MDX_PME_SPREAD_BRICK", "0" if arm == "tile" else "1")
+        for k, v in (("MDX_PME_BRICK_EDGE", edge), ("MDX_PME_BRICK_CAP", cap)):
+            monkeypatch.delenv(k, raising=False)
+            if v is not None and arm == "brick":
+                monkeypatch.setenv(k, v)
+        with mdx.MdState(s, MdConfig(**base)) as md:
+            f = md.forces().astype(np.float64)
+            e = md.energy()
+            md.step(0.0005, None, 12)
+            out[arm] = (f, e, md.positions().astype(np.float64), md.pme_brick_overflows())
+    (ft, et, pt, ot), (fb, eb, pb, ob) = out["tile"], out["brick"]
+    assert ot == 0 and (ob > 0) == (cap is not None), (ot, ob)
+    assert eb["coulomb_recip"] == pytest.approx(et["coulomb_recip"], rel=5e-6)      # (fp32 mesh, sums in another order)
+    scale = np.maximum(np.abs(ft).max(1), 1.0)
+    assert (np.abs(fb - ft).max(1) / scale).max() < 2e-5          # fp32 sums in another order on the mesh
+    assert np.abs(pb - pt).max() < 2e-4
+
+
 def test_spme_follows_the_box_and_rejects_bad_setups(mdx):
     s = systems.water_box(6, seed=3)
     cfg = MdConfig(lj_cutoff=7.0, coulomb_cutoff=7.0, skin=1.0, coulomb_mode=_abi.COULOMB_EWALD, ewald_alpha=0.4,

@@ -34,6 +34,9 @@ def row(name, key, nbytes, note):
 fk = [k for k in st if k.startswith("fft_rtc")]
 print(f"# {sites} sites, {charged} charged, mesh {K}^3 = {pts} points")
 row("pme_spread_tile_kernel", "pme_spread_tile_kernel", charged * (16 + 64 * 4), "16 B posq + 4^3 x 4 B mesh RMW per charge")
+row("pme_bin_kernel", "pme_bin_kernel", sites * 17 + charged * 20, "posq + flag per slot, 20-B record per charge")
+row("pme_canvas_kernel", "pme_canvas_kernel", charged * 20 + pts * 4 * 1.67, "20-B record per charge in, canvases out: (19/16)^3 x mesh")
+row("pme_combine_kernel", "pme_combine_kernel", pts * 4 * (1.67 + 1.0), "canvases in, mesh out")
 row("pme_gather_kernel", "pme_gather_kernel", charged * (16 + 64 * 4) + sites * 16, "16 B posq + 4^3 x 4 B mesh reads per charge + 16 B force row per slot")
 row("pme_solve_kernel", "pme_solve_kernel", cplx * (4 + 16), "theta 4 B + complex RW 16 B per point of the half-complex mesh")
 for k in sorted(fk):
