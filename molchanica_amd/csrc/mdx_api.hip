@@ -143,10 +143,10 @@ static void free_device(mdx_handle* h) {
                     d.vel_orig, d.ext_orig, d.posq, d.posq_alt, d.lj, d.vel, d.force, d.ref, d.orig_of, d.slot_of, d.gid, d.lflag,
                     d.slot_flags, d.cell_of,
                     d.cell_count, d.cell_start, d.cell_cursor, d.sorted_orig, d.sorted_tmp, d.col_tiles, d.tile_start,
-                    d.tile_col, d.scan_tmp, d.cl_lo, d.cl_hi, d.list_counts, d.entry_cnt, d.entry_off,
+                    d.tile_col, d.scan_tmp, d.cl_lo, d.cl_hi, d.cl_kind, d.list_counts, d.entry_cnt, d.entry_off,
                     d.mchunk_cnt, d.mchunk_off, d.entries, d.entries_in, d.inner_nch, d.list_cursors, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
                     d.role_off_s, d.role_rec_s, d.role_prm, d.ctl, d.energy,
-                    d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.pme_force, d.cons_o, d.cons_s, d.cons_vir, d.vsite_o, d.vsite_s, d.pme_q, d.pme_f,
+                    d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.pme_force, d.cons_o, d.cons_s, d.cons_tmp, d.cons_mask, d.cons_cnt, d.cons_off, d.cons_vir, d.vsite_o, d.vsite_s, d.pme_q, d.pme_f,
                     d.pme_theta, d.pme_q2, d.pme_f2, d.scratch4, d.tile_bnd, d.tile_scan, d.tile_order, d.tile_lpt, d.rb_ctl, d.scan_chain};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = DeviceState{};
@@ -222,6 +222,17 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
         if (!(fl & MDX_ATOM_GHOST)) h->total_mass += s->mass[i];
     }
     h->h_mass = mass; h->h_lj = lj;
+    {   // Clusters by interaction kind (mdx_grid.hip, rb_assign_kernel): worth it when the system has a sizeable share of atoms with
+        // a Lennard-Jones well and no charge AND of charged atoms without a well - four-site water (OPC / TIP4P: the oxygen carries
+        // the well, hydrogens and the M site the charges): 6 of the 16 site pairs of two such waters do not interact at all.
+        uint32_t n_lj_only = 0, n_q_only = 0;
+        for (uint32_t i = 0; i < N; ++i) {
+            const bool has_lj = lj[i].y != 0.f, has_q = qs[i] != 0.f;
+            n_lj_only += has_lj && !has_q; n_q_only += has_q && !has_lj;
+        }
+        const char* const e = std::getenv("MDX_KIND_CLUSTERS");
+        h->kind_split = e ? e[0] != '0' : (n_lj_only >= N / 20u && n_q_only >= N / 20u && N >= 200000u);      // (23 k sites: 6780 steps/s without, 6650 with)
+    }
     h->mol_start.assign(s->mol_start ? s->mol_start : nullptr, s->mol_start ? s->mol_start + s->n_mols : nullptr);
     h->total_charge = 0.0; h->sum_q2 = 0.0;
     for (uint32_t i = 0; i < N; ++i) { h->total_charge += q[i]; h->sum_q2 += (double)q[i] * q[i]; }

@@ -368,6 +368,54 @@ __device__ __forceinline__ void bitonic_group(float& key, float& p1, float& p2, 
     }
 }
 
+// 64 lanes sorted by (segment, coordinate AXIS, atom): segments are runs of lanes (an element's segment = the first lane of its
+// run), so every element stays inside its run.  AXIS < 0: by segment and atom alone.
+template <int AXIS>
+__device__ __forceinline__ void bitonic64_seg(int& seg, float& x, float& y, float& z, uint32_t& o, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int os = __shfl_xor(seg, j);
+            const float ox = __shfl_xor(x, j), oy = __shfl_xor(y, j), oz = __shfl_xor(z, j);
+            const uint32_t oo = __shfl_xor(o, j);
+            const float key = AXIS == 0 ? x : (AXIS == 1 ? y : (AXIS == 2 ? z : 0.f));
+            const float ok = AXIS == 0 ? ox : (AXIS == 1 ? oy : (AXIS == 2 ? oz : 0.f));
+            const bool asc = ((lane & k) == 0) || (k == 64);
+            const bool lower = (lane & j) == 0;
+            const bool mine_gt = seg > os || (seg == os && (key > ok || (key == ok && o > oo)));
+            const bool mine_lt = seg < os || (seg == os && (key < ok || (key == ok && o < oo)));
+            const bool take = (lower == asc) ? mine_gt : mine_lt;
+            if (take) { seg = os; x = ox; y = oy; z = oz; o = oo; }
+        }
+    }
+}
+
+// Clusters by interaction kind (handles with kind_split).  The 64 atoms of a tile are first parted into those with a Lennard-Jones
+// well and NO charge, the rest, and padding; each part is then cut like the whole tile is otherwise - by y, then x, then z - but
+// at the multiple of 8 lanes nearest the middle of the run, so that the parts may have any size: a run [a, b) that touches c > 1
+// clusters is sorted along the level's axis and cut at lane 8 (floor(a / 8) + ceil(c / 2)).  Three levels bring every run inside
+// one cluster (8 -> 4 -> 2 -> 1 clusters).  Four-site water: a tile of 16 molecules becomes 2 clusters of oxygens and 6 of
+// hydrogens and M sites; the pruning pass then drops the cluster pairs between the two kinds (6 of the 16 site pairs of two such
+// waters interact neither way).  Measured at 1,048,576 sites of OPC (rc 10 + skin 2): 9 % fewer cluster pairs - the single-kind
+// clusters are larger boxes, so more of them come within range of one another - pair kernel 820 -> 783 us per step, pruning pass
+// 290 -> 345 us per rebuild, 712 -> 742 steps/s.  (A pair-kernel body that also left the Lennard-Jones arithmetic out for
+// charge-only entries and the Coulomb arithmetic for well-only ones - 9 and 24 of ~47 VALU instructions - bought another 1.3 %
+// of the kernel, 742 -> 747, and lost at 23 k sites: dropped.)
+__device__ __forceinline__ void kind_tile_order(float& x, float& y, float& z, uint32_t& o, int group, int lane) {
+    int seg = group;                    // 0: well and no charge, 1: the other atoms, 2: padding
+    bitonic64_seg<-1>(seg, x, y, z, o, lane);
+    const int n0 = __popcll(__ballot(seg == 0)), nv = __popcll(__ballot(seg != 2));
+    int a = lane < n0 ? 0 : (lane < nv ? n0 : nv), b = lane < n0 ? n0 : (lane < nv ? nv : 64);
+    auto cut = [&]() {
+        const int fa = a >> 3, c = ((b + 7) >> 3) - fa;
+        if (c > 1) { const int m = 8 * (fa + ((c + 1) >> 1)); if (lane < m) b = m; else a = m; }
+    };
+    seg = a; bitonic64_seg<1>(seg, x, y, z, o, lane); cut();
+    seg = a; bitonic64_seg<0>(seg, x, y, z, o, lane); cut();
+    seg = a; bitonic64_seg<2>(seg, x, y, z, o, lane);
+}
+
 __global__ __launch_bounds__(256) void assign_tiles_kernel(
     uint32_t T, int nzb, const uint32_t* __restrict__ tile_col, const uint32_t* __restrict__ tile_start,
     const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ sorted_orig,
@@ -433,22 +481,26 @@ __global__ void gather_slots_kernel(uint32_t S, const uint32_t* __restrict__ ori
 
 __global__ void cluster_bbox_kernel(uint32_t NC, const uint32_t* __restrict__ orig_of,
                                     const float4* __restrict__ posq, const uint8_t* __restrict__ slot_flags,
-                                    float4* __restrict__ cl_lo, float4* __restrict__ cl_hi) {
+                                    float4* __restrict__ cl_lo, float4* __restrict__ cl_hi,
+                                    const float2* __restrict__ lj, uint8_t* __restrict__ cl_kind) {
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= NC) return;
     float3 lo = make_float3(3.0e38f, 3.0e38f, 3.0e38f), hi = make_float3(-3.0e38f, -3.0e38f, -3.0e38f);
     int n = 0, n_owned = 0;
+    uint32_t kind = 0;
     for (int k = 0; k < MDX_CLUSTER; ++k) {
         uint32_t s = c * MDX_CLUSTER + k;
         if (orig_of[s] == MDX_INVALID) continue;
         n_owned += (slot_flags[s] >> 1) & 1;
         float4 p = posq[s];
+        kind |= (lj[s].y != 0.f ? 1u : 0u) | (p.w != 0.f ? 2u : 0u);
         lo.x = fminf(lo.x, p.x); lo.y = fminf(lo.y, p.y); lo.z = fminf(lo.z, p.z);
         hi.x = fmaxf(hi.x, p.x); hi.y = fmaxf(hi.y, p.y); hi.z = fmaxf(hi.z, p.z);
         ++n;
     }
     cl_lo[c] = make_float4(lo.x, lo.y, lo.z, (float)n);
     cl_hi[c] = make_float4(hi.x, hi.y, hi.z, (float)n_owned);   // .w: atoms this rank owns (half list)
+    cl_kind[c] = (uint8_t)kind;
 }
 
 __global__ void unsort_kernel(uint32_t N, const uint32_t* __restrict__ gid, const uint32_t* __restrict__ slot_of,
@@ -996,7 +1048,8 @@ __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, f
                                                          const float4* __restrict__ posq, ListCounts* __restrict__ counts,
                                                          const uint32_t* __restrict__ entry_off, uint2* __restrict__ entries,
                                                          uint32_t null_cluster, unsigned long long* __restrict__ pair_count,
-                                                         const uint32_t* __restrict__ rb_ctl, uint32_t* __restrict__ tile_int) {
+                                                         const uint32_t* __restrict__ rb_ctl, uint32_t* __restrict__ tile_int,
+                                                         const uint8_t* __restrict__ cl_kind) {
     __shared__ float4 s_j[4][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t first_ghost_cluster = 0xFFFFFFFFu;
@@ -1027,6 +1080,14 @@ __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, f
     float4 rep[NTRY ? NTRY : 1];
 #pragma unroll
     for (int k = 0; k < NTRY; ++k) rep[k] = posq[(size_t)t * MDX_TILE + (lane & 7) * MDX_CLUSTER + TI[k]];
+    // interaction kinds (cl_kind, null: every cluster pair may interact): which i-clusters hold an atom with a Lennard-Jones
+    // well / a charged atom.  A cluster pair with no kind in common - oxygens of a four-site water against hydrogens and M sites -
+    // has no force between any of its atoms and leaves the list whatever the distances say.
+    uint32_t ilj = 0xFFu, iq = 0xFFu;
+    if (cl_kind) {
+        const uint32_t k = lane < MDX_CL_PER_TILE ? cl_kind[(size_t)t * MDX_CL_PER_TILE + lane] : 0u;
+        ilj = (uint32_t)__ballot((k & 1u) != 0u) & 0xFFu; iq = (uint32_t)__ballot((k & 2u) != 0u) & 0xFFu;
+    }
     const ListCounts cnt = counts[t];
     const uint32_t e0 = entry_off[t], nmc = cnt.n_masked >> 3, nchunks = (cnt.n_masked + cnt.n_plain) >> 3;
     uint32_t kept = 0, wcur = 0;                   // wcur: plain entries written back so far
@@ -1051,6 +1112,11 @@ __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, f
         s_j[wave][lane] = pj;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
         uint32_t newy = ent.y;                     // lanes 8e .. 8e+7 hold entry e
+        if (cl_kind) {                             // i-clusters that share a kind with this lane's entry
+            const uint32_t kj = ent.x < null_cluster ? cl_kind[ent.x] : 0u;
+            newy = (ent.y & 0xFFu) | (ent.y & ((((kj & 1u) ? ilj : 0u) | ((kj & 2u) ? iq : 0u)) << 8));
+        }
+        const uint32_t y_in = newy;
         unsigned long long acc = 0ull;             // bit e * 8 + ci: cluster pair (ci, e) has an atom pair inside r for sure
 #pragma unroll
         for (int k = 0; k < NTRY; ++k) {
@@ -1061,7 +1127,7 @@ __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, f
 #pragma unroll 2
         for (int e = 0; e < 8; ++e) {
             const float4 q = s_j[wave][e * 8 + jj];
-            const uint32_t y = __builtin_amdgcn_readlane(ent.y, e * 8);
+            const uint32_t y = __builtin_amdgcn_readlane(y_in, e * 8);
             const uint32_t sure = (uint32_t)(acc >> (e * 8)) & 0xFFu;
             uint32_t any = sure;
             // only the i-clusters the bounding-box test let through (~5 of 8) and the quick accept left open
@@ -1111,7 +1177,8 @@ __global__ __launch_bounds__(W * 64) void prune_list_mw_kernel(uint32_t T, float
                                                                const float4* __restrict__ posq, ListCounts* __restrict__ counts,
                                                                const uint32_t* __restrict__ entry_off, uint2* __restrict__ entries,
                                                                uint32_t null_cluster, unsigned long long* __restrict__ pair_count,
-                                                               const uint32_t* __restrict__ rb_ctl, uint32_t* __restrict__ tile_int) {
+                                                               const uint32_t* __restrict__ rb_ctl, uint32_t* __restrict__ tile_int,
+                                                               const uint8_t* __restrict__ cl_kind) {
     __shared__ float4 s_j[W][64];
     __shared__ uint32_t s_ghost;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1133,6 +1200,14 @@ __global__ __launch_bounds__(W * 64) void prune_list_mw_kernel(uint32_t T, float
         xi[ci] = p.x; yi[ci] = p.y; zi[ci] = p.z;
     }
     const float4 rep = posq[(size_t)t * MDX_TILE + (lane & 7) * MDX_CLUSTER];      // quick accept: atom 0 of i-cluster (lane & 7)
+    // interaction kinds (cl_kind, null: every cluster pair may interact): which i-clusters hold an atom with a Lennard-Jones
+    // well / a charged atom.  A cluster pair with no kind in common - oxygens of a four-site water against hydrogens and M sites -
+    // has no force between any of its atoms and leaves the list whatever the distances say.
+    uint32_t ilj = 0xFFu, iq = 0xFFu;
+    if (cl_kind) {
+        const uint32_t k = lane < MDX_CL_PER_TILE ? cl_kind[(size_t)t * MDX_CL_PER_TILE + lane] : 0u;
+        ilj = (uint32_t)__ballot((k & 1u) != 0u) & 0xFFu; iq = (uint32_t)__ballot((k & 2u) != 0u) & 0xFFu;
+    }
     const ListCounts cnt = counts[t];
     const uint32_t e0 = entry_off[t], nchunks = (cnt.n_masked + cnt.n_plain) >> 3;
     uint32_t kept = 0;
@@ -1153,6 +1228,11 @@ __global__ __launch_bounds__(W * 64) void prune_list_mw_kernel(uint32_t T, float
         s_j[wave][lane] = pj;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
         uint32_t newy = ent.y;
+        if (cl_kind) {                             // (see prune_list_kernel)
+            const uint32_t kj = ent.x < null_cluster ? cl_kind[ent.x] : 0u;
+            newy = (ent.y & 0xFFu) | (ent.y & ((((kj & 1u) ? ilj : 0u) | ((kj & 2u) ? iq : 0u)) << 8));
+        }
+        const uint32_t y_in = newy;
         unsigned long long acc;
         {
             const float4 q = s_j[wave][lane & ~7];
@@ -1162,7 +1242,7 @@ __global__ __launch_bounds__(W * 64) void prune_list_mw_kernel(uint32_t T, float
 #pragma unroll 2
         for (int e = 0; e < 8; ++e) {
             const float4 q = s_j[wave][e * 8 + jj];
-            const uint32_t y = __builtin_amdgcn_readlane(ent.y, e * 8);
+            const uint32_t y = __builtin_amdgcn_readlane(y_in, e * 8);
             const uint32_t sure = (uint32_t)(acc >> (e * 8)) & 0xFFu;
             uint32_t any = sure;
 #pragma unroll
@@ -1335,7 +1415,7 @@ static int setup_grid(mdx_handle* h) {
         ALLOC(d.orig_of, S); ALLOC(d.slot_flags, S); ALLOC(d.pme_force, S);
         ALLOC(d.role_cnt_s, S + 1); ALLOC(d.role_off_s, S + 1);
         ALLOC(d.tile_col, need_tiles);
-        ALLOC(d.cl_lo, NC); ALLOC(d.cl_hi, NC);
+        ALLOC(d.cl_lo, NC); ALLOC(d.cl_hi, NC); ALLOC(d.cl_kind, NC);
         ALLOC(d.list_counts, need_tiles);
         ALLOC(d.inner_nch, (size_t)need_tiles * 8);
         ALLOC(d.entry_cnt, (size_t)need_tiles + 1); ALLOC(d.entry_off, (size_t)need_tiles + 1);
@@ -1545,6 +1625,7 @@ struct AssignArgs {
     float4* posq; float2* lj; float4* vel; float4* ref; float4* force; uint8_t* slot_flags;
     float4* cl_lo; float4* cl_hi;
     const uint32_t* role_off_o; uint32_t* role_cnt_s;     // null without bonded roles
+    uint8_t* cl_kind; int kind_split;                     // interaction kinds per cluster; kind_split: clusters are formed per kind
 };
 __global__ __launch_bounds__(256) void rb_assign_kernel(AssignArgs a) {
     const int lane = threadIdx.x & 63;
@@ -1559,10 +1640,20 @@ __global__ __launch_bounds__(256) void rb_assign_kernel(AssignArgs a) {
         const uint32_t aend = a.cell_start[(size_t)(c + 1) * a.nzb];
         const uint32_t p = a0 + lane;
         if (p < aend) { o = a.sorted_orig[p]; const float4 q = a.pos_orig[o]; x = q.x; y = q.y; z = q.z; }
-        // halves by y, quarters by x, eighths (clusters) by z
-        bitonic_group<64>(y, x, z, o, lane);
-        bitonic_group<32>(x, y, z, o, lane);
-        bitonic_group<16>(z, x, y, o, lane);
+        if (a.kind_split) {
+            int group = 2;
+            if (o != MDX_INVALID) {
+                const uint32_t g = a.gid[o];
+                const bool silent = (a.lflag[o] & 2u) != 0;
+                group = (!silent && a.o_lj[g].y != 0.f && a.o_qs[g] == 0.f) ? 0 : 1;
+            }
+            kind_tile_order(x, y, z, o, group, lane);
+        } else {
+            // halves by y, quarters by x, eighths (clusters) by z
+            bitonic_group<64>(y, x, z, o, lane);
+            bitonic_group<32>(x, y, z, o, lane);
+            bitonic_group<16>(z, x, y, o, lane);
+        }
     }
     const uint32_t s = t * MDX_TILE + lane;
     a.orig_of[s] = o;
@@ -1603,10 +1694,12 @@ __global__ __launch_bounds__(256) void rb_assign_kernel(AssignArgs a) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) { lo[d] = fminf(lo[d], __shfl_xor(lo[d], m)); hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], m)); }
     const unsigned long long bv = __ballot(valid), bo = __ballot((fl & 2u) != 0);
+    const unsigned long long kl = __ballot(l.y != 0.f), kq = __ballot(p.w != 0.f);     // (-0.0f, the coupled atom without a well, counts as none)
     if ((lane & 7) == 0) {
         const uint32_t c = t * MDX_CL_PER_TILE + (uint32_t)(lane >> 3);
         a.cl_lo[c] = make_float4(lo[0], lo[1], lo[2], (float)__popcll((bv >> lane) & 0xFFull));
         a.cl_hi[c] = make_float4(hi[0], hi[1], hi[2], (float)__popcll((bo >> lane) & 0xFFull));   // .w: atoms this rank owns (half list)
+        a.cl_kind[c] = (uint8_t)((((kl >> lane) & 0xFFull) ? 1u : 0u) | (((kq >> lane) & 0xFFull) ? 2u : 0u));
     }
 }
 
@@ -1759,6 +1852,7 @@ static int rebuild_fast(mdx_handle* h, RebuildResult* res, bool* fell_back) {
         aa.rb_ctl = d.rb_ctl; aa.nzb = g.nzb; aa.tile_col = d.tile_col; aa.tile_start = d.tile_start; aa.cell_start = d.cell_start;
         aa.sorted_orig = d.sorted_orig; aa.pos_orig = d.pos_orig; aa.vel_orig = d.vel_orig; aa.gid = d.gid; aa.lflag = d.lflag;
         aa.o_qs = d.o_qs; aa.o_lj = d.o_lj; aa.o_invm = d.o_invm; aa.orig_of = d.orig_of; aa.slot_of = d.slot_of;
+        aa.cl_kind = d.cl_kind; aa.kind_split = h->kind_split ? 1 : 0;
         aa.posq = d.posq; aa.lj = d.lj; aa.vel = d.vel; aa.ref = d.ref; aa.force = d.force; aa.slot_flags = d.slot_flags;
         aa.cl_lo = d.cl_lo; aa.cl_hi = d.cl_hi;
         aa.role_off_o = h->n_roles ? d.role_off_o : nullptr; aa.role_cnt_s = h->n_roles ? d.role_cnt_s : nullptr;
@@ -1800,16 +1894,17 @@ static int rebuild_fast(mdx_handle* h, RebuildResult* res, bool* fell_back) {
         const float shx = h->per[0] ? h->box_hi[0] - h->box_lo[0] : 0.f, shy = h->per[1] ? h->box_hi[1] - h->box_lo[1] : 0.f,
                     shz = h->per[2] ? h->box_hi[2] - h->box_lo[2] : 0.f;
         uint32_t* const tint = classify_here ? d.tile_bnd : nullptr;
+        const uint8_t* const kinds = h->kind_split ? d.cl_kind : nullptr;     // cluster pairs without a common interaction kind leave the list
         // One wave per tile is a launch as long as its longest list: one rank of 8 of the 1 M-atom box - 3.3 k tiles, the owned ones
         // with ~150 chunks - took 233 us where the whole box, five times the work, takes 256.  Eight waves per tile up to
         // MDX_PRUNE_MW_BELOW tiles (the unfused chain keeps its 2048)
         static const uint32_t mw_below = [] { const char* e = std::getenv("MDX_PRUNE_MW_BELOW"); return e ? (uint32_t)std::atoi(e) : 12000u; }();
         if (T_bound < mw_below)
             hipLaunchKernelGGL(prune_list_mw_kernel<8>, dim3(T_bound), dim3(512), 0, st, T_bound, rb * rb, shx, shy, shz, d.posq, d.list_counts,
-                               d.entry_off, d.entries, a.null_cluster, d.pair_count, (const uint32_t*)d.rb_ctl, tint);
+                               d.entry_off, d.entries, a.null_cluster, d.pair_count, (const uint32_t*)d.rb_ctl, tint, kinds);
         else
             hipLaunchKernelGGL(prune_list_kernel, dim3((div_up(T_bound, 4) + 7u) & ~7u), dim3(256), 0, st, T_bound, rb * rb, shx, shy, shz,
-                               d.posq, d.list_counts, d.entry_off, d.entries, a.null_cluster, d.pair_count, (const uint32_t*)d.rb_ctl, tint);
+                               d.posq, d.list_counts, d.entry_off, d.entries, a.null_cluster, d.pair_count, (const uint32_t*)d.rb_ctl, tint, kinds);
     }
     MDX_TRY(mdx_remap_constraints(h));
     // ---- finish: tile orders, totals, the one read-back ----
@@ -1920,7 +2015,7 @@ int mdx_rebuild(mdx_handle* h) {
                        d.pos_orig, d.vel_orig, d.o_qs, d.o_lj, d.o_invm, d.posq, d.lj, d.vel, d.ref, d.force,
                        d.slot_flags);
     hipLaunchKernelGGL(cluster_bbox_kernel, dim3(div_up(NC, 256)), dim3(256), 0, st, NC, d.orig_of, d.posq,
-                       d.slot_flags, d.cl_lo, d.cl_hi);
+                       d.slot_flags, d.cl_lo, d.cl_hi, d.lj, d.cl_kind);
     h->in_slot_space = true;
 
     // ---- pair list: count, scan, fill ----
@@ -2008,15 +2103,16 @@ int mdx_rebuild(mdx_handle* h) {
     static const bool exact_prune = [] { const char* e = std::getenv("MDX_EXACT_PRUNE"); return !(e && e[0] == '0'); }();   // A/B knob
     auto launch_prune = [&]() {
         if (!(prune && T && exact_prune)) return;
+        const uint8_t* const kinds = h->kind_split ? d.cl_kind : nullptr;
         const float rb = a.r_build;
         const float shx = h->per[0] ? h->box_hi[0] - h->box_lo[0] : 0.f, shy = h->per[1] ? h->box_hi[1] - h->box_lo[1] : 0.f,
                     shz = h->per[2] ? h->box_hi[2] - h->box_lo[2] : 0.f;
         if (T < 2048u)          // a few hundred tiles: eight waves per tile (one wave per tile is a 1/3-empty chip waiting for its longest list)
             hipLaunchKernelGGL(prune_list_mw_kernel<8>, dim3(T), dim3(512), 0, st, T, rb * rb, shx, shy, shz, d.posq, d.list_counts,
-                               d.entry_off, d.entries, a.null_cluster, d.pair_count, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                               d.entry_off, d.entries, a.null_cluster, d.pair_count, (const uint32_t*)nullptr, (uint32_t*)nullptr, kinds);
         else
             hipLaunchKernelGGL(prune_list_kernel, dim3((div_up(T, 4) + 7u) & ~7u), dim3(256), 0, st, T, rb * rb, shx, shy, shz,
-                               d.posq, d.list_counts, d.entry_off, d.entries, a.null_cluster, d.pair_count, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                               d.posq, d.list_counts, d.entry_off, d.entries, a.null_cluster, d.pair_count, (const uint32_t*)nullptr, (uint32_t*)nullptr, kinds);
     };
     launch_prune();
 

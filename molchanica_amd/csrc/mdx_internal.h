@@ -155,6 +155,7 @@ struct DeviceState {
     uint32_t* scan_tmp = nullptr;
     // cluster bounding boxes
     float4* cl_lo = nullptr; float4* cl_hi = nullptr;  // [NC]
+    uint8_t* cl_kind = nullptr;                        // [NC] bit 0: the cluster holds an atom with a Lennard-Jones well, bit 1: a charged atom
     // pair list
     ListCounts* list_counts = nullptr;  // [T]
     uint32_t* entry_cnt = nullptr;      // [T+1] entries per tile (masked+plain), then scanned
@@ -177,6 +178,9 @@ struct DeviceState {
     float4* pme_force = nullptr;   // [S] reciprocal-space force when the chain runs on its side stream
     // constraints and virtual sites
     ConsGroup* cons_o = nullptr; ConsGroup* cons_s = nullptr;
+    // clusters in slot order (mdx_remap_constraints): staging copy, leaders per tile (a bit per slot), their counts and offsets
+    ConsGroup* cons_tmp = nullptr; unsigned long long* cons_mask = nullptr; uint32_t* cons_cnt = nullptr; uint32_t* cons_off = nullptr;
+    uint32_t cons_cap_tiles = 0; const uint32_t* cons_n_dev = nullptr;     // cons_n_dev: clusters this handle solves (device word), null = n_groups
     float* cons_vir = nullptr;     // per constraint cluster: r . G of the last SHAKE position stage (kcal/mol)
     VSite* vsite_o = nullptr; VSite* vsite_s = nullptr;
     // control / reductions
@@ -258,6 +262,7 @@ struct mdx_handle {
     bool prune_latch = false;    // ... latched for the (up to two) launches of that force call
     bool moved_outside = true;   // something other than the step loop moved atoms in slot space (minimiser, constraint projection):
                                  // the path accumulators did not see it, the next mdx_step starts with a pruning pass
+    bool kind_split = false;     // clusters are formed per interaction kind and cluster pairs without a common kind are dropped (mdx_grid.hip)
     uint32_t n_interior = 0;     // decomposed handle: tiles whose lists involve no ghost (0: no split)
     bool tile_split = false;     // tile_order / n_interior describe the current list
     bool tile_lpt_on = false;    // tile_lpt describes the current list

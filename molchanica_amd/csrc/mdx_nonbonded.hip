@@ -812,6 +812,12 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
     const uint32_t grid = ((nblocks + 7) / 8) * 8;
     if (nblocks == 0) return;
     dim3 g(grid), b(bw * 64);
+    // MDX_NB_LDS_PAD=<bytes> (experiment): dynamic LDS the pair kernel asks for and never touches, on handles whose reciprocal-space
+    // chain runs on a side stream.  Four waves of this kernel per SIMD hold the whole register file, so the chain's kernels only get
+    // a CU when a pair workgroup retires - the two time-slice instead of overlapping; padding the LDS footprint caps the pair
+    // workgroups per CU and leaves registers and LDS for the chain.
+    static const uint32_t lds_pad_env = [] { const char* e = std::getenv("MDX_NB_LDS_PAD"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+    const uint32_t lds_pad = (h->pme_on && h->pme_overlap && !ENERGY) ? lds_pad_env : 0u;
     // ONE kernel picks the inner-walk or the pruning body on the device (round 2 measured the merged launch at +1 % for 23 k atoms
     // and -0.4 % at 1 M, and launched the two flavours back to back for the large classes, the device running exactly one; since
     // the chunk loop exists twice the merged kernel is faster there too: the gated-off twin was ~5 us of a 550 us step).
@@ -830,43 +836,43 @@ static void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samec
         if (fb_all && a.b_S && (wpt == 2 || wpt == 4)) {   /* bonded workgroups behind the pair grid of both twins */  \
             NbArgs af = a; af.pair_grid = grid;                                                                        \
             const dim3 gf(grid + (uint32_t)(((size_t)a.b_S * 4 + bw * 64 - 1) / (bw * 64)));                           \
-            if (wpt == 2) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 2, true, false, D, true>), gf, b, 0, h->stream, af); \
-            else hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 4, true, false, D, true>), gf, b, 0, h->stream, af);          \
+            if (wpt == 2) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 2, true, false, D, true>), gf, b, lds_pad, h->stream, af); \
+            else hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 4, true, false, D, true>), gf, b, lds_pad, h->stream, af);          \
             h->bonded_fused = true;                                                                                    \
         }                                                                                                              \
-        else if (wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, D>), g, b, 0, h->stream, a); \
-        else if (wpt == 2) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 2, true, false, D>), g, b, 0, h->stream, a); \
-        else if (wpt == 1) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 1, true, false, D>), g, b, 0, h->stream, a); \
-        else hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 4, true, false, D>), g, b, 0, h->stream, a);               \
+        else if (wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, D>), g, b, lds_pad, h->stream, a); \
+        else if (wpt == 2) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 2, true, false, D>), g, b, lds_pad, h->stream, a); \
+        else if (wpt == 1) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 1, true, false, D>), g, b, lds_pad, h->stream, a); \
+        else hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 4, true, false, D>), g, b, lds_pad, h->stream, a);               \
     } while (0)
 #define NB_LAUNCH(G, S)                                                                                    \
     do {                                                                                                   \
-        if (h->alch_on && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true, true>), g, b, 0, h->stream, a); \
-        else if (h->alch_on) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, true, true>), g, b, 0, h->stream, a); \
-        else if (var == 1) hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, G, S>), g, b, 0, h->stream, a);     \
+        if (h->alch_on && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true, true>), g, b, lds_pad, h->stream, a); \
+        else if (h->alch_on) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, true, true>), g, b, lds_pad, h->stream, a); \
+        else if (var == 1) hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, G, S>), g, b, lds_pad, h->stream, a);     \
         else if (half && a.inner && dual_merged && wpt == 8 && split2 && !ENERGY) {   /* a tile = two workgroups of four waves */ \
             NbArgs af = a;                                                                                         \
             const uint32_t nb2 = (a.tile_order ? a.t_count : a.T) * 2u;                                            \
             af.pair_grid = ((nb2 + 7) / 8) * 8;                                                                    \
             const dim3 gf(af.pair_grid + (a.b_S ? (uint32_t)(((size_t)a.b_S * 4 + 255) / 256) : 0u)), bf(256);     \
-            if (a.b_S) { hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, 4, false, 2>), gf, bf, 0, h->stream, af); h->bonded_fused = true; } \
-            else hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, 3, false, 2>), gf, bf, 0, h->stream, af); \
+            if (a.b_S) { hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, 4, false, 2>), gf, bf, lds_pad, h->stream, af); h->bonded_fused = true; } \
+            else hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, 3, false, 2>), gf, bf, lds_pad, h->stream, af); \
         }                                                                                                          \
         else if (half && a.inner && dual_merged && wpt == 8 && a.b_S && !ENERGY) {                                 \
             NbArgs af = a; af.pair_grid = grid;                                                                    \
             const dim3 gf(grid + (uint32_t)(((size_t)a.b_S * 4 + bw * 64 - 1) / (bw * 64)));                       \
-            hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, 4>), gf, b, 0, h->stream, af); \
+            hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, 4>), gf, b, lds_pad, h->stream, af); \
             h->bonded_fused = true;                                                                                \
         }                                                                                                          \
         else if (half && a.inner && dual_merged && (wpt == 8 || merge_all)) { NB_DUAL(G, S, 3); }                  \
         else if (half && a.inner) { if (!a.force_prune) NB_DUAL(G, S, 1); NB_DUAL(G, S, 2); }   /* (a pass the host forces: no twin) */ \
-        else if (half && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true>), g, b, 0, h->stream, a); \
-        else if (half && wpt == 2) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 2, true>), g, b, 0, h->stream, a); \
-        else if (half && wpt == 1) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 1, true>), g, b, 0, h->stream, a); \
-        else if (half) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, true>), g, b, 0, h->stream, a); \
-        else if (wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, false>), g, b, 0, h->stream, a); \
-        else if (wpt == 4) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, false>), g, b, 0, h->stream, a); \
-        else hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 1, false>), g, b, 0, h->stream, a);        \
+        else if (half && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true>), g, b, lds_pad, h->stream, a); \
+        else if (half && wpt == 2) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 2, true>), g, b, lds_pad, h->stream, a); \
+        else if (half && wpt == 1) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 1, true>), g, b, lds_pad, h->stream, a); \
+        else if (half) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, true>), g, b, lds_pad, h->stream, a); \
+        else if (wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, false>), g, b, lds_pad, h->stream, a); \
+        else if (wpt == 4) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, false>), g, b, lds_pad, h->stream, a); \
+        else hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 1, false>), g, b, lds_pad, h->stream, a);        \
     } while (0)
     if (geom) { if (samecut) NB_LAUNCH(true, true); else NB_LAUNCH(true, false); }
     else      { if (samecut) NB_LAUNCH(false, true); else NB_LAUNCH(false, false); }

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from molchanica_amd import MdConfig, systems
+from molchanica_amd import _abi
 
 pytestmark = pytest.mark.gpu
 KB = 0.0019872041
@@ -122,6 +123,49 @@ def test_opc_box_conserves_energy_after_equilibration(mdx):
     drift = (e1["potential"] + e1["kinetic"]) - (e0["potential"] + e0["kinetic"])
     assert abs(drift) < 0.01 * e0["kinetic"], f"dE = {drift:.1f} kcal/mol (kinetic {e0['kinetic']:.0f})"
     assert abs(e1["temperature"] - e0["temperature"]) < 25.0
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_clusters_by_interaction_kind_change_the_list_not_the_forces(mdx, mode, monkeypatch):
+    """Four-site water: oxygens carry the Lennard-Jones well and no charge, hydrogens and M sites the charges.  The tile assignment
+    (mdx_grid.hip kind_tile_order) then forms clusters per kind and the pruning pass drops the cluster pairs between the kinds -
+    fewer listed pairs, the same trajectory, forces and energies; a system without such atoms forced through the same ordering
+    (MDX_KIND_CLUSTERS=1) comes out the same too."""
+    s = systems.opc_water_box(10, seed=13)
+    cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=2.0, coulomb_mode=mode, ewald_alpha=0.35,
+                   overrides=_abi.OVR_LONG_RANGE_RECIP_DISABLED if mode == 2 else 0)
+    out = {}
+    for arm in ("0", "1", None):
+        if arm is None: monkeypatch.delenv("MDX_KIND_CLUSTERS")          # the library's own choice for a system this small: off
+        else: monkeypatch.setenv("MDX_KIND_CLUSTERS", arm)
+        with mdx.MdState(s, cfg) as md:
+            md.step(0.002, None, 40)                    # (the first list of a handle is built by the unfused chain, which keeps the plain order)
+            st = md.stats()
+            out[arm] = (md.forces().astype(np.float64), md.energy(), st["n_cluster_pairs"], md.positions().astype(np.float64), st["rebuild_count"])
+    (f0, e0, n0, p0, r0), (f1, e1, n1, p1, r1) = out["0"], out["1"]
+    assert n1 < 0.95 * n0 and abs(out[None][2] - n0) < 0.01 * n0, (n0, n1, out[None][2])
+    assert r0 >= 2 and r1 >= 2 and np.abs(p1 - p0).max() < 5e-3
+    # forces and energies of the two arms at ONE geometry (a new set of positions is a rebuild through the fused chain)
+    at = {}
+    for arm in ("0", "1"):
+        monkeypatch.setenv("MDX_KIND_CLUSTERS", arm)
+        with mdx.MdState(s, cfg) as md:
+            md.set_positions(p1.astype(np.float32))
+            at[arm] = (md.forces().astype(np.float64), md.energy(), md.stats()["n_cluster_pairs"])
+    assert at["1"][2] < 0.95 * at["0"][2]
+    scale = np.maximum(np.abs(at["0"][0]).max(1), 1.0)
+    assert (np.abs(at["1"][0] - at["0"][0]).max(1) / scale).max() < 1e-4
+    for k in ("lj", "coulomb", "potential"):
+        assert at["1"][1][k] == pytest.approx(at["0"][1][k], rel=1e-5, abs=1e-3), k
+    w = systems.small_solvated()
+    wcfg = MdConfig(lj_cutoff=8.0, coulomb_cutoff=8.0, skin=1.0, coulomb_mode=1)
+    outw = {}
+    for arm in ("0", "1"):
+        monkeypatch.setenv("MDX_KIND_CLUSTERS", arm)
+        with mdx.MdState(w, wcfg) as md:
+            md.step(0.0005, None, 30)
+            outw[arm] = (md.positions().astype(np.float64), md.stats()["rebuild_count"])
+    assert outw["1"][1] >= 1 and np.abs(outw["1"][0] - outw["0"][0]).max() < 2e-4
 
 
 def test_xh_constraints_on_a_solvated_chain(mdx, orc):
