@@ -12,7 +12,8 @@ short = lambda n: re.match(r"(?:void )?([A-Za-z0-9_]+)", n).group(1)
 idx = [i for i, r in enumerate(rows) if short(r[0]) in ("integrate_kernel", "bonded_integrate_kernel")]
 n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 stretch = None
-for end in range(len(idx) - 1, n_steps, -1):
+# STEP_TL_END_FRAC: search backwards from this fraction of the run (bench.py ends with profiled, unfused tails)
+for end in range(int((len(idx) - 1) * float(os.environ.get('STEP_TL_END_FRAC', '1.0'))), n_steps, -1):
     seg = rows[idx[end - n_steps]:idx[end]]
     if not any(short(r[0]) in ("build_list_kernel", "bin_atoms_kernel", "kinetic_kernel", "rb_prep_kernel") for r in seg):
         stretch = (idx[end - n_steps], idx[end]); break
