@@ -753,7 +753,20 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         }
         h->prof_tag = -1;
         if (h->dd) h->chunk_s = -1;
+        // MDX_DEBUG_HOST=1: where the host spends a chunk - enqueueing it, or waiting for the device to finish it
+        static const bool dbg_host = [] { const char* e = std::getenv("MDX_DEBUG_HOST"); return e && e[0] == '1'; }();
+        const auto t_enq = std::chrono::steady_clock::now();
         MDX_TRY(ctl_to_host(h));
+        if (dbg_host && chunk >= 8) {      // (chunks cut short by a per-step thermostat or cadence say nothing about the step loop)
+            static double enq = 0.0, wait = 0.0; static unsigned long long steps = 0, chunks = 0;
+            const auto t_w = std::chrono::steady_clock::now();
+            enq += std::chrono::duration<double, std::micro>(t_enq - t_chunk).count();
+            wait += std::chrono::duration<double, std::micro>(t_w - t_enq).count();
+            steps += chunk; ++chunks;
+            if ((chunks & 31ull) == 0ull)
+                std::fprintf(stderr, "[mdx host] %llu steps in %llu chunks: enqueue %.1f us per step, wait at the chunk end %.1f us per step\n",
+                             steps, chunks, enq / (double)steps, wait / (double)steps);
+        }
         uint32_t done = chunk;
         bool stale_hit = false;
         int first_stale = 1 << 30;

@@ -463,6 +463,7 @@ extern "C" int mdx_configure_alchemical_window(mdx_handle* h, uint32_t mol_index
     HIP_TRY(hipStreamSynchronize(h->stream));
     MDX_TRY(mdx_unsort_state(h));       // the per-slot copy of the LJ record is refreshed by the next rebuild
     h->alch_on = on; h->alch_lambda = on ? lambda : 0.0; h->alch_lo = lo; h->alch_hi = hi;
+    h->pme_canvas_clean = false; h->pme_canvas2_clean = false;      // (a slab-decomposed mesh keeps only its block clean; the window spreads whole meshes)
     h->list_valid = false; h->forces_valid = false;
     return MDX_OK;
 }

@@ -788,6 +788,7 @@ static void pme_slab_free(PmePlan* p) {
 // Geometry, message lists, buffers and plans of the slab-decomposed mesh; called at every mdx_pme_setup (attach, box change).
 // MDX_PME_SLAB=0 keeps the replicated mesh (A/B).
 static int pme_slab_setup(mdx_handle* h, PmePlan* p) {
+    h->pme_canvas_clean = false; h->pme_clear_pending = false;      // (the block this rank clears and touches may be another from here on)
     PmePlan::Slab& sl = p->slab;
     pme_slab_free(p);
     MdxDecomp* dd = h->dd;
@@ -1043,13 +1044,31 @@ int mdx_pme_setup(mdx_handle* h) {
 // reference's default operating point (1 M sites) showed it at ~0.45 ms per step - as long as spread and both FFTs together.  It
 // now runs BEHIND the chain that dirtied the mesh, after the event the step joins on: the fill overlaps the step's light tail
 // (bonded terms, constraints, the next drift) and the next chain starts on a clean mesh.
+// The charge canvas of a handle.  Slab-decomposed mesh: a rank only ever touches its own spread block (its brick widened by drift
+// margin and spline support), and x is the slowest dimension of the mesh - the block's x-planes are one or two contiguous runs, so
+// only those are cleared (8 x 1 x 1 ranks: an eighth of the 55 MB of a 240^3 mesh per force call; 2 x 2 x 2: a bit over half).
+static int pme_clear_canvas(mdx_handle* h, PmePlan* p, float* Q, hipStream_t st) {
+    const int K1 = h->pme_K[0];
+    const size_t plane = (size_t)h->pme_K[1] * h->pme_K[2];
+    if (p->slab.on && !h->alch_on && p->slab.nb[p->slab.rank][0] < K1) {      // (an alchemical window spreads two replicated meshes: all of each)
+        const int nbx = p->slab.nb[p->slab.rank][0];
+        int x0 = p->slab.b0[p->slab.rank][0] % K1; if (x0 < 0) x0 += K1;
+        const int first = std::min(nbx, K1 - x0);
+        HIP_TRY(hipMemsetAsync(Q + (size_t)x0 * plane, 0, sizeof(float) * plane * (size_t)first, st));
+        if (nbx > first) HIP_TRY(hipMemsetAsync(Q, 0, sizeof(float) * plane * (size_t)(nbx - first), st));
+        return MDX_OK;
+    }
+    HIP_TRY(hipMemsetAsync(Q, 0, sizeof(float) * p->n_real, st));
+    return MDX_OK;
+}
+
 static int pme_clear_behind(mdx_handle* h, hipStream_t st) {
     if (!h->pme_clear_pending) return MDX_OK;
     h->pme_clear_pending = false;
     if (h->pme_block_spread_used) return MDX_OK;       // the brick spread stores every point: nothing to clear
     if (h->pme_spread_main) return MDX_OK;             // (the spread runs on the handle's stream: it clears in front of itself, alone on the chip)
     PmePlan* p = (PmePlan*)h->pme_plan;
-    HIP_TRY(hipMemsetAsync(h->d.pme_q, 0, sizeof(float) * p->n_real, st));
+    MDX_TRY(pme_clear_canvas(h, p, h->d.pme_q, st));
     h->pme_canvas_clean = true;
     if (h->alch_on && h->d.pme_q2) { HIP_TRY(hipMemsetAsync(h->d.pme_q2, 0, sizeof(float) * p->n_real, st)); h->pme_canvas2_clean = true; }
     return MDX_OK;
@@ -1089,7 +1108,7 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
     static const bool per_atom_spread = [] { const char* e = std::getenv("MDX_PME_SPREAD_PER_ATOM"); return e && e[0] == '1'; }();
     if (p->slab.on && !alch) {      // decomposed handle: x-slabs of the mesh, one per rank (above)
         float* Q = h->d.pme_q;
-        if (!h->pme_canvas_clean) HIP_TRY(hipMemsetAsync(Q, 0, sizeof(float) * p->n_real, st));
+        if (!h->pme_canvas_clean) MDX_TRY(pme_clear_canvas(h, p, Q, st));
         h->pme_canvas_clean = false;
         if (per_atom_spread || !h->in_slot_space)
             hipLaunchKernelGGL(pme_spread_kernel, dim3(div_up(h->S * 16u, 256)), dim3(256), 0, st, h->S, h->d.posq,
