@@ -403,6 +403,7 @@ def main():
         mine = md.comm_diag()
         prof(0)
         mine["step_wall_ms_profiled"] = wall_d
+        mine["rebuild_fallbacks"] = int(stats().get("rebuild_fallbacks", 0))
         mine["phase_ms_per_step"] = {k: v / 48.0 for k, v in mine.pop("phase_ms_sum").items()}
         gpu_sum = sum(mine["phase_ms_per_step"].values())
         mine["gpu_phases_ms_per_step"] = gpu_sum
@@ -415,6 +416,7 @@ def main():
                  "halo_bytes_per_step_per_rank": [r["halo_bytes_per_step"] for r in per_rank],
                  "n_owned": [r["n_owned"] for r in per_rank], "n_ghost": [r["n_ghost"] for r in per_rank],
                  "repartitions": [r["repartitions"] for r in per_rank], "local_rebuilds": [r["local_rebuilds"] for r in per_rank],
+                 "rebuild_fallbacks": [r["rebuild_fallbacks"] for r in per_rank],
                  "overlap_split_kept": [r["overlap_split"] for r in per_rank],
                  "phase_ms_per_step": {k: [round(r["phase_ms_per_step"][k], 5) for r in per_rank] for k in mine["phase_ms_per_step"]},
                  "step_wall_ms_profiled": [round(r["step_wall_ms_profiled"], 5) for r in per_rank],
@@ -493,6 +495,7 @@ def main():
                    "energy_evaluations_in_timed_region": n_energy, "untimed_preparation": prep,
                    "repartitions": int(st_nb["repartitions"]) if (world > 1 or args.decomposed) else None,
                    "local_rebuilds": int(st_nb["local_rebuilds"]) if (world > 1 or args.decomposed) else None,
+                   "rebuild_fallbacks": int(st_nb.get("rebuild_fallbacks", 0)),
                    "n_owned_rank0": int(st_nb["n_owned"]), "n_ghost_rank0": int(st_nb["n_ghost"])},
         "roofline": {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

@@ -203,6 +203,9 @@ typedef struct mdx_stats {
     /* energies: force calls of the energy flavour enqueued so far (one the device gated off behind a stale list counts), and mdx_energy / snapshot / barostat reads served by the evaluation
      * the step loop made at a cadence step (mdx_set_energy_cadence) instead of one of their own */
     uint64_t energy_evaluations, energies_from_step_loop;
+    /* list rebuilds that left the fused chain for the unfused one (a tile's entries beyond the LDS buffer of the single-pass build, a
+     * list that outgrew its arrays): correct, 2-4 x slower - a count that keeps growing says the buffers are too small for this system */
+    uint64_t rebuild_fallbacks;
 } mdx_stats;
 
 typedef struct mdx_handle mdx_handle;

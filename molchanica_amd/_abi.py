@@ -118,6 +118,7 @@ class CStats(C.Structure):
         ("local_rebuilds", C.c_uint64), ("repartition_ms_sum", C.c_double),
         ("fused_ms_sum", C.c_double), ("fused_launches", C.c_uint64),
         ("energy_evaluations", C.c_uint64), ("energies_from_step_loop", C.c_uint64),
+        ("rebuild_fallbacks", C.c_uint64),
     ]
 
     def as_dict(self) -> dict:

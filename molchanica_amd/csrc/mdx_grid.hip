@@ -593,7 +593,10 @@ constexpr int LB_MAXFLAG = LB_MAXFLAG_SIZE;
 constexpr int LB_SPC = 4;        // excluded partners per atom whose slots are kept in registers between the two uses
 constexpr int LB_CAND = 256;     // candidate j-tiles buffered between the two phases of the neighbourhood search
 constexpr int LB_PLAIN = LB_PLAIN_SIZE;   // single-pass build: plain entries of a tile buffered in LDS before its slice of the list is claimed
-constexpr int LB_PLAIN_DD = 1024;   // ... on a half-shell decomposed handle, whose ghost columns at the rim of the halo are slivers with tall tiles
+constexpr int LB_PLAIN_DD = 1536;   // ... on a half-shell decomposed handle, whose ghost columns at the rim of the halo are slivers with tall tiles
+                                    // (1024 until round 4: rank 0 of a 2 x 2 x 1 decomposition of the 1 M-atom box - corner columns 2.4 A x 2.4 A, tiles
+                                    // 110 A tall - overflowed it at EVERY rebuild and took the unfused chain: 0.85-1.4 ms per rebuild instead of 0.30;
+                                    // mdx_stats.rebuild_fallbacks counts such rebuilds, bench.py reports it per rank)
                                     // (32 KB more LDS per workgroup: with it for everybody the 1 M-atom list build went 0.37 -> 0.43 ms)
 
 __device__ __forceinline__ uint32_t hash_u32(uint32_t k) { return ((k * 2654435761u) >> 22) & (uint32_t)(LB_HASH - 1); }  // 10 bits, cut to the table
@@ -1974,7 +1977,7 @@ int mdx_rebuild(mdx_handle* h) {
         bool fell_back = false;
         MDX_TRY(rebuild_fast(h, &res, &fell_back));
         fast_done = !fell_back;
-        if (fell_back) MDX_TRY(mdx_unsort_state(h));
+        if (fell_back) { MDX_TRY(mdx_unsort_state(h)); h->stats.rebuild_fallbacks++; }
     }
     uint32_t E = res.E, MC = res.MC;
     unsigned long long npairs = res.npairs;

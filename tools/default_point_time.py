@@ -21,6 +21,6 @@ for name, cfg in cases:
         st = md.stats()
         if skin == 0.0:
             print("   library-chosen skin: %.2f A (still tuning: %s)" % md.skin(), flush=True)
-        print("inner_skin %.1f skin %.1f | OPC %d sites, dt 2 fs, %s: %.0f steps/s = %.1f ns/day  (T %.0f K, %d list rebuilds, %d pruning passes, inner/verlet cluster pairs %.2f)" % (
+        print("inner_skin %.1f skin %.1f | OPC %d sites, dt 2 fs, %s: %.0f steps/s = %.1f ns/day  (T %.0f K, %d list rebuilds, %d pruning passes, inner/verlet cluster pairs %.2f, %d rebuilds left the fused chain)" % (
             inner or 0.5, skin, s.n_atoms, name, n / el, n / el * 0.002e-3 * 86400, e["temperature"], st["rebuild_count"], st["prune_passes"],
-            st["n_inner_cluster_pairs"] / max(st["n_cluster_pairs"], 1)), flush=True)
+            st["n_inner_cluster_pairs"] / max(st["n_cluster_pairs"], 1), st.get("rebuild_fallbacks", 0)), flush=True)

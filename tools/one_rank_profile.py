@@ -35,13 +35,14 @@ def fresh(world, overlap):
 for world in worlds:
     for overlap in (os.environ.get("ONE_RANK_SPLIT", "1,0").split(",")):      # ONE_RANK_SPLIT=1 or 0: one arm only
         n_rep = max(1, steps // STRETCH)
-        wall = 0.0; rebuilds = 0; reparts = 0; rb_sum = 0.0; rp_sum = 0.0; rb_n = 0; rp_n = 0
+        wall = 0.0; rebuilds = 0; reparts = 0; rb_sum = 0.0; rp_sum = 0.0; rb_n = 0; rp_n = 0; fallbacks = 0
         for rep in range(n_rep):                      # plain (event-free) stretches: the step wall
             with fresh(world, overlap) as md:
                 md.profile(2); md.profile(0)          # (resets the timers)
                 st0 = md.stats()
                 t0 = time.perf_counter(); md.step(0.0005, None, STRETCH); st1 = md.stats(); wall += time.perf_counter() - t0    # stats() synchronises
                 rebuilds += st1["rebuild_count"] - st0["rebuild_count"]; reparts += st1["repartitions"] - st0["repartitions"]
+                fallbacks += st1.get("rebuild_fallbacks", 0) - st0.get("rebuild_fallbacks", 0)
         n_steps = n_rep * STRETCH
         if os.environ.get("ONE_RANK_TRACE", "0") == "1":     # under rocprofv3: stop here, the trace ends with plain (event-free) steps
             print("world %d split %s: step wall %.3f ms" % (world, overlap, 1e3 * wall / n_steps)); continue
@@ -61,8 +62,8 @@ for world in worlds:
         k_i = st["integ_ms_sum"] / max(st["integ_launches"], 1)
         amort = (rebuilds * rb_ms + reparts * max(rp_ms - rb_ms, 0.0)) / n_steps
         print("world %d rank 0 (interior/boundary split %s): owned %d ghost %d tiles %d | pair %.3f ms bonded %.3f integrate %.3f = %.3f ms of kernels | "
-              "step wall %.3f ms (%d list rebuilds in %d steps at %.2f ms, %d repartitions at %.2f ms incl. their rebuild: %.3f ms per step amortised; %.3f ms of the wall is in neither kernels nor list builds) -> ceiling %.0f steps/s without wire time | cluster pairs verlet %.1f M inner %.1f M" % (
+              "step wall %.3f ms (%d list rebuilds in %d steps at %.2f ms - %d left the fused chain -, %d repartitions at %.2f ms incl. their rebuild: %.3f ms per step amortised; %.3f ms of the wall is in neither kernels nor list builds) -> ceiling %.0f steps/s without wire time | cluster pairs verlet %.1f M inner %.1f M" % (
                   world, {"1": "on", "0": "off"}.get(overlap, "auto-tuned"), st["n_owned"], st["n_ghost"], st["n_tiles"], k_nb, k_b, k_i, k_nb + k_b + k_i,
-                  1e3 * wall / n_steps, rebuilds, n_steps, rb_ms, reparts, rp_ms, amort,
+                  1e3 * wall / n_steps, rebuilds, n_steps, rb_ms, fallbacks, reparts, rp_ms, amort,
                   1e3 * wall / n_steps - (k_nb + k_b + k_i) - amort, n_steps / wall,
                   st["n_cluster_pairs"] / 1e6, st["n_inner_cluster_pairs"] / 1e6), flush=True)
