@@ -548,6 +548,12 @@ __global__ void dd_add_force_kernel(uint32_t n, const uint32_t* __restrict__ ato
 }
 
 bool mdx_dd_half_shell(const mdx_handle* h) { return h->dd && h->dd->half_shell && h->dd->world > 1; }
+// the brick of this rank in a cut dimension (false: the dimension is not cut, or the handle is not decomposed)
+bool mdx_dd_brick_bounds(const mdx_handle* h, int d, float* lo, float* hi) {
+    if (!h->dd || h->dd->grid[d] <= 1) return false;
+    *lo = h->dd->brick_lo[d]; *hi = h->dd->brick_hi[d];
+    return true;
+}
 
 int mdx_dd_force_return_begin(mdx_handle* h, int flag_word) {
     MdxDecomp* dd = h->dd;

@@ -285,8 +285,8 @@ __global__ void bin_atoms_kernel(float4* __restrict__ pos_orig, uint32_t N, Grid
     if (g.per[1]) p.y = wrap1(p.y, g.lo[1], g.len[1]);
     if (g.per[2]) p.z = wrap1(p.z, g.lo[2], g.len[2]);
     pos_orig[o] = p;
-    int cx = min(g.ncx - 1, max(0, (int)((p.x - g.lo[0]) * g.inv_col[0])));
-    int cy = min(g.ncy - 1, max(0, (int)((p.y - g.lo[1]) * g.inv_col[1])));
+    int cx = min(g.ncx - 1, max(0, mdx_col_of(g, 0, p.x)));
+    int cy = min(g.ncy - 1, max(0, mdx_col_of(g, 1, p.y)));
     int zb = min(g.nzb - 1, max(0, (int)((p.z - g.lo[2]) * g.inv_zbin)));
     const int pop = (g.npop > 1 && (lflag[o] & 1u)) ? 1 : 0;      // ghosts get column sets of their own
     uint32_t cell = (uint32_t)(((pop * g.ncx + cx) * g.ncy + cy) * g.nzb + zb);
@@ -766,10 +766,10 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
     if (isinf(r) || r > 1.0e30f) {
         ix0 = 0; ix1 = g.ncx - 1; iy0 = 0; iy1 = g.ncy - 1;
     } else {
-        ix0 = (int)floorf((lo[0] - r - g.lo[0]) * g.inv_col[0]);
-        ix1 = (int)floorf((hi[0] + r - g.lo[0]) * g.inv_col[0]);
-        iy0 = (int)floorf((lo[1] - r - g.lo[1]) * g.inv_col[1]);
-        iy1 = (int)floorf((hi[1] + r - g.lo[1]) * g.inv_col[1]);
+        ix0 = mdx_col_of(g, 0, lo[0] - r);
+        ix1 = mdx_col_of(g, 0, hi[0] + r);
+        iy0 = mdx_col_of(g, 1, lo[1] - r);
+        iy1 = mdx_col_of(g, 1, hi[1] + r);
         if (!g.per[0]) { ix0 = max(ix0, 0); ix1 = min(ix1, g.ncx - 1); }
         else { ix0 = max(ix0, -g.ncx); ix1 = min(ix1, 2 * g.ncx - 1); }
         if (!g.per[1]) { iy0 = max(iy0, 0); iy1 = min(iy1, g.ncy - 1); }
@@ -779,7 +779,6 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
             if (hi[2] + r >= g.lo[2] + g.len[2]) kz1 = 1;
         }
     }
-    const float colw_x = 1.0f / g.inv_col[0], colw_y = 1.0f / g.inv_col[1];
 
     // The neighbourhood is searched in two phases (round 3; it was one loop nest over columns, images and z-windows whose every
     // iteration began with a chain of dependent loads - tile_start, cell_start, then the cluster boxes - for a window of ~4 tiles,
@@ -879,9 +878,9 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
             const int wx = ix - kx * g.ncx, wy = iy - ky * g.ncy;
             const float sx = (float)kx * g.len[0], sy = (float)ky * g.len[1], sz = (float)kz * g.len[2];
             // column slab distance in x and y (column interval, slightly widened)
-            const float cxlo = g.lo[0] + (float)wx * colw_x + sx - 1e-3f, cxhi = cxlo + colw_x + 2e-3f;
+            const float cxlo = mdx_col_lo(g, 0, wx) + sx - 1e-3f, cxhi = mdx_col_lo(g, 0, wx + 1) + sx + 1e-3f;
             const float gx = (wx == 0 || wx == g.ncx - 1) ? 0.f : gap(cxlo, cxhi, lo[0], hi[0]);
-            const float cylo = g.lo[1] + (float)wy * colw_y + sy - 1e-3f, cyhi = cylo + colw_y + 2e-3f;
+            const float cylo = mdx_col_lo(g, 1, wy) + sy - 1e-3f, cyhi = mdx_col_lo(g, 1, wy + 1) + sy + 1e-3f;
             const float gy = (wy == 0 || wy == g.ncy - 1) ? 0.f : gap(cylo, cyhi, lo[1], hi[1]);
             if (gx * gx + gy * gy < r2) {
                 const uint32_t c2 = (uint32_t)((pop * g.ncx + wx) * g.ncy + wy);
@@ -1382,6 +1381,21 @@ static int setup_grid(mdx_handle* h) {
     while ((double)g.ncx * g.ncy > 4.0e6) { g.ncx = std::max(1, g.ncx / 2); g.ncy = std::max(1, g.ncy / 2); }
     g.inv_col[0] = (float)(g.ncx / (double)g.len[0]);
     g.inv_col[1] = (float)(g.ncy / (double)g.len[1]);
+    {   // piecewise columns in the cut dimensions of a half-shell decomposed handle (GridParams; MDX_GRID_PIECEWISE=0: uniform, A/B)
+        static const bool pw_env = [] { const char* e = std::getenv("MDX_GRID_PIECEWISE"); return !(e && e[0] == '0'); }();
+        for (int d = 0; d < 2; ++d) {
+            g.pw[d] = 0; g.nh[d] = 0; g.nbk[d] = 0; g.b_lo[d] = g.b_hi[d] = 0.f; g.inv_wh[d] = g.inv_wb[d] = 0.f;
+            float blo = 0.f, bhi = 0.f;
+            if (!pw_env || h->per[d] || !h->have_local_bounds || !mdx_dd_half_shell(h) || !mdx_dd_brick_bounds(h, d, &blo, &bhi)) continue;
+            const double wh = (double)blo - (double)g.lo[d], wb = (double)bhi - (double)blo, wh2 = (double)g.lo[d] + (double)g.len[d] - (double)bhi;
+            if (!(wh > 0.5 && wb > 0.5 && std::fabs(wh - wh2) < 1e-2 * wh)) continue;
+            g.pw[d] = 1; g.b_lo[d] = blo; g.b_hi[d] = bhi;
+            g.nh[d] = std::max(1, (int)std::lround(wh / s)); g.nbk[d] = std::max(1, (int)std::lround(wb / s));
+            g.inv_wh[d] = (float)(g.nh[d] / wh); g.inv_wb[d] = (float)(g.nbk[d] / wb);
+            (d == 0 ? g.ncx : g.ncy) = 2 * g.nh[d] + g.nbk[d];
+            g.inv_col[d] = (float)((d == 0 ? g.ncx : g.ncy) / (double)g.len[d]);      // (the mean width: sizes the z-bins below)
+        }
+    }
     const double col_area = ((double)g.len[0] / g.ncx) * ((double)g.len[1] / g.ncy);
     double zh = 6.0 / (rho * col_area);          // ~6 atoms per fine cell
     zh = std::min(std::max(zh, 0.25), (double)g.len[2]);
@@ -1534,8 +1548,8 @@ __global__ __launch_bounds__(256) void rb_prep_kernel(uint32_t N, GridParams g, 
     if (g.per[1]) p.y = wrap1(p.y, g.lo[1], g.len[1]);
     if (g.per[2]) p.z = wrap1(p.z, g.lo[2], g.len[2]);
     pos_orig[o] = p;
-    const int cx = min(g.ncx - 1, max(0, (int)((p.x - g.lo[0]) * g.inv_col[0])));
-    const int cy = min(g.ncy - 1, max(0, (int)((p.y - g.lo[1]) * g.inv_col[1])));
+    const int cx = min(g.ncx - 1, max(0, mdx_col_of(g, 0, p.x)));
+    const int cy = min(g.ncy - 1, max(0, mdx_col_of(g, 1, p.y)));
     const int zb = min(g.nzb - 1, max(0, (int)((p.z - g.lo[2]) * g.inv_zbin)));
     const int pop = (g.npop > 1 && (lflag[o] & 1u)) ? 1 : 0;      // ghosts get column sets of their own
     const uint32_t cell = (uint32_t)(((pop * g.ncx + cx) * g.ncy + cy) * g.nzb + zb);

@@ -46,7 +46,29 @@ struct GridParams {
                        // sets (column = (pop * ncx + cx) * ncy + cy), so every tile and cluster is all-owned or all-ghost and
                        // "no ghost-ghost pair is evaluated" is a cluster-level decision (mdx_decomp.hip: forces on ghosts go back)
     int per[3];        // periodic per dimension (a decomposed dimension is not periodic locally)
+    // Piecewise column grid (x, y of a half-shell decomposed handle, dimension by dimension; pw[d] = 0: uniform).  The local region
+    // of a rank is halo | brick | halo; one uniform grid over it cuts the columns at the brick faces into an owned part and a ghost
+    // part - slivers a few Angstrom wide whose 64-atom tiles are 30-110 A tall (needle clusters: several times the neighbours of a
+    // compact one, and lists that overflowed the list build's LDS buffer).  Here each of the three regions has whole columns of
+    // its own width: nh of them per halo region, nbk over the brick.
+    int pw[2], nh[2], nbk[2];
+    float b_lo[2], b_hi[2], inv_wh[2], inv_wb[2];
 };
+// column of a coordinate (unclamped) and lower edge of a column, for either grid form
+__host__ __device__ static inline int mdx_col_of(const GridParams& g, int d, float x) {
+    if (!g.pw[d]) return (int)floorf((x - g.lo[d]) * g.inv_col[d]);
+    if (x < g.b_lo[d]) return (int)floorf((x - g.lo[d]) * g.inv_wh[d]);
+    if (x < g.b_hi[d]) { const int i = (int)((x - g.b_lo[d]) * g.inv_wb[d]); return g.nh[d] + (i < g.nbk[d] ? i : g.nbk[d] - 1); }
+    return g.nh[d] + g.nbk[d] + (int)floorf((x - g.b_hi[d]) * g.inv_wh[d]);
+}
+__host__ __device__ static inline float mdx_col_lo(const GridParams& g, int d, int i) {
+    if (!g.pw[d]) return g.lo[d] + (float)i / g.inv_col[d];
+    if (i < g.nh[d]) return g.lo[d] + (float)i / g.inv_wh[d];
+    if (i == g.nh[d]) return g.b_lo[d];
+    if (i < g.nh[d] + g.nbk[d]) return g.b_lo[d] + (float)(i - g.nh[d]) / g.inv_wb[d];
+    if (i == g.nh[d] + g.nbk[d]) return g.b_hi[d];
+    return g.b_hi[d] + (float)(i - g.nh[d] - g.nbk[d]) / g.inv_wh[d];
+}
 
 struct NbParams {
     float rc2_lj, rc2_coul;  // squared cut-offs (FLT_MAX = none)
@@ -206,6 +228,7 @@ struct DeviceState {
 
 struct MdxDecomp;   // mdx_comm.h: the handle is one rank of a spatially decomposed box
 struct mdx_handle;
+bool mdx_dd_brick_bounds(const mdx_handle* h, int d, float* lo, float* hi);   // this rank's brick in a cut dimension (false: not cut / not decomposed)
 bool mdx_dd_half_shell(const mdx_handle* h);   // decomposed with a half-shell halo: every cross-rank pair is evaluated on ONE rank, ghost forces travel back
 
 struct mdx_handle {
