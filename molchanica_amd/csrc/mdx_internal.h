@@ -285,6 +285,9 @@ struct mdx_handle {
     bool prune_latch = false;    // ... latched for the (up to two) launches of that force call
     bool moved_outside = true;   // something other than the step loop moved atoms in slot space (minimiser, constraint projection):
                                  // the path accumulators did not see it, the next mdx_step starts with a pruning pass
+    // host work to do while the device finishes an energy evaluation (mdx_single_point: the fingerprint of the static arrays);
+    // called once, between the read-back's enqueue and the wait for it
+    void (*wait_hook)(void*) = nullptr; void* wait_hook_arg = nullptr;
     bool kind_split = false;     // clusters are formed per interaction kind and cluster pairs without a common kind are dropped (mdx_grid.hip)
     uint32_t n_interior = 0;     // decomposed handle: tiles whose lists involve no ghost (0: no split)
     bool tile_split = false;     // tile_order / n_interior describe the current list

@@ -387,6 +387,17 @@ def test_single_point_scorer_pose_after_pose(mdx, orc):
     e4 = mdx.compute_energy_snapshot(s, cfg)
     with mdx.MdState(s, cfg) as md:
         assert close(e4["potential"], md.energy()["potential"])
+    # the same counts and config but other charges: the cached handle passes every cheap comparison and is scored optimistically
+    # while the fingerprint of the static arrays is computed - which must then send the call the long way
+    import copy
+    s5 = copy.deepcopy(s)
+    s5.charge = (s5.charge * np.float32(0.9)).astype(np.float32)
+    e5 = mdx.compute_energy_snapshot(s5, cfg)
+    with mdx.MdState(s5, cfg) as md:
+        e5_fresh = md.energy()
+    assert close(e5["coulomb"], e5_fresh["coulomb"]) and not close(e5["coulomb"], e4["coulomb"])
+    e6 = mdx.compute_energy_snapshot(s, cfg)
+    assert close(e6["potential"], e4["potential"])
     mdx.release_single_point_cache()
     mdx.release_single_point_cache()      # idempotent
 
