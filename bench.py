@@ -500,6 +500,8 @@ def main():
         "roofline": {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "launch_ms": nb_ms, "launches": nb_launches,
+                     "launch_sampling": ("HIP events around every %s-th executed pair launch of the timed region + tail (MDX_PROF_SAMPLE; a bracket on "
+                                         "every launch costs 10-14 us of a step: 2 %% at water1M, 28 %% at dhfr23k)" % os.environ.get("MDX_PROF_SAMPLE", "8")),
                      "algorithmic_bytes_per_launch": B_ALG_NONBONDED * atoms_per_launch,
                      "note": "pair loop is fp32-VALU bound, see valu.frac; HBM fraction is low by physics"},
         # the streaming kernels, in SURVEY 8d's algorithmic bytes (profiled 48-step tail, every kernel bracketed)

@@ -551,6 +551,14 @@ void mdx_prof_begin(mdx_handle* h, int kind, hipStream_t st) {
     h->prof_open = false;
     if (!h->profile) return;
     if (h->profile_level == 2 && kind != 0 && kind != 4) return;   // pair kernel of the step loop only
+    if (h->profile_level == 2) {
+        // ... and of those every eighth launch (MDX_PROF_SAMPLE; 1 = all): two hipEventRecords around a launch cost 10-14 us of a
+        // step - 28 % of a 23 k-atom step, 16 % at 51 k atoms, 2 % at 1 M (bench.py --profile-level 0 against 2, round 4) - so a
+        // bracket on every launch made the measured rate an artefact of measuring.  The two halves of a split launch go together.
+        static const uint32_t every = [] { const char* e = std::getenv("MDX_PROF_SAMPLE"); const int v = e ? std::atoi(e) : 8; return (uint32_t)(v < 1 ? 1 : v); }();
+        if (kind == 0) h->prof_sampled = (h->prof_seq++ % every) == 0u;
+        if (!h->prof_sampled) return;
+    }
     if (kind >= 6 && h->profile_level != 3) return;                // the phases of a decomposed step: level 3
     h->prof_open = true;
     mdx_handle::EvPair p{};

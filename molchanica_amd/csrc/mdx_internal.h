@@ -322,6 +322,7 @@ struct mdx_handle {
     bool profile = false; int profile_level = 0; bool prof_open = false;
     struct EvPair { hipEvent_t a, b; int kind; int tag; hipStream_t st; };
     int prof_tag = -1;       // chunk step of the launches being enqueued (-1: ungated)
+    uint32_t prof_seq = 0; bool prof_sampled = false;     // level 2 brackets every MDX_PROF_SAMPLE-th pair launch (mdx_prof_begin)
     std::vector<EvPair> ev_pending;
     std::vector<hipEvent_t> ev_pool;
     mdx_stats stats{};
