@@ -1445,10 +1445,11 @@ int mdx_set_local_atoms_impl(mdx_handle* h, uint32_t n_local, const uint32_t* d_
     MDX_TRY(check_box(per, h->box_lo, h->box_hi, &h->cfg));
     hipStream_t st = h->stream;
     DeviceState& d = h->d;
-    HIP_TRY(hipMemcpyAsync(d.gid, d_gid, sizeof(uint32_t) * n_local, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d.lflag, d_ghost, sizeof(uint8_t) * n_local, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d.pos_orig, d_pos4, sizeof(float4) * n_local, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d.vel_orig, d_vel4, sizeof(float4) * n_local, hipMemcpyDeviceToDevice, st));
+    // (the library's own decomposition fills these arrays in place: nothing to copy then)
+    if (d_gid != d.gid) HIP_TRY(hipMemcpyAsync(d.gid, d_gid, sizeof(uint32_t) * n_local, hipMemcpyDeviceToDevice, st));
+    if (d_ghost != d.lflag) HIP_TRY(hipMemcpyAsync(d.lflag, d_ghost, sizeof(uint8_t) * n_local, hipMemcpyDeviceToDevice, st));
+    if ((const void*)d_pos4 != (const void*)d.pos_orig) HIP_TRY(hipMemcpyAsync(d.pos_orig, d_pos4, sizeof(float4) * n_local, hipMemcpyDeviceToDevice, st));
+    if ((const void*)d_vel4 != (const void*)d.vel_orig) HIP_TRY(hipMemcpyAsync(d.vel_orig, d_vel4, sizeof(float4) * n_local, hipMemcpyDeviceToDevice, st));
     h->n_local = n_local;
     for (int k = 0; k < 3; ++k) { h->per[k] = per[k]; h->local_lo[k] = lo[k]; h->local_hi[k] = hi[k]; }
     h->periodic = per[0] || per[1] || per[2];

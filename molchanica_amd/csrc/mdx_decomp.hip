@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void dd_classify_kernel(uint32_t N, const floa
                                                           const RoleRec* __restrict__ roles,
                                                           uint8_t* __restrict__ cls, uint8_t* __restrict__ owner,
                                                           uint8_t* __restrict__ shift_code, uint32_t* __restrict__ send_mask,
-                                                          uint32_t* __restrict__ flags, uint32_t* __restrict__ err) {
+                                                          uint32_t* __restrict__ err) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
     const float4 pg = g_pos[g];
@@ -159,14 +159,30 @@ __global__ __launch_bounds__(256) void dd_classify_kernel(uint32_t N, const floa
         }
     }
     cls[g] = (uint8_t)c; owner[g] = (uint8_t)own; shift_code[g] = (uint8_t)code; send_mask[g] = mask;
-    // compaction flags: segment 2q = "send to q", 2q + 1 = "received from q", 2W = local, 2W + 1 = owned
-    const size_t Ns = N;
-    for (int q = 0; q < p.world; ++q) {
-        flags[(size_t)(2 * q) * Ns + g] = (mask >> q) & 1u;
-        flags[(size_t)(2 * q + 1) * Ns + g] = (c >= 2u && own == q) ? 1u : 0u;
+}
+
+// Compaction of the partition's lists (segment 2q = "send to q", 2q + 1 = "received from q", 2W = local, 2W + 1 = owned), two
+// levels (round 4; it was one flag word per atom and segment - 18 x 1 M flags at 8 ranks - and one scan over all of them: 126 us
+// of a 320 us repartition).  Membership is a function of what dd_classify_kernel already stored per atom; a wave counts its members
+// of every segment with one ballot each, the counts [segment][wave] are scanned (a few hundred thousand words), and the fill
+// pass ranks an atom inside its wave with the same ballots: lists in ascending atom order, as before.
+__device__ __forceinline__ bool dd_member(int seg, int world, uint32_t c, uint32_t own, uint32_t mask) {
+    if (seg < 2 * world) { const int q = seg >> 1; return (seg & 1) ? (c >= 2u && own == (uint32_t)q) : (((mask >> q) & 1u) != 0u); }
+    return seg == 2 * world ? c != 0u : c == 1u;
+}
+__global__ __launch_bounds__(256) void dd_count_kernel(uint32_t N, int world, const uint8_t* __restrict__ cls, const uint8_t* __restrict__ owner,
+                                                       const uint32_t* __restrict__ send_mask, uint32_t n_waves, uint32_t* __restrict__ wave_cnt) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = g < N;
+    const uint32_t c = in ? cls[g] : 0u, own = in ? owner[g] : 0xFFu, mask = in ? send_mask[g] : 0u;
+    const uint32_t wave = g >> 6;
+    if (wave >= n_waves) return;
+    const int nseg = 2 * world + 2;
+    for (int seg = 0; seg < nseg; ++seg) {
+        const unsigned long long b = __ballot(in && dd_member(seg, world, c, own, mask));
+        if ((threadIdx.x & 63) == 0) wave_cnt[(size_t)seg * n_waves + wave] = (uint32_t)__popcll(b);
     }
-    flags[(size_t)(2 * p.world) * Ns + g] = c != 0u;
-    flags[(size_t)(2 * p.world + 1) * Ns + g] = c == 1u;
+    if (g == 0) wave_cnt[(size_t)nseg * n_waves] = 0u;      // the scan's trailing element: the grand total lands there
 }
 
 struct DdFill {
@@ -174,38 +190,55 @@ struct DdFill {
     uint32_t send_base[DD_MAX_WORLD], recv_base[DD_MAX_WORLD];   // first row of a peer's segment in the halo buffers
 };
 
-__global__ __launch_bounds__(256) void dd_fill_kernel(uint32_t N, int world, DdPart p, DdFill f, const uint32_t* __restrict__ flags,
+__global__ __launch_bounds__(256) void dd_fill_kernel(uint32_t N, int world, DdPart p, DdFill f, const uint32_t* __restrict__ send_mask,
+                                                      const uint8_t* __restrict__ owner, uint32_t n_waves,
                                                       const uint32_t* __restrict__ scan, const float4* __restrict__ g_pos,
                                                       const float4* __restrict__ g_vel, const uint8_t* __restrict__ cls,
                                                       const uint8_t* __restrict__ shift_code, uint32_t* __restrict__ send_ids,
                                                       uint32_t* __restrict__ recv_ids, float4* __restrict__ recv_shift,
                                                       uint32_t* __restrict__ gid_local, uint8_t* __restrict__ ghost_local,
-                                                      float4* __restrict__ pos_l, float4* __restrict__ vel_l, uint32_t* __restrict__ owned_gid) {
+                                                      float4* __restrict__ pos_l, float4* __restrict__ vel_l, uint32_t* __restrict__ owned_gid,
+                                                      float4* __restrict__ pos_at_part) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    const int seg = blockIdx.y;
-    if (g >= N) return;
-    const size_t idx = (size_t)seg * N + g;
-    if (!flags[idx]) return;
-    const uint32_t k = scan[idx] - f.seg_start[seg];
-    const uint32_t code = shift_code[g];
+    if (blockIdx.x == 0 && (int)threadIdx.x < world && (int)threadIdx.x != p.rank) {
+        // the flag row behind every peer's segment (it was three fills over the whole lists and a kernel's worth of gaps)
+        const int q = threadIdx.x;
+        const uint32_t ns = f.seg_start[2 * q + 1] - f.seg_start[2 * q], nr = f.seg_start[2 * q + 2] - f.seg_start[2 * q + 1];
+        send_ids[f.send_base[q] + ns] = MDX_INVALID;
+        recv_ids[f.recv_base[q] + nr] = MDX_INVALID; recv_shift[f.recv_base[q] + nr] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const bool in = g < N;
+    const uint32_t c = in ? cls[g] : 0u, own = in ? owner[g] : 0xFFu, mask = in ? send_mask[g] : 0u;
+    const uint32_t wave = g >> 6;
+    if (wave >= n_waves) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t code = in ? shift_code[g] : 0u;
     const float sx = (float)((int)(code & 3u) - 1) * p.len[0], sy = (float)((int)((code >> 2) & 3u) - 1) * p.len[1],
                 sz = (float)((int)((code >> 4) & 3u) - 1) * p.len[2];
-    if (seg < 2 * world) {
-        const int q = seg >> 1;
-        if (!(seg & 1)) send_ids[f.send_base[q] + k] = g;
-        else { recv_ids[f.recv_base[q] + k] = g; recv_shift[f.recv_base[q] + k] = make_float4(sx, sy, sz, 0.f); }
-    } else if (seg == 2 * world) {
-        const float4 pg = g_pos[g];
-        gid_local[k] = g; ghost_local[k] = cls[g] == 2 ? 1 : (cls[g] == 3 ? 3 : 0);   // bit 0: ghost, bit 1: no pair interactions here
-        pos_l[k] = make_float4(dd_wrap1(pg.x, p.lo[0], p.len[0]) + sx, dd_wrap1(pg.y, p.lo[1], p.len[1]) + sy,
-                               dd_wrap1(pg.z, p.lo[2], p.len[2]) + sz, 0.f);
-        vel_l[k] = g_vel[g];
-    } else owned_gid[k] = g;
+    const int nseg = 2 * world + 2;
+    for (int seg = 0; seg < nseg; ++seg) {
+        const bool m = in && dd_member(seg, world, c, own, mask);
+        const unsigned long long b = __ballot(m);
+        if (!m) continue;
+        const uint32_t k = scan[(size_t)seg * n_waves + wave] - f.seg_start[seg] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        if (seg < 2 * world) {
+            const int q = seg >> 1;
+            if (!(seg & 1)) send_ids[f.send_base[q] + k] = g;
+            else { recv_ids[f.recv_base[q] + k] = g; recv_shift[f.recv_base[q] + k] = make_float4(sx, sy, sz, 0.f); }
+        } else if (seg == 2 * world) {
+            const float4 pg = g_pos[g];
+            gid_local[k] = g; ghost_local[k] = c == 2u ? 1 : (c == 3u ? 3 : 0);   // bit 0: ghost, bit 1: no pair interactions here
+            const float4 pl = make_float4(dd_wrap1(pg.x, p.lo[0], p.len[0]) + sx, dd_wrap1(pg.y, p.lo[1], p.len[1]) + sy,
+                                          dd_wrap1(pg.z, p.lo[2], p.len[2]) + sz, 0.f);
+            pos_l[k] = pl; pos_at_part[k] = pl;
+            vel_l[k] = g_vel[g];
+        } else owned_gid[k] = g;
+    }
 }
 
-__global__ void dd_seg_heads_kernel(int nseg, uint32_t N, const uint32_t* __restrict__ scan, uint32_t* __restrict__ out) {
+__global__ void dd_seg_heads_kernel(int nseg, uint32_t n_waves, const uint32_t* __restrict__ scan, uint32_t* __restrict__ out) {
     const int s = threadIdx.x;
-    if (s <= nseg) out[s] = scan[(size_t)s * N];
+    if (s <= nseg) out[s] = scan[(size_t)s * n_waves];
 }
 
 // owned rows of the global gather: (x, y, z, global id), (vx, vy, vz, -)[, (fx, fy, fz, -)]
@@ -300,21 +333,21 @@ static int dd_partition(mdx_handle* h) {
     hipStream_t st = h->stream;
     const DdPart p = make_part(dd);
     const int nseg = 2 * W + 2;
-    const size_t nflags = (size_t)nseg * N + 1;
-    if (nflags > 0xFFFFFFF0ull) FAIL(MDX_EPARAM, "system too large for the partition scan");
+    const uint32_t n_waves = div_up(N, 64);
+    const size_t nflags = (size_t)nseg * n_waves + 1;      // per-wave member counts of every segment (+ the scan's trailing element)
     if (nflags > dd->cap_flags) {
         MDX_TRY(dd_alloc(&dd->flags, nflags)); MDX_TRY(dd_alloc(&dd->scan, nflags));
         MDX_TRY(dd_alloc(&dd->scan_sums, nflags / 2048 + 64));
         dd->cap_flags = nflags;
     }
     HIP_TRY(hipMemsetAsync(h->d.flags_dev, 0, sizeof(uint32_t) * 4, st));
-    HIP_TRY(hipMemsetAsync(dd->flags + (nflags - 1), 0, sizeof(uint32_t), st));
     hipLaunchKernelGGL(dd_classify_kernel, dim3(div_up(N, 256)), dim3(256), 0, st, N, dd->g_pos, dd->anchor, p, dd->half_shell ? 1 : 0,
                        h->n_roles ? h->d.role_off_o : nullptr, h->d.role_rec_o, dd->cls, dd->owner,
-                       dd->shift_code, dd->send_mask, dd->flags, h->d.flags_dev);
+                       dd->shift_code, dd->send_mask, h->d.flags_dev);
+    hipLaunchKernelGGL(dd_count_kernel, dim3(div_up(n_waves * 64u, 256)), dim3(256), 0, st, N, W, dd->cls, dd->owner, dd->send_mask, n_waves, dd->flags);
     MDX_TRY(mdx_exclusive_scan_u32_ex(h, dd->flags, dd->scan, (uint32_t)nflags, dd->scan_sums));
     uint32_t* d_heads = (uint32_t*)dd->red;     // 64 doubles = 128 words of scratch
-    hipLaunchKernelGGL(dd_seg_heads_kernel, dim3(1), dim3(128), 0, st, nseg, N, dd->scan, d_heads);
+    hipLaunchKernelGGL(dd_seg_heads_kernel, dim3(1), dim3(128), 0, st, nseg, n_waves, dd->scan, d_heads);
     uint32_t heads[2 * DD_MAX_WORLD + 3], err[4];
     HIP_TRY(hipMemcpyAsync(heads, d_heads, sizeof(uint32_t) * (nseg + 1), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(err, h->d.flags_dev, sizeof(err), hipMemcpyDeviceToHost, st));
@@ -354,13 +387,12 @@ static int dd_partition(mdx_handle* h) {
         MDX_TRY(dd_alloc(&dd->recv_ids, dd->cap_recv)); MDX_TRY(dd_alloc(&dd->recv_buf, dd->cap_recv)); MDX_TRY(dd_alloc(&dd->recv_shift, dd->cap_recv));
         MDX_TRY(dd_alloc(&dd->frc_send, dd->cap_recv));
     }
-    if (s0) HIP_TRY(hipMemsetAsync(dd->send_ids, 0xFF, sizeof(uint32_t) * s0, st));
-    if (r0) { HIP_TRY(hipMemsetAsync(dd->recv_ids, 0xFF, sizeof(uint32_t) * r0, st)); HIP_TRY(hipMemsetAsync(dd->recv_shift, 0, sizeof(float4) * r0, st)); }
-    hipLaunchKernelGGL(dd_fill_kernel, dim3(div_up(N, 256), nseg), dim3(256), 0, st, N, W, p, f, dd->flags, dd->scan, dd->g_pos, dd->g_vel,
+    // the engine's own arrays are the partition's output (gid, ghost flags, positions, velocities of the local atoms in list order)
+    dd->gid_local = h->d.gid; dd->ghost_local = h->d.lflag; dd->pos_l = h->d.pos_orig; dd->vel_l = h->d.vel_orig;
+    hipLaunchKernelGGL(dd_fill_kernel, dim3(div_up(n_waves * 64u, 256)), dim3(256), 0, st, N, W, p, f, dd->send_mask, dd->owner, n_waves, dd->scan, dd->g_pos, dd->g_vel,
                        dd->cls, dd->shift_code, dd->send_ids, dd->recv_ids, dd->recv_shift, dd->gid_local, dd->ghost_local, dd->pos_l,
-                       dd->vel_l, dd->owned_gid);
+                       dd->vel_l, dd->owned_gid, dd->pos_at_part);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(dd->pos_at_part, dd->pos_l, sizeof(float4) * dd->n_local, hipMemcpyDeviceToDevice, st));
     // the local region: brick + halo (+ a little room) in cut dimensions, the whole box in the others
     float lo[3], hi[3];
     int per_mask = 0x10;
@@ -708,7 +740,7 @@ void mdx_dd_destroy(mdx_handle* h) {
     if (!dd) return;
     if (dd->comm_stream && dd->comm_stream != h->stream) (void)hipStreamSynchronize(dd->comm_stream);
     void* ptrs[] = {dd->anchor, dd->g_pos, dd->g_vel, dd->g_frc, dd->cls, dd->owner, dd->shift_code, dd->send_mask, dd->flags, dd->scan,
-                    dd->scan_sums, dd->gid_local, dd->ghost_local, dd->pos_l, dd->vel_l, dd->pos_at_part, dd->owned_gid, dd->send_ids,
+                    dd->scan_sums, dd->pos_at_part, dd->owned_gid, dd->send_ids,
                     dd->recv_ids, dd->recv_shift, dd->send_buf, dd->recv_buf, dd->frc_send, dd->frc_recv, dd->gat_send, dd->gat_recv, dd->red, dd->drift_bits};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (dd->ev_packed) (void)hipEventDestroy(dd->ev_packed);
@@ -884,7 +916,6 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
 #define DD_HIP(x) do { if ((x) != hipSuccess) { mdx_set_error(#x " failed"); return bail(MDX_EDEVICE); } } while (0)
     DD_TRY(dd_alloc(&dd->anchor, N)); DD_TRY(dd_alloc(&dd->g_pos, N)); DD_TRY(dd_alloc(&dd->g_vel, N));
     DD_TRY(dd_alloc(&dd->cls, N)); DD_TRY(dd_alloc(&dd->owner, N)); DD_TRY(dd_alloc(&dd->shift_code, N)); DD_TRY(dd_alloc(&dd->send_mask, N));
-    DD_TRY(dd_alloc(&dd->gid_local, N)); DD_TRY(dd_alloc(&dd->ghost_local, N)); DD_TRY(dd_alloc(&dd->pos_l, N)); DD_TRY(dd_alloc(&dd->vel_l, N));
     DD_TRY(dd_alloc(&dd->pos_at_part, N)); DD_TRY(dd_alloc(&dd->owned_gid, N)); DD_TRY(dd_alloc(&dd->red, 64));
     dd->cap_local = N;
     // Every RCCL operation of a handle goes to ONE stream.  By default that is the compute stream itself: pack -> send/recv
