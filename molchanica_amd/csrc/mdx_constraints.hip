@@ -113,7 +113,8 @@ __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_gro
                                                                   float4* __restrict__ ref, float dt, ConsParams p,
                                                                   float* __restrict__ cons_vir,
                                                                   const uint32_t* gate, uint32_t* disp_out, uint32_t thr,
-                                                                  uint32_t* prune_out, float path_thr, const uint32_t* __restrict__ n_dev) {
+                                                                  uint32_t* prune_out, float path_thr, const uint32_t* __restrict__ n_dev,
+                                                                  const GroupSite* __restrict__ gsite) {
     if (gate && *gate > thr) return;
     if (n_dev) n_groups = min(n_groups, *n_dev);      // (clusters in slot order: the ones this handle solves come first)
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -199,6 +200,22 @@ __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_gro
             }
         }
         (void)x0;
+        if (gsite) {
+            // the cluster's virtual site (GroupSite): r_p0 + a (r_p1 - r_p0) + b (r_p2 - r_p0) from the constrained positions in
+            // registers, moved to the periodic image nearest to where the site is stored (see vsite_construct_kernel)
+            const GroupSite gv = gsite[g];
+            if (gv.on && gv.site != MDX_INVALID) {
+                auto pick = [&](int k) { return k == 0 ? xn[0] : (k == 1 ? xn[1] : (k == 2 ? xn[2] : xn[3])); };     // (selects: no indexed registers)
+                const float3 q0 = pick(gv.k0), q1 = pick(gv.k1), q2 = pick(gv.k2);
+                const float3 fresh = make_float3(p0.x + q0.x + gv.a * (q1.x - q0.x) + gv.b * (q2.x - q0.x),
+                                                 p0.y + q0.y + gv.a * (q1.y - q0.y) + gv.b * (q2.y - q0.y),
+                                                 p0.z + q0.z + gv.a * (q1.z - q0.z) + gv.b * (q2.z - q0.z));
+                float4 m = posq[gv.site];
+                const float3 back = mimg3(make_float3(m.x - fresh.x, m.y - fresh.y, m.z - fresh.z), p);
+                m.x -= back.x; m.y -= back.y; m.z -= back.z;
+                posq[gv.site] = m;
+            }
+        }
     }
     if (disp_out) {
         if (!(d2max < 1.0e30f)) d2max = 3.0e38f;
@@ -358,10 +375,16 @@ __global__ void vsite_spread_kernel(uint32_t n, const VSite* __restrict__ vs, fl
 // 3.6 x its algorithmic bytes and ran at 13 % of the HBM roofline.)
 __global__ void remap_groups_kernel(uint32_t n, const ConsGroup* __restrict__ go, const uint32_t* __restrict__ slot_of,
                                     ConsGroup* __restrict__ gs, uint32_t* err, const uint8_t* __restrict__ slot_flags,
-                                    unsigned long long* __restrict__ leaders) {
+                                    unsigned long long* __restrict__ leaders, const GroupSite* __restrict__ so = nullptr,
+                                    GroupSite* __restrict__ ss = nullptr) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     ConsGroup g = go[i];
+    if (so) {      // the cluster's virtual site travels with it
+        GroupSite v = so[i];
+        if (v.on) { v.site = slot_of[v.site]; if (v.site == MDX_INVALID) v.on = 0; }
+        ss[i] = v;
+    }
     if (slot_flags) {
         const uint32_t s0 = slot_of[g.atom[0]];
         if (s0 == MDX_INVALID || !(slot_flags[s0] & 2u)) { g.natoms = 0; g.ncons = 0; gs[i] = g; return; }
@@ -379,13 +402,16 @@ __global__ void group_count_kernel(uint32_t nt, const unsigned long long* __rest
     if (t <= nt) cnt[t] = t < nt ? (uint32_t)__popcll(leaders[t]) : 0u;      // (the trailing element: the scan leaves the total there)
 }
 __global__ void group_place_kernel(uint32_t n, const ConsGroup* __restrict__ tmp, const unsigned long long* __restrict__ leaders,
-                                   const uint32_t* __restrict__ off, ConsGroup* __restrict__ gs) {
+                                   const uint32_t* __restrict__ off, ConsGroup* __restrict__ gs,
+                                   const GroupSite* __restrict__ stmp = nullptr, GroupSite* __restrict__ ss = nullptr) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const ConsGroup g = tmp[i];
     if (!g.natoms || g.atom[0] == MDX_INVALID) return;      // not solved here: beyond the count the solvers read
     const uint32_t s0 = g.atom[0], t = s0 >> 6;
-    gs[off[t] + (uint32_t)__popcll(leaders[t] & ((1ull << (s0 & 63u)) - 1ull))] = g;
+    const uint32_t at = off[t] + (uint32_t)__popcll(leaders[t] & ((1ull << (s0 & 63u)) - 1ull));
+    gs[at] = g;
+    if (stmp) ss[at] = stmp[i];
 }
 
 __global__ void remap_vsites_kernel(uint32_t n, const VSite* __restrict__ vo, const uint32_t* __restrict__ slot_of,
@@ -496,6 +522,33 @@ int mdx_build_constraints(mdx_handle* h, const mdx_system* s) {
         HIP_TRY(hipMemcpyAsync(h->d.vsite_o, vs.data(), sizeof(VSite) * vs.size(), hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
+    // Sites whose three parents are the members of ONE constraint cluster (rigid four-site water) are placed by that cluster's
+    // position stage (GroupSite).  All of them or none: MDX_VSITE_IN_GROUPS=0 keeps the construct launch (A/B).
+    h->vsites_in_groups = false; h->vsites_fresh = false;
+    for (void** q : {(void**)&h->d.gsite_o, (void**)&h->d.gsite_s, (void**)&h->d.gsite_tmp}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+    const char* const ve = std::getenv("MDX_VSITE_IN_GROUPS");
+    if (h->n_vsites && h->n_groups && !(ve && ve[0] == '0')) {
+        std::vector<int> grp(N, -1), loc(N, -1);
+        for (size_t gi = 0; gi < h->h_groups.size(); ++gi)
+            for (uint32_t k = 0; k < h->h_groups[gi].natoms; ++k) { grp[h->h_groups[gi].atom[k]] = (int)gi; loc[h->h_groups[gi].atom[k]] = (int)k; }
+        std::vector<GroupSite> gsv(h->h_groups.size());
+        for (auto& x : gsv) { x.site = MDX_INVALID; x.k0 = x.k1 = x.k2 = x.on = 0; x.a = x.b = 0.f; }
+        size_t attached = 0;
+        for (const VSite& v : h->h_vsites) {
+            const int gi = grp[v.p0];
+            if (gi < 0 || grp[v.p1] != gi || grp[v.p2] != gi || gsv[gi].on) continue;
+            gsv[gi].site = v.site; gsv[gi].k0 = (uint8_t)loc[v.p0]; gsv[gi].k1 = (uint8_t)loc[v.p1]; gsv[gi].k2 = (uint8_t)loc[v.p2];
+            gsv[gi].on = 1; gsv[gi].a = v.a; gsv[gi].b = v.b;
+            ++attached;
+        }
+        if (attached == h->h_vsites.size()) {
+            HIP_TRY(hipMalloc((void**)&h->d.gsite_o, sizeof(GroupSite) * gsv.size()));
+            HIP_TRY(hipMalloc((void**)&h->d.gsite_s, sizeof(GroupSite) * gsv.size()));
+            HIP_TRY(hipMemcpyAsync(h->d.gsite_o, gsv.data(), sizeof(GroupSite) * gsv.size(), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            h->vsites_in_groups = true;
+        }
+    }
     return MDX_OK;
 }
 
@@ -503,7 +556,7 @@ int mdx_remap_constraints(mdx_handle* h) {
     static const bool sort_env = [] { const char* e = std::getenv("MDX_CONS_SORT"); return !(e && e[0] == '0'); }();   // A/B knob
     DeviceState& d = h->d;
     const uint8_t* const sf = (h->dd || h->n_local != h->N) ? d.slot_flags : nullptr;
-    if (h->n_groups && sort_env && h->n_groups >= 4096u && h->cap_tiles) {
+    if (h->n_groups && sort_env && h->n_groups >= 32768u && h->cap_tiles) {      // (below: the solvers are latency-bound, and the four extra launches per rebuild cost more than they save)
         // clusters in slot order (every tile word of leaders is at most 64 clusters; a slot leads at most one cluster)
         const uint32_t nt = h->cap_tiles;
         if (d.cons_cap_tiles < nt || !d.cons_tmp) {
@@ -516,16 +569,17 @@ int mdx_remap_constraints(mdx_handle* h) {
             d.cons_cap_tiles = nt;
         }
         HIP_TRY(hipMemsetAsync(d.cons_mask, 0, sizeof(unsigned long long) * nt, h->stream));
+        if (d.gsite_o && !d.gsite_tmp) HIP_TRY(hipMalloc((void**)&d.gsite_tmp, sizeof(GroupSite) * h->n_groups));
         hipLaunchKernelGGL(remap_groups_kernel, dim3(div_up(h->n_groups, 256)), dim3(256), 0, h->stream, h->n_groups,
-                           d.cons_o, d.slot_of, d.cons_tmp, d.flags_dev, sf, d.cons_mask);
+                           d.cons_o, d.slot_of, d.cons_tmp, d.flags_dev, sf, d.cons_mask, (const GroupSite*)d.gsite_o, d.gsite_tmp);
         hipLaunchKernelGGL(group_count_kernel, dim3(div_up(nt + 1, 256)), dim3(256), 0, h->stream, nt, d.cons_mask, d.cons_cnt);
         MDX_TRY(mdx_exclusive_scan_u32_ex(h, d.cons_cnt, d.cons_off, nt + 1, d.cons_off + nt + 1));
         hipLaunchKernelGGL(group_place_kernel, dim3(div_up(h->n_groups, 256)), dim3(256), 0, h->stream, h->n_groups,
-                           d.cons_tmp, d.cons_mask, d.cons_off, d.cons_s);
+                           d.cons_tmp, d.cons_mask, d.cons_off, d.cons_s, (const GroupSite*)(d.gsite_o ? d.gsite_tmp : nullptr), d.gsite_s);
         d.cons_n_dev = d.cons_off + nt;
     } else if (h->n_groups) {
         hipLaunchKernelGGL(remap_groups_kernel, dim3(div_up(h->n_groups, 256)), dim3(256), 0, h->stream, h->n_groups,
-                           d.cons_o, d.slot_of, d.cons_s, d.flags_dev, sf, (unsigned long long*)nullptr);
+                           d.cons_o, d.slot_of, d.cons_s, d.flags_dev, sf, (unsigned long long*)nullptr, (const GroupSite*)d.gsite_o, d.gsite_s);
         d.cons_n_dev = nullptr;
     }
     if (h->n_vsites)
@@ -544,7 +598,9 @@ int mdx_launch_constrain_positions(mdx_handle* h, float dt, const uint32_t* d_ga
     hipLaunchKernelGGL(constrain_positions_kernel, dim3(div_up(h->n_groups, 128)), dim3(128), 0, h->stream, h->n_groups,
                        h->d.cons_s, h->d.posq, h->d.vel, h->d.ref, dt, cp,
                        dt != 0.f ? h->d.cons_vir : nullptr,   // a dt = 0 projection (new coordinates, rescaled box) keeps the last step's virial
-                       d_gate, d_disp_out, thr, d_prune_out, 0.5f * h->inner_skin * (1.0f - 1.0e-4f), h->d.cons_n_dev);
+                       d_gate, d_disp_out, thr, d_prune_out, 0.5f * h->inner_skin * (1.0f - 1.0e-4f), h->d.cons_n_dev,
+                       (const GroupSite*)(h->vsites_in_groups ? h->d.gsite_s : nullptr));
+    if (h->vsites_in_groups) h->vsites_fresh = true;
     HIP_TRY(hipGetLastError());
     return MDX_OK;
 }
@@ -577,6 +633,8 @@ int mdx_launch_constrain_velocities(mdx_handle* h, const uint32_t* d_gate, uint3
 
 int mdx_launch_vsite_construct(mdx_handle* h, const uint32_t* d_gate, uint32_t thr) {
     if (!h->n_vsites) return MDX_OK;
+    // every site was placed by the position stage of its cluster's constraint solver, and nothing has moved a parent since
+    if (h->vsites_fresh) { h->vsites_fresh = false; return MDX_OK; }
     hipLaunchKernelGGL(vsite_construct_kernel, dim3(div_up(h->n_vsites, 256)), dim3(256), 0, h->stream, h->n_vsites,
                        h->d.vsite_s, h->d.posq, cons_params(h), d_gate, thr);
     HIP_TRY(hipGetLastError());

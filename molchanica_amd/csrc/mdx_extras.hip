@@ -208,6 +208,7 @@ static int apply_barostat(mdx_handle* h, double dt_couple) {
         return MDX_OK;
     }
     MDX_TRY(mdx_unsort_state(h));
+    h->vsites_fresh = false;
     hipLaunchKernelGGL(scale_positions_kernel, dim3(div_up(h->n_local, 256)), dim3(256), 0, h->stream, h->n_local,
                        h->d.pos_orig, h->box_lo[0], h->box_lo[1], h->box_lo[2], (float)mu);
     HIP_TRY(hipGetLastError());
@@ -262,6 +263,7 @@ extern "C" int mdx_shrink_cell_towards(mdx_handle* h, const float target_lo[3], 
     }
     MDX_TRY(mdx_check_box(h, lo, hi));   // refuse BEFORE touching the state (an edge below 2 (rc + skin))
     MDX_TRY(mdx_unsort_state(h));
+    h->vsites_fresh = false;
     hipLaunchKernelGGL(scale_positions_about_kernel, dim3(div_up(h->n_local, 256)), dim3(256), 0, h->stream, h->n_local,
                        h->d.pos_orig, c[0], c[1], c[2], mu[0], mu[1], mu[2]);
     HIP_TRY(hipGetLastError());
@@ -692,6 +694,7 @@ extern "C" int mdx_minimize_energy(mdx_handle* h, uint32_t max_iters, const floa
     while (it < max_iters && cur.max_force >= (double)f_tol && cur.max_force > 0.0) {
         const float scale = (float)(hstep / cur.max_force);
         if (hipMemsetAsync(&h->d.ctl->disp2[1], 0, sizeof(uint32_t), st) != hipSuccess) return done(MDX_EDEVICE);
+        h->vsites_fresh = false;
         hipLaunchKernelGGL(min_move_kernel, dim3(div_up(h->S, 256)), dim3(256), 0, st, h->S, h->d.posq, h->d.force,
                            h->d.vel, h->d.ref, scale, &h->d.ctl->disp2[1], thr);
         uint32_t flag = 0;

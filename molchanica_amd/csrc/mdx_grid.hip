@@ -1968,6 +1968,7 @@ static int rebuild_fast(mdx_handle* h, RebuildResult* res, bool* fell_back) {
 
 int mdx_rebuild(mdx_handle* h) {
     MdxRange range_rebuild("mdx list rebuild");
+    h->vsites_fresh = false;      // (the next force call constructs the virtual sites itself: one launch per rebuild)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profile) {
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));

@@ -225,6 +225,7 @@ int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_ga
                          uint32_t thr_bits, uint32_t* d_prune_out) {
     const dim3 g((h->S + 255) / 256), b(256);
     DeviceState& d = h->d;
+    if (mode != 2) h->vsites_fresh = false;      // a drift: the virtual sites follow at the next position stage / construct launch
     mdx_prof_begin(h, 2);
     LangevinArgs lg{};
     if (mode == 3) {

@@ -130,6 +130,13 @@ struct __attribute__((aligned(16))) ConsGroup {
     uint8_t  ca[6], cb[6]; // constraint k ties local atoms ca[k], cb[k]
     uint32_t ncons, natoms;
 };
+// The virtual site of a constraint cluster whose three parents are all members of the cluster (the M site of a rigid four-site
+// water): the position stage of the constraint solver places it (mdx_constraints.hip) - no launch of its own.
+struct __attribute__((aligned(16))) GroupSite {
+    uint32_t site;         // caller index (*_o) or slot (*_s); MDX_INVALID: none
+    uint8_t k0, k1, k2, on; // local indices of the site's parents p0, p1, p2 in ConsGroup::atom
+    float a, b;
+};
 struct __attribute__((aligned(16))) VSite {  // r_site = r0 + a (r1 - r0) + b (r2 - r0)
     uint32_t site, p0, p1, p2;
     float a, b, pad0, pad1;
@@ -205,6 +212,7 @@ struct DeviceState {
     uint32_t cons_cap_tiles = 0; const uint32_t* cons_n_dev = nullptr;     // cons_n_dev: clusters this handle solves (device word), null = n_groups
     float* cons_vir = nullptr;     // per constraint cluster: r . G of the last SHAKE position stage (kcal/mol)
     VSite* vsite_o = nullptr; VSite* vsite_s = nullptr;
+    GroupSite* gsite_o = nullptr; GroupSite* gsite_s = nullptr; GroupSite* gsite_tmp = nullptr;   // per constraint cluster (null: no cluster carries its site)
     // control / reductions
     StepCtl* ctl = nullptr;
     double*  energy = nullptr;     // [EN_COUNT + 8 + MDX_ESTRIDE*MDX_EPART]: energies, max|F|^2 bits, momentum (px,py,pz,mass),
@@ -248,6 +256,8 @@ struct mdx_handle {
     uint32_t n_bonds = 0, n_angles = 0, n_dih = 0, n_p14 = 0;
     uint32_t n_roles = 0;
     uint32_t n_groups = 0, n_cons = 0, n_vsites = 0;   // constraint clusters / constraints / virtual sites
+    bool vsites_in_groups = false;   // every virtual site is placed by its parents' constraint cluster (GroupSite)
+    bool vsites_fresh = false;       // ... and the last position stage did so: the next force call has nothing to construct
     std::vector<ConsGroup> h_groups; std::vector<VSite> h_vsites;   // host copies (caller order): ownership anchors of a decomposition
     int hc_kind = 1; uint32_t hc_order = 0, hc_iter = 0; std::string hc_text;   // mdx_set_hydrogen_constraint: what the host asked for
     bool cons_dirty = false;                           // positions were set from outside: project them once
