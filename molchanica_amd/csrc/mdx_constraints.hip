@@ -204,7 +204,7 @@ __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_gro
             // the cluster's virtual site (GroupSite): r_p0 + a (r_p1 - r_p0) + b (r_p2 - r_p0) from the constrained positions in
             // registers, moved to the periodic image nearest to where the site is stored (see vsite_construct_kernel)
             const GroupSite gv = gsite[g];
-            if (gv.on && gv.site != MDX_INVALID) {
+            if (gv.on && gv.site != MDX_INVALID && cg.natoms >= 3) {
                 auto pick = [&](int k) { return k == 0 ? xn[0] : (k == 1 ? xn[1] : (k == 2 ? xn[2] : xn[3])); };     // (selects: no indexed registers)
                 const float3 q0 = pick(gv.k0), q1 = pick(gv.k1), q2 = pick(gv.k2);
                 const float3 fresh = make_float3(p0.x + q0.x + gv.a * (q1.x - q0.x) + gv.b * (q2.x - q0.x),
@@ -387,7 +387,7 @@ __global__ void remap_groups_kernel(uint32_t n, const ConsGroup* __restrict__ go
     }
     if (slot_flags) {
         const uint32_t s0 = slot_of[g.atom[0]];
-        if (s0 == MDX_INVALID || !(slot_flags[s0] & 2u)) { g.natoms = 0; g.ncons = 0; gs[i] = g; return; }
+        if (s0 == MDX_INVALID || !(slot_flags[s0] & 2u)) { g.natoms = 0; g.ncons = 0; gs[i] = g; if (so) ss[i].on = 0; return; }     // (not solved here: nor is its site placed here)
     }
     for (uint32_t k = 0; k < g.natoms; ++k) {
         const uint32_t s = slot_of[g.atom[k]];
