@@ -26,3 +26,5 @@ def run(name, s, cfg, dt, n_eq, n_nve, thermo_in_eq=True):
 run("rigid OPC 23,328 sites, SPME, dt 2 fs (the reference's default operating point)", systems.opc_water_box(18, seed=5), MdConfig(coulomb_mode=2, ewald_alpha=0.3, overrides=0), 0.002, 25000, 50000)
 run("dhfr23k flexible chain + water, SPME, dt 0.5 fs", systems.BY_NAME["dhfr23k"](), MdConfig(coulomb_mode=2, ewald_alpha=0.3, overrides=0), 0.0005, 10000, 40000)
 run("water1M flexible TIP3P, reaction field, dt 0.5 fs", systems.BY_NAME["water1M"](), MdConfig(coulomb_mode=1), 0.0005, 2000, 20000)
+# round 4: the paths only the large default-point box takes (brick charge spread, clusters by interaction kind, cluster table in slot order)
+run("rigid OPC 1,048,576 sites, SPME, dt 2 fs", systems.opc_water_box(64, seed=5), MdConfig(coulomb_mode=2, ewald_alpha=0.3, overrides=0), 0.002, 1500, 5000)
