@@ -420,7 +420,8 @@ __global__ __launch_bounds__(256) void assign_tiles_kernel(
     uint32_t T, int nzb, const uint32_t* __restrict__ tile_col, const uint32_t* __restrict__ tile_start,
     const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ sorted_orig,
     const float4* __restrict__ pos_orig, const uint32_t* __restrict__ gid, uint32_t* __restrict__ orig_of,
-    uint32_t* __restrict__ slot_of) {
+    uint32_t* __restrict__ slot_of, int kind_split, const uint8_t* __restrict__ lflag, const float* __restrict__ o_qs,
+    const float2* __restrict__ o_lj) {
     const int lane = threadIdx.x & 63;
     const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (t > T) return;
@@ -436,10 +437,19 @@ __global__ __launch_bounds__(256) void assign_tiles_kernel(
     uint32_t o = valid ? sorted_orig[p] : MDX_INVALID;
     float x = FLT_MAX, y = FLT_MAX, z = FLT_MAX;
     if (valid) { float4 q = pos_orig[o]; x = q.x; y = q.y; z = q.z; }
+    if (kind_split) {      // the same order rb_assign_kernel gives: slot assignment is a function of the positions, not of the chain that ran
+        int group = 2;
+        if (valid) {
+            const uint32_t g = gid[o];
+            group = (!(lflag[o] & 2u) && o_lj[g].y != 0.f && o_qs[g] == 0.f) ? 0 : 1;
+        }
+        kind_tile_order(x, y, z, o, group, lane);
+    } else {
     // halves by y, quarters by x, eighths (clusters) by z
     bitonic_group<64>(y, x, z, o, lane);
     bitonic_group<32>(x, y, z, o, lane);
     bitonic_group<16>(z, x, y, o, lane);
+    }
     const uint32_t slot = t * MDX_TILE + lane;
     orig_of[slot] = o;
     if (o != MDX_INVALID) slot_of[gid[o]] = slot;
@@ -2028,7 +2038,8 @@ int mdx_rebuild(mdx_handle* h) {
     hipLaunchKernelGGL(tile_col_kernel, dim3(div_up(h->ncol, 256)), dim3(256), 0, st, d.tile_start, h->ncol,
                        d.tile_col);
     hipLaunchKernelGGL(assign_tiles_kernel, dim3(div_up(T + 1, 4)), dim3(256), 0, st, T, g.nzb, d.tile_col,
-                       d.tile_start, d.cell_start, d.sorted_orig, d.pos_orig, d.gid, d.orig_of, d.slot_of);
+                       d.tile_start, d.cell_start, d.sorted_orig, d.pos_orig, d.gid, d.orig_of, d.slot_of, h->kind_split ? 1 : 0,
+                       d.lflag, d.o_qs, d.o_lj);
     hipLaunchKernelGGL(gather_slots_kernel, dim3(div_up(S, 256)), dim3(256), 0, st, S, d.orig_of, d.gid, d.lflag,
                        d.pos_orig, d.vel_orig, d.o_qs, d.o_lj, d.o_invm, d.posq, d.lj, d.vel, d.ref, d.force,
                        d.slot_flags);

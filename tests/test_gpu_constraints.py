@@ -139,7 +139,7 @@ def test_clusters_by_interaction_kind_change_the_list_not_the_forces(mdx, mode, 
         if arm is None: monkeypatch.delenv("MDX_KIND_CLUSTERS")          # the library's own choice for a system this small: off
         else: monkeypatch.setenv("MDX_KIND_CLUSTERS", arm)
         with mdx.MdState(s, cfg) as md:
-            md.step(0.002, None, 40)                    # (the first list of a handle is built by the unfused chain, which keeps the plain order)
+            md.step(0.002, None, 40)                    # (lists of the unfused first build and of the fused rebuilds alike)
             st = md.stats()
             out[arm] = (md.forces().astype(np.float64), md.energy(), st["n_cluster_pairs"], md.positions().astype(np.float64), st["rebuild_count"])
     (f0, e0, n0, p0, r0), (f1, e1, n1, p1, r1) = out["0"], out["1"]
