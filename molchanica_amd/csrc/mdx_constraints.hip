@@ -556,7 +556,11 @@ int mdx_remap_constraints(mdx_handle* h) {
     static const bool sort_env = [] { const char* e = std::getenv("MDX_CONS_SORT"); return !(e && e[0] == '0'); }();   // A/B knob
     DeviceState& d = h->d;
     const uint8_t* const sf = (h->dd || h->n_local != h->N) ? d.slot_flags : nullptr;
-    if (h->n_groups && sort_env && h->n_groups >= 32768u && h->cap_tiles) {      // (below: the solvers are latency-bound, and the four extra launches per rebuild cost more than they save)
+    // (below 32 k clusters the solvers are latency-bound and the four extra launches per rebuild cost more than they save;
+    // MDX_CONS_SORT_MIN: another threshold - the tests use 1 to take small systems through this path)
+    const char* const me = std::getenv("MDX_CONS_SORT_MIN");
+    const uint32_t sort_min = me ? (uint32_t)std::max(1, std::atoi(me)) : 32768u;
+    if (h->n_groups && sort_env && h->n_groups >= sort_min && h->cap_tiles) {
         // clusters in slot order (every tile word of leaders is at most 64 clusters; a slot leads at most one cluster)
         const uint32_t nt = h->cap_tiles;
         if (d.cons_cap_tiles < nt || !d.cons_tmp) {

@@ -273,14 +273,17 @@ def test_rigid_waters_straddling_the_periodic_seam_between_ranks(model, world):
     assert abs(t(r0["e1"]) - t(e1_ref)) < 1e-4 * s.n_atoms
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_default_operating_point_on_decomposed_handles(world):
+@pytest.mark.parametrize("world", [2, 4, 8, -4])
+def test_default_operating_point_on_decomposed_handles(world, monkeypatch):
     """The reference's default operating point - dt = 2 fs (src/prefs/mod.rs:203), constrained hydrogens
     (src/ui/panels/md.rs:362-371), rigid 4-site OPC water with its massless M site
     (src/properties/sol_shrinking_box.rs:605-613), CSVR thermostat (README.md:237-238) - on 2 / 4 / 8 ranks against one
     GPU: every water is owned as a whole by one rank, SHAKE / RATTLE and the M-site construction / force spreading never
     cross a rank boundary, ONE all-reduced kinetic energy drives the (identically seeded) thermostat."""
     from molchanica_amd.md_state import MdState
+    if world < 0:      # four ranks with the cluster table laid out in slot order (the library's own choice from 32 k clusters on):
+        world = -world  # a rank's table then holds the clusters it solves, in front, and a device-resident count of them
+        monkeypatch.setenv("MDX_CONS_SORT_MIN", "1")
     s = systems.opc_water_box(16, seed=3)        # 4,096 waters = 16,384 sites, 49.7 A box
     cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, coulomb_mode=1, chunk_steps=8)
 

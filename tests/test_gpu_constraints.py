@@ -28,8 +28,10 @@ def bond_errors(s, x):
     return np.abs(np.linalg.norm(d, axis=1) - s.constraint_len) / s.constraint_len
 
 
-@pytest.mark.parametrize("model", ["tip3p_rigid", "opc"])
-def test_rigid_water_parity_at_2fs(mdx, orc, model):
+@pytest.mark.parametrize("model", ["tip3p_rigid", "opc", "opc_clusters_in_slot_order"])
+def test_rigid_water_parity_at_2fs(mdx, orc, model, monkeypatch):
+    if model == "opc_clusters_in_slot_order":      # the cluster table laid out in slot order (the library's own choice from 32 k clusters on)
+        monkeypatch.setenv("MDX_CONS_SORT_MIN", "1")
     s = systems.water_box(8, seed=3, rigid=True) if model == "tip3p_rigid" else systems.opc_water_box(8, seed=3)
     cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, coulomb_mode=1)
     with mdx.MdState(s, cfg) as md:
