@@ -277,8 +277,12 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
         };
         count_term(s->bond_idx, s->n_bonds, 2); count_term(s->angle_idx, s->n_angles, 3);
         count_term(s->dihedral_idx, s->n_dihedrals, 4); count_term(s->pairs14_idx, s->n_pairs14, 2);
-        if (pme_on)   // the reciprocal sum sees every pair: excluded and 1-4 partners get erf(beta r)/r removed
-            for (uint32_t i = 0; i < N; ++i) cnt[i + 1] += (uint32_t)ex[i].size();
+        // the reciprocal sum sees every pair: excluded and 1-4 partners get erf(beta r)/r removed - those that carry charge on both
+        // sides (the oxygen of a four-site water has none: three of its molecule's six excluded pairs are no terms at all)
+        auto recip_excluded = [&](uint32_t i, uint32_t j) { return q[i] != 0.f && q[j] != 0.f; };
+        if (pme_on)
+            for (uint32_t i = 0; i < N; ++i)
+                for (uint32_t j : ex[i]) cnt[i + 1] += recip_excluded(i, j) ? 1u : 0u;
         for (uint32_t i = 0; i < N; ++i) cnt[i + 1] += cnt[i];
         const uint32_t R = cnt[N];
         std::vector<RoleRec> recs(R);
@@ -330,7 +334,7 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
         if (pme_on)
             for (uint32_t i = 0; i < N; ++i)
                 for (uint32_t j : ex[i])
-                    if (i < j) {
+                    if (i < j && recip_excluded(i, j)) {
                         const uint32_t at[2] = {i, j};
                         add_term(at, 2, ROLE_EWALD_EXCL, c->coulomb_k * q[i] * q[j], 0.f, 0.f);
                     }
