@@ -108,6 +108,10 @@ __device__ __forceinline__ bool settle_positions(const float3 xo[4], float3 xn[4
 }
 
 // ---- SHAKE: positions ---------------------------------------------------------------------------
+// RIGID3: every cluster of the handle is a rigid three-site water (host-checked): constraint pairs are (0,1), (0,2), (1,2) by
+// construction, so nothing indexes the local position arrays with a run-time value and they live in registers - the general
+// flavour keeps them in scratch memory (112 B per lane) because its SHAKE sweep addresses them through cg.ca / cg.cb.
+template <bool RIGID3>
 __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_groups, const ConsGroup* __restrict__ groups,
                                                                   float4* __restrict__ posq, float4* __restrict__ vel,
                                                                   float4* __restrict__ ref, float dt, ConsParams p,
@@ -145,8 +149,8 @@ __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_gro
         // the OLD bond vector r; its contribution to sum r_i . F_i is G . (r_a - r_b) = 2 gk |r|^2 / dt^2.
         float wc = 0.f;
         bool settled = false;
+        const Triangle tri = rigid_triangle(cg, im);
         if (p.settle && dt != 0.f) {      // (dt = 0 is the projection of caller-supplied geometry: its "old" positions are not on the constraints)
-            const Triangle tri = rigid_triangle(cg, im);
             if (tri.ok && settle_positions(xo, xn, im, tri)) {
                 settled = true;
                 // the virial sum of the equivalent pair corrections: sum_k g_k |r_k|^2 = sum_i (dx_i / im_i) . x_old_i
@@ -155,14 +159,15 @@ __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_gro
                     wc += ((xn[k].x - xs[k].x) * xo[k].x + (xn[k].y - xs[k].y) * xo[k].y + (xn[k].z - xs[k].z) * xo[k].z) / im[k];
             }
         }
-        for (int it = 0; it < (settled ? 0 : p.max_iter); ++it) {
+        for (int it = 0; it < ((settled || (RIGID3 && cg.natoms != 3)) ? 0 : p.max_iter); ++it) {
             bool done = true;
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                if (c >= (int)cg.ncons) break;
-                const int a = cg.ca[c], b = cg.cb[c];
+            for (int c = 0; c < (RIGID3 ? 3 : 6); ++c) {
+                if (!RIGID3 && c >= (int)cg.ncons) break;
+                const int a = RIGID3 ? (c == 2 ? 1 : 0) : cg.ca[c], b = RIGID3 ? (c == 0 ? 1 : 2) : cg.cb[c];
                 const float3 s = make_float3(xn[a].x - xn[b].x, xn[a].y - xn[b].y, xn[a].z - xn[b].z);
-                const float l2 = cg.len[c] * cg.len[c];
+                const float lc = RIGID3 ? (c == 2 ? tri.l12 : tri.l01) : cg.len[c];
+                const float l2 = lc * lc;
                 const float diff = l2 - (s.x * s.x + s.y * s.y + s.z * s.z);
                 if (fabsf(diff) > 2.0f * p.tol * l2) {
                     done = false;
@@ -205,11 +210,14 @@ __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_gro
             // registers, moved to the periodic image nearest to where the site is stored (see vsite_construct_kernel)
             const GroupSite gv = gsite[g];
             if (gv.on && gv.site != MDX_INVALID && cg.natoms >= 3) {
-                auto pick = [&](int k) { return k == 0 ? xn[0] : (k == 1 ? xn[1] : (k == 2 ? xn[2] : xn[3])); };     // (selects: no indexed registers)
-                const float3 q0 = pick(gv.k0), q1 = pick(gv.k1), q2 = pick(gv.k2);
-                const float3 fresh = make_float3(p0.x + q0.x + gv.a * (q1.x - q0.x) + gv.b * (q2.x - q0.x),
-                                                 p0.y + q0.y + gv.a * (q1.y - q0.y) + gv.b * (q2.y - q0.y),
-                                                 p0.z + q0.z + gv.a * (q1.z - q0.z) + gv.b * (q2.z - q0.z));
+                // weights of the cluster's atoms in the site (per atom, by comparison: an indexed read of xn would put the array
+                // into scratch memory)
+                float3 fresh = make_float3(p0.x, p0.y, p0.z);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float wk = (k == (int)gv.k0 ? 1.0f - gv.a - gv.b : 0.f) + (k == (int)gv.k1 ? gv.a : 0.f) + (k == (int)gv.k2 ? gv.b : 0.f);
+                    fresh.x += wk * xn[k].x; fresh.y += wk * xn[k].y; fresh.z += wk * xn[k].z;
+                }
                 float4 m = posq[gv.site];
                 const float3 back = mimg3(make_float3(m.x - fresh.x, m.y - fresh.y, m.z - fresh.z), p);
                 m.x -= back.x; m.y -= back.y; m.z -= back.z;
@@ -231,6 +239,7 @@ __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_gro
 }
 
 // ---- RATTLE: velocities -----------------------------------------------------------------------------
+template <bool RIGID3>      // (see constrain_positions_kernel)
 __global__ __launch_bounds__(128) void constrain_velocities_kernel(uint32_t n_groups, const ConsGroup* __restrict__ groups,
                                                                    const float4* __restrict__ posq, float4* __restrict__ vel,
                                                                    ConsParams p, const uint32_t* gate, uint32_t thr,
@@ -261,7 +270,7 @@ __global__ __launch_bounds__(128) void constrain_velocities_kernel(uint32_t n_gr
         float3 r[3]; float rhs[3]; int ia[3], ib[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            ia[c] = cg.ca[c]; ib[c] = cg.cb[c];
+            ia[c] = RIGID3 ? (c == 2 ? 1 : 0) : cg.ca[c]; ib[c] = RIGID3 ? (c == 0 ? 1 : 2) : cg.cb[c];
             r[c] = make_float3(x[ia[c]].x - x[ib[c]].x, x[ia[c]].y - x[ib[c]].y, x[ia[c]].z - x[ib[c]].z);
             rhs[c] = dot3f(r[c], make_float3(v[ia[c]].x - v[ib[c]].x, v[ia[c]].y - v[ib[c]].y, v[ia[c]].z - v[ib[c]].z));
         }
@@ -294,16 +303,16 @@ __global__ __launch_bounds__(128) void constrain_velocities_kernel(uint32_t n_gr
             solved = true;
         }
     }
-    for (int it = 0; it < (solved ? 0 : p.max_iter); ++it) {
+    for (int it = 0; it < ((solved || (RIGID3 && cg.natoms != 3)) ? 0 : p.max_iter); ++it) {
         bool done = true;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            if (c >= (int)cg.ncons) break;
-            const int a = cg.ca[c], b = cg.cb[c];
+        for (int c = 0; c < (RIGID3 ? 3 : 6); ++c) {
+            if (!RIGID3 && c >= (int)cg.ncons) break;
+            const int a = RIGID3 ? (c == 2 ? 1 : 0) : cg.ca[c], b = RIGID3 ? (c == 0 ? 1 : 2) : cg.cb[c];
             const float3 s = make_float3(x[a].x - x[b].x, x[a].y - x[b].y, x[a].z - x[b].z);
             const float3 w = make_float3(v[a].x - v[b].x, v[a].y - v[b].y, v[a].z - v[b].z);
             const float dot = s.x * w.x + s.y * w.y + s.z * w.z;
-            const float l2 = cg.len[c] * cg.len[c];
+            const float l2 = RIGID3 ? s.x * s.x + s.y * s.y + s.z * s.z : cg.len[c] * cg.len[c];      // (positions are on the constraints: |s| = the length)
             // |d/dt of the bond length| relative to 1 Å/ps-scale speeds
             if (fabsf(dot) > p.tol * l2 * 10.0f) {
                 done = false;
@@ -485,6 +494,25 @@ int mdx_build_constraints(mdx_handle* h, const mdx_system* s) {
         }
         h->n_groups = (uint32_t)groups.size();
         h->h_groups = groups;
+        // every cluster a rigid three-site water in canonical order (legs from atom 0, equal masses on atoms 1 and 2, constraints
+        // exactly (0,1), (0,2), (1,2)): the solvers then run their RIGID3 flavour
+        h->cons_all_rigid3 = !groups.empty();
+        for (const ConsGroup& g : groups) {
+            bool ok = g.natoms == 3 && g.ncons == 3;
+            float l01 = 0.f, l02 = 0.f, l12 = 0.f;
+            for (uint32_t c = 0; ok && c < 3; ++c) {
+                const int a = std::min((int)g.ca[c], (int)g.cb[c]), b = std::max((int)g.ca[c], (int)g.cb[c]);
+                if (a == 0 && b == 1) l01 = g.len[c]; else if (a == 0 && b == 2) l02 = g.len[c]; else if (a == 1 && b == 2) l12 = g.len[c]; else ok = false;
+            }
+            ok = ok && l01 > 0.f && l02 > 0.f && l12 > 0.f && std::fabs(l01 - l02) <= 1e-6f * l01 && l12 < 2.0f * l01;
+            if (ok) {
+                const uint32_t a0 = g.atom[0], a1 = g.atom[1], a2 = g.atom[2];
+                const bool mob = !(h->flags[a0] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST)) && !(h->flags[a1] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST)) &&
+                                 !(h->flags[a2] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST));
+                ok = mob && s->mass[a1] == s->mass[a2] && s->mass[a0] > 0.f && s->mass[a1] > 0.f;
+            }
+            if (!ok) { h->cons_all_rigid3 = false; break; }
+        }
         if (h->d.cons_o) (void)hipFree(h->d.cons_o);
         if (h->d.cons_s) (void)hipFree(h->d.cons_s);
         HIP_TRY(hipMalloc((void**)&h->d.cons_o, sizeof(ConsGroup) * groups.size()));
@@ -599,7 +627,10 @@ int mdx_launch_constrain_positions(mdx_handle* h, float dt, const uint32_t* d_ga
     if (!h->dual_on) d_prune_out = nullptr;
     ConsParams cp = cons_params(h);
     cp.vir_scale = h->cons_full_kick ? 1.0f : 2.0f;
-    hipLaunchKernelGGL(constrain_positions_kernel, dim3(div_up(h->n_groups, 128)), dim3(128), 0, h->stream, h->n_groups,
+    // (MDX_CONS_RIGID3=0: the general flavour for every handle, A/B)
+    static const bool rigid3_env = [] { const char* e = std::getenv("MDX_CONS_RIGID3"); return !(e && e[0] == '0'); }();
+    auto kern = (h->cons_all_rigid3 && rigid3_env) ? constrain_positions_kernel<true> : constrain_positions_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3(div_up(h->n_groups, 128)), dim3(128), 0, h->stream, h->n_groups,
                        h->d.cons_s, h->d.posq, h->d.vel, h->d.ref, dt, cp,
                        dt != 0.f ? h->d.cons_vir : nullptr,   // a dt = 0 projection (new coordinates, rescaled box) keeps the last step's virial
                        d_gate, d_disp_out, thr, d_prune_out, 0.5f * h->inner_skin * (1.0f - 1.0e-4f), h->d.cons_n_dev,
@@ -629,7 +660,9 @@ int mdx_launch_constraint_virial(mdx_handle* h) {
 
 int mdx_launch_constrain_velocities(mdx_handle* h, const uint32_t* d_gate, uint32_t thr) {
     if (!h->n_groups) return MDX_OK;
-    hipLaunchKernelGGL(constrain_velocities_kernel, dim3(div_up(h->n_groups, 128)), dim3(128), 0, h->stream, h->n_groups,
+    static const bool rigid3_env = [] { const char* e = std::getenv("MDX_CONS_RIGID3"); return !(e && e[0] == '0'); }();
+    auto kern = (h->cons_all_rigid3 && rigid3_env) ? constrain_velocities_kernel<true> : constrain_velocities_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3(div_up(h->n_groups, 128)), dim3(128), 0, h->stream, h->n_groups,
                        h->d.cons_s, h->d.posq, h->d.vel, cons_params(h), d_gate, thr, h->d.cons_n_dev);
     HIP_TRY(hipGetLastError());
     return MDX_OK;

@@ -256,6 +256,7 @@ struct mdx_handle {
     uint32_t n_bonds = 0, n_angles = 0, n_dih = 0, n_p14 = 0;
     uint32_t n_roles = 0;
     uint32_t n_groups = 0, n_cons = 0, n_vsites = 0;   // constraint clusters / constraints / virtual sites
+    bool cons_all_rigid3 = false;    // every constraint cluster is a rigid three-site water: the solvers' register-only flavour
     bool vsites_in_groups = false;   // every virtual site is placed by its parents' constraint cluster (GroupSite)
     bool vsites_fresh = false;       // ... and the last position stage did so: the next force call has nothing to construct
     std::vector<ConsGroup> h_groups; std::vector<VSite> h_vsites;   // host copies (caller order): ownership anchors of a decomposition
