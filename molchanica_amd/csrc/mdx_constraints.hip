@@ -107,6 +107,26 @@ __device__ __forceinline__ bool settle_positions(const float3 xo[4], float3 xn[4
     return true;
 }
 
+// The constraints of a cluster as a table over the six atom pairs of up to four atoms, in the fixed order (0,1) (0,2) (0,3) (1,2)
+// (1,3) (2,3): length of the constraint on that pair, 0 = none.  The sweeps below then walk the PAIRS with compile-time atom
+// indices; walking the constraints (cg.ca[c], cg.cb[c]) indexes the local position arrays with run-time values, which puts them
+// into scratch memory (64-112 B per lane, and every access of the sweep a memory instruction).
+__device__ __forceinline__ void pair_lengths(const ConsGroup& cg, float L[6]) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) L[q] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        if (c < (int)cg.ncons) {
+            const int a = min((int)cg.ca[c], (int)cg.cb[c]), b = max((int)cg.ca[c], (int)cg.cb[c]);
+            const int q = a == 0 ? b - 1 : (a == 1 ? b + 1 : 5);      // (0,1) 0  (0,2) 1  (0,3) 2  (1,2) 3  (1,3) 4  (2,3) 5
+#pragma unroll
+            for (int k = 0; k < 6; ++k) L[k] = (k == q) ? cg.len[c] : L[k];
+        }
+    }
+}
+#define MDX_PAIR_A(q) ((q) < 3 ? 0 : ((q) < 5 ? 1 : 2))
+#define MDX_PAIR_B(q) ((q) < 3 ? (q) + 1 : ((q) < 5 ? (q) - 1 : 3))
+
 // ---- SHAKE: positions ---------------------------------------------------------------------------
 // RIGID3: every cluster of the handle is a rigid three-site water (host-checked): constraint pairs are (0,1), (0,2), (1,2) by
 // construction, so nothing indexes the local position arrays with a run-time value and they live in registers - the general
@@ -159,15 +179,18 @@ __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_gro
                     wc += ((xn[k].x - xs[k].x) * xo[k].x + (xn[k].y - xs[k].y) * xo[k].y + (xn[k].z - xs[k].z) * xo[k].z) / im[k];
             }
         }
+        float Lq[6];
+        if (RIGID3) { Lq[0] = tri.l01; Lq[1] = tri.l01; Lq[2] = 0.f; Lq[3] = tri.l12; Lq[4] = 0.f; Lq[5] = 0.f; }
+        else pair_lengths(cg, Lq);
         for (int it = 0; it < ((settled || (RIGID3 && cg.natoms != 3)) ? 0 : p.max_iter); ++it) {
             bool done = true;
 #pragma unroll
-            for (int c = 0; c < (RIGID3 ? 3 : 6); ++c) {
-                if (!RIGID3 && c >= (int)cg.ncons) break;
-                const int a = RIGID3 ? (c == 2 ? 1 : 0) : cg.ca[c], b = RIGID3 ? (c == 0 ? 1 : 2) : cg.cb[c];
+            for (int q = 0; q < 6; ++q) {
+                if (RIGID3 && (q == 2 || q > 3)) continue;
+                if (!(Lq[q] > 0.f)) continue;
+                const int a = MDX_PAIR_A(q), b = MDX_PAIR_B(q);
                 const float3 s = make_float3(xn[a].x - xn[b].x, xn[a].y - xn[b].y, xn[a].z - xn[b].z);
-                const float lc = RIGID3 ? (c == 2 ? tri.l12 : tri.l01) : cg.len[c];
-                const float l2 = lc * lc;
+                const float l2 = Lq[q] * Lq[q];
                 const float diff = l2 - (s.x * s.x + s.y * s.y + s.z * s.z);
                 if (fabsf(diff) > 2.0f * p.tol * l2) {
                     done = false;
@@ -270,7 +293,7 @@ __global__ __launch_bounds__(128) void constrain_velocities_kernel(uint32_t n_gr
         float3 r[3]; float rhs[3]; int ia[3], ib[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            ia[c] = RIGID3 ? (c == 2 ? 1 : 0) : cg.ca[c]; ib[c] = RIGID3 ? (c == 0 ? 1 : 2) : cg.cb[c];
+            ia[c] = c == 2 ? 1 : 0; ib[c] = c == 0 ? 1 : 2;      // (a rigid triangle: its constraints are (0,1), (0,2), (1,2), whatever their order in the record)
             r[c] = make_float3(x[ia[c]].x - x[ib[c]].x, x[ia[c]].y - x[ib[c]].y, x[ia[c]].z - x[ib[c]].z);
             rhs[c] = dot3f(r[c], make_float3(v[ia[c]].x - v[ib[c]].x, v[ia[c]].y - v[ib[c]].y, v[ia[c]].z - v[ib[c]].z));
         }
@@ -303,16 +326,20 @@ __global__ __launch_bounds__(128) void constrain_velocities_kernel(uint32_t n_gr
             solved = true;
         }
     }
+    float Lq[6];
+    if (RIGID3) { Lq[0] = 1.f; Lq[1] = 1.f; Lq[2] = 0.f; Lq[3] = 1.f; Lq[4] = 0.f; Lq[5] = 0.f; }      // (which pairs; the lengths are read off the positions)
+    else pair_lengths(cg, Lq);
     for (int it = 0; it < ((solved || (RIGID3 && cg.natoms != 3)) ? 0 : p.max_iter); ++it) {
         bool done = true;
 #pragma unroll
-        for (int c = 0; c < (RIGID3 ? 3 : 6); ++c) {
-            if (!RIGID3 && c >= (int)cg.ncons) break;
-            const int a = RIGID3 ? (c == 2 ? 1 : 0) : cg.ca[c], b = RIGID3 ? (c == 0 ? 1 : 2) : cg.cb[c];
+        for (int q = 0; q < 6; ++q) {
+            if (RIGID3 && (q == 2 || q > 3)) continue;
+            if (!(Lq[q] > 0.f)) continue;
+            const int a = MDX_PAIR_A(q), b = MDX_PAIR_B(q);
             const float3 s = make_float3(x[a].x - x[b].x, x[a].y - x[b].y, x[a].z - x[b].z);
             const float3 w = make_float3(v[a].x - v[b].x, v[a].y - v[b].y, v[a].z - v[b].z);
             const float dot = s.x * w.x + s.y * w.y + s.z * w.z;
-            const float l2 = RIGID3 ? s.x * s.x + s.y * s.y + s.z * s.z : cg.len[c] * cg.len[c];      // (positions are on the constraints: |s| = the length)
+            const float l2 = RIGID3 ? s.x * s.x + s.y * s.y + s.z * s.z : Lq[q] * Lq[q];      // (positions are on the constraints: |s| = the length)
             // |d/dt of the bond length| relative to 1 Å/ps-scale speeds
             if (fabsf(dot) > p.tol * l2 * 10.0f) {
                 done = false;
