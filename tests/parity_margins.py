@@ -1,7 +1,7 @@
 """What the parity tests' tolerances leave in hand, measured: for BASELINE configs C1-C5 the worst per-atom force error as a
 multiple of SURVEY 8(c)'s 1e-4 * max(|F|, 1) (no RMS floor), the RMS ratio, the relative error of every energy term, and the
 100-step trajectory deviation of dhfr23k (C2) under reaction field and under the shifted cutoff.  The numbers the tests quote
-come from here.  Usage (through gpurun): python tools/parity_margins.py [c1 c2 c3 c4 c5 traj]"""
+come from here.  Usage (through gpurun): python tests/parity_margins.py [c1 c2 c3 c4 c5 traj]"""
 import math, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

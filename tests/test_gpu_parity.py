@@ -1,7 +1,7 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle and the committed goldens.
 
 Run on the MI355X box with `pytest -m gpu`.  Tolerances (fp32 device state vs the
-fp64 oracle; the margins they leave were measured with tools/parity_margins.py, round 4 - quoted below):
+fp64 oracle; the margins they leave were measured with tests/parity_margins.py, round 4 - quoted below):
   per-atom force   |dF| <= 1e-4 * max(|F|, 1) kcal/mol/Å (+ the force of any pair whose fp32
                    distance sits within 1e-5 relative of a cutoff - such a pair may legitimately
                    flip in or out under a one-ulp difference in the distance arithmetic).  No other

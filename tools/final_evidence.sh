@@ -8,7 +8,7 @@ python3 tools/default_point_time.py 64 > "$F/dp64.txt" 2>/dev/null
 python3 tools/default_point_time.py 18 > "$F/dp18.txt" 2>/dev/null
 MDX_PME_OVERLAP=0 bash tools/kt_default_point_single.sh ${TAG}_final_serial 64 > "$F/dp_serial.txt" 2>&1
 bash tools/kt_default_point_single.sh ${TAG}_final_overlap 64 > "$F/dp_overlap.txt" 2>&1
-python3 tools/parity_margins.py > "$F/parity_margins.txt" 2>&1
+python3 tests/parity_margins.py > "$F/parity_margins.txt" 2>&1
 python3 tools/single_point_time.py > "$F/single_point.txt" 2>&1
 python3 tools/nve_soak.py > "$F/nve_soak.txt" 2>&1
 python3 tools/decomp_soak.py > "$F/decomp_soak.txt" 2>&1
