@@ -481,11 +481,13 @@ static int compute_forces(mdx_handle* h, bool energy, const uint32_t* gate, uint
         MDX_TRY(mdx_launch_pme(h, energy, gate, thr));
     }
     MDX_TRY(mdx_launch_nonbonded(h, energy, gate, thr, split ? 2 : 0));
-    if (split) HIP_TRY(hipStreamWaitEvent(h->stream, h->dd->ev_interior, 0));
     // half-shell decomposition: the forces this rank computed on its ghosts go back to their owners (the bonded gather, which
     // only touches owned rows, runs while the message is on the wire when the communication stream is a separate one)
     const int fr_word = (h->dd && gate) ? h->nb_step + 1 : -1;
     if (h->dd) { MdxRange range_fr("mdx ghost-force return"); MDX_TRY(mdx_dd_force_return_begin(h, fr_word)); }
+    // the interior tiles join here: they touch owned rows only (tile_class_kernel), the message above carries ghost rows only,
+    // so the ~10 us event hop of the join passes behind the pack and the send instead of in front of them
+    if (split) HIP_TRY(hipStreamWaitEvent(h->stream, h->dd->ev_interior, 0));
     MDX_TRY(mdx_launch_bonded(h, energy, gate, thr));
     if (h->dd) MDX_TRY(mdx_dd_force_return_end(h, fr_word));
     if (h->pme_on && h->pme_overlap) MDX_TRY(mdx_pme_join(h, gate, thr));
