@@ -15,9 +15,12 @@ Prints ONE JSON line on rank 0: the contract keys plus
                  x atoms per launch / mean launch duration from HIP events on the library's stream
   cpu_baseline — oracle/cpu_production.c (fp32, half Verlet list reused across steps, OpenMP over all host cores,
                  built -O3 -march=native on the machine it runs on) on a bounded sample of the same box
-The driver's command times 20 steps (12 ms: no list rebuild, no energy evaluation falls into it), so after the timed
-region an UNTIMED-for-`value` tail of 1000 steps runs with rebuilds at their natural cadence and energies every 100
-steps; its rate is reported beside `value` as `steps_per_s_1000`.
+The driver's command times 20 steps (10 ms: zero or one list rebuild, no energy evaluation falls into it), so after the
+timed region an UNTIMED-for-`value` tail of 1000 steps runs with rebuilds at their natural cadence and energies every 100
+steps; its rate is reported beside `value` as `steps_per_s_1000`.  The handle that is timed is created from the prepared
+state just before the run; --settle-steps (300, untimed, reported in config.untimed_preparation) let its step loop reach
+its steady state (rebuild cadence -> chunk lengths, dual-list buffer, decomposed: the split's A/B over 16 chunks) before
+the W warm-up steps - with --warmup 5 alone the window measured the start-up of a new handle (tools/window_warmup.sh).
 """
 from __future__ import annotations
 
@@ -72,6 +75,11 @@ def parse():
     ap.add_argument("--reference-steps", type=int, default=100, help="steps the --reference-cmd run performs")
     ap.add_argument("--tail-steps", type=int, default=-1,
                     help="untimed-for-value tail with natural rebuilds and energies every 100 steps; -1 = 1000 when --steps < 1000, else 0")
+    ap.add_argument("--settle-steps", type=int, default=300,
+                    help="untimed NVE steps on the handle that is timed, in front of the --warmup steps: the preparation above runs on a "
+                         "handle of its own, and a new handle's step loop learns its rebuild cadence (chunk lengths), its dual-list buffer "
+                         "and - decomposed - whether the interior / boundary split pays over its first ~16 chunks; with the driver's "
+                         "--warmup 5 the 20 timed steps otherwise measure that start-up (0.52-0.56 ms per step against 0.48-0.52)")
     ap.add_argument("--nb-variant", type=int, default=0)
     ap.add_argument("--decomposed", action="store_true", help="drive the decomposed path even on one GPU")
     ap.add_argument("--no-equilibrate", dest="equilibrate", action="store_false",
@@ -345,6 +353,8 @@ def main():
 
     if args.energy_every > 0:
         md.set_energy_cadence(args.energy_every)
+    if args.settle_steps > 0:
+        stepper(args.settle_steps)
     stepper(args.warmup)
     if world > 1 and args.profile_level == 2:
         # decomposed runs are timed in their production arrangement: the event brackets would switch the interior /
@@ -492,7 +502,8 @@ def main():
                    "rebuilds_in_timed_region": int(st["rebuild_count"] - st0["rebuild_count"]),
                    "dual_list": ({"inner_skin": cfg.inner_skin or 0.5, "verlet_pair_evals": verlet_evals, "inner_pair_evals": inner_evals,
                                   "prune_frac": prune_frac} if dual else None),
-                   "energy_evaluations_in_timed_region": n_energy, "untimed_preparation": prep,
+                   "energy_evaluations_in_timed_region": n_energy,
+                   "untimed_preparation": dict(prep or {}, nve_settle_steps_on_the_timed_handle=args.settle_steps),
                    "repartitions": int(st_nb["repartitions"]) if (world > 1 or args.decomposed) else None,
                    "local_rebuilds": int(st_nb["local_rebuilds"]) if (world > 1 or args.decomposed) else None,
                    "rebuild_fallbacks": int(st_nb.get("rebuild_fallbacks", 0)),
