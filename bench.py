@@ -48,7 +48,7 @@ def _nb_kernel_rev():
     written by tools/summarize_rocprof.py with the hash of the tree it was measured on) is quoted only while it matches."""
     import hashlib
     h = hashlib.sha1()
-    for f in ("mdx_nonbonded.hip", "mdx_internal.h"):
+    for f in ("mdx_nonbonded_impl.h", "mdx_pair_dev.h", "mdx_internal.h"):
         with open(os.path.join(ROOT, "molchanica_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]

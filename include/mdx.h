@@ -328,7 +328,8 @@ int mdx_set_integrator(mdx_handle* h, int kind, float gamma_per_ps, float temper
  * + (1 - lambda) 2 E_env,mol, and each atom's force is interpolated from its own group's potential plus (1 - lambda)
  * times the other's; the uniform background of a charged molecule is left unscaled.
  * Every energy evaluation (hence every snapshot) reports dh_dlambda = dU/dlambda and coupled_interaction =
- * (1 - lambda) U_cross.  Needs mol_start in the system description; not available on a decomposed handle.
+ * (1 - lambda) U_cross.  Needs mol_start in the system description.  Works on a decomposed handle too (cutoff and SPME; the
+ * reciprocal mesh is then replicated and all-reduced instead of slab-decomposed: mdx_pme_info).
  * lambda < 0 switches the window off.  mdx_set_alchemical_softcore: alpha = 0 selects plain linear coupling
  * (singular in dU/dlambda at lambda -> 1 for overlapping sites). */
 int mdx_set_alchemical_softcore(mdx_handle* h, float alpha, float sigma_min);
@@ -425,6 +426,33 @@ uint32_t mdx_snapshot_hbond_count(const mdx_handle* h, uint32_t k);
 int      mdx_snapshot_read_hbonds(mdx_handle* h, uint32_t k, mdx_hbond* out, uint32_t capacity);
 double   mdx_time_ps(const mdx_handle* h);
 
+/* ---- SnapshotEnergyData.energy_potential_between_mols --------------------------------------------------------------------
+ * [ref: src/properties/crystal.rs:347-370 `cohesive_energy_from_matrix(&e.energy_potential_between_mols, n_mol)`: flat row-major
+ * n_mol x n_mol, called on every snapshot at :533; src/ui/panels/md_viewer.rs:234-237.]  The non-bonded energy between molecules -
+ * or between caller-chosen groups of atoms: "receptor / ligand / solvent" makes it the docking scorer's receptor-ligand
+ * interaction energy (BASELINE config 3, src/docking/mod.rs:81-154).  Off until groups are set:
+ *   mdx_set_energy_groups(h, NULL, 0)        one group per molecule of mdx_system.mol_start (at most 255 molecules)
+ *   mdx_set_energy_groups(h, group_of_atom, n) group_of_atom[i] < n <= 255 for every atom
+ *   mdx_set_energy_groups(h, NULL, 0) on a system without mol_start: off again
+ * The matrix is symmetric, kcal/mol:
+ *   M[a][b] (a != b)  sum over atom pairs (i in a, j in b) of the pair loop's Lennard-Jones + Coulomb energy - the configured
+ *                     real-space treatment (shifted cutoff / reaction field / erfc(beta r)/r), same cutoffs, exclusions and periodic
+ *                     images as the forces - plus the scaled 1-4 energy of 1-4 pairs between the two groups
+ *   M[a][a]           the same over the pairs inside group a, every pair once
+ * so that  sum_{a <= b} M[a][b] = lj + coulomb + lj14 + coulomb14  of mdx_energies (= potential_nonbonded - coulomb_recip: the SPME
+ * mesh term belongs to the whole charge density and is not split).  With an alchemical window the coupled pairs enter scaled,
+ * as in mdx_energies.  mdx_energy_between_mols evaluates the current state (one extra pass over the pair list; collective on a
+ * decomposed handle); while groups are set every stored snapshot carries its matrix (mdx_snapshot_read_between_mols). */
+int      mdx_set_energy_groups(mdx_handle* h, const uint8_t* group_of_atom /* [N] or NULL */, uint32_t n_groups);
+uint32_t mdx_energy_group_count(const mdx_handle* h);
+int      mdx_energy_between_mols(mdx_handle* h, float* out /* [n * n] row-major */, uint32_t n);
+int      mdx_snapshot_read_between_mols(mdx_handle* h, uint32_t k, float* out /* [n * n] */, uint32_t n);
+/* compute_energy_snapshot with the matrix: mdx_single_point (same pose cache, same results) followed by the matrix of the same
+ * pose for the given groups (group_of_atom NULL: by molecule).  The ligand row of a receptor / ligand / solvent map is what a
+ * docking pose is ranked by. */
+int      mdx_single_point_between_mols(const mdx_system* sys, const mdx_config* cfg, int device, const uint8_t* group_of_atom,
+                                       uint32_t n_groups, mdx_energies* out, float* forces_or_null, float* matrix_out /* [n * n] */);
+
 /* ---- multi-GPU: one periodic box spatially decomposed over the GPUs of a node (the reference is
  * single-device, src/util.rs:1086 `CudaContext::new(0)`, so this is new capability, not parity) -------------------
  * One rank (process or thread) per GPU.  Every rank creates a handle from the SAME global system (static per-atom data
@@ -442,8 +470,10 @@ double   mdx_time_ps(const mdx_handle* h);
  * control; the accepted state is the gathered global positions) and alchemical windows (cutoff and SPME) work on a decomposed
  * handle (a constraint cluster / virtual-site family is owned as a whole by one rank).  The halo is a HALF shell when the
  * half-list pair kernel runs (the default): a pair of atoms owned by two ranks is evaluated on one of them and the force on
- * the ghost travels back in a second send/recv group per step.  Uploads (mdx_upload*, mdx_set_box, mdx_shrink_cell_towards,
- * mdx_initialize_velocities) are refused (MDX_EPARAM): the state is distributed - set it before joining.
+ * the ghost travels back in a second send/recv group per step.  Host mutation of a joined handle - mdx_upload, mdx_upload_range,
+ * mdx_set_box, mdx_shrink_cell_towards, mdx_initialize_velocities - is COLLECTIVE as well: every rank passes the same data; the
+ * distributed state is gathered, the named rows / the box are overwritten on every rank alike and the ranks repartition
+ * (about 1 ms at 1 M atoms; a pose loop that wants the single-GPU latency keeps its handle undecomposed).
  *
  * mdx_comm_unique_id: rank 0 draws the id (ncclGetUniqueId; librccl is dlopen'd on first use) and hands the 128 bytes
  * to the other ranks by whatever means the host has.  mdx_comm_init is ncclCommInitRank + the first partition. */

@@ -147,7 +147,7 @@ static void free_device(mdx_handle* h) {
                     d.mchunk_cnt, d.mchunk_off, d.entries, d.entries_in, d.inner_nch, d.list_cursors, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
                     d.role_off_s, d.role_rec_s, d.role_prm, d.ctl, d.energy,
                     d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.pme_force, d.cons_o, d.cons_s, d.cons_tmp, d.cons_mask, d.cons_cnt, d.cons_off, d.cons_vir, d.vsite_o, d.vsite_s, d.gsite_o, d.gsite_s, d.gsite_tmp, d.pme_q, d.pme_f,
-                    d.pme_theta, d.pme_q2, d.pme_f2, d.scratch4, d.tile_bnd, d.tile_scan, d.tile_order, d.tile_lpt, d.rb_ctl, d.scan_chain};
+                    d.pme_theta, d.pme_q2, d.pme_f2, d.scratch4, d.tile_bnd, d.tile_scan, d.tile_order, d.tile_lpt, d.rb_ctl, d.scan_chain, d.grp, d.grp_mat};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = DeviceState{};
 }
@@ -770,7 +770,9 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         // MDX_DEBUG_HOST=1: where the host spends a chunk - enqueueing it, or waiting for the device to finish it
         static const bool dbg_host = [] { const char* e = std::getenv("MDX_DEBUG_HOST"); return e && e[0] == '1'; }();
         const auto t_enq = std::chrono::steady_clock::now();
+        if (h->dd) h->dd->probe_both_buffers = fuse_bi && chunk > 1;
         MDX_TRY(ctl_to_host(h));
+        if (h->dd) h->dd->probe_both_buffers = false;
         if (dbg_host && chunk >= 8) {      // (chunks cut short by a per-step thermostat or cadence say nothing about the step loop)
             static double enq = 0.0, wait = 0.0; static unsigned long long steps = 0, chunks = 0;
             const auto t_w = std::chrono::steady_clock::now();
@@ -1031,6 +1033,21 @@ struct SinglePointCache {
     }
 };
 static thread_local SinglePointCache g_sp_cache;
+
+extern "C" int mdx_single_point_between_mols(const mdx_system* sys, const mdx_config* cfg, int device, const uint8_t* group_of_atom,
+                                             uint32_t n_groups, mdx_energies* out, float* forces_or_null, float* matrix_out) {
+    if (!matrix_out) FAIL(MDX_EPARAM, "null matrix_out");
+    MDX_TRY(mdx_single_point(sys, cfg, device, out, forces_or_null));
+    mdx_handle* h = g_sp_cache.h;      // the pose just scored lives on the calling thread's kept handle
+    if (!h) FAIL(MDX_EDEVICE, "internal: the scorer kept no handle");
+    // the group map is part of the request, not of the system: set it when it differs from what the kept handle holds
+    const uint32_t N = h->N;
+    bool same = h->n_grp != 0;
+    if (group_of_atom) same = same && h->n_grp == n_groups && h->grp_host.size() == N && std::memcmp(h->grp_host.data(), group_of_atom, N) == 0 && !h->grp_by_mol;
+    else same = same && h->grp_by_mol;
+    if (!same) MDX_TRY(mdx_set_energy_groups(h, group_of_atom, group_of_atom ? n_groups : 0u));
+    return mdx_groups_evaluate(h, matrix_out);
+}
 
 extern "C" void mdx_single_point_release(void) {
     if (g_sp_cache.h) { std::string keep = g_last_error; mdx_destroy(g_sp_cache.h); g_last_error = keep; }

@@ -92,7 +92,9 @@ struct MdxDecomp {
     // last kernel, every chunk, and comes back with the step-control words - a stale list then needs no second round trip to
     // decide between a local rebuild and a repartition (it was: drift kernel, all-reduce, copy, synchronise - ~80 us per rebuild)
     uint32_t* drift_bits = nullptr;    // [2] device
-    bool spec_valid = false; uint32_t spec_bits = 0;
+    bool spec_valid = false; uint32_t spec_bits = 0; uint64_t spec_checks = 0;
+    bool probe_both_buffers = false;   // the chunk just enqueued ran fused bonded + kick + drift passes: which of the two position buffers holds the
+                                       // state of the step the list went stale at depends on the parity of the gated-off passes behind it
     // statistics
     uint64_t repartitions = 0, local_rebuilds = 0; uint32_t local_rebuilds_since = 0;
     double repartition_ms = 0.0;
@@ -117,6 +119,7 @@ int  mdx_dd_force_return_end(mdx_handle* h, int flag_word);     // ... and add w
 int  mdx_dd_chunk_end_probe(mdx_handle* h, const uint32_t** word_out);   // enqueue the speculative drift probe; *word_out: the device word to read back
 int  mdx_dd_on_stale(mdx_handle* h);                     // the list went stale somewhere: local rebuild or repartition (same branch on every rank)
 int  mdx_dd_allreduce_host(mdx_handle* h, double* v, int n, bool max_u32 = false);
+int  mdx_dd_allreduce_dev(mdx_handle* h, double* dev, size_t n);   // in-place sum of a device array of doubles over the ranks (any n; produced on the handle's stream)
 int  mdx_dd_allreduce_f32(mdx_handle* h, float* dev, size_t n, hipStream_t produced_on);   // sum of a large device array over the ranks
 int  mdx_dd_exchange(mdx_handle* h, const float4* send, const std::vector<MdxSeg>& ssegs, float4* recv, const std::vector<MdxSeg>& rsegs,
                      hipStream_t produced_on);                // one send/recv group, ordered against `produced_on`

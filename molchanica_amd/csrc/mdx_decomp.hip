@@ -10,9 +10,12 @@
 //     locally.  Ownership is decided per constraint cluster / virtual-site family (by the position of its first atom),
 //     so SHAKE, RATTLE and the construction / force spreading of virtual sites never cross a rank boundary.
 //   * Per step: drift (+ SHAKE, + virtual sites) -> pack -> ONE group of ncclSend / ncclRecv on the communication
-//     stream -> unpack -> forces.  A pair with at least one owned atom is evaluated on every rank that owns one of its
-//     atoms, so no force message travels back.  The "list went stale" word of every rank rides on the message (each
-//     peer's segment ends with a flag row), so all ranks stop at the same step without a separate collective.
+//     stream -> unpack -> forces -> ghost forces back.  The halo is a HALF shell (default, with the half-list pair kernel):
+//     a rank keeps ghosts only of atoms whose owner's brick lies in an upper direction, so a pair of atoms owned by two ranks
+//     is evaluated on exactly one of them, and the forces that rank computed on its ghosts return to their owners in a second
+//     send/recv group along the same segments (MDX_HALF_SHELL=0: full shell, every rank evaluates every pair of its owned
+//     atoms, no force message).  The "list went stale" word of every rank rides on both messages (each peer's segment ends
+//     with a flag row), so all ranks stop at the same step without a separate collective.
 //   * A stale list is rebuilt LOCALLY while the owned + ghost set is still complete (no atom further than margin/2 from
 //     where it was at the last repartition: one small all-reduce decides, the same way on every rank); otherwise the
 //     ranks REPARTITION: every rank's owned rows are gathered everywhere (one group of sends/receives: each rank's block
@@ -424,6 +427,14 @@ static int dd_comm_leave(mdx_handle* h) {
     HIP_TRY(hipStreamWaitEvent(h->stream, dd->ev_arrived, 0));
     return MDX_OK;
 }
+int mdx_dd_allreduce_dev(mdx_handle* h, double* dev, size_t n) {
+    MdxDecomp* dd = h->dd;
+    if (!dd || dd->world == 1 || n == 0) return MDX_OK;
+    MDX_TRY(dd_comm_enter(h));
+    for (size_t k = 0; k < n; k += 4096) MDX_TRY(dd->tr->all_reduce(dev + k, std::min<size_t>(4096, n - k), 0, dd->comm_stream));
+    MDX_TRY(dd_comm_leave(h));
+    return MDX_OK;
+}
 int mdx_dd_allreduce_f32(mdx_handle* h, float* dev, size_t n, hipStream_t produced_on) {
     MdxDecomp* dd = h->dd;
     if (dd->comm_stream == produced_on) return dd->tr->all_reduce_f32(dev, n, produced_on);
@@ -633,9 +644,18 @@ static int dd_enqueue_drift_probe(mdx_handle* h, uint32_t* bits) {
     MdxDecomp* dd = h->dd;
     hipStream_t st = h->stream;
     HIP_TRY(hipMemsetAsync(bits, 0, sizeof(uint32_t), st));
-    if (h->in_slot_space)
+    if (h->in_slot_space) {
         hipLaunchKernelGGL(dd_drift_kernel, dim3(std::min(div_up(dd->n_local, 256), 64u)), dim3(256), 0, st, dd->n_local, dd->gid_local, h->d.slot_of,
                            h->d.posq, dd->pos_at_part, make_part(dd), bits);
+        // Chunk-end probe behind fused bonded + kick + drift passes: every enqueued pass swaps the host's posq / posq_alt pointers, the
+        // gated-off ones included, while on the device the passes behind a stale step write nothing - with an odd number of them
+        // behind the stale step h->d.posq names the buffer that still holds the positions of the step BEFORE it (mdx_step repoints
+        // it after the read-back).  The two buffers hold the last two states: the larger of their drifts is the stale step's or
+        // an upper bound within one step of it - never an under-estimate that would approve a local rebuild on an incomplete set.
+        if (dd->probe_both_buffers && h->d.posq_alt)
+            hipLaunchKernelGGL(dd_drift_kernel, dim3(std::min(div_up(dd->n_local, 256), 64u)), dim3(256), 0, st, dd->n_local, dd->gid_local, h->d.slot_of,
+                               h->d.posq_alt, dd->pos_at_part, make_part(dd), bits);
+    }
     MDX_TRY(dd_comm_enter(h));
     MDX_TRY(dd->tr->all_reduce(bits, 1, 1, dd->comm_stream));
     MDX_TRY(dd_comm_leave(h));
@@ -668,6 +688,18 @@ static int dd_local_set_still_valid(mdx_handle* h, bool* valid) {
     if (dd->spec_valid) {      // measured and all-reduced behind the chunk that went stale: the same word on every rank
         dd->spec_valid = false;
         *valid = dd_drift_allows_local_rebuild(dd, dd->spec_bits);
+        // MDX_DD_SPEC_CHECK=1 (tests): measure again now - mdx_step has repointed posq at the stale step's buffer - and insist that
+        // the word that rode behind the chunk was not smaller (collective: every rank runs the same check)
+        const char* chk = std::getenv("MDX_DD_SPEC_CHECK");
+        if (chk && chk[0] == '1') {
+            uint32_t* bits = (uint32_t*)dd->red;
+            MDX_TRY(dd_enqueue_drift_probe(h, bits));
+            uint32_t b = 0;
+            HIP_TRY(hipMemcpyAsync(&b, bits, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            dd->spec_checks++;
+            if (dd->spec_bits < b) FAIL(MDX_EDEVICE, "internal: the chunk-end drift probe under-reported the drift since the last repartition");
+        }
         return MDX_OK;
     }
     uint32_t* bits = (uint32_t*)dd->red;
@@ -878,6 +910,7 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
     MdxDecomp* dd = new MdxDecomp();
     dd->tr = tr; dd->rank = tr->rank; dd->world = tr->world;
     h->dd = dd;
+    if (dd->world > DD_MAX_WORLD) { mdx_set_error("decomposition: more than 32 ranks"); return bail(MDX_EPARAM); }
     process_grid(dd->world, dd->grid);
     dd->coord[0] = dd->rank / (dd->grid[1] * dd->grid[2]); dd->coord[1] = (dd->rank / dd->grid[2]) % dd->grid[1]; dd->coord[2] = dd->rank % dd->grid[2];
     dd_set_bricks(h);
@@ -942,6 +975,27 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
         if (h->pme_overlap && h->stream_pme) DD_HIP(hipStreamSynchronize(h->stream_pme));
         h->pme_overlap = false;
         DD_TRY(mdx_pme_setup(h));
+    }
+    {   // One Verlet skin for all ranks.  A handle created with mdx_config.skin == 0 tunes its skin from its own wall clock while it
+        // steps alone (mdx_step); handles that stepped before joining may arrive here with different skins - different list radii,
+        // halo widths and stale thresholds, i.e. send lists that disagree with the peers' receive lists.  The tuning stops here
+        // (ranks' clocks do not agree; mdx_get_skin reports tuning = 0 from now on) and every rank takes the smallest skin any
+        // rank holds (a legal choice everywhere: it was checked against the same box).  Placed behind every check a rank can fail
+        // on its own: a rank that refuses to join must not leave its peers waiting in a collective.
+        uint32_t words[DD_MAX_WORLD];
+        uint32_t mine; std::memcpy(&mine, &h->cfg.skin, 4);
+        if (tr->all_gather_u32(mine, words, h->stream) != MDX_OK) return bail(MDX_EDEVICE);
+        float smin = h->cfg.skin;
+        for (int q = 0; q < tr->world; ++q) { float s; std::memcpy(&s, &words[q], 4); if (s >= 0.f && s < smin) smin = s; }
+        h->skin_tune.phase = 4;
+        if (smin != h->cfg.skin) {
+            h->cfg.skin = smin;
+            h->r_list = std::max(h->cfg.lj_cutoff, h->cfg.coulomb_cutoff) + smin;
+            h->list_valid = false; h->stretch_samples = 0;
+            h->inner_skin_auto = 0.f; h->dual_auto_off = false; h->dual_win_steps = 0; h->dual_win_prunes = 0;
+            dd->r_list = h->r_list;
+            if (dd_set_halo(h) != MDX_OK) return bail(MDX_EPARAM);
+        }
     }
     DD_TRY(dd_partition(h));
     DD_TRY(mdx_rebuild(h));

@@ -372,6 +372,10 @@ static int take_snapshot(mdx_handle* h) {
         MDX_TRY(mdx_download(h, MDX_VEL, sn.vel.data()));
     }
     if (!h->hb_heavy.empty() && n_rows == h->N) detect_hbonds(h, sn.pos.data(), sn.hbonds);
+    if (h->n_grp) {      // SnapshotEnergyData.energy_potential_between_mols (src/properties/crystal.rs:533)
+        sn.between.resize((size_t)h->n_grp * h->n_grp);
+        MDX_TRY(mdx_groups_evaluate(h, sn.between.data()));
+    }
     h->snapshots.push_back(std::move(sn));
     return MDX_OK;
 }
@@ -506,6 +510,15 @@ extern "C" int mdx_set_snapshot_cadence(mdx_handle* h, uint32_t every_n, int wit
 }
 
 extern "C" uint32_t mdx_snapshot_count(const mdx_handle* h) { return h ? (uint32_t)h->snapshots.size() : 0u; }
+extern "C" int mdx_snapshot_read_between_mols(mdx_handle* h, uint32_t k, float* out, uint32_t n) {
+    if (!h || !out) FAIL(MDX_EPARAM, "null argument");
+    if (k >= h->snapshots.size()) FAIL(MDX_EPARAM, "snapshot index out of range");
+    const auto& sn = h->snapshots[k];
+    if (sn.between.empty()) FAIL(MDX_EPARAM, "the snapshot was taken without energy groups (mdx_set_energy_groups)");
+    if ((size_t)n * n != sn.between.size()) FAIL(MDX_EPARAM, "n must be the number of groups the snapshot was taken with");
+    std::memcpy(out, sn.between.data(), sizeof(float) * sn.between.size());
+    return MDX_OK;
+}
 extern "C" double mdx_time_ps(const mdx_handle* h) { return h ? h->time_ps : 0.0; }
 
 extern "C" int mdx_snapshot_read(mdx_handle* h, uint32_t k, double* time_ps, uint64_t* step, mdx_energies* e, float* pos,

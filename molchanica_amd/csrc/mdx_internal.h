@@ -31,6 +31,7 @@
 #define MDX_DUMMY_BASE 1.0e6f
 #define MDX_DUMMY_STEP 64.0f
 #define MDX_MAX_CHUNK 64
+#define MDX_MAX_GROUPS 255  // mdx_set_energy_groups: a group index is a byte
 
 #define MDX_ESTRIDE 5   // {lj, coulomb, virial, cross (alchemical: unscaled energy of the coupled pairs), dU/dlambda} per slot
 #define MDX_EPART 256   // the pair kernel spreads its energy atomics over this many slots (contended f64 atomics cost ~10 ns each)
@@ -232,6 +233,8 @@ struct DeviceState {
     // [3] interior tiles, [4] S + 1 = (T + 1) * 64 + 1 (length of the role-count scan)
     uint32_t* rb_ctl = nullptr;
     unsigned long long* scan_chain = nullptr;   // [64] chained-window scans: (generation << 32) | running total per window, then the windows' done ticks
+    // energy between molecules / groups (mdx_groups.hip): group of every GLOBAL atom, and the raw n x n sums
+    uint8_t* grp = nullptr; double* grp_mat = nullptr;
 };
 
 struct MdxDecomp;   // mdx_comm.h: the handle is one rank of a spatially decomposed box
@@ -275,6 +278,7 @@ struct mdx_handle {
     std::vector<float> h_mass;
     std::vector<float2> h_lj;          // host copy of the per-atom LJ record (sign of .y marks the alchemical molecule)
     std::vector<uint32_t> mol_start;   // first atom of each molecule
+    std::vector<uint8_t> grp_host; uint32_t n_grp = 0; bool grp_by_mol = false;   // mdx_set_energy_groups: group of every atom (0: no matrix is kept)
     bool alch_on = false; double alch_lambda = 0.0; uint32_t alch_lo = 0, alch_hi = 0;
     float sc_alpha = 0.5f, sc_sigma_min = 3.0f;   // soft core of the alchemical window (mdx_set_alchemical_softcore)
     // grid
@@ -350,7 +354,7 @@ struct mdx_handle {
     bool zero_com = false;
     uint32_t snap_every = 0; bool snap_vel = false;
     double time_ps = 0.0;
-    struct Snapshot { double time; uint64_t step; mdx_energies e; std::vector<float> pos, vel; std::vector<mdx_hbond> hbonds; };
+    struct Snapshot { double time; uint64_t step; mdx_energies e; std::vector<float> pos, vel; std::vector<mdx_hbond> hbonds; std::vector<float> between; };
     // md.water views and hydrogen-bond detection (mdx_set_water_layout / mdx_set_hbond_detection)
     uint32_t water_first = 0, n_waters = 0, water_sites = 0;
     std::vector<uint8_t> hb_heavy; float hb_dmax = 2.5f, hb_angle_min = 120.f;
@@ -483,6 +487,7 @@ int mdx_after_steps(mdx_handle* h, float dt, uint32_t done);      // thermostat 
 uint32_t mdx_steps_to_next_event(const mdx_handle* h);            // chunk lengths stop at these boundaries
 bool mdx_energy_wanted_at(const mdx_handle* h, uint64_t step);    // does something read the energies after step `step`?
 int mdx_finalize_energy_cache(mdx_handle* h);                     // e_pending -> e_cache (kinetic energy, constraint virial, read-back)
+int mdx_groups_evaluate(mdx_handle* h, float* out /* [n_grp^2] */);   // energy_potential_between_mols of the current state (mdx_groups.hip)
 int mdx_launch_scale_velocities(mdx_handle* h, float lambda, const double* com_v_or_null);
 int mdx_launch_momentum(mdx_handle* h);                           // energy[EN_COUNT+1..] <- sum m v (3 doubles) + mass
 

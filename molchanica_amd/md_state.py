@@ -145,6 +145,13 @@ def load_library():
     lib.mdx_constraint_description.argtypes = [H]
     lib.mdx_constraint_description.restype = C.c_char_p
     lib.mdx_comm_diag_read.argtypes = [H, C.POINTER(CCommDiag)]
+    lib.mdx_set_energy_groups.argtypes = [H, C.c_void_p, C.c_uint32]
+    lib.mdx_energy_group_count.argtypes = [H]
+    lib.mdx_energy_group_count.restype = C.c_uint32
+    lib.mdx_energy_between_mols.argtypes = [H, _fp, C.c_uint32]
+    lib.mdx_snapshot_read_between_mols.argtypes = [H, C.c_uint32, _fp, C.c_uint32]
+    lib.mdx_single_point_between_mols.argtypes = [C.POINTER(CSystem), C.POINTER(CConfig), C.c_int, C.c_void_p, C.c_uint32,
+                                                  C.POINTER(CEnergies), _fp, _fp]
     lib.mdx_comm_info.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _u32p, _u32p, _fp]
     _lib = lib
     return lib
@@ -222,6 +229,25 @@ class MdState:
         e = CEnergies()
         _check(load_library().mdx_energy(self._h, C.byref(e)))
         return e.as_dict()
+
+    def set_energy_groups(self, group_of_atom=None, n_groups: int = 0) -> int:
+        """Groups of `energy_potential_between_mols` (src/properties/crystal.rs:533): None = one per molecule (mol_start);
+        else group_of_atom[i] < n_groups <= 255.  -> number of groups in force (0: off)."""
+        lib = load_library()
+        if group_of_atom is None:
+            _check(lib.mdx_set_energy_groups(self._h, None, 0))
+        else:
+            g = np.ascontiguousarray(group_of_atom, dtype=np.uint8).reshape(self.n_atoms)
+            _check(lib.mdx_set_energy_groups(self._h, g.ctypes.data, int(n_groups)))
+        return int(lib.mdx_energy_group_count(self._h))
+
+    def energy_between_mols(self) -> np.ndarray:
+        """`SnapshotEnergyData.energy_potential_between_mols` of the current state: symmetric [n, n] f32, kcal/mol."""
+        lib = load_library()
+        n = int(lib.mdx_energy_group_count(self._h))
+        out = np.zeros((max(n, 1), max(n, 1)), dtype=np.float32)
+        _check(lib.mdx_energy_between_mols(self._h, out.ctypes.data_as(_fp), n))
+        return out
 
     def _download(self, which: int) -> np.ndarray:
         out = np.empty((self.n_atoms, 3), dtype=np.float32)
@@ -352,6 +378,11 @@ class MdState:
                 o, h0, h1 = (np.empty((self._n_waters, 3), dtype=np.float32) for _ in range(3))
                 _check(lib.mdx_snapshot_read_water(self._h, k, o.ctypes.data_as(_fp), h0.ctypes.data_as(_fp), h1.ctypes.data_as(_fp)))
                 snap.update(all_posits=pos, atom_posits=pos[:self._water_first], water_o_posits=o, water_h0_posits=h0, water_h1_posits=h1)
+            n_g = int(lib.mdx_energy_group_count(self._h))
+            if n_g:
+                m = np.zeros((n_g, n_g), dtype=np.float32)
+                if lib.mdx_snapshot_read_between_mols(self._h, k, m.ctypes.data_as(_fp), n_g) == MDX_OK:
+                    snap["energy_data"]["energy_potential_between_mols"] = m
             n_hb = int(lib.mdx_snapshot_hbond_count(self._h, k))
             hb = (CHBond * max(n_hb, 1))()
             if n_hb:
@@ -581,15 +612,25 @@ def release_single_point_cache():
 
 
 def compute_energy_snapshot(system: MdSystem, cfg: MdConfig | None = None, device: int = 0,
-                            with_forces: bool = False):
+                            with_forces: bool = False, groups=None, n_groups: int = 0):
     """`dynamics::compute_energy_snapshot` (src/md/mod.rs:1036): stateless single-point scorer.
-    Returns the energy dict (and forces [N,3] when asked)."""
+    Returns the energy dict (and forces [N,3] when asked).  groups: "mol" or a [N] group map -> the dict also carries
+    `energy_potential_between_mols` [n, n] (the receptor-ligand interaction energy of a docking pose is one element)."""
     lib = load_library()
     cfg = cfg or MdConfig()
     system.normalise()
     cs, cc = system.to_c(), cfg.to_c()
     e = CEnergies()
     f = np.zeros((system.n_atoms, 3), dtype=np.float32) if with_forces else None
+    if groups is not None:
+        by_mol = isinstance(groups, str)
+        n = int(system.mol_start.size) if by_mol else int(n_groups)
+        g = None if by_mol else np.ascontiguousarray(groups, dtype=np.uint8).reshape(system.n_atoms)
+        m = np.zeros((n, n), dtype=np.float32)
+        _check(lib.mdx_single_point_between_mols(C.byref(cs), C.byref(cc), int(device), None if g is None else g.ctypes.data, n,
+                                                 C.byref(e), None if f is None else f.ctypes.data_as(_fp), m.ctypes.data_as(_fp)))
+        d = e.as_dict(); d["energy_potential_between_mols"] = m
+        return (d, f) if with_forces else d
     _check(lib.mdx_single_point(C.byref(cs), C.byref(cc), int(device), C.byref(e),
                                 None if f is None else f.ctypes.data_as(_fp)))
     return (e.as_dict(), f) if with_forces else e.as_dict()

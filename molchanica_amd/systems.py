@@ -431,6 +431,66 @@ def complex50k(seed: int = 3, box: float = 80.0, n_total: int = 51200) -> MdSyst
     return _solvate([chain, ligd], box, n_total, seed, "complex50k")
 
 
+def small_complex(seed: int = 13, n_chain: int = 120, box: float = 30.0) -> MdSystem:
+    """A few-thousand-atom receptor (chain) + the 50-atom ligand + water: complex50k's shape at test size (three molecule
+    classes for `energy_potential_between_mols`: mol_start[0] the chain, [1] the ligand, [2:] the waters)."""
+    rng = np.random.default_rng(seed)
+    pos, bonds, types = _serpentine_chain(n_chain, np.full(3, box / 2), 14.0, rng, rows_per_layer=3)
+    chain = _solute_dict(pos, bonds, types, rng)
+    lig = lig50(seed=1)
+    lp = lig.pos.astype(np.float64)
+    lp = lp - lp.mean(0)
+    lp += np.array([box / 2, box / 2, pos[:, 2].max() + 5.0 + (lp[:, 2].max() - lp[:, 2].min()) / 2])
+    ligd = _solute_dict(lp, lig.bond_idx.astype(np.int64), rng.integers(0, 3, size=lp.shape[0]), rng)
+    return _solvate([chain, ligd], box, None, seed, "small_complex")
+
+
+def molecular_crystal(n_cells=(4, 2, 2), n_atoms: int = 12, spacing: float = 10.0, seed: int = 21) -> MdSystem:
+    """n_cells[0] x [1] x [2] copies of one small flexible molecule on a lattice, randomly rotated, no solvent: the shape of the
+    reference's crystal runs (/root/reference src/properties/crystal.rs:596-638; one `mol_start` entry per copy)."""
+    rng = np.random.default_rng(seed)
+    mol = lig50(seed=seed, n_atoms=n_atoms)
+    p0 = mol.pos.astype(np.float64)
+    p0 = p0 - p0.mean(0)
+    rots = _random_rotations(int(np.prod(n_cells)), rng)
+    solutes = []
+    k = 0
+    for ix in range(n_cells[0]):
+        for iy in range(n_cells[1]):
+            for iz in range(n_cells[2]):
+                pos = p0 @ rots[k].T + (np.array([ix, iy, iz]) + 0.5) * spacing
+                sd = _solute_dict(pos, mol.bond_idx.astype(np.int64), mol.lj_type.astype(np.int64) % 3, np.random.default_rng(seed + 1))
+                solutes.append(sd)
+                k += 1
+    n = sum(sd["pos"].shape[0] for sd in solutes)
+    bonds, bk, br0, angles, ak, at0, dih, dv, dp, dn, p14, excl_pairs, mol_start = ([] for _ in range(13))
+    base = 0
+    for sd in solutes:
+        mol_start.append(base)
+        bonds.append(sd["bonds"] + base); bk.append(sd["bond_k"]); br0.append(sd["bond_r0"])
+        angles.append(sd["angles"].astype(np.int64) + base); ak.append(sd["angle_k"]); at0.append(sd["angle_t0"])
+        dih.append(sd["dihedrals"].astype(np.int64) + base); dv.append(sd["dih_v"]); dp.append(sd["dih_phase"]); dn.append(sd["dih_n"])
+        p14.append(sd["p14"].astype(np.int64) + base)
+        eo, ei = sd["excl_off"].astype(np.int64), sd["excl_idx"].astype(np.int64)
+        ii = np.repeat(np.arange(sd["pos"].shape[0]), np.diff(eo))
+        m = ii < ei
+        excl_pairs.append(np.stack([ii[m], ei[m]], 1) + base)
+        base += sd["pos"].shape[0]
+    off, idx = topo.csr_from_pairs(n, np.concatenate(excl_pairs))
+    mass = np.concatenate([sd["mass"] for sd in solutes]).astype(np.float32)
+    box = tuple(float(c * spacing) for c in n_cells)
+    return MdSystem(
+        pos=np.concatenate([sd["pos"] for sd in solutes]), mass=mass, charge=np.concatenate([sd["charge"] for sd in solutes]),
+        lj_type=np.concatenate([sd["types"] for sd in solutes]), lj_sigma=[t[0] for t in SOLUTE_TYPES], lj_eps=[t[1] for t in SOLUTE_TYPES],
+        vel=maxwell_boltzmann(mass, 300.0, np.random.default_rng(seed + 100)),
+        bond_idx=np.concatenate(bonds), bond_k=np.concatenate(bk), bond_r0=np.concatenate(br0),
+        angle_idx=np.concatenate(angles), angle_k=np.concatenate(ak), angle_theta0=np.concatenate(at0),
+        dihedral_idx=np.concatenate(dih), dihedral_v=np.concatenate(dv), dihedral_phase=np.concatenate(dp), dihedral_n=np.concatenate(dn),
+        excl_offsets=off, excl_idx=idx, pairs14_idx=np.concatenate(p14), mol_start=np.asarray(mol_start, dtype=np.uint32),
+        periodic=True, box_lo=(0, 0, 0), box_hi=box, name="crystal%d" % len(solutes),
+    ).normalise()
+
+
 def dna100k(seed: int = 4, box: float = 100.0, n_total: int = 100000) -> MdSystem:
     """S3/C4: two ~800-atom helical strands + water, 100 Å cube."""
     rng = np.random.default_rng(seed)

@@ -588,6 +588,111 @@ int orc_forces(const mdx_system* s, const mdx_config* c, const double* x_in, con
     return 0;
 }
 
+/* SnapshotEnergyData.energy_potential_between_mols (consumed at /root/reference src/properties/crystal.rs:347-370, :533: flat
+ * row-major n x n, upper triangle summed): the non-bonded energy between groups of atoms.  group[i] < G.  mat[a*G+b] = mat[b*G+a]
+ * = sum over pairs (i in a, j in b) of the pair loop's LJ + Coulomb energy (same inclusion rule, images, exclusions and Coulomb
+ * treatment as orc_forces) + the scaled 1-4 energy of 1-4 pairs between a and b; the diagonal holds the pairs inside a group,
+ * each once.  gross: the same sums over |e_pair| (the scale fp32 rounding of the engine's pair terms acts on).  The alchemical
+ * window, if set, scales the coupled pairs as orc_forces does. */
+int orc_between_mols(const mdx_system* s, const mdx_config* c, const double* x_in, const uint8_t* group, uint32_t G,
+                     double* mat, double* gross, int use_cells) {
+    uint32_t N = s->n_atoms;
+    double* x = (double*)malloc(sizeof(double) * 3 * (N ? N : 1));
+    float* xf = (float*)malloc(sizeof(float) * 3 * (N ? N : 1));
+    for (uint32_t i = 0; i < 3 * N; ++i) x[i] = x_in ? x_in[i] : (double)s->pos[i];
+    orc_vsite_construct(s, x);
+    for (uint32_t i = 0; i < 3 * N; ++i) xf[i] = (float)x[i];
+    for (uint32_t k = 0; k < G * G; ++k) { mat[k] = 0.0; gross[k] = 0.0; }
+    excl_t ex = build_excl(s);
+    int cut_lj = cutoff_on(c->lj_cutoff), cut_c = cutoff_on(c->coulomb_cutoff);
+    float rc2_lj = c->lj_cutoff * c->lj_cutoff, rc2_c = c->coulomb_cutoff * c->coulomb_cutoff;
+    double rmax = fmax(cut_lj ? c->lj_cutoff : 0.0, cut_c ? c->coulomb_cutoff : 0.0);
+    if (use_cells && !(cut_lj && cut_c)) use_cells = 0;
+    grid_t g; if (use_cells) g = build_grid(s, x, rmax);
+    const int alch = g_alch_lambda >= 0.0;
+    const double asc = alch ? 1.0 - g_alch_lambda : 1.0;
+#pragma omp parallel
+    {
+        double* m_loc = (double*)calloc((size_t)G * G * 2, sizeof(double));
+        double* g_loc = m_loc + (size_t)G * G;
+#pragma omp for schedule(dynamic, 64)
+        for (uint32_t i = 0; i < N; ++i) {
+            if (!nb_active(s, i)) continue;
+            uint32_t ids[27]; int ncell = 1; uint32_t jbeg = 0, jend = N;
+            if (use_cells) {
+                int cc[3];
+                for (int a = 0; a < 3; ++a) {
+                    double L = g.w[a] * g.n[a], t = x[3*i+a] - g.lo[a];
+                    if (s->periodic) t -= floor(t / L) * L;
+                    int k = (int)floor(t / g.w[a]);
+                    if (k < 0) k = 0; if (k >= g.n[a]) k = g.n[a] - 1;
+                    cc[a] = k;
+                }
+                ncell = neighbour_cells(&g, cc[0], cc[1], cc[2], ids);
+            }
+            for (int ci = 0; ci < ncell; ++ci) {
+                if (use_cells) { jbeg = g.start[ids[ci]]; jend = g.start[ids[ci] + 1]; }
+                for (uint32_t jj = jbeg; jj < jend; ++jj) {
+                    uint32_t j = use_cells ? g.items[jj] : jj;
+                    if (j <= i || !nb_active(s, j)) continue;          /* every pair once */
+                    float r2f = r2_canonical(s, xf + 3 * i, xf + 3 * j);
+                    int in_lj = !cut_lj || r2f < rc2_lj, in_c = !cut_c || r2f < rc2_c;
+                    if (!in_lj && !in_c) continue;
+                    if (is_excluded(&ex, i, j)) continue;
+                    double d[3] = { x[3*i]-x[3*j], x[3*i+1]-x[3*j+1], x[3*i+2]-x[3*j+2] };
+                    min_image(s, d);
+                    double r2 = d[0]*d[0]+d[1]*d[1]+d[2]*d[2];
+                    double sig, eps; lj_pair(s, c, i, j, &sig, &eps);
+                    double qq = (double)s->charge[i] * (double)s->charge[j];
+                    double fs, el = 0.0, ec = 0.0;
+                    const int cross = alch && ((i >= g_alch_lo && i < g_alch_hi) != (j >= g_alch_lo && j < g_alch_hi));
+                    if (cross && g_sc_alpha > 0.0) {
+                        const double sg = (sig > 0.0 && eps > 0.0) ? sig : g_sc_sigma_min;
+                        const double sig6 = sg * sg * sg * sg * sg * sg;
+                        const double rsc2 = cbrt(g_sc_alpha * sig6 * g_alch_lambda + r2 * r2 * r2);
+                        pair_terms(c, sig, eps, qq, rsc2, in_lj, in_c, &fs, &el, &ec);
+                    } else pair_terms(c, sig, eps, qq, r2, in_lj, in_c, &fs, &el, &ec);
+                    if (cross) { el *= asc; ec *= asc; }
+                    const uint32_t a = group[i], b = group[j];
+                    const size_t k = a <= b ? (size_t)a * G + b : (size_t)b * G + a;      /* upper triangle, mirrored below */
+                    m_loc[k] += el + ec; g_loc[k] += fabs(el) + fabs(ec);
+                }
+            }
+        }
+#pragma omp critical
+        for (size_t k = 0; k < (size_t)G * G; ++k) { mat[k] += m_loc[k]; gross[k] += g_loc[k]; }
+        free(m_loc);
+    }
+    /* scaled 1-4 pairs (bonded_forces above): no cutoff, no potential shift */
+    if (!(c->overrides & MDX_OVR_BONDED_DISABLED))
+        for (uint32_t p = 0; p < s->n_pairs14; ++p) {
+            uint32_t i = s->pairs14_idx[2*p], j = s->pairs14_idx[2*p+1];
+            if (!nb_active(s, i) || !nb_active(s, j)) continue;
+            double d[3] = { x[3*i]-x[3*j], x[3*i+1]-x[3*j+1], x[3*i+2]-x[3*j+2] };
+            min_image(s, d);
+            double r2 = d[0]*d[0]+d[1]*d[1]+d[2]*d[2], inv_r = 1.0 / sqrt(r2);
+            double sig, eps; lj_pair(s, c, i, j, &sig, &eps);
+            double e = 0.0, ga = 0.0;
+            if (!(c->overrides & MDX_OVR_LJ_DISABLED)) {
+                double sr = sig * inv_r, sr2 = sr*sr, sr6 = sr2*sr2*sr2, sr12 = sr6*sr6;
+                double t = (double)c->scale14_lj * 4.0 * eps * (sr12 - sr6);
+                e += t; ga += fabs(t);
+            }
+            if (!(c->overrides & MDX_OVR_COULOMB_DISABLED)) {
+                double t = (double)c->scale14_coulomb * (double)c->coulomb_k * (double)s->charge[i] * (double)s->charge[j] * inv_r;
+                e += t; ga += fabs(t);
+            }
+            const uint32_t a = group[i], b = group[j];
+            const size_t k = a <= b ? (size_t)a * G + b : (size_t)b * G + a;
+            mat[k] += e; gross[k] += ga;
+        }
+    for (uint32_t a = 0; a < G; ++a)
+        for (uint32_t b = a + 1; b < G; ++b) { mat[(size_t)b * G + a] = mat[(size_t)a * G + b]; gross[(size_t)b * G + a] = gross[(size_t)a * G + b]; }
+    if (use_cells) free_grid(&g);
+    free(ex.off); free(ex.idx); free(x); free(xf);
+    return 0;
+}
+
 /* Kinetic energy (kcal/mol) of fp64 velocities. */
 double orc_kinetic(const mdx_system* s, const double* v) {
     double ke = 0.0;

@@ -65,6 +65,7 @@ def lib(path: str | None = None):
         l.orc_thermostat_lambda.restype = C.c_double
         l.orc_step_thermo.argtypes = [C.POINTER(CSystem), C.POINTER(CConfig), _dp, _dp, C.c_double, C.c_uint32,
                                       C.c_int, C.c_double, C.c_double, C.c_uint32, C.c_uint64, C.c_int, _dp, C.c_int]
+        l.orc_between_mols.argtypes = [C.POINTER(CSystem), C.POINTER(CConfig), _dp, C.c_void_p, C.c_uint32, _dp, _dp, C.c_int]
         l.orc_minimize.argtypes = [C.POINTER(CSystem), C.POINTER(CConfig), _dp, C.c_uint32, _dp, C.c_double, _dp, C.c_int]
         if path is not None:
             return l
@@ -88,6 +89,19 @@ def forces(sys: MdSystem, cfg: MdConfig, pos=None, ext=None, use_cells=False, _l
     rc = l.orc_forces(C.byref(cs), C.byref(cc), _d(x), _d(e), _d(f), _d(en), int(use_cells))
     assert rc == 0
     return f, _energies(en)
+
+
+def between_mols(sys: MdSystem, cfg: MdConfig, group, n_groups: int, pos=None, use_cells=False):
+    """energy_potential_between_mols (/root/reference src/properties/crystal.rs:347-370, 533) -> (matrix [G,G] f64, gross [G,G])."""
+    cs, cc = sys.to_c(), cfg.to_c()
+    n = sys.n_atoms
+    x = None if pos is None else np.ascontiguousarray(pos, dtype=np.float64).reshape(n, 3)
+    g = np.ascontiguousarray(group, dtype=np.uint8).reshape(n)
+    assert int(g.max()) < n_groups
+    m = np.zeros((n_groups, n_groups)); gr = np.zeros((n_groups, n_groups))
+    rc = lib().orc_between_mols(C.byref(cs), C.byref(cc), _d(x), g.ctypes.data, int(n_groups), _d(m), _d(gr), int(use_cells))
+    assert rc == 0
+    return m, gr
 
 
 def _energies(en):

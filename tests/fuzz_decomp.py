@@ -27,9 +27,14 @@ for case in range(n_cases):
     L = np.array(s.box_hi, np.float64) - np.array(s.box_lo, np.float64)
     world = int(rng.choice([2, 4, 8]))
     rc = float(rng.uniform(6.5, 8.5)); skin = float(rng.uniform(0.8, 1.6))
-    # (not the plain shifted cut-off: its FORCE is discontinuous at rc, and with 20 k sites a handful of pairs sit within an fp32 ulp of
-    # the cut-off at every step - which side they fall on differs between two summation orders, the trajectories part within 30 steps)
-    mode = int(rng.choice([1, 2]))
+    # The plain shifted cut-off (mode 0) is the mode `bench.py --gpus N` times (flexible water, dt 0.5 fs).  Its FORCE is discontinuous
+    # at rc: with 20 k sites a handful of pairs sit within an fp32 ulp of the cut-off at every step, which side they fall on differs
+    # between two summation orders, and a flipped pair kicks its atoms by k q q / rc^2.  Flexible systems at dt 0.5 fs are drawn
+    # with it and held to 3e-4 A rms (measured <= 7e-5 over 40 steps; the other modes 1e-4, measured <= 1e-5); at dt 2 fs with
+    # rigid water one flip moves a molecule 3e-4 A within the step and the two runs part by 5e-3 ... 7e-2 A in 35 steps whatever
+    # computes them (measured, round 5) - there the comparison would test the truncation, not the decomposition, so constrained
+    # systems draw reaction field or Ewald only.
+    mode = int(rng.choice([0, 1, 2])) if dt < 0.001 else int(rng.choice([1, 2]))
     cfgk = dict(lj_cutoff=rc, coulomb_cutoff=rc, skin=skin, coulomb_mode=mode, chunk_steps=int(rng.choice([4, 8, 16])))
     if mode == 2: cfgk.update(ewald_alpha=float(rng.uniform(0.3, 0.4)), overrides=0 if rng.random() < 0.6 else _abi.OVR_LONG_RANGE_RECIP_DISABLED)
     cfg = MdConfig(**cfgk)
@@ -57,7 +62,7 @@ for case in range(n_cases):
             assert abs(r0["e0"][k] - e_ref[k]) <= max(0.3 if (mode == 2 and k == "coulomb") else 2e-2, 5e-6 * abs(e_ref[k])), (k, r0["e0"][k], e_ref[k])
         dev = max(rms_dev(res[r]["pos"], p_ref, L) for r in res)
         # constrained waters at dt 2 fs amplify last-bit differences faster (cf. tests/test_gpu_comm.py: 2e-4 A after 40 steps there)
-        assert dev < (4e-4 if dt > 0.001 else 1e-4), f"trajectory deviates by {dev:.2e} A rms"
+        assert dev < (3e-4 if mode == 0 else (4e-4 if dt > 0.001 else 1e-4)), f"trajectory deviates by {dev:.2e} A rms"
         assert all(np.array_equal(res[r]["pos"], res[0]["pos"]) for r in res), "ranks disagree about the global positions"
         print("ok  ", what, f"| dev {dev:.1e}", flush=True)
     except Exception as ex:

@@ -121,14 +121,17 @@ def test_half_shell_halo_evaluates_every_cross_pair_once_and_returns_the_ghost_f
     assert rms_dev(half[0]["pos"], full[0]["pos"], L) < 5e-4
 
 
-def test_c5_water1m_on_eight_ranks_follows_one_gpu():
+def test_c5_water1m_on_eight_ranks_follows_one_gpu(monkeypatch):
     """BASELINE config 5 in the north star's arrangement: the 1,029,000-atom box on 2 x 2 x 2 ranks (virtual ranks of the one
     MI355X, in-process fabric; the production partition, halo, force return, local rebuilds and repartitions) against the
     same box on one GPU, from a prepared state (relaxed, 300 K, atoms wrapped one by one - a running box, not the generator's
     lattice of whole molecules).  60 steps: <= 2e-4 A RMS - fp32 coordinates in a 217 A box resolve 1.3e-5 A, and the two runs
     round in different frames (measured 1.0e-4, profiles/r02_decomp_soak_water1M.txt) - and every energy term of the start
-    to 1e-6 (the fp64 all-reduce of eight ranks' sums against one device's)."""
+    to 1e-6 (the fp64 all-reduce of eight ranks' sums against one device's).  These ranks run the fused bonded + kick + drift pass
+    (3.4 k tiles each); MDX_DD_SPEC_CHECK=1 makes every stale list re-measure the drift since the last repartition synchronously and
+    fail if the word that rode behind the chunk (whichever of the two position buffers the host's pointer named) was smaller."""
     import dataclasses
+    monkeypatch.setenv("MDX_DD_SPEC_CHECK", "1")
     from molchanica_amd.md_state import MdState
     s = systems.water1m()
     cfg = MdConfig()

@@ -82,3 +82,26 @@ def test_to_c_aliases_arrays():
     assert c.n_atoms == 50 and c.n_bonds == 49 and c.periodic == 0
     assert c.pos[3] == pytest.approx(float(s.pos[1, 0]))
     assert MdConfig().to_c().coulomb_k == pytest.approx(332.0637)
+
+
+def test_fingerprint_of_static_arrays_sees_permuted_blocks():
+    """The stateless scorer recognises "the same molecules, next pose" by a fingerprint of the static arrays (mdx_hostutil.cpp).
+    Two arrays made of the same 128-byte blocks in a different order (charges of atoms 0-31 swapped with atoms 32-63) are
+    different molecules."""
+    import ctypes as C
+    import os
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "molchanica_amd", "libmdx.so"))
+    fn = getattr(lib, "_Z10mdx_fp_mixmPKvm")
+    fn.restype = C.c_uint64
+    fn.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(5)
+    a = rng.normal(size=4096).astype(np.float32)
+    b = a.copy()
+    b[0:32], b[32:64] = a[32:64].copy(), a[0:32].copy()
+    c = a.copy(); c[1000] = np.nextafter(c[1000], np.float32(10.0))
+    ha, hb, hc = (fn(7, x.ctypes.data, x.nbytes) for x in (a, b, c))
+    assert ha != hb and ha != hc and hb != hc
+    assert fn(7, a.ctypes.data, a.nbytes) == ha and fn(8, a.ctypes.data, a.nbytes) != ha
+    small = a[:64]      # below the vector path's threshold: the portable flavour
+    sb = small.copy(); sb[0:8], sb[8:16] = small[8:16].copy(), small[0:8].copy()
+    assert fn(7, small.ctypes.data, small.nbytes) != fn(7, sb.ctypes.data, sb.nbytes)

@@ -112,7 +112,7 @@ if nbk:
         fetch, write = raw["FETCH_SIZE"] * 1024.0, raw["WRITE_SIZE"] * 1024.0
         traffic = {
             "workload": "water1M", "kernel": nbk[0], "round": tag,
-            "kernel_rev": __import__("hashlib").sha1(b"".join(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "molchanica_amd", "csrc", f), "rb").read() for f in ("mdx_nonbonded.hip", "mdx_internal.h"))).hexdigest()[:12],   # = bench.py's NB_KERNEL_REV
+            "kernel_rev": __import__("hashlib").sha1(b"".join(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "molchanica_amd", "csrc", f), "rb").read() for f in ("mdx_nonbonded_impl.h", "mdx_pair_dev.h", "mdx_internal.h"))).hexdigest()[:12],   # = bench.py's NB_KERNEL_REV
             "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, {tag}",
             "FETCH_SIZE_KB_per_launch": raw["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": raw["WRITE_SIZE"],
             "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE tallies 128-B read requests at 64 B -> x2 "
