@@ -106,7 +106,8 @@ typedef struct mdx_system {
      * hydrogens and 4-site OPC water  [ref: HydrogenConstraint::{Shake,Linear,Flexible},
      * src/ui/panels/md.rs:362-371; md.water[i].{o,h0,h1,m}, sol_shrinking_box.rs:605-613]. */
     uint32_t        n_constraints;  /* holonomic distance constraints: X-H bonds; rigid water = O-H, O-H, H-H.
-                                       Connected clusters may span at most 4 atoms / 6 constraints.
+                                       Connected clusters span at most 4 atoms / 6 constraints, or are a heavy atom with four
+                                       hydrogens (5 atoms, 4 bonds from one centre: ammonium, methane).
                                        HydrogenConstraint::Shake{shake_tolerance} -> constraint_tol.
                                        HydrogenConstraint::Linear{order, iter} (LINCS, the reference's UI default,
                                        src/ui/panels/md.rs:363-366) maps onto the SAME solver: LINCS's `order` (terms of

@@ -147,7 +147,7 @@ static void free_device(mdx_handle* h) {
                     d.mchunk_cnt, d.mchunk_off, d.entries, d.entries_in, d.inner_nch, d.list_cursors, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
                     d.role_off_s, d.role_rec_s, d.role_prm, d.ctl, d.energy,
                     d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.pme_force, d.cons_o, d.cons_s, d.cons_tmp, d.cons_mask, d.cons_cnt, d.cons_off, d.cons_vir, d.vsite_o, d.vsite_s, d.gsite_o, d.gsite_s, d.gsite_tmp, d.pme_q, d.pme_f,
-                    d.pme_theta, d.pme_q2, d.pme_f2, d.scratch4, d.tile_bnd, d.tile_scan, d.tile_order, d.tile_lpt, d.rb_ctl, d.scan_chain, d.grp, d.grp_mat};
+                    d.pme_theta, d.pme_q2, d.pme_f2, d.scratch4, d.tile_bnd, d.tile_scan, d.tile_order, d.tile_lpt, d.rb_ctl, d.scan_chain, d.grp, d.grp_mat, d.star_o, d.star_s};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = DeviceState{};
 }
@@ -376,7 +376,7 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
     HIP_TRY(hipStreamSynchronize(st));  // host vectors go out of scope
     h->in_slot_space = false; h->list_valid = false; h->forces_valid = false;
     MDX_TRY(mdx_build_constraints(h, s));
-    h->cons_dirty = h->n_groups > 0;
+    h->cons_dirty = mdx_has_constraints(h);
     MDX_TRY(mdx_pme_setup(h));
     MDX_TRY(mdx_rebuild(h));
     return MDX_OK;
@@ -723,7 +723,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         static const bool rattle_every = [] { const char* e = std::getenv("MDX_RATTLE_EVERY_STEP"); return e && e[0] == '1'; }();
         const int integ = h->integrator;
         const bool vv = integ == MDX_INTEGRATOR_VERLET_VELOCITY;
-        const bool fused = vv && (h->n_groups == 0 || !rattle_every);
+        const bool fused = vv && (!mdx_has_constraints(h) || !rattle_every);
         // Large classes: steps 1 .. chunk-1 run bonded gather + full kick + drift as ONE pass over double-buffered positions
         // (mdx_integrate.hip); the force call in front of such a pass leaves its bonded launch out.  The last force call of
         // the chunk is complete again (the closing half kick, energies, downloads read the force array).
@@ -1220,7 +1220,7 @@ extern "C" int mdx_upload(mdx_handle* h, int which, const float* src) {
     }
     if (h->dd) {      // joined handle: collective, every rank passes the same array (mdx_decomp.hip)
         MDX_TRY(mdx_dd_upload(h, which, 0, N, b.data()));
-        if (h->n_groups) h->cons_dirty = true;
+        if (mdx_has_constraints(h)) h->cons_dirty = true;
         return MDX_OK;
     }
     MDX_TRY(mdx_unsort_state(h));  // keep the other array: both now live in caller-order staging
@@ -1228,7 +1228,7 @@ extern "C" int mdx_upload(mdx_handle* h, int which, const float* src) {
                            hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->list_valid = false; h->forces_valid = false;
-    if (h->n_groups) h->cons_dirty = true;
+    if (mdx_has_constraints(h)) h->cons_dirty = true;
     return MDX_OK;
 }
 
@@ -1279,7 +1279,7 @@ extern "C" int mdx_upload_range(mdx_handle* h, int which, uint32_t first, uint32
     }
     if (h->dd) {      // joined handle: collective (the moved rows may change owner: gather, overwrite, repartition)
         MDX_TRY(mdx_dd_upload(h, which, first, count, b.data()));
-        if (h->n_groups) h->cons_dirty = true;
+        if (mdx_has_constraints(h)) h->cons_dirty = true;
         return MDX_OK;
     }
     const bool keep_list = which == MDX_POS && h->in_slot_space && h->list_valid && !std::isinf(h->r_list);
@@ -1289,7 +1289,7 @@ extern "C" int mdx_upload_range(mdx_handle* h, int which, uint32_t first, uint32
                                hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
         h->list_valid = false; h->forces_valid = false;
-        if (h->n_groups) h->cons_dirty = true;
+        if (mdx_has_constraints(h)) h->cons_dirty = true;
         return MDX_OK;
     }
     // pose update in slot space: ext_orig is free between steps (mdx_step re-installs it), use its head as the stage
@@ -1308,7 +1308,7 @@ extern "C" int mdx_upload_range(mdx_handle* h, int which, uint32_t first, uint32
     h->forces_valid = false;
     h->prune_pending = true; h->moved_outside = true;   // dual list: the path accumulators did not see this move
     if (flag > thr) h->list_valid = false; // moved further than skin/2 from the list's reference: rebuild on next use
-    if (h->n_groups) h->cons_dirty = true;
+    if (mdx_has_constraints(h)) h->cons_dirty = true;
     return MDX_OK;
 }
 
@@ -1449,7 +1449,7 @@ extern "C" int mdx_set_local_atoms(mdx_handle* h, uint32_t n_local, const uint32
                                    int32_t periodic) {
     if (!h || !d_gid || !d_ghost || !d_pos4 || !d_vel4 || !lo || !hi) FAIL(MDX_EPARAM, "null argument");
     if (h->dd) FAIL(MDX_EPARAM, "the handle's decomposition is managed by the library (mdx_comm_init)");
-    if (h->n_groups || h->n_vsites)
+    if (mdx_has_constraints(h) || h->n_vsites)
         FAIL(MDX_EPARAM, "constraints / virtual sites need cluster-wise ownership: use mdx_comm_init, which decides it");
     return mdx_set_local_atoms_impl(h, n_local, d_gid, d_ghost, d_pos4, d_vel4, lo, hi, periodic);
 }

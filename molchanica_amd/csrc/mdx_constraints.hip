@@ -7,7 +7,8 @@
 // (src/properties/sol_shrinking_box.rs:605-613).  The solver itself lives in the absent crate; what
 // is built here (and restated by the oracle):
 //   * constraints are grouped into connected clusters of <= 4 atoms / <= 6 constraints — a rigid
-//     water (O-H, O-H, H-H) or a heavy atom with its hydrogens — one lane per cluster, the whole
+//     water (O-H, O-H, H-H) or a heavy atom with up to three hydrogens — or a heavy atom with FOUR hydrogens (ConsStar5:
+//     ammonium, methane), one lane per cluster, the whole
 //     Gauss-Seidel SHAKE iteration in registers.  Clusters are independent, so there is no
 //     inter-lane traffic and no atomics; a cluster's atoms sit in the same or an adjacent tile.
 //   * position stage after every kick+drift: x(t) is rebuilt as x' - dt v', the SHAKE corrections
@@ -361,6 +362,145 @@ __global__ __launch_bounds__(128) void constrain_velocities_kernel(uint32_t n_gr
     }
 }
 
+// ---- X-H4 stars (ConsStar5): the same SHAKE / RATTLE sweeps over the four bonds of a heavy atom with four hydrogens ---------
+// One lane per star, everything in registers (the bonds are (0, k): compile-time indices).  A record whose atom[0] is
+// MDX_INVALID is not solved here (decomposed handle: the owner of the centre solves the star).
+__global__ __launch_bounds__(128) void constrain_positions_star5_kernel(uint32_t n, const ConsStar5* __restrict__ stars, float4* __restrict__ posq,
+                                                                        float4* __restrict__ vel, float4* __restrict__ ref, float dt, ConsParams p,
+                                                                        float* __restrict__ cons_vir, const uint32_t* gate, uint32_t* disp_out,
+                                                                        uint32_t thr, uint32_t* prune_out, float path_thr) {
+    if (gate && *gate > thr) return;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    float d2max = 0.f, pmax = 0.f;
+    if (g < n) {
+        const ConsStar5 cs = stars[g];
+        if (cs.atom[0] != MDX_INVALID) {
+            float3 xn[5], xo[5], xs[5];
+            float im[5];
+            float4 p0 = make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const float4 pk = posq[cs.atom[k]], vk = vel[cs.atom[k]];
+                if (k == 0) p0 = pk;
+                xn[k] = mimg3(make_float3(pk.x - p0.x, pk.y - p0.y, pk.z - p0.z), p);
+                xo[k] = make_float3(xn[k].x - dt * vk.x, xn[k].y - dt * vk.y, xn[k].z - dt * vk.z);
+                im[k] = vk.w; xs[k] = xn[k];
+            }
+            float wc = 0.f;
+            for (int it = 0; it < p.max_iter; ++it) {
+                bool done = true;
+#pragma unroll
+                for (int b = 1; b < 5; ++b) {
+                    const float3 s = make_float3(xn[0].x - xn[b].x, xn[0].y - xn[b].y, xn[0].z - xn[b].z);
+                    const float l2 = cs.len[b - 1] * cs.len[b - 1];
+                    const float diff = l2 - (s.x * s.x + s.y * s.y + s.z * s.z);
+                    if (fabsf(diff) > 2.0f * p.tol * l2) {
+                        done = false;
+                        const float3 r = make_float3(xo[0].x - xo[b].x, xo[0].y - xo[b].y, xo[0].z - xo[b].z);
+                        const float sr = s.x * r.x + s.y * r.y + s.z * r.z;
+                        const float gk = diff / (2.0f * sr * (im[0] + im[b]));
+                        wc += gk * (r.x * r.x + r.y * r.y + r.z * r.z);
+                        xn[0].x += gk * im[0] * r.x; xn[0].y += gk * im[0] * r.y; xn[0].z += gk * im[0] * r.z;
+                        xn[b].x -= gk * im[b] * r.x; xn[b].y -= gk * im[b] * r.y; xn[b].z -= gk * im[b] * r.z;
+                    }
+                }
+                if (done) break;
+            }
+            const float idt = dt != 0.f ? 1.0f / dt : 0.f;
+            if (cons_vir) cons_vir[g] = p.vir_scale * wc * idt * idt;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const float3 dx = make_float3(xn[k].x - xs[k].x, xn[k].y - xs[k].y, xn[k].z - xs[k].z);
+                if (dx.x != 0.f || dx.y != 0.f || dx.z != 0.f) {
+                    float4 pk = posq[cs.atom[k]], vk = vel[cs.atom[k]];
+                    pk.x += dx.x; pk.y += dx.y; pk.z += dx.z;
+                    vk.x += dx.x * idt; vk.y += dx.y * idt; vk.z += dx.z * idt;
+                    posq[cs.atom[k]] = pk; vel[cs.atom[k]] = vk;
+                    const float4 r = ref[cs.atom[k]];
+                    const float ex = pk.x - r.x, ey = pk.y - r.y, ez = pk.z - r.z;
+                    d2max = fmaxf(d2max, ex * ex + ey * ey + ez * ez);
+                    if (prune_out) {
+                        const float w = r.w + sqrtf(dx.x * dx.x + dx.y * dx.y + dx.z * dx.z);
+                        ref[cs.atom[k]].w = w;
+                        pmax = fmaxf(pmax, w);
+                    }
+                }
+            }
+        } else if (cons_vir) cons_vir[g] = 0.f;
+    }
+    if (disp_out) {
+        if (!(d2max < 1.0e30f)) d2max = 3.0e38f;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) d2max = fmaxf(d2max, __shfl_xor(d2max, m));
+        if ((threadIdx.x & 63) == 0 && __float_as_uint(d2max) > thr) atomicMax(disp_out, __float_as_uint(d2max));
+    }
+    if (prune_out) {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, m));
+        if ((threadIdx.x & 63) == 0 && !(pmax <= path_thr)) *prune_out = 1u;
+    }
+}
+
+__global__ __launch_bounds__(128) void constrain_velocities_star5_kernel(uint32_t n, const ConsStar5* __restrict__ stars, const float4* __restrict__ posq,
+                                                                         float4* __restrict__ vel, ConsParams p, const uint32_t* gate, uint32_t thr) {
+    if (gate && *gate > thr) return;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const ConsStar5 cs = stars[g];
+    if (cs.atom[0] == MDX_INVALID) return;
+    float3 x[5], v[5], v0[5];
+    float im[5];
+    float4 p0 = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float4 pk = posq[cs.atom[k]], vk = vel[cs.atom[k]];
+        if (k == 0) p0 = pk;
+        x[k] = mimg3(make_float3(pk.x - p0.x, pk.y - p0.y, pk.z - p0.z), p);
+        v[k] = make_float3(vk.x, vk.y, vk.z); v0[k] = v[k]; im[k] = vk.w;
+    }
+    for (int it = 0; it < p.max_iter; ++it) {
+        bool done = true;
+#pragma unroll
+        for (int b = 1; b < 5; ++b) {
+            const float3 s = make_float3(x[0].x - x[b].x, x[0].y - x[b].y, x[0].z - x[b].z);
+            const float3 w = make_float3(v[0].x - v[b].x, v[0].y - v[b].y, v[0].z - v[b].z);
+            const float dot = s.x * w.x + s.y * w.y + s.z * w.z;
+            const float l2 = cs.len[b - 1] * cs.len[b - 1];
+            if (fabsf(dot) > p.tol * l2 * 10.0f) {
+                done = false;
+                const float gk = dot / (l2 * (im[0] + im[b]));
+                v[0].x -= gk * im[0] * s.x; v[0].y -= gk * im[0] * s.y; v[0].z -= gk * im[0] * s.z;
+                v[b].x += gk * im[b] * s.x; v[b].y += gk * im[b] * s.y; v[b].z += gk * im[b] * s.z;
+            }
+        }
+        if (done) break;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        if (v[k].x != v0[k].x || v[k].y != v0[k].y || v[k].z != v0[k].z) {
+            float4 vk = vel[cs.atom[k]];
+            vk.x = v[k].x; vk.y = v[k].y; vk.z = v[k].z;
+            vel[cs.atom[k]] = vk;
+        }
+}
+
+__global__ void remap_star5_kernel(uint32_t n, const ConsStar5* __restrict__ so, const uint32_t* __restrict__ slot_of, ConsStar5* __restrict__ ss,
+                                   uint32_t* err, const uint8_t* __restrict__ slot_flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ConsStar5 g = so[i];
+    if (slot_flags) {      // decomposed handle: the star is solved by the rank that owns its centre
+        const uint32_t s0 = slot_of[g.atom[0]];
+        if (s0 == MDX_INVALID || !(slot_flags[s0] & 2u)) { g.atom[0] = MDX_INVALID; ss[i] = g; return; }
+    }
+    for (int k = 0; k < 5; ++k) {
+        const uint32_t s = slot_of[g.atom[k]];
+        if (s == MDX_INVALID) atomicOr(err, 8u);
+        g.atom[k] = s;
+    }
+    ss[i] = g;
+}
+
 // ---- virtual sites -----------------------------------------------------------------------------------
 __global__ void vsite_construct_kernel(uint32_t n, const VSite* __restrict__ vs, float4* __restrict__ posq, ConsParams p,
                                        const uint32_t* gate, uint32_t thr) {
@@ -480,7 +620,7 @@ static ConsParams cons_params(const mdx_handle* h) {
 
 int mdx_build_constraints(mdx_handle* h, const mdx_system* s) {
     const uint32_t N = s->n_atoms;
-    h->n_cons = s->n_constraints; h->n_vsites = s->n_vsites; h->n_groups = 0;
+    h->n_cons = s->n_constraints; h->n_vsites = s->n_vsites; h->n_groups = 0; h->n_star5 = 0; h->h_star5.clear();
     hipStream_t st = h->stream;
     if (s->n_constraints) {
         if (!s->constraint_idx || !s->constraint_len) FAIL(MDX_EPARAM, "missing constraint arrays");
@@ -495,11 +635,47 @@ int mdx_build_constraints(mdx_handle* h, const mdx_system* s) {
             if (fa && fb) FAIL(MDX_EPARAM, "constraint between two immobile atoms");
             parent[find(a)] = find(b);
         }
+        // cluster sizes; a cluster of five atoms must be a star of four bonds (X-H4) and gets its own record
+        std::vector<uint32_t> csize(N, 0);
+        for (uint32_t i = 0; i < N; ++i) csize[find(i)]++;
+        std::vector<int> star_of(N, -1);
+        std::vector<ConsStar5> stars;
+        for (uint32_t c = 0; c < s->n_constraints; ++c) {
+            const uint32_t a = s->constraint_idx[2 * c], b = s->constraint_idx[2 * c + 1];
+            const uint32_t root = find(a);
+            if (csize[root] > 5) FAIL(MDX_EPARAM, "constraint cluster larger than 5 atoms (only rigid waters and heavy atoms with up to four hydrogens)");
+            if (csize[root] != 5) continue;
+            if (star_of[root] < 0) {
+                star_of[root] = (int)stars.size();
+                ConsStar5 st{};
+                for (int k = 0; k < 5; ++k) st.atom[k] = MDX_INVALID;
+                st.pad[0] = 0;      // bonds filed so far
+                stars.push_back(st);
+            }
+            ConsStar5& st = stars[star_of[root]];
+            const uint32_t nb = st.pad[0];
+            if (nb == 0) { st.atom[0] = a; st.atom[1] = b; st.len[0] = s->constraint_len[c]; st.pad[0] = 1; continue; }
+            if (nb == 1 && st.atom[0] != a && st.atom[0] != b) {      // the centre is the atom the first two bonds share
+                if (st.atom[1] == a || st.atom[1] == b) std::swap(st.atom[0], st.atom[1]);
+            }
+            const uint32_t leaf = st.atom[0] == a ? b : (st.atom[0] == b ? a : MDX_INVALID);
+            bool dup = false;
+            for (uint32_t k = 1; k <= nb; ++k) dup = dup || st.atom[k] == leaf;
+            if (leaf == MDX_INVALID || nb >= 4 || dup)
+                FAIL(MDX_EPARAM, "a constraint cluster of five atoms must be a heavy atom with four constrained hydrogens (four bonds from one centre)");
+            st.atom[nb + 1] = leaf; st.len[nb] = s->constraint_len[c]; st.pad[0] = nb + 1;
+        }
+        for (ConsStar5& st : stars) {
+            if (st.pad[0] != 4) FAIL(MDX_EPARAM, "a constraint cluster of five atoms must be a heavy atom with four constrained hydrogens (four bonds from one centre)");
+            st.pad[0] = 0;
+        }
+        h->n_star5 = (uint32_t)stars.size(); h->h_star5 = stars;
         std::vector<int> gid(N, -1);
         std::vector<ConsGroup> groups;
         for (uint32_t c = 0; c < s->n_constraints; ++c) {
             const uint32_t a = s->constraint_idx[2 * c], b = s->constraint_idx[2 * c + 1];
             const uint32_t root = find(a);
+            if (csize[root] == 5) continue;
             if (gid[root] < 0) {
                 gid[root] = (int)groups.size();
                 ConsGroup g{};
@@ -515,7 +691,7 @@ int mdx_build_constraints(mdx_handle* h, const mdx_system* s) {
             };
             const int la = local(a), lb = local(b);
             if (la < 0 || lb < 0 || g.ncons >= 6)
-                FAIL(MDX_EPARAM, "constraint cluster larger than 4 atoms / 6 constraints (only X-H and rigid-water clusters)");
+                FAIL(MDX_EPARAM, "constraint cluster of up to 4 atoms with more than 6 constraints");
             g.ca[g.ncons] = (uint8_t)la; g.cb[g.ncons] = (uint8_t)lb; g.len[g.ncons] = s->constraint_len[c];
             g.ncons++;
         }
@@ -540,14 +716,19 @@ int mdx_build_constraints(mdx_handle* h, const mdx_system* s) {
             }
             if (!ok) { h->cons_all_rigid3 = false; break; }
         }
-        if (h->d.cons_o) (void)hipFree(h->d.cons_o);
-        if (h->d.cons_s) (void)hipFree(h->d.cons_s);
-        HIP_TRY(hipMalloc((void**)&h->d.cons_o, sizeof(ConsGroup) * groups.size()));
-        HIP_TRY(hipMalloc((void**)&h->d.cons_s, sizeof(ConsGroup) * groups.size()));
-        if (h->d.cons_vir) (void)hipFree(h->d.cons_vir);
-        HIP_TRY(hipMalloc((void**)&h->d.cons_vir, sizeof(float) * groups.size()));
-        HIP_TRY(hipMemsetAsync(h->d.cons_vir, 0, sizeof(float) * groups.size(), st));
-        HIP_TRY(hipMemcpyAsync(h->d.cons_o, groups.data(), sizeof(ConsGroup) * groups.size(), hipMemcpyHostToDevice, st));
+        for (void** q : {(void**)&h->d.cons_o, (void**)&h->d.cons_s, (void**)&h->d.cons_vir, (void**)&h->d.star_o, (void**)&h->d.star_s})
+            if (*q) { (void)hipFree(*q); *q = nullptr; }
+        const size_t n_all = groups.size() + stars.size();
+        HIP_TRY(hipMalloc((void**)&h->d.cons_o, std::max<size_t>(sizeof(ConsGroup) * groups.size(), 16)));
+        HIP_TRY(hipMalloc((void**)&h->d.cons_s, std::max<size_t>(sizeof(ConsGroup) * groups.size(), 16)));
+        HIP_TRY(hipMalloc((void**)&h->d.cons_vir, sizeof(float) * n_all));
+        HIP_TRY(hipMemsetAsync(h->d.cons_vir, 0, sizeof(float) * n_all, st));
+        if (!groups.empty()) HIP_TRY(hipMemcpyAsync(h->d.cons_o, groups.data(), sizeof(ConsGroup) * groups.size(), hipMemcpyHostToDevice, st));
+        if (!stars.empty()) {
+            HIP_TRY(hipMalloc((void**)&h->d.star_o, sizeof(ConsStar5) * stars.size()));
+            HIP_TRY(hipMalloc((void**)&h->d.star_s, sizeof(ConsStar5) * stars.size()));
+            HIP_TRY(hipMemcpyAsync(h->d.star_o, stars.data(), sizeof(ConsStar5) * stars.size(), hipMemcpyHostToDevice, st));
+        }
         HIP_TRY(hipStreamSynchronize(st));
     }
     if (s->n_vsites) {
@@ -641,6 +822,8 @@ int mdx_remap_constraints(mdx_handle* h) {
                            d.cons_o, d.slot_of, d.cons_s, d.flags_dev, sf, (unsigned long long*)nullptr, (const GroupSite*)d.gsite_o, d.gsite_s);
         d.cons_n_dev = nullptr;
     }
+    if (h->n_star5)
+        hipLaunchKernelGGL(remap_star5_kernel, dim3(div_up(h->n_star5, 256)), dim3(256), 0, h->stream, h->n_star5, d.star_o, d.slot_of, d.star_s, d.flags_dev, sf);
     if (h->n_vsites)
         hipLaunchKernelGGL(remap_vsites_kernel, dim3(div_up(h->n_vsites, 256)), dim3(256), 0, h->stream, h->n_vsites,
                            h->d.vsite_o, h->d.slot_of, h->d.vsite_s, h->d.flags_dev, (h->dd || h->n_local != h->N) ? h->d.slot_flags : nullptr);
@@ -650,10 +833,15 @@ int mdx_remap_constraints(mdx_handle* h) {
 
 int mdx_launch_constrain_positions(mdx_handle* h, float dt, const uint32_t* d_gate, uint32_t* d_disp_out, uint32_t thr,
                                    uint32_t* d_prune_out) {
-    if (!h->n_groups) return MDX_OK;
+    if (!mdx_has_constraints(h)) return MDX_OK;
     if (!h->dual_on) d_prune_out = nullptr;
     ConsParams cp = cons_params(h);
     cp.vir_scale = h->cons_full_kick ? 1.0f : 2.0f;
+    if (h->n_star5)
+        hipLaunchKernelGGL(constrain_positions_star5_kernel, dim3(div_up(h->n_star5, 128)), dim3(128), 0, h->stream, h->n_star5, h->d.star_s, h->d.posq,
+                           h->d.vel, h->d.ref, dt, cp, dt != 0.f ? h->d.cons_vir + h->n_groups : nullptr, d_gate, d_disp_out, thr, d_prune_out,
+                           0.5f * h->inner_skin * (1.0f - 1.0e-4f));
+    if (!h->n_groups) { HIP_TRY(hipGetLastError()); return MDX_OK; }
     // (MDX_CONS_RIGID3=0: the general flavour for every handle, A/B)
     static const bool rigid3_env = [] { const char* e = std::getenv("MDX_CONS_RIGID3"); return !(e && e[0] == '0'); }();
     auto kern = (h->cons_all_rigid3 && rigid3_env) ? constrain_positions_kernel<true> : constrain_positions_kernel<false>;
@@ -678,7 +866,11 @@ __global__ __launch_bounds__(256) void constraint_virial_kernel(uint32_t n, cons
 }
 
 int mdx_launch_constraint_virial(mdx_handle* h) {
-    if (!h->n_groups || !h->d.cons_vir) return MDX_OK;
+    if (!mdx_has_constraints(h) || !h->d.cons_vir) return MDX_OK;
+    if (h->n_star5)
+        hipLaunchKernelGGL(constraint_virial_kernel, dim3(std::min<uint32_t>(div_up(h->n_star5, 256), 256u)), dim3(256), 0, h->stream,
+                           h->n_star5, h->d.cons_vir + h->n_groups, h->d.energy, (const uint32_t*)nullptr);
+    if (!h->n_groups) { HIP_TRY(hipGetLastError()); return MDX_OK; }
     hipLaunchKernelGGL(constraint_virial_kernel, dim3(std::min<uint32_t>(div_up(h->n_groups, 256), 256u)), dim3(256), 0, h->stream,
                        h->n_groups, h->d.cons_vir, h->d.energy, h->d.cons_n_dev);
     HIP_TRY(hipGetLastError());
@@ -686,7 +878,11 @@ int mdx_launch_constraint_virial(mdx_handle* h) {
 }
 
 int mdx_launch_constrain_velocities(mdx_handle* h, const uint32_t* d_gate, uint32_t thr) {
-    if (!h->n_groups) return MDX_OK;
+    if (!mdx_has_constraints(h)) return MDX_OK;
+    if (h->n_star5)
+        hipLaunchKernelGGL(constrain_velocities_star5_kernel, dim3(div_up(h->n_star5, 128)), dim3(128), 0, h->stream, h->n_star5, h->d.star_s,
+                           h->d.posq, h->d.vel, cons_params(h), d_gate, thr);
+    if (!h->n_groups) { HIP_TRY(hipGetLastError()); return MDX_OK; }
     static const bool rigid3_env = [] { const char* e = std::getenv("MDX_CONS_RIGID3"); return !(e && e[0] == '0'); }();
     auto kern = (h->cons_all_rigid3 && rigid3_env) ? constrain_velocities_kernel<true> : constrain_velocities_kernel<false>;
     hipLaunchKernelGGL(kern, dim3(div_up(h->n_groups, 128)), dim3(128), 0, h->stream, h->n_groups,
@@ -717,7 +913,7 @@ int mdx_launch_vsite_spread(mdx_handle* h, const uint32_t* d_gate, uint32_t thr)
 extern "C" int mdx_set_hydrogen_constraint(mdx_handle* h, int kind, uint32_t lincs_order, uint32_t lincs_iter, float shake_tolerance) {
     if (!h) { mdx_set_error("null handle"); return MDX_EPARAM; }
     if (kind == MDX_HC_FLEXIBLE) {
-        if (h->n_groups) { mdx_set_error("HydrogenConstraint::Flexible on a system created with constraints: build it without them"); return MDX_EPARAM; }
+        if (mdx_has_constraints(h)) { mdx_set_error("HydrogenConstraint::Flexible on a system created with constraints: build it without them"); return MDX_EPARAM; }
         h->hc_kind = kind; return MDX_OK;
     }
     if (kind == MDX_HC_SHAKE) {
@@ -739,13 +935,13 @@ extern "C" const char* mdx_constraint_description(mdx_handle* h) {
     if (!h) return "";
     char buf[384];
     const float tol = h->cfg.constraint_tol > 0.f ? h->cfg.constraint_tol : 1e-5f;
-    if (!h->n_groups) std::snprintf(buf, sizeof(buf), "no constraints (flexible)");
+    if (!mdx_has_constraints(h)) std::snprintf(buf, sizeof(buf), "no constraints (flexible)");
     else if (h->hc_kind == MDX_HC_LINEAR)
         std::snprintf(buf, sizeof(buf), "Linear{order %u, iter %u} mapped onto the converged cluster solver: %u clusters, SHAKE + RATTLE in registers to a relative "
                       "tolerance of %.1e (rigid three-site waters in closed form, SETTLE); LINCS at these settings would leave ~%.0e",
-                      h->hc_order, h->hc_iter, h->n_groups, (double)tol, std::pow(10.0, -(0.5 * h->hc_order + h->hc_iter + 1.0)));
+                      h->hc_order, h->hc_iter, h->n_groups + h->n_star5, (double)tol, std::pow(10.0, -(0.5 * h->hc_order + h->hc_iter + 1.0)));
     else std::snprintf(buf, sizeof(buf), "Shake: %u clusters, SHAKE + RATTLE in registers to a relative tolerance of %.1e (rigid three-site waters in closed form, SETTLE)",
-                       h->n_groups, (double)tol);
+                       h->n_groups + h->n_star5, (double)tol);
     h->hc_text = buf;
     return h->hc_text.c_str();
 }

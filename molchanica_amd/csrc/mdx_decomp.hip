@@ -927,6 +927,8 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
         for (int k = 0; k < 4; ++k) for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) dist[a][b] = std::min(dist[a][b], dist[a][k] + dist[k][b]);
         for (uint32_t k = 0; k < g.natoms; ++k) { anchor[g.atom[k]] = g.atom[0]; if (dist[0][k] < 1e29) ext = std::max(ext, dist[0][k]); }
     }
+    for (const auto& st : h->h_star5)      // X-H4: the centre anchors its hydrogens
+        for (int k = 1; k < 5; ++k) { anchor[st.atom[k]] = st.atom[0]; ext = std::max(ext, (double)st.len[k - 1]); }
     for (const auto& v : h->h_vsites) {   // a site follows its first parent (inside the parents' triangle: no extra reach)
         const uint32_t a = anchor[v.p0];
         anchor[v.site] = a; anchor[v.p1] = a; anchor[v.p2] = a;

@@ -203,7 +203,7 @@ static int apply_barostat(mdx_handle* h, double dt_couple) {
     MDX_TRY(mdx_check_box(h, h->box_lo, hi));   // refuse BEFORE touching the state (box < 2 (rc + skin): stop, cf. sol_shrinking_box.rs guards)
     if (h->dd) {      // decomposed: the same mu on every rank (the pressure is all-reduced); scale the gathered state, repartition
         MDX_TRY(mdx_dd_rescale_box(h, hi, (float)mu));
-        if (h->n_groups) h->cons_dirty = true;
+        if (mdx_has_constraints(h)) h->cons_dirty = true;
         h->last_pressure = e.pressure; h->last_mu = mu;
         return MDX_OK;
     }
@@ -213,7 +213,7 @@ static int apply_barostat(mdx_handle* h, double dt_couple) {
                        h->d.pos_orig, h->box_lo[0], h->box_lo[1], h->box_lo[2], (float)mu);
     HIP_TRY(hipGetLastError());
     MDX_TRY(mdx_set_box(h, h->box_lo, hi));
-    if (h->n_groups) h->cons_dirty = true;   // bonds of constrained clusters were scaled too: project back
+    if (mdx_has_constraints(h)) h->cons_dirty = true;   // bonds of constrained clusters were scaled too: project back
     h->last_pressure = e.pressure; h->last_mu = mu;
     return MDX_OK;
 }
@@ -258,7 +258,7 @@ extern "C" int mdx_shrink_cell_towards(mdx_handle* h, const float target_lo[3], 
             if (hi[d] - lo[d] < 2.0f * h->r_list) FAIL(MDX_EPARAM, "box edge shorter than 2*(cutoff+skin): minimum image is not unique");
         h->e_cache_valid = false; h->e_pending = false;
         MDX_TRY(mdx_dd_set_box(h, lo, hi, c, mu));
-        if (h->n_groups) h->cons_dirty = true;
+        if (mdx_has_constraints(h)) h->cons_dirty = true;
         return MDX_OK;
     }
     MDX_TRY(mdx_check_box(h, lo, hi));   // refuse BEFORE touching the state (an edge below 2 (rc + skin))
@@ -268,7 +268,7 @@ extern "C" int mdx_shrink_cell_towards(mdx_handle* h, const float target_lo[3], 
                        h->d.pos_orig, c[0], c[1], c[2], mu[0], mu[1], mu[2]);
     HIP_TRY(hipGetLastError());
     MDX_TRY(mdx_set_box(h, lo, hi));
-    if (h->n_groups) h->cons_dirty = true;   // constrained bonds were scaled too: project back
+    if (mdx_has_constraints(h)) h->cons_dirty = true;   // constrained bonds were scaled too: project back
     return MDX_OK;
 }
 
@@ -719,7 +719,7 @@ extern "C" int mdx_minimize_energy(mdx_handle* h, uint32_t max_iters, const floa
             h->list_valid = false;
             if (dd) { rc = mdx_dd_on_stale(h); if (rc != MDX_OK) return done(rc); }
         }
-        if (h->n_groups) {                           // keep constrained bonds at their length
+        if (mdx_has_constraints(h)) {                           // keep constrained bonds at their length
             if (!h->list_valid) { rc = mdx_rebuild(h); if (rc != MDX_OK) return done(rc); }
             rc = mdx_launch_constrain_positions(h, 0.f, nullptr, nullptr, 0);
             if (rc != MDX_OK) return done(rc);

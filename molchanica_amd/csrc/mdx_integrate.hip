@@ -271,7 +271,7 @@ bool mdx_bonded_integrate_ok(const mdx_handle* h) {
     const bool dd_ok = dd_env && h->dd != nullptr;
     // (n_roles counts the whole system; a decomposed handle holds n_local of its N atoms)
     const double roles_here = (double)h->n_roles * ((h->n_local != h->N && h->N) ? (double)h->n_local / (double)h->N : 1.0);
-    return on && mdx_nb_variant(h) >= 2 && h->integrator == MDX_INTEGRATOR_VERLET_VELOCITY && h->n_groups == 0 && h->n_vsites == 0 &&
+    return on && mdx_nb_variant(h) >= 2 && h->integrator == MDX_INTEGRATOR_VERLET_VELOCITY && !mdx_has_constraints(h) && h->n_vsites == 0 &&
            !h->pme_on && !h->have_ext && (dd_ok || (!h->dd && h->n_local == h->N)) && !h->alch_on && mdx_bonded_wanted(h) && h->T >= mdx_wpt8_below(h) &&
            roles_here < 2.6 * (double)h->S && h->d.posq_alt != nullptr;
 }

@@ -131,6 +131,11 @@ struct __attribute__((aligned(16))) ConsGroup {
     uint8_t  ca[6], cb[6]; // constraint k ties local atoms ca[k], cb[k]
     uint32_t ncons, natoms;
 };
+// A heavy atom with FOUR constrained hydrogens (ammonium, methane, silane ...: X-H4) - the one cluster shape beyond four atoms that
+// "constrain the bonds to hydrogens" (HydrogenConstraint, /root/reference src/ui/panels/md.rs:362-371) produces: a star, atom[0] its
+// centre, len[k] the length of the bond to atom[k + 1].  Its own record and its own small kernels: the 64-byte ConsGroup that a
+// million rigid waters stream through SETTLE stays as it is.
+struct __attribute__((aligned(16))) ConsStar5 { uint32_t atom[5]; float len[4]; uint32_t pad[3]; };
 // The virtual site of a constraint cluster whose three parents are all members of the cluster (the M site of a rigid four-site
 // water): the position stage of the constraint solver places it (mdx_constraints.hip) - no launch of its own.
 struct __attribute__((aligned(16))) GroupSite {
@@ -211,7 +216,8 @@ struct DeviceState {
     // clusters in slot order (mdx_remap_constraints): staging copy, leaders per tile (a bit per slot), their counts and offsets
     ConsGroup* cons_tmp = nullptr; unsigned long long* cons_mask = nullptr; uint32_t* cons_cnt = nullptr; uint32_t* cons_off = nullptr;
     uint32_t cons_cap_tiles = 0; const uint32_t* cons_n_dev = nullptr;     // cons_n_dev: clusters this handle solves (device word), null = n_groups
-    float* cons_vir = nullptr;     // per constraint cluster: r . G of the last SHAKE position stage (kcal/mol)
+    float* cons_vir = nullptr;     // per constraint cluster: r . G of the last SHAKE position stage (kcal/mol); the X-H4 stars behind the others
+    ConsStar5* star_o = nullptr; ConsStar5* star_s = nullptr;
     VSite* vsite_o = nullptr; VSite* vsite_s = nullptr;
     GroupSite* gsite_o = nullptr; GroupSite* gsite_s = nullptr; GroupSite* gsite_tmp = nullptr;   // per constraint cluster (null: no cluster carries its site)
     // control / reductions
@@ -258,7 +264,8 @@ struct mdx_handle {
     float box_lo[3]{}, box_hi[3]{};
     uint32_t n_bonds = 0, n_angles = 0, n_dih = 0, n_p14 = 0;
     uint32_t n_roles = 0;
-    uint32_t n_groups = 0, n_cons = 0, n_vsites = 0;   // constraint clusters / constraints / virtual sites
+    uint32_t n_groups = 0, n_cons = 0, n_vsites = 0;   // constraint clusters of up to four atoms / constraints / virtual sites
+    uint32_t n_star5 = 0; std::vector<ConsStar5> h_star5;   // X-H4 clusters (caller order)
     bool cons_all_rigid3 = false;    // every constraint cluster is a rigid three-site water: the solvers' register-only flavour
     bool vsites_in_groups = false;   // every virtual site is placed by its parents' constraint cluster (GroupSite)
     bool vsites_fresh = false;       // ... and the last position stage did so: the next force call has nothing to construct
@@ -491,6 +498,7 @@ int mdx_groups_evaluate(mdx_handle* h, float* out /* [n_grp^2] */);   // energy_
 int mdx_launch_scale_velocities(mdx_handle* h, float lambda, const double* com_v_or_null);
 int mdx_launch_momentum(mdx_handle* h);                           // energy[EN_COUNT+1..] <- sum m v (3 doubles) + mass
 
+static inline bool mdx_has_constraints(const mdx_handle* h) { return h->n_groups != 0 || h->n_star5 != 0; }
 // degrees of freedom: 3 per mobile atom, minus constraints, minus the centre of mass
 static inline double mdx_dof(const mdx_handle* h) {
     const double d = 3.0 * (double)h->n_mobile - (double)h->n_cons - 3.0;

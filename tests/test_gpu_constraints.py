@@ -283,3 +283,101 @@ def test_oversized_constraint_cluster_is_rejected(mdx):
     s.constraint_len = s.bond_r0[:12].copy()
     with pytest.raises(mdx.ParamError, match="cluster"):
         mdx.MdState(s, MdConfig(lj_cutoff=0, coulomb_cutoff=0))
+
+
+def _ammonium_in_water(n_side=12, n_ions=10, spacing=3.1034, seed=12):
+    """n_ions NH4+ (all four N-H bonds constrained: a cluster of five atoms, the X-H4 star) among rigid TIP3P waters
+    (three-atom clusters solved in closed form): `HydrogenConstraint` constrains "the hydrogens", whatever the heavy atom
+    carries (/root/reference src/ui/panels/md.rs:362-371)."""
+    from molchanica_amd._abi import MdSystem
+    from molchanica_amd import topology as topo
+    rng = np.random.default_rng(seed)
+    g = (np.arange(n_side) + 0.5) * spacing
+    sites = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    pick = np.sort(rng.choice(len(sites), size=n_ions, replace=False))
+    ion_sites = sites[pick]
+    wat_sites = np.delete(sites, pick, axis=0)
+    w = len(wat_sites)
+    t = 1.0 / math.sqrt(3.0)
+    tet = 1.01 * np.array([[t, t, t], [t, -t, -t], [-t, t, -t], [-t, -t, t]])
+    rot = systems._random_rotations(n_ions, rng)
+    ip = np.empty((n_ions, 5, 3))
+    ip[:, 0] = ion_sites
+    ip[:, 1:] = ion_sites[:, None, :] + np.einsum("mij,kj->mki", rot, tet)
+    wp = systems._water_atoms(wat_sites, rng, 0.0)
+    pos = np.concatenate([ip.reshape(-1, 3), wp])
+    n_i = 5 * n_ions
+    c = 5 * np.arange(n_ions)
+    nh = np.stack([np.repeat(c, 4), (c[:, None] + np.arange(1, 5)).ravel()], 1)
+    angles = np.array([[c0 + a, c0, c0 + b] for c0 in c for a in range(1, 5) for b in range(a + 1, 5)])
+    o = n_i + 3 * np.arange(w)
+    tp = systems.TIP3P
+    hh = 2 * tp["r_oh"] * math.sin(tp["theta"] / 2)
+    wcons = np.stack([np.stack([o, o + 1], 1), np.stack([o, o + 2], 1), np.stack([o + 1, o + 2], 1)], 1).reshape(-1, 2)
+    cons = np.concatenate([nh, wcons])
+    clen = np.concatenate([np.full(len(nh), 1.01), np.tile([tp["r_oh"], tp["r_oh"], hh], w)])
+    pairs = np.concatenate([nh, angles[:, [0, 2]], wcons])
+    off, idx = topo.csr_from_pairs(len(pos), pairs)
+    mass = np.concatenate([np.tile([14.007, 1.008, 1.008, 1.008, 1.008], n_ions), np.tile([tp["m_o"], tp["m_h"], tp["m_h"]], w)]).astype(np.float32)
+    box = n_side * spacing
+    return MdSystem(
+        pos=pos, mass=mass, charge=np.concatenate([np.tile([-0.4, 0.35, 0.35, 0.35, 0.35], n_ions), np.tile([tp["q_o"], tp["q_h"], tp["q_h"]], w)]),
+        lj_type=np.concatenate([np.tile([2, 1, 1, 1, 1], n_ions), np.tile([0, 1, 1], w)]),
+        lj_sigma=[tp["o_sigma"], 0.0, 3.25], lj_eps=[tp["o_eps"], 0.0, 0.17],
+        vel=systems.maxwell_boltzmann(mass, 300.0, np.random.default_rng(seed + 1)),
+        angle_idx=angles, angle_k=np.full(len(angles), 40.0), angle_theta0=np.full(len(angles), math.radians(109.47)),
+        excl_offsets=off, excl_idx=idx, mol_start=np.concatenate([c, o]), constraint_idx=cons, constraint_len=clen,
+        periodic=True, box_lo=(0, 0, 0), box_hi=(box, box, box), name="ammonium_in_water",
+    ).normalise()
+
+
+def test_ammonium_in_water_five_atom_clusters_at_2fs(mdx, orc):
+    """X-H4 clusters (five atoms, four bonds from one centre) beside rigid waters at dt = 2 fs: SHAKE keeps every bond within the
+    tolerance, RATTLE leaves no velocity along a bond, the trajectory follows the oracle's (generic iterative SHAKE / RATTLE in
+    fp64) and a run on two ranks - a star is owned by the rank of its nitrogen - follows the single-GPU one."""
+    from tests.test_gpu_comm import run_ranks, rms_dev
+    s = _ammonium_in_water()
+    cfg = MdConfig(lj_cutoff=6.5, coulomb_cutoff=6.5, skin=1.0, coulomb_mode=1, chunk_steps=8)
+    L = np.array(s.box_hi)
+    with mdx.MdState(s, cfg) as md:
+        assert "clusters" in md.set_hydrogen_constraint("shake")
+        md.minimize_energy(60)
+        md.initialize_velocities(300.0, True, seed=4)
+        md.forces()
+        x0, v0 = md.positions().astype(np.float64), md.velocities().astype(np.float64)
+        assert bond_errors(s, x0).max() < 3e-5
+        md.step(0.002, None, 30)
+        x, v = md.positions().astype(np.float64), md.velocities().astype(np.float64)
+        assert bond_errors(s, x).max() < 3e-5, "a constrained bond left the tolerance"
+        b = s.constraint_idx.astype(int)
+        d = x[b[:, 0]] - x[b[:, 1]]
+        d -= np.round(d / L) * L
+        assert np.abs((d * (v[b[:, 0]] - v[b[:, 1]])).sum(1)).max() < 5e-3, "velocity along a constrained bond"
+        e = md.energy()
+        assert np.isfinite(e["pressure"]) and np.isfinite(e["virial"])
+    xo, vo, _ = orc.step(s, cfg, 0.002, 30, pos=x0, vel=v0, use_cells=True)
+    dd = x - xo
+    dd -= np.round(dd / L) * L
+    ions = slice(0, 5 * 10)
+    assert math.sqrt((dd ** 2).sum(1).mean()) < 2e-3
+    assert math.sqrt((dd[ions] ** 2).sum(1).mean()) < 2e-3, "the ammonium ions leave the oracle's trajectory"
+    import dataclasses
+    s2 = dataclasses.replace(s, pos=x0.astype(np.float32), vel=v0.astype(np.float32))
+    with mdx.MdState(s2, cfg) as md:
+        md.step(0.002, None, 20)
+        p1 = md.positions()
+    res = run_ranks(s2, cfg, 2, 20, dt=0.002)
+    assert rms_dev(res[0]["pos"], p1, L) < 5e-4
+    assert bond_errors(s, res[0]["pos"].astype(np.float64)).max() < 3e-5
+
+
+def test_five_atom_cluster_that_is_not_a_star_is_rejected(mdx):
+    s = systems.lig50()
+    s.constraint_idx = s.bond_idx[:4].copy()        # the first four bonds of the generator's tree
+    s.constraint_len = s.bond_r0[:4].copy()
+    import collections
+    deg = collections.Counter(s.constraint_idx.ravel().tolist())
+    if max(deg.values()) == 4 and len(deg) == 5:
+        pytest.skip("the generator's first four bonds happen to form a star")
+    with pytest.raises(mdx.ParamError, match="cluster"):
+        mdx.MdState(s, MdConfig(lj_cutoff=0, coulomb_cutoff=0))
