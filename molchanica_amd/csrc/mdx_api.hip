@@ -733,10 +733,12 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         h->e_cache_valid = false; h->e_pending = false;
         const size_t e_bytes = sizeof(double) * (EN_COUNT + 8 + MDX_ESTRIDE * MDX_EPART);
         float4* pos_after[MDX_MAX_CHUNK + 1];      // the buffer that holds the positions after step s's drift
+        const bool pipe_chunk = fuse_bi && mdx_dd_fold_eligible(h);      // decomposed handle: the fused pass also packs the halo and adds the returned ghost forces
         for (uint32_t s = 0; s < chunk; ++s) {
             h->prof_tag = (int)s;
             h->lang_step = h->step_count + s;
             const int mode = !vv ? (integ == MDX_INTEGRATOR_LANGEVIN_MIDDLE ? 3 : 1) : ((s == 0 || !fused) ? 0 : 1);
+            if (h->dd) h->dd->pipe_now = pipe_chunk && mode == 1 && !(want_e && s + 1 == chunk);
             if (fuse_bi && mode == 1) MDX_TRY(mdx_launch_bonded_integrate(h, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
             else MDX_TRY(mdx_launch_integrate(h, mode, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
             pos_after[s] = d.posq;
@@ -766,7 +768,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
             MDX_TRY(mdx_launch_constrain_velocities(h, &d.ctl->disp2[chunk], thr));     // (no-op without constraints)
         }
         h->prof_tag = -1;
-        if (h->dd) h->chunk_s = -1;
+        if (h->dd) { h->chunk_s = -1; mdx_dd_pipe_chunk_end(h); }
         // MDX_DEBUG_HOST=1: where the host spends a chunk - enqueueing it, or waiting for the device to finish it
         static const bool dbg_host = [] { const char* e = std::getenv("MDX_DEBUG_HOST"); return e && e[0] == '1'; }();
         const auto t_enq = std::chrono::steady_clock::now();

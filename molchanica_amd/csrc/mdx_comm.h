@@ -27,6 +27,10 @@ struct MdxTransport {
     virtual int all_gather_u32(uint32_t mine, uint32_t* all, hipStream_t stream) = 0;
     virtual const char* name() const = 0;
     virtual bool delivers() const { return true; }   // false: the null transport (peers' rows never arrive)
+    // the null transport with MDX_NULL_WIRE_US set: every send/recv group is a device-side wait of that many microseconds on the stream
+    // it is enqueued on, and the handle keeps its receive buffers filled with what the unpack / add kernels turn into no-ops - one rank of N
+    // measured alone then runs every kernel of the real step and pays a stated wire time (tools/one_rank_profile.py)
+    virtual bool loopback() const { return false; }
     // RCCL only: ncclGetVersion and ncclCommCount of this handle's communicator (0, 0 elsewhere) - for mdx_comm_diag
     virtual void wire_info(int* version, int* comm_count) const { *version = 0; *comm_count = 0; }
 };
@@ -95,6 +99,15 @@ struct MdxDecomp {
     bool spec_valid = false; uint32_t spec_bits = 0; uint64_t spec_checks = 0;
     bool probe_both_buffers = false;   // the chunk just enqueued ran fused bonded + kick + drift passes: which of the two position buffers holds the
                                        // state of the step the list went stale at depends on the parity of the gated-off passes behind it
+    // ---- the fused bonded + kick + drift pass carries halo pack and ghost-force add (mdx_decomp.hip "fold") ------------------------------
+    bool fold_ok = false;              // the drift pass may pack the halo and add the returned ghost forces (half shell, communication on the compute stream, MDX_HALO_FOLD != 0)
+    bool pipe_now = false;             // the step being enqueued has its halo packed by the drift pass (mdx_step)
+    bool packed_by_drift = false;      // ... and that pass has been enqueued: the halo exchange starts at the send/recv group
+    bool frc_deferred = false;         // the ghost forces returned for the last force call are still in frc_recv: the next drift pass adds them
+    uint32_t pipe_gen = 0;             // generation of the last pipelined step enqueued
+    PipeCtl* pipe_ctl = nullptr;
+    uint32_t* send_cnt = nullptr; uint32_t* send_rows = nullptr; uint32_t cap_rows_slots = 0; bool rows_valid = false;   // per slot: its rows of the position message
+    uint64_t pipe_steps = 0;
     // statistics
     uint64_t repartitions = 0, local_rebuilds = 0; uint32_t local_rebuilds_since = 0;
     double repartition_ms = 0.0;
@@ -107,6 +120,11 @@ struct MdxDecomp {
 static inline bool mdx_dd_split_now(const mdx_handle* h) {
     return h->dd && h->tile_split && h->dd->overlap && h->dd->world > 1 && mdx_nb_variant(h) >= 2 && !h->pme_on && (!h->profile || h->profile_level == 3);
 }
+// Does the fused bonded + kick + drift pass of a decomposed handle carry the halo pack and the add of the returned ghost forces?
+// (two kernels and two launch boundaries less per step, whichever way the pair kernel is launched)
+static inline bool mdx_dd_fold_eligible(const mdx_handle* h) {
+    return h->dd && h->dd->fold_ok && h->dd->world > 1 && mdx_nb_half(h) && !h->pme_on && !h->alch_on;
+}
 
 int  mdx_set_local_atoms_impl(mdx_handle* h, uint32_t n_local, const uint32_t* d_gid, const uint8_t* d_ghost, const float* d_pos4,
                               const float* d_vel4, const float lo[3], const float hi[3], int32_t periodic);
@@ -114,6 +132,7 @@ int  mdx_dd_attach(mdx_handle* h, MdxTransport* tr);     // takes ownership of `
 void mdx_dd_destroy(mdx_handle* h);
 int  mdx_dd_halo_begin(mdx_handle* h);                   // pack + exchange (async on the comm stream)
 int  mdx_dd_halo_end(mdx_handle* h);                     // wait + unpack: ghost positions, peers' flag words
+void mdx_dd_pipe_chunk_end(mdx_handle* h);              // a chunk has been enqueued: nothing is deferred across it
 int  mdx_dd_force_return_begin(mdx_handle* h, int flag_word);   // half shell: pack the ghosts' forces + exchange (reverse of the halo)
 int  mdx_dd_force_return_end(mdx_handle* h, int flag_word);     // ... and add what came back to the owned atoms
 int  mdx_dd_chunk_end_probe(mdx_handle* h, const uint32_t** word_out);   // enqueue the speculative drift probe; *word_out: the device word to read back

@@ -287,10 +287,23 @@ struct FabricTransport : MdxTransport {
     }
 };
 
+// MDX_NULL_WIRE_US=x: every send/recv group of the null transport occupies its stream for x microseconds (one wave watching the
+// 100 MHz wall clock) - the wire time a real exchange would put there, so that what the step hides of it can be measured on one GPU
+__global__ void null_wire_kernel(uint32_t us) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(16);
+}
 struct NullTransport : MdxTransport {
-    const char* name() const override { return "null (delivers nothing)"; }
+    int wire_us = -1;      // < 0: MDX_NULL_WIRE_US not set (the transport of rounds 3-4: nothing is enqueued, unpack / add kernels are skipped)
+    NullTransport() { const char* e = std::getenv("MDX_NULL_WIRE_US"); if (e) wire_us = std::max(0, std::atoi(e)); }
+    const char* name() const override { return wire_us >= 0 ? "null (stated wire time, loop-back buffers)" : "null (delivers nothing)"; }
     bool delivers() const override { return false; }
-    int exchange(const float4*, const std::vector<MdxSeg>&, float4*, const std::vector<MdxSeg>&, hipStream_t) override { return MDX_OK; }
+    bool loopback() const override { return wire_us >= 0; }
+    int exchange(const float4*, const std::vector<MdxSeg>&, float4*, const std::vector<MdxSeg>&, hipStream_t st) override {
+        if (wire_us > 0) { hipLaunchKernelGGL(null_wire_kernel, dim3(1), dim3(64), 0, st, (uint32_t)wire_us); HIP_TRY(hipGetLastError()); }
+        return MDX_OK;
+    }
     int all_reduce(void*, size_t, int, hipStream_t) override { return MDX_OK; }
     int all_reduce_f32(float*, size_t, hipStream_t) override { return MDX_OK; }
     int all_gather_u32(uint32_t mine, uint32_t* all, hipStream_t) override { for (int q = 0; q < world; ++q) all[q] = mine; return MDX_OK; }

@@ -407,6 +407,7 @@ static int dd_partition(mdx_handle* h) {
                                      lo, hi, per_mask));
     dd->repartitions++;
     dd->local_rebuilds_since = 0;
+    dd->rows_valid = false;
     return MDX_OK;
 }
 
@@ -528,14 +529,19 @@ int mdx_dd_allreduce_host(mdx_handle* h, double* v, int n, bool max_u32) {
 }
 
 // ---- per-step halo ------------------------------------------------------------------------------------------------
+static int dd_pipe_tables(mdx_handle* h);
 int mdx_dd_halo_begin(mdx_handle* h) {
     MdxDecomp* dd = h->dd;
     if (dd->world == 1) return MDX_OK;
     const int fw = dd->halo_step >= 0 ? dd->halo_step + 1 : -1;
-    mdx_prof_begin(h, 6);
-    const int rc_pack = mdx_pack_positions(h, dd->send_ids, dd->n_send, (float*)dd->send_buf, fw);
-    mdx_prof_end(h);
-    MDX_TRY(rc_pack);
+    if (dd->tr->loopback() && !dd->rows_valid && h->in_slot_space) MDX_TRY(dd_pipe_tables(h));      // (keeps the loop-back buffers current)
+    if (dd->packed_by_drift) dd->packed_by_drift = false;      // the fused bonded + kick + drift pass has filled the message (flag rows included)
+    else {
+        mdx_prof_begin(h, 6);
+        const int rc_pack = mdx_pack_positions(h, dd->send_ids, dd->n_send, (float*)dd->send_buf, fw);
+        mdx_prof_end(h);
+        MDX_TRY(rc_pack);
+    }
     if (dd->comm_stream != h->stream) {
         HIP_TRY(hipEventRecord(dd->ev_packed, h->stream));
         HIP_TRY(hipStreamWaitEvent(dd->comm_stream, dd->ev_packed, 0));
@@ -553,7 +559,7 @@ int mdx_dd_halo_end(mdx_handle* h) {
     if (dd->world == 1) return MDX_OK;
     const int fw = dd->halo_step >= 0 ? dd->halo_step + 1 : -1;
     if (dd->comm_stream != h->stream) HIP_TRY(hipStreamWaitEvent(h->stream, dd->ev_arrived, 0));
-    if (dd->tr->delivers()) {
+    if (dd->tr->delivers() || dd->tr->loopback()) {
         mdx_prof_begin(h, 8);
         const int rc_u = mdx_unpack_positions(h, dd->recv_ids, dd->n_recv, (const float*)dd->recv_buf, (const float*)dd->recv_shift, fw);
         mdx_prof_end(h);
@@ -628,8 +634,10 @@ int mdx_dd_force_return_end(mdx_handle* h, int flag_word) {
     dd->force_return_pending = false;
     hipStream_t st = h->stream;
     if (dd->comm_stream != st) HIP_TRY(hipStreamWaitEvent(st, dd->ev_arrived, 0));
+    // the next step's fused bonded + kick + drift pass adds the rows (and merges the peers' stale words) itself
+    if (dd->pipe_now && h->bonded_deferred && flag_word >= 0) { dd->frc_deferred = true; return MDX_OK; }
     uint32_t* fw = flag_word >= 0 ? &h->d.ctl->disp2[flag_word] : nullptr;
-    if (dd->tr->delivers() && dd->n_send) {
+    if ((dd->tr->delivers() || dd->tr->loopback()) && dd->n_send) {
         mdx_prof_begin(h, 11);
         hipLaunchKernelGGL(dd_add_force_kernel, dim3(div_up(dd->n_send, 256)), dim3(256), 0, st, dd->n_send, dd->send_ids, h->d.slot_of,
                            h->d.force, dd->frc_recv, fw);
@@ -637,6 +645,87 @@ int mdx_dd_force_return_end(mdx_handle* h, int flag_word) {
     }
     HIP_TRY(hipGetLastError());
     return MDX_OK;
+}
+
+// ---- what the fused bonded + kick + drift pass of a decomposed step carries ("fold") ----------------------------------------------------
+// The plain arrangement of a step is a chain on one stream: drift -> pack -> [send/recv] -> unpack -> pair kernel -> ghost-force pack ->
+// [send/recv] -> add, with ~4 us between dependent launches.  In the steps of the fused bonded + kick + drift pass (mdx_integrate.hip)
+// that pass takes the pack and the add with it: a slot knows its rows of the position message (at most seven, one per peer), writes its
+// new position into them, and adds the rows of the force message - same layout - that came back for it after the previous force call;
+// the workgroup that finishes last writes the flag rows.  Two kernels and two launch boundaries less per step.
+// (Round 5 also built and measured the arrangement the round-4 verdict sketched - ONE pair launch on a side stream whose boundary
+// workgroups wait for a word the unpack kernel publishes, both messages on the compute stream - and dropped it: DESIGN_HISTORY.md
+// "Round 5", profiles/r05_pipe_experiments.txt.)
+__global__ void pipe_rows_kernel(uint32_t n_send, const uint32_t* __restrict__ send_ids, const uint32_t* __restrict__ slot_of,
+                                 uint32_t* __restrict__ send_cnt, uint32_t* __restrict__ send_rows, uint32_t* err) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_send) return;
+    const uint32_t g = send_ids[i];
+    if (g == MDX_INVALID) return;            // a flag row
+    const uint32_t s = slot_of[g];
+    if (s == MDX_INVALID) return;
+    const uint32_t k = atomicAdd(send_cnt + s, 1u);
+    if (k < 7u) send_rows[(size_t)s * 7 + k] = i; else atomicOr(err, 16u);
+}
+// null transport with a stated wire time: the receive buffers hold what the unpack / add kernels turn into no-ops
+__global__ void pipe_loopback_kernel(uint32_t n_recv, const uint32_t* __restrict__ recv_ids, const uint32_t* __restrict__ slot_of,
+                                     const float4* __restrict__ posq, const float4* __restrict__ shift, float4* __restrict__ recv_buf) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_recv) return;
+    const uint32_t g = recv_ids[i];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g != MDX_INVALID) {
+        const uint32_t s = slot_of[g];
+        if (s != MDX_INVALID) { v = posq[s]; const float4 sh = shift[i]; v.x -= sh.x; v.y -= sh.y; v.z -= sh.z; }
+    }
+    recv_buf[i] = v;
+}
+
+void mdx_dd_note_rebuild(mdx_handle* h) { if (h->dd) h->dd->rows_valid = false; }
+void mdx_dd_pipe_chunk_end(mdx_handle* h) { if (h->dd) { h->dd->pipe_now = false; h->dd->frc_deferred = false; h->dd->packed_by_drift = false; } }
+
+// per-slot rows of the position message, tile counts of the pair launch; (null transport with a wire time) the loop-back buffers
+static int dd_pipe_tables(mdx_handle* h) {
+    MdxDecomp* dd = h->dd;
+    hipStream_t st = h->stream;
+    if (!dd->pipe_ctl) {
+        HIP_TRY(hipMalloc((void**)&dd->pipe_ctl, sizeof(PipeCtl)));
+        HIP_TRY(hipMemsetAsync(dd->pipe_ctl, 0, sizeof(PipeCtl), st));
+    }
+    if (dd->cap_rows_slots < h->S) {
+        dd->cap_rows_slots = h->cap_tiles * MDX_TILE;
+        MDX_TRY(dd_alloc(&dd->send_cnt, dd->cap_rows_slots)); MDX_TRY(dd_alloc(&dd->send_rows, (size_t)dd->cap_rows_slots * 7));
+    }
+    HIP_TRY(hipMemsetAsync(dd->send_cnt, 0, sizeof(uint32_t) * (size_t)h->S, st));
+    if (dd->n_send)
+        hipLaunchKernelGGL(pipe_rows_kernel, dim3(div_up(dd->n_send, 256)), dim3(256), 0, st, dd->n_send, dd->send_ids, h->d.slot_of, dd->send_cnt,
+                           dd->send_rows, h->d.flags_dev);
+    if (dd->tr->loopback()) {
+        if (dd->n_recv)
+            hipLaunchKernelGGL(pipe_loopback_kernel, dim3(div_up(dd->n_recv, 256)), dim3(256), 0, st, dd->n_recv, dd->recv_ids, h->d.slot_of, h->d.posq,
+                               dd->recv_shift, dd->recv_buf);
+        if (dd->n_send) HIP_TRY(hipMemsetAsync(dd->frc_recv, 0, sizeof(float4) * (size_t)dd->n_send, st));
+    }
+    HIP_TRY(hipGetLastError());
+    dd->rows_valid = true;
+    return MDX_OK;
+}
+
+// the fused bonded + kick + drift pass about to be launched: returned ghost forces in (if the last force call left them to it), halo
+// pack out (if this step's drift carries it)
+bool mdx_dd_pipe_fill(mdx_handle* h, FusedArgs& a, uint32_t* gate_word) {
+    MdxDecomp* dd = h->dd;
+    a.pipe_flags = 0u;
+    if (!dd || !(dd->pipe_now || dd->frc_deferred)) return false;
+    if (!dd->rows_valid && dd_pipe_tables(h) != MDX_OK) return false;
+    a.pipe_flags = (dd->frc_deferred ? 1u : 0u) | (dd->pipe_now ? 2u : 0u);
+    dd->frc_deferred = false;
+    a.send_cnt = dd->send_cnt; a.send_rows = dd->send_rows; a.frc_in = dd->frc_recv; a.send_buf = dd->send_buf;
+    a.n_flag = 0;
+    for (const MdxSeg& sg : dd->send_segs) if (a.n_flag < 8 && sg.nrows) a.flag_rows[a.n_flag++] = sg.row0 + sg.nrows - 1;
+    a.pc = dd->pipe_ctl; a.gate_word = gate_word;
+    if (dd->pipe_now) { ++dd->pipe_gen; ++dd->pipe_steps; dd->packed_by_drift = true; }
+    return true;
 }
 
 // ---- stale list: local rebuild or repartition (the same branch on every rank) --------------------------------------
@@ -773,7 +862,7 @@ void mdx_dd_destroy(mdx_handle* h) {
     if (dd->comm_stream && dd->comm_stream != h->stream) (void)hipStreamSynchronize(dd->comm_stream);
     void* ptrs[] = {dd->anchor, dd->g_pos, dd->g_vel, dd->g_frc, dd->cls, dd->owner, dd->shift_code, dd->send_mask, dd->flags, dd->scan,
                     dd->scan_sums, dd->pos_at_part, dd->owned_gid, dd->send_ids,
-                    dd->recv_ids, dd->recv_shift, dd->send_buf, dd->recv_buf, dd->frc_send, dd->frc_recv, dd->gat_send, dd->gat_recv, dd->red, dd->drift_bits};
+                    dd->recv_ids, dd->recv_shift, dd->send_buf, dd->recv_buf, dd->frc_send, dd->frc_recv, dd->gat_send, dd->gat_recv, dd->red, dd->drift_bits, dd->pipe_ctl, dd->send_cnt, dd->send_rows};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (dd->ev_packed) (void)hipEventDestroy(dd->ev_packed);
     if (dd->ev_arrived) (void)hipEventDestroy(dd->ev_arrived);
@@ -963,7 +1052,15 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
     }
     DD_HIP(hipEventCreateWithFlags(&dd->ev_packed, hipEventDisableTiming));
     DD_HIP(hipEventCreateWithFlags(&dd->ev_arrived, hipEventDisableTiming));
-    DD_HIP(hipStreamCreateWithFlags(&dd->side_stream, hipStreamNonBlocking));
+    {   // the side stream (interior tiles) runs at the lowest priority, so that the kernels on the compute stream - the ones the messages wait
+        // for - are dispatched first when both have workgroups pending (rank 0 of 8: split step 0.154 -> 0.142 ms, 0.206 -> 0.186 with 25 us
+        // per message; MDX_SIDE_PRIO=0: A/B)
+        const char* e = std::getenv("MDX_SIDE_PRIO");
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (!(e && e[0] == '0')) DD_HIP(hipStreamCreateWithPriority(&dd->side_stream, hipStreamNonBlocking, lo));
+        else DD_HIP(hipStreamCreateWithFlags(&dd->side_stream, hipStreamNonBlocking));
+    }
     DD_HIP(hipEventCreateWithFlags(&dd->ev_fork, hipEventDisableTiming));
     DD_HIP(hipEventCreateWithFlags(&dd->ev_interior, hipEventDisableTiming));
     DD_HIP(hipMemcpyAsync(dd->anchor, anchor.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice, h->stream));
@@ -972,6 +1069,10 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
     DD_TRY(mdx_unsort_state(h));
     DD_HIP(hipMemcpyAsync(dd->g_pos, h->d.pos_orig, sizeof(float4) * N, hipMemcpyDeviceToDevice, h->stream));
     DD_HIP(hipMemcpyAsync(dd->g_vel, h->d.vel_orig, sizeof(float4) * N, hipMemcpyDeviceToDevice, h->stream));
+    {   // the drift pass of a decomposed step carries the halo pack and the add of the returned ghost forces (MDX_HALO_FOLD=0: A/B)
+        const char* f = std::getenv("MDX_HALO_FOLD");
+        dd->fold_ok = dd->world > 1 && dd->half_shell && dd->comm_stream == h->stream && !(f && f[0] == '0');
+    }
     h->want_tile_split = dd->world > 1 && (dd->overlap || dd->tune_phase < 2);
     if (h->pme_on) {   // the reciprocal-space chain of a decomposed handle runs on the handle's own stream (mesh all-reduce inside)
         if (h->pme_overlap && h->stream_pme) DD_HIP(hipStreamSynchronize(h->stream_pme));

@@ -2215,6 +2215,7 @@ int mdx_rebuild(mdx_handle* h) {
     h->list_valid = true;
     h->forces_valid = false;
     h->rebuild_count++; h->steps_since_rebuild = 0;
+    mdx_dd_note_rebuild(h);
     // dual pair list: the step loop of a half-list run walks a rolling-pruned inner list.  What moves an atom inside
     // the step loop feeds its path accumulator: the drift pass, SHAKE, and - for the ghosts of a decomposed handle - the
     // halo unpack; a virtual site inside the triangle of its parents never moves further than they do (anything else

@@ -116,18 +116,25 @@ __global__ __launch_bounds__(256) void integrate_kernel(uint32_t S, float dt, fl
 // the drift produces t + dt, so positions are double-buffered: read posq_in, write posq_out, the host swaps the two
 // pointers (slots that are never integrated - static, ghost, dummy - are copied through).  The bonded terms evaluated here
 // are those of the PREVIOUS force call (whose own bonded launch mdx_step left out): positions have not moved since.
-struct FusedArgs {
-    uint32_t S; float dt;
-    const float4* posq_in; float4* posq_out; float4* vel; float4* force; float4* ref;
-    const uint32_t* role_off; const RoleRec* roles; const float4* prm; BondedParams p; uint32_t R;
-    const uint32_t* gate_in; uint32_t* disp_out; uint32_t thr_bits; uint32_t* prune_out; float path_thr;
-};
-template <bool DUAL>
+// (FusedArgs: mdx_internal.h - the decomposition fills its pipeline fields)
+__device__ __forceinline__ void pipe_publish(const FusedArgs& a, uint32_t word) {
+    for (uint32_t q = 0; q < a.n_flag; ++q) a.send_buf[a.flag_rows[q]] = make_float4(__uint_as_float(word), 0.f, 0.f, 0.f);
+    for (int k = 0; k < 9; ++k) a.pc->m1_shard[k] = 0u;
+}
+template <bool DUAL, bool PIPE>
 __global__ __launch_bounds__(256) void bonded_integrate_kernel(FusedArgs a) {
-    const uint32_t gate = a.gate_in ? *a.gate_in : 0u;
+    uint32_t gate = a.gate_in ? *a.gate_in : 0u;
+    if (PIPE && (a.pipe_flags & 1u))       // what the ranks below this one found during the last drift came back with their ghost forces
+        for (uint32_t q = 0; q < a.n_flag; ++q) gate = max(gate, __float_as_uint(a.frc_in[a.flag_rows[q]].x));
     if (gate > a.thr_bits) {  // list already stale: stay a no-op.  Positions stay in posq_in; the launcher has swapped the host's pointers
                               // all the same (it enqueues blind), so mdx_step points d.posq back at the buffer the stale step's drift wrote
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(a.disp_out, gate);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            atomicMax(a.disp_out, gate);
+            if (PIPE) {
+                if (a.gate_word) atomicMax(a.gate_word, gate);
+                if (a.pipe_flags & 2u) pipe_publish(a, gate);      // the message still travels, carrying the word; the queues are drawn empty
+            }
+        }
         return;
     }
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -150,6 +157,10 @@ __global__ __launch_bounds__(256) void bonded_integrate_kernel(FusedArgs a) {
 #pragma unroll
             for (int i = 0; i < FUSED_PRE; ++i) { q0[i] = a.posq_in[rr[i].p[0]]; q1[i] = a.posq_in[rr[i].p[1]]; prm[i] = a.prm[rr[i].meta >> 8]; }
             RoleEnergies en;
+            if (PIPE && (a.pipe_flags & 1u)) {
+                const uint32_t nr = a.send_cnt[s];
+                for (uint32_t k = 0; k < nr; ++k) { const float4 g = a.frc_in[a.send_rows[(size_t)s * 7 + k]]; f.x += g.x; f.y += g.y; f.z += g.z; }
+            }
 #pragma unroll
             for (int i = 0; i < FUSED_PRE; ++i)
                 if (rb + (uint32_t)i < re) role_compute<false>(rr[i], prm[i], p, q0[i], q1[i], a.posq_in, a.p, f.x, f.y, f.z, en);
@@ -175,6 +186,10 @@ __global__ __launch_bounds__(256) void bonded_integrate_kernel(FusedArgs a) {
         }
         a.posq_out[s] = p;
         a.force[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PIPE && (a.pipe_flags & 2u)) {
+            const uint32_t nr = a.send_cnt[s];
+            for (uint32_t k = 0; k < nr; ++k) a.send_buf[a.send_rows[(size_t)s * 7 + k]] = p;
+        }
     }
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, m));
@@ -183,6 +198,19 @@ __global__ __launch_bounds__(256) void bonded_integrate_kernel(FusedArgs a) {
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) path = fmaxf(path, __shfl_xor(path, m));
         if ((threadIdx.x & 63) == 0 && !(path <= a.path_thr)) *a.prune_out = 1u;
+    }
+    if (PIPE && (a.pipe_flags & 2u)) {
+        // the workgroup that arrives last knows the stale word is complete: every workgroup's atomicMax (if it issued one) has been
+        // acknowledged before it counts itself in.  Two levels (eight shards by blockIdx & 7): ~100 arrivals per word instead of 800.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t shard = blockIdx.x & 7u, in_shard = (gridDim.x - shard + 7u) >> 3;
+            if (atomicAdd(a.pc->m1_shard + shard, 1u) + 1u == in_shard) {
+                const uint32_t n_shards = gridDim.x < 8u ? gridDim.x : 8u;
+                if (atomicAdd(a.pc->m1_shard + 8, 1u) + 1u == n_shards) pipe_publish(a, atomicMax(a.disp_out, 0u));
+            }
+        }
     }
 }
 
@@ -287,9 +315,15 @@ int mdx_launch_bonded_integrate(mdx_handle* h, float dt, const uint32_t* d_gate_
     a.path_thr = 0.5f * h->inner_skin * (1.0f - 1.0e-4f);
     const bool dual = h->dual_on && d_prune_out != nullptr;
     const dim3 g((h->S + 255) / 256), b(256);
+    const bool pipe = mdx_dd_pipe_fill(h, a, const_cast<uint32_t*>(d_gate_in));      // decomposed handle, pipelined arrangement: returned ghost forces in, halo pack out
     mdx_prof_begin(h, 5);
-    if (dual) hipLaunchKernelGGL(bonded_integrate_kernel<true>, g, b, 0, h->stream, a);
-    else hipLaunchKernelGGL(bonded_integrate_kernel<false>, g, b, 0, h->stream, a);
+    if (pipe) {
+        if (dual) hipLaunchKernelGGL((bonded_integrate_kernel<true, true>), g, b, 0, h->stream, a);
+        else hipLaunchKernelGGL((bonded_integrate_kernel<false, true>), g, b, 0, h->stream, a);
+    } else {
+        if (dual) hipLaunchKernelGGL((bonded_integrate_kernel<true, false>), g, b, 0, h->stream, a);
+        else hipLaunchKernelGGL((bonded_integrate_kernel<false, false>), g, b, 0, h->stream, a);
+    }
     mdx_prof_end(h);
     HIP_TRY(hipGetLastError());
     std::swap(d.posq, d.posq_alt);

@@ -114,6 +114,12 @@ struct StepCtl {
     uint32_t prune_ghost[MDX_MAX_CHUNK + 2];
 };
 
+// Decomposed handle, steps of the fused bonded + kick + drift pass: the pass also packs the halo and adds the ghost forces the peers
+// returned for the previous force call (mdx_integrate.hip, mdx_decomp.hip).  Its workgroups count themselves in here - two levels, by
+// blockIdx & 7 and then by shard - so that the one that arrives last can write the flag rows of the message (the "list went stale"
+// word is complete only then).
+struct __attribute__((aligned(128))) PipeCtl { uint32_t m1_shard[16]; uint32_t pad[16]; };
+
 // One (term, atom-of-that-term) record of the atom-owned bonded gather (mdx_bonded.hip).
 enum { ROLE_BOND = 0, ROLE_ANGLE = 1, ROLE_DIHEDRAL = 2, ROLE_PAIR14 = 3, ROLE_EWALD_EXCL = 4 };
 // 16 bytes: the parameters live in a table of DISTINCT parameter sets (role_prm: a force field has a few hundred; the
@@ -377,6 +383,29 @@ struct mdx_handle {
     bool cell_count_clean = false;   // fused rebuild: d.cell_count is all zero (the grid-scan kernel zeroes what it has consumed)
     bool slot_of_clean = false;      // ... and d.slot_of holds no slot of an atom that has left the local set
 };
+
+// argument block of the fused bonded + kick + drift pass (mdx_integrate.hip)
+struct FusedArgs {
+    uint32_t S; float dt;
+    const float4* posq_in; float4* posq_out; float4* vel; float4* force; float4* ref;
+    const uint32_t* role_off; const RoleRec* roles; const float4* prm; BondedParams p; uint32_t R;
+    const uint32_t* gate_in; uint32_t* disp_out; uint32_t thr_bits; uint32_t* prune_out; float path_thr;
+    // Decomposed handle, pipelined step (PIPE; mdx_decomp.hip).  The pass takes over what two kernels and two launch boundaries did:
+    //   pipe_flags & 1  the ghost forces the peers returned for the previous force call are ADDED here (frc_in has the layout of the
+    //                   position message: the rows a slot fills there are the rows that come back for it) - no add kernel, no atomics;
+    //                   the peers' "my list went stale" words ride in the flag rows and are merged into the gate
+    //   pipe_flags & 2  the halo PACK: a slot's new position goes straight into its rows of the position message; the workgroup that
+    //                   finishes last writes the flag rows (the stale word is only complete then) and resets the tile queues of the
+    //                   pair launch that follows
+    uint32_t pipe_flags;
+    const uint32_t* send_cnt; const uint32_t* send_rows;      // per slot: rows of the position message it fills (at most 7: one per peer), [S], [7 S]
+    const float4* frc_in; float4* send_buf;
+    uint32_t n_flag; uint32_t flag_rows[8];
+    PipeCtl* pc;
+    uint32_t* gate_word;                                       // = gate_in, writable: the merged stale word is stored back for the kernels behind
+};
+bool mdx_dd_pipe_fill(mdx_handle* h, FusedArgs& a, uint32_t* gate_word);   // decomposed handle in its pipelined arrangement: fills the pipe fields (false: plain pass)
+void mdx_dd_note_rebuild(mdx_handle* h);                                     // the slot order changed: per-slot tables of the decomposition are stale
 
 // ---- error plumbing ------------------------------------------------------------------------------
 void mdx_set_error(const std::string& s);

@@ -12,7 +12,8 @@ from tests.test_gpu_comm import run_ranks, rms_dev
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 base_seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 KNOBS = {"MDX_GRID_PIECEWISE": ["0", "1"], "MDX_HALO_OVERLAP": ["0", "1"], "MDX_HALF_SHELL": ["0", "1"], "MDX_CONS_SORT_MIN": ["1", "100000000"],
-         "MDX_KIND_CLUSTERS": ["0", "1"], "MDX_VSITE_IN_GROUPS": ["0", "1"], "MDX_FUSE_BONDED_INTEGRATE_DD": ["0", "1"], "MDX_PME_SLAB": ["0", "1"]}
+         "MDX_KIND_CLUSTERS": ["0", "1"], "MDX_VSITE_IN_GROUPS": ["0", "1"], "MDX_FUSE_BONDED_INTEGRATE_DD": ["0", "1"], "MDX_PME_SLAB": ["0", "1"], "MDX_HALO_FOLD": ["0", "1"],
+         "MDX_SIDE_PRIO": ["0", "1"]}
 fails = 0; t0 = time.time()
 for case in range(n_cases):
     rng = np.random.default_rng([base_seed, case])

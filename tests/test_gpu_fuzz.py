@@ -13,10 +13,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_script(name, cases, seed):
+def run_script(name, cases, seed, extra_env=None):
     env = dict(os.environ)
     for k in [k for k in env if k.startswith("MDX_") or k.startswith("FUZZ_")]:
         env.pop(k)
+    env.update(extra_env or {})
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", name), str(cases), str(seed)], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
     tail = "\n".join((p.stdout + p.stderr).splitlines()[-25:])
@@ -35,3 +36,9 @@ def test_randomised_parity_against_the_oracle(seed):
 @pytest.mark.parametrize("seed", [21, 22])
 def test_randomised_decomposed_runs_follow_one_gpu(seed):
     run_script("fuzz_decomp.py", 16, seed)
+
+
+def test_randomised_decomposed_runs_with_the_fused_drift_pass_on_small_boxes():
+    """The fused bonded + kick + drift pass - on a decomposed handle it also packs the halo and adds the returned ghost forces -
+    is a large-system arrangement (>= 2048 tiles per rank); MDX_WPT8_BELOW=32 takes the small boxes of the fuzz through it."""
+    run_script("fuzz_decomp.py", 24, 23, {"MDX_WPT8_BELOW": "32"})

@@ -7,7 +7,7 @@ import glob, os, re, sqlite3, sys
 src = sys.argv[1]
 db = sqlite3.connect(glob.glob(os.path.join(src, "**", "*.db"), recursive=True)[0])
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
-short = lambda n: re.match(r"(?:void )?([A-Za-z0-9_]+)", n).group(1)
+short = lambda n: (re.match(r"(?:void )?([A-Za-z0-9_]+)", n) or re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*(?:<|\(|$)", n) or re.search(r"(.*)", n)).group(1)
 # steps are delimited by integrate_kernel launches; take a stretch without list rebuilds near the end
 idx = [i for i, r in enumerate(rows) if short(r[0]) in ("integrate_kernel", "bonded_integrate_kernel")]
 n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
