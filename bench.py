@@ -193,6 +193,33 @@ def cpu_baseline(system, cfg, dt, n_steps):
     }
 
 
+def with_watchdog(fn, what, rank, world, timeout_s):
+    """Runs fn() (a collective of the library's own communicator: ncclCommInitRank, the transport self-test) on a helper thread.  The
+    first multi-rank RCCL run happens on a box nobody watches: if the call has not returned within timeout_s - a peer that never
+    arrived, a bootstrap that cannot connect - this rank says which rank, which phase and for how long, and exits non-zero
+    instead of hanging until the driver's own limit.  (os._exit: the stuck call holds the GIL-free native wait, no clean way out.)"""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["v"] = fn()
+        except BaseException as e:  # noqa: BLE001 - handed to the caller
+            box["e"] = e
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(timeout_s)
+    if t.is_alive():
+        sys.stderr.write(f"[bench rank {rank} of {world}] watchdog: {what} has not returned after {timeout_s:.0f} s - a peer did not arrive "
+                         f"or the bootstrap cannot connect (MASTER_ADDR={os.environ.get('MASTER_ADDR')}, LOCAL_RANK={os.environ.get('LOCAL_RANK')}); exiting\n")
+        sys.stderr.flush()
+        os._exit(3)
+    if "e" in box:
+        raise box["e"]
+    return box.get("v")
+
+
 def main():
     args = parse()
     import torch
@@ -287,7 +314,11 @@ def main():
             uid = uid.cpu()
         transport = "RCCL"
         shm_name = "bench_" + bytes(uid.numpy().tobytes())[:8].hex()
-        if same_gpu and world > 1:
+        # MDX_BENCH_TRY_RCCL=1 (with MDX_BENCH_SAME_GPU=1): go through the RCCL branch all the same - on one device ncclCommInitRank
+        # refuses the second rank, which exercises exactly the failure -> shared-memory fallback path below.
+        # MDX_BENCH_FAIL_RANK=k (tests): rank k never calls mdx_comm_init - the peers' watchdogs must fire.
+        comm_timeout = float(os.environ.get("MDX_BENCH_COMM_TIMEOUT_S", "120"))
+        if same_gpu and world > 1 and os.environ.get("MDX_BENCH_TRY_RCCL", "0") != "1":
             md.comm_init_shm(shm_name, rank, world)
             transport = "shared memory (verification aid, not a measurement)"
         else:
@@ -296,14 +327,18 @@ def main():
             # says so on stderr and the run continues over the library's host shared-memory transport - GPU kernels
             # unchanged, halo through host memory - and the JSON line names the transport it was measured on.
             err = ""
+            if os.environ.get("MDX_BENCH_FAIL_RANK", "") == str(rank):
+                sys.stderr.write(f"[bench rank {rank}] MDX_BENCH_FAIL_RANK: this rank stays away from mdx_comm_init (fault injection)\n"); sys.stderr.flush()
+                time.sleep(10.0 * comm_timeout)
+                raise SystemExit(4)
             try:
-                md.comm_init(bytes(uid.numpy().tobytes()), rank, world)
-                md.comm_selftest()
+                with_watchdog(lambda: md.comm_init(bytes(uid.numpy().tobytes()), rank, world), "mdx_comm_init (ncclCommInitRank + first partition)", rank, world, comm_timeout)
+                with_watchdog(md.comm_selftest, "mdx_comm_selftest (send/recv group to every rank + all-reduces)", rank, world, comm_timeout)
             except Exception as e:  # noqa: BLE001 - reported, never swallowed
                 err = f"{type(e).__name__}: {e}"
             if world > 1:
                 bad = torch.tensor([1.0 if err else 0.0], device="cpu" if pg_cpu else "cuda")
-                dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                with_watchdog(lambda: dist.all_reduce(bad, op=dist.ReduceOp.MAX), "the launcher's all-reduce of the transport verdict", rank, world, comm_timeout)
                 if bad.item() > 0:
                     sys.stderr.write(f"[bench rank {rank} of {world}, device {local_rank}] RCCL transport unusable: "
                                      f"{err or 'no error on this rank (another rank failed)'}; continuing over the shared-memory transport\n")

@@ -235,7 +235,8 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
     }
     h->mol_start.assign(s->mol_start ? s->mol_start : nullptr, s->mol_start ? s->mol_start + s->n_mols : nullptr);
     h->total_charge = 0.0; h->sum_q2 = 0.0;
-    for (uint32_t i = 0; i < N; ++i) { h->total_charge += q[i]; h->sum_q2 += (double)q[i] * q[i]; }
+    h->q_abs_max = 0.0;
+    for (uint32_t i = 0; i < N; ++i) { h->total_charge += q[i]; h->sum_q2 += (double)q[i] * q[i]; h->q_abs_max = std::max(h->q_abs_max, (double)std::fabs(q[i])); }
     const bool pme_on = c->coulomb_mode == MDX_COULOMB_EWALD && !(c->overrides & MDX_OVR_LONG_RANGE_RECIP_DISABLED) &&
                         !coul_off;
     MDX_TRY(upload_vec(&d.o_qs, qs, st)); MDX_TRY(upload_vec(&d.o_lj, lj, st));

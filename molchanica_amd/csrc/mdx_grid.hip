@@ -1436,6 +1436,9 @@ static int setup_grid(mdx_handle* h) {
     // capacity in tiles: sum ceil(cnt/64) <= N/64 + ncol, + the null tile
     const uint32_t need_tiles = N / MDX_TILE + new_ncol + 2;
     if (need_tiles > h->cap_tiles) {
+        // the slot-space arrays are about to be re-allocated (ALLOC does not copy): a handle whose dynamic state lives in them - the
+        // fused rebuild skips the unsort - saves it into the caller-order staging first (mdx_rebuild then leaves the fused chain)
+        if (h->in_slot_space && h->cap_tiles) MDX_TRY(mdx_unsort_state(h));
         h->cap_tiles = need_tiles;
         const size_t S = (size_t)need_tiles * MDX_TILE, NC = (size_t)need_tiles * MDX_CL_PER_TILE;
         ALLOC(d.posq, S); ALLOC(d.lj, S); ALLOC(d.vel, S); ALLOC(d.force, S); ALLOC(d.ref, S); ALLOC(d.posq_alt, S);
@@ -1843,7 +1846,7 @@ static int rebuild_fast(mdx_handle* h, RebuildResult* res, bool* fell_back) {
     if (!h->cell_count_clean) { HIP_TRY(hipMemsetAsync(d.cell_count, 0, sizeof(uint32_t) * ((size_t)h->ncells + 1), st)); h->cell_count_clean = true; }
     if (!h->slot_of_clean) { HIP_TRY(hipMemsetAsync(d.slot_of, 0xFF, sizeof(uint32_t) * (size_t)h->N, st)); h->slot_of_clean = true; }
     const uint32_t T_bound = N / MDX_TILE + h->ncol + 1;        // sum over columns of ceil(n / 64) <= N / 64 + ncol
-    if (T_bound + 1 > h->cap_tiles) { mdx_set_error("internal: tile capacity exceeded"); return MDX_EDEVICE; }
+    if (T_bound + 1 > h->cap_tiles) { *fell_back = true; return MDX_OK; }      // (cannot happen behind setup_grid; if it does, the unfused chain sizes its arrays itself)
     const TileOrderPlan plan = tile_order_plan(h, T_bound);
     const bool prune = !std::isinf(h->r_list) && mdx_nb_variant(h) >= 2;
     static const bool exact_prune = [] { const char* e = std::getenv("MDX_EXACT_PRUNE"); return !(e && e[0] == '0'); }();
@@ -1993,6 +1996,7 @@ int mdx_rebuild(mdx_handle* h) {
     if (!fast) MDX_TRY(mdx_unsort_state(h));  // dynamic state -> caller-order staging
     MDX_TRY(setup_grid(h));
     if (fast && (size_t)h->ncells + 1 > ((size_t)1 << 21)) { fast = false; MDX_TRY(mdx_unsort_state(h)); }   // (the grid scan is a chain of at most 32 windows)
+    if (fast && !h->in_slot_space) fast = false;      // (setup_grid had to grow the slot-space arrays and moved the state to the staging)
     const uint32_t N = h->n_local;   // atoms simulated here (all of them on a single GPU)
     const GridParams g = h->grid;
     hipStream_t st = h->stream;

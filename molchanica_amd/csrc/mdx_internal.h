@@ -284,7 +284,7 @@ struct mdx_handle {
     // the charge mesh is cleared BEHIND the chain that dirtied it (mdx_pme.hip), not in front of the next one
     bool pme_canvas_clean = false, pme_canvas2_clean = false, pme_clear_pending = false, pme_block_spread_used = false, pme_spread_main = false;
     bool pme_overlap = false; hipStream_t stream_pme = nullptr; hipEvent_t ev_pme_fork = nullptr, ev_pme_join = nullptr;
-    double ewald_self = 0.0, ewald_background = 0.0; double total_charge = 0.0, sum_q2 = 0.0;
+    double ewald_self = 0.0, ewald_background = 0.0; double total_charge = 0.0, sum_q2 = 0.0, q_abs_max = 0.0;
     uint32_t n_mobile = 0;
     double total_mass = 0.0;
     std::vector<uint8_t> flags;

@@ -30,6 +30,7 @@ static inline unsigned div_up(unsigned a, unsigned b) { return (a + b - 1) / b; 
 struct PmeDev {
     float lo[3], inv_len[3], scale[3];   // scale = K / L
     int K[3];
+    float fix, unfix;                    // fixed-point scale of the LDS charge canvases and its inverse (PME_FIX below)
 };
 
 struct PmeBrickGeom {
@@ -142,11 +143,15 @@ __global__ __launch_bounds__(256) void pme_spread_kernel(uint32_t S, const float
 // (a sparse tile) falls back to direct atomics.
 // gfx950 retires ds_add_f32 at ONE lane per three clocks and CU - 0.33 lane-adds per clock whatever the addresses, against 10 per
 // clock for ds_add_u32 (tools/ubench/lds_atomic_rate.hip, profiles/r04_lds_atomic_rate_ubench.txt): the LDS canvases of the charge
-// spread therefore accumulate in 32-bit fixed point, 2^-25 e per count.  A mesh point holds the charge of the handful of atoms
-// whose 4^3 support covers it (|sum| < 2 e in condensed matter; the format holds +-64 e), the rounding of one contribution
-// (1.5e-8 e) is that of an fp32 value near 0.25 e, and - integer adds commute - the sum no longer depends on the order of the lanes.
-constexpr float PME_FIX = 33554432.0f;             // 2^25
-constexpr float PME_UNFIX = 1.0f / 33554432.0f;
+// spread therefore accumulate in 32-bit fixed point, and - integer adds commute - the sum no longer depends on the order of the lanes.
+// The values spread are posq.w = q sqrt(k_e) (18.2 per elementary charge), times three spline weights (at most 0.30 together).  The
+// scale PME_FIX = PmeDev::fix is a power of two chosen per handle (mdx_pme_setup) from the largest |q sqrt(k_e)| of the system so that
+// EIGHT atoms of that charge could sit at full weight on one mesh point without the 32-bit sum wrapping - atoms an Angstrom apart put
+// one or two there - and never above 2^25: TIP3P water (15.2 for its oxygen) gets 2^24, i.e. 3e-9 e per count, rounding 1.6e-9 e per
+// contribution (an fp32 value near 0.25 e rounds to 1.5e-8 e), headroom +-7 e of net spline-weighted charge per point; OPC's M site
+// (24.7) gets 2^23, an ion of charge 3 2^22.  (Round 4 used a fixed 2^25 and said "+-64 e": it forgot the sqrt(k_e), the true headroom
+// was +-3.5 e and nothing adapted to large charges.)
+constexpr float PME_FIX_MAX = 33554432.0f;          // 2^25
 constexpr int PME_TB = 14;    // LDS block edge in mesh points
 __global__ __launch_bounds__(256) void pme_spread_tile_kernel(uint32_t T, const float4* __restrict__ posq,
                                                               const uint8_t* __restrict__ slot_flags, PmeDev g,
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(256) void pme_spread_tile_kernel(uint32_t T, const 
             for (int c = 0; c < 4; ++c) {
                 const float v = p.w * mx[a] * my[b] * mz[c];
                 if (fits) {
-                    atomicAdd(&s_q[((lx + a) * PME_TB + (ly + b)) * PME_TB + (lz + c)], __float2int_rn(v * PME_FIX));
+                    atomicAdd(&s_q[((lx + a) * PME_TB + (ly + b)) * PME_TB + (lz + c)], __float2int_rn(v * g.fix));
                 } else {
                     int kx = (k0[0] + a) % g.K[0]; if (kx < 0) kx += g.K[0];
                     int ky = (k0[1] + b) % g.K[1]; if (ky < 0) ky += g.K[1];
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(256) void pme_spread_tile_kernel(uint32_t T, const 
     for (int k = tid; k < PME_TB * PME_TB * PME_TB; k += 256) {
         const int vi = s_q[k];
         if (vi != 0) {
-            const float v = (float)vi * PME_UNFIX;
+            const float v = (float)vi * g.unfix;
             const int lz = k % PME_TB, ly = (k / PME_TB) % PME_TB, lx = k / (PME_TB * PME_TB);
             int kx = (ox + lx) % g.K[0]; if (kx < 0) kx += g.K[0];
             int ky = (oy + ly) % g.K[1]; if (ky < 0) ky += g.K[1];
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(256) void pme_canvas_kernel(PmeBrickArgs a) {
         const int lx = (int)(c & 255u), ly = (int)((c >> 8) & 255u), lz = (int)((c >> 16) & 255u);
         float mx[4], my[4], mz[4], dd[4];
         bspline4(r.x, mx, dd); bspline4(r.y, my, dd); bspline4(r.z, mz, dd);
-        const float qy = r.w * my[yb] * PME_FIX;
+        const float qy = r.w * my[yb] * a.pg.fix;
         int* row = s_q + ((size_t)lx * cb1 + (ly + yb)) * cb2 + lz;     // canvas origin = brick start - 3: cell l holds points l .. l + 3
 #pragma unroll
         for (int qa = 0; qa < 4; ++qa) {
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(256) void pme_combine_kernel(PmeBrickArgs a, size_t
             }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (ok[j]) qrow[kz0 + lane + 64 * j] = (float)v[j] * PME_UNFIX;
+            if (ok[j]) qrow[kz0 + lane + 64 * j] = (float)v[j] * a.pg.unfix;
     }
 }
 
@@ -1009,6 +1014,12 @@ int mdx_pme_setup(mdx_handle* h) {
     for (int d = 0; d < 3; ++d) {
         p->dev.lo[d] = h->box_lo[d]; p->dev.inv_len[d] = (float)(1.0 / L[d]);
         p->dev.scale[d] = (float)(K[d] / L[d]); p->dev.K[d] = K[d];
+    }
+    {   // fixed-point scale of the charge canvases: eight atoms of the largest charge at full weight must fit 2^31 counts
+        const double qmax = std::max(1e-3, h->q_abs_max * std::sqrt((double)h->cfg.coulomb_k));
+        double fix = PME_FIX_MAX;
+        while (fix * qmax * 8.0 > 2147483648.0 && fix > 1.0) fix *= 0.5;
+        p->dev.fix = (float)fix; p->dev.unfix = (float)(1.0 / fix);
     }
     // theta table in fp64 on the host (depends on the box: recomputed by mdx_set_box)
     const double beta = c.ewald_alpha, V = L[0] * L[1] * L[2];

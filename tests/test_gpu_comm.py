@@ -657,6 +657,40 @@ def test_bench_process_per_rank_flow_on_one_gpu(n):
     assert j["value_no_rebuild"] is None or j["value_no_rebuild"] >= j["value"] * 0.999
 
 
+def _torchrun_bench(n, extra_env, extra_args=(), timeout=600):
+    import os, socket, subprocess, sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MDX_BENCH_SAME_GPU="1", MASTER_ADDR="127.0.0.1", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "20", "--warmup", "4",
+           "--workload", "dna100k", "--no-cpu-baseline", "--tail-steps", "0", *extra_args]
+    return subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_falls_back_to_shared_memory_when_rccl_refuses():
+    """First-RCCL-run insurance: the ranks go through the RCCL branch (MDX_BENCH_TRY_RCCL=1); on this box's one device
+    ncclCommInitRank refuses the second rank, every rank says so, a FRESH handle joins over the shared-memory transport in the
+    same process (never a re-exec), the JSON line names the transport it was measured on and every rank exits 0."""
+    import json
+    out = _torchrun_bench(2, {"MDX_BENCH_TRY_RCCL": "1", "MDX_BENCH_COMM_TIMEOUT_S": "90"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "RCCL transport unusable" in out.stderr
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert "RCCL initialisation failed" in j["config"]["parallelism"] and j["value"] > 0
+    assert j["multi_gpu"]["transport"].startswith("shared memory") and j["multi_gpu"]["rccl_world"] == 0
+
+
+def test_bench_watchdog_names_the_phase_when_a_peer_never_arrives():
+    """... and a rank whose peer never reaches mdx_comm_init does not hang to the driver's limit: its watchdog prints rank, phase and
+    rendezvous address and exits non-zero."""
+    out = _torchrun_bench(2, {"MDX_BENCH_TRY_RCCL": "1", "MDX_BENCH_FAIL_RANK": "1", "MDX_BENCH_COMM_TIMEOUT_S": "8"}, timeout=300)
+    assert out.returncode != 0
+    assert "MDX_BENCH_FAIL_RANK" in out.stderr
+    assert "watchdog: mdx_comm_init" in out.stderr or "RCCL transport unusable" in out.stderr, out.stderr[-2000:]      # (RCCL may also refuse outright on one device)
+
+
 def test_shared_memory_transport_matches_single_gpu():
     """Two PROCESSES on the one GPU through the shared-memory transport: energies and a 30-step trajectory of the decomposed box
     equal the single-handle run (the process-level twin of the thread + fabric tests above)."""

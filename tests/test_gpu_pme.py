@@ -115,3 +115,39 @@ def test_spme_follows_the_box_and_rejects_bad_setups(mdx):
     with pytest.raises(mdx.ParamError):
         mdx.MdState(s, MdConfig(lj_cutoff=7.0, coulomb_cutoff=7.0, skin=1.0, coulomb_mode=_abi.COULOMB_EWALD,
                                 ewald_alpha=0.4, overrides=0, pme_order=6))
+
+
+@pytest.mark.parametrize("brick", ["0", "1"])
+def test_large_like_signed_charges_on_a_coarse_mesh(mdx, brick, monkeypatch):
+    """The LDS canvases of the charge spread accumulate in 32-bit fixed point (mdx_pme.hip, PME_FIX).  The scale is chosen per handle
+    from the largest |q sqrt(k_e)| of the system: charges of +-4 e on a 2.3 A mesh - more spline-weighted charge per mesh point than
+    the fixed 2^25 of round 4 could hold (it wrapped, silently, beyond +-3.5 e) - must give the mesh the fp64 restatement gives."""
+    from oracle import pme_ref as P
+    monkeypatch.setenv("MDX_PME_SPREAD_BRICK", brick)
+    s = systems.water_box(6, seed=4)
+    rng = np.random.default_rng(2)
+    q = s.charge.copy()
+    big = rng.choice(s.n_atoms, size=40, replace=False)
+    q[big] = 4.0
+    q[rng.choice(np.setdiff1d(np.arange(s.n_atoms), big), size=40, replace=False)] = -4.0
+    q -= q.mean()                                   # neutral cell
+    s.charge = q.astype(np.float32)
+    L = float(s.box_hi[0])
+    beta, grid = 0.35, (8, 8, 8)                    # 18.6 A / 8 = 2.3 A per mesh point (the smallest mesh the library takes): many atoms per point
+    base = dict(lj_cutoff=8.0, coulomb_cutoff=8.0, skin=1.0, coulomb_mode=_abi.COULOMB_EWALD, ewald_alpha=beta)
+    with mdx.MdState(s, MdConfig(overrides=_abi.OVR_LONG_RANGE_RECIP_DISABLED, **base)) as md:
+        pos = md.positions()
+        f_real = md.forces().astype(np.float64)
+    with mdx.MdState(s, MdConfig(overrides=0, pme_grid=grid, **base)) as md:
+        f_full = md.forces().astype(np.float64)
+        e_full = md.energy()
+    box = np.full(3, L)
+    q64 = s.charge.astype(np.float64)
+    e_ref, f_ref = P.spme_recip(pos.astype(np.float64), q64, (0, 0, 0), box, beta, grid, 4)
+    e_x, f_x = P.excluded_pair_correction(pos.astype(np.float64), q64, excluded_pairs(s), box, beta)
+    e_ref += e_x + P.ewald_self_energy(q64, beta) + P.ewald_background_energy(q64, box, beta)
+    f_ref += f_x
+    f_rec = f_full - f_real
+    err = math.sqrt(((f_rec - f_ref) ** 2).sum(1).mean()) / math.sqrt((f_ref ** 2).sum(1).mean())
+    assert err < 3e-4, f"reciprocal force rms error {err:.2e} vs the numpy SPME on the same mesh"
+    assert e_full["coulomb_recip"] == pytest.approx(e_ref, rel=3e-5, abs=5e-2)
