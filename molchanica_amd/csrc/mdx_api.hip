@@ -147,7 +147,7 @@ static void free_device(mdx_handle* h) {
                     d.mchunk_cnt, d.mchunk_off, d.entries, d.entries_in, d.inner_nch, d.list_cursors, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
                     d.role_off_s, d.role_rec_s, d.role_prm, d.ctl, d.energy,
                     d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.pme_force, d.cons_o, d.cons_s, d.cons_tmp, d.cons_mask, d.cons_cnt, d.cons_off, d.cons_vir, d.vsite_o, d.vsite_s, d.gsite_o, d.gsite_s, d.gsite_tmp, d.pme_q, d.pme_f,
-                    d.pme_theta, d.pme_q2, d.pme_f2, d.scratch4, d.tile_bnd, d.tile_scan, d.tile_order, d.tile_lpt, d.rb_ctl, d.scan_chain, d.grp, d.grp_mat, d.star_o, d.star_s};
+                    d.pme_theta, d.pme_q2, d.pme_f2, d.scratch4, d.tile_bnd, d.tile_scan, d.tile_order, d.tile_lpt, d.rb_ctl, d.scan_chain, d.grp, d.grp_mat, d.star_o, d.star_s, d.ewald_tab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = DeviceState{};
 }
@@ -377,6 +377,7 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
     HIP_TRY(hipStreamSynchronize(st));  // host vectors go out of scope
     h->in_slot_space = false; h->list_valid = false; h->forces_valid = false;
     MDX_TRY(mdx_build_constraints(h, s));
+    MDX_TRY(mdx_build_ewald_table(h));
     h->cons_dirty = mdx_has_constraints(h);
     MDX_TRY(mdx_pme_setup(h));
     MDX_TRY(mdx_rebuild(h));

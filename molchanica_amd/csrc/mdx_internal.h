@@ -84,6 +84,9 @@ struct NbParams {
     float sc_al, sc_alpha, sc_sigmin;   // soft core of those pairs: r_sc^6 = sc_al sigma^6 + r^6, sc_al = alpha lambda (0: linear coupling)
     int geometric;           // combining rule
     int lj_on, coul_on;
+    // Ewald real space, force flavour: the smooth part g(r^2) = [erf(beta r)/r - 2 beta/sqrt(pi) exp(-beta^2 r^2)] / r^2 from a table
+    // (mdx_pair_dev.h: EWALD_TAB_*): F/r = q q (1/r^3 - g) without v_exp / v_rcp in the pair loop.  null: the closed form.
+    const float2* etab; uint32_t etab_n;
 };
 
 struct BondedParams {
@@ -247,6 +250,7 @@ struct DeviceState {
     unsigned long long* scan_chain = nullptr;   // [64] chained-window scans: (generation << 32) | running total per window, then the windows' done ticks
     // energy between molecules / groups (mdx_groups.hip): group of every GLOBAL atom, and the raw n x n sums
     uint8_t* grp = nullptr; double* grp_mat = nullptr;
+    float2* ewald_tab = nullptr;   // Ewald real space: table of the smooth part of the force (mdx_pair_dev.h)
 };
 
 struct MdxDecomp;   // mdx_comm.h: the handle is one rank of a spatially decomposed box
@@ -284,6 +288,7 @@ struct mdx_handle {
     // the charge mesh is cleared BEHIND the chain that dirtied it (mdx_pme.hip), not in front of the next one
     bool pme_canvas_clean = false, pme_canvas2_clean = false, pme_clear_pending = false, pme_block_spread_used = false, pme_spread_main = false;
     bool pme_overlap = false; hipStream_t stream_pme = nullptr; hipEvent_t ev_pme_fork = nullptr, ev_pme_join = nullptr;
+    uint32_t ewald_tab_n = 0;
     double ewald_self = 0.0, ewald_background = 0.0; double total_charge = 0.0, sum_q2 = 0.0, q_abs_max = 0.0;
     uint32_t n_mobile = 0;
     double total_mass = 0.0;
@@ -431,6 +436,7 @@ int mdx_order_tiles_by_length(mdx_handle* h, bool grouped);   // tile_lpt: longe
 // part: 0 = every tile; 1 = the interior tiles of a decomposed handle (no ghost in their lists: they run while the halo
 // message is in flight); 2 = its boundary tiles (after the unpack)
 int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr_bits, int part = 0);
+int mdx_build_ewald_table(mdx_handle* h);     // (mdx_nonbonded.hip) at creation: depends on ewald_alpha and the cut-offs
 int mdx_launch_bonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr_bits);
 bool mdx_bonded_wanted(const mdx_handle* h);                       // there are bonded roles to evaluate in a force call
 void mdx_fill_bonded_params(const mdx_handle* h, BondedParams& p);

@@ -37,6 +37,8 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 
 // the kernels and their launcher live in mdx_nonbonded_impl.h and are instantiated per (ENERGY, COUL) in mdx_nb_inst.hip
 template <bool ENERGY, int COUL>
@@ -74,6 +76,39 @@ void mdx_fill_nb_params(const mdx_handle* h, NbParams& p, int* mode_out, bool* g
         if (ccut) p.coul_shift = 1.0f / rc;
     }
     *mode_out = mode; *geom_out = c.combining_rule == MDX_COMBINE_GEOMETRIC; *samecut_out = p.rc2_lj == p.rc2_coul;
+    // Ewald real space: the table of the smooth part (MDX_EWALD_TABLE=0: the closed form, A/B)
+    static const bool tab_on = [] { const char* e = std::getenv("MDX_EWALD_TABLE"); return !(e && e[0] == '0'); }();
+    p.etab = (mode == CM_EWALD && tab_on) ? h->d.ewald_tab : nullptr;
+    p.etab_n = p.etab ? h->ewald_tab_n : 0u;
+}
+
+// g(r^2) = [erf(beta r)/r - 2 beta/sqrt(pi) exp(-beta^2 r^2)] / r^2 at the nodes of the bit-indexed table (mdx_pair_dev.h), in fp64
+int mdx_build_ewald_table(mdx_handle* h) {
+    if (h->d.ewald_tab) { (void)hipFree(h->d.ewald_tab); h->d.ewald_tab = nullptr; }
+    h->ewald_tab_n = 0;
+    const mdx_config& c = h->cfg;
+    if (c.coulomb_mode != MDX_COULOMB_EWALD || !cut_on(c.lj_cutoff) || !cut_on(c.coulomb_cutoff)) return MDX_OK;
+    const double beta = c.ewald_alpha, rmax = std::max(c.lj_cutoff, c.coulomb_cutoff);
+    auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    const uint32_t k_last = (bits((float)(rmax * rmax * 1.0001) + EWALD_TAB_C) >> EWALD_TAB_SHIFT) - EWALD_TAB_OFF;
+    if (k_last + 2 > EWALD_TAB_MAX) return MDX_OK;      // a cutoff beyond ~22 A: the closed form stays
+    auto g = [&](double r2) {
+        const double z2 = beta * beta * r2;
+        if (z2 < 1e-2) return beta * beta * beta * 1.1283791670955126 * (2.0 / 3.0 - 0.4 * z2 + z2 * z2 / 7.0 - z2 * z2 * z2 / 27.0);
+        const double r = std::sqrt(r2);
+        return (std::erf(beta * r) / r - 1.1283791670955126 * beta * std::exp(-z2)) / r2;
+    };
+    std::vector<float2> tab(k_last + 2);
+    for (uint32_t k = 0; k < tab.size(); ++k) {
+        const uint32_t b0 = (k + EWALD_TAB_OFF) << EWALD_TAB_SHIFT, b1 = (k + 1 + EWALD_TAB_OFF) << EWALD_TAB_SHIFT;
+        float x0, x1; std::memcpy(&x0, &b0, 4); std::memcpy(&x1, &b1, 4);
+        const double g0 = g((double)x0 - EWALD_TAB_C), g1 = g((double)x1 - EWALD_TAB_C);
+        tab[k] = make_float2((float)g0, (float)((g1 - g0) / ((double)x1 - (double)x0)));
+    }
+    HIP_TRY(hipMalloc((void**)&h->d.ewald_tab, sizeof(float2) * tab.size()));
+    HIP_TRY(hipMemcpy(h->d.ewald_tab, tab.data(), sizeof(float2) * tab.size(), hipMemcpyHostToDevice));
+    h->ewald_tab_n = (uint32_t)tab.size();
+    return MDX_OK;
 }
 
 int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr_bits, int part) {
