@@ -86,7 +86,8 @@ struct NbParams {
     int lj_on, coul_on;
     // Ewald real space, force flavour: the smooth part g(r^2) = [erf(beta r)/r - 2 beta/sqrt(pi) exp(-beta^2 r^2)] / r^2 from a table
     // (mdx_pair_dev.h: EWALD_TAB_*): F/r = q q (1/r^3 - g) without v_exp / v_rcp in the pair loop.  null: the closed form.
-    const float2* etab; uint32_t etab_n;
+    const float4* etab; uint32_t etab_n;
+    float etab_scale; uint32_t etab_shift;      // x = r^2 * etab_scale + EWALD_TAB_C; index = (bits(x) >> etab_shift) - (bits(EWALD_TAB_C) >> etab_shift)
 };
 
 struct BondedParams {
@@ -250,7 +251,7 @@ struct DeviceState {
     unsigned long long* scan_chain = nullptr;   // [64] chained-window scans: (generation << 32) | running total per window, then the windows' done ticks
     // energy between molecules / groups (mdx_groups.hip): group of every GLOBAL atom, and the raw n x n sums
     uint8_t* grp = nullptr; double* grp_mat = nullptr;
-    float2* ewald_tab = nullptr;   // Ewald real space: table of the smooth part of the force (mdx_pair_dev.h)
+    float4* ewald_tab = nullptr;   // Ewald real space: table of the smooth part of the force (mdx_pair_dev.h)
 };
 
 struct MdxDecomp;   // mdx_comm.h: the handle is one rank of a spatially decomposed box
@@ -288,7 +289,7 @@ struct mdx_handle {
     // the charge mesh is cleared BEHIND the chain that dirtied it (mdx_pme.hip), not in front of the next one
     bool pme_canvas_clean = false, pme_canvas2_clean = false, pme_clear_pending = false, pme_block_spread_used = false, pme_spread_main = false;
     bool pme_overlap = false; hipStream_t stream_pme = nullptr; hipEvent_t ev_pme_fork = nullptr, ev_pme_join = nullptr;
-    uint32_t ewald_tab_n = 0;
+    uint32_t ewald_tab_n = 0, ewald_tab_shift = 16; float ewald_tab_scale = 1.f;
     double ewald_self = 0.0, ewald_background = 0.0; double total_charge = 0.0, sum_q2 = 0.0, q_abs_max = 0.0;
     uint32_t n_mobile = 0;
     double total_mass = 0.0;

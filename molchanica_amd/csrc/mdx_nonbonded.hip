@@ -80,34 +80,39 @@ void mdx_fill_nb_params(const mdx_handle* h, NbParams& p, int* mode_out, bool* g
     static const bool tab_on = [] { const char* e = std::getenv("MDX_EWALD_TABLE"); return !(e && e[0] == '0'); }();
     p.etab = (mode == CM_EWALD && tab_on) ? h->d.ewald_tab : nullptr;
     p.etab_n = p.etab ? h->ewald_tab_n : 0u;
+    p.etab_scale = h->ewald_tab_scale; p.etab_shift = h->ewald_tab_shift;
 }
 
-// g(r^2) = [erf(beta r)/r - 2 beta/sqrt(pi) exp(-beta^2 r^2)] / r^2 at the nodes of the bit-indexed table (mdx_pair_dev.h), in fp64
+// g(r^2) = [erf(beta r)/r - 2 beta/sqrt(pi) exp(-beta^2 r^2)] / r^2 over the intervals of the bit-indexed table (mdx_pair_dev.h), in fp64
 int mdx_build_ewald_table(mdx_handle* h) {
     if (h->d.ewald_tab) { (void)hipFree(h->d.ewald_tab); h->d.ewald_tab = nullptr; }
     h->ewald_tab_n = 0;
     const mdx_config& c = h->cfg;
     if (c.coulomb_mode != MDX_COULOMB_EWALD || !cut_on(c.lj_cutoff) || !cut_on(c.coulomb_cutoff)) return MDX_OK;
     const double beta = c.ewald_alpha, rmax = std::max(c.lj_cutoff, c.coulomb_cutoff);
+    const double scale = std::max(1.0, (beta / 0.3) * (beta / 0.3));
+    const uint32_t sh = beta > 0.36 ? 16u : 17u;      // mantissa bits kept: 7 or 6
     auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
-    const uint32_t k_last = (bits((float)(rmax * rmax * 1.0001) + EWALD_TAB_C) >> EWALD_TAB_SHIFT) - EWALD_TAB_OFF;
-    if (k_last + 2 > EWALD_TAB_MAX) return MDX_OK;      // a cutoff beyond ~22 A: the closed form stays
-    auto g = [&](double r2) {
-        const double z2 = beta * beta * r2;
+    auto flt = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+    const uint32_t off = EWALD_TAB_CBITS >> sh;
+    const uint32_t k_last = (bits((float)(rmax * rmax * 1.0001 * scale) + EWALD_TAB_C) >> sh) - off;
+    if (k_last + 2 > EWALD_TAB_MAX) return MDX_OK;      // beta rc far beyond the usual 3: the closed form stays
+    auto g = [&](double x) {
+        const double r2 = std::max(0.0, (x - (double)EWALD_TAB_C) / scale), z2 = beta * beta * r2;
         if (z2 < 1e-2) return beta * beta * beta * 1.1283791670955126 * (2.0 / 3.0 - 0.4 * z2 + z2 * z2 / 7.0 - z2 * z2 * z2 / 27.0);
         const double r = std::sqrt(r2);
         return (std::erf(beta * r) / r - 1.1283791670955126 * beta * std::exp(-z2)) / r2;
     };
-    std::vector<float2> tab(k_last + 2);
-    for (uint32_t k = 0; k < tab.size(); ++k) {
-        const uint32_t b0 = (k + EWALD_TAB_OFF) << EWALD_TAB_SHIFT, b1 = (k + 1 + EWALD_TAB_OFF) << EWALD_TAB_SHIFT;
-        float x0, x1; std::memcpy(&x0, &b0, 4); std::memcpy(&x1, &b1, 4);
-        const double g0 = g((double)x0 - EWALD_TAB_C), g1 = g((double)x1 - EWALD_TAB_C);
-        tab[k] = make_float2((float)g0, (float)((g1 - g0) / ((double)x1 - (double)x0)));
+    std::vector<float4> tab(k_last + 2);
+    for (uint32_t k = 0; k < tab.size(); ++k) {      // the parabola through both ends and the middle of the interval
+        const double x0 = flt((k + off) << sh), x1 = flt((k + 1 + off) << sh), hh = x1 - x0;
+        const double g0 = g(x0), gm = g(x0 + 0.5 * hh), g1 = g(x1);
+        const double cq = 2.0 * (g0 - 2.0 * gm + g1) / (hh * hh), bq = (g1 - g0) / hh - cq * hh;
+        tab[k] = make_float4((float)g0, (float)bq, (float)cq, 0.f);
     }
-    HIP_TRY(hipMalloc((void**)&h->d.ewald_tab, sizeof(float2) * tab.size()));
-    HIP_TRY(hipMemcpy(h->d.ewald_tab, tab.data(), sizeof(float2) * tab.size(), hipMemcpyHostToDevice));
-    h->ewald_tab_n = (uint32_t)tab.size();
+    HIP_TRY(hipMalloc((void**)&h->d.ewald_tab, sizeof(float4) * tab.size()));
+    HIP_TRY(hipMemcpy(h->d.ewald_tab, tab.data(), sizeof(float4) * tab.size(), hipMemcpyHostToDevice));
+    h->ewald_tab_n = (uint32_t)tab.size(); h->ewald_tab_scale = (float)scale; h->ewald_tab_shift = sh;
     return MDX_OK;
 }
 

@@ -225,7 +225,7 @@ __device__ __forceinline__ float dpp_xadd(float v) {
 template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF, bool ALCH, int DUAL, int BW>
 __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owned_prune, float4 (*s_xyzq)[64], float2 (*s_lj)[64],
                                                 float (*s_red)[3][64], float (*s_ownj)[64], float4 (*s_g)[64],
-                                                unsigned long long (*s_mask)[64], const float2* __restrict__ etab = nullptr) {
+                                                unsigned long long (*s_mask)[64], const float4* __restrict__ etab = nullptr) {
     // the wave index is wave-uniform: say so, and tile number, list bounds and the chunk loop
     // live in SGPRs with scalar branches instead of VGPR compares and exec-mask loops
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -579,7 +579,7 @@ __device__ __forceinline__ void bonded_workgroup(const NbArgs& a, uint32_t wg, u
 template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF, bool ALCH, int DUAL, int BW>
 __device__ __attribute__((noinline)) void nb_cluster_body_call(const NbArgs& a, const bool owned_prune, float4 (*s_xyzq)[64], float2 (*s_lj)[64],
                                                                float (*s_red)[3][64], float (*s_ownj)[64], float4 (*s_g)[64],
-                                                               unsigned long long (*s_mask)[64], const float2* __restrict__ etab = nullptr) {
+                                                               unsigned long long (*s_mask)[64], const float4* __restrict__ etab = nullptr) {
     nb_cluster_body<ENERGY, COUL, GEOM, SAMECUT, WPT, HALF, ALCH, DUAL, BW>(a, owned_prune, s_xyzq, s_lj, s_red, s_ownj, s_g, s_mask, etab);
 }
 
@@ -605,8 +605,8 @@ __global__ __launch_bounds__((SPLIT > 1 ? WPT / SPLIT : (WPT > NB_WAVES ? WPT : 
     __shared__ float4 s_g[HALF ? BW : 1][64];                 // minus the chunk's j-forces (.w: the j-slot), until flushed
     __shared__ unsigned long long s_mask[BW][64];             // a masked chunk's per-lane exclusion bits
     // Ewald force flavour: the table of the smooth part (mdx_pair_dev.h) in dynamic LDS, one copy per workgroup
-    extern __shared__ float2 s_dyn_etab[];
-    const float2* etab = nullptr;
+    extern __shared__ float4 s_dyn_etab[];
+    const float4* etab = nullptr;
     if (COUL == CM_EWALD && !ENERGY && !ALCH && a.p.etab) {
         for (uint32_t k = threadIdx.x; k < a.p.etab_n; k += BW * 64) s_dyn_etab[k] = a.p.etab[k];
         __syncthreads();
@@ -659,7 +659,7 @@ void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samecut) {
     // workgroups per CU and leaves registers and LDS for the chain.
     static const uint32_t lds_pad_env = [] { const char* e = std::getenv("MDX_NB_LDS_PAD"); return e ? (uint32_t)std::atoi(e) : 0u; }();
     const uint32_t lds_pad = ((h->pme_on && h->pme_overlap && !ENERGY) ? lds_pad_env : 0u) +
-                             ((COUL == CM_EWALD && !ENERGY && !h->alch_on && a.p.etab) ? a.p.etab_n * (uint32_t)sizeof(float2) : 0u);      // + the Ewald table
+                             ((COUL == CM_EWALD && !ENERGY && !h->alch_on && a.p.etab) ? a.p.etab_n * (uint32_t)sizeof(float4) : 0u);      // + the Ewald table
     // ONE kernel picks the inner-walk or the pruning body on the device (round 2 measured the merged launch at +1 % for 23 k atoms
     // and -0.4 % at 1 M, and launched the two flavours back to back for the large classes, the device running exactly one; since
     // the chunk loop exists twice the merged kernel is faster there too: the gated-off twin was ~5 us of a 550 us step).

@@ -47,16 +47,17 @@ struct NbArgs {
 enum { CM_SHIFTED = 0, CM_RF = 1, CM_EWALD = 2, CM_SOFT = 3 };
 
 // Table of the smooth part of the Ewald real-space force (round 5).  erfc(beta r)/r^3 + 2 beta/sqrt(pi) exp(-beta^2 r^2)/r^2 =
-// 1/r^3 - g(r^2) with g = [erf(beta r)/r - 2 beta/sqrt(pi) exp(-beta^2 r^2)] / r^2: bounded (4 beta^3 / (3 sqrt(pi)) at r = 0), smooth,
-// with nearly all of its curvature below beta r ~ 1.5.  The table is indexed by the FLOAT BITS of x = r^2 + EWALD_TAB_C - seven mantissa
-// bits per octave: spacing 0.031 A^2 below r = 2 A, 0.5 A^2 at 10 A - so ~600 entries (4.7 kB, staged in LDS by every workgroup) do
-// what 2048 uniform ones do: max |g error| 2e-8 = 1e-5 kcal/mol/A on the strongest pair of OPC water, below the 1.5e-7 the erfc
-// formula it replaces carries.  An entry holds g at its node and the slope to the next: g = entry.x + (x - node) * entry.y, node =
-// x with the low 16 bits cleared.  Per pair: 2 adds, 2 ands, 1 shift, 1 sub, one ds_read_b64, 1 fma - against two quarter-rate
-// transcendentals (v_exp_f32, v_rcp_f32) and 12 VALU of the closed form.  Energies keep the closed form (they need erfc itself).
+// 1/r^3 - g(r^2) with g = [erf(beta r)/r - 2 beta/sqrt(pi) exp(-beta^2 r^2)] / r^2: bounded (4 beta^3 / (3 sqrt(pi)) at r = 0) and
+// smooth.  The table is indexed by the FLOAT BITS of x = r^2 s + EWALD_TAB_C, s = max(1, (beta / 0.3)^2) - six mantissa bits per octave
+// (seven above beta = 0.36) - and holds a PARABOLA per interval (through g at both ends and the middle): g = a + dx (b + dx c), dx = x -
+// node, node = x with the low bits cleared.  ~300 entries of 16 bytes (4.8 kB, staged in LDS by every workgroup).  Max |g error| 2e-9 at
+// beta 0.3 (fp32 evaluation included): 2e-6 kcal/mol/A on the strongest pair of OPC water at any distance - below the erfc formula it replaces (|error|
+// 1.5e-7 in erfc) - growing with beta^3 only (s keeps the resolution in beta^2 r^2).  (Straight lines need ~2000 entries for that: the
+// 1/r^3 tail of g keeps its curvature; 600 log-spaced lines left 7e-5 per pair.)  Per pair: three fma, two ands, shift, two subs, one
+// ds_read_b128 - against two quarter-rate transcendentals (v_exp_f32, v_rcp_f32) and 12 VALU of the closed form.  Energies keep the
+// closed form (they need erfc itself).
 #define EWALD_TAB_C 4.0f
-#define EWALD_TAB_SHIFT 16
-#define EWALD_TAB_OFF (0x40800000u >> EWALD_TAB_SHIFT)      // the bits of 4.0f
+#define EWALD_TAB_CBITS 0x40800000u      // the bits of 4.0f
 #define EWALD_TAB_MAX 1024u
 
 // One pair, seen from atom i: adds the force on i.  `allowed` carries the exclusion mask bit.
@@ -82,7 +83,7 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
                                           float& fx, float& fy, float& fz, float& elj, float& ecoul,
                                           float* g = nullptr, float* evir = nullptr, float* ecross = nullptr,
                                           float r2bias = 0.f, float* r2_out = nullptr, float* edudl = nullptr,
-                                          const float2* __restrict__ etab = nullptr) {
+                                          const float4* __restrict__ etab = nullptr) {
     static_assert(!NANMASK || BRANCHY, "the NaN-coded exclusion needs the early-out");
     const float dx = xi - pj.x, dy = yi - pj.y, dz = zi - pj.z;   // tgt - src (src/cuda/util.cu:118-140)
     const float r2 = NANMASK ? __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, r2bias)))
@@ -125,10 +126,11 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
     else if (COUL == CM_RF) fc_r2 = qq * (rinv - p.k_rf2 * r2e);
     float erfc_ar = 0.f;
     if (COUL == CM_EWALD && !ENERGY && !ALCH && etab) {
-        const float x = r2e + EWALD_TAB_C;
-        const uint32_t xb = __float_as_uint(x);
-        const float2 en = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(etab) + (((xb >> (EWALD_TAB_SHIFT - 3)) & ~7u) - (EWALD_TAB_OFF << 3)));
-        const float gsm = __builtin_fmaf(x - __uint_as_float(xb & (0xFFFFFFFFu << EWALD_TAB_SHIFT)), en.y, en.x);
+        const float x = __builtin_fmaf(r2e, p.etab_scale, EWALD_TAB_C);
+        const uint32_t xb = __float_as_uint(x), sh = p.etab_shift;
+        const float4 en = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(etab) + (((xb >> (sh - 4u)) & ~15u) - ((EWALD_TAB_CBITS >> sh) << 4)));
+        const float dxt = x - __uint_as_float(xb & (0xFFFFFFFFu << sh));
+        const float gsm = __builtin_fmaf(dxt, __builtin_fmaf(dxt, en.z, en.y), en.x);
         fc_r2 = qq * __builtin_fmaf(-gsm, r2e, rinv);
     } else if (COUL == CM_EWALD) {
         // erfc by Abramowitz & Stegun 7.1.26 (|error| < 1.5e-7) sharing the exponential the force

@@ -1,9 +1,9 @@
 #!/bin/bash
 # One call that collects the round's evidence on the GPU box: bash tools/final_evidence.sh TAG   (outputs under gpurun_out/TAG_final/)
-TAG=${1:-r04}; F=$PWD/gpurun_out/${TAG}_final; mkdir -p "$F"; export TMPDIR=/tmp
+TAG=${1:-r05}; F=$PWD/gpurun_out/${TAG}_final; mkdir -p "$F"; export TMPDIR=/tmp
 bash tools/profile_round.sh $TAG > "$F/profile_round.log" 2>&1
 for w in dhfr23k complex50k dna100k; do python3 bench.py --workload $w --steps 3000 --warmup 200 --no-cpu-baseline > "$F/bench_$w.json" 2> /dev/null; done
-for n in 2 4 8; do python3 tools/one_rank_profile.py $n 192 2>/dev/null | grep "^world" >> "$F/one_rank.txt"; done
+for n in 2 4 8; do ONE_RANK_WIRE=",0,25" ONE_RANK_SPLIT="1,0" python3 tools/one_rank_profile.py $n 192 2>/dev/null | grep "^world" >> "$F/one_rank.txt"; done
 python3 tools/default_point_time.py 64 > "$F/dp64.txt" 2>/dev/null
 python3 tools/default_point_time.py 18 > "$F/dp18.txt" 2>/dev/null
 MDX_PME_OVERLAP=0 bash tools/kt_default_point_single.sh ${TAG}_final_serial 64 > "$F/dp_serial.txt" 2>&1
