@@ -387,6 +387,20 @@ uint32_t mdx_snapshot_count(const mdx_handle* h);
 int      mdx_snapshot_read(mdx_handle* h, uint32_t k, double* time_ps, uint64_t* step, mdx_energies* e,
                            float* pos /* [3N] */, float* vel_or_null /* [3N] */);
 int      mdx_flush_snapshot_queues(mdx_handle* h);       /* drop the stored snapshots (after the host cloned them) */
+/* `MdConfig.snapshot_handlers { memory: Option<every_n>, dcd: Option<every_n>, gromacs: OutputControl { nstxout, nstvout, nstfout,
+ * nstenergy, nstcalcenergy, nstxout_compressed } }`  [ref: src/properties/water_sol.rs:185-189; src/properties/crystal.rs:335-342;
+ * src/ui/panels/md.rs:775-899]: every handler with its own cadence, below the ABI.  A snapshot is stored after every step that is a
+ * multiple of ANY handler's cadence (0 = handler off); it always carries time, step, energies and positions, velocities when the
+ * nstvout handler (or mdx_set_snapshot_cadence's with_velocities) is due, forces when nstfout is due; mdx_snapshot_handler_mask says
+ * which handlers wanted it (bit MDX_SNAP_*; bit 31: the plain cadence of mdx_set_snapshot_cadence), so the host feeds each of its
+ * writers - the in-memory list, the DCD / TRR / XTC / EDR files, which stay on the Rust side - exactly the frames it asked for.
+ * Energies of the steps nstenergy / nstcalcenergy name are evaluated inside the step loop (as with mdx_set_energy_cadence). */
+#define MDX_SNAP_HANDLERS 8
+enum { MDX_SNAP_MEMORY = 0, MDX_SNAP_DCD = 1, MDX_SNAP_NSTXOUT = 2, MDX_SNAP_NSTVOUT = 3, MDX_SNAP_NSTFOUT = 4, MDX_SNAP_NSTENERGY = 5,
+       MDX_SNAP_NSTCALCENERGY = 6, MDX_SNAP_NSTXOUT_COMPRESSED = 7 };
+int      mdx_set_snapshot_handlers(mdx_handle* h, const uint32_t every_n[MDX_SNAP_HANDLERS] /* NULL: all off */);
+uint32_t mdx_snapshot_handler_mask(const mdx_handle* h, uint32_t k);
+int      mdx_snapshot_read_forces(mdx_handle* h, uint32_t k, float* frc /* [3N] */);
 
 /* ---- md.water and the water / hydrogen-bond part of a Snapshot -------------------------------------------------------
  * The reference keeps solvent water apart from `md.atoms`: `md.water[i].{o,h0,h1,m}.{posit,force}`

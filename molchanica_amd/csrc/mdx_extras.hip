@@ -360,16 +360,29 @@ static void detect_hbonds(const mdx_handle* h, const float* pos, std::vector<mdx
     }
 }
 
+// which handlers of mdx_set_snapshot_handlers want the state after `step` (bit i: handler i); the plain cadence is bit 31
+static uint32_t snapshot_mask_at(const mdx_handle* h, uint64_t step) {
+    uint32_t m = (h->snap_every && step % h->snap_every == 0) ? 0x80000000u : 0u;
+    for (int i = 0; i < MDX_SNAP_HANDLERS; ++i) if (h->snap_handlers[i] && step % h->snap_handlers[i] == 0) m |= 1u << i;
+    return m;
+}
 static int take_snapshot(mdx_handle* h) {
     mdx_handle::Snapshot sn;
     sn.time = h->time_ps; sn.step = h->step_count;
+    sn.handler_mask = snapshot_mask_at(h, h->step_count);
+    const bool want_vel = h->snap_vel || (sn.handler_mask & (1u << MDX_SNAP_NSTVOUT));
+    const bool want_frc = (sn.handler_mask & (1u << MDX_SNAP_NSTFOUT)) != 0;
     MDX_TRY(mdx_energy_impl(h, &sn.e));
     const uint32_t n_rows = h->dd ? h->N : h->n_local;     // (a decomposed handle's read-back is the gathered global array)
     sn.pos.resize(3 * (size_t)n_rows);
     MDX_TRY(mdx_download(h, MDX_POS, sn.pos.data()));
-    if (h->snap_vel) {
+    if (want_vel) {
         sn.vel.resize(3 * (size_t)n_rows);
         MDX_TRY(mdx_download(h, MDX_VEL, sn.vel.data()));
+    }
+    if (want_frc) {
+        sn.frc.resize(3 * (size_t)n_rows);
+        MDX_TRY(mdx_download(h, MDX_FORCE, sn.frc.data()));
     }
     if (!h->hb_heavy.empty() && n_rows == h->N) detect_hbonds(h, sn.pos.data(), sn.hbonds);
     if (h->n_grp) {      // SnapshotEnergyData.energy_potential_between_mols (src/properties/crystal.rs:533)
@@ -387,6 +400,7 @@ uint32_t mdx_steps_to_next_event(const mdx_handle* h) {
     if (h->zero_com) upd(h->tstat_kind ? h->tstat_every : 100u);
     if (h->baro_kind) upd(h->baro_every);
     upd(h->snap_every);
+    for (int i = 0; i < MDX_SNAP_HANDLERS; ++i) upd(h->snap_handlers[i]);
     upd(h->energy_every);
     return n;
 }
@@ -394,7 +408,7 @@ uint32_t mdx_steps_to_next_event(const mdx_handle* h) {
 bool mdx_energy_wanted_at(const mdx_handle* h, uint64_t step) {
     static const bool off = [] { const char* e = std::getenv("MDX_ENERGY_IN_STEP"); return e && e[0] == '0'; }();   // A/B: evaluate afresh when asked
     if (off) return false;
-    return (h->energy_every && step % h->energy_every == 0) || (h->snap_every && step % h->snap_every == 0) ||
+    return (h->energy_every && step % h->energy_every == 0) || snapshot_mask_at(h, step) != 0u ||
            (h->baro_kind && h->baro_every && step % h->baro_every == 0);
 }
 
@@ -405,7 +419,7 @@ int mdx_after_steps(mdx_handle* h, float dt, uint32_t done) {
     if (h->tstat_kind && sc % h->tstat_every == 0) MDX_TRY(apply_thermostat(h, (double)dt * h->tstat_every));
     MDX_TRY(mdx_finalize_energy_cache(h));      // (behind the thermostat: the kinetic energy is the coupled one)
     if (h->baro_kind && sc % h->baro_every == 0) MDX_TRY(apply_barostat(h, (double)dt * h->baro_every));
-    if (h->snap_every && sc % h->snap_every == 0) MDX_TRY(take_snapshot(h));
+    if (snapshot_mask_at(h, sc) != 0u) MDX_TRY(take_snapshot(h));
     return MDX_OK;
 }
 
@@ -521,6 +535,22 @@ extern "C" int mdx_snapshot_read_between_mols(mdx_handle* h, uint32_t k, float* 
 }
 extern "C" double mdx_time_ps(const mdx_handle* h) { return h ? h->time_ps : 0.0; }
 
+extern "C" int mdx_set_snapshot_handlers(mdx_handle* h, const uint32_t every_n[MDX_SNAP_HANDLERS]) {
+    if (!h) FAIL(MDX_EPARAM, "null handle");
+    for (int i = 0; i < MDX_SNAP_HANDLERS; ++i) h->snap_handlers[i] = every_n ? every_n[i] : 0u;
+    return MDX_OK;
+}
+extern "C" uint32_t mdx_snapshot_handler_mask(const mdx_handle* h, uint32_t k) {
+    return (h && k < h->snapshots.size()) ? h->snapshots[k].handler_mask : 0u;
+}
+extern "C" int mdx_snapshot_read_forces(mdx_handle* h, uint32_t k, float* frc) {
+    if (!h || !frc) FAIL(MDX_EPARAM, "null argument");
+    if (k >= h->snapshots.size()) FAIL(MDX_EPARAM, "snapshot index out of range");
+    const auto& sn = h->snapshots[k];
+    if (sn.frc.empty()) FAIL(MDX_EPARAM, "snapshot was taken without forces (no nstfout handler at its step)");
+    std::memcpy(frc, sn.frc.data(), sizeof(float) * sn.frc.size());
+    return MDX_OK;
+}
 extern "C" int mdx_snapshot_read(mdx_handle* h, uint32_t k, double* time_ps, uint64_t* step, mdx_energies* e, float* pos,
                                  float* vel) {
     if (!h) FAIL(MDX_EPARAM, "null handle");

@@ -1994,9 +1994,10 @@ int mdx_rebuild(mdx_handle* h) {
     bool fast = fused_env && !two_pass_env0 && d.entries && d.masks && h->cap_entries && h->cap_mchunks && h->T > 0 && h->n_local > 0;
     for (int k = 0; k < 3; ++k) if (!h->per[k] && !h->have_local_bounds) fast = false;      // (a vacuum system: the grid follows the atoms' bounding box)
     if (!fast) MDX_TRY(mdx_unsort_state(h));  // dynamic state -> caller-order staging
+    const bool was_in_slot_space = h->in_slot_space;
     MDX_TRY(setup_grid(h));
     if (fast && (size_t)h->ncells + 1 > ((size_t)1 << 21)) { fast = false; MDX_TRY(mdx_unsort_state(h)); }   // (the grid scan is a chain of at most 32 windows)
-    if (fast && !h->in_slot_space) fast = false;      // (setup_grid had to grow the slot-space arrays and moved the state to the staging)
+    if (fast && was_in_slot_space && !h->in_slot_space) fast = false;      // (setup_grid had to grow the slot-space arrays and moved the state to the staging)
     const uint32_t N = h->n_local;   // atoms simulated here (all of them on a single GPU)
     const GridParams g = h->grid;
     hipStream_t st = h->stream;

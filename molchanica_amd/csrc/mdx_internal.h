@@ -372,8 +372,9 @@ struct mdx_handle {
     uint64_t rng_state = 0;
     bool zero_com = false;
     uint32_t snap_every = 0; bool snap_vel = false;
+    uint32_t snap_handlers[MDX_SNAP_HANDLERS] = {};   // mdx_set_snapshot_handlers: cadence per handler (0 = off); snap_every stays the plain cadence of mdx_set_snapshot_cadence
     double time_ps = 0.0;
-    struct Snapshot { double time; uint64_t step; mdx_energies e; std::vector<float> pos, vel; std::vector<mdx_hbond> hbonds; std::vector<float> between; };
+    struct Snapshot { double time; uint64_t step; mdx_energies e; std::vector<float> pos, vel, frc; std::vector<mdx_hbond> hbonds; std::vector<float> between; uint32_t handler_mask = 0; };
     // md.water views and hydrogen-bond detection (mdx_set_water_layout / mdx_set_hbond_detection)
     uint32_t water_first = 0, n_waters = 0, water_sites = 0;
     std::vector<uint8_t> hb_heavy; float hb_dmax = 2.5f, hb_angle_min = 120.f;

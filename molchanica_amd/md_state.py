@@ -100,6 +100,10 @@ def load_library():
     lib.mdx_snapshot_read.argtypes = [H, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                       C.POINTER(CEnergies), _fp, _fp]
     lib.mdx_flush_snapshot_queues.argtypes = [H]
+    lib.mdx_set_snapshot_handlers.argtypes = [H, _u32p]
+    lib.mdx_snapshot_handler_mask.argtypes = [H, C.c_uint32]
+    lib.mdx_snapshot_handler_mask.restype = C.c_uint32
+    lib.mdx_snapshot_read_forces.argtypes = [H, C.c_uint32, _fp]
     lib.mdx_set_water_layout.argtypes = [H, C.c_uint32, C.c_uint32, C.c_uint32]
     lib.mdx_water_download.argtypes = [H, C.c_int, _fp, _fp, _fp, _fp]
     lib.mdx_set_hbond_detection.argtypes = [H, C.c_void_p, C.c_float, C.c_float]
@@ -358,6 +362,16 @@ class MdState:
         """`snapshot_handlers.memory: Some(every_n)` (water_sol.rs:185-189)."""
         _check(load_library().mdx_set_snapshot_cadence(self._h, int(every_n), int(with_velocities)))
 
+    SNAP_HANDLERS = ("memory", "dcd", "nstxout", "nstvout", "nstfout", "nstenergy", "nstcalcenergy", "nstxout_compressed")
+
+    def set_snapshot_handlers(self, **every_n):
+        """`MdConfig.snapshot_handlers {memory, dcd, gromacs{nstxout, nstvout, nstfout, nstenergy, nstcalcenergy, nstxout_compressed}}`
+        (src/properties/crystal.rs:335-342): a cadence per handler; every snapshot says which handlers wanted it."""
+        a = np.array([int(every_n.pop(k, 0) or 0) for k in self.SNAP_HANDLERS], dtype=np.uint32)
+        if every_n:
+            raise ParamError("unknown snapshot handler: " + ", ".join(every_n))
+        _check(load_library().mdx_set_snapshot_handlers(self._h, a.ctypes.data_as(_u32p)))
+
     @property
     def snapshots(self) -> list:
         """`md.snapshots` (src/md/mod.rs:121-122): list of dicts time/step/energy_data/atom_posits[/velocities]."""
@@ -378,6 +392,12 @@ class MdState:
                 o, h0, h1 = (np.empty((self._n_waters, 3), dtype=np.float32) for _ in range(3))
                 _check(lib.mdx_snapshot_read_water(self._h, k, o.ctypes.data_as(_fp), h0.ctypes.data_as(_fp), h1.ctypes.data_as(_fp)))
                 snap.update(all_posits=pos, atom_posits=pos[:self._water_first], water_o_posits=o, water_h0_posits=h0, water_h1_posits=h1)
+            mask = int(lib.mdx_snapshot_handler_mask(self._h, k))
+            snap["handlers"] = [n for i, n in enumerate(self.SNAP_HANDLERS) if mask >> i & 1]
+            if mask >> 4 & 1:
+                frc = np.empty((self.n_atoms, 3), dtype=np.float32)
+                if lib.mdx_snapshot_read_forces(self._h, k, frc.ctypes.data_as(_fp)) == MDX_OK:
+                    snap["atom_forces"] = frc
             n_g = int(lib.mdx_energy_group_count(self._h))
             if n_g:
                 m = np.zeros((n_g, n_g), dtype=np.float32)

@@ -153,6 +153,39 @@ def test_snapshots_cadence_and_contents(mdx):
         assert md.snapshots == []
 
 
+def test_snapshot_handlers_each_with_its_own_cadence(mdx):
+    """`snapshot_handlers {memory, dcd, gromacs: OutputControl{nstxout, nstvout, nstfout, ...}}` (src/properties/crystal.rs:335-342,
+    src/ui/panels/md.rs:775-899): one snapshot per step that ANY handler names, tagged with the handlers that wanted it; velocities
+    only where nstvout is due, forces only where nstfout is due - and those equal an independent run stopped there."""
+    s = systems.water_box(6, seed=9)
+    cfg = MdConfig(lj_cutoff=7.0, coulomb_cutoff=7.0, skin=1.5, chunk_steps=16)
+    with mdx.MdState(s, cfg) as md, mdx.MdState(s, cfg) as md2:
+        md.set_snapshot_handlers(memory=4, dcd=10, nstvout=12, nstfout=20)
+        md.step(0.0005, None, 41)
+        snaps = md.snapshots
+        assert [sn["step"] for sn in snaps] == [4, 8, 10, 12, 16, 20, 24, 28, 30, 32, 36, 40]
+        by_step = {sn["step"]: sn for sn in snaps}
+        assert by_step[8]["handlers"] == ["memory"] and by_step[10]["handlers"] == ["dcd"]
+        assert by_step[12]["handlers"] == ["memory", "nstvout"] and by_step[20]["handlers"] == ["memory", "dcd", "nstfout"]
+        assert by_step[40]["handlers"] == ["memory", "dcd", "nstfout"]
+        for st, sn in by_step.items():
+            assert (sn["atom_velocities"] is not None) == (st % 12 == 0), st
+            assert ("atom_forces" in sn) == (st % 20 == 0), st
+        md2.step(0.0005, None, 20)
+        assert np.abs(by_step[20]["atom_posits"] - md2.positions()).max() < 1e-4
+        f2 = md2.forces()
+        assert np.abs(by_step[20]["atom_forces"] - f2).max() <= 2e-3 * max(1.0, float(np.abs(f2).max()))
+        md2.step(0.0005, None, 4)
+        # (flexible O-H: 1e-5 A of position difference is 2e-3 A/ps of hydrogen velocity one step later)
+        assert np.abs(by_step[24]["atom_velocities"] - md2.velocities()).max() < 3e-2
+        # all handlers off again; an unknown handler name is refused
+        md.flush_snapshot_queues(); md.set_snapshot_handlers()
+        md.step(0.0005, None, 12)
+        assert md.snapshots == []
+        with pytest.raises(Exception):
+            md.set_snapshot_handlers(xtc=5)
+
+
 def test_snapshots_follow_the_oracle_trajectory(mdx, orc):
     """Every stored snapshot - positions, velocities, per-term energies - against the ORACLE's trajectory stopped at the
     same step (not against a second engine run)."""
