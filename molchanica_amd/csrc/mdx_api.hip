@@ -192,7 +192,9 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) FAIL(MDX_EDEVICE, "no HIP device available");
     if (device < 0 || device >= ndev) FAIL(MDX_EDEVICE, "device index out of range");
     HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->pme_cus_per_xcd = mdx_pme_cu_split(h, c);
+    if (h->pme_cus_per_xcd) MDX_TRY(mdx_stream_create_masked(&h->stream, h->pme_cus_per_xcd, true));
+    else HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     hipStream_t st = h->stream;
     DeviceState& d = h->d;
 

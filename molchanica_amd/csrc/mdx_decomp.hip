@@ -1045,6 +1045,7 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
     // Every RCCL operation of a handle goes to ONE stream.  By default that is the compute stream itself: pack -> send/recv
     // group -> unpack run back to back without cross-stream event hops (each hop is ~5-10 us of idle time on this stack; the
     // overlap with the message comes from the interior tiles on the side stream).  MDX_COMM_STREAM=1: a separate stream.
+    DD_TRY(mdx_stream_unmask(h));      // (a joined handle's chain has the mesh all-reduce inside: no CU split)
     {
         const char* e = std::getenv("MDX_COMM_STREAM");
         if (e && e[0] == '1') DD_HIP(hipStreamCreateWithFlags(&dd->comm_stream, hipStreamNonBlocking));

@@ -288,6 +288,7 @@ struct mdx_handle {
     bool pme_on = false; int pme_K[3] = {0, 0, 0}; void* pme_plan = nullptr;  // opaque PmePlan
     // the charge mesh is cleared BEHIND the chain that dirtied it (mdx_pme.hip), not in front of the next one
     bool pme_canvas_clean = false, pme_canvas2_clean = false, pme_clear_pending = false, pme_block_spread_used = false, pme_spread_main = false;
+    int pme_cus_per_xcd = 0;     // > 0: the handle's stream is confined to the other 32 - n compute units of every XCD (mdx_pme_cu_split)
     bool pme_overlap = false; hipStream_t stream_pme = nullptr; hipEvent_t ev_pme_fork = nullptr, ev_pme_join = nullptr;
     uint32_t ewald_tab_n = 0, ewald_tab_shift = 16; float ewald_tab_scale = 1.f;
     double ewald_self = 0.0, ewald_background = 0.0; double total_charge = 0.0, sum_q2 = 0.0, q_abs_max = 0.0;
@@ -517,7 +518,10 @@ int mdx_check_box(const mdx_handle* h, const float* lo, const float* hi);   // t
 int mdx_launch_vsite_spread(mdx_handle* h, const uint32_t* d_gate, uint32_t thr);
 
 // SPME reciprocal space (mdx_pme.hip)
-int mdx_pme_setup(mdx_handle* h);                      // plans, mesh, theta table (again after set_box)
+int mdx_pme_setup(mdx_handle* h);
+int mdx_pme_cu_split(const mdx_handle* h, const mdx_config* c);      // compute units per XCD the reciprocal-space chain gets for itself (0: none)
+int mdx_stream_create_masked(hipStream_t* s, int cus_per_xcd, bool complement);
+int mdx_stream_unmask(mdx_handle* h);                                // the handle's stream back on every compute unit (idle handle)                      // plans, mesh, theta table (again after set_box)
 void mdx_pme_destroy(mdx_handle* h);
 int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr);
 int mdx_pme_fork(mdx_handle* h);                                             // side stream starts behind the handle's stream

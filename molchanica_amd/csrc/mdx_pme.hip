@@ -765,6 +765,51 @@ extern "C" int mdx_pme_brick_overflows(mdx_handle* h, uint64_t* n) {
     return MDX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Compute units of its own for the reciprocal-space chain: MEASURED AND LEFT OFF (MDX_PME_CUS=n turns it on: n CUs per XCD for the
+// chain, the handle's stream on the other 32 - n; hipExtStreamCreateWithCUMask, mask bit b = XCD b % 8, CU b / 8 of it - read back
+// with HW_ID / XCC_ID by tools/ubench/cu_mask.hip).  The idea: on plain streams the chain does not overlap - the pair kernel is 16 k
+// one-wave workgroups that refill every wave slot the moment it frees, a 256-thread workgroup with LDS never finds its slots
+// together, and the chain's first kernel waits for the pair kernel's tail (pme_bin_kernel 19 -> 363 us; 44 of 395 us hidden) - while
+// with disjoint CU masks the two run side by side without disturbing each other (ubench: a VALU kernel and a copy, each as fast as
+// alone on its CUs).  The price decides it: the pair kernel slows by exactly the CUs it gives up (534 -> 710 us per launch on 24 of
+// 32) and the chain's kernels are NOT the streaming kind that loses little on fewer CUs (a plain copy keeps 45 % of its bandwidth
+// on a quarter of the CUs; the gather takes 3.6x, canvas 3.0x, combine 3.4x, the FFT passes 1.6-2.0x as long):
+// 1,048,576 sites, steps/s: no split 773 | 4 CUs per XCD 509 | 6: 512 | 8: 748 | 10: 654  (profiles/r05_cu_mask.txt).
+// ---------------------------------------------------------------------------------------------
+int mdx_pme_cu_split(const mdx_handle* h, const mdx_config* c) {
+    if (c->coulomb_mode != MDX_COULOMB_EWALD || (c->overrides & MDX_OVR_LONG_RANGE_RECIP_DISABLED)) return 0;
+    const char* const o = std::getenv("MDX_PME_OVERLAP");
+    if (o ? o[0] != '1' : h->N < 262144u) return 0;              // (the same rule as pme_overlap below, and the explicit A/B arms keep the plain streams)
+    int n = 0;
+    if (const char* e = std::getenv("MDX_PME_CUS")) n = std::atoi(e);
+    if (n <= 0 || n >= 24) return 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) != hipSuccess || prop.multiProcessorCount != 256) return 0;     // 8 XCDs x 32 CUs: the layout the mask is written for
+    return n;
+}
+int mdx_stream_create_masked(hipStream_t* s, int cus_per_xcd, bool complement) {
+    uint32_t m[8] = {};
+    for (int b = 0; b < 256; ++b)
+        if (((b >> 3) < cus_per_xcd) != complement) m[b >> 5] |= 1u << (b & 31);
+    HIP_TRY(hipExtStreamCreateWithCUMask(s, 8, m));
+    return MDX_OK;
+}
+int mdx_stream_unmask(mdx_handle* h) {
+    if (!h->pme_cus_per_xcd) return MDX_OK;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->stream_pme) {
+        HIP_TRY(hipStreamSynchronize(h->stream_pme));
+        (void)hipEventDestroy(h->ev_pme_fork); (void)hipEventDestroy(h->ev_pme_join);
+        (void)hipStreamDestroy(h->stream_pme);
+        h->stream_pme = nullptr;
+    }
+    (void)hipStreamDestroy(h->stream);
+    h->stream = nullptr; h->pme_cus_per_xcd = 0;
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    return MDX_OK;
+}
+
 void mdx_pme_destroy(mdx_handle* h) {
     if (h->stream_pme) {
         (void)hipStreamSynchronize(h->stream_pme);
@@ -995,6 +1040,7 @@ int mdx_pme_setup(mdx_handle* h) {
         const char* const e = std::getenv("MDX_PME_OVERLAP");      // read at every setup: a test can choose per handle
         const int env = e ? (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)) : -1;
         h->pme_overlap = !h->dd && (env >= 0 ? env >= 1 : h->N >= 65536u);
+        if (h->pme_cus_per_xcd && (!h->pme_overlap || env == 2)) MDX_TRY(mdx_stream_unmask(h));      // (decided at create from the same inputs; a joined handle gets here)
         // MDX_PME_OVERLAP=2 (A/B): the charge spread stays on the handle's stream, in FRONT of the pair kernel, and only the rest
         // of the chain (FFTs, solve, gather) runs beside it: spread and pair kernel both live on the LDS pipeline (ds_add_f32 /
         // the staged j-atoms) and run no faster side by side than one after the other
@@ -1003,7 +1049,8 @@ int mdx_pme_setup(mdx_handle* h) {
             // (MDX_PME_PRIORITY=1: the chain's stream above the handle's - A/B; round 3 measured it 3 % slower)
             static const bool prio = [] { const char* e = std::getenv("MDX_PME_PRIORITY"); return e && e[0] == '1'; }();
             int lo_p = 0, hi_p = 0;
-            if (prio && hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) == hipSuccess) HIP_TRY(hipStreamCreateWithPriority(&h->stream_pme, hipStreamNonBlocking, hi_p));
+            if (h->pme_cus_per_xcd) MDX_TRY(mdx_stream_create_masked(&h->stream_pme, h->pme_cus_per_xcd, false));
+            else if (prio && hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) == hipSuccess) HIP_TRY(hipStreamCreateWithPriority(&h->stream_pme, hipStreamNonBlocking, hi_p));
             else HIP_TRY(hipStreamCreateWithFlags(&h->stream_pme, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&h->ev_pme_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&h->ev_pme_join, hipEventDisableTiming));

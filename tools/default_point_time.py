@@ -12,6 +12,7 @@ pre = int(sys.argv[4]) if len(sys.argv) > 4 else 300         # untimed steps at 
 s = systems.opc_water_box(n_side, seed=5)
 cases = (("SPME", MdConfig(coulomb_mode=2, ewald_alpha=0.3, overrides=0, inner_skin=inner, skin=skin)), ("cutoff (reaction field)", MdConfig(coulomb_mode=1, inner_skin=inner, skin=skin)))
 if os.environ.get("DP_ONLY") == "spme": cases = cases[:1]
+if os.environ.get("DP_ONLY") == "rf": cases = cases[1:]
 for name, cfg in cases:
     with MdState(s, cfg) as md:
         md.minimize_energy(100); md.initialize_velocities(300.0, True, seed=1)

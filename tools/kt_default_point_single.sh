@@ -2,7 +2,7 @@
 # kernel trace of the reference's default operating point on one GPU (tools/default_point_time.py N_SIDE): bash tools/kt_default_point_single.sh TAG [N_SIDE=64]
 TAG=${1:-kt_dps}; NS=${2:-64}
 OUT=$PWD/gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
-export DP_ONLY=spme
+export DP_ONLY=${DP_ONLY:-spme}
 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -- python3 tools/default_point_time.py $NS > "$OUT/run.log" 2> "$OUT/kt.err"
 python3 - "$OUT" <<'PY'
 import glob, os, sqlite3, sys, re
