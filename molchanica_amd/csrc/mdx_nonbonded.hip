@@ -45,6 +45,7 @@ template <bool ENERGY, int COUL>
 void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samecut);
 #define NB_EXTERN(E, C) extern template void launch_variant<E, C>(mdx_handle*, const NbArgs&, bool, bool);
 NB_EXTERN(false, CM_SHIFTED) NB_EXTERN(false, CM_RF) NB_EXTERN(false, CM_EWALD) NB_EXTERN(false, CM_SOFT)
+NB_EXTERN(false, CM_EWALD_TAB)
 NB_EXTERN(true, CM_SHIFTED) NB_EXTERN(true, CM_RF) NB_EXTERN(true, CM_EWALD) NB_EXTERN(true, CM_SOFT)
 #undef NB_EXTERN
 
@@ -176,7 +177,11 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
     case CM_RF: launch_variant<E, CM_RF>(h, a, geom, samecut); break;               \
     default: launch_variant<E, CM_EWALD>(h, a, geom, samecut); break;               \
     }
-    if (energy) { NB_DISPATCH(true) } else { NB_DISPATCH(false) }
+    // (force-only Ewald launches of the cluster kernels read the smooth part from the table: a flavour of its own, so that the
+    // lookup is straight-line code - as a run-time branch inside CM_EWALD it cost two scalar branches per cluster pair and pinned
+    // the LDS read's wait right behind the read)
+    if (!energy && mode == CM_EWALD && a.p.etab && !h->alch_on && mdx_nb_variant(h) != 1) launch_variant<false, CM_EWALD_TAB>(h, a, geom, samecut);
+    else if (energy) { NB_DISPATCH(true) } else { NB_DISPATCH(false) }
 #undef NB_DISPATCH
     mdx_prof_end(h);
     HIP_TRY(hipGetLastError());

@@ -607,10 +607,11 @@ __global__ __launch_bounds__((SPLIT > 1 ? WPT / SPLIT : (WPT > NB_WAVES ? WPT : 
     // Ewald force flavour: the table of the smooth part (mdx_pair_dev.h) in dynamic LDS, one copy per workgroup
     extern __shared__ float4 s_dyn_etab[];
     const float4* etab = nullptr;
-    if (COUL == CM_EWALD && !ENERGY && !ALCH && a.p.etab) {
+    if (COUL == CM_EWALD_TAB && !ENERGY && !ALCH) {
         for (uint32_t k = threadIdx.x; k < a.p.etab_n; k += BW * 64) s_dyn_etab[k] = a.p.etab[k];
         __syncthreads();
-        etab = s_dyn_etab;
+        // (biased by the byte offset of the table's first binade: pair_eval adds the masked bits of x, shifted, and nothing else)
+        etab = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_dyn_etab) - ((EWALD_TAB_CBITS >> a.p.etab_shift) << 4));
     }
     if (DUAL == 0) {
         nb_cluster_body<ENERGY, COUL, GEOM, SAMECUT, WPT, HALF, ALCH, 0, BW>(a, true, s_xyzq, s_lj, s_red, s_ownj, s_g, s_mask, etab);
@@ -659,7 +660,7 @@ void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samecut) {
     // workgroups per CU and leaves registers and LDS for the chain.
     static const uint32_t lds_pad_env = [] { const char* e = std::getenv("MDX_NB_LDS_PAD"); return e ? (uint32_t)std::atoi(e) : 0u; }();
     const uint32_t lds_pad = ((h->pme_on && h->pme_overlap && !ENERGY) ? lds_pad_env : 0u) +
-                             ((COUL == CM_EWALD && !ENERGY && !h->alch_on && a.p.etab) ? a.p.etab_n * (uint32_t)sizeof(float4) : 0u);      // + the Ewald table
+                             ((COUL == CM_EWALD_TAB && !ENERGY) ? a.p.etab_n * (uint32_t)sizeof(float4) : 0u);      // + the Ewald table
     // ONE kernel picks the inner-walk or the pruning body on the device (round 2 measured the merged launch at +1 % for 23 k atoms
     // and -0.4 % at 1 M, and launched the two flavours back to back for the large classes, the device running exactly one; since
     // the chunk loop exists twice the merged kernel is faster there too: the gated-off twin was ~5 us of a 550 us step).
@@ -689,8 +690,8 @@ void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samecut) {
     } while (0)
 #define NB_LAUNCH(G, S)                                                                                    \
     do {                                                                                                   \
-        if (h->alch_on && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true, true>), g, b, lds_pad, h->stream, a); \
-        else if (h->alch_on) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, true, true>), g, b, lds_pad, h->stream, a); \
+        if (h->alch_on && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true, COUL != CM_EWALD_TAB>), g, b, lds_pad, h->stream, a); \
+        else if (h->alch_on) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, true, COUL != CM_EWALD_TAB>), g, b, lds_pad, h->stream, a); \
         else if (var == 1) hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, G, S>), g, b, lds_pad, h->stream, a);     \
         else if (half && a.inner && dual_merged && wpt == 8 && split2 && !ENERGY) {   /* a tile = two workgroups of four waves */ \
             NbArgs af = a;                                                                                         \

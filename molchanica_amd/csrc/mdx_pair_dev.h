@@ -44,7 +44,8 @@ struct NbArgs {
     BondedParams b_p;
 };
 
-enum { CM_SHIFTED = 0, CM_RF = 1, CM_EWALD = 2, CM_SOFT = 3 };
+enum { CM_SHIFTED = 0, CM_RF = 1, CM_EWALD = 2, CM_SOFT = 3,
+       CM_EWALD_TAB = 4 };     // Ewald real space with the smooth part from the LDS table: force-only, non-alchemical launches (mdx_launch_nonbonded picks it)
 
 // Table of the smooth part of the Ewald real-space force (round 5).  erfc(beta r)/r^3 + 2 beta/sqrt(pi) exp(-beta^2 r^2)/r^2 =
 // 1/r^3 - g(r^2) with g = [erf(beta r)/r - 2 beta/sqrt(pi) exp(-beta^2 r^2)] / r^2: bounded (4 beta^3 / (3 sqrt(pi)) at r = 0) and
@@ -102,6 +103,18 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
     const bool cross = ALCH && __float_as_int(eps_s) < 0;
     const float ascale = cross ? p.alch_scale : 1.0f;
     float rinv, r2e = r2, sg6 = 0.f;
+    // Ewald force table (force-only, non-alchemical flavours): its LDS read goes out FIRST - index and fraction need nothing but
+    // r^2 - so the rsq and the Lennard-Jones arithmetic below run under its latency (with the lookup in source order the compiler
+    // parked an s_waitcnt two instructions behind the read).  `etab` arrives biased by the first binade's offset (nb_cluster_kernel),
+    // and the masked bits serve both as the entry's byte offset and as the entry's left edge: 5 VALU + the 3 FMAs below.
+    float4 en = make_float4(0.f, 0.f, 0.f, 0.f); float dxt = 0.f;
+    constexpr bool tab = COUL == CM_EWALD_TAB && !ENERGY && !ALCH;      // (compile time: one straight block for the scheduler)
+    if (tab) {
+        const float x = __builtin_fmaf(r2, p.etab_scale, EWALD_TAB_C);
+        const uint32_t sh = p.etab_shift, xm = __float_as_uint(x) & (0xFFFFFFFFu << sh);
+        en = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(etab) + (xm >> (sh - 4u)));
+        dxt = x - __uint_as_float(xm);
+    }
     if (ALCH) {
         const float sgsc = (sig > 0.f && eps != 0.f) ? sig : p.sc_sigmin;
         const float sg2 = sgsc * sgsc;
@@ -125,14 +138,10 @@ __device__ __forceinline__ void pair_eval(float xi, float yi, float zi, float qi
     else if (COUL == CM_SOFT) fc_r2 = qq * rinv * r2e * __frcp_rn(r2e + p.soft2);
     else if (COUL == CM_RF) fc_r2 = qq * (rinv - p.k_rf2 * r2e);
     float erfc_ar = 0.f;
-    if (COUL == CM_EWALD && !ENERGY && !ALCH && etab) {
-        const float x = __builtin_fmaf(r2e, p.etab_scale, EWALD_TAB_C);
-        const uint32_t xb = __float_as_uint(x), sh = p.etab_shift;
-        const float4 en = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(etab) + (((xb >> (sh - 4u)) & ~15u) - ((EWALD_TAB_CBITS >> sh) << 4)));
-        const float dxt = x - __uint_as_float(xb & (0xFFFFFFFFu << sh));
+    if (tab) {
         const float gsm = __builtin_fmaf(dxt, __builtin_fmaf(dxt, en.z, en.y), en.x);
         fc_r2 = qq * __builtin_fmaf(-gsm, r2e, rinv);
-    } else if (COUL == CM_EWALD) {
+    } else if (COUL == CM_EWALD || COUL == CM_EWALD_TAB) {
         // erfc by Abramowitz & Stegun 7.1.26 (|error| < 1.5e-7) sharing the exponential the force
         // needs anyway: ~10 VALU ops instead of the ~45 of libm's erfcf
         const float ar = p.alpha * r2e * rinv;
