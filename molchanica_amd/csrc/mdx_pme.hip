@@ -49,7 +49,8 @@ struct PmePlan {
     hipfftHandle fwd{}, inv{};
     bool have_plans = false;
     PmeDev dev{};
-    size_t n_real = 0, n_cplx = 0;
+    size_t n_real = 0, n_cplx = 0;      // n_cplx = K0 K1 pitch
+    int pitch = 0;                      // complex numbers per (x, y) row of the half-complex mesh: K2 / 2 + 1, padded on single-device handles
     // ---- brick spread (single-GPU handles; see "Brick spread" below) ----
     struct Brick {
         bool on = false;
@@ -439,6 +440,7 @@ __global__ __launch_bounds__(256) void pme_solve_kernel(size_t n, int K1, int K2
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float t = theta[i];
         float2 f = F[i];
+        if (t == 0.f) { F[i] = make_float2(0.f, 0.f); continue; }      // m = 0, and the pad entries of a padded row (never written by the transform)
         if (ENERGY) {
             const int k3 = (int)(i % (size_t)K3h);
             const float mult = (k3 == 0 || (2 * k3 == K3)) ? 1.0f : 2.0f;
@@ -483,6 +485,7 @@ __global__ __launch_bounds__(256) void pme_solve2_kernel(size_t n, int K1, int K
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float t = theta[i];
         float2 f = F[i], g = G[i];
+        if (t == 0.f) { F[i] = make_float2(0.f, 0.f); G[i] = make_float2(0.f, 0.f); continue; }      // (as in pme_solve_kernel)
         if (ENERGY) {
             const int k3 = (int)(i % (size_t)K3h);
             const float mult = (k3 == 0 || (2 * k3 == K3)) ? 1.0f : 2.0f;
@@ -1013,14 +1016,27 @@ int mdx_pme_setup(mdx_handle* h) {
         K[d] = c.pme_grid[d] ? (int)c.pme_grid[d] : good_size(L[d] / 1.0);
         if (K[d] < 8 || K[d] > 2048) FAIL(MDX_EPARAM, "pme_grid must be in 8..2048");
     }
-    const bool regrid = !p->have_plans || K[0] != h->pme_K[0] || K[1] != h->pme_K[1] || K[2] != h->pme_K[2];
     const int K3h = K[2] / 2 + 1;
+    // Row pitch of the half-complex mesh.  hipfftPlan3d packs it [K0][K1][K2/2 + 1]: rows of 101 complex numbers at 200^3 start on
+    // every 8-byte phase of a cache line, and rocFFT's strided passes read and write them in pieces.  Padded to a multiple of 16
+    // complex numbers (128 B; hipfftPlanMany's advanced layout) forward + inverse take 133 us instead of 144 at 200^3, 189 instead of
+    // 294 at 256^3 (tools/ubench/fft_pitch.cpp, profiles/r05_fft_pitch.txt).  The pad entries carry theta = 0.  Decomposed handles
+    // keep the packed rows (their slab transposes and the replicated-mesh all-reduce index with K2/2 + 1).  MDX_PME_PITCH=0: packed.
+    static const bool pad_rows = [] { const char* e = std::getenv("MDX_PME_PITCH"); return !(e && e[0] == '0'); }();
+    const int pitch = (pad_rows && !h->dd && p->plan_many) ? (K3h + 15) & ~15 : K3h;
+    const bool regrid = !p->have_plans || K[0] != h->pme_K[0] || K[1] != h->pme_K[1] || K[2] != h->pme_K[2] || pitch != p->pitch;
     p->n_real = (size_t)K[0] * K[1] * K[2];
-    p->n_cplx = (size_t)K[0] * K[1] * K3h;
+    p->n_cplx = (size_t)K[0] * K[1] * pitch;
+    p->pitch = pitch;
     if (regrid) {
         if (p->have_plans) { p->destroy(p->fwd); p->destroy(p->inv); p->have_plans = false; }
-        if (p->plan3d(&p->fwd, K[0], K[1], K[2], HIPFFT_R2C) != HIPFFT_SUCCESS ||
-            p->plan3d(&p->inv, K[0], K[1], K[2], HIPFFT_C2R) != HIPFFT_SUCCESS)
+        if (pitch != K3h) {
+            int n[3] = {K[0], K[1], K[2]}, re[3] = {K[0], K[1], K[2]}, cx[3] = {K[0], K[1], pitch};
+            if (p->plan_many(&p->fwd, 3, n, re, 1, (int)p->n_real, cx, 1, (int)p->n_cplx, HIPFFT_R2C, 1) != HIPFFT_SUCCESS ||
+                p->plan_many(&p->inv, 3, n, cx, 1, (int)p->n_cplx, re, 1, (int)p->n_real, HIPFFT_C2R, 1) != HIPFFT_SUCCESS)
+                FAIL(MDX_EDEVICE, "hipfftPlanMany failed");
+        } else if (p->plan3d(&p->fwd, K[0], K[1], K[2], HIPFFT_R2C) != HIPFFT_SUCCESS ||
+                   p->plan3d(&p->inv, K[0], K[1], K[2], HIPFFT_C2R) != HIPFFT_SUCCESS)
             FAIL(MDX_EDEVICE, "hipfftPlan3d failed");
         p->have_plans = true;
         for (void** q : {(void**)&h->d.pme_q, (void**)&h->d.pme_f, (void**)&h->d.pme_theta, (void**)&h->d.pme_q2, (void**)&h->d.pme_f2})
@@ -1071,7 +1087,7 @@ int mdx_pme_setup(mdx_handle* h) {
     // theta table in fp64 on the host (depends on the box: recomputed by mdx_set_box)
     const double beta = c.ewald_alpha, V = L[0] * L[1] * L[2];
     std::vector<double> b[3] = {bspline_moduli4(K[0]), bspline_moduli4(K[1]), bspline_moduli4(K[2])};
-    std::vector<float> th(p->n_cplx);
+    std::vector<float> th(p->n_cplx, 0.f);
     for (int i = 0; i < K[0]; ++i) {
         const double m1 = (i <= K[0] / 2 ? i : i - K[0]) / L[0];
         for (int j = 0; j < K[1]; ++j) {
@@ -1081,7 +1097,7 @@ int mdx_pme_setup(mdx_handle* h) {
                 const double msq = m1 * m1 + m2 * m2 + m3 * m3;
                 double t = 0.0;
                 if (msq > 0.0) t = b[0][i] * b[1][j] * b[2][k] * std::exp(-M_PI * M_PI * msq / (beta * beta)) / (M_PI * V * msq);
-                th[((size_t)i * K[1] + j) * K3h + k] = (float)t;
+                th[((size_t)i * K[1] + j) * pitch + k] = (float)t;
             }
         }
     }
@@ -1153,7 +1169,7 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
     if (!h->pme_on) return MDX_OK;
     PmePlan* p = (PmePlan*)h->pme_plan;
     hipStream_t st = h->pme_overlap ? h->stream_pme : h->stream;      // (non-const: MDX_PME_OVERLAP=2 spreads on the handle's stream)
-    const int K3h = h->pme_K[2] / 2 + 1;
+    const int K3h = p->pitch;      // (the solve kernels index rows by the pitch: pad entries have theta = 0)
     const uint32_t need = h->dd ? 3u : 1u;              // decomposed: every rank spreads the charges it OWNS ...
     const double escale = h->dd ? 1.0 / (double)h->dd->world : 1.0;
     const bool alch = h->alch_on;      // two meshes: environment in pme_q / pme_f, coupled molecule in pme_q2 / pme_f2
