@@ -55,7 +55,8 @@ struct PmePlan {
     struct Brick {
         bool on = false;
         PmeBrickGeom g{};
-        float4* rec = nullptr; uint32_t* code = nullptr; uint32_t* count = nullptr; uint32_t* ovf = nullptr; int* scratch = nullptr;
+        float4* rec = nullptr; uint32_t* code = nullptr; uint32_t* slot = nullptr; uint32_t* count = nullptr; uint32_t* ovf = nullptr; int* scratch = nullptr;
+        uint64_t force_zero_epoch = ~0ull;      // list generation the separate force array was last cleared for (brick gather)
         uint32_t ovf_S = 0;
     } brick;
     // ---- slab-decomposed mesh of a decomposed handle (round 3; see "Slab-decomposed SPME" below) ----
@@ -249,7 +250,8 @@ constexpr int PME_CB_MAX = 19;             // canvas edge: at most 16 + 3 points
 constexpr size_t PME_BRICK_MIN_MESH = (size_t)1 << 20;      // mesh points from which the brick spread is the default
 struct PmeBrickArgs {
     uint32_t S; const float4* posq; const uint8_t* slot_flags; const float2* lj; PmeDev pg; PmeBrickGeom bg;
-    float4* rec; uint32_t* code; uint32_t* count;      // count[nbricks]; [nbricks] = overflow slots of this step; [nbricks + 1] = of all steps
+    float4* rec; uint32_t* code; uint32_t* slot; uint32_t* count;      // count[nbricks]; [nbricks] = overflow slots of this step; [nbricks + 1] = of all steps; [nbricks + 2] = of this step, kept for the gather
+    int keep;                                          // 1: the buckets outlive the spread (pme_gather_brick_kernel empties them)
     uint32_t* ovf; int* scratch; float* Q;
     const uint32_t* gate; uint32_t thr; uint32_t need; int sel;
 };
@@ -297,6 +299,7 @@ __global__ __launch_bounds__(256) void pme_bin_kernel(PmeBrickArgs a) {
         const size_t at = (size_t)id * a.bg.cap + rank;
         a.rec[at] = make_float4(w[0], w[1], w[2], p.w);
         a.code[at] = cell;
+        a.slot[at] = s;
     } else {
         a.ovf[atomicAdd(a.count + a.bg.nbricks, 1u)] = s;      // (the list holds S slots: it cannot overflow)
     }
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(256) void pme_canvas_kernel(PmeBrickArgs a) {
 // in a dimension, the next brick's canvas (periodic) holds it too, in its bottom three planes
 __global__ __launch_bounds__(256) void pme_combine_kernel(PmeBrickArgs a, size_t n_real) {
     if (a.gate && *a.gate > a.thr) return;
-    if (blockIdx.x * 256u + threadIdx.x < a.bg.nbricks) a.count[blockIdx.x * 256u + threadIdx.x] = 0u;      // the buckets are spent: empty for the next step
+    if (!a.keep && blockIdx.x * 256u + threadIdx.x < a.bg.nbricks) a.count[blockIdx.x * 256u + threadIdx.x] = 0u;      // the buckets are spent: empty for the next step
     // one WAVE per (kx, ky) row of the mesh: the x / y bricks are the same for the whole row (scalar); a lane takes four kz at a
     // time and issues all their loads before it adds (a pass with one load in flight per lane ran at 1.4 TB/s: latency)
     const int K1 = a.pg.K[1], K2 = a.pg.K[2];
@@ -403,6 +406,7 @@ __global__ __launch_bounds__(256) void pme_combine_kernel(PmeBrickArgs a, size_t
 __global__ __launch_bounds__(256) void pme_overflow_kernel(PmeBrickArgs a) {
     if (a.gate && *a.gate > a.thr) return;
     const uint32_t n_all = a.count[a.bg.nbricks];
+    if (threadIdx.x == 0) a.count[a.bg.nbricks + 2] = n_all;
     if (n_all == 0u) return;
     const uint32_t n = n_all;
     const int tid = threadIdx.x, b = (tid >> 2) & 3, c = tid & 3;
@@ -572,6 +576,93 @@ __global__ __launch_bounds__(256) void pme_gather_kernel(uint32_t S, const float
     force[s] = f;
 }
 
+// the atoms that did not fit their bucket (the spread's overflow list, its length kept in count[nbricks + 2]): per-atom form, by the
+// extra workgroup behind the bricks' (in practice it finds the list empty)
+template <bool SEPARATE>
+__device__ __forceinline__ void pme_gather_overflow(const PmeBrickArgs& a, const float* __restrict__ phi, float4* __restrict__ force) {
+    const uint32_t n = a.count[a.bg.nbricks + 2];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t s = a.ovf[i];
+        const float4 p = a.posq[s];
+        int k0[3]; float w[3];
+        mesh_coords(p, a.pg, k0, w);
+        float mx[4], my[4], mz[4], dx[4], dy[4], dz[4];
+        bspline4(w[0], mx, dx); bspline4(w[1], my, dy); bspline4(w[2], mz, dz);
+        float fx = 0.f, fy = 0.f, fz = 0.f;
+        for (int qa = 0; qa < 4; ++qa) {
+            int kx = k0[0] + qa; if (kx < 0) kx += a.pg.K[0];
+            for (int qb = 0; qb < 4; ++qb) {
+                int ky = k0[1] + qb; if (ky < 0) ky += a.pg.K[1];
+                const float* row = phi + ((size_t)kx * a.pg.K[1] + ky) * a.pg.K[2];
+                float s0 = 0.f, s1 = 0.f;
+                for (int qc = 0; qc < 4; ++qc) { int kz = k0[2] + qc; if (kz < 0) kz += a.pg.K[2]; const float v = row[kz]; s0 += mz[qc] * v; s1 += dz[qc] * v; }
+                fx += dx[qa] * my[qb] * s0; fy += mx[qa] * dy[qb] * s0; fz += mx[qa] * my[qb] * s1;
+            }
+        }
+        float4 f = SEPARATE ? make_float4(0.f, 0.f, 0.f, 0.f) : force[s];
+        f.x -= p.w * fx * a.pg.scale[0]; f.y -= p.w * fy * a.pg.scale[1]; f.z -= p.w * fz * a.pg.scale[2];
+        force[s] = f;
+    }
+}
+
+// Brick gather (round 5): the interpolation of the mesh potential back onto the atoms, brick by brick through LDS.  The per-slot
+// kernel above issues 64 scattered 4-byte loads per charge (1 M wave-level gathers per step at 786 k charges: bound by the address
+// unit, 50 us); here a workgroup loads the (B + 3)^3 points its brick's atoms can reach ONCE (the canvas of the spread, read
+// instead of written: 1.67 x the mesh in row pieces), and every record of the bucket the spread filled - spline fractions, charge,
+// cell, and now the slot - takes its 64 values from LDS.  The buckets are emptied here (the combine pass leaves them: keep = 1).
+// Slots without a record (uncharged sites, dummies) are not visited: the separate force array is cleared once per list generation.
+template <bool SEPARATE>
+__global__ __launch_bounds__(256) void pme_gather_brick_kernel(PmeBrickArgs a, const float* __restrict__ phi, float4* __restrict__ force) {
+    if (a.gate && *a.gate > a.thr) return;
+    __shared__ float s_phi[PME_CB_MAX * PME_CB_MAX * PME_CB_MAX];
+    const int tid = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (b == a.bg.nbricks) { pme_gather_overflow<SEPARATE>(a, phi, force); return; }
+    const int cb1 = a.bg.cb[1], cb2 = a.bg.cb[2];
+    const uint32_t vol = a.bg.stride;
+    const int bz = (int)(b % (uint32_t)a.bg.nb[2]), by = (int)((b / (uint32_t)a.bg.nb[2]) % (uint32_t)a.bg.nb[1]), bx = (int)(b / (uint32_t)(a.bg.nb[2] * a.bg.nb[1]));
+    const int K0 = a.pg.K[0], K1 = a.pg.K[1], K2 = a.pg.K[2];
+    const int ox = pme_brick_start(bx, K0, a.bg.nb[0]) - 3, oy = pme_brick_start(by, K1, a.bg.nb[1]) - 3, oz = pme_brick_start(bz, K2, a.bg.nb[2]) - 3;
+    const uint32_t n = min(a.count[b], a.bg.cap);
+    if (n) {
+        for (uint32_t k = tid; k < vol; k += 256) {
+            const int cz = (int)(k % (uint32_t)cb2), cy = (int)((k / (uint32_t)cb2) % (uint32_t)cb1), cx = (int)(k / (uint32_t)(cb2 * cb1));
+            int kx = ox + cx, ky = oy + cy, kz = oz + cz;      // (a canvas is at most K + 2 wide: one wrap either way)
+            kx += kx < 0 ? K0 : (kx >= K0 ? -K0 : 0); ky += ky < 0 ? K1 : (ky >= K1 ? -K1 : 0); kz += kz < 0 ? K2 : (kz >= K2 ? -K2 : 0);
+            kx = min(max(kx, 0), K0 - 1); ky = min(max(ky, 0), K1 - 1); kz = min(max(kz, 0), K2 - 1);      // (meshes narrower than a canvas: cells no atom of the brick reads)
+            s_phi[k] = phi[((size_t)kx * K1 + ky) * K2 + kz];
+        }
+    }
+    __syncthreads();
+    const float4* rec = a.rec + (size_t)b * a.bg.cap;
+    const uint32_t* code = a.code + (size_t)b * a.bg.cap;
+    const uint32_t* slot = a.slot + (size_t)b * a.bg.cap;
+    for (uint32_t i = tid; i < n; i += 256) {
+        const float4 r = rec[i];
+        const uint32_t c = code[i], s = slot[i];
+        const int lx = (int)(c & 255u), ly = (int)((c >> 8) & 255u), lz = (int)((c >> 16) & 255u);
+        float mx[4], my[4], mz[4], dx[4], dy[4], dz[4];
+        bspline4(r.x, mx, dx); bspline4(r.y, my, dy); bspline4(r.z, mz, dz);
+        float fx = 0.f, fy = 0.f, fz = 0.f;
+#pragma unroll
+        for (int qa = 0; qa < 4; ++qa) {
+#pragma unroll
+            for (int qb = 0; qb < 4; ++qb) {
+                const float* row = s_phi + ((size_t)(lx + qa) * cb1 + (ly + qb)) * cb2 + lz;
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int qc = 0; qc < 4; ++qc) { const float v = row[qc]; s0 += mz[qc] * v; s1 += dz[qc] * v; }
+                fx += dx[qa] * my[qb] * s0;
+                fy += mx[qa] * dy[qb] * s0;
+                fz += mx[qa] * my[qb] * s1;
+            }
+        }
+        float4 f = SEPARATE ? make_float4(0.f, 0.f, 0.f, 0.f) : force[s];
+        f.x -= r.w * fx * a.pg.scale[0]; f.y -= r.w * fy * a.pg.scale[1]; f.z -= r.w * fz * a.pg.scale[2];
+        force[s] = f;
+    }
+    if (tid == 0) a.count[b] = 0u;      // (read into n by every thread in front of the barrier above)
+}
 __global__ __launch_bounds__(256) void pme_add_force_kernel(uint32_t S, float4* __restrict__ force, const float4* __restrict__ add,
                                                             const uint32_t* gate, uint32_t thr) {
     if (gate && *gate > thr) return;
@@ -707,7 +798,7 @@ static std::vector<double> bspline_moduli4(int K) {
 
 static void pme_slab_free(PmePlan* p);
 static void pme_brick_free(PmePlan* p) {
-    for (void** q : {(void**)&p->brick.rec, (void**)&p->brick.code, (void**)&p->brick.count, (void**)&p->brick.ovf, (void**)&p->brick.scratch})
+    for (void** q : {(void**)&p->brick.rec, (void**)&p->brick.code, (void**)&p->brick.slot, (void**)&p->brick.count, (void**)&p->brick.ovf, (void**)&p->brick.scratch})
         if (*q) { (void)hipFree(*q); *q = nullptr; }
     p->brick.on = false;
 }
@@ -747,8 +838,10 @@ static int pme_brick_setup(mdx_handle* h, PmePlan* p) {
     if (const char* ce = std::getenv("MDX_PME_BRICK_CAP")) g.cap = (uint32_t)std::max(1, std::atoi(ce));
     HIP_TRY(hipMalloc((void**)&p->brick.rec, sizeof(float4) * (size_t)g.nbricks * g.cap));
     HIP_TRY(hipMalloc((void**)&p->brick.code, sizeof(uint32_t) * (size_t)g.nbricks * g.cap));
-    HIP_TRY(hipMalloc((void**)&p->brick.count, sizeof(uint32_t) * ((size_t)g.nbricks + 2)));
-    HIP_TRY(hipMemset(p->brick.count, 0, sizeof(uint32_t) * ((size_t)g.nbricks + 2)));
+    HIP_TRY(hipMalloc((void**)&p->brick.slot, sizeof(uint32_t) * (size_t)g.nbricks * g.cap));
+    p->brick.force_zero_epoch = ~0ull;
+    HIP_TRY(hipMalloc((void**)&p->brick.count, sizeof(uint32_t) * ((size_t)g.nbricks + 4)));
+    HIP_TRY(hipMemset(p->brick.count, 0, sizeof(uint32_t) * ((size_t)g.nbricks + 4)));
     HIP_TRY(hipMalloc((void**)&p->brick.ovf, sizeof(uint32_t) * ((size_t)h->N + 64)));
     HIP_TRY(hipMalloc((void**)&p->brick.scratch, sizeof(int) * (size_t)g.nbricks * g.stride));
     p->brick.on = true;
@@ -1198,6 +1291,10 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
         if (!h->pme_overlap) MDX_TRY(pme_clear_behind(h, st));
         return MDX_OK;
     }
+    // brick gather behind a brick spread (not for the two meshes of an alchemical window); MDX_PME_GATHER_BRICK=0: the per-slot kernel
+    static const bool gather_brick_env = [] { const char* e = std::getenv("MDX_PME_GATHER_BRICK"); return !(e && e[0] == '0'); }();
+    const bool gather_brick = gather_brick_env && p->brick.on && !per_atom_spread && !h->dd && !alch;
+    PmeBrickArgs ga{};
     for (int grp = 0; grp < (alch ? 2 : 1); ++grp) {
         float* Q = grp ? h->d.pme_q2 : h->d.pme_q;
         const int sel = alch ? grp + 1 : 0;
@@ -1209,7 +1306,8 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
             // brick spread: every mesh point is stored once by the combine pass - no clear, no global f32 atomics
             PmeBrickArgs ba{};
             ba.S = h->S; ba.posq = h->d.posq; ba.slot_flags = h->d.slot_flags; ba.lj = h->d.lj; ba.pg = p->dev; ba.bg = p->brick.g;
-            ba.rec = p->brick.rec; ba.code = p->brick.code; ba.count = p->brick.count; ba.ovf = p->brick.ovf;
+            ba.rec = p->brick.rec; ba.code = p->brick.code; ba.slot = p->brick.slot; ba.count = p->brick.count; ba.ovf = p->brick.ovf;
+            ba.keep = gather_brick ? 1 : 0; ga = ba;
             ba.scratch = p->brick.scratch; ba.Q = Q; ba.gate = d_gate; ba.thr = thr; ba.need = need; ba.sel = sel;
             hipLaunchKernelGGL(pme_bin_kernel, dim3(div_up(h->S, 256)), dim3(256), 0, st, ba);
             hipLaunchKernelGGL(pme_canvas_kernel, dim3(ba.bg.nbricks), dim3(256), 0, st, ba);
@@ -1254,7 +1352,18 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
     }
     if (p->exec_c2r(p->inv, (hipfftComplex*)h->d.pme_f, h->d.pme_q) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecC2R failed");
     const float* phi2 = alch ? h->d.pme_q2 : nullptr;
-    if (h->pme_overlap)
+    if (gather_brick) {
+        const uint64_t epoch = h->rebuild_count ^ ((uint64_t)h->S << 40) ^ (h->in_slot_space ? 1ull << 63 : 0ull);
+        if (h->pme_overlap && p->brick.force_zero_epoch != epoch) {      // slots without a record keep their zero until the slots are dealt again
+            HIP_TRY(hipMemsetAsync(h->d.pme_force, 0, sizeof(float4) * (size_t)h->S, st));
+            p->brick.force_zero_epoch = epoch;
+        }
+        if (h->pme_overlap) {
+            hipLaunchKernelGGL(pme_gather_brick_kernel<true>, dim3(ga.bg.nbricks + 1), dim3(256), 0, st, ga, (const float*)h->d.pme_q, h->d.pme_force);
+        } else {
+            hipLaunchKernelGGL(pme_gather_brick_kernel<false>, dim3(ga.bg.nbricks + 1), dim3(256), 0, st, ga, (const float*)h->d.pme_q, h->d.force);
+        }
+    } else if (h->pme_overlap)
         hipLaunchKernelGGL(pme_gather_kernel<true>, dim3(div_up(h->S, 256)), dim3(256), 0, st, h->S, h->d.posq, h->d.slot_flags,
                            p->dev, h->d.pme_q, h->d.pme_force, d_gate, thr, phi2, h->d.lj, asc);
     else

@@ -72,17 +72,19 @@ def test_spme_matches_numpy_restatement_and_ewald(mdx, orc, which, side_stream, 
     assert abs((e20["potential"] + e20["kinetic"]) - (e_full["potential"] + e_full["kinetic"])) / s.n_atoms < 0.05
 
 
-@pytest.mark.parametrize("grid,edge,cap", [((24, 24, 24), None, None), ((50, 36, 30), "16", None), ((50, 36, 30), "11", None),
-                                           ((27, 20, 45), "8", None), ((32, 32, 32), None, "8"), ((16, 8, 12), "16", "8")])
-def test_brick_spread_equals_the_tile_spread(mdx, grid, edge, cap, monkeypatch):
-    """The charge spread of a single-GPU handle (mdx_pme.hip "Brick spread": bin -> canvas -> combine, no global atomics) against
-    the tile kernel it replaced, on meshes whose edges the bricks do not divide, with every brick edge, and with buckets so small
-    that most atoms travel through the overflow list."""
+@pytest.mark.parametrize("grid,edge,cap,side", [((24, 24, 24), None, None, False), ((50, 36, 30), "16", None, False), ((50, 36, 30), "11", None, True),
+                                                ((27, 20, 45), "8", None, False), ((32, 32, 32), None, "8", False), ((16, 8, 12), "16", "8", True)])
+def test_brick_spread_equals_the_tile_spread(mdx, grid, edge, cap, side, monkeypatch):
+    """The charge spread of a single-GPU handle (mdx_pme.hip "Brick spread": bin -> canvas -> combine, no global atomics) and the
+    gather through the same bricks (pme_gather_brick_kernel) against the tile kernel and the per-slot gather they replaced, on meshes
+    whose edges the bricks do not divide, with every brick edge, with buckets so small that most atoms travel through the overflow
+    lists, and (side) with the chain on its side stream, where the reciprocal force has an array of its own."""
     s = systems.small_solvated()
     base = dict(lj_cutoff=8.0, coulomb_cutoff=8.0, skin=1.0, coulomb_mode=_abi.COULOMB_EWALD, ewald_alpha=0.4, overrides=0, pme_grid=grid)
     out = {}
     for arm in ("tile", "brick"):
         monkeypatch.setenv("MDX_PME_SPREAD_BRICK", "0" if arm == "tile" else "1")
+        monkeypatch.setenv("MDX_PME_OVERLAP", "1" if (side and arm == "brick") else "0")
         for k, v in (("MDX_PME_BRICK_EDGE", edge), ("MDX_PME_BRICK_CAP", cap)):
             monkeypatch.delenv(k, raising=False)
             if v is not None and arm == "brick":
