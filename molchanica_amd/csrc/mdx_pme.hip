@@ -48,6 +48,11 @@ struct PmePlan {
     decltype(&hipfftDestroy) destroy = nullptr;
     hipfftHandle fwd{}, inv{};
     bool have_plans = false;
+    // ---- hand-written x pass (single-device handles; see pme_xpass_solve_kernel) ----
+    hipfftHandle fwd2{}, inv2{};           // K0 batches of the 2-D transform over (y, z)
+    bool have_xpass = false;
+    float2* tw = nullptr;                  // exp(-2 pi i k / K0), k < K0 (fp64 on the host)
+    int nfac = 0, fac[16] = {};
     PmeDev dev{};
     size_t n_real = 0, n_cplx = 0;      // n_cplx = K0 K1 pitch
     int pitch = 0;                      // complex numbers per (x, y) row of the half-complex mesh: K2 / 2 + 1, padded on single-device handles
@@ -472,6 +477,143 @@ __global__ __launch_bounds__(256) void pme_solve_kernel(size_t n, int K1, int K2
             e = s_e[0] + s_e[1] + s_e[2] + s_e[3]; w = s_w[0] + s_w[1] + s_w[2] + s_w[3];
             // (decomposed handle: every rank solves the same mesh; each reports its 1/world share of the energy)
             if (e != 0.0) { atomicAdd(&energy[EN_RECIP], e * escale); atomicAdd(&energy[EN_VIRIAL], w * escale); }
+        }
+    }
+}
+
+// ---- x pass + solve + x pass in ONE kernel (round 5) ---------------------------------------------------------------------------
+// hipFFT's 3-D plan at 200^3 is a 100-point R2C pass along z and two strided 200-point passes (y, x) each way; the strided passes run
+// at 2.2 TB/s and the x passes bracket the solve: mesh out, mesh in, theta in, mesh out, mesh in - five trips of the 36 MB
+// half-complex mesh through memory for what is, per line along x, a transform, a multiplication and the inverse transform.
+// Here hipFFT does the batched 2-D transform over (y, z) for every x (81 us forward + inverse at 200^3 against 133 for the 3-D plan,
+// tools/ubench/fft_2d_batch.cpp) and this kernel does the rest in one trip: a workgroup takes 16 neighbouring z of one y - K0 rows
+// of 128 B - into LDS, runs 16 Stockham transforms of length K0 (radices 4, 2, 3, 5; twiddles from an fp64 table), multiplies by
+// theta (energy and virial in the flavour that wants them), transforms back and stores.  y[q + s (r p + u)] = w_n^(p u) sum_t
+// x[q + s (p + t m)] w_r^(t u), n -> n / r, s -> s r per pass (autosort: natural order in, natural order out; restated and checked
+// against numpy in tests/test_pme_reference.py).  MDX_PME_XPASS=0: the 3-D plan and pme_solve_kernel.
+struct XpassArgs {
+    float2* F; const float* theta; const float2* tw;
+    int K0, K1, K3, pitch, nfac; int fac[16];
+    float3 inv_len; float pi2_over_beta2; double* energy; double escale;
+    const uint32_t* gate; uint32_t thr;
+};
+constexpr int XP_TK_LOG = 3, XP_TK = 1 << XP_TK_LOG;      // lines per workgroup (8: 26 KB of LDS at K0 = 200, five workgroups per CU; 16 ran at 56 us, two per CU)
+// LDS layout of the tile: row x at x * 9 float2.  (Measured: the kernel is bound by instruction issue - ~4.6 k wave instructions per
+// workgroup, a wave64 instruction is four cycles of its SIMD - not by LDS bank conflicts: a conflict-free swizzle of the rows cost
+// more integer work than it saved, 44.7 against 39.7 us; 16 lines per workgroup 56 us; load / theta / store folded into the passes 56.6.)
+__device__ __forceinline__ int xp_row(int x) { return x * (XP_TK + 1); }
+constexpr int XP_ROWS(int n) { return n * (XP_TK + 1); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+template <bool INV> __device__ __forceinline__ float2 mul_mi(float2 a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }   // a * (-i) (forward), a * i (inverse)
+// One pass of radix R over the K0 x XP_TK tile in LDS.  The radix is a template parameter and the butterfly loop is unrolled: the
+// LDS reads of several butterflies go out together (with the radix a run-time value inside the loop every butterfly waited for its
+// own reads: 2 us per pass, 41 us per launch at 200^3).
+template <bool INV, int R>
+__device__ __forceinline__ void xpass_pass(const float2* __restrict__ cur, float2* __restrict__ oth, const float2* __restrict__ stw,
+                                           int N, int n, int s, int kk, int g) {
+    const int m = n / R, nb = N / R;
+    const float inv_s = 1.0f / (float)s;
+#pragma unroll 4
+    for (int b = g; b < nb; b += 256 / XP_TK) {
+        const int pp = (int)(((float)b + 0.5f) * inv_s), q = b - pp * s;
+        const int xi = q + s * pp, di = s * m, xo = q + s * R * pp;      // input rows xi + t di, output rows xo + u s
+        const int tws = pp * s;                    // twiddle of output u: w_N^(p u s)
+        float2 in[R], o[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) in[t] = cur[xp_row(xi + t * di) + kk];
+        if (R == 2) {
+            o[0] = cadd(in[0], in[1]); o[1] = csub(in[0], in[1]);
+        } else if (R == 4) {
+            const float2 t0 = cadd(in[0], in[2]), t1 = csub(in[0], in[2]), t2 = cadd(in[1], in[3]), t3 = mul_mi<INV>(csub(in[1], in[3]));
+            o[0] = cadd(t0, t2); o[1] = cadd(t1, t3); o[2] = csub(t0, t2); o[3] = csub(t1, t3);
+        } else if (R == 3) {
+            const float2 t1 = cadd(in[1], in[2]), d = csub(in[1], in[2]);
+            const float2 t2 = make_float2(in[0].x - 0.5f * t1.x, in[0].y - 0.5f * t1.y);
+            const float2 t3 = mul_mi<INV>(make_float2(0.8660254037844386f * d.x, 0.8660254037844386f * d.y));
+            o[0] = cadd(in[0], t1); o[1] = cadd(t2, t3); o[2] = csub(t2, t3);
+        } else {      // 5
+            const float c1 = 0.30901699437494745f, c2 = -0.8090169943749475f, s1 = 0.9510565162951535f, s2 = 0.5877852522924731f;
+            const float2 t1 = cadd(in[1], in[R - 1]), t2 = cadd(in[2], in[R - 2]), t3 = csub(in[1], in[R - 1]), t4 = csub(in[2], in[R - 2]);
+            const float2 m1 = make_float2(in[0].x + c1 * t1.x + c2 * t2.x, in[0].y + c1 * t1.y + c2 * t2.y);
+            const float2 m2 = make_float2(in[0].x + c2 * t1.x + c1 * t2.x, in[0].y + c2 * t1.y + c1 * t2.y);
+            const float2 n1 = mul_mi<INV>(make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y));
+            const float2 n2 = mul_mi<INV>(make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y));
+            o[0] = make_float2(in[0].x + t1.x + t2.x, in[0].y + t1.y + t2.y);
+            o[1] = cadd(m1, n1); o[R - 1] = csub(m1, n1); o[2] = cadd(m2, n2); o[R - 2] = csub(m2, n2);
+        }
+        oth[xp_row(xo) + kk] = o[0];
+#pragma unroll
+        for (int u = 1; u < R; ++u) {
+            float2 w = stw[tws * u];
+            if (INV) w.y = -w.y;
+            oth[xp_row(xo + u * s) + kk] = cmul(o[u], w);
+        }
+    }
+}
+template <bool INV>
+__device__ __forceinline__ void xpass_fft(float2*& cur, float2*& oth, const float2* __restrict__ stw, const XpassArgs& a, int kk, int g) {
+    int n = a.K0, s = 1;
+    for (int f = 0; f < a.nfac; ++f) {
+        const int r = a.fac[f];
+        if (r == 4) xpass_pass<INV, 4>(cur, oth, stw, a.K0, n, s, kk, g);
+        else if (r == 5) xpass_pass<INV, 5>(cur, oth, stw, a.K0, n, s, kk, g);
+        else if (r == 2) xpass_pass<INV, 2>(cur, oth, stw, a.K0, n, s, kk, g);
+        else xpass_pass<INV, 3>(cur, oth, stw, a.K0, n, s, kk, g);
+        __syncthreads();
+        float2* t = cur; cur = oth; oth = t;
+        n /= r; s *= r;
+    }
+}
+template <bool ENERGY>
+__global__ __launch_bounds__(256) void pme_xpass_solve_kernel(XpassArgs a) {
+    if (a.gate && *a.gate > a.thr) return;
+    extern __shared__ float2 xp_lds[];
+    float2* cur = xp_lds;
+    float2* oth = xp_lds + XP_ROWS(a.K0);
+    float2* stw = xp_lds + 2 * XP_ROWS(a.K0);
+    const int tid = threadIdx.x, kk = tid & (XP_TK - 1), g = tid >> XP_TK_LOG;
+    const int ktiles = a.pitch / XP_TK;
+    const int y = (int)(blockIdx.x / (unsigned)ktiles), k0 = (int)(blockIdx.x % (unsigned)ktiles) * XP_TK;
+    const size_t row = (size_t)a.K1 * a.pitch, base = (size_t)y * a.pitch + k0 + kk;
+#pragma unroll 8
+    for (int x = g; x < a.K0; x += 256 / XP_TK) cur[xp_row(x) + kk] = a.F[(size_t)x * row + base];
+    for (int i = tid; i < a.K0; i += 256) stw[i] = a.tw[i];
+    __syncthreads();
+    xpass_fft<false>(cur, oth, stw, a, kk, g);
+    double e = 0.0, w = 0.0;
+    const int k3 = k0 + kk;
+#pragma unroll 8
+    for (int x = g; x < a.K0; x += 256 / XP_TK) {
+        const float t = a.theta[(size_t)x * row + base];      // 0 at m = 0 and in the pad entries of a row
+        float2 f = cur[xp_row(x) + kk];
+        if (t == 0.f) f = make_float2(0.f, 0.f);
+        if (ENERGY && t != 0.f) {
+            const float mult = (k3 == 0 || (2 * k3 == a.K3)) ? 1.0f : 2.0f;
+            const double ei = 0.5 * (double)(mult * t * (f.x * f.x + f.y * f.y));
+            const float m1 = (float)(x <= a.K0 / 2 ? x : x - a.K0) * a.inv_len.x;
+            const float m2 = (float)(y <= a.K1 / 2 ? y : y - a.K1) * a.inv_len.y;
+            const float m3 = (float)k3 * a.inv_len.z;
+            e += ei;
+            w += ei * (1.0 - 2.0 * (double)(a.pi2_over_beta2 * (m1 * m1 + m2 * m2 + m3 * m3)));
+        }
+        f.x *= t; f.y *= t;
+        cur[xp_row(x) + kk] = f;
+    }
+    __syncthreads();
+    xpass_fft<true>(cur, oth, stw, a, kk, g);
+#pragma unroll 8
+    for (int x = g; x < a.K0; x += 256 / XP_TK) a.F[(size_t)x * row + base] = cur[xp_row(x) + kk];
+    if (ENERGY) {
+        __shared__ double s_e[4], s_w[4];
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) { e += __shfl_xor(e, m); w += __shfl_xor(w, m); }
+        if ((tid & 63) == 0) { s_e[tid >> 6] = e; s_w[tid >> 6] = w; }
+        __syncthreads();
+        if (tid == 0) {
+            e = s_e[0] + s_e[1] + s_e[2] + s_e[3]; w = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+            if (e != 0.0) { atomicAdd(&a.energy[EN_RECIP], e * a.escale); atomicAdd(&a.energy[EN_VIRIAL], w * a.escale); }
         }
     }
 }
@@ -916,6 +1058,8 @@ void mdx_pme_destroy(mdx_handle* h) {
     PmePlan* p = (PmePlan*)h->pme_plan;
     if (!p) return;
     if (p->have_plans) { p->destroy(p->fwd); p->destroy(p->inv); }
+    if (p->have_xpass) { p->destroy(p->fwd2); p->destroy(p->inv2); p->have_xpass = false; }
+    if (p->tw) { (void)hipFree(p->tw); p->tw = nullptr; }
     pme_slab_free(p);
     pme_brick_free(p);
     if (p->lib) dlclose(p->lib);
@@ -1132,6 +1276,37 @@ int mdx_pme_setup(mdx_handle* h) {
                    p->plan3d(&p->inv, K[0], K[1], K[2], HIPFFT_C2R) != HIPFFT_SUCCESS)
             FAIL(MDX_EDEVICE, "hipfftPlan3d failed");
         p->have_plans = true;
+        // the hand-written x pass: K0 batches of the 2-D transform + pme_xpass_solve_kernel (padded rows, K0 <= 512: two LDS buffers)
+        if (p->have_xpass) { p->destroy(p->fwd2); p->destroy(p->inv2); p->have_xpass = false; }
+        if (p->tw) { (void)hipFree(p->tw); p->tw = nullptr; }
+        static const bool xpass_env = [] { const char* e = std::getenv("MDX_PME_XPASS"); return !(e && e[0] == '0'); }();
+        if (xpass_env && pitch != K3h && pitch % XP_TK == 0 && K[0] <= 512) {
+            int n2[2] = {K[1], K[2]}, re2[2] = {K[1], K[2]}, cx2[2] = {K[1], pitch};
+            if (p->plan_many(&p->fwd2, 2, n2, re2, 1, K[1] * K[2], cx2, 1, K[1] * pitch, HIPFFT_R2C, K[0]) == HIPFFT_SUCCESS) {
+                if (p->plan_many(&p->inv2, 2, n2, cx2, 1, K[1] * pitch, re2, 1, K[1] * K[2], HIPFFT_C2R, K[0]) == HIPFFT_SUCCESS) p->have_xpass = true;
+                else p->destroy(p->fwd2);
+            }
+            if (p->have_xpass) {
+                p->nfac = 0;
+                int rest = K[0];
+                for (int r : {4, 2, 3, 5})
+                    while (rest % r == 0 && !(r == 2 && rest % 4 == 0)) { p->fac[p->nfac++] = r; rest /= r; }
+                if (rest != 1) { p->destroy(p->fwd2); p->destroy(p->inv2); p->have_xpass = false; }      // (good_size gives 2-3-5-smooth meshes; a caller's own pme_grid may not)
+            }
+            if (p->have_xpass) {
+                std::vector<float2> tw(K[0]);
+                for (int k = 0; k < K[0]; ++k) tw[k] = make_float2((float)std::cos(-2.0 * M_PI * k / K[0]), (float)std::sin(-2.0 * M_PI * k / K[0]));
+                HIP_TRY(hipMalloc((void**)&p->tw, sizeof(float2) * K[0]));
+                HIP_TRY(hipMemcpy(p->tw, tw.data(), sizeof(float2) * K[0], hipMemcpyHostToDevice));
+                const int lds = (int)(sizeof(float2) * ((size_t)2 * XP_ROWS(K[0]) + K[0]));
+                if (lds > 64 * 1024) {
+                    if (hipFuncSetAttribute((const void*)pme_xpass_solve_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+                        hipFuncSetAttribute((const void*)pme_xpass_solve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+                        (void)hipGetLastError(); p->destroy(p->fwd2); p->destroy(p->inv2); p->have_xpass = false;
+                    }
+                }
+            }
+        }
         for (void** q : {(void**)&h->d.pme_q, (void**)&h->d.pme_f, (void**)&h->d.pme_theta, (void**)&h->d.pme_q2, (void**)&h->d.pme_f2})
             if (*q) { (void)hipFree(*q); *q = nullptr; }
         HIP_TRY(hipMalloc((void**)&h->d.pme_q, sizeof(float) * p->n_real));
@@ -1166,6 +1341,7 @@ int mdx_pme_setup(mdx_handle* h) {
         }
         hipStream_t fst = h->pme_overlap ? h->stream_pme : h->stream;
         p->set_stream(p->fwd, fst); p->set_stream(p->inv, fst);
+        if (p->have_xpass) { p->set_stream(p->fwd2, fst); p->set_stream(p->inv2, fst); }
     }
     for (int d = 0; d < 3; ++d) {
         p->dev.lo[d] = h->box_lo[d]; p->dev.inv_len[d] = (float)(1.0 / L[d]);
@@ -1295,6 +1471,7 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
     static const bool gather_brick_env = [] { const char* e = std::getenv("MDX_PME_GATHER_BRICK"); return !(e && e[0] == '0'); }();
     const bool gather_brick = gather_brick_env && p->brick.on && !per_atom_spread && !h->dd && !alch;
     PmeBrickArgs ga{};
+    const bool xpass = p->have_xpass && !alch && !h->dd;      // (the alchemical window solves two meshes together: 3-D plans + pme_solve2_kernel)
     for (int grp = 0; grp < (alch ? 2 : 1); ++grp) {
         float* Q = grp ? h->d.pme_q2 : h->d.pme_q;
         const int sel = alch ? grp + 1 : 0;
@@ -1333,7 +1510,7 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
         // decomposed handle: the meshes are summed over the ranks - a replicated mesh, every rank then solves it and
         // interpolates the forces of its own atoms (the all-reduce is ungated: a collective must be entered by every rank alike)
         if (h->dd && h->dd->world > 1) MDX_TRY(mdx_dd_allreduce_f32(h, Q, p->n_real, st));
-        if (p->exec_r2c(p->fwd, Q, (hipfftComplex*)(grp ? h->d.pme_f2 : h->d.pme_f)) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecR2C failed");
+        if (p->exec_r2c(xpass ? p->fwd2 : p->fwd, Q, (hipfftComplex*)(grp ? h->d.pme_f2 : h->d.pme_f)) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecR2C failed");
     }
     const dim3 gs((unsigned)std::min<size_t>((p->n_cplx + 255) / 256, energy ? 1024 : (size_t)1 << 30));
     const float3 inv_len = make_float3(p->dev.inv_len[0], p->dev.inv_len[1], p->dev.inv_len[2]);
@@ -1344,13 +1521,23 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
         else hipLaunchKernelGGL(pme_solve2_kernel<false>, gs, dim3(256), 0, st, p->n_cplx, h->pme_K[0], h->pme_K[1], K3h, h->pme_K[2],
                                 inv_len, pb, h->d.pme_f, h->d.pme_f2, h->d.pme_theta, h->d.energy, (double)asc, d_gate, thr, escale);
         if (p->exec_c2r(p->inv, (hipfftComplex*)h->d.pme_f2, h->d.pme_q2) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecC2R failed");
+    } else if (xpass) {
+        XpassArgs xa{};
+        xa.F = h->d.pme_f; xa.theta = h->d.pme_theta; xa.tw = p->tw;
+        xa.K0 = h->pme_K[0]; xa.K1 = h->pme_K[1]; xa.K3 = h->pme_K[2]; xa.pitch = p->pitch; xa.nfac = p->nfac;
+        for (int i = 0; i < p->nfac; ++i) xa.fac[i] = p->fac[i];
+        xa.inv_len = inv_len; xa.pi2_over_beta2 = pb; xa.energy = h->d.energy; xa.escale = escale; xa.gate = d_gate; xa.thr = thr;
+        const dim3 gx((unsigned)(h->pme_K[1] * (p->pitch / XP_TK)));
+        const size_t lds = sizeof(float2) * ((size_t)2 * XP_ROWS(xa.K0) + xa.K0);
+        if (energy) hipLaunchKernelGGL(pme_xpass_solve_kernel<true>, gx, dim3(256), lds, st, xa);
+        else hipLaunchKernelGGL(pme_xpass_solve_kernel<false>, gx, dim3(256), lds, st, xa);
     } else {
         if (energy) hipLaunchKernelGGL(pme_solve_kernel<true>, gs, dim3(256), 0, st, p->n_cplx, h->pme_K[0], h->pme_K[1], K3h,
                                        h->pme_K[2], inv_len, pb, h->d.pme_f, h->d.pme_theta, h->d.energy, d_gate, thr, escale);
         else hipLaunchKernelGGL(pme_solve_kernel<false>, gs, dim3(256), 0, st, p->n_cplx, h->pme_K[0], h->pme_K[1], K3h,
                                 h->pme_K[2], inv_len, pb, h->d.pme_f, h->d.pme_theta, h->d.energy, d_gate, thr, escale);
     }
-    if (p->exec_c2r(p->inv, (hipfftComplex*)h->d.pme_f, h->d.pme_q) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecC2R failed");
+    if (p->exec_c2r(xpass ? p->inv2 : p->inv, (hipfftComplex*)h->d.pme_f, h->d.pme_q) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecC2R failed");
     const float* phi2 = alch ? h->d.pme_q2 : nullptr;
     if (gather_brick) {
         const uint64_t epoch = h->rebuild_count ^ ((uint64_t)h->S << 40) ^ (h->in_slot_space ? 1ull << 63 : 0ull);

@@ -102,6 +102,23 @@ def test_brick_spread_equals_the_tile_spread(mdx, grid, edge, cap, side, monkeyp
     assert np.abs(pb - pt).max() < 2e-4
 
 
+@pytest.mark.parametrize("grid", [(27, 20, 45), (50, 36, 30), (48, 24, 40), (30, 30, 30), (64, 64, 64), (20, 96, 10)])
+def test_fused_x_pass_equals_the_library_transform(mdx, grid, monkeypatch):
+    """pme_xpass_solve_kernel (batched 2-D hipFFT + hand-written x pass with the solve inside; radices 4, 2, 3, 5, padded rows) against
+    hipFFT's 3-D plan + pme_solve_kernel on the same handle inputs: energies (incl. the virial's pressure) and every force."""
+    s = systems.small_solvated()
+    base = dict(lj_cutoff=8.0, coulomb_cutoff=8.0, skin=1.0, coulomb_mode=_abi.COULOMB_EWALD, ewald_alpha=0.4, overrides=0, pme_grid=grid)
+    out = {}
+    for arm in ("0", "1"):
+        monkeypatch.setenv("MDX_PME_XPASS", arm)
+        with mdx.MdState(s, MdConfig(**base)) as md:
+            out[arm] = (md.forces().astype(np.float64), md.energy())
+    (f0, e0), (f1, e1) = out["0"], out["1"]
+    assert e1["coulomb_recip"] == pytest.approx(e0["coulomb_recip"], rel=2e-6)
+    assert e1["pressure"] == pytest.approx(e0["pressure"], rel=1e-5, abs=1e-3)
+    assert np.abs(f1 - f0).max() <= 2e-5 * max(1.0, np.abs(f0).max())
+
+
 def test_spme_follows_the_box_and_rejects_bad_setups(mdx):
     s = systems.water_box(6, seed=3)
     cfg = MdConfig(lj_cutoff=7.0, coulomb_cutoff=7.0, skin=1.0, coulomb_mode=_abi.COULOMB_EWALD, ewald_alpha=0.4,

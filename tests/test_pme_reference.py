@@ -67,3 +67,38 @@ def test_madelung_constant_of_rock_salt():
                 e_real += 0.5 * P.KE * (np.outer(q, q)[m] * erfc(beta * r[m]) / r[m]).sum()
     e = e_real + e_rec + P.ewald_self_energy(q, beta)
     assert e / (len(q) / 2) == pytest.approx(-1.747565 * P.KE / a, rel=2e-5)
+
+
+def _stockham(x, inverse=False):
+    """The x pass of pme_xpass_solve_kernel (molchanica_amd/csrc/mdx_pme.hip) restated: autosort Stockham passes of radix 4, 2, 3, 5,
+    y[q + s (r p + u)] = w_N^(p u s) sum_t x[q + s (p + t m)] w_r^(t u), n -> n / r, s -> s r; unnormalised both ways like hipFFT."""
+    N = len(x)
+    fac, rest = [], N
+    for r in (4, 2, 3, 5):
+        while rest % r == 0 and not (r == 2 and rest % 4 == 0):
+            fac.append(r); rest //= r
+    assert rest == 1, "mesh sizes are 2-3-5-smooth (good_size)"
+    tw = np.exp(-2j * np.pi * np.arange(N) / N)
+    if inverse:
+        tw = np.conj(tw)
+    a, b = x.astype(np.complex128).copy(), np.zeros(N, np.complex128)
+    n, s = N, 1
+    for r in fac:
+        m = n // r
+        for bf in range(N // r):
+            p, q = divmod(bf, s)
+            v = [a[q + s * (p + t * m)] for t in range(r)]
+            for u in range(r):
+                assert p * u * s < N                      # the kernel reads the twiddle table without a modulo
+                b[q + s * (r * p + u)] = tw[p * u * s] * sum(v[t] * tw[((N // r) * t * u) % N] for t in range(r))
+        a, b = b, a
+        n, s = m, s * r
+    return a
+
+
+@pytest.mark.parametrize("n", [8, 12, 20, 27, 30, 50, 64, 96, 100, 200, 240, 250, 256, 384, 512])
+def test_stockham_x_pass_equals_the_dft(n):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    assert np.abs(_stockham(x) - np.fft.fft(x)).max() < 1e-11 * n
+    assert np.abs(_stockham(x, inverse=True) - np.fft.ifft(x) * n).max() < 1e-11 * n
