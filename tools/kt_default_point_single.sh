@@ -38,7 +38,10 @@ row("pme_bin_kernel", "pme_bin_kernel", sites * 17 + charged * 20, "posq + flag 
 row("pme_canvas_kernel", "pme_canvas_kernel", charged * 20 + pts * 4 * 1.67, "20-B record per charge in, canvases out: (19/16)^3 x mesh")
 row("pme_combine_kernel", "pme_combine_kernel", pts * 4 * (1.67 + 1.0), "canvases in, mesh out")
 row("pme_gather_kernel", "pme_gather_kernel", charged * (16 + 64 * 4) + sites * 16, "16 B posq + 4^3 x 4 B mesh reads per charge + 16 B force row per slot")
+row("pme_gather_brick_kernel", "pme_gather_brick_kernel", charged * (28 + 16) + pts * 4 * 1.67, "28-B record in + 16-B force row out per charge, the potential once per covering canvas: (19/16)^3 x mesh")
 row("pme_solve_kernel", "pme_solve_kernel", cplx * (4 + 16), "theta 4 B + complex RW 16 B per point of the half-complex mesh")
+pitch = (K // 2 + 1 + 15) // 16 * 16
+row("pme_xpass_solve_kernel", "pme_xpass_solve_kernel", K * K * pitch * (4 + 16), "x transform + solve + inverse x transform in one trip: theta 4 B + complex RW 16 B per point of the padded half-complex mesh")
 for k in sorted(fk):
     row(k[:34], k, 2 * 8 * pts, "2 x 8 B x K^3 per pass (the verdict's convention; the half-complex data is half of that)")
 row("constrain_positions_kernel (SETTLE)", "constrain_positions_kernel", (sites // 4) * 3 * (32 + 32 + 16), "3 constrained atoms per water: pos RW, vel RW, ref R")
