@@ -150,11 +150,14 @@ __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_gro
         float3 xn[4], xo[4];
         float im[4];
         float4 p0 = make_float4(0, 0, 0, 0);
+        float4 pk_in[4], vk_in[4];      // kept for the write-back (it re-read both rows: 6 of the 22 scattered loads per water)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             xn[k] = make_float3(0, 0, 0); xo[k] = make_float3(0, 0, 0); im[k] = 0.f;
+            pk_in[k] = make_float4(0, 0, 0, 0); vk_in[k] = pk_in[k];
             if (k < (int)cg.natoms) {
                 const float4 pk = posq[cg.atom[k]], vk = vel[cg.atom[k]];
+                pk_in[k] = pk; vk_in[k] = vk;
                 if (k == 0) p0 = pk;
                 xn[k] = mimg3(make_float3(pk.x - p0.x, pk.y - p0.y, pk.z - p0.z), p);
                 xo[k] = make_float3(xn[k].x - dt * vk.x, xn[k].y - dt * vk.y, xn[k].z - dt * vk.z);
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_gro
             if (k >= (int)cg.natoms) break;
             const float3 dx = make_float3(xn[k].x - xs[k].x, xn[k].y - xs[k].y, xn[k].z - xs[k].z);
             if (dx.x != 0.f || dx.y != 0.f || dx.z != 0.f) {
-                float4 pk = posq[cg.atom[k]], vk = vel[cg.atom[k]];
+                float4 pk = pk_in[k], vk = vk_in[k];
                 pk.x += dx.x; pk.y += dx.y; pk.z += dx.z;
                 vk.x += dx.x * idt; vk.y += dx.y * idt; vk.z += dx.z * idt;
                 posq[cg.atom[k]] = pk; vel[cg.atom[k]] = vk;

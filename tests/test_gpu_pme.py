@@ -102,7 +102,7 @@ def test_brick_spread_equals_the_tile_spread(mdx, grid, edge, cap, side, monkeyp
     assert np.abs(pb - pt).max() < 2e-4
 
 
-@pytest.mark.parametrize("grid", [(27, 20, 45), (50, 36, 30), (48, 24, 40), (30, 30, 30), (64, 64, 64), (20, 96, 10)])
+@pytest.mark.parametrize("grid", [(27, 20, 45), (50, 36, 30), (48, 24, 40), (30, 30, 30), (64, 64, 64), (20, 96, 10), (480, 16, 20)])      # (480: more than 64 KB of LDS per workgroup)
 def test_fused_x_pass_equals_the_library_transform(mdx, grid, monkeypatch):
     """pme_xpass_solve_kernel (batched 2-D hipFFT + hand-written x pass with the solve inside; radices 4, 2, 3, 5, padded rows) against
     hipFFT's 3-D plan + pme_solve_kernel on the same handle inputs: energies (incl. the virial's pressure) and every force."""
