@@ -77,9 +77,8 @@ void mdx_fill_nb_params(const mdx_handle* h, NbParams& p, int* mode_out, bool* g
         if (ccut) p.coul_shift = 1.0f / rc;
     }
     *mode_out = mode; *geom_out = c.combining_rule == MDX_COMBINE_GEOMETRIC; *samecut_out = p.rc2_lj == p.rc2_coul;
-    // Ewald real space: the table of the smooth part (MDX_EWALD_TABLE=0: the closed form, A/B)
-    static const bool tab_on = [] { const char* e = std::getenv("MDX_EWALD_TABLE"); return !(e && e[0] == '0'); }();
-    p.etab = (mode == CM_EWALD && tab_on) ? h->d.ewald_tab : nullptr;
+    // Ewald real space: the table of the smooth part, where the handle has one (mdx_build_ewald_table)
+    p.etab = mode == CM_EWALD ? h->d.ewald_tab : nullptr;
     p.etab_n = p.etab ? h->ewald_tab_n : 0u;
     p.etab_scale = h->ewald_tab_scale; p.etab_shift = h->ewald_tab_shift;
 }
@@ -90,6 +89,7 @@ int mdx_build_ewald_table(mdx_handle* h) {
     h->ewald_tab_n = 0;
     const mdx_config& c = h->cfg;
     if (c.coulomb_mode != MDX_COULOMB_EWALD || !cut_on(c.lj_cutoff) || !cut_on(c.coulomb_cutoff)) return MDX_OK;
+    if (const char* e = std::getenv("MDX_EWALD_TABLE")) { if (e[0] == '0') return MDX_OK; }      // the closed form (A/B; read per handle, at create)
     const double beta = c.ewald_alpha, rmax = std::max(c.lj_cutoff, c.coulomb_cutoff);
     const double scale = std::max(1.0, (beta / 0.3) * (beta / 0.3));
     const uint32_t sh = beta > 0.36 ? 16u : 17u;      // mantissa bits kept: 7 or 6
