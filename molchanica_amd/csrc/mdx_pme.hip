@@ -52,6 +52,7 @@ struct PmePlan {
     hipfftHandle fwd2{}, inv2{};           // K0 batches of the 2-D transform over (y, z)
     bool have_xpass = false;
     float2* tw = nullptr;                  // exp(-2 pi i k / K0), k < K0 (fp64 on the host)
+    float* phi = nullptr;                  // the potential mesh of handles whose spread needs a cleared charge mesh (see XpassArgs::zero)
     int nfac = 0, fac[16] = {};
     PmeDev dev{};
     size_t n_real = 0, n_cplx = 0;      // n_cplx = K0 K1 pitch
@@ -496,6 +497,7 @@ struct XpassArgs {
     int K0, K1, K3, pitch, nfac; int fac[16];
     float3 inv_len; float pi2_over_beta2; double* energy; double escale;
     const uint32_t* gate; uint32_t thr;
+    float* zero; size_t zero_n; uint32_t tiles;      // workgroups behind the first `tiles` clear the charge mesh for the next step's spread
 };
 constexpr int XP_TK_LOG = 3, XP_TK = 1 << XP_TK_LOG;      // lines per workgroup (8: 26 KB of LDS at K0 = 200, five workgroups per CU; 16 ran at 56 us, two per CU)
 // LDS layout of the tile: row x at x * 9 float2.  (Measured: the kernel is bound by instruction issue - ~4.6 k wave instructions per
@@ -569,6 +571,16 @@ __device__ __forceinline__ void xpass_fft(float2*& cur, float2*& oth, const floa
 template <bool ENERGY>
 __global__ __launch_bounds__(256) void pme_xpass_solve_kernel(XpassArgs a) {
     if (a.gate && *a.gate > a.thr) return;
+    if (blockIdx.x >= a.tiles) {
+        // The tile spread (meshes below 2^20 points) adds into a cleared mesh: that was a fill launch per step - 5 of the 101 us of a
+        // 23 k-site step.  The forward transform has consumed the charge mesh by now and the inverse one writes the potential to a
+        // mesh of its own (PmePlan::phi), so the extra workgroups of this launch clear it.
+        const size_t per = (size_t)blockDim.x * 16;
+        const size_t i0 = (size_t)(blockIdx.x - a.tiles) * per;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const size_t i = i0 + (size_t)k * blockDim.x + threadIdx.x; if (i < a.zero_n) a.zero[i] = 0.f; }
+        return;
+    }
     extern __shared__ float2 xp_lds[];
     float2* cur = xp_lds;
     float2* oth = xp_lds + XP_ROWS(a.K0);
@@ -1060,6 +1072,7 @@ void mdx_pme_destroy(mdx_handle* h) {
     if (p->have_plans) { p->destroy(p->fwd); p->destroy(p->inv); }
     if (p->have_xpass) { p->destroy(p->fwd2); p->destroy(p->inv2); p->have_xpass = false; }
     if (p->tw) { (void)hipFree(p->tw); p->tw = nullptr; }
+    if (p->phi) { (void)hipFree(p->phi); p->phi = nullptr; }
     pme_slab_free(p);
     pme_brick_free(p);
     if (p->lib) dlclose(p->lib);
@@ -1279,6 +1292,7 @@ int mdx_pme_setup(mdx_handle* h) {
         // the hand-written x pass: K0 batches of the 2-D transform + pme_xpass_solve_kernel (padded rows, K0 <= 512: two LDS buffers)
         if (p->have_xpass) { p->destroy(p->fwd2); p->destroy(p->inv2); p->have_xpass = false; }
         if (p->tw) { (void)hipFree(p->tw); p->tw = nullptr; }
+    if (p->phi) { (void)hipFree(p->phi); p->phi = nullptr; }
         static const bool xpass_env = [] { const char* e = std::getenv("MDX_PME_XPASS"); return !(e && e[0] == '0'); }();
         if (xpass_env && pitch != K3h && pitch % XP_TK == 0 && K[0] <= 512) {
             int n2[2] = {K[1], K[2]}, re2[2] = {K[1], K[2]}, cx2[2] = {K[1], pitch};
@@ -1512,6 +1526,10 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
         if (h->dd && h->dd->world > 1) MDX_TRY(mdx_dd_allreduce_f32(h, Q, p->n_real, st));
         if (p->exec_r2c(xpass ? p->fwd2 : p->fwd, Q, (hipfftComplex*)(grp ? h->d.pme_f2 : h->d.pme_f)) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecR2C failed");
     }
+    // the tile / per-atom spread adds into a cleared mesh: with the x-pass kernel in the chain the potential gets a mesh of its own and
+    // that launch clears the charge mesh (XpassArgs::zero); the brick spread stores every point and needs neither
+    const bool phi_own = xpass && !h->pme_block_spread_used;
+    if (phi_own && !p->phi) HIP_TRY(hipMalloc((void**)&p->phi, sizeof(float) * p->n_real));
     const dim3 gs((unsigned)std::min<size_t>((p->n_cplx + 255) / 256, energy ? 1024 : (size_t)1 << 30));
     const float3 inv_len = make_float3(p->dev.inv_len[0], p->dev.inv_len[1], p->dev.inv_len[2]);
     const float pb = (float)(M_PI * M_PI / ((double)h->cfg.ewald_alpha * h->cfg.ewald_alpha));
@@ -1527,7 +1545,9 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
         xa.K0 = h->pme_K[0]; xa.K1 = h->pme_K[1]; xa.K3 = h->pme_K[2]; xa.pitch = p->pitch; xa.nfac = p->nfac;
         for (int i = 0; i < p->nfac; ++i) xa.fac[i] = p->fac[i];
         xa.inv_len = inv_len; xa.pi2_over_beta2 = pb; xa.energy = h->d.energy; xa.escale = escale; xa.gate = d_gate; xa.thr = thr;
-        const dim3 gx((unsigned)(h->pme_K[1] * (p->pitch / XP_TK)));
+        xa.tiles = (uint32_t)(h->pme_K[1] * (p->pitch / XP_TK));
+        if (phi_own) { xa.zero = h->d.pme_q; xa.zero_n = p->n_real; }
+        const dim3 gx(xa.tiles + (phi_own ? (unsigned)((p->n_real + 4095) / 4096) : 0u));
         const size_t lds = sizeof(float2) * ((size_t)2 * XP_ROWS(xa.K0) + xa.K0);
         if (energy) hipLaunchKernelGGL(pme_xpass_solve_kernel<true>, gx, dim3(256), lds, st, xa);
         else hipLaunchKernelGGL(pme_xpass_solve_kernel<false>, gx, dim3(256), lds, st, xa);
@@ -1537,7 +1557,8 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
         else hipLaunchKernelGGL(pme_solve_kernel<false>, gs, dim3(256), 0, st, p->n_cplx, h->pme_K[0], h->pme_K[1], K3h,
                                 h->pme_K[2], inv_len, pb, h->d.pme_f, h->d.pme_theta, h->d.energy, d_gate, thr, escale);
     }
-    if (p->exec_c2r(xpass ? p->inv2 : p->inv, (hipfftComplex*)h->d.pme_f, h->d.pme_q) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecC2R failed");
+    float* const phi = phi_own ? p->phi : h->d.pme_q;
+    if (p->exec_c2r(xpass ? p->inv2 : p->inv, (hipfftComplex*)h->d.pme_f, phi) != HIPFFT_SUCCESS) FAIL(MDX_EDEVICE, "hipfftExecC2R failed");
     const float* phi2 = alch ? h->d.pme_q2 : nullptr;
     if (gather_brick) {
         const uint64_t epoch = h->rebuild_count ^ ((uint64_t)h->S << 40) ^ (h->in_slot_space ? 1ull << 63 : 0ull);
@@ -1552,11 +1573,12 @@ int mdx_launch_pme(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t 
         }
     } else if (h->pme_overlap)
         hipLaunchKernelGGL(pme_gather_kernel<true>, dim3(div_up(h->S, 256)), dim3(256), 0, st, h->S, h->d.posq, h->d.slot_flags,
-                           p->dev, h->d.pme_q, h->d.pme_force, d_gate, thr, phi2, h->d.lj, asc);
+                           p->dev, phi, h->d.pme_force, d_gate, thr, phi2, h->d.lj, asc);
     else
         hipLaunchKernelGGL(pme_gather_kernel<false>, dim3(div_up(h->S, 256)), dim3(256), 0, st, h->S, h->d.posq, h->d.slot_flags,
-                           p->dev, h->d.pme_q, h->d.force, d_gate, thr, phi2, h->d.lj, asc);
+                           p->dev, phi, h->d.force, d_gate, thr, phi2, h->d.lj, asc);
     HIP_TRY(hipGetLastError());
+    if (phi_own) { h->pme_canvas_clean = true; h->pme_clear_pending = false; return MDX_OK; }      // (cleared inside the x-pass launch)
     h->pme_clear_pending = true;
     if (!h->pme_overlap) MDX_TRY(pme_clear_behind(h, st));      // (on the handle's own stream: still behind the gather)
     return MDX_OK;
