@@ -620,7 +620,7 @@ void mdx_prof_collect(mdx_handle* h, int first_stale_step) {
 // reference's default operating point - rigid water, dt 2 fs - the list goes stale every 4-5 steps at 2 A).  No model: the step
 // rate is MEASURED over windows of >= 12 rebuilds (>= 400 steps) at the current skin, then at 0.5 A less; while that is > 3 %
 // faster the walk goes on downwards in 0.25 A steps (not below 0.75 A), else it tries upwards in 0.5 A steps while the box
-// allows (edge >= 2 (cutoff + skin)); the best stays.  Forces do not depend on the skin, so nothing but speed changes.  Single
+// allows (edge >= 2 (cutoff + skin)) and the rate does not fall; the best stays if it beats the start by 1 %.  Forces do not depend on the skin, so nothing but speed changes.  Single
 // device only: ranks of a decomposed handle would have to agree, and their clocks do not.
 static void skin_apply(mdx_handle* h, float s) {
     h->cfg.skin = s;
@@ -628,7 +628,7 @@ static void skin_apply(mdx_handle* h, float s) {
     h->list_valid = false;
     h->inner_skin_auto = 0.f; h->dual_auto_off = false; h->dual_win_steps = 0; h->dual_win_prunes = 0;
     h->stretch_samples = 0;
-    h->skin_tune.win_steps = 0; h->skin_tune.win_rebuilds = 0; h->skin_tune.skip_rebuilds = 2;     // (the first lists at a new radius may regrow their arrays)
+    h->skin_tune.win_steps = 0; h->skin_tune.win_rebuilds = 0; h->skin_tune.skip_rebuilds = 5;     // (the first lists at a new radius may regrow their arrays; the chunk-length prediction relearns over three intervals)
 }
 static bool skin_fits(const mdx_handle* h, float s) {
     for (int d = 0; d < 3; ++d)
@@ -648,6 +648,8 @@ static void skin_autotune(mdx_handle* h, uint32_t done, bool stale_hit) {
     if (!((t.win_rebuilds >= 12 && t.win_steps >= 400 && stale_hit) || t.win_steps >= 6000)) return;     // (windows end ON a rebuild: whole stretches)
     const double rate = (double)t.win_steps / std::chrono::duration<double>(now - t.t0).count();
     const float cur = h->cfg.skin;
+    static const bool dbg = [] { const char* e = std::getenv("MDX_DEBUG_SKIN"); return e && e[0] == '1'; }();
+    if (dbg) fprintf(stderr, "[mdx skin tune] phase %d skin %.2f: %.1f steps/s over %u steps, %u rebuilds (best %.1f at %.2f, base %.1f)\n", t.phase, cur, rate, t.win_steps, t.win_rebuilds, t.best_rate, t.best_skin, t.base_rate);
     auto finish = [&]() { t.phase = 4; if (h->cfg.skin != t.best_skin) skin_apply(h, t.best_skin); };
     if (t.phase == 1) {
         t.base_rate = t.best_rate = rate; t.base_skin = t.best_skin = cur;
@@ -661,10 +663,15 @@ static void skin_autotune(mdx_handle* h, uint32_t done, bool stale_hit) {
         } else if (t.best_skin == t.base_skin && skin_fits(h, t.base_skin + 0.5f)) { t.phase = 3; skin_apply(h, t.base_skin + 0.5f); }
         else finish();
     } else if (t.phase == 3) {
-        if (rate > t.best_rate * 1.03) {
-            t.best_rate = rate; t.best_skin = cur;
-            if (skin_fits(h, cur + 0.5f) && cur + 0.5f <= 4.0f) skin_apply(h, cur + 0.5f); else finish();
-        } else finish();
+        // Upwards the rate climbs in small steps (1,048,576 OPC sites, dt 2 fs, SPME: 849 steps/s at 2.0 A, 865 at 3.0, 875 at 3.5 -
+        // +1 ... +1.5 % per half Angstrom): a walk that wants 3 % per step stops at once.  It goes on while a step is not worse than the
+        // best by 1 % (windows repeat to ~0.5 %), remembers the best, and keeps it if it beats the base by 1 %.
+        if (rate > t.best_rate * 1.005) { t.best_rate = rate; t.best_skin = cur; }
+        if (rate >= t.best_rate * 0.99 && skin_fits(h, cur + 0.5f) && cur + 0.5f <= 4.0f) skin_apply(h, cur + 0.5f);
+        else {
+            if (t.best_rate < t.base_rate * 1.01) { t.best_skin = t.base_skin; t.best_rate = t.base_rate; }
+            finish();
+        }
     }
 }
 
@@ -883,7 +890,14 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
                 }
             }
         }
-        if (h->skin_tune.on && h->skin_tune.phase < 4 && !h->dd) { skin_autotune(h, done, stale_hit); thr = stale_threshold_bits(h); }
+        if (h->skin_tune.on && !h->dd) {
+            // the best skin depends on the time step (how many steps a list lasts): a run that relaxes at 1 fs and produces at 2 fs
+            // tunes again when the step it is called with has changed by more than a fifth
+            mdx_handle::SkinTune& tn = h->skin_tune;
+            if (tn.dt_tuned > 0.f && fabsf(dt - tn.dt_tuned) > 0.2f * tn.dt_tuned) { tn.phase = 0; tn.warm_steps = 0; }
+            tn.dt_tuned = dt;
+            if (tn.phase < 4) { skin_autotune(h, done, stale_hit); thr = stale_threshold_bits(h); }
+        }
         h->steps_since_rebuild = stale_hit ? 0u : h->steps_since_rebuild + done;
         h->forces_valid = true;
         h->e_pending = want_e && done == chunk;

@@ -344,6 +344,7 @@ struct mdx_handle {
         bool on = false; int phase = 0;          // 0 warm-up, 1 measuring the base, 2 walking down, 3 walking up, 4 done
         float base_skin = 2.f, best_skin = 2.f, trial = 2.f; double base_rate = 0.0, best_rate = 0.0;
         uint32_t win_steps = 0, win_rebuilds = 0, skip_rebuilds = 0, warm_steps = 0;
+        float dt_tuned = 0.f;                    // the time step the walk ran (or runs) at
         std::chrono::steady_clock::time_point t0;
     } skin_tune;
     int chunk_s = -1;            // decomposed driver: chunk step whose drift has been enqueued (its prune word is shared by the halo unpack)
