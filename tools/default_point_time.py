@@ -18,7 +18,8 @@ for name, cfg in cases:
         md.minimize_energy(100); md.initialize_velocities(300.0, True, seed=1)
         md.set_thermostat(1, 300.0, 0.02, 1); md.step(0.001, None, 1500)       # untimed: the random-orientation lattice relaxes
         md.set_thermostat(2, 300.0, 0.1, 10, seed=2); md.step(0.002, None, pre)
-        t = time.perf_counter(); n = 500; md.step(0.002, None, n); e = md.energy(); el = time.perf_counter() - t
+        n = 500 if s.n_atoms >= 500000 else 5000      # (500 steps of a 23 k-site box are 60 ms: inside the GPU's return from idle, profiles/r05_fresh_handle_ramp.txt)
+        t = time.perf_counter(); md.step(0.002, None, n); e = md.energy(); el = time.perf_counter() - t
         st = md.stats()
         if skin == 0.0:
             print("   library-chosen skin: %.2f A (still tuning: %s)" % md.skin(), flush=True)
