@@ -37,6 +37,10 @@ struct PmeBrickGeom {
     int nb[3];                             // bricks per dimension; brick i of dimension d starts at (i * K[d]) / nb[d]
     int cb[3];                             // canvas extent = largest brick of the dimension + 3
     uint32_t nbricks, cap, stride;         // bucket capacity (records), canvas stride in scratch (floats)
+    // brick of a mesh cell and the cell's place in it, per dimension: ctab[coff[d] + k] = brick << 16 | k - start(brick); and, for the
+    // combine pass, the one or two canvas columns that hold mesh plane kz: ztab[kz] = (i0, i1 or -1).  (Computed per atom / per point
+    // these were six and twelve 32-bit integer divisions by run-time values: half of the bin pass's instructions.)
+    const uint32_t* ctab; int coff[3]; const int2* ztab;
 };
 
 struct PmePlan {
@@ -62,6 +66,7 @@ struct PmePlan {
         bool on = false;
         PmeBrickGeom g{};
         float4* rec = nullptr; uint32_t* code = nullptr; uint32_t* slot = nullptr; uint32_t* count = nullptr; uint32_t* ovf = nullptr; int* scratch = nullptr;
+        uint32_t* ctab = nullptr; int2* ztab = nullptr;
         uint64_t force_zero_epoch = ~0ull;      // list generation the separate force array was last cleared for (brick gather)
         uint32_t ovf_S = 0;
     } brick;
@@ -281,8 +286,9 @@ __global__ __launch_bounds__(256) void pme_bin_kernel(PmeBrickArgs a) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int fl = k0[d] + 3;
-            bi[d] = pme_brick_of(fl, a.pg.K[d], a.bg.nb[d]);
-            cell |= (uint32_t)(fl - pme_brick_start(bi[d], a.pg.K[d], a.bg.nb[d])) << (8 * d);
+            const uint32_t ct = a.bg.ctab[a.bg.coff[d] + fl];
+            bi[d] = (int)(ct >> 16);
+            cell |= (ct & 0xFFFFu) << (8 * d);
         }
         id = (uint32_t)((bi[0] * a.bg.nb[1] + bi[1]) * a.bg.nb[2] + bi[2]);
     }
@@ -383,13 +389,10 @@ __global__ __launch_bounds__(256) void pme_combine_kernel(PmeBrickArgs a, size_t
         for (int j = 0; j < 4; ++j) {
             const int kz = kz0 + lane + 64 * j;
             ok[j] = kz < K2;
-            const int kc = ok[j] ? kz : 0;
-            const int bz = pme_brick_of(kc, K2, nbz);
-            const int s0 = pme_brick_start(bz, K2, nbz), s1 = pme_brick_start(bz + 1, K2, nbz);
-            const int l = kc - s0;
-            two[j] = l >= s1 - s0 - 3;
-            i0[j] = bz * cb2 + l + 3;
-            i1[j] = two[j] ? (bz + 1 == nbz ? 0 : bz + 1) * cb2 + l - (s1 - s0) + 3 : i0[j];
+            const int2 zt = a.bg.ztab[ok[j] ? kz : 0];
+            two[j] = zt.y >= 0;
+            i0[j] = zt.x;
+            i1[j] = two[j] ? zt.y : zt.x;
         }
         int v[4] = {0, 0, 0, 0};      // fixed point: the sum is exact and does not depend on which workgroup finished first
         for (int ix = 0; ix < nn[0]; ++ix)
@@ -952,7 +955,7 @@ static std::vector<double> bspline_moduli4(int K) {
 
 static void pme_slab_free(PmePlan* p);
 static void pme_brick_free(PmePlan* p) {
-    for (void** q : {(void**)&p->brick.rec, (void**)&p->brick.code, (void**)&p->brick.slot, (void**)&p->brick.count, (void**)&p->brick.ovf, (void**)&p->brick.scratch})
+    for (void** q : {(void**)&p->brick.ctab, (void**)&p->brick.ztab, (void**)&p->brick.rec, (void**)&p->brick.code, (void**)&p->brick.slot, (void**)&p->brick.count, (void**)&p->brick.ovf, (void**)&p->brick.scratch})
         if (*q) { (void)hipFree(*q); *q = nullptr; }
     p->brick.on = false;
 }
@@ -998,6 +1001,27 @@ static int pme_brick_setup(mdx_handle* h, PmePlan* p) {
     HIP_TRY(hipMemset(p->brick.count, 0, sizeof(uint32_t) * ((size_t)g.nbricks + 4)));
     HIP_TRY(hipMalloc((void**)&p->brick.ovf, sizeof(uint32_t) * ((size_t)h->N + 64)));
     HIP_TRY(hipMalloc((void**)&p->brick.scratch, sizeof(int) * (size_t)g.nbricks * g.stride));
+    {   // the tables (host mirrors of pme_brick_of / pme_brick_start)
+        auto start = [](int i, int K, int nb) { return (i * K) / nb; };
+        auto brick_of = [](int k, int K, int nb) { return ((k + 1) * nb - 1) / K; };
+        std::vector<uint32_t> ct;
+        for (int d = 0; d < 3; ++d) {
+            g.coff[d] = (int)ct.size();
+            for (int k = 0; k < h->pme_K[d]; ++k) { const int b = brick_of(k, h->pme_K[d], g.nb[d]); ct.push_back(((uint32_t)b << 16) | (uint32_t)(k - start(b, h->pme_K[d], g.nb[d]))); }
+        }
+        const int K2 = h->pme_K[2], nbz = g.nb[2], cb2 = g.cb[2];
+        std::vector<int2> zt(K2);
+        for (int kz = 0; kz < K2; ++kz) {
+            const int bz = brick_of(kz, K2, nbz), s0 = start(bz, K2, nbz), s1 = start(bz + 1, K2, nbz), l = kz - s0;
+            zt[kz].x = bz * cb2 + l + 3;
+            zt[kz].y = l >= s1 - s0 - 3 ? (bz + 1 == nbz ? 0 : bz + 1) * cb2 + l - (s1 - s0) + 3 : -1;
+        }
+        HIP_TRY(hipMalloc((void**)&p->brick.ctab, sizeof(uint32_t) * ct.size()));
+        HIP_TRY(hipMalloc((void**)&p->brick.ztab, sizeof(int2) * zt.size()));
+        HIP_TRY(hipMemcpy(p->brick.ctab, ct.data(), sizeof(uint32_t) * ct.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->brick.ztab, zt.data(), sizeof(int2) * zt.size(), hipMemcpyHostToDevice));
+        g.ctab = p->brick.ctab; g.ztab = p->brick.ztab;
+    }
     p->brick.on = true;
     return MDX_OK;
 }
