@@ -352,9 +352,15 @@ __global__ __launch_bounds__(256) void pme_canvas_kernel(PmeBrickArgs a) {
     const int bz = (int)(b % (uint32_t)a.bg.nb[2]), by = (int)((b / (uint32_t)a.bg.nb[2]) % (uint32_t)a.bg.nb[1]), bx = (int)(b / (uint32_t)(a.bg.nb[2] * a.bg.nb[1]));
     const size_t PY = (size_t)a.bg.nb[1] * cb1, PZ = (size_t)a.bg.nb[2] * cb2;
     int* out = a.scratch + ((size_t)bx * cb0 * PY + (size_t)by * cb1) * PZ + (size_t)bz * cb2;
-    for (uint32_t k = tid; k < vol; k += 256) {
-        const uint32_t cz = k % (uint32_t)cb2, cy = (k / (uint32_t)cb2) % (uint32_t)cb1, cx = k / (uint32_t)(cb2 * cb1);
-        out[((size_t)cx * PY + cy) * PZ + cz] = s_q[k];
+    {   // (element k = tid, carried forward by 256 per iteration: see pme_gather_brick_kernel)
+        int cz = tid % cb2, cy = (tid / cb2) % cb1, cx = tid / (cb2 * cb1);
+        const int dz = 256 % cb2, dy = (256 / cb2) % cb1, dx = 256 / (cb2 * cb1);
+        for (uint32_t k = tid; k < vol; k += 256) {
+            out[((size_t)cx * PY + cy) * PZ + cz] = s_q[k];
+            cz += dz; if (cz >= cb2) { cz -= cb2; ++cy; }
+            cy += dy; if (cy >= cb1) { cy -= cb1; ++cx; }
+            cx += dx;
+        }
     }
 }
 
@@ -782,12 +788,18 @@ __global__ __launch_bounds__(256) void pme_gather_brick_kernel(PmeBrickArgs a, c
     const int ox = pme_brick_start(bx, K0, a.bg.nb[0]) - 3, oy = pme_brick_start(by, K1, a.bg.nb[1]) - 3, oz = pme_brick_start(bz, K2, a.bg.nb[2]) - 3;
     const uint32_t n = min(a.count[b], a.bg.cap);
     if (n) {
+        // (cx, cy, cz) of element k = tid, then carried forward by 256 per iteration: three integer divisions per thread instead of
+        // four per element (27 elements per thread: the divisions were most of this loop)
+        int cz = tid % cb2, cy = (tid / cb2) % cb1, cx = tid / (cb2 * cb1);
+        const int dz = 256 % cb2, dy = (256 / cb2) % cb1, dx = 256 / (cb2 * cb1);
         for (uint32_t k = tid; k < vol; k += 256) {
-            const int cz = (int)(k % (uint32_t)cb2), cy = (int)((k / (uint32_t)cb2) % (uint32_t)cb1), cx = (int)(k / (uint32_t)(cb2 * cb1));
             int kx = ox + cx, ky = oy + cy, kz = oz + cz;      // (a canvas is at most K + 2 wide: one wrap either way)
             kx += kx < 0 ? K0 : (kx >= K0 ? -K0 : 0); ky += ky < 0 ? K1 : (ky >= K1 ? -K1 : 0); kz += kz < 0 ? K2 : (kz >= K2 ? -K2 : 0);
             kx = min(max(kx, 0), K0 - 1); ky = min(max(ky, 0), K1 - 1); kz = min(max(kz, 0), K2 - 1);      // (meshes narrower than a canvas: cells no atom of the brick reads)
             s_phi[k] = phi[((size_t)kx * K1 + ky) * K2 + kz];
+            cz += dz; if (cz >= cb2) { cz -= cb2; ++cy; }
+            cy += dy; if (cy >= cb1) { cy -= cb1; ++cx; }
+            cx += dx;
         }
     }
     __syncthreads();
