@@ -166,6 +166,8 @@ __global__ __launch_bounds__(256) void pme_spread_kernel(uint32_t S, const float
 // was +-3.5 e and nothing adapted to large charges.)
 constexpr float PME_FIX_MAX = 33554432.0f;          // 2^25
 constexpr int PME_TB = 14;    // LDS block edge in mesh points
+// k into [0, K): an index a few points outside the mesh (a canvas may be wider than a small mesh: a loop, but no integer division)
+__device__ __forceinline__ int pme_wrap(int k, int K) { while (k >= K) k -= K; while (k < 0) k += K; return k; }
 __global__ __launch_bounds__(256) void pme_spread_tile_kernel(uint32_t T, const float4* __restrict__ posq,
                                                               const uint8_t* __restrict__ slot_flags, PmeDev g,
                                                               float* __restrict__ Q, const uint32_t* gate, uint32_t thr, uint32_t need,
@@ -220,9 +222,7 @@ __global__ __launch_bounds__(256) void pme_spread_tile_kernel(uint32_t T, const 
                 if (fits) {
                     atomicAdd(&s_q[((lx + a) * PME_TB + (ly + b)) * PME_TB + (lz + c)], __float2int_rn(v * g.fix));
                 } else {
-                    int kx = (k0[0] + a) % g.K[0]; if (kx < 0) kx += g.K[0];
-                    int ky = (k0[1] + b) % g.K[1]; if (ky < 0) ky += g.K[1];
-                    int kz = (k0[2] + c) % g.K[2]; if (kz < 0) kz += g.K[2];
+                    const int kx = pme_wrap(k0[0] + a, g.K[0]), ky = pme_wrap(k0[1] + b, g.K[1]), kz = pme_wrap(k0[2] + c, g.K[2]);
                     atomicAdd(Q + ((size_t)kx * g.K[1] + ky) * g.K[2] + kz, v);
                 }
             }
@@ -235,9 +235,7 @@ __global__ __launch_bounds__(256) void pme_spread_tile_kernel(uint32_t T, const 
         if (vi != 0) {
             const float v = (float)vi * g.unfix;
             const int lz = k % PME_TB, ly = (k / PME_TB) % PME_TB, lx = k / (PME_TB * PME_TB);
-            int kx = (ox + lx) % g.K[0]; if (kx < 0) kx += g.K[0];
-            int ky = (oy + ly) % g.K[1]; if (ky < 0) ky += g.K[1];
-            int kz = (oz + lz) % g.K[2]; if (kz < 0) kz += g.K[2];
+            const int kx = pme_wrap(ox + lx, g.K[0]), ky = pme_wrap(oy + ly, g.K[1]), kz = pme_wrap(oz + lz, g.K[2]);
             atomicAdd(Q + ((size_t)kx * g.K[1] + ky) * g.K[2] + kz, v);
         }
     }
