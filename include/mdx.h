@@ -288,6 +288,14 @@ const char* mdx_constraint_description(mdx_handle* h);
  * step loop least). */
 int mdx_profile(mdx_handle* h, int enable);
 int mdx_get_stats(mdx_handle* h, mdx_stats* out);
+/* Diagnostics: which instantiation of the pair kernel the handle launched last - out[0..7] by the step loop over the dual pair
+ * list, out[8..15] by any other force call (mdx_energy, the minimiser, single points); all zero until such a launch happened.
+ * Per block: {waves per tile (0: the whole-tile kernel), dual-list body (0 plain list, 1 / 2 inner-walk / pruning twins, 3 one merged
+ * launch - the device picks the body, 4 merged + the bonded gather in extra workgroups), half list, Coulomb flavour (0 shifted cutoff,
+ * 1 reaction field, 2 Ewald closed form, 3 softened, 4 Ewald table), energy flavour, workgroups per tile, bonded workgroups behind
+ * twin launches, tiles in the launch}.  The parity tests use it to name the body they hold against the oracle; no call of the
+ * reference corresponds to it. */
+int mdx_pair_launch_info(const mdx_handle* h, uint32_t out[16]);
 /* The Verlet skin in force, and whether the library is still tuning it (mdx_config.skin == 0). */
 int mdx_get_skin(const mdx_handle* h, float* skin, int* tuning);
 
@@ -448,7 +456,8 @@ double   mdx_time_ps(const mdx_handle* h);
  * interaction energy (BASELINE config 3, src/docking/mod.rs:81-154).  Off until groups are set:
  *   mdx_set_energy_groups(h, NULL, 0)        one group per molecule of mdx_system.mol_start (at most 255 molecules)
  *   mdx_set_energy_groups(h, group_of_atom, n) group_of_atom[i] < n <= 255 for every atom
- *   mdx_set_energy_groups(h, NULL, 0) on a system without mol_start: off again
+ *   mdx_set_energy_groups(h, NULL, MDX_GROUPS_OFF)  off again, on any system (snapshots stop paying the extra pair-list pass);
+ *                                            (h, NULL, 0) on a system without mol_start also means off
  * The matrix is symmetric, kcal/mol:
  *   M[a][b] (a != b)  sum over atom pairs (i in a, j in b) of the pair loop's Lennard-Jones + Coulomb energy - the configured
  *                     real-space treatment (shifted cutoff / reaction field / erfc(beta r)/r), same cutoffs, exclusions and periodic
@@ -458,12 +467,14 @@ double   mdx_time_ps(const mdx_handle* h);
  * mesh term belongs to the whole charge density and is not split).  With an alchemical window the coupled pairs enter scaled,
  * as in mdx_energies.  mdx_energy_between_mols evaluates the current state (one extra pass over the pair list; collective on a
  * decomposed handle); while groups are set every stored snapshot carries its matrix (mdx_snapshot_read_between_mols). */
+#define MDX_GROUPS_OFF 0xFFFFFFFFu
 int      mdx_set_energy_groups(mdx_handle* h, const uint8_t* group_of_atom /* [N] or NULL */, uint32_t n_groups);
 uint32_t mdx_energy_group_count(const mdx_handle* h);
 int      mdx_energy_between_mols(mdx_handle* h, float* out /* [n * n] row-major */, uint32_t n);
 int      mdx_snapshot_read_between_mols(mdx_handle* h, uint32_t k, float* out /* [n * n] */, uint32_t n);
 /* compute_energy_snapshot with the matrix: mdx_single_point (same pose cache, same results) followed by the matrix of the same
- * pose for the given groups (group_of_atom NULL: by molecule).  The ligand row of a receptor / ligand / solvent map is what a
+ * pose for the given groups (group_of_atom NULL: by molecule, and n_groups must then equal mdx_system.n_mols - matrix_out is
+ * n_groups x n_groups either way; a mismatch is MDX_EPARAM, nothing is written).  The ligand row of a receptor / ligand / solvent map is what a
  * docking pose is ranked by. */
 int      mdx_single_point_between_mols(const mdx_system* sys, const mdx_config* cfg, int device, const uint8_t* group_of_atom,
                                        uint32_t n_groups, mdx_energies* out, float* forces_or_null, float* matrix_out /* [n * n] */);

@@ -16,6 +16,7 @@
 // GPUs (the reference degrades to its CPU path, src/util.rs:1072-1119; this library has none and says so),
 // `BlowUpError` for non-finite state (sol_shrinking_box.rs:776-789).
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <stdexcept>
@@ -69,6 +70,47 @@ struct Snapshot {
 /// `SimBox {bounds_low, bounds_high}` (src/properties/sol_shrinking_box.rs:600-603).
 struct SimBox {
     std::array<float, 3> bounds_low{}, bounds_high{};
+    std::array<float, 3> extent() const { return {bounds_high[0] - bounds_low[0], bounds_high[1] - bounds_low[1], bounds_high[2] - bounds_low[2]}; }
+    std::array<float, 3> center() const { return {0.5f * (bounds_high[0] + bounds_low[0]), 0.5f * (bounds_high[1] + bounds_low[1]), 0.5f * (bounds_high[2] + bounds_low[2])}; }
+    /// Writes the cell into a system description and makes it periodic (what `MdState::new` does with `cfg.sim_box`).
+    void apply(mdx_system& sys) const {
+        for (int k = 0; k < 3; ++k) { sys.box_lo[k] = bounds_low[k]; sys.box_hi[k] = bounds_high[k]; }
+        sys.periodic = 1;
+    }
+};
+
+/// `SimBoxInit::{Pad(f32), Fixed((lo, hi))}` + `SimBoxInit::new_cube(side)` (src/md/mod.rs:656-659; src/ui/panels/md.rs:582-584;
+/// src/properties/water_sol.rs:190, crystal.rs:321, logp.rs:119).  `Pad`: the cell is the extent of the atoms plus `pad` on every
+/// side - the rule the reference restates itself at src/gromacs/mod.rs:540-576 ("a copy+paste of SimBox::from_atoms in dynamics":
+/// bounds_low = min - pad, bounds_high = max + pad).  `new_cube`: a cube of the given edge; where the crate centres it is not
+/// visible in the tree - here about `centre` (default: the origin; callers set `recenter_sim_box`, water_sol.rs:192).
+struct SimBoxInit {
+    enum class Kind { Pad, Fixed } kind = Kind::Pad;
+    float pad = 12.f;                         // the UI's default (src/ui/panels/md.rs:582)
+    SimBox fixed{};
+    static SimBoxInit Pad(float pad_angstrom) { SimBoxInit b; b.kind = Kind::Pad; b.pad = pad_angstrom; return b; }
+    static SimBoxInit Fixed(const std::array<float, 3>& lo, const std::array<float, 3>& hi) {
+        SimBoxInit b; b.kind = Kind::Fixed; b.fixed.bounds_low = lo; b.fixed.bounds_high = hi; return b;
+    }
+    static SimBoxInit new_cube(float side, const std::array<float, 3>& centre = {0.f, 0.f, 0.f}) {
+        const float h = 0.5f * side;
+        return Fixed({centre[0] - h, centre[1] - h, centre[2] - h}, {centre[0] + h, centre[1] + h, centre[2] + h});
+    }
+    /// `SimBox::from_atoms`: the cell for `n_atoms` positions ([3 n] floats).  Pad with no atoms is an error, as in the reference
+    /// (`sim_box_nm` returns None, src/gromacs/mod.rs:571-573).
+    SimBox resolve(const float* pos, size_t n_atoms) const {
+        if (kind == Kind::Fixed) return fixed;
+        if (!pos || n_atoms == 0) throw ParamError("SimBoxInit::Pad needs at least one atom");
+        SimBox b;
+        for (int k = 0; k < 3; ++k) { b.bounds_low[k] = pos[k]; b.bounds_high[k] = pos[k]; }
+        for (size_t i = 1; i < n_atoms; ++i)
+            for (int k = 0; k < 3; ++k) {
+                b.bounds_low[k] = std::min(b.bounds_low[k], pos[3 * i + k]);
+                b.bounds_high[k] = std::max(b.bounds_high[k], pos[3 * i + k]);
+            }
+        for (int k = 0; k < 3; ++k) { b.bounds_low[k] -= pad; b.bounds_high[k] += pad; }
+        return b;
+    }
 };
 
 class MdState {

@@ -168,6 +168,41 @@ def _arr(a, dtype, shape=None):
     return a
 
 
+class SimBoxInit:
+    """`SimBoxInit::{Pad(f32), Fixed((lo, hi))}` and `SimBoxInit::new_cube(side)` (/root/reference src/md/mod.rs:656-659,
+    src/ui/panels/md.rs:582-584, src/properties/water_sol.rs:190, crystal.rs:321, logp.rs:119).  Pad: the extent of the atoms plus
+    `pad` on every side - the rule the reference restates itself at src/gromacs/mod.rs:540-576 ("a copy+paste of SimBox::from_atoms
+    in dynamics").  new_cube: a cube of the given edge about `centre` (where the crate centres it is not visible in the tree)."""
+
+    def __init__(self, kind: str, pad: float = 12.0, lo=None, hi=None):
+        assert kind in ("pad", "fixed")
+        self.kind, self.pad = kind, float(pad)
+        self.lo = None if lo is None else np.asarray(lo, np.float32).reshape(3)
+        self.hi = None if hi is None else np.asarray(hi, np.float32).reshape(3)
+
+    @classmethod
+    def Pad(cls, pad: float) -> "SimBoxInit":
+        return cls("pad", pad=pad)
+
+    @classmethod
+    def Fixed(cls, lo, hi) -> "SimBoxInit":
+        return cls("fixed", lo=lo, hi=hi)
+
+    @classmethod
+    def new_cube(cls, side: float, centre=(0.0, 0.0, 0.0)) -> "SimBoxInit":
+        c = np.asarray(centre, np.float32)
+        return cls.Fixed(c - np.float32(0.5 * side), c + np.float32(0.5 * side))
+
+    def resolve(self, pos):
+        """`SimBox::from_atoms` -> (bounds_low, bounds_high), float32[3] each."""
+        if self.kind == "fixed":
+            return self.lo.copy(), self.hi.copy()
+        p = np.asarray(pos, np.float32).reshape(-1, 3)
+        if p.shape[0] == 0:
+            raise ValueError("SimBoxInit.Pad needs at least one atom")        # (`sim_box_nm` returns None, src/gromacs/mod.rs:571-573)
+        return p.min(0) - np.float32(self.pad), p.max(0) + np.float32(self.pad)
+
+
 @dataclass
 class MdSystem:
     """Flat SoA system: the shape `setup_mols_dyn` hands to `MdState::new`
@@ -207,6 +242,12 @@ class MdSystem:
     @property
     def n_atoms(self) -> int:
         return int(np.asarray(self.pos).reshape(-1, 3).shape[0])
+
+    def apply_sim_box(self, init: "SimBoxInit") -> "MdSystem":
+        """`cfg.sim_box` as `MdState::new` applies it (src/md/mod.rs:656-659): the cell of these atoms, periodic."""
+        lo, hi = init.resolve(self.pos)
+        self.box_lo, self.box_hi, self.periodic = tuple(float(v) for v in lo), tuple(float(v) for v in hi), True
+        return self
 
     def normalise(self) -> "MdSystem":
         n = self.n_atoms

@@ -1057,6 +1057,10 @@ static thread_local SinglePointCache g_sp_cache;
 extern "C" int mdx_single_point_between_mols(const mdx_system* sys, const mdx_config* cfg, int device, const uint8_t* group_of_atom,
                                              uint32_t n_groups, mdx_energies* out, float* forces_or_null, float* matrix_out) {
     if (!matrix_out) FAIL(MDX_EPARAM, "null matrix_out");
+    // matrix_out holds n_groups^2 floats: with the by-molecule map that must be the system's molecule count (a caller that sized the
+    // buffer by another number would be overrun)
+    if (sys && !group_of_atom && n_groups != sys->n_mols)
+        FAIL(MDX_EPARAM, "group_of_atom == NULL groups by molecule: n_groups must equal mdx_system.n_mols (the matrix is n_mols x n_mols)");
     MDX_TRY(mdx_single_point(sys, cfg, device, out, forces_or_null));
     mdx_handle* h = g_sp_cache.h;      // the pose just scored lives on the calling thread's kept handle
     if (!h) FAIL(MDX_EDEVICE, "internal: the scorer kept no handle");
@@ -1382,6 +1386,12 @@ extern "C" int mdx_get_skin(const mdx_handle* h, float* skin, int* tuning) {
     if (!h) FAIL(MDX_EPARAM, "null handle");
     if (skin) *skin = h->cfg.skin;
     if (tuning) *tuning = (h->skin_tune.on && h->skin_tune.phase < 4) ? 1 : 0;
+    return MDX_OK;
+}
+
+extern "C" int mdx_pair_launch_info(const mdx_handle* h, uint32_t out[16]) {
+    if (!h || !out) FAIL(MDX_EPARAM, "null argument");
+    for (int k = 0; k < 8; ++k) { out[k] = h->pair_info_step[k]; out[8 + k] = h->pair_info_any[k]; }
     return MDX_OK;
 }
 

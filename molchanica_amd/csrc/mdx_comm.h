@@ -101,6 +101,7 @@ struct MdxDecomp {
                                        // state of the step the list went stale at depends on the parity of the gated-off passes behind it
     // ---- the fused bonded + kick + drift pass carries halo pack and ghost-force add (mdx_decomp.hip "fold") ------------------------------
     bool fold_ok = false;              // the drift pass may pack the halo and add the returned ghost forces (half shell, communication on the compute stream, MDX_HALO_FOLD != 0)
+    bool rows_fit = true;              // this partition sends no atom to more than seven peers (dd_classify_kernel): the per-slot row table of the fold holds them all
     bool pipe_now = false;             // the step being enqueued has its halo packed by the drift pass (mdx_step)
     bool packed_by_drift = false;      // ... and that pass has been enqueued: the halo exchange starts at the send/recv group
     bool frc_deferred = false;         // the ghost forces returned for the last force call are still in frc_recv: the next drift pass adds them
@@ -123,7 +124,7 @@ static inline bool mdx_dd_split_now(const mdx_handle* h) {
 // Does the fused bonded + kick + drift pass of a decomposed handle carry the halo pack and the add of the returned ghost forces?
 // (two kernels and two launch boundaries less per step, whichever way the pair kernel is launched)
 static inline bool mdx_dd_fold_eligible(const mdx_handle* h) {
-    return h->dd && h->dd->fold_ok && h->dd->world > 1 && mdx_nb_half(h) && !h->pme_on && !h->alch_on;
+    return h->dd && h->dd->fold_ok && h->dd->rows_fit && h->dd->world > 1 && mdx_nb_half(h) && !h->pme_on && !h->alch_on;
 }
 
 int  mdx_set_local_atoms_impl(mdx_handle* h, uint32_t n_local, const uint32_t* d_gid, const uint8_t* d_ghost, const float* d_pos4,

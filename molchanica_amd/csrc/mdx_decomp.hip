@@ -161,6 +161,9 @@ __global__ __launch_bounds__(256) void dd_classify_kernel(uint32_t N, const floa
             }
         }
     }
+    // the folded drift pass keeps at most seven message rows per slot (one per peer of a 2 x 2 x 2 grid); thinner bricks / more ranks
+    // can exceed that: the host then leaves the fold off for this partition (MdxDecomp::rows_fit)
+    if (__popc(mask) > 7) atomicOr(err, 8u);
     cls[g] = (uint8_t)c; owner[g] = (uint8_t)own; shift_code[g] = (uint8_t)code; send_mask[g] = mask;
 }
 
@@ -366,6 +369,7 @@ static int dd_partition(mdx_handle* h) {
                  err[3] & 0xFFu, dd->rank, dd->halo);
         FAIL(MDX_EPARAM, buf);
     }
+    dd->rows_fit = !(err[0] & 8u);      // (a rank-local matter: the messages are the same whoever packs them)
     DdFill f{};
     for (int s = 0; s <= nseg; ++s) f.seg_start[s] = heads[s];
     dd->send_segs.clear(); dd->recv_segs.clear();
@@ -665,7 +669,7 @@ __global__ void pipe_rows_kernel(uint32_t n_send, const uint32_t* __restrict__ s
     const uint32_t s = slot_of[g];
     if (s == MDX_INVALID) return;
     const uint32_t k = atomicAdd(send_cnt + s, 1u);
-    if (k < 7u) send_rows[(size_t)s * 7 + k] = i; else atomicOr(err, 16u);
+    if (k < 7u) send_rows[(size_t)s * 7 + k] = i; else atomicOr(err, 1u);      // (cannot happen while MdxDecomp::rows_fit gates the fold; a word of its own in PipeCtl)
 }
 // null transport with a stated wire time: the receive buffers hold what the unpack / add kernels turn into no-ops
 __global__ void pipe_loopback_kernel(uint32_t n_recv, const uint32_t* __restrict__ recv_ids, const uint32_t* __restrict__ slot_of,
@@ -699,7 +703,7 @@ static int dd_pipe_tables(mdx_handle* h) {
     HIP_TRY(hipMemsetAsync(dd->send_cnt, 0, sizeof(uint32_t) * (size_t)h->S, st));
     if (dd->n_send)
         hipLaunchKernelGGL(pipe_rows_kernel, dim3(div_up(dd->n_send, 256)), dim3(256), 0, st, dd->n_send, dd->send_ids, h->d.slot_of, dd->send_cnt,
-                           dd->send_rows, h->d.flags_dev);
+                           dd->send_rows, &dd->pipe_ctl->rows_overflow);
     if (dd->tr->loopback()) {
         if (dd->n_recv)
             hipLaunchKernelGGL(pipe_loopback_kernel, dim3(div_up(dd->n_recv, 256)), dim3(256), 0, st, dd->n_recv, dd->recv_ids, h->d.slot_of, h->d.posq,
@@ -717,12 +721,22 @@ bool mdx_dd_pipe_fill(mdx_handle* h, FusedArgs& a, uint32_t* gate_word) {
     MdxDecomp* dd = h->dd;
     a.pipe_flags = 0u;
     if (!dd || !(dd->pipe_now || dd->frc_deferred)) return false;
-    if (!dd->rows_valid && dd_pipe_tables(h) != MDX_OK) return false;
+    if (!dd->rows_valid && dd_pipe_tables(h) != MDX_OK) {
+        // no tables, no fold: the plain pass runs instead.  Ghost forces that mdx_dd_force_return_end left to this pass are added by
+        // the kernel of the unfolded arrangement first (gate_word: the control word of that force call, where the peers' stale words
+        // merge), and the step's halo goes out through the pack kernel (pipe_now off: mdx_dd_halo_begin packs)
+        if (dd->frc_deferred && (dd->tr->delivers() || dd->tr->loopback()) && dd->n_send)
+            hipLaunchKernelGGL(dd_add_force_kernel, dim3(div_up(dd->n_send, 256)), dim3(256), 0, h->stream, dd->n_send, dd->send_ids, h->d.slot_of,
+                               h->d.force, dd->frc_recv, gate_word);
+        dd->frc_deferred = false; dd->pipe_now = false; dd->fold_ok = false;
+        return false;
+    }
     a.pipe_flags = (dd->frc_deferred ? 1u : 0u) | (dd->pipe_now ? 2u : 0u);
     dd->frc_deferred = false;
     a.send_cnt = dd->send_cnt; a.send_rows = dd->send_rows; a.frc_in = dd->frc_recv; a.send_buf = dd->send_buf;
     a.n_flag = 0;
-    for (const MdxSeg& sg : dd->send_segs) if (a.n_flag < 8 && sg.nrows) a.flag_rows[a.n_flag++] = sg.row0 + sg.nrows - 1;
+    static_assert(sizeof(a.flag_rows) / sizeof(a.flag_rows[0]) >= DD_MAX_WORLD, "one flag row per peer");
+    for (const MdxSeg& sg : dd->send_segs) if (sg.nrows) a.flag_rows[a.n_flag++] = sg.row0 + sg.nrows - 1;      // EVERY peer must hear "my list went stale"
     a.pc = dd->pipe_ctl; a.gate_word = gate_word;
     if (dd->pipe_now) { ++dd->pipe_gen; ++dd->pipe_steps; dd->packed_by_drift = true; }
     return true;

@@ -225,10 +225,13 @@ extern "C" int mdx_set_energy_groups(mdx_handle* h, const uint8_t* group_of_atom
     std::vector<uint8_t> g(N, 0);
     uint32_t G = n_groups;
     if (!group_of_atom) {
-        if (n_groups == 0 && h->mol_start.empty()) {      // off
+        if (n_groups == MDX_GROUPS_OFF || (n_groups == 0 && h->mol_start.empty())) {      // off (explicitly, or as before on a system without molecules)
+            if (h->d.grp) { (void)hipFree(h->d.grp); h->d.grp = nullptr; }
+            if (h->d.grp_mat) { (void)hipFree(h->d.grp_mat); h->d.grp_mat = nullptr; }
             h->n_grp = 0; h->grp_host.clear();
             return MDX_OK;
         }
+        if (n_groups != 0) FAIL(MDX_EPARAM, "a NULL group map takes n_groups = 0 (one group per molecule) or MDX_GROUPS_OFF");
         // by molecule: md.mol_start_indices (src/md/mod.rs:809-947)
         if (h->mol_start.empty()) FAIL(MDX_EPARAM, "grouping by molecule needs mol_start in the system description");
         if (h->mol_start.size() > MDX_MAX_GROUPS) FAIL(MDX_EPARAM, "more than 255 molecules: pass a group map (mdx_set_energy_groups) of at most 255 groups");

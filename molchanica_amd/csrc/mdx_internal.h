@@ -122,7 +122,7 @@ struct StepCtl {
 // returned for the previous force call (mdx_integrate.hip, mdx_decomp.hip).  Its workgroups count themselves in here - two levels, by
 // blockIdx & 7 and then by shard - so that the one that arrives last can write the flag rows of the message (the "list went stale"
 // word is complete only then).
-struct __attribute__((aligned(128))) PipeCtl { uint32_t m1_shard[16]; uint32_t pad[16]; };
+struct __attribute__((aligned(128))) PipeCtl { uint32_t m1_shard[16]; uint32_t rows_overflow; uint32_t pad[15]; };
 
 // One (term, atom-of-that-term) record of the atom-owned bonded gather (mdx_bonded.hip).
 enum { ROLE_BOND = 0, ROLE_ANGLE = 1, ROLE_DIHEDRAL = 2, ROLE_PAIR14 = 3, ROLE_EWALD_EXCL = 4 };
@@ -370,6 +370,7 @@ struct mdx_handle {
     bool force_zeroed = false;   // the integrate pass just enqueued cleared the force array (half-list kernel: skip the fill)
     bool cons_full_kick = false; // the SHAKE pass about to be enqueued follows a fused full kick (closing + opening): its corrections are those of a force acting through dt
     bool bonded_fused = false;   // the pair launch just enqueued carried the bonded gather in extra workgroups: skip its own launch
+    uint32_t pair_info_step[8] = {}, pair_info_any[8] = {};   // the pair-kernel instantiation last launched by the step loop over the dual list / by anything else (mdx_pair_launch_info)
     bool bonded_deferred = false; // step loop, large classes: the NEXT step's fused bonded + kick + drift pass evaluates the bonded terms of this force call
     uint64_t rng_state = 0;
     bool zero_com = false;
@@ -409,7 +410,7 @@ struct FusedArgs {
     uint32_t pipe_flags;
     const uint32_t* send_cnt; const uint32_t* send_rows;      // per slot: rows of the position message it fills (at most 7: one per peer), [S], [7 S]
     const float4* frc_in; float4* send_buf;
-    uint32_t n_flag; uint32_t flag_rows[8];
+    uint32_t n_flag; uint32_t flag_rows[32];                   // one per peer (DD_MAX_WORLD: mdx_decomp.hip asserts it)
     PipeCtl* pc;
     uint32_t* gate_word;                                       // = gate_in, writable: the merged stale word is stored back for the kernels behind
 };

@@ -672,6 +672,12 @@ void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samecut) {
     static const int split_env = [] { const char* e = std::getenv("MDX_TILE_SPLIT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     const bool split2 = split_env >= 0 ? split_env == 1 : (a.tile_order ? a.t_count : a.T) < 1024u;
     static const bool fb_all = [] { const char* e = std::getenv("MDX_FUSE_BONDED"); return e && e[0] == '2'; }();   // A/B: also the twin launches of the large classes
+    // which instantiation goes out (mdx_pair_launch_info: the parity tests name the body they hold against the oracle)
+    auto note = [&](int dual, int w, int split, int fb) {
+        uint32_t* const o = a.inner ? h->pair_info_step : h->pair_info_any;
+        o[0] = (uint32_t)w; o[1] = (uint32_t)dual; o[2] = half ? 1u : 0u; o[3] = (uint32_t)COUL; o[4] = ENERGY ? 1u : 0u;
+        o[5] = (uint32_t)split; o[6] = (uint32_t)fb; o[7] = a.tile_order ? a.t_count : a.T;
+    };
     // dual list: the inner-walk kernel and the pruning kernel back to back, the device runs exactly one of them
 #define NB_DUAL(G, S, D)                                                                                              \
     do {                                                                                                               \
@@ -681,15 +687,18 @@ void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samecut) {
             const dim3 gf(grid + (uint32_t)(((size_t)a.b_S * 4 + bw * 64 - 1) / (bw * 64)));                           \
             if (wpt == 2) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 2, true, false, D, true>), gf, b, lds_pad, h->stream, af); \
             else hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 4, true, false, D, true>), gf, b, lds_pad, h->stream, af);          \
-            h->bonded_fused = true;                                                                                    \
+            h->bonded_fused = true; note(D, wpt, 1, 1);                                                                \
+            break;                                                                                                     \
         }                                                                                                              \
-        else if (wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, D>), g, b, lds_pad, h->stream, a); \
+        note(D, wpt == 8 || wpt == 2 || wpt == 1 ? wpt : 4, 1, 0);                                                     \
+        if (wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, D>), g, b, lds_pad, h->stream, a); \
         else if (wpt == 2) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 2, true, false, D>), g, b, lds_pad, h->stream, a); \
         else if (wpt == 1) hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 1, true, false, D>), g, b, lds_pad, h->stream, a); \
         else hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 4, true, false, D>), g, b, lds_pad, h->stream, a);               \
     } while (0)
 #define NB_LAUNCH(G, S)                                                                                    \
     do {                                                                                                   \
+        note(0, var == 1 ? 0 : ((h->alch_on && wpt != 8) ? 4 : wpt), 1, 0);   /* (the dual-list branches below overwrite it) */ \
         if (h->alch_on && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true, COUL != CM_EWALD_TAB>), g, b, lds_pad, h->stream, a); \
         else if (h->alch_on) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, true, COUL != CM_EWALD_TAB>), g, b, lds_pad, h->stream, a); \
         else if (var == 1) hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, G, S>), g, b, lds_pad, h->stream, a);     \
@@ -698,14 +707,14 @@ void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samecut) {
             const uint32_t nb2 = (a.tile_order ? a.t_count : a.T) * 2u;                                            \
             af.pair_grid = ((nb2 + 7) / 8) * 8;                                                                    \
             const dim3 gf(af.pair_grid + (a.b_S ? (uint32_t)(((size_t)a.b_S * 4 + 255) / 256) : 0u)), bf(256);     \
-            if (a.b_S) { hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, 4, false, 2>), gf, bf, lds_pad, h->stream, af); h->bonded_fused = true; } \
-            else hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, 3, false, 2>), gf, bf, lds_pad, h->stream, af); \
+            if (a.b_S) { hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, 4, false, 2>), gf, bf, lds_pad, h->stream, af); h->bonded_fused = true; note(4, 8, 2, 0); } \
+            else { hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, 3, false, 2>), gf, bf, lds_pad, h->stream, af); note(3, 8, 2, 0); } \
         }                                                                                                          \
         else if (half && a.inner && dual_merged && wpt == 8 && a.b_S && !ENERGY) {                                 \
             NbArgs af = a; af.pair_grid = grid;                                                                    \
             const dim3 gf(grid + (uint32_t)(((size_t)a.b_S * 4 + bw * 64 - 1) / (bw * 64)));                       \
             hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, G, S, 8, true, false, 4>), gf, b, lds_pad, h->stream, af); \
-            h->bonded_fused = true;                                                                                \
+            h->bonded_fused = true; note(4, 8, 1, 0);                                                              \
         }                                                                                                          \
         else if (half && a.inner && dual_merged && (wpt == 8 || merge_all)) { NB_DUAL(G, S, 3); }                  \
         else if (half && a.inner) { if (!a.force_prune) NB_DUAL(G, S, 1); NB_DUAL(G, S, 2); }   /* (a pass the host forces: no twin) */ \

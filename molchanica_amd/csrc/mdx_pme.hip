@@ -16,6 +16,7 @@
 // Self term, neutralising background and the erf(beta r)/r of excluded / 1-4 pairs (an extra role
 // kind in the bonded gather) complete the Ewald sum.  All mesh kernels are HBM/atomic-bound.
 #include "mdx_comm.h"
+#include <climits>
 #include <cstdlib>
 #include <hipfft/hipfft.h>
 #include <dlfcn.h>
@@ -1085,6 +1086,7 @@ int mdx_stream_unmask(mdx_handle* h) {
     if (h->stream_pme) {
         HIP_TRY(hipStreamSynchronize(h->stream_pme));
         (void)hipEventDestroy(h->ev_pme_fork); (void)hipEventDestroy(h->ev_pme_join);
+        h->ev_pme_fork = nullptr; h->ev_pme_join = nullptr;
         (void)hipStreamDestroy(h->stream_pme);
         h->stream_pme = nullptr;
     }
@@ -1098,6 +1100,7 @@ void mdx_pme_destroy(mdx_handle* h) {
     if (h->stream_pme) {
         (void)hipStreamSynchronize(h->stream_pme);
         (void)hipEventDestroy(h->ev_pme_fork); (void)hipEventDestroy(h->ev_pme_join);
+        h->ev_pme_fork = nullptr; h->ev_pme_join = nullptr;
         (void)hipStreamDestroy(h->stream_pme);
         h->stream_pme = nullptr;
     }
@@ -1307,7 +1310,11 @@ int mdx_pme_setup(mdx_handle* h) {
     // 294 at 256^3 (tools/ubench/fft_pitch.cpp, profiles/r05_fft_pitch.txt).  The pad entries carry theta = 0.  Decomposed handles
     // keep the packed rows (their slab transposes and the replicated-mesh all-reduce index with K2/2 + 1).  MDX_PME_PITCH=0: packed.
     static const bool pad_rows = [] { const char* e = std::getenv("MDX_PME_PITCH"); return !(e && e[0] == '0'); }();
-    const int pitch = (pad_rows && !h->dd && p->plan_many) ? (K3h + 15) & ~15 : K3h;
+    // (hipfftPlanMany takes the distance between transforms as an int: a padded mesh beyond 2^31 - 1 elements - above ~1290^3 -
+    // keeps the packed rows of hipfftPlan3d, which has no such argument)
+    const int pitch_pad = (K3h + 15) & ~15;
+    const bool pad_fits = (size_t)K[0] * K[1] * (size_t)pitch_pad <= (size_t)INT_MAX && (size_t)K[0] * K[1] * (size_t)K[2] <= (size_t)INT_MAX;
+    const int pitch = (pad_rows && !h->dd && p->plan_many && pad_fits) ? pitch_pad : K3h;
     const bool regrid = !p->have_plans || K[0] != h->pme_K[0] || K[1] != h->pme_K[1] || K[2] != h->pme_K[2] || pitch != p->pitch;
     p->n_real = (size_t)K[0] * K[1] * K[2];
     p->n_cplx = (size_t)K[0] * K[1] * pitch;
@@ -1373,6 +1380,7 @@ int mdx_pme_setup(mdx_handle* h) {
         const int env = e ? (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)) : -1;
         h->pme_overlap = !h->dd && (env >= 0 ? env >= 1 : h->N >= 65536u);
         if (h->pme_cus_per_xcd && (!h->pme_overlap || env == 2)) MDX_TRY(mdx_stream_unmask(h));      // (decided at create from the same inputs; a joined handle gets here)
+        // (mdx_stream_unmask replaces h->stream: every plan is pointed at its stream again right below, the slab plans in pme_slab_setup)
         // MDX_PME_OVERLAP=2 (A/B): the charge spread stays on the handle's stream, in FRONT of the pair kernel, and only the rest
         // of the chain (FFTs, solve, gather) runs beside it: spread and pair kernel both live on the LDS pipeline (ds_add_f32 /
         // the staged j-atoms) and run no faster side by side than one after the other

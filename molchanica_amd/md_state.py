@@ -84,6 +84,7 @@ def load_library():
     lib.mdx_profile.argtypes = [H, C.c_int]
     lib.mdx_get_stats.argtypes = [H, C.POINTER(CStats)]
     lib.mdx_get_skin.argtypes = [H, _fp, C.POINTER(C.c_int)]
+    lib.mdx_pair_launch_info.argtypes = [H, _u32p]
     lib.mdx_minimize_energy.argtypes = [H, C.c_uint32, _fp, C.c_float, C.POINTER(CEnergies), _u32p]
     lib.mdx_initialize_velocities.argtypes = [H, C.c_float, C.c_int, C.c_uint64]
     lib.mdx_set_thermostat.argtypes = [H, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_uint64]
@@ -244,6 +245,10 @@ class MdState:
             g = np.ascontiguousarray(group_of_atom, dtype=np.uint8).reshape(self.n_atoms)
             _check(lib.mdx_set_energy_groups(self._h, g.ctypes.data, int(n_groups)))
         return int(lib.mdx_energy_group_count(self._h))
+
+    def clear_energy_groups(self):
+        """Matrix output off again (`mdx_set_energy_groups(h, NULL, MDX_GROUPS_OFF)`): snapshots stop paying the extra pass."""
+        _check(load_library().mdx_set_energy_groups(self._h, None, 0xFFFFFFFF))
 
     def energy_between_mols(self) -> np.ndarray:
         """`SnapshotEnergyData.energy_potential_between_mols` of the current state: symmetric [n, n] f32, kcal/mol."""
@@ -458,6 +463,13 @@ class MdState:
         s = CStats()
         _check(load_library().mdx_get_stats(self._h, C.byref(s)))
         return s.as_dict()
+
+    def pair_launch_info(self) -> dict:
+        """Which pair-kernel instantiation ran last: {"step": {...}, "any": {...}} (include/mdx.h: mdx_pair_launch_info)."""
+        out = (C.c_uint32 * 16)()
+        _check(load_library().mdx_pair_launch_info(self._h, out))
+        keys = ("waves_per_tile", "dual", "half", "coulomb", "energy", "workgroups_per_tile", "bonded_workgroups", "tiles")
+        return {"step": dict(zip(keys, (int(v) for v in out[0:8]))), "any": dict(zip(keys, (int(v) for v in out[8:16])))}
 
     def skin(self):
         """-> (Verlet skin in force, still tuning?)  (MdConfig.skin == 0 lets the library choose it)."""

@@ -26,7 +26,11 @@ for case in range(n_cases):
     elif kind == "opc": s = systems.opc_water_box(int(rng.integers(14, 18)), seed=seed); dt = 0.002
     else: s = systems.small_solvated(seed=seed, n_chain=int(rng.integers(100, 400)), box=float(rng.uniform(44.0, 52.0))); dt = 0.0005
     L = np.array(s.box_hi, np.float64) - np.array(s.box_lo, np.float64)
-    world = int(rng.choice([2, 4, 8]))
+    world = int(rng.choice([int(w) for w in os.environ.get("FUZZ_WORLDS", "2,4,8").split(",")]))
+    if world > 8 and kind != "solvated":      # more ranks than the 2 x 2 x 2 grid: bricks stay wider than the halo in a larger box
+        nside = int(rng.integers(19, 22))
+        s = systems.water_box(nside, seed=seed, rigid=(kind == "rigid")) if kind != "opc" else systems.opc_water_box(nside, seed=seed)
+        L = np.array(s.box_hi, np.float64) - np.array(s.box_lo, np.float64)
     rc = float(rng.uniform(6.5, 8.5)); skin = float(rng.uniform(0.8, 1.6))
     # The plain shifted cut-off (mode 0) is the mode `bench.py --gpus N` times (flexible water, dt 0.5 fs).  Its FORCE is discontinuous
     # at rc: with 20 k sites a handful of pairs sit within an fp32 ulp of the cut-off at every step, which side they fall on differs
@@ -40,6 +44,8 @@ for case in range(n_cases):
     if mode == 2: cfgk.update(ewald_alpha=float(rng.uniform(0.3, 0.4)), overrides=0 if rng.random() < 0.6 else _abi.OVR_LONG_RANGE_RECIP_DISABLED)
     cfg = MdConfig(**cfgk)
     env = {k: str(rng.choice(v)) for k, v in KNOBS.items() if rng.random() < 0.5}
+    for kv in filter(None, os.environ.get("FUZZ_FORCE", "").split(",")):      # knobs a caller pins for every case
+        env[kv.split("=")[0]] = kv.split("=")[1]
     for k in KNOBS: os.environ.pop(k, None)
     os.environ.update(env)
     n_steps = int(rng.integers(30, 41))

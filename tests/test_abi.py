@@ -42,6 +42,33 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, name), f"libmdx.so does not export {name}"
 
 
+def test_every_export_is_bound_or_listed():
+    """INTEGRATION.md is what a maintainer of the reference copies from: every export of include/mdx.h is either declared in its Rust
+    `extern "C"` block or named in its "not bound" list, and neither names a symbol the header does not have."""
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blk = txt[txt.index('extern "C" {'):]
+    blk = blk[:blk.index("\n}\n")]
+    bound = set(re.findall(r"pub fn (mdx_[a-z0-9_]+)", blk))
+    nb = txt[txt.index("<!-- not-bound:begin -->"):txt.index("<!-- not-bound:end -->")]
+    listed = set(re.findall(r"`(mdx_[a-z0-9_]+)`", nb))
+    syms = set(declared_symbols())
+    assert not (syms - bound - listed), f"exports neither bound nor listed in INTEGRATION.md: {sorted(syms - bound - listed)}"
+    assert not ((bound | listed) - syms), f"INTEGRATION.md names symbols include/mdx.h does not declare: {sorted((bound | listed) - syms)}"
+    assert not (bound & listed)
+    # md.computation_time() (/root/reference src/md/mod.rs:740-743) needs these two and the struct
+    assert {"mdx_get_stats", "mdx_profile", "mdx_time_ps"} <= bound and "pub struct MdxStats" in txt
+
+
+def test_rust_stats_struct_mirrors_the_ctypes_one():
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    body = txt[txt.index("pub struct MdxStats {"):]
+    body = body[:body.index("\n}\n")]
+    body = re.sub(r"//.*", "", body)
+    rust = re.findall(r"pub ([a-z0-9_]+): (u64|u32|f64)", body)
+    want = {C.c_uint64: "u64", C.c_uint32: "u32", C.c_double: "f64"}
+    assert rust == [(n, want[t]) for n, t in _abi.CStats._fields_]
+
+
 def test_struct_layouts_match_c(tmp_path):
     prog = r'''
 #include <stdio.h>

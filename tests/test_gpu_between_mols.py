@@ -144,6 +144,20 @@ def test_refusals(mdx):
         import ctypes as C
         out = np.zeros(9, np.float32)
         assert lib.mdx_energy_between_mols(md._h, out.ctypes.data_as(C.POINTER(C.c_float)), 3) != 0      # n != number of groups
+        # off again, explicitly, on a system WITH molecules ((NULL, 0) switches the by-molecule groups back on there)
+        md.clear_energy_groups()
+        assert lib.mdx_energy_group_count(md._h) == 0
+        with pytest.raises(mdx.ParamError):
+            md.energy_between_mols()
+        assert lib.mdx_set_energy_groups(md._h, None, 5) != 0                   # a NULL map takes 0 or MDX_GROUPS_OFF
+    # the stateless scorer with the by-molecule map: the caller's n_groups sizes matrix_out, so it must be the molecule count
+    s.normalise()
+    cs, cc = s.to_c(), MdConfig(lj_cutoff=8.0, coulomb_cutoff=8.0, skin=1.0).to_c()
+    from molchanica_amd._abi import CEnergies
+    e = CEnergies()
+    small = np.full(4, -7.0, np.float32)
+    rc = lib.mdx_single_point_between_mols(C.byref(cs), C.byref(cc), 0, None, 2, C.byref(e), None, small.ctypes.data_as(C.POINTER(C.c_float)))
+    assert rc != 0 and (small == -7.0).all(), "a by-molecule request with n_groups != n_mols must be refused before anything is written"
     w = systems.water_box(8, seed=3)                   # 512 molecules: more than a byte can index
     with mdx.MdState(w, MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5)) as md:
         with pytest.raises(mdx.ParamError):

@@ -42,3 +42,11 @@ def test_randomised_decomposed_runs_with_the_fused_drift_pass_on_small_boxes():
     """The fused bonded + kick + drift pass - on a decomposed handle it also packs the halo and adds the returned ghost forces -
     is a large-system arrangement (>= 2048 tiles per rank); MDX_WPT8_BELOW=32 takes the small boxes of the fuzz through it."""
     run_script("fuzz_decomp.py", 24, 23, {"MDX_WPT8_BELOW": "32"})
+
+
+def test_randomised_decomposed_runs_on_twelve_and_sixteen_ranks_with_the_fold():
+    """More peers than the seven of a 2 x 2 x 2 grid: the folded drift pass publishes its stale word to EVERY peer
+    (FusedArgs::flag_rows holds one row per rank) and a partition that sends an atom to more than seven peers leaves the fold off
+    (MdxDecomp::rows_fit); MDX_DD_SPEC_CHECK=1 holds every speculative drift probe against the synchronous one."""
+    run_script("fuzz_decomp.py", 6, 24, {"MDX_WPT8_BELOW": "32", "FUZZ_WORLDS": "12,16", "MDX_DD_SPEC_CHECK": "1",
+                                         "FUZZ_FORCE": "MDX_HALO_FOLD=1,MDX_HALF_SHELL=1,MDX_FUSE_BONDED_INTEGRATE_DD=1"})

@@ -526,18 +526,23 @@ def test_every_pair_kernel_variant_against_the_oracle(mdx, orc, name, variant):
         assert np.abs(f.astype(np.float64).sum(0)).max() < 2e-3
 
 
-def test_half_list_four_waves_per_tile_size_class(mdx, orc):
-    """The default kernel picks 8 / 4 / 2 waves per tile by system size; the small and the 1 M-atom cases exercise
-    8 and 2 - this one (273 k atoms, ~4300 tiles) the 4-waves-per-tile class."""
-    s = systems.water_box(45, seed=6)
+@pytest.mark.parametrize("n_side,waves,lo,hi", [(45, 2, 3000, 12000), (38, 4, 2048, 3000)])
+def test_half_list_mid_size_classes(mdx, orc, n_side, waves, lo, hi):
+    """The default kernel picks 8 / 4 / 2 / 1 waves per tile by tile count (mdx_wpt_rule, csrc/mdx_internal.h): the small cases
+    exercise 8 and water1M 1 - these two the classes between: 273 k atoms (~4300 tiles: two waves per tile since round 3) and
+    165 k atoms (~2600 tiles: four).  Plain-list body (`md.forces()`); the dual-list body of the same classes inside the step
+    loop is tests/test_gpu_timed_body.py."""
+    s = systems.water_box(n_side, seed=6)
     cfg = MdConfig()
     with mdx.MdState(s, cfg) as md:
         st = md.stats()
-        assert 4096 <= st["n_tiles"] < 12000
+        assert lo <= st["n_tiles"] < hi
         pos = md.positions(); f = md.forces(); e = md.energy()
+        info = md.pair_launch_info()["any"]
+        assert info["waves_per_tile"] == waves and info["half"] == 1 and info["dual"] == 0, info
     fo, eo = orc.forces(s, cfg, pos=pos.astype(np.float64), use_cells=True)
-    assert_forces(f, fo, orc.cutoff_slack(s, cfg, pos=pos, rel=2e-5), "water273k")
-    assert_energies(e, eo, "water273k")
+    assert_forces(f, fo, orc.cutoff_slack(s, cfg, pos=pos, rel=2e-5), f"water_box({n_side})")
+    assert_energies(e, eo, f"water_box({n_side})")
 
 
 def test_energy_conservation_and_momentum_water(mdx):
@@ -594,7 +599,7 @@ def test_c5_water1m_properties(mdx, orc):
         e = md.energy()
         assert_energies(e, eo, "water1M")
         assert np.isfinite(e["potential"]) and e["lj14"] == 0.0 and e["dihedral"] == 0.0
-        md.step(0.0005, None, 20)
-        assert md.step_count == 20
-        e2 = md.energy()
-        assert abs((e2["potential"] + e2["kinetic"]) - (e["potential"] + e["kinetic"])) / s.n_atoms < 0.05
+        info = md.pair_launch_info()["any"]
+        assert info["waves_per_tile"] == 1 and info["half"] == 1, info
+        # (the step loop at this size - one wave per tile, merged dual-list body: the instantiation bench.py times - beside the
+        # oracle's own trajectory and against the oracle's forces: tests/test_gpu_timed_body.py)

@@ -105,3 +105,48 @@ def test_fingerprint_of_static_arrays_sees_permuted_blocks():
     small = a[:64]      # below the vector path's threshold: the portable flavour
     sb = small.copy(); sb[0:8], sb[8:16] = small[8:16].copy(), small[0:8].copy()
     assert fn(7, small.ctypes.data, small.nbytes) != fn(7, sb.ctypes.data, sb.nbytes)
+
+
+def test_sim_box_init_pad_fixed_and_cube(tmp_path):
+    """`SimBoxInit::{Pad, Fixed}` / `new_cube` (/root/reference src/md/mod.rs:656-659; the Pad rule as the reference restates it at
+    src/gromacs/mod.rs:540-576: bounds = atom extent -/+ pad), in the Python mirror and - compiled here - in include/mdx.hpp."""
+    import os
+    import subprocess
+    from molchanica_amd import SimBoxInit
+    s = systems.lig50()
+    lo, hi = SimBoxInit.Pad(12.0).resolve(s.pos)
+    assert np.allclose(lo, s.pos.min(0) - 12.0) and np.allclose(hi, s.pos.max(0) + 12.0)
+    s.apply_sim_box(SimBoxInit.Pad(12.0))
+    assert s.periodic and np.allclose(np.array(s.box_hi) - np.array(s.box_lo), s.pos.max(0) - s.pos.min(0) + 24.0, atol=1e-4)
+    lo, hi = SimBoxInit.new_cube(50.0).resolve(s.pos)
+    assert np.allclose(lo, -25.0) and np.allclose(hi, 25.0)
+    lo, hi = SimBoxInit.new_cube(30.0, centre=(1.0, 2.0, 3.0)).resolve(None)
+    assert np.allclose(hi - lo, 30.0) and np.allclose(0.5 * (hi + lo), (1.0, 2.0, 3.0))
+    lo, hi = SimBoxInit.Fixed((0, 0, 0), (10, 20, 30)).resolve(s.pos)
+    assert np.allclose(hi, (10, 20, 30))
+    with pytest.raises(ValueError):
+        SimBoxInit.Pad(5.0).resolve(np.zeros((0, 3)))
+    # the same three constructors of the C++ host mirror (header-only; no device call is made)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "box.cpp"
+    src.write_text(r"""
+#include "mdx.hpp"
+#include <cstdio>
+int main() {
+    const float pos[9] = {1.f, 2.f, 3.f, -4.f, 5.f, 0.f, 2.f, -1.f, 7.f};
+    mdx::SimBox b = mdx::SimBoxInit::Pad(12.f).resolve(pos, 3);
+    if (b.bounds_low[0] != -16.f || b.bounds_high[0] != 14.f || b.bounds_low[1] != -13.f || b.bounds_high[2] != 19.f) return 1;
+    b = mdx::SimBoxInit::new_cube(40.f).resolve(nullptr, 0);
+    if (b.bounds_low[2] != -20.f || b.bounds_high[1] != 20.f || b.extent()[0] != 40.f || b.center()[1] != 0.f) return 2;
+    mdx_system sys{};
+    b.apply(sys);
+    if (!sys.periodic || sys.box_hi[0] != 20.f) return 3;
+    try { (void)mdx::SimBoxInit::Pad(1.f).resolve(pos, 0); return 4; } catch (const mdx::ParamError&) {}
+    std::puts("ok");
+    return 0;
+}
+""")
+    exe = tmp_path / "box"
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(root, "include"), str(src), "-L", os.path.join(root, "molchanica_amd"),
+                           "-lmdx", "-Wl,-rpath," + os.path.join(root, "molchanica_amd"), "-o", str(exe)])
+    assert subprocess.check_output([str(exe)]).decode().strip() == "ok"
