@@ -44,14 +44,11 @@ B_ALG_FUSED_WATER = 116.0      # bonded gather + kick + drift as one pass: the t
 B_ALG_STEP_WATER = 170.0       # whole step, water box
 FLOP_PER_PAIR = 45.0
 def _nb_kernel_rev():
-    """Revision of the default pair kernel = a hash of its sources: the cached PMC traffic figure (profiles/nb_traffic.json,
-    written by tools/summarize_rocprof.py with the hash of the tree it was measured on) is quoted only while it matches."""
-    import hashlib
-    h = hashlib.sha1()
-    for f in ("mdx_nonbonded_impl.h", "mdx_pair_dev.h", "mdx_internal.h"):
-        with open(os.path.join(ROOT, "molchanica_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:12]
+    """Revision of the default pair kernel's code (molchanica_amd/_build_info.py: comment- and white-space-insensitive hash of the
+    two headers that hold the kernel + the parameter structs it reads): the cached PMC traffic figure (profiles/nb_traffic.json,
+    written by tools/summarize_rocprof.py with the revision of the tree it was measured on) is quoted only while it matches."""
+    from molchanica_amd._build_info import pair_kernel_rev
+    return pair_kernel_rev()
 
 
 NB_KERNEL_REV = _nb_kernel_rev()
@@ -96,6 +93,9 @@ def parse():
     ap.add_argument("--skin", type=float, default=2.0, help="Verlet buffer in A (the measurement contract says 2)")
     ap.add_argument("--inner-skin", type=float, default=0.0,
                     help="dual pair list: buffer of the rolling-pruned inner list in A (0 = library default 0.5, < 0 = off)")
+    ap.add_argument("--no-extras", dest="extras", action="store_false",
+                    help="skip the extra keys of the default run (N = 1, water1M): `classes` = steps/s of BASELINE configs 2-4 (dhfr23k, "
+                         "complex50k, dna100k) and `default_operating_point` = the reference's own configuration (rigid OPC, SPME, dt 2 fs)")
     ap.add_argument("--pme", action="store_true", help="Ewald Coulomb with the SPME reciprocal sum (not the headline config)")
     return ap.parse_args()
 
@@ -218,6 +218,50 @@ def with_watchdog(fn, what, rank, world, timeout_s):
     if "e" in box:
         raise box["e"]
     return box.get("v")
+
+
+def class_rate(name, dt, device):
+    """steps/s of one of BASELINE.json's smaller configs on this GPU, measured like the headline (relaxed + 300 K start on a handle of
+    its own, a fresh handle, untimed settle steps, NVE with rebuilds at their natural cadence), without event brackets: ~0.3 s each."""
+    import torch
+    from molchanica_amd import MdConfig, systems
+    from molchanica_amd.md_state import MdState
+    s = systems.BY_NAME[name]()
+    cfg = MdConfig()
+    with MdState(s, cfg, device=device) as eq:
+        eq.minimize_energy(100); eq.initialize_velocities(300.0, True, seed=105)
+        eq.set_thermostat(1, 300.0, 0.02, 1); eq.step(dt, None, 600); eq.set_thermostat(0, 300.0, 0.02, 1)
+        s.pos, s.vel = np.ascontiguousarray(eq.positions(), np.float32), np.ascontiguousarray(eq.velocities(), np.float32)
+    n = 3000
+    with MdState(s, cfg, device=device) as md:
+        md.step(dt, None, 1000)                      # untimed: chunk lengths / dual-list buffer settle, the GPU is back at its clocks
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); md.step(dt, None, n); torch.cuda.synchronize(); el = time.perf_counter() - t0
+        st = md.stats()
+    return {"n_atoms": s.n_atoms, "steps": n, "steps_per_s": n / el, "ms_per_step": 1e3 * el / n,
+            "atom_updates_per_s": s.n_atoms * n / el, "rebuilds_so_far": int(st["rebuild_count"]), "n_tiles": int(st["n_tiles"])}
+
+
+def default_operating_point_rate(device):
+    """What a user of the reference runs (/root/reference src/prefs/mod.rs:203, src/ui/panels/md.rs:362-371, README.md:236-240): rigid
+    4-site OPC water (SETTLE + M virtual site), dt 2 fs, SPME, CSVR thermostat - 64^3 waters = 1,048,576 sites, skin 2 A."""
+    import torch
+    from molchanica_amd import MdConfig, systems
+    from molchanica_amd.md_state import MdState
+    s = systems.opc_water_box(64, seed=5)
+    cfg = MdConfig(coulomb_mode=2, ewald_alpha=0.3, overrides=0, skin=2.0)
+    n = 500
+    with MdState(s, cfg, device=device) as md:
+        md.minimize_energy(100); md.initialize_velocities(300.0, True, seed=1)
+        md.set_thermostat(1, 300.0, 0.02, 1); md.step(0.001, None, 1500)       # untimed: the random-orientation lattice relaxes
+        md.set_thermostat(2, 300.0, 0.1, 10, seed=2); md.step(0.002, None, 300)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); md.step(0.002, None, n); e = md.energy(); torch.cuda.synchronize(); el = time.perf_counter() - t0
+        st = md.stats()
+    return {"workload": "opc64: 262,144 rigid OPC waters = 1,048,576 sites, SPME (order 4, ~1 A mesh, beta 0.3), rc 10 A, skin 2 A, "
+                        "dt 2 fs, CSVR 300 K every 10 steps; 500 timed steps + one energy read",
+            "n_sites": s.n_atoms, "steps": n, "steps_per_s": n / el, "ms_per_step": 1e3 * el / n, "ns_per_day": n / el * 0.002e-3 * 86400,
+            "temperature_K": round(float(e["temperature"]), 1), "rebuilds_so_far": int(st["rebuild_count"])}
 
 
 def main():
@@ -463,6 +507,9 @@ def main():
                  "repartitions": [r["repartitions"] for r in per_rank], "local_rebuilds": [r["local_rebuilds"] for r in per_rank],
                  "rebuild_fallbacks": [r["rebuild_fallbacks"] for r in per_rank],
                  "overlap_split_kept": [r["overlap_split"] for r in per_rank],
+                 # one message per step (full shell) or two (half shell + force return): chosen below the ABI from the message time
+                 # measured when the handles joined (include/mdx.h: mdx_comm_diag.wire_ns_measured)
+                 "half_shell": [r["half_shell"] for r in per_rank], "wire_us_measured_at_attach": [r["wire_ns_measured"] / 1e3 for r in per_rank],
                  "phase_ms_per_step": {k: [round(r["phase_ms_per_step"][k], 5) for r in per_rank] for k in mine["phase_ms_per_step"]},
                  "step_wall_ms_profiled": [round(r["step_wall_ms_profiled"], 5) for r in per_rank],
                  "host_and_idle_ms_per_step": [round(r["host_and_idle_ms_per_step"], 5) for r in per_rank],
@@ -575,6 +622,20 @@ def main():
                       "bonded_plus_integrate_per_step": streaming_ms_per_step,
                       "rebuild_total": st_nb["rebuild_ms_sum"] - st0["rebuild_ms_sum"]},
     }
+    if rank == 0 and world == 1 and args.extras and args.workload == "water1M" and not args.pme and not args.decomposed:
+        # BASELINE configs 2-4 and the reference's own operating point, measured by whoever runs this command (the driver), on this
+        # GPU, after the headline numbers are in hand; a failure is reported inside the line, never instead of it
+        md.close()
+        out["classes"] = {}
+        for w in ("dhfr23k", "complex50k", "dna100k"):
+            try:
+                out["classes"][w] = class_rate(w, args.dt, local_rank)
+            except Exception as e:  # noqa: BLE001
+                out["classes"][w] = {"steps_per_s": None, "error": f"{type(e).__name__}: {e}"}
+        try:
+            out["default_operating_point"] = default_operating_point_rate(local_rank)
+        except Exception as e:  # noqa: BLE001
+            out["default_operating_point"] = {"steps_per_s": None, "error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the GPU measurement above must reach the driver whatever happens to the CPU leg (a failed -march=native build,
         # a missing compiler on the box): its failure is reported inside the JSON line, not instead of it

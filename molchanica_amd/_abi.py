@@ -86,7 +86,7 @@ class CCommDiag(C.Structure):
     _fields_ = [
         ("transport", C.c_char * 64), ("rank", C.c_int32), ("world", C.c_int32), ("grid", C.c_int32 * 3),
         ("rccl_version", C.c_int32), ("rccl_comm_count", C.c_int32), ("half_shell", C.c_int32),
-        ("overlap_split", C.c_int32), ("comm_stream_separate", C.c_int32), ("pad0", C.c_int32),
+        ("overlap_split", C.c_int32), ("comm_stream_separate", C.c_int32), ("wire_ns_measured", C.c_int32),
         ("n_owned", C.c_uint32), ("n_ghost", C.c_uint32), ("n_tiles", C.c_uint32), ("n_interior_tiles", C.c_uint32),
         ("halo_rows_out", C.c_uint32), ("halo_rows_in", C.c_uint32), ("halo_bytes_per_step", C.c_uint64),
         ("repartitions", C.c_uint64), ("local_rebuilds", C.c_uint64), ("repartition_ms_sum", C.c_double),
@@ -94,7 +94,7 @@ class CCommDiag(C.Structure):
     ]
 
     def as_dict(self) -> dict:
-        d = {n: getattr(self, n) for n, _ in self._fields_ if n not in ("transport", "grid", "phase_ms", "phase_n", "pad0")}
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n not in ("transport", "grid", "phase_ms", "phase_n")}
         d["transport"] = self.transport.decode()
         d["grid"] = tuple(self.grid)
         d["phase_ms_sum"] = {k: float(self.phase_ms[i]) for i, k in enumerate(DIAG_PHASES)}

@@ -31,6 +31,10 @@ struct MdxTransport {
     // it is enqueued on, and the handle keeps its receive buffers filled with what the unpack / add kernels turn into no-ops - one rank of N
     // measured alone then runs every kernel of the real step and pays a stated wire time (tools/one_rank_profile.py)
     virtual bool loopback() const { return false; }
+    // Does the handle choose between the half-shell halo (two messages per step) and the full shell (one) from this transport's
+    // measured message time (mdx_dd_attach)?  The wire (RCCL) and the null transport with a stated wire time do; the in-process
+    // fabric and the shared-memory staging - verification aids, their "wire" is host synchronisation - keep the half shell.
+    virtual bool wire_time_decides() const { return false; }
     // RCCL only: ncclGetVersion and ncclCommCount of this handle's communicator (0, 0 elsewhere) - for mdx_comm_diag
     virtual void wire_info(int* version, int* comm_count) const { *version = 0; *comm_count = 0; }
 };
@@ -74,6 +78,7 @@ struct MdxDecomp {
     // evaluated on exactly one of them, and the forces that rank computed on its ghosts travel back along the same
     // segments in the opposite direction: frc_send has the layout of recv_buf, frc_recv that of send_buf.
     bool half_shell = false;
+    float wire_us = -1.f;              // one send/recv group of a typical halo message on this transport, measured at attach (max over the ranks); < 0: not measured
     float4* frc_send = nullptr; float4* frc_recv = nullptr;
     bool force_return_pending = false;   // begin() was enqueued, end() has not been yet
     // gather of the global state (repartition, read-back)

@@ -91,6 +91,7 @@ struct RcclTransport : MdxTransport {
         if (d_words) (void)hipFree(d_words);
     }
     const char* name() const override { return "rccl"; }
+    bool wire_time_decides() const override { return true; }
     void wire_info(int* version, int* comm_count) const override {
         *version = 0; *comm_count = 0;
         if (g_rccl.GetVersion) (void)g_rccl.GetVersion(version);
@@ -300,6 +301,7 @@ struct NullTransport : MdxTransport {
     const char* name() const override { return wire_us >= 0 ? "null (stated wire time, loop-back buffers)" : "null (delivers nothing)"; }
     bool delivers() const override { return false; }
     bool loopback() const override { return wire_us >= 0; }
+    bool wire_time_decides() const override { return wire_us >= 0; }
     int exchange(const float4*, const std::vector<MdxSeg>&, float4*, const std::vector<MdxSeg>&, hipStream_t st) override {
         if (wire_us > 0) { hipLaunchKernelGGL(null_wire_kernel, dim3(1), dim3(64), 0, st, (uint32_t)wire_us); HIP_TRY(hipGetLastError()); }
         return MDX_OK;

@@ -1004,6 +1004,46 @@ int mdx_dd_restore_global(mdx_handle* h, const float4* backup) {
     return MDX_OK;
 }
 
+// One send/recv group of a typical halo message on this transport, in microseconds (the largest any rank saw): 8192 rows of 16 B to
+// and from every peer, three groups to warm the path up, eight timed between two events on `st`.  Collective.
+static int dd_measure_wire_us(MdxTransport* tr, hipStream_t st, float* us_out) {
+    *us_out = 0.f;
+    if (tr->world <= 1) return MDX_OK;
+    const uint32_t rows = 8192u, n = rows * (uint32_t)(tr->world - 1);
+    float4 *snd = nullptr, *rcv = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto done = [&](int rc) {
+        if (snd) (void)hipFree(snd);
+        if (rcv) (void)hipFree(rcv);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        return rc;
+    };
+    if (hipMalloc((void**)&snd, sizeof(float4) * n) != hipSuccess || hipMalloc((void**)&rcv, sizeof(float4) * n) != hipSuccess ||
+        hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipMemsetAsync(snd, 0, sizeof(float4) * n, st) != hipSuccess) {
+        mdx_set_error("decomposition: no memory for the wire-time probe");
+        return done(MDX_EOOM);
+    }
+    std::vector<MdxSeg> segs;
+    uint32_t r0 = 0;
+    for (int q = 0; q < tr->world; ++q) if (q != tr->rank) { segs.push_back({q, r0, rows}); r0 += rows; }
+    for (int k = 0; k < 3; ++k) { const int rc = tr->exchange(snd, segs, rcv, segs, st); if (rc != MDX_OK) return done(rc); }
+    if (hipEventRecord(e0, st) != hipSuccess) return done(MDX_EDEVICE);
+    for (int k = 0; k < 8; ++k) { const int rc = tr->exchange(snd, segs, rcv, segs, st); if (rc != MDX_OK) return done(rc); }
+    float ms = 0.f;
+    if (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
+        mdx_set_error("decomposition: the wire-time probe failed");
+        return done(MDX_EDEVICE);
+    }
+    float us = ms * 1000.f / 8.f;
+    uint32_t words[DD_MAX_WORLD], mine;
+    std::memcpy(&mine, &us, 4);
+    if (tr->all_gather_u32(mine, words, st) != MDX_OK) return done(MDX_EDEVICE);
+    for (int q = 0; q < tr->world; ++q) { float v; std::memcpy(&v, &words[q], 4); if (v > us) us = v; }
+    *us_out = us;
+    return done(MDX_OK);
+}
+
 int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
     auto bail = [&](int rc) { std::string keep = mdx_last_error(); if (!h->dd) delete tr; else mdx_dd_destroy(h); mdx_set_error(keep); return rc; };
     if (!(h->per[0] && h->per[1] && h->per[2])) { mdx_set_error("spatial decomposition needs a fully periodic box"); return bail(MDX_EPARAM); }
@@ -1040,9 +1080,25 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
     if (!h->h_vsites.empty() && h->h_groups.empty()) ext = std::max(ext, 2.0);   // flexible parents: a bond length of room
     dd->ext = (float)(ext * 1.05 + (ext > 0.0 ? 0.05 : 0.0));
     if (dd_set_halo(h) != MDX_OK) return bail(MDX_EPARAM);
-    {   // half shell needs Newton's third law across the rank boundary: the half-list pair kernel (MDX_HALF_SHELL=0: A/B knob)
+    {   // Half shell (every cross-rank pair on one rank, ghost forces travel back: TWO messages per step) or full shell (cross pairs
+        // on both ranks, twice the ghosts, ONE message)?  Measured round 6 on rank 0 of the 1 M-atom box with a stated time per
+        // message (profiles/r06_one_rank_of_N.txt; step in ms, half / full): 8 ranks 0.132 / 0.141 at 0 us, 0.149 / 0.142 at 5,
+        // 0.162 / 0.148 at 10, 0.208 / 0.173 at 25, 0.272 / 0.196 at 50; 4 ranks 0.200 / 0.219 at 0, 0.259 / 0.249 at 25; 2 ranks
+        // 0.330 / 0.335 at 0, 0.395 / 0.365 at 25 - a microsecond of message time costs the half shell 2.4-3.0 us of step, the full
+        // shell 1.2-1.3: they cross at ~4 us per message (16 us on four ranks).  So a transport whose message time means something
+        // is measured here, once (every rank takes the largest value any rank saw: the choice is part of the partition), and the
+        // half shell stays only below that crossing.  Half shell needs Newton's third law across the rank boundary: the half-list
+        // pair kernel.  MDX_HALF_SHELL=0 / 1 pins the choice; MDX_HALF_SHELL_WIRE_US moves the crossing.
         const char* e = std::getenv("MDX_HALF_SHELL");
-        dd->half_shell = dd->world > 1 && mdx_nb_half(h) && !(e && e[0] == '0');
+        bool hs = dd->world > 1 && mdx_nb_half(h);
+        if (e && (e[0] == '0' || e[0] == '1')) hs = hs && e[0] == '1';
+        else if (hs && tr->wire_time_decides()) {
+            if (dd_measure_wire_us(tr, h->stream, &dd->wire_us) != MDX_OK) return bail(MDX_EDEVICE);
+            const char* t = std::getenv("MDX_HALF_SHELL_WIRE_US");
+            const float crossing = t ? (float)std::atof(t) : (dd->world == 4 ? 16.f : 4.f);
+            hs = dd->wire_us < crossing;
+        }
+        dd->half_shell = hs;
     }
     {
         const char* e = std::getenv("MDX_HALO_OVERLAP");
@@ -1155,6 +1211,7 @@ extern "C" int mdx_comm_diag_read(mdx_handle* h, mdx_comm_diag* out) {
     for (int d = 0; d < 3; ++d) out->grid[d] = dd->grid[d];
     dd->tr->wire_info(&out->rccl_version, &out->rccl_comm_count);
     out->half_shell = mdx_dd_half_shell(h) ? 1 : 0;
+    out->wire_ns_measured = dd->wire_us < 0.f ? -1 : (int32_t)std::min(2.0e9f, dd->wire_us * 1000.f);
     out->overlap_split = dd->world > 1 ? (dd->tune_phase < 2 ? -1 : (dd->overlap ? 1 : 0)) : 0;
     out->comm_stream_separate = dd->comm_stream != h->stream ? 1 : 0;
     out->n_owned = dd->n_owned; out->n_ghost = dd->n_local - dd->n_owned;

@@ -725,3 +725,27 @@ def _shm_rank(rank, world, name, q):
             q.put((rank, None, e0, md.positions()))
     except BaseException as e:   # pragma: no cover
         q.put((rank, repr(e), None, None))
+
+
+@pytest.mark.parametrize("wire_us,pin,want_half", [("0", None, 1), ("2", None, 1), ("25", None, 0), ("25", "1", 1), ("0", "0", 0)])
+def test_half_or_full_shell_follows_the_measured_message_time(monkeypatch, wire_us, pin, want_half):
+    """Two messages per step (half shell + force return) pay only below ~4 us per message (profiles/r06_one_rank_of_N.txt): a handle
+    that joins over a transport with a real message time measures one send/recv group and chooses (mdx_comm_diag.wire_ns_measured,
+    .half_shell); MDX_HALF_SHELL pins it.  The null transport with a stated wire time stands in for the wire on this one-GPU box."""
+    from molchanica_amd.md_state import MdState
+    monkeypatch.setenv("MDX_NULL_WIRE_US", wire_us)
+    if pin is None:
+        monkeypatch.delenv("MDX_HALF_SHELL", raising=False)
+    else:
+        monkeypatch.setenv("MDX_HALF_SHELL", pin)
+    s = systems.water_box(14, seed=6)
+    with MdState(s, MdConfig(**CFG)) as md:
+        md.comm_init_null(0, 8)
+        d = md.comm_diag()
+        assert d["half_shell"] == want_half, d
+        if pin is None:
+            assert abs(d["wire_ns_measured"] / 1e3 - float(wire_us)) < 3.0 + 0.2 * float(wire_us), d["wire_ns_measured"]
+        else:
+            assert d["wire_ns_measured"] == -1
+        md.step(0.0005, None, 12)
+        assert md.step_count == 12

@@ -103,6 +103,8 @@ print("\n".join(lines))
 
 # ---- HBM traffic of the pair kernel (MI355X_MICROARCH.md §HBM: FETCH_SIZE on gfx950 reports 1/2 of the
 # bytes of wide coalesced reads -> x2; units are KiB-ish 'FETCH_SIZE'=KB, WRITE_SIZE uncalibrated) ----
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from molchanica_amd._build_info import pair_kernel_rev as _pair_kernel_rev  # noqa: E402
 nbk = sorted((k for k in pmc if is_step_pair_kernel(k)), key=lambda k: -max(v[0] for v in pmc[k].values()))
 if nbk:
     cs = pmc[nbk[0]]
@@ -112,7 +114,7 @@ if nbk:
         fetch, write = raw["FETCH_SIZE"] * 1024.0, raw["WRITE_SIZE"] * 1024.0
         traffic = {
             "workload": "water1M", "kernel": nbk[0], "round": tag,
-            "kernel_rev": __import__("hashlib").sha1(b"".join(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "molchanica_amd", "csrc", f), "rb").read() for f in ("mdx_nonbonded_impl.h", "mdx_pair_dev.h", "mdx_internal.h"))).hexdigest()[:12],   # = bench.py's NB_KERNEL_REV
+            "kernel_rev": _pair_kernel_rev(),   # = bench.py's NB_KERNEL_REV (molchanica_amd/_build_info.py)
             "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, {tag}",
             "FETCH_SIZE_KB_per_launch": raw["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": raw["WRITE_SIZE"],
             "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE tallies 128-B read requests at 64 B -> x2 "
