@@ -747,5 +747,5 @@ def test_half_or_full_shell_follows_the_measured_message_time(monkeypatch, wire_
             assert abs(d["wire_ns_measured"] / 1e3 - float(wire_us)) < 3.0 + 0.2 * float(wire_us), d["wire_ns_measured"]
         else:
             assert d["wire_ns_measured"] == -1
-        md.step(0.0005, None, 12)
-        assert md.step_count == 12
+        md.step(0.0005, None, 2)       # (a lone rank of eight gets no ghost updates: a couple of steps show the arrangement runs, no more)
+        assert md.step_count == 2

@@ -6,8 +6,9 @@ fp64 oracle; the margins they leave were measured with tests/parity_margins.py, 
                    distance sits within 1e-5 relative of a cutoff - such a pair may legitimately
                    flip in or out under a one-ulp difference in the distance arithmetic).  No other
                    allowance: worst atom at 0.12 (C1), 0.99 (C2), 0.72 (C3), 1.00 (C4) of it; at C5 the
-                   maximum over 1,029,000 atoms is an extreme-value statistic - 1 atom at 1.06 - so that
-                   test allows ten atoms in a million up to twice the bound, none beyond
+                   maximum over 1,029,000 atoms is an extreme-value statistic - 1 atom at 1.06, fp32 summation order on
+                   an atom whose 424 pair forces nearly cancel (round 6: tests/parity_margins.py prints the diagnosis) - so
+                   that test allows two atoms up to twice the bound, none beyond
   RMS force        <= 2e-5 * RMS(F)   (measured 4e-7 ... 9e-7)
   per-term energy  bonded and 1-4 terms: rel 2e-6, abs floor 1e-3 kcal/mol (measured <= 1e-6 everywhere).
                    Pair sums: 2e-6 |E| + c G, G = the oracle's GROSS sum of |e_pair| - what fp32 rounds is the terms,
@@ -595,7 +596,11 @@ def test_c5_water1m_properties(mdx, orc):
         fo, eo = orc.forces(s, cfg, pos=pos.astype(np.float64), use_cells=True)
         # coordinates up to 217 Å carry an fp32 ulp of 1.5e-5 Å, so the band in which the two distance
         # arithmetics may disagree about a cutoff is wider here: 4e-5 relative in r^2
-        assert_forces(f, fo, orc.cutoff_slack(s, cfg, pos=pos, rel=4e-5), "water1M", outliers=10)
+        # (outliers: the worst atom of 1,029,000 measures 1.06 x the bound - atom 1027848, net |F| = 1.19 kcal/mol/A out of 424 pair
+        # forces whose magnitudes add up to G = 1560, no pair within 5e-4 of the cutoff: its |dF| = 1.26e-4 is 8e-8 G, one fp32 ulp of
+        # what is being summed, in an order the two sides do not share (tests/parity_margins.py c5, profiles/r06_parity_margins.txt).
+        # The bound is written in the NET force; two atoms in a million may sit between 1 x and 2 x of it, none beyond.)
+        assert_forces(f, fo, orc.cutoff_slack(s, cfg, pos=pos, rel=4e-5), "water1M", outliers=2)
         e = md.energy()
         assert_energies(e, eo, "water1M")
         assert np.isfinite(e["potential"]) and e["lj14"] == 0.0 and e["dihedral"] == 0.0
