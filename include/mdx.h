@@ -293,9 +293,11 @@ int mdx_get_stats(mdx_handle* h, mdx_stats* out);
  * Per block: {waves per tile (0: the whole-tile kernel), dual-list body (0 plain list, 1 / 2 inner-walk / pruning twins, 3 one merged
  * launch - the device picks the body, 4 merged + the bonded gather in extra workgroups), half list, Coulomb flavour (0 shifted cutoff,
  * 1 reaction field, 2 Ewald closed form, 3 softened, 4 Ewald table), energy flavour, workgroups per tile, bonded workgroups behind
- * twin launches, tiles in the launch}.  The parity tests use it to name the body they hold against the oracle; no call of the
- * reference corresponds to it. */
-int mdx_pair_launch_info(const mdx_handle* h, uint32_t out[16]);
+ * twin launches, tiles in the launch}.  out[16]: list rebuilds so far whose exact pruning pass also wrote the inner list (the force
+ * call behind such a rebuild walks the inner list instead of being a pruning pass: one wave per tile, single device), out[17]: the
+ * last rebuild was one of them, out[18..19]: 0.  The parity tests use it to name the body they hold against the oracle; no call
+ * of the reference corresponds to it. */
+int mdx_pair_launch_info(const mdx_handle* h, uint32_t out[20]);
 /* The Verlet skin in force, and whether the library is still tuning it (mdx_config.skin == 0). */
 int mdx_get_skin(const mdx_handle* h, float* skin, int* tuning);
 

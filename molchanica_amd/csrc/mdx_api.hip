@@ -853,7 +853,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         if (h->dual_on && h->cfg.inner_skin == 0.f) {
             for (uint32_t s = 0; s < done; ++s) h->dual_win_prunes += h->h_ctl->prune[s + 1] != 0u;
             // (round 3: the force call behind a rebuild is a pruning pass too; at dt = 2 fs there is a rebuild every 4-5 steps)
-            if (stale_hit) ++h->dual_win_prunes;
+            if (stale_hit && !h->inner_from_rebuild) ++h->dual_win_prunes;
             h->dual_win_steps += done;
             if (h->dual_win_steps >= 96) {
                 const float f = (float)h->dual_win_prunes / (float)h->dual_win_steps;
@@ -1389,9 +1389,10 @@ extern "C" int mdx_get_skin(const mdx_handle* h, float* skin, int* tuning) {
     return MDX_OK;
 }
 
-extern "C" int mdx_pair_launch_info(const mdx_handle* h, uint32_t out[16]) {
+extern "C" int mdx_pair_launch_info(const mdx_handle* h, uint32_t out[20]) {
     if (!h || !out) FAIL(MDX_EPARAM, "null argument");
     for (int k = 0; k < 8; ++k) { out[k] = h->pair_info_step[k]; out[8 + k] = h->pair_info_any[k]; }
+    out[16] = h->inner_rebuilds; out[17] = h->inner_from_rebuild ? 1u : 0u; out[18] = 0u; out[19] = 0u;
     return MDX_OK;
 }
 

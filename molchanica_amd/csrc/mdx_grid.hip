@@ -1056,12 +1056,21 @@ __global__ __launch_bounds__(LB_WAVES * 64) void build_list_kernel(ListArgs a) {
 // separate column populations, so every tile from rb_ctl[1] on is all-ghost): 1 <=> the tile is owned and no entry that
 // SURVIVES this pass names a ghost cluster - everything its pair evaluation reads is owned by this rank, it may run before
 // the halo message has arrived.  (It was a pass of its own over the finished list, tile_class_kernel, + a scan + a host copy.)
+// INNER (round 6, the one-wave-per-tile class of a single-device handle): the same pass also derives the INNER list of the dual
+// pair list - cluster pairs with an atom pair inside cutoff + inner_skin at the positions of this rebuild, which are the positions
+// the force call behind the rebuild evaluates (the path accumulators start from zero there) - in the layout the pair kernel's own
+// pruning pass writes for one wave per tile (masked run in place, plain run compacted from chunk n_masked / 8 on, loop bound in
+// inner_nch[8 t]).  The force call behind a rebuild then WALKS the inner list instead of being a pruning pass over the Verlet
+// list: 569 -> 418 us at 1 M atoms, for one more ballot per cluster pair here.  The quick accept is off in this flavour (every
+// surviving cluster pair needs its distances for the second test anyway).
+struct PruneInner { uint2* entries_in; uint32_t* inner_nch; float rin2; WptRule rule; };
+template <bool INNER>
 __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, float shx, float shy, float shz,
                                                          const float4* __restrict__ posq, ListCounts* __restrict__ counts,
                                                          const uint32_t* __restrict__ entry_off, uint2* __restrict__ entries,
                                                          uint32_t null_cluster, unsigned long long* __restrict__ pair_count,
                                                          const uint32_t* __restrict__ rb_ctl, uint32_t* __restrict__ tile_int,
-                                                         const uint8_t* __restrict__ cl_kind) {
+                                                         const uint8_t* __restrict__ cl_kind, PruneInner pin) {
     __shared__ float4 s_j[4][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t first_ghost_cluster = 0xFFFFFFFFu;
@@ -1069,6 +1078,9 @@ __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, f
         T = __builtin_amdgcn_readfirstlane(rb_ctl[0]); null_cluster = T * MDX_CL_PER_TILE;
         first_ghost_cluster = __builtin_amdgcn_readfirstlane(rb_ctl[1]) * MDX_CL_PER_TILE;
     }
+    // (the pair kernel reads the inner list in the layout of ITS waves-per-tile class: only the one-wave class is written here, and
+    // the host applies the same rule to the same tile count when it decides what the force call behind the rebuild is)
+    const bool inner_on = INNER && mdx_wpt_rule(pin.rule, T) == 1;
     bool ghost_hit = false;
     // one wave per tile (the plain run is compacted in place); a contiguous eighth of the tiles per XCD, as in the pair
     // kernel: the j-atoms a tile's list names are its spatial neighbours, and each XCD has its own L2
@@ -1087,7 +1099,7 @@ __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, f
     // cluster pair.  What the try leaves open gets the exact test - the kept set is the same either way.  (The counters
     // say the pass is bound by VALU + SALU issue - 108 M + 107 M instructions per launch, the scalar half being the
     // ballot / branch bookkeeping per cluster pair - so more tries cost what they save.)
-    constexpr int NTRY = PRUNE_TRIES;
+    constexpr int NTRY = INNER ? 0 : PRUNE_TRIES;
     constexpr int TI[6] = {0, 7, 3, 0, 7, 4}, TJ[6] = {0, 7, 4, 7, 0, 3};
     float4 rep[NTRY ? NTRY : 1];
 #pragma unroll
@@ -1103,6 +1115,7 @@ __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, f
     const ListCounts cnt = counts[t];
     const uint32_t e0 = entry_off[t], nmc = cnt.n_masked >> 3, nchunks = (cnt.n_masked + cnt.n_plain) >> 3;
     uint32_t kept = 0, wcur = 0;                   // wcur: plain entries written back so far
+    uint32_t wcur_in = 0;                          // (INNER) ... and into the inner list
     // two-deep prefetch, as in the pair kernel: the entries of chunk c + 2 and the atoms of chunk c + 1 are in flight while
     // chunk c is tested (one-deep, the atom load waited for the entry load it depends on at the top of every chunk)
     uint2 ent_n = make_uint2(null_cluster, 13u), ent_nn = make_uint2(null_cluster, 13u);
@@ -1129,6 +1142,7 @@ __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, f
             newy = (ent.y & 0xFFu) | (ent.y & ((((kj & 1u) ? ilj : 0u) | ((kj & 2u) ? iq : 0u)) << 8));
         }
         const uint32_t y_in = newy;
+        uint32_t newy_in = newy & 0xFFu;           // (INNER) this lane's entry word with the inner mask
         unsigned long long acc = 0ull;             // bit e * 8 + ci: cluster pair (ci, e) has an atom pair inside r for sure
 #pragma unroll
         for (int k = 0; k < NTRY; ++k) {
@@ -1141,24 +1155,29 @@ __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, f
             const float4 q = s_j[wave][e * 8 + jj];
             const uint32_t y = __builtin_amdgcn_readlane(y_in, e * 8);
             const uint32_t sure = (uint32_t)(acc >> (e * 8)) & 0xFFu;
-            uint32_t any = sure;
+            uint32_t any = sure, anyin = 0u;
             // only the i-clusters the bounding-box test let through (~5 of 8) and the quick accept left open
             // (all eight, branch-free: 357 us per rebuild at 1 M atoms; this: 278 us)
 #pragma unroll
             for (int ci = 0; ci < 8; ++ci) {
                 if (!(((y >> 8) & ~sure) & (1u << ci))) continue;
                 const float dx = xi[ci] - q.x, dy = yi[ci] - q.y, dz = zi[ci] - q.z;
-                any |= (__ballot(dx * dx + dy * dy + dz * dz < r2) != 0ull ? 1u : 0u) << ci;
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                const bool hit = __ballot(d2 < r2) != 0ull;
+                any |= (hit ? 1u : 0u) << ci;
+                if (INNER && hit) anyin |= (__ballot(d2 < pin.rin2) != 0ull ? 1u : 0u) << ci;
             }
             const uint32_t im = (y >> 8) & any;
             kept += __popc(im & 0xFFu);
             if ((lane >> 3) == e) newy = (y & 0xFFu) | ((im & 0xFFu) << 8);
+            if (INNER && (lane >> 3) == e) newy_in = (y & 0xFFu) | ((((y >> 8) & anyin) & 0xFFu) << 8);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
         ghost_hit |= ((newy >> 8) & 0xFFu) != 0u && ent.x >= first_ghost_cluster && ent.x < null_cluster;
         if (c < nmc) {
             // masked run: per-lane exclusion masks are addressed by chunk position, entries stay where they are
             if ((lane & 7) == 0 && newy != ent.y) entries[e0 + c * 8 + (lane >> 3)].y = newy;
+            if (inner_on && (lane & 7) == 0) pin.entries_in[e0 + c * 8 + (lane >> 3)] = make_uint2(ent.x, newy_in);
         } else {
             // plain run: survivors move down (write cursor <= read position, and the next chunk is already in registers)
             const bool alive = (lane & 7) == 0 && ((newy >> 8) & 0xFFu) != 0u;
@@ -1168,10 +1187,21 @@ __global__ __launch_bounds__(256) void prune_list_kernel(uint32_t T, float r2, f
                 entries[e0 + cnt.n_masked + wcur + rank] = make_uint2(ent.x, newy);
             }
             wcur += __popcll(bal);
+            if (inner_on) {
+                const bool alive_in = (lane & 7) == 0 && ((newy_in >> 8) & 0xFFu) != 0u;
+                const unsigned long long bin = __ballot(alive_in);
+                if (alive_in) pin.entries_in[e0 + cnt.n_masked + wcur_in + __popcll(bin & ((1ull << lane) - 1ull))] = make_uint2(ent.x, newy_in);
+                wcur_in += __popcll(bin);
+            }
         }
     }
     const uint32_t np_pad = (wcur + 7u) & ~7u;
     if (lane < (int)(np_pad - wcur)) entries[e0 + cnt.n_masked + wcur + lane] = make_uint2(null_cluster, 13u);
+    if (inner_on) {
+        const uint32_t nin_pad = (wcur_in + 7u) & ~7u;
+        if (lane < (int)(nin_pad - wcur_in)) pin.entries_in[e0 + cnt.n_masked + wcur_in + lane] = make_uint2(null_cluster, 13u);
+        if (lane == 0) pin.inner_nch[(size_t)t * 8] = nmc + (nin_pad >> 3);
+    }
     const bool any_ghost = __any(ghost_hit);
     if (lane == 0) {
         counts[t].n_plain = np_pad;
@@ -1812,7 +1842,7 @@ static int spin_on_readback(mdx_handle* h, uint32_t seq) {
     return MDX_OK;
 }
 
-struct RebuildResult { uint32_t T = 0, E = 0, MC = 0, n_interior = 0; unsigned long long npairs = 0; bool ordered = false, classified = false; };
+struct RebuildResult { uint32_t T = 0, E = 0, MC = 0, n_interior = 0; unsigned long long npairs = 0; bool ordered = false, classified = false, inner_built = false; };
 
 // which tile orders the rebuild produces (shared by both chains)
 struct TileOrderPlan { bool lpt, grouped, split; };
@@ -1919,6 +1949,22 @@ static int rebuild_fast(mdx_handle* h, RebuildResult* res, bool* fell_back) {
     }
     if (g.npop > 1) hipLaunchKernelGGL((build_list_kernel<LB_SINGLE, LB_PLAIN_DD>), dim3(a.list_grid + rf_blocks), dim3(LB_WAVES * 64), 0, st, a);
     else hipLaunchKernelGGL(build_list_kernel<LB_SINGLE>, dim3(a.list_grid + rf_blocks), dim3(LB_WAVES * 64), 0, st, a);
+    // Dual list: the inner list of the one-wave-per-tile class comes out of the exact pruning pass (prune_list_kernel<true>), so
+    // that the force call behind this rebuild walks it instead of being a pruning pass itself.  Single-device handles, the
+    // conditions under which mdx_rebuild switches the dual list on (below), MDX_REBUILD_INNER=0: A/B knob.
+    // Measured (round 6, profiles/r06_rebuild_inner_ab.txt): the pass costs +96 us per rebuild at 1 M atoms (quick accept off, a second
+    // ballot per surviving cluster pair) and saves the 151 us a pruning pass costs over an inner-list walk: 1936.6 -> 1946.6 steps/s on
+    // the flexible headline box.  At the reference's default operating point (rigid OPC, dt 2 fs: a rebuild every 8 steps, the
+    // pruning pass only 20 % dearer than the walk, kind filter in the pass) it LOSES: 864 -> 853 steps/s.  So: flexible systems
+    // only; MDX_REBUILD_INNER=0 never, =2 always (A/B).
+    static const int inner_mode = [] { const char* e = std::getenv("MDX_REBUILD_INNER"); return e ? (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)) : 1; }();
+    const bool inner_env = inner_mode == 2 || (inner_mode == 1 && !mdx_has_constraints(h) && h->n_vsites == 0);
+    const float inner_skin_next = h->inner_skin_auto > 0.f ? h->inner_skin_auto : c_inner_skin(h->cfg);
+    const bool dual_next = !h->dual_auto_off && mdx_nb_half(h) && prune && inner_skin_next > 0.f && inner_skin_next < h->cfg.skin &&
+                           (h->n_vsites == 0 || h->vsites_convex);
+    const bool inner_here = inner_env && dual_next && exact_prune && !h->dd && h->n_local == h->N && g.npop == 1 && !h->alch_on &&
+                            d.entries_in && d.inner_nch;
+    bool inner_launched = false;
     if (prune && exact_prune) {
         const float rb = a.r_build;
         const float shx = h->per[0] ? h->box_hi[0] - h->box_lo[0] : 0.f, shy = h->per[1] ? h->box_hi[1] - h->box_lo[1] : 0.f,
@@ -1932,9 +1978,19 @@ static int rebuild_fast(mdx_handle* h, RebuildResult* res, bool* fell_back) {
         if (T_bound < mw_below)
             hipLaunchKernelGGL(prune_list_mw_kernel<8>, dim3(T_bound), dim3(512), 0, st, T_bound, rb * rb, shx, shy, shz, d.posq, d.list_counts,
                                d.entry_off, d.entries, a.null_cluster, d.pair_count, (const uint32_t*)d.rb_ctl, tint, kinds);
-        else
-            hipLaunchKernelGGL(prune_list_kernel, dim3((div_up(T_bound, 4) + 7u) & ~7u), dim3(256), 0, st, T_bound, rb * rb, shx, shy, shz,
-                               d.posq, d.list_counts, d.entry_off, d.entries, a.null_cluster, d.pair_count, (const uint32_t*)d.rb_ctl, tint, kinds);
+        else if (inner_here) {
+            PruneInner pin{};
+            pin.entries_in = d.entries_in; pin.inner_nch = d.inner_nch; pin.rule = mdx_wpt_rule_of(h);
+            const float rin = std::max(std::isfinite(h->cfg.lj_cutoff) && h->cfg.lj_cutoff > 0.f ? h->cfg.lj_cutoff : 0.f,
+                                       std::isfinite(h->cfg.coulomb_cutoff) && h->cfg.coulomb_cutoff > 0.f ? h->cfg.coulomb_cutoff : 0.f) + inner_skin_next;
+            pin.rin2 = rin * rin;      // (= NbArgs::rin2 of the pair kernel's pruning pass, mdx_nonbonded.hip)
+            hipLaunchKernelGGL(prune_list_kernel<true>, dim3((div_up(T_bound, 4) + 7u) & ~7u), dim3(256), 0, st, T_bound, rb * rb, shx, shy, shz,
+                               d.posq, d.list_counts, d.entry_off, d.entries, a.null_cluster, d.pair_count, (const uint32_t*)d.rb_ctl, tint, kinds, pin);
+            inner_launched = true;
+        } else
+            hipLaunchKernelGGL(prune_list_kernel<false>, dim3((div_up(T_bound, 4) + 7u) & ~7u), dim3(256), 0, st, T_bound, rb * rb, shx, shy, shz,
+                               d.posq, d.list_counts, d.entry_off, d.entries, a.null_cluster, d.pair_count, (const uint32_t*)d.rb_ctl, tint, kinds,
+                               PruneInner{});
     }
     MDX_TRY(mdx_remap_constraints(h));
     // ---- finish: tile orders, totals, the one read-back ----
@@ -1972,6 +2028,8 @@ static int rebuild_fast(mdx_handle* h, RebuildResult* res, bool* fell_back) {
     res->npairs = (prune && exact_prune) ? kept : built;
     h->E = res->E; h->MC = res->MC;
     res->ordered = true;
+    res->inner_built = inner_launched && mdx_wpt_rule(mdx_wpt_rule_of(h), T) == 1;      // (the kernel applied the same rule to the same T)
+    h->force_zeroed = true;      // rb_assign_kernel cleared every slot's force: the pair launch behind this rebuild needs no fill of its own
     h->tile_lpt_on = plan.lpt; h->tile_lpt_grouped = plan.grouped;
     h->tile_split = false; h->n_interior = 0;
     if (classify_here) { h->tile_split = true; h->n_interior = h->h_rb[3]; res->classified = true; }
@@ -1983,8 +2041,11 @@ int mdx_rebuild(mdx_handle* h) {
     MdxRange range_rebuild("mdx list rebuild");
     h->vsites_fresh = false;      // (the next force call constructs the virtual sites itself: one launch per rebuild)
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->profile) {
-        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    if (h->profile) {      // (events come from the handle's pool and go back to it: creating and destroying two per rebuild was host time in front of the first kernel)
+        for (hipEvent_t* e : {&e0, &e1}) {
+            if (!h->ev_pool.empty()) { *e = h->ev_pool.back(); h->ev_pool.pop_back(); }
+            else HIP_TRY(hipEventCreate(e));
+        }
         HIP_TRY(hipEventRecord(e0, h->stream));
     }
     DeviceState& d = h->d;
@@ -2145,8 +2206,9 @@ int mdx_rebuild(mdx_handle* h) {
             hipLaunchKernelGGL(prune_list_mw_kernel<8>, dim3(T), dim3(512), 0, st, T, rb * rb, shx, shy, shz, d.posq, d.list_counts,
                                d.entry_off, d.entries, a.null_cluster, d.pair_count, (const uint32_t*)nullptr, (uint32_t*)nullptr, kinds);
         else
-            hipLaunchKernelGGL(prune_list_kernel, dim3((div_up(T, 4) + 7u) & ~7u), dim3(256), 0, st, T, rb * rb, shx, shy, shz,
-                               d.posq, d.list_counts, d.entry_off, d.entries, a.null_cluster, d.pair_count, (const uint32_t*)nullptr, (uint32_t*)nullptr, kinds);
+            hipLaunchKernelGGL(prune_list_kernel<false>, dim3((div_up(T, 4) + 7u) & ~7u), dim3(256), 0, st, T, rb * rb, shx, shy, shz,
+                               d.posq, d.list_counts, d.entry_off, d.entries, a.null_cluster, d.pair_count, (const uint32_t*)nullptr, (uint32_t*)nullptr, kinds,
+                               PruneInner{});
     };
     launch_prune();
 
@@ -2228,7 +2290,9 @@ int mdx_rebuild(mdx_handle* h) {
     h->inner_skin = h->inner_skin_auto > 0.f ? h->inner_skin_auto : c_inner_skin(h->cfg);
     h->dual_on = !h->dual_auto_off && mdx_nb_half(h) && prune && h->inner_skin > 0.f && h->inner_skin < h->cfg.skin &&
                  (h->n_vsites == 0 || h->vsites_convex);
-    h->prune_pending = true;
+    h->prune_pending = !(res.inner_built && h->dual_on);      // (the fused chain's pruning pass has written the inner list of these positions)
+    h->inner_from_rebuild = !h->prune_pending;
+    if (h->inner_from_rebuild) ++h->inner_rebuilds;
     if (!d.inner_count) { ALLOC(d.inner_count, MDX_EPART + 8); HIP_TRY(hipMemsetAsync(d.inner_count, 0, sizeof(unsigned long long) * (MDX_EPART + 8), st)); }
     uint64_t nmask = (uint64_t)MC * 8;
     h->stats.n_atoms = N; h->stats.n_slots = S; h->stats.n_tiles = T; h->stats.n_clusters = NC;
@@ -2239,7 +2303,7 @@ int mdx_rebuild(mdx_handle* h) {
         HIP_TRY(hipEventRecord(e1, st)); HIP_TRY(hipEventSynchronize(e1));
         HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
         h->stats.rebuild_ms_sum += ms;
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        h->ev_pool.push_back(e0); h->ev_pool.push_back(e1);
     }
     return MDX_OK;
 }

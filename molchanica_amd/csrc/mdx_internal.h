@@ -317,6 +317,8 @@ struct mdx_handle {
     // self-tuning of the library-default buffer (cfg.inner_skin == 0): pruning passes per step over a window of steps
     float inner_skin_auto = 0.f; bool dual_auto_off = false; uint32_t dual_win_steps = 0, dual_win_prunes = 0;
     bool prune_pending = true;   // the next step-loop force call must prune (after a rebuild / at the start of mdx_step)
+    uint32_t inner_rebuilds = 0;       // list rebuilds so far whose pruning pass wrote the inner list
+    bool inner_from_rebuild = false;   // the last list rebuild produced the inner list itself (prune_list_kernel<true>): the force call behind it walks it
     bool prune_latch = false;    // ... latched for the (up to two) launches of that force call
     bool moved_outside = true;   // something other than the step loop moved atoms in slot space (minimiser, constraint projection):
                                  // the path accumulators did not see it, the next mdx_step starts with a pruning pass

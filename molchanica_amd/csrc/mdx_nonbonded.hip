@@ -142,7 +142,8 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
     // ... except the one that finishes the step behind a rebuild (nb_post_rebuild): that one IS the pruning pass (round 3: it
     // used to walk the plain list, 514 us at 1 M atoms, and the next step pruned, 604; now 604 here and 445 there)
     const bool step_call = h->nb_step >= 0 && d_gate != nullptr;
-    a.inner = (h->dual_on && !h->alch_on && !energy && (step_call || (h->nb_post_rebuild && h->prune_pending))) ? 1u : 0u;
+    // (round 6: ... or, where the rebuild's own pruning pass wrote the inner list - one wave per tile, single device - an inner-list walk)
+    a.inner = (h->dual_on && !h->alch_on && !energy && (step_call || (h->nb_post_rebuild && (h->prune_pending || h->inner_from_rebuild)))) ? 1u : 0u;
     if (a.inner) {
         if (part != 2) { h->prune_latch = h->prune_pending; h->prune_pending = false; }   // one decision for both halves of a split launch
         a.force_prune = h->prune_latch ? 1u : 0u;

@@ -96,9 +96,16 @@ def test_c5_water1m_step_loop_forces_against_the_oracle(mdx, orc):
         st = md.stats()
         assert st["rebuild_count"] >= 2 and st["prune_passes"] >= 3, (st["rebuild_count"], st["prune_passes"])
         assert st["rebuild_fallbacks"] == 0
+        # round 6: at this size the rebuild's own pruning pass writes the inner list; the force call behind it walks it
+        assert md.pair_launch_info()["inner_lists_from_rebuilds"] >= 1
         info2 = md.pair_launch_info()["step"]
         assert {k: v for k, v in info2.items() if k != "tiles"} == {k: v for k, v in info.items() if k != "tiles"}, (info, info2)
-        step_loop_forces_vs_oracle(md, orc, s, cfg, "water1M after 32 steps", slack_rel=4e-5, outliers=2)
+        # (outliers: the box as generated is at ~1300 K by now; measured (tools/dbg/c5_outliers.py): three atoms of 1,029,000 between 1 x and
+        # 1.61 x the bound, all three oxygens with a net |F| < 3 kcal/mol/A - bound 1e-4 - whose ~420 pair forces add up to a gross ~2000:
+        # |dF| = 2e-4 ... 4e-4 is 1-2 fp32 ulp of what is being summed, in an order the two sides do not share; the plain-list evaluation
+        # of the same positions shows the same three atoms.  No pair within 4e-5 of the cutoff is involved (those carry their slack).
+        # Five in a million may sit between 1 x and 2 x, none beyond.)
+        step_loop_forces_vs_oracle(md, orc, s, cfg, "water1M after 32 steps", slack_rel=4e-5, outliers=5)
     assert all(v <= b for v, b in report.values()), line
 
 
@@ -119,7 +126,7 @@ def test_mid_size_classes_step_loop_forces_against_the_oracle(mdx, orc, n_side, 
         step_loop_forces_vs_oracle(md, orc, s, cfg, f"water_box({n_side}) after a rebuild", slack_rel=2e-5)
 
 
-@pytest.mark.parametrize("wpt,fused", [(1, False), (2, False), (4, False), (8, False), (1, True), (2, True)])
+@pytest.mark.parametrize("wpt,fused", [(1, False), (2, False), (4, False), (8, False), (1, True), (2, True), (1, "inner")])
 def test_every_waves_per_tile_instantiation_against_the_oracle(wpt, fused):
     """MDX_WPT is read once per process: each value in a child (tests/timed_body_child.py).  `fused`: MDX_WPT8_BELOW=32 also
     selects the large classes' fused bonded + kick + drift pass - with MDX_WPT=1 the complete water1M arrangement on 12 k atoms."""
@@ -127,7 +134,9 @@ def test_every_waves_per_tile_instantiation_against_the_oracle(wpt, fused):
     env["MDX_WPT"] = str(wpt)
     if fused:
         env["MDX_WPT8_BELOW"] = "32"
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "timed_body_child.py"), str(wpt)] + (["fused"] if fused else []),
+    if fused == "inner":      # ... and the one-wave pruning pass of the list rebuild, which then writes the inner list itself (water1M's path)
+        env["MDX_PRUNE_MW_BELOW"] = "0"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "timed_body_child.py"), str(wpt)] + ([str(fused).replace("True", "fused")] if fused else []),
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     tail = "\n".join((p.stdout + p.stderr).splitlines()[-25:])
     assert p.returncode == 0 and "TIMED-BODY-OK" in p.stdout, tail

@@ -22,7 +22,8 @@ from tests.test_gpu_timed_body import step_loop_forces_vs_oracle  # noqa: E402
 
 def main():
     w = int(sys.argv[1])
-    fused = len(sys.argv) > 2 and sys.argv[2] == "fused"
+    fused = len(sys.argv) > 2 and sys.argv[2] in ("fused", "inner")
+    inner = len(sys.argv) > 2 and sys.argv[2] == "inner"
     assert os.environ.get("MDX_WPT") == str(w)
     assert md_state.device_count() >= 1
     orc.lib()
@@ -48,6 +49,9 @@ def main():
                 step_loop_forces_vs_oracle(md, orc, s, cfg, f"{name} wpt {w} after {done} steps")
             st = md.stats()
             assert st["prune_passes"] >= 3 and st["rebuild_count"] >= 2, (st["prune_passes"], st["rebuild_count"])
+            if inner:
+                n_in = md.pair_launch_info()["inner_lists_from_rebuilds"]
+                assert n_in >= 1, (n_in, st["rebuild_count"])      # (every rebuild of the fused chain; a handle's first takes the unfused one)
             if fused and name == "water12k":      # (the chain's mean role count keeps it on the separate bonded gather: mdx_bonded_integrate_ok)
                 assert st["fused_launches"] > 0, "the fused bonded + kick + drift pass did not run"
             print(f"{name}: wpt {w} dual {info['dual']} tiles {info['tiles']} prune passes {st['prune_passes']} rebuilds {st['rebuild_count']}"
