@@ -342,6 +342,8 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
                         add_term(at, 2, ROLE_EWALD_EXCL, c->coulomb_k * q[i] * q[j], 0.f, 0.f);
                     }
         h->n_roles = R;
+        h->n_roles_excl = 0;
+        for (const RoleRec& r : recs) h->n_roles_excl += (r.meta & 0xFu) == ROLE_EWALD_EXCL ? 1u : 0u;
         if (prm_overflow) FAIL(MDX_EPARAM, "more than 16.7 M distinct bonded parameter sets");
         MDX_TRY(upload_vec(&d.role_prm, prm_tab, st));
         MDX_TRY(upload_vec(&d.role_off_o, cnt, st)); MDX_TRY(upload_vec(&d.role_rec_o, recs, st));
@@ -744,19 +746,34 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         h->e_cache_valid = false; h->e_pending = false;
         const size_t e_bytes = sizeof(double) * (EN_COUNT + 8 + MDX_ESTRIDE * MDX_EPART);
         float4* pos_after[MDX_MAX_CHUNK + 1];      // the buffer that holds the positions after step s's drift
+        // boxes of rigid water (the reference's default operating point): site-force spread + kick + drift + SETTLE + site placement in ONE pass
+        const bool water = fused && mdx_water_step_ok(h);
         const bool pipe_chunk = fuse_bi && mdx_dd_fold_eligible(h);      // decomposed handle: the fused pass also packs the halo and adds the returned ghost forces
         for (uint32_t s = 0; s < chunk; ++s) {
             h->prof_tag = (int)s;
             h->lang_step = h->step_count + s;
             const int mode = !vv ? (integ == MDX_INTEGRATOR_LANGEVIN_MIDDLE ? 3 : 1) : ((s == 0 || !fused) ? 0 : 1);
             if (h->dd) h->dd->pipe_now = pipe_chunk && mode == 1 && !(want_e && s + 1 == chunk);
-            if (fuse_bi && mode == 1) MDX_TRY(mdx_launch_bonded_integrate(h, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
+            const bool water_now = water && (mode == 0 || mode == 1);
+            if (water_now) MDX_TRY(mdx_launch_water_step(h, mode, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
+            else if (fuse_bi && mode == 1) MDX_TRY(mdx_launch_bonded_integrate(h, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
             else MDX_TRY(mdx_launch_integrate(h, mode, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
             pos_after[s] = d.posq;
-            h->bonded_deferred = fuse_bi && s + 1 < chunk;
-            h->cons_full_kick = vv && mode == 1;
-            MDX_TRY(mdx_launch_constrain_positions(h, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
-            h->cons_full_kick = false;
+            // Rigid-water boxes under Ewald: the only "bonded" terms are the exclusion corrections between the sites of one rigid
+            // molecule - a self-equilibrated, in-plane force system on a rigid triangle, i.e. a combination of pair forces along its
+            // three constrained edges at time t, which is exactly the form of a SHAKE / SETTLE correction: the constrained positions
+            // and velocities come out the same with or without them (the multipliers absorb them).  Force calls whose result only
+            // the next step's kick reads leave them out; the last two of a chunk are complete (forces, energies and the constraint
+            // virial of the chunk's last position stage are then what they always were).  MDX_RIGID_EXCL_SKIP=0: A/B.
+            static const bool excl_skip_env = [] { const char* e = std::getenv("MDX_RIGID_EXCL_SKIP"); return !(e && e[0] == '0'); }();
+            const bool excl_skip = excl_skip_env && water && h->excl_inside_rigid && h->n_roles != 0 && h->n_roles == h->n_roles_excl && s + 2 < chunk &&
+                                   !(want_e && s + 1 == chunk);
+            h->bonded_deferred = (fuse_bi && s + 1 < chunk) || excl_skip;
+            if (!water_now) {
+                h->cons_full_kick = vv && mode == 1;
+                MDX_TRY(mdx_launch_constrain_positions(h, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
+                h->cons_full_kick = false;
+            }
             // Langevin middle: friction and noise sit between the two half drifts, so SHAKE's dx/dt is not an
             // exact velocity projection; RATTLE the half-step velocities (same gate as SHAKE: it belongs to the
             // drift, which has happened even when the step's forces turn out to be gated off)
@@ -765,8 +782,9 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
             if (h->dd) { h->dd->halo_pending = true; h->dd->halo_step = (int)s; h->chunk_s = (int)s; }
             const bool e_now = want_e && s + 1 == chunk;
             if (e_now) HIP_TRY(hipMemsetAsync(d.energy, 0, e_bytes, st));
+            h->vsite_spread_deferred = water && s + 1 < chunk && !e_now;      // (the next step's water_step_kernel spreads the sites' forces)
             const int frc = compute_forces(h, e_now, &d.ctl->disp2[s + 1], thr);
-            h->nb_step = -1; h->bonded_deferred = false;
+            h->nb_step = -1; h->bonded_deferred = false; h->vsite_spread_deferred = false;
             MDX_TRY(frc);
             if (vv && !fused) {
                 MDX_TRY(mdx_launch_integrate(h, 2, dt, &d.ctl->disp2[s + 1], nullptr, thr));

@@ -761,6 +761,25 @@ int mdx_build_constraints(mdx_handle* h, const mdx_system* s) {
         HIP_TRY(hipMemcpyAsync(h->d.vsite_o, vs.data(), sizeof(VSite) * vs.size(), hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
+    {   // does every excluded pair lie inside one rigid three-site cluster (site included)?  (mdx_step: such corrections change nothing
+        // the constraints do not undo, and the step loop of a rigid-water box leaves them to the force calls whose result is read)
+        h->excl_inside_rigid = false;
+        if (s->excl_offsets && s->excl_idx && h->cons_all_rigid3 && !h->h_groups.empty()) {
+            std::vector<int> cl(N, -1);
+            for (size_t gi = 0; gi < h->h_groups.size(); ++gi)
+                for (uint32_t k = 0; k < h->h_groups[gi].natoms; ++k) cl[h->h_groups[gi].atom[k]] = (int)gi;
+            bool ok = true;
+            for (const VSite& v : h->h_vsites) {      // a site belongs to the cluster all three of its parents are members of
+                if (cl[v.p0] >= 0 && cl[v.p0] == cl[v.p1] && cl[v.p0] == cl[v.p2]) cl[v.site] = cl[v.p0]; else ok = false;
+            }
+            for (uint32_t i = 0; i < N && ok; ++i)
+                for (uint32_t k = s->excl_offsets[i]; k < s->excl_offsets[i + 1]; ++k) {
+                    const uint32_t j = s->excl_idx[k];
+                    if (cl[i] < 0 || cl[i] != cl[j]) { ok = false; break; }
+                }
+            h->excl_inside_rigid = ok;
+        }
+    }
     // Sites whose three parents are the members of ONE constraint cluster (rigid four-site water) are placed by that cluster's
     // position stage (GroupSite).  All of them or none: MDX_VSITE_IN_GROUPS=0 keeps the construct launch (A/B).
     h->vsites_in_groups = false; h->vsites_fresh = false;
@@ -880,6 +899,175 @@ int mdx_launch_constraint_virial(mdx_handle* h) {
     return MDX_OK;
 }
 
+
+// ---- one pass per step for boxes of rigid water (round 6) -----------------------------------------------------------------------
+// The reference's default operating point is a box of rigid four-site OPC water at dt = 2 fs (/root/reference src/prefs/mod.rs:203,
+// src/ui/panels/md.rs:362-371).  Per step such a handle ran vsite_spread_kernel (M's force onto O, H, H: 17 us at 1 M sites),
+// integrate_kernel (kick + drift: 25 us) and constrain_positions_kernel (SETTLE + M placed: 35 us) - three passes over the same
+// rows.  Where EVERY mobile atom is a member of a rigid three-site cluster and every virtual site is its cluster's (host-checked:
+// mdx_water_step_ok) a lane takes one water through all of it: force of the site handed to its parents, kick, drift, SETTLE in
+// closed form on the old / new triangle, velocities corrected, site placed, forces cleared for the pair kernel's atomics, rebuild
+// and pruning triggers raised - every row read once and written once.  KICK 0: opening half kick (first step of a chunk), 1: full
+// kick (closing + opening).  The arithmetic of the pieces is the separate kernels' (same SETTLE, same image convention); the old
+// positions are the stored ones instead of x' - dt v'.  MDX_WATER_STEP=0: the three launches (A/B).
+template <int KICK>
+__global__ __launch_bounds__(128) void water_step_kernel(uint32_t n_groups, const ConsGroup* __restrict__ groups, const GroupSite* __restrict__ gsite,
+                                                         float4* __restrict__ posq, float4* __restrict__ vel, float4* __restrict__ force,
+                                                         float4* __restrict__ ref, float dt, ConsParams p, float* __restrict__ cons_vir,
+                                                         const uint32_t* gate_in, uint32_t* disp_out, uint32_t thr, uint32_t* prune_out,
+                                                         float path_thr, const uint32_t* __restrict__ n_dev, uint32_t spread, uint32_t zero) {
+    const uint32_t gate = gate_in ? *gate_in : 0u;
+    if (gate > thr) {      // list already stale: stay a no-op, keep the flag raised (integrate_kernel's rule)
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(disp_out, gate);
+        return;
+    }
+    if (n_dev) n_groups = min(n_groups, *n_dev);
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    float d2max = 0.f, pmax = 0.f;
+    if (g < n_groups) {
+        const ConsGroup cg = groups[g];
+        if (cg.natoms == 3) {
+            GroupSite gv{}; gv.site = MDX_INVALID;
+            if (gsite) gv = gsite[g];
+            const bool have_site = gv.on && gv.site != MDX_INVALID;
+            float4 pk[3], vk[3], fk[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { pk[k] = posq[cg.atom[k]]; vk[k] = vel[cg.atom[k]]; fk[k] = force[cg.atom[k]]; }
+            if (have_site && spread) {      // the site's force belongs to its parents (vsite_spread_kernel's weights)
+                const float4 fm = force[gv.site];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float wk = (k == (int)gv.k0 ? 1.0f - gv.a - gv.b : 0.f) + (k == (int)gv.k1 ? gv.a : 0.f) + (k == (int)gv.k2 ? gv.b : 0.f);
+                    fk[k].x += wk * fm.x; fk[k].y += wk * fm.y; fk[k].z += wk * fm.z;
+                }
+            }
+            float3 xo[4], xn[4], xs[4];
+            float im[4];
+            xo[3] = xn[3] = xs[3] = make_float3(0, 0, 0); im[3] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float kdt = (KICK == 1 ? dt : 0.5f * dt) * vk[k].w;
+                vk[k].x += kdt * fk[k].x; vk[k].y += kdt * fk[k].y; vk[k].z += kdt * fk[k].z;
+                xo[k] = mimg3(make_float3(pk[k].x - pk[0].x, pk[k].y - pk[0].y, pk[k].z - pk[0].z), p);
+                xn[k] = make_float3(xo[k].x + dt * vk[k].x, xo[k].y + dt * vk[k].y, xo[k].z + dt * vk[k].z);
+                xs[k] = xn[k];
+                im[k] = vk[k].w;
+            }
+            float wc = 0.f;
+            bool settled = false;
+            const Triangle tri = rigid_triangle(cg, im);
+            if (p.settle && tri.ok && settle_positions(xo, xn, im, tri)) {
+                settled = true;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    wc += ((xn[k].x - xs[k].x) * xo[k].x + (xn[k].y - xs[k].y) * xo[k].y + (xn[k].z - xs[k].z) * xo[k].z) / im[k];
+            }
+            if (!settled) {      // degenerate step or SETTLE switched off: the Gauss-Seidel sweep over the three pairs
+                const float Lq[3] = {tri.l01, tri.l01, tri.l12};
+                for (int it = 0; it < p.max_iter; ++it) {
+                    bool done = true;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const int a = q == 2 ? 1 : 0, b = q == 0 ? 1 : 2;
+                        if (!(Lq[q] > 0.f)) continue;
+                        const float3 s = make_float3(xn[a].x - xn[b].x, xn[a].y - xn[b].y, xn[a].z - xn[b].z);
+                        const float l2 = Lq[q] * Lq[q];
+                        const float diff = l2 - (s.x * s.x + s.y * s.y + s.z * s.z);
+                        if (fabsf(diff) > 2.0f * p.tol * l2) {
+                            done = false;
+                            const float3 r = make_float3(xo[a].x - xo[b].x, xo[a].y - xo[b].y, xo[a].z - xo[b].z);
+                            const float sr = s.x * r.x + s.y * r.y + s.z * r.z;
+                            const float gk = diff / (2.0f * sr * (im[a] + im[b]));
+                            wc += gk * (r.x * r.x + r.y * r.y + r.z * r.z);
+                            xn[a].x += gk * im[a] * r.x; xn[a].y += gk * im[a] * r.y; xn[a].z += gk * im[a] * r.z;
+                            xn[b].x -= gk * im[b] * r.x; xn[b].y -= gk * im[b] * r.y; xn[b].z -= gk * im[b] * r.z;
+                        }
+                    }
+                    if (done) break;
+                }
+            }
+            const float idt = 1.0f / dt;
+            if (cons_vir) cons_vir[g] = p.vir_scale * wc * idt * idt;
+            float4 p0n = pk[0];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float4 pn = pk[k];
+                const float mx = xn[k].x - xo[k].x, my = xn[k].y - xo[k].y, mz = xn[k].z - xo[k].z;      // this step's displacement of the atom
+                pn.x += mx; pn.y += my; pn.z += mz;
+                vk[k].x += (xn[k].x - xs[k].x) * idt; vk[k].y += (xn[k].y - xs[k].y) * idt; vk[k].z += (xn[k].z - xs[k].z) * idt;
+                posq[cg.atom[k]] = pn; vel[cg.atom[k]] = vk[k];
+                if (zero) force[cg.atom[k]] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k == 0) p0n = pn;
+                const float4 r = ref[cg.atom[k]];
+                const float ex = pn.x - r.x, ey = pn.y - r.y, ez = pn.z - r.z;
+                d2max = fmaxf(d2max, ex * ex + ey * ey + ez * ez);
+                if (prune_out) {
+                    const float w = r.w + sqrtf(mx * mx + my * my + mz * mz);
+                    ref[cg.atom[k]].w = w;
+                    pmax = fmaxf(pmax, w);
+                }
+            }
+            if (have_site) {
+                // r_p0 + a (r_p1 - r_p0) + b (r_p2 - r_p0) from the constrained positions in registers, at the periodic image nearest to
+                // where the site is stored (constrain_positions_kernel's rule)
+                float3 fresh = make_float3(p0n.x - xn[0].x, p0n.y - xn[0].y, p0n.z - xn[0].z);      // the frame's origin (the old position of atom 0)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float wk = (k == (int)gv.k0 ? 1.0f - gv.a - gv.b : 0.f) + (k == (int)gv.k1 ? gv.a : 0.f) + (k == (int)gv.k2 ? gv.b : 0.f);
+                    fresh.x += wk * xn[k].x; fresh.y += wk * xn[k].y; fresh.z += wk * xn[k].z;
+                }
+                float4 m = posq[gv.site];
+                const float3 back = mimg3(make_float3(m.x - fresh.x, m.y - fresh.y, m.z - fresh.z), p);
+                m.x -= back.x; m.y -= back.y; m.z -= back.z;
+                posq[gv.site] = m;
+                if (zero || spread) force[gv.site] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    if (!(d2max < 1.0e30f)) d2max = 3.0e38f;      // NaN / inf -> huge: forces a stop
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) d2max = fmaxf(d2max, __shfl_xor(d2max, m));
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(d2max) > thr) atomicMax(disp_out, __float_as_uint(d2max));
+    if (prune_out) {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, m));
+        if ((threadIdx.x & 63) == 0 && !(pmax <= path_thr)) *prune_out = 1u;
+    }
+}
+
+// Is this handle a box of rigid water the one-pass step applies to?  (every mobile atom a member of a rigid three-site cluster, every
+// other atom the virtual site of such a cluster, velocity Verlet, one device)
+bool mdx_water_step_ok(const mdx_handle* h) {
+    static const bool on = [] { const char* e = std::getenv("MDX_WATER_STEP"); return !(e && e[0] == '0'); }();
+    static const bool rigid3_env = [] { const char* e = std::getenv("MDX_CONS_RIGID3"); return !(e && e[0] == '0'); }();
+    return on && rigid3_env && h->integrator == MDX_INTEGRATOR_VERLET_VELOCITY && h->n_groups != 0 && h->cons_all_rigid3 && h->n_star5 == 0 &&
+           (h->n_vsites == 0 || h->vsites_in_groups) && h->n_mobile == 3u * h->n_groups && h->N == h->n_mobile + h->n_vsites &&
+           !h->dd && h->n_local == h->N && mdx_nb_variant(h) >= 2;
+}
+
+// mode 0: opening half kick + drift, 1: full kick + drift (mdx_launch_integrate's modes); then SETTLE and the site, all in one launch
+int mdx_launch_water_step(mdx_handle* h, int mode, float dt, const uint32_t* d_gate, uint32_t* d_disp_out, uint32_t thr, uint32_t* d_prune_out) {
+    if (!h->dual_on) d_prune_out = nullptr;
+    ConsParams cp = cons_params(h);
+    cp.vir_scale = mode == 1 ? 1.0f : 2.0f;      // (mdx_launch_constrain_positions: cons_full_kick)
+    const uint32_t zero = mdx_nb_half(h) ? 1u : 0u, spread = (h->n_vsites && h->vsite_spread_pending) ? 1u : 0u;
+    h->vsite_spread_pending = false;
+    const GroupSite* const gs = h->vsites_in_groups ? (const GroupSite*)h->d.gsite_s : nullptr;
+    const dim3 g(div_up(h->n_groups, 128)), b(128);
+    mdx_prof_begin(h, 2);
+    if (mode == 1)
+        hipLaunchKernelGGL(water_step_kernel<1>, g, b, 0, h->stream, h->n_groups, h->d.cons_s, gs, h->d.posq, h->d.vel, h->d.force, h->d.ref, dt, cp,
+                           h->d.cons_vir, d_gate, d_disp_out, thr, d_prune_out, 0.5f * h->inner_skin * (1.0f - 1.0e-4f), h->d.cons_n_dev, spread, zero);
+    else
+        hipLaunchKernelGGL(water_step_kernel<0>, g, b, 0, h->stream, h->n_groups, h->d.cons_s, gs, h->d.posq, h->d.vel, h->d.force, h->d.ref, dt, cp,
+                           h->d.cons_vir, d_gate, d_disp_out, thr, d_prune_out, 0.5f * h->inner_skin * (1.0f - 1.0e-4f), h->d.cons_n_dev, spread, zero);
+    mdx_prof_end(h);
+    if (zero) h->force_zeroed = true;
+    if (h->vsites_in_groups) h->vsites_fresh = true;
+    HIP_TRY(hipGetLastError());
+    return MDX_OK;
+}
+
 int mdx_launch_constrain_velocities(mdx_handle* h, const uint32_t* d_gate, uint32_t thr) {
     if (!mdx_has_constraints(h)) return MDX_OK;
     if (h->n_star5)
@@ -906,6 +1094,9 @@ int mdx_launch_vsite_construct(mdx_handle* h, const uint32_t* d_gate, uint32_t t
 
 int mdx_launch_vsite_spread(mdx_handle* h, const uint32_t* d_gate, uint32_t thr) {
     if (!h->n_vsites) return MDX_OK;
+    // step loop of a rigid-water box: the next step's one-pass kernel hands the sites' forces to their parents itself
+    if (h->vsite_spread_deferred) { h->vsite_spread_pending = true; return MDX_OK; }
+    h->vsite_spread_pending = false;
     hipLaunchKernelGGL(vsite_spread_kernel, dim3(div_up(h->n_vsites, 256)), dim3(256), 0, h->stream, h->n_vsites,
                        h->d.vsite_s, h->d.force, d_gate, thr);
     HIP_TRY(hipGetLastError());

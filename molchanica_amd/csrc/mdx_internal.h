@@ -275,10 +275,14 @@ struct mdx_handle {
     float box_lo[3]{}, box_hi[3]{};
     uint32_t n_bonds = 0, n_angles = 0, n_dih = 0, n_p14 = 0;
     uint32_t n_roles = 0;
+    uint32_t n_roles_excl = 0;        // ... of which Ewald exclusion corrections (ROLE_EWALD_EXCL)
+    bool excl_inside_rigid = false;   // every excluded pair lies inside ONE rigid three-site cluster (its virtual site included)
     uint32_t n_groups = 0, n_cons = 0, n_vsites = 0;   // constraint clusters of up to four atoms / constraints / virtual sites
     uint32_t n_star5 = 0; std::vector<ConsStar5> h_star5;   // X-H4 clusters (caller order)
     bool cons_all_rigid3 = false;    // every constraint cluster is a rigid three-site water: the solvers' register-only flavour
     bool vsites_in_groups = false;   // every virtual site is placed by its parents' constraint cluster (GroupSite)
+    bool vsite_spread_deferred = false;   // step loop, rigid-water boxes: the force call being enqueued leaves the sites' forces to the next water_step_kernel ...
+    bool vsite_spread_pending = false;    // ... and has done so: that kernel spreads them
     bool vsites_fresh = false;       // ... and the last position stage did so: the next force call has nothing to construct
     std::vector<ConsGroup> h_groups; std::vector<VSite> h_vsites;   // host copies (caller order): ownership anchors of a decomposition
     int hc_kind = 1; uint32_t hc_order = 0, hc_iter = 0; std::string hc_text;   // mdx_set_hydrogen_constraint: what the host asked for
@@ -516,6 +520,8 @@ int mdx_remap_constraints(mdx_handle* h);                  // caller order -> sl
 int mdx_launch_constrain_positions(mdx_handle* h, float dt, const uint32_t* d_gate, uint32_t* d_disp_out, uint32_t thr,
                                    uint32_t* d_prune_out = nullptr);
 int mdx_launch_constrain_velocities(mdx_handle* h, const uint32_t* d_gate, uint32_t thr);
+bool mdx_water_step_ok(const mdx_handle* h);               // a box of rigid water: spread + kick + drift + SETTLE + site placement as ONE pass per step
+int mdx_launch_water_step(mdx_handle* h, int mode, float dt, const uint32_t* d_gate, uint32_t* d_disp_out, uint32_t thr, uint32_t* d_prune_out);
 int mdx_launch_vsite_construct(mdx_handle* h, const uint32_t* d_gate, uint32_t thr);
 int mdx_launch_constraint_virial(mdx_handle* h);
 int mdx_check_box(const mdx_handle* h, const float* lo, const float* hi);   // the checks mdx_set_box applies   // energy[EN_VIRIAL] += sum of cons_vir

@@ -127,6 +127,40 @@ def test_opc_box_conserves_energy_after_equilibration(mdx):
     assert abs(e1["temperature"] - e0["temperature"]) < 25.0
 
 
+def test_one_pass_water_step_against_the_three_launches(tmp_path):
+    """Boxes of rigid water step through ONE kernel per step (water_step_kernel, mdx_constraints.hip: site-force spread + kick + drift +
+    SETTLE + site placement; the tests above hold it against the oracle).  MDX_WATER_STEP=0 keeps the three launches it replaces:
+    same trajectories, energies and virial to rounding (the fused pass takes the old positions as stored instead of x' - dt v')."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    arms = {}
+    for arm in ("0", "1"):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("MDX_")}
+        env["MDX_WATER_STEP"] = arm
+        out = tmp_path / f"arm{arm}.npz"
+        p = subprocess.run([sys.executable, os.path.join(root, "tests", "water_step_child.py"), str(out)], cwd=root, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "WATER-STEP-CHILD-OK" in p.stdout, (p.stdout + p.stderr)[-2000:]
+        arms[arm] = np.load(out)
+    a, b = arms["0"], arms["1"]
+    for name in ("tip3p_rigid", "opc", "opc_straddling_spme"):
+        d = a[name + "_pos"].astype(np.float64) - b[name + "_pos"].astype(np.float64)
+        d -= np.round(d / 24.8272) * 24.8272
+        # (60 steps at 2 fs from a 300 K start: two fp32 evaluations of the same step part at rounding level and grow apart like any two
+        # trajectories do - measured 2.2e-4 A rms; each arm is within 2e-3 A of the fp64 oracle over 50 steps in the tests above)
+        assert math.sqrt((d ** 2).sum(1).mean()) < 1e-3, (name, math.sqrt((d ** 2).sum(1).mean()))
+        dv = a[name + "_vel"].astype(np.float64) - b[name + "_vel"].astype(np.float64)
+        assert math.sqrt((dv ** 2).sum(1).mean()) < 0.2, (name, math.sqrt((dv ** 2).sum(1).mean()))
+        ea, eb = a[name + "_e"], b[name + "_e"]
+        assert abs(ea[0] - eb[0]) < 2e-5 * abs(ea[0]) + 0.05 and abs(ea[1] - eb[1]) < 2e-4 * ea[1], (name, ea, eb)
+        assert abs(ea[2] - eb[2]) < 2e-3 * abs(ea[2]) + 1.0, (name, "virial", ea[2], eb[2])
+        assert a[name + "_rebuilds"][0] >= 3
+        if name.startswith("opc"):
+            assert np.abs(b[name + "_frc"][3::4]).max() == 0.0, "a virtual site must not keep a force"
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 def test_clusters_by_interaction_kind_change_the_list_not_the_forces(mdx, mode, monkeypatch):
     """Four-site water: oxygens carry the Lennard-Jones well and no charge, hydrogens and M sites the charges.  The tile assignment
