@@ -295,7 +295,8 @@ int mdx_get_stats(mdx_handle* h, mdx_stats* out);
  * 1 reaction field, 2 Ewald closed form, 3 softened, 4 Ewald table), energy flavour, workgroups per tile, bonded workgroups behind
  * twin launches, tiles in the launch}.  out[16]: list rebuilds so far whose exact pruning pass also wrote the inner list (the force
  * call behind such a rebuild walks the inner list instead of being a pruning pass: one wave per tile, single device), out[17]: the
- * last rebuild was one of them, out[18..19]: 0.  The parity tests use it to name the body they hold against the oracle; no call
+ * last rebuild was one of them, out[18]: steps so far that took the handle's rigid waters through the one-pass water_step_kernel, out[19]: ... of
+ * which with other mobile atoms beside them (a solute in rigid water).  The parity tests use it to name the body they hold against the oracle; no call
  * of the reference corresponds to it. */
 int mdx_pair_launch_info(const mdx_handle* h, uint32_t out[20]);
 /* The Verlet skin in force, and whether the library is still tuning it (mdx_config.skin == 0). */

@@ -146,7 +146,7 @@ static void free_device(mdx_handle* h) {
                     d.tile_col, d.scan_tmp, d.cl_lo, d.cl_hi, d.cl_kind, d.list_counts, d.entry_cnt, d.entry_off,
                     d.mchunk_cnt, d.mchunk_off, d.entries, d.entries_in, d.inner_nch, d.list_cursors, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
                     d.role_off_s, d.role_rec_s, d.role_prm, d.ctl, d.energy,
-                    d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.pme_force, d.cons_o, d.cons_s, d.cons_tmp, d.cons_mask, d.cons_cnt, d.cons_off, d.cons_vir, d.vsite_o, d.vsite_s, d.gsite_o, d.gsite_s, d.gsite_tmp, d.pme_q, d.pme_f,
+                    d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.pme_force, d.wstep_s, d.cons_o, d.cons_s, d.cons_tmp, d.cons_mask, d.cons_cnt, d.cons_off, d.cons_vir, d.vsite_o, d.vsite_s, d.gsite_o, d.gsite_s, d.gsite_tmp, d.pme_q, d.pme_f,
                     d.pme_theta, d.pme_q2, d.pme_f2, d.scratch4, d.tile_bnd, d.tile_scan, d.tile_order, d.tile_lpt, d.rb_ctl, d.scan_chain, d.grp, d.grp_mat, d.star_o, d.star_s, d.ewald_tab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = DeviceState{};
@@ -755,7 +755,11 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
             const int mode = !vv ? (integ == MDX_INTEGRATOR_LANGEVIN_MIDDLE ? 3 : 1) : ((s == 0 || !fused) ? 0 : 1);
             if (h->dd) h->dd->pipe_now = pipe_chunk && mode == 1 && !(want_e && s + 1 == chunk);
             const bool water_now = water && (mode == 0 || mode == 1);
-            if (water_now) MDX_TRY(mdx_launch_water_step(h, mode, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
+            const bool water_rest = water_now && mdx_water_step_mixed(h);      // a solute beside the waters: it keeps its own passes
+            if (water_now) {
+                MDX_TRY(mdx_launch_water_step(h, mode, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
+                if (water_rest) MDX_TRY(mdx_launch_integrate(h, mode, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1], true));
+            }
             else if (fuse_bi && mode == 1) MDX_TRY(mdx_launch_bonded_integrate(h, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
             else MDX_TRY(mdx_launch_integrate(h, mode, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
             pos_after[s] = d.posq;
@@ -766,12 +770,12 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
             // the next step's kick reads leave them out; the last two of a chunk are complete (forces, energies and the constraint
             // virial of the chunk's last position stage are then what they always were).  MDX_RIGID_EXCL_SKIP=0: A/B.
             static const bool excl_skip_env = [] { const char* e = std::getenv("MDX_RIGID_EXCL_SKIP"); return !(e && e[0] == '0'); }();
-            const bool excl_skip = excl_skip_env && water && h->excl_inside_rigid && h->n_roles != 0 && h->n_roles == h->n_roles_excl && s + 2 < chunk &&
+            const bool excl_skip = excl_skip_env && water && h->wstep_all && h->excl_inside_rigid && h->n_roles != 0 && h->n_roles == h->n_roles_excl && s + 2 < chunk &&
                                    !(want_e && s + 1 == chunk);
             h->bonded_deferred = (fuse_bi && s + 1 < chunk) || excl_skip;
-            if (!water_now) {
+            if (!water_now || water_rest) {
                 h->cons_full_kick = vv && mode == 1;
-                MDX_TRY(mdx_launch_constrain_positions(h, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1]));
+                MDX_TRY(mdx_launch_constrain_positions(h, dt, &d.ctl->disp2[s], &d.ctl->disp2[s + 1], thr, &d.ctl->prune[s + 1], water_now));
                 h->cons_full_kick = false;
             }
             // Langevin middle: friction and noise sit between the two half drifts, so SHAKE's dx/dt is not an
@@ -782,7 +786,7 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
             if (h->dd) { h->dd->halo_pending = true; h->dd->halo_step = (int)s; h->chunk_s = (int)s; }
             const bool e_now = want_e && s + 1 == chunk;
             if (e_now) HIP_TRY(hipMemsetAsync(d.energy, 0, e_bytes, st));
-            h->vsite_spread_deferred = water && s + 1 < chunk && !e_now;      // (the next step's water_step_kernel spreads the sites' forces)
+            h->vsite_spread_deferred = water && h->wstep_sites_all && s + 1 < chunk && !e_now;      // (the next step's water_step_kernel spreads the sites' forces)
             const int frc = compute_forces(h, e_now, &d.ctl->disp2[s + 1], thr);
             h->nb_step = -1; h->bonded_deferred = false; h->vsite_spread_deferred = false;
             MDX_TRY(frc);
@@ -1410,7 +1414,7 @@ extern "C" int mdx_get_skin(const mdx_handle* h, float* skin, int* tuning) {
 extern "C" int mdx_pair_launch_info(const mdx_handle* h, uint32_t out[20]) {
     if (!h || !out) FAIL(MDX_EPARAM, "null argument");
     for (int k = 0; k < 8; ++k) { out[k] = h->pair_info_step[k]; out[8 + k] = h->pair_info_any[k]; }
-    out[16] = h->inner_rebuilds; out[17] = h->inner_from_rebuild ? 1u : 0u; out[18] = 0u; out[19] = 0u;
+    out[16] = h->inner_rebuilds; out[17] = h->inner_from_rebuild ? 1u : 0u; out[18] = h->water_step_launches; out[19] = h->water_step_mixed_launches;
     return MDX_OK;
 }
 

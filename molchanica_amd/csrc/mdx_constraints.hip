@@ -139,12 +139,13 @@ __global__ __launch_bounds__(128) void constrain_positions_kernel(uint32_t n_gro
                                                                   float* __restrict__ cons_vir,
                                                                   const uint32_t* gate, uint32_t* disp_out, uint32_t thr,
                                                                   uint32_t* prune_out, float path_thr, const uint32_t* __restrict__ n_dev,
-                                                                  const GroupSite* __restrict__ gsite) {
+                                                                  const GroupSite* __restrict__ gsite, uint32_t skip_wstep) {
     if (gate && *gate > thr) return;
     if (n_dev) n_groups = min(n_groups, *n_dev);      // (clusters in slot order: the ones this handle solves come first)
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     float d2max = 0.f, pmax = 0.f;   // pmax: dual pair list, the longest path since the last pruning pass (ref[].w)
-    if (g < n_groups) {
+    // (skip_wstep: this step's water_step_kernel has taken the rigid waters through kick, drift and SETTLE - the rest is solved here)
+    if (g < n_groups && !(skip_wstep && groups[g].wstep)) {
         const ConsGroup cg = groups[g];
         // local frame: displacement of every atom from atom 0 (minimum image), new and old
         float3 xn[4], xo[4];
@@ -703,7 +704,8 @@ int mdx_build_constraints(mdx_handle* h, const mdx_system* s) {
         // every cluster a rigid three-site water in canonical order (legs from atom 0, equal masses on atoms 1 and 2, constraints
         // exactly (0,1), (0,2), (1,2)): the solvers then run their RIGID3 flavour
         h->cons_all_rigid3 = !groups.empty();
-        for (const ConsGroup& g : groups) {
+        h->n_wstep_groups = 0;
+        for (ConsGroup& g : groups) {
             bool ok = g.natoms == 3 && g.ncons == 3;
             float l01 = 0.f, l02 = 0.f, l12 = 0.f;
             for (uint32_t c = 0; ok && c < 3; ++c) {
@@ -717,8 +719,10 @@ int mdx_build_constraints(mdx_handle* h, const mdx_system* s) {
                                  !(h->flags[a2] & (MDX_ATOM_STATIC | MDX_ATOM_GHOST));
                 ok = mob && s->mass[a1] == s->mass[a2] && s->mass[a0] > 0.f && s->mass[a1] > 0.f;
             }
-            if (!ok) { h->cons_all_rigid3 = false; break; }
+            g.wstep = ok ? 1u : 0u;      // (such a water's whole step may go through water_step_kernel)
+            if (ok) ++h->n_wstep_groups; else h->cons_all_rigid3 = false;
         }
+        h->h_groups = groups;
         for (void** q : {(void**)&h->d.cons_o, (void**)&h->d.cons_s, (void**)&h->d.cons_vir, (void**)&h->d.star_o, (void**)&h->d.star_s})
             if (*q) { (void)hipFree(*q); *q = nullptr; }
         const size_t n_all = groups.size() + stars.size();
@@ -760,6 +764,16 @@ int mdx_build_constraints(mdx_handle* h, const mdx_system* s) {
         HIP_TRY(hipMalloc((void**)&h->d.vsite_s, sizeof(VSite) * vs.size()));
         HIP_TRY(hipMemcpyAsync(h->d.vsite_o, vs.data(), sizeof(VSite) * vs.size(), hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
+    }
+    {   // what the one-pass water step covers: every site its cluster's?  every atom of the handle?
+        std::vector<int> wcl(N, -1);
+        for (size_t gi = 0; gi < h->h_groups.size(); ++gi)
+            if (h->h_groups[gi].wstep) for (uint32_t k = 0; k < 3; ++k) wcl[h->h_groups[gi].atom[k]] = (int)gi;
+        h->wstep_sites_all = true;
+        for (const VSite& v : h->h_vsites)
+            if (!(wcl[v.p0] >= 0 && wcl[v.p0] == wcl[v.p1] && wcl[v.p0] == wcl[v.p2])) h->wstep_sites_all = false;
+        h->wstep_all = h->n_wstep_groups != 0 && h->n_wstep_groups == h->n_groups && h->n_star5 == 0 && h->wstep_sites_all &&
+                       h->n_mobile == 3u * h->n_wstep_groups && N == h->n_mobile + h->n_vsites;
     }
     {   // does every excluded pair lie inside one rigid three-site cluster (site included)?  (mdx_step: such corrections change nothing
         // the constraints do not undo, and the step loop of a rigid-water box leaves them to the force calls whose result is read)
@@ -810,7 +824,40 @@ int mdx_build_constraints(mdx_handle* h, const mdx_system* s) {
     return MDX_OK;
 }
 
+// mixed systems: bit 4 of wstep_s[slot] <=> the slot is a member (or the site) of a rigid water that water_step_kernel steps
+__global__ void mark_wstep_kernel(uint32_t n, const ConsGroup* __restrict__ gs, const GroupSite* __restrict__ ss, const uint32_t* __restrict__ n_dev,
+                                  uint8_t* __restrict__ wstep_s) {
+    if (n_dev) n = min(n, *n_dev);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const ConsGroup g = gs[i];
+    if (!g.wstep || g.natoms != 3) return;
+    for (int k = 0; k < 3; ++k) if (g.atom[k] != MDX_INVALID) wstep_s[g.atom[k]] = 4u;
+    if (ss) { const GroupSite v = ss[i]; if (v.on && v.site != MDX_INVALID) wstep_s[v.site] = 4u; }
+}
+static int mark_wstep_slots(mdx_handle* h) {
+    DeviceState& d = h->d;
+    if (!h->n_wstep_groups || h->wstep_all || h->dd || h->n_local != h->N) return MDX_OK;
+    const uint32_t need = h->cap_tiles * MDX_TILE;
+    if (d.cap_wstep < need) {
+        if (d.wstep_s) (void)hipFree(d.wstep_s);
+        d.wstep_s = nullptr; d.cap_wstep = 0;
+        HIP_TRY(hipMalloc((void**)&d.wstep_s, need));
+        d.cap_wstep = need;
+    }
+    HIP_TRY(hipMemsetAsync(d.wstep_s, 0, need, h->stream));
+    hipLaunchKernelGGL(mark_wstep_kernel, dim3(div_up(h->n_groups, 256)), dim3(256), 0, h->stream, h->n_groups, d.cons_s,
+                       (const GroupSite*)(h->vsites_in_groups ? d.gsite_s : nullptr), d.cons_n_dev, d.wstep_s);
+    HIP_TRY(hipGetLastError());
+    return MDX_OK;
+}
+
+static int remap_constraints_impl(mdx_handle* h);
 int mdx_remap_constraints(mdx_handle* h) {
+    MDX_TRY(remap_constraints_impl(h));
+    return mark_wstep_slots(h);
+}
+static int remap_constraints_impl(mdx_handle* h) {
     static const bool sort_env = [] { const char* e = std::getenv("MDX_CONS_SORT"); return !(e && e[0] == '0'); }();   // A/B knob
     DeviceState& d = h->d;
     const uint8_t* const sf = (h->dd || h->n_local != h->N) ? d.slot_flags : nullptr;
@@ -854,7 +901,7 @@ int mdx_remap_constraints(mdx_handle* h) {
 }
 
 int mdx_launch_constrain_positions(mdx_handle* h, float dt, const uint32_t* d_gate, uint32_t* d_disp_out, uint32_t thr,
-                                   uint32_t* d_prune_out) {
+                                   uint32_t* d_prune_out, bool skip_wstep) {
     if (!mdx_has_constraints(h)) return MDX_OK;
     if (!h->dual_on) d_prune_out = nullptr;
     ConsParams cp = cons_params(h);
@@ -871,7 +918,7 @@ int mdx_launch_constrain_positions(mdx_handle* h, float dt, const uint32_t* d_ga
                        h->d.cons_s, h->d.posq, h->d.vel, h->d.ref, dt, cp,
                        dt != 0.f ? h->d.cons_vir : nullptr,   // a dt = 0 projection (new coordinates, rescaled box) keeps the last step's virial
                        d_gate, d_disp_out, thr, d_prune_out, 0.5f * h->inner_skin * (1.0f - 1.0e-4f), h->d.cons_n_dev,
-                       (const GroupSite*)(h->vsites_in_groups ? h->d.gsite_s : nullptr));
+                       (const GroupSite*)(h->vsites_in_groups ? h->d.gsite_s : nullptr), skip_wstep ? 1u : 0u);
     if (h->vsites_in_groups) h->vsites_fresh = true;
     HIP_TRY(hipGetLastError());
     return MDX_OK;
@@ -926,7 +973,7 @@ __global__ __launch_bounds__(128) void water_step_kernel(uint32_t n_groups, cons
     float d2max = 0.f, pmax = 0.f;
     if (g < n_groups) {
         const ConsGroup cg = groups[g];
-        if (cg.natoms == 3) {
+        if (cg.natoms == 3 && cg.wstep) {
             GroupSite gv{}; gv.site = MDX_INVALID;
             if (gsite) gv = gsite[g];
             const bool have_site = gv.on && gv.site != MDX_INVALID;
@@ -1039,11 +1086,13 @@ __global__ __launch_bounds__(128) void water_step_kernel(uint32_t n_groups, cons
 // other atom the virtual site of such a cluster, velocity Verlet, one device)
 bool mdx_water_step_ok(const mdx_handle* h) {
     static const bool on = [] { const char* e = std::getenv("MDX_WATER_STEP"); return !(e && e[0] == '0'); }();
-    static const bool rigid3_env = [] { const char* e = std::getenv("MDX_CONS_RIGID3"); return !(e && e[0] == '0'); }();
-    return on && rigid3_env && h->integrator == MDX_INTEGRATOR_VERLET_VELOCITY && h->n_groups != 0 && h->cons_all_rigid3 && h->n_star5 == 0 &&
-           (h->n_vsites == 0 || h->vsites_in_groups) && h->n_mobile == 3u * h->n_groups && h->N == h->n_mobile + h->n_vsites &&
+    static const bool mixed_on = [] { const char* e = std::getenv("MDX_WATER_STEP_MIXED"); return !(e && e[0] == '0'); }();
+    return on && h->integrator == MDX_INTEGRATOR_VERLET_VELOCITY && h->n_wstep_groups != 0 && (h->wstep_all || mixed_on) &&
            !h->dd && h->n_local == h->N && mdx_nb_variant(h) >= 2;
 }
+// ... with other mobile atoms / clusters beside the waters (a solute in rigid water - what the reference's users run): those keep
+// integrate_kernel (which then skips the waters' slots: d.wstep_s) and the cluster solvers (which skip the waters' records)
+bool mdx_water_step_mixed(const mdx_handle* h) { return !h->wstep_all; }
 
 // mode 0: opening half kick + drift, 1: full kick + drift (mdx_launch_integrate's modes); then SETTLE and the site, all in one launch
 int mdx_launch_water_step(mdx_handle* h, int mode, float dt, const uint32_t* d_gate, uint32_t* d_disp_out, uint32_t thr, uint32_t* d_prune_out) {
@@ -1054,6 +1103,7 @@ int mdx_launch_water_step(mdx_handle* h, int mode, float dt, const uint32_t* d_g
     h->vsite_spread_pending = false;
     const GroupSite* const gs = h->vsites_in_groups ? (const GroupSite*)h->d.gsite_s : nullptr;
     const dim3 g(div_up(h->n_groups, 128)), b(128);
+    if (!h->wstep_all && !h->d.wstep_s) FAIL(MDX_EDEVICE, "internal: the slots of the rigid waters are not marked");
     mdx_prof_begin(h, 2);
     if (mode == 1)
         hipLaunchKernelGGL(water_step_kernel<1>, g, b, 0, h->stream, h->n_groups, h->d.cons_s, gs, h->d.posq, h->d.vel, h->d.force, h->d.ref, dt, cp,
@@ -1062,8 +1112,10 @@ int mdx_launch_water_step(mdx_handle* h, int mode, float dt, const uint32_t* d_g
         hipLaunchKernelGGL(water_step_kernel<0>, g, b, 0, h->stream, h->n_groups, h->d.cons_s, gs, h->d.posq, h->d.vel, h->d.force, h->d.ref, dt, cp,
                            h->d.cons_vir, d_gate, d_disp_out, thr, d_prune_out, 0.5f * h->inner_skin * (1.0f - 1.0e-4f), h->d.cons_n_dev, spread, zero);
     mdx_prof_end(h);
-    if (zero) h->force_zeroed = true;
-    if (h->vsites_in_groups) h->vsites_fresh = true;
+    ++h->water_step_launches;
+    if (!h->wstep_all) ++h->water_step_mixed_launches;
+    if (zero && h->wstep_all) h->force_zeroed = true;      // (mixed systems: integrate_kernel clears the other slots and says so)
+    if (h->vsites_in_groups && h->wstep_sites_all) h->vsites_fresh = true;
     HIP_TRY(hipGetLastError());
     return MDX_OK;
 }

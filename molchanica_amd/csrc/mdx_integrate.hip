@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void integrate_kernel(uint32_t S, float dt, fl
                                                         float4* __restrict__ vel, float4* __restrict__ force,
                                                         float4* __restrict__ ref, const uint32_t* gate_in,
                                                         uint32_t* disp_out, uint32_t thr_bits, LangevinArgs lg,
-                                                        uint32_t* prune_out, float path_thr) {
+                                                        uint32_t* prune_out, float path_thr, const uint8_t* __restrict__ skip) {
     const uint32_t gate = gate_in ? *gate_in : 0u;
     if (gate > thr_bits) {  // list already stale: stay a no-op, keep the flag raised
         if (MODE != 2 && blockIdx.x == 0 && threadIdx.x == 0) atomicMax(disp_out, gate);
@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void integrate_kernel(uint32_t S, float dt, fl
     }
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     float d2 = 0.f, path = 0.f;
-    if (s < S) {
+    // (skip: a solute in rigid water - the waters' slots went through water_step_kernel this step, force cleared and all)
+    if (s < S && !(skip && (skip[s] & 4u))) {
         float4 v = vel[s];
         if (v.w != 0.f) {   // w = 418.4/m; 0 marks static, ghost and dummy slots
             const float4 f = force[s];
@@ -250,7 +251,8 @@ __global__ __launch_bounds__(256) void kinetic_kernel(uint32_t S, const float4* 
 }
 
 int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_gate_in, uint32_t* d_disp_out,
-                         uint32_t thr_bits, uint32_t* d_prune_out) {
+                         uint32_t thr_bits, uint32_t* d_prune_out, bool skip_wstep) {
+    const uint8_t* const skip = (skip_wstep && mode != 2) ? h->d.wstep_s : nullptr;
     const dim3 g((h->S + 255) / 256), b(256);
     DeviceState& d = h->d;
     if (mode != 2) h->vsites_fresh = false;      // a drift: the virtual sites follow at the next position stage / construct launch
@@ -270,11 +272,11 @@ int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_ga
 #define INTEG(M)                                                                                                      \
     do {                                                                                                              \
         if (dual) hipLaunchKernelGGL((integrate_kernel<M, true, true>), g, b, 0, h->stream, h->S, dt, d.posq, d.vel, d.force, \
-                                     d.ref, d_gate_in, d_disp_out, thr_bits, lg, d_prune_out, path_thr);              \
+                                     d.ref, d_gate_in, d_disp_out, thr_bits, lg, d_prune_out, path_thr, skip);        \
         else if (zero) hipLaunchKernelGGL((integrate_kernel<M, true, false>), g, b, 0, h->stream, h->S, dt, d.posq, d.vel, d.force, \
-                                     d.ref, d_gate_in, d_disp_out, thr_bits, lg, nullptr, 0.f);                       \
+                                     d.ref, d_gate_in, d_disp_out, thr_bits, lg, nullptr, 0.f, skip);                 \
         else hipLaunchKernelGGL((integrate_kernel<M, false, false>), g, b, 0, h->stream, h->S, dt, d.posq, d.vel, d.force,  \
-                                d.ref, d_gate_in, d_disp_out, thr_bits, lg, nullptr, 0.f);                            \
+                                d.ref, d_gate_in, d_disp_out, thr_bits, lg, nullptr, 0.f, skip);                      \
     } while (0)
     switch (mode) {
     case 0: INTEG(0); break;

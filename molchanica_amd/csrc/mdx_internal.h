@@ -140,7 +140,9 @@ struct __attribute__((aligned(16))) ConsGroup {
     float    len[6];
     uint8_t  ca[6], cb[6]; // constraint k ties local atoms ca[k], cb[k]
     uint32_t ncons, natoms;
+    uint32_t wstep;        // 1: a rigid three-site water whose whole step is water_step_kernel's (mdx_constraints.hip); fills the record's 64 bytes
 };
+static_assert(sizeof(ConsGroup) == 64, "ConsGroup is one 64-byte record");
 // A heavy atom with FOUR constrained hydrogens (ammonium, methane, silane ...: X-H4) - the one cluster shape beyond four atoms that
 // "constrain the bonds to hydrogens" (HydrogenConstraint, /root/reference src/ui/panels/md.rs:362-371) produces: a star, atom[0] its
 // centre, len[k] the length of the bond to atom[k + 1].  Its own record and its own small kernels: the 64-byte ConsGroup that a
@@ -229,6 +231,7 @@ struct DeviceState {
     float* cons_vir = nullptr;     // per constraint cluster: r . G of the last SHAKE position stage (kcal/mol); the X-H4 stars behind the others
     ConsStar5* star_o = nullptr; ConsStar5* star_s = nullptr;
     VSite* vsite_o = nullptr; VSite* vsite_s = nullptr;
+    uint8_t* wstep_s = nullptr; uint32_t cap_wstep = 0;     // [slots] bit 4: the slot is stepped by water_step_kernel (mixed systems: integrate_kernel skips it)
     GroupSite* gsite_o = nullptr; GroupSite* gsite_s = nullptr; GroupSite* gsite_tmp = nullptr;   // per constraint cluster (null: no cluster carries its site)
     // control / reductions
     StepCtl* ctl = nullptr;
@@ -281,6 +284,10 @@ struct mdx_handle {
     uint32_t n_star5 = 0; std::vector<ConsStar5> h_star5;   // X-H4 clusters (caller order)
     bool cons_all_rigid3 = false;    // every constraint cluster is a rigid three-site water: the solvers' register-only flavour
     bool vsites_in_groups = false;   // every virtual site is placed by its parents' constraint cluster (GroupSite)
+    uint32_t water_step_launches = 0, water_step_mixed_launches = 0;      // (diagnostics: mdx_pair_launch_info)
+    uint32_t n_wstep_groups = 0;          // rigid three-site water clusters the one-pass step kernel may take (ConsGroup::wstep)
+    bool wstep_all = false;               // ... and they (with their sites) are every atom of the handle: nothing else to integrate or constrain
+    bool wstep_sites_all = false;         // every virtual site belongs to such a cluster: the sites' forces can be left to that kernel
     bool vsite_spread_deferred = false;   // step loop, rigid-water boxes: the force call being enqueued leaves the sites' forces to the next water_step_kernel ...
     bool vsite_spread_pending = false;    // ... and has done so: that kernel spreads them
     bool vsites_fresh = false;       // ... and the last position stage did so: the next force call has nothing to construct
@@ -455,7 +462,7 @@ int mdx_launch_add_ext(mdx_handle* h, const uint32_t* d_gate, uint32_t thr_bits)
 // integration (mode: 0 = half kick + drift, 1 = full kick + drift (also: one leapfrog step), 2 = closing half
 // kick, 3 = one Langevin-middle step: full kick, half drift, friction + noise, half drift)
 int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_gate_in,
-                         uint32_t* d_disp_out, uint32_t thr_bits, uint32_t* d_prune_out = nullptr);
+                         uint32_t* d_disp_out, uint32_t thr_bits, uint32_t* d_prune_out = nullptr, bool skip_wstep = false);
 // one pass for the bonded gather of step s-1's positions, the full kick and the drift of step s (velocity Verlet inside a
 // chunk, no constraints / virtual sites / SPME / external forces, one lane per atom): reads posq, writes posq_alt, swaps
 bool mdx_bonded_integrate_ok(const mdx_handle* h);
@@ -518,9 +525,10 @@ static inline int mdx_nb_wpt_half(const mdx_handle* h, uint32_t T) { return mdx_
 int mdx_build_constraints(mdx_handle* h, const mdx_system* s);
 int mdx_remap_constraints(mdx_handle* h);                  // caller order -> slot order, at every rebuild
 int mdx_launch_constrain_positions(mdx_handle* h, float dt, const uint32_t* d_gate, uint32_t* d_disp_out, uint32_t thr,
-                                   uint32_t* d_prune_out = nullptr);
+                                   uint32_t* d_prune_out = nullptr, bool skip_wstep = false);
 int mdx_launch_constrain_velocities(mdx_handle* h, const uint32_t* d_gate, uint32_t thr);
-bool mdx_water_step_ok(const mdx_handle* h);               // a box of rigid water: spread + kick + drift + SETTLE + site placement as ONE pass per step
+bool mdx_water_step_ok(const mdx_handle* h);
+bool mdx_water_step_mixed(const mdx_handle* h);          // ... beside other mobile atoms / clusters: they keep integrate_kernel and the cluster solvers               // a box of rigid water: spread + kick + drift + SETTLE + site placement as ONE pass per step
 int mdx_launch_water_step(mdx_handle* h, int mode, float dt, const uint32_t* d_gate, uint32_t* d_disp_out, uint32_t thr, uint32_t* d_prune_out);
 int mdx_launch_vsite_construct(mdx_handle* h, const uint32_t* d_gate, uint32_t thr);
 int mdx_launch_constraint_virial(mdx_handle* h);

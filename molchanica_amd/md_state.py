@@ -470,7 +470,8 @@ class MdState:
         _check(load_library().mdx_pair_launch_info(self._h, out))
         keys = ("waves_per_tile", "dual", "half", "coulomb", "energy", "workgroups_per_tile", "bonded_workgroups", "tiles")
         return {"step": dict(zip(keys, (int(v) for v in out[0:8]))), "any": dict(zip(keys, (int(v) for v in out[8:16]))),
-                "inner_lists_from_rebuilds": int(out[16]), "last_rebuild_wrote_the_inner_list": bool(out[17])}
+                "inner_lists_from_rebuilds": int(out[16]), "last_rebuild_wrote_the_inner_list": bool(out[17]),
+                "water_step_launches": int(out[18]), "water_step_mixed_launches": int(out[19])}
 
     def skin(self):
         """-> (Verlet skin in force, still tuning?)  (MdConfig.skin == 0 lets the library choose it)."""

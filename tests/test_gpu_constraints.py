@@ -2,6 +2,7 @@
 default operating point: dt = 2 fs, constrained hydrogens, 4-site OPC water
 (/root/reference src/prefs/mod.rs:203; src/ui/panels/md.rs:362-371; sol_shrinking_box.rs:605-613)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -52,6 +53,8 @@ def test_rigid_water_parity_at_2fs(mdx, orc, model, monkeypatch):
         b = s.constraint_idx.astype(int)
         assert bond_errors(s, x0).max() < 3e-5
         md.step(0.002, None, 50)                       # the reference's default dt (src/prefs/mod.rs:203)
+        if os.environ.get("MDX_WATER_STEP", "1") != "0":     # round 6: every step of a rigid-water box is ONE pass (water_step_kernel)
+            assert md.pair_launch_info()["water_step_launches"] == 50
         x, v = md.positions().astype(np.float64), md.velocities().astype(np.float64)
         assert bond_errors(s, x).max() < 3e-5, "constraints drifted"
         d = x[b[:, 0]] - x[b[:, 1]]
@@ -415,3 +418,58 @@ def test_five_atom_cluster_that_is_not_a_star_is_rejected(mdx):
         pytest.skip("the generator's first four bonds happen to form a star")
     with pytest.raises(mdx.ParamError, match="cluster"):
         mdx.MdState(s, MdConfig(lj_cutoff=0, coulomb_cutoff=0))
+
+
+def _chain_in_rigid_water(flexible=0):
+    """A flexible chain with its X-H bonds constrained (HydrogenConstraint::Shake) in RIGID three-site water - what the reference's
+    users run (solute + rigid water, /root/reference src/ui/panels/md.rs:362-371); the first `flexible` waters keep their bonds and
+    angles instead (mobile atoms that belong to no cluster, like any unconstrained part of a solute)."""
+    s = systems.small_solvated(n_chain=160, box=30.0)
+    n_sol = int(s.mol_start[1])
+    n_keep = n_sol + 3 * flexible                                            # atoms below this index keep their bonded terms
+    t = systems.TIP3P
+    nw = (s.n_atoms - n_sol) // 3
+    keep_b = (s.bond_idx < n_keep).all(1)
+    keep_a = (s.angle_idx < n_keep).all(1)
+    h_side = np.nonzero(s.lj_type == 3)[0]
+    is_h = np.zeros(s.n_atoms, bool); is_h[h_side] = True
+    xh = (s.bond_idx < n_sol).all(1) & (is_h[s.bond_idx[:, 0]] | is_h[s.bond_idx[:, 1]])
+    base = n_sol + 3 * np.arange(flexible, nw, dtype=np.int64)
+    hh = 2 * t["r_oh"] * math.sin(t["theta"] / 2)
+    wc = np.stack([np.stack([base, base + 1], 1), np.stack([base, base + 2], 1), np.stack([base + 1, base + 2], 1)], 1).reshape(-1, 2)
+    s.constraint_idx = np.concatenate([s.bond_idx[xh].astype(np.int64), wc]).astype(np.uint32)
+    s.constraint_len = np.concatenate([s.bond_r0[xh], np.tile([t["r_oh"], t["r_oh"], hh], len(base))]).astype(np.float32)
+    keep_b &= ~xh
+    s.bond_idx, s.bond_k, s.bond_r0 = s.bond_idx[keep_b], s.bond_k[keep_b], s.bond_r0[keep_b]
+    s.angle_idx, s.angle_k, s.angle_theta0 = s.angle_idx[keep_a], s.angle_k[keep_a], s.angle_theta0[keep_a]
+    return s, n_sol
+
+
+@pytest.mark.parametrize("flexible", [0, 12])
+def test_solute_in_rigid_water_one_pass_for_the_waters(mdx, orc, flexible):
+    """Mixed system: the rigid waters go through water_step_kernel, the solute (and free atoms) through integrate_kernel - which skips
+    the waters' slots - and its X-H clusters through the general solver - which skips the waters' records.  Against the oracle."""
+    s, n_sol = _chain_in_rigid_water(flexible)
+    cfg = MdConfig(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, coulomb_mode=1)
+    with mdx.MdState(s, cfg) as md:
+        md.forces()
+        x0, v0 = md.positions().astype(np.float64), md.velocities().astype(np.float64)
+        assert bond_errors(s, x0).max() < 3e-5
+        for burst in (1, 9, 16, 14):
+            md.step(0.001, None, burst)
+        x = md.positions().astype(np.float64)
+        assert bond_errors(s, x).max() < 3e-5
+        f = md.forces().astype(np.float64)                      # what the step loop left behind: complete
+        fo, _ = orc.forces(s, cfg, pos=x, use_cells=True)
+        err = np.linalg.norm(f - fo, axis=1)
+        tol = 1e-4 * np.maximum(np.linalg.norm(fo, axis=1), 1.0) + orc.cutoff_slack(s, cfg, pos=md.positions())
+        assert (err <= tol).all(), float((err / tol).max())
+        assert md.stats()["rebuild_count"] >= 2
+        info = md.pair_launch_info()
+        if os.environ.get("MDX_WATER_STEP_MIXED", "1") != "0" and os.environ.get("MDX_WATER_STEP", "1") != "0":
+            assert info["water_step_mixed_launches"] == 40, info
+    xo, vo, _ = orc.step(s, cfg, 0.001, 40, pos=x0, vel=v0, use_cells=True)
+    L = np.array(s.box_hi)
+    d = x - xo
+    d -= np.round(d / L) * L
+    assert math.sqrt((d ** 2).sum(1).mean()) < 2e-3
