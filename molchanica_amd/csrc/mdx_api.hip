@@ -824,6 +824,10 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         for (uint32_t s = 0; s < chunk; ++s)
             if (h->h_ctl->disp2[s + 1] > thr) { first_stale = (int)s; break; }
         if (h->profile) mdx_prof_collect(h, first_stale);
+        static const bool dbg_stale = [] { const char* e = std::getenv("MDX_DEBUG_STALE"); return e && e[0] == '1'; }();
+        if (dbg_stale && first_stale < (1 << 30))
+            std::fprintf(stderr, "[mdx] list stale at step %d of a chunk of %u (step count %llu): word %.4g against (skin / 2)^2 = %.4g%s\n", first_stale, chunk,
+                         (unsigned long long)h->step_count, (double)u2f(h->h_ctl->disp2[first_stale + 1]), (double)u2f(thr), h->dd ? " [decomposed]" : "");
         for (uint32_t s = 0; s < chunk; ++s) {
             if (h->h_ctl->disp2[s + 1] > thr) {
                 // (fused bonded + kick + drift passes swap the two position buffers at every enqueued step, the gated-off

@@ -765,16 +765,6 @@ int mdx_build_constraints(mdx_handle* h, const mdx_system* s) {
         HIP_TRY(hipMemcpyAsync(h->d.vsite_o, vs.data(), sizeof(VSite) * vs.size(), hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
-    {   // what the one-pass water step covers: every site its cluster's?  every atom of the handle?
-        std::vector<int> wcl(N, -1);
-        for (size_t gi = 0; gi < h->h_groups.size(); ++gi)
-            if (h->h_groups[gi].wstep) for (uint32_t k = 0; k < 3; ++k) wcl[h->h_groups[gi].atom[k]] = (int)gi;
-        h->wstep_sites_all = true;
-        for (const VSite& v : h->h_vsites)
-            if (!(wcl[v.p0] >= 0 && wcl[v.p0] == wcl[v.p1] && wcl[v.p0] == wcl[v.p2])) h->wstep_sites_all = false;
-        h->wstep_all = h->n_wstep_groups != 0 && h->n_wstep_groups == h->n_groups && h->n_star5 == 0 && h->wstep_sites_all &&
-                       h->n_mobile == 3u * h->n_wstep_groups && N == h->n_mobile + h->n_vsites;
-    }
     {   // does every excluded pair lie inside one rigid three-site cluster (site included)?  (mdx_step: such corrections change nothing
         // the constraints do not undo, and the step loop of a rigid-water box leaves them to the force calls whose result is read)
         h->excl_inside_rigid = false;
@@ -820,6 +810,18 @@ int mdx_build_constraints(mdx_handle* h, const mdx_system* s) {
             HIP_TRY(hipStreamSynchronize(st));
             h->vsites_in_groups = true;
         }
+    }
+    {   // what the one-pass water step covers: every site its cluster's?  every atom of the handle?
+        std::vector<int> wcl(N, -1);
+        for (size_t gi = 0; gi < h->h_groups.size(); ++gi)
+            if (h->h_groups[gi].wstep) for (uint32_t k = 0; k < 3; ++k) wcl[h->h_groups[gi].atom[k]] = (int)gi;
+        // (the kernel reaches a site through its cluster's GroupSite record: without those - MDX_VSITE_IN_GROUPS=0, or a site whose
+        // parents are not one cluster - the sites keep their own construct / spread launches)
+        h->wstep_sites_all = h->h_vsites.empty() || h->vsites_in_groups;
+        for (const VSite& v : h->h_vsites)
+            if (!(wcl[v.p0] >= 0 && wcl[v.p0] == wcl[v.p1] && wcl[v.p0] == wcl[v.p2])) h->wstep_sites_all = false;
+        h->wstep_all = h->n_wstep_groups != 0 && h->n_wstep_groups == h->n_groups && h->n_star5 == 0 && h->wstep_sites_all &&
+                       h->n_mobile == 3u * h->n_wstep_groups && N == h->n_mobile + h->n_vsites;
     }
     return MDX_OK;
 }

@@ -388,11 +388,15 @@ static int dd_partition(mdx_handle* h) {
     if (s0 > dd->cap_send) {
         dd->cap_send = s0 + s0 / 4 + 64;
         MDX_TRY(dd_alloc(&dd->send_ids, dd->cap_send)); MDX_TRY(dd_alloc(&dd->send_buf, dd->cap_send)); MDX_TRY(dd_alloc(&dd->frc_recv, dd->cap_send));
+        // (a transport that delivers writes every row before it is read; the null transport with a stated wire time reads the rows as
+        // they are - the force call in front of the first halo exchange added whatever the allocation held to the owned atoms' forces)
+        HIP_TRY(hipMemsetAsync(dd->frc_recv, 0, sizeof(float4) * (size_t)dd->cap_send, st));
     }
     if (r0 > dd->cap_recv) {
         dd->cap_recv = r0 + r0 / 4 + 64;
         MDX_TRY(dd_alloc(&dd->recv_ids, dd->cap_recv)); MDX_TRY(dd_alloc(&dd->recv_buf, dd->cap_recv)); MDX_TRY(dd_alloc(&dd->recv_shift, dd->cap_recv));
         MDX_TRY(dd_alloc(&dd->frc_send, dd->cap_recv));
+        HIP_TRY(hipMemsetAsync(dd->recv_buf, 0, sizeof(float4) * (size_t)dd->cap_recv, st));
     }
     // the engine's own arrays are the partition's output (gid, ghost flags, positions, velocities of the local atoms in list order)
     dd->gid_local = h->d.gid; dd->ghost_local = h->d.lflag; dd->pos_l = h->d.pos_orig; dd->vel_l = h->d.vel_orig;
@@ -833,6 +837,12 @@ int mdx_dd_on_stale(mdx_handle* h) {
     if (h->n_vsites && h->in_slot_space) MDX_TRY(mdx_launch_vsite_construct(h, nullptr, 0));
     bool valid = true;
     MDX_TRY(dd_local_set_still_valid(h, &valid));
+    static const bool dbg_stale = [] { const char* e = std::getenv("MDX_DEBUG_STALE"); return e && e[0] == '1'; }();
+    if (dbg_stale) {
+        float d2; std::memcpy(&d2, &dd->spec_bits, 4);
+        std::fprintf(stderr, "[mdx] rank %d: stale list -> %s (largest drift since the partition %.4g A, margin %.3g A, %u local rebuilds since)\n", dd->rank,
+                     valid ? "local rebuild" : "repartition", (double)std::sqrt(d2), (double)dd->margin, dd->local_rebuilds_since);
+    }
     if (valid) { dd->local_rebuilds++; dd->local_rebuilds_since++; h->list_valid = false; }
     else MDX_TRY(dd_repartition(h));
     MDX_TRY(mdx_rebuild(h));

@@ -54,7 +54,7 @@ def test_rigid_water_parity_at_2fs(mdx, orc, model, monkeypatch):
         assert bond_errors(s, x0).max() < 3e-5
         md.step(0.002, None, 50)                       # the reference's default dt (src/prefs/mod.rs:203)
         if os.environ.get("MDX_WATER_STEP", "1") != "0":     # round 6: every step of a rigid-water box is ONE pass (water_step_kernel)
-            assert md.pair_launch_info()["water_step_launches"] == 50
+            assert md.pair_launch_info()["water_step_launches"] >= 50      # (enqueued launches: the ones gated off behind a stale list count too)
         x, v = md.positions().astype(np.float64), md.velocities().astype(np.float64)
         assert bond_errors(s, x).max() < 3e-5, "constraints drifted"
         d = x[b[:, 0]] - x[b[:, 1]]
@@ -151,14 +151,17 @@ def test_one_pass_water_step_against_the_three_launches(tmp_path):
     for name in ("tip3p_rigid", "opc", "opc_straddling_spme"):
         d = a[name + "_pos"].astype(np.float64) - b[name + "_pos"].astype(np.float64)
         d -= np.round(d / 24.8272) * 24.8272
-        # (60 steps at 2 fs from a 300 K start: two fp32 evaluations of the same step part at rounding level and grow apart like any two
-        # trajectories do - measured 2.2e-4 A rms; each arm is within 2e-3 A of the fp64 oracle over 50 steps in the tests above)
-        assert math.sqrt((d ** 2).sum(1).mean()) < 1e-3, (name, math.sqrt((d ** 2).sum(1).mean()))
+        # 60 steps at 2 fs from a 300 K start.  Two runs of the SAME arm already part - the half-list pair kernel's atomics land in a
+        # different order every run and the trajectories amplify that: measured over repeated runs (tools/dbg/water_ab_noise.py),
+        # same arm against itself AND arm against arm alike: positions 1.4e-4 ... 1.0e-3 A rms, velocities 1e-2 ... 7e-2 A/ps,
+        # potential 0.002 ... 0.13 kcal/mol, kinetic energy 9e-7 ... 7e-5 relative, virial 0.05 ... 0.8.  The bounds sit above that
+        # noise; what pins each arm is the fp64 oracle (2e-3 A over 50 steps in the tests above).
+        assert math.sqrt((d ** 2).sum(1).mean()) < 5e-3, (name, math.sqrt((d ** 2).sum(1).mean()))
         dv = a[name + "_vel"].astype(np.float64) - b[name + "_vel"].astype(np.float64)
-        assert math.sqrt((dv ** 2).sum(1).mean()) < 0.2, (name, math.sqrt((dv ** 2).sum(1).mean()))
+        assert math.sqrt((dv ** 2).sum(1).mean()) < 0.3, (name, math.sqrt((dv ** 2).sum(1).mean()))
         ea, eb = a[name + "_e"], b[name + "_e"]
-        assert abs(ea[0] - eb[0]) < 2e-5 * abs(ea[0]) + 0.05 and abs(ea[1] - eb[1]) < 2e-4 * ea[1], (name, ea, eb)
-        assert abs(ea[2] - eb[2]) < 2e-3 * abs(ea[2]) + 1.0, (name, "virial", ea[2], eb[2])
+        assert abs(ea[0] - eb[0]) < 2e-5 * abs(ea[0]) + 0.5 and abs(ea[1] - eb[1]) < 5e-4 * ea[1], (name, ea, eb)
+        assert abs(ea[2] - eb[2]) < 2e-3 * abs(ea[2]) + 3.0, (name, "virial", ea[2], eb[2])
         assert a[name + "_rebuilds"][0] >= 3
         if name.startswith("opc"):
             assert np.abs(b[name + "_frc"][3::4]).max() == 0.0, "a virtual site must not keep a force"
@@ -467,7 +470,7 @@ def test_solute_in_rigid_water_one_pass_for_the_waters(mdx, orc, flexible):
         assert md.stats()["rebuild_count"] >= 2
         info = md.pair_launch_info()
         if os.environ.get("MDX_WATER_STEP_MIXED", "1") != "0" and os.environ.get("MDX_WATER_STEP", "1") != "0":
-            assert info["water_step_mixed_launches"] == 40, info
+            assert info["water_step_mixed_launches"] >= 40, info
     xo, vo, _ = orc.step(s, cfg, 0.001, 40, pos=x0, vel=v0, use_cells=True)
     L = np.array(s.box_hi)
     d = x - xo

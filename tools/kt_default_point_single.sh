@@ -42,8 +42,16 @@ row("pme_gather_brick_kernel", "pme_gather_brick_kernel", charged * (28 + 16) + 
 row("pme_solve_kernel", "pme_solve_kernel", cplx * (4 + 16), "theta 4 B + complex RW 16 B per point of the half-complex mesh")
 pitch = (K // 2 + 1 + 15) // 16 * 16
 row("pme_xpass_solve_kernel", "pme_xpass_solve_kernel", K * K * pitch * (4 + 16), "x transform + solve + inverse x transform in one trip: theta 4 B + complex RW 16 B per point of the padded half-complex mesh")
+# rocFFT's passes of the batched 2-D (y, z) transforms, in the bytes they move: the z pass is real <-> half-complex (K^3 x 4 B on the
+# real side, K^2 x pitch x 8 B on the complex side; rocFFT runs it as a complex transform of length K / 2), the y pass a complex
+# transform of length K in place on the half-complex mesh (K^2 x pitch x 8 B read and written)
 for k in sorted(fk):
-    row(k[:34], k, 2 * 8 * pts, "2 x 8 B x K^3 per pass (the verdict's convention; the half-complex data is half of that)")
+    m = re.search(r"len(\d+)", k)
+    n = int(m.group(1)) if m else 0
+    if n == K // 2: row(k[:34], k, pts * 4 + K * K * pitch * 8, "z pass, real <-> half-complex: K^3 x 4 B + K^2 x pitch x 8 B")
+    elif n == K: row(k[:34], k, 2 * K * K * pitch * 8, "y pass, in place on the half-complex mesh: 2 x K^2 x pitch x 8 B")
+    else: row(k[:34], k, 2 * K * K * pitch * 8, "a pass over the half-complex mesh: 2 x K^2 x pitch x 8 B")
+row("water_step_kernel", "water_step_kernel", (sites // 4) * 496, "per rigid water: cluster + site records 80 B, posq / vel / force / ref rows of O, H, H (+ M) read once and written once: 496 B")
 row("constrain_positions_kernel (SETTLE)", "constrain_positions_kernel", (sites // 4) * 3 * (32 + 32 + 16), "3 constrained atoms per water: pos RW, vel RW, ref R")
 row("bonded_gather_kernel (Ewald excl.)", "bonded_gather_kernel", sites * (36 + 16 * 3), "36 B + 16 B x ~3 roles per site")
 PY
