@@ -553,7 +553,7 @@ typedef struct mdx_comm_diag {
     int32_t  comm_stream_separate;   /* 1: RCCL calls on their own stream (MDX_COMM_STREAM=1) */
     int32_t  wire_ns_measured;       /* one send/recv group of a typical halo message, measured when the handle joined (largest over the
                                       * ranks), in ns; -1: not measured (MDX_HALF_SHELL pinned, or a transport without a wire).  It decides
-                                      * half_shell: two messages per step pay below ~4 us per message only */
+                                      * half_shell: two messages per step pay below ~8 us per message only */
     uint32_t n_owned, n_ghost, n_tiles, n_interior_tiles;
     uint32_t halo_rows_out, halo_rows_in;     /* float4 rows per position message, flag rows included */
     uint64_t halo_bytes_per_step;    /* positions out + in, plus the force rows back and forth with the half shell */

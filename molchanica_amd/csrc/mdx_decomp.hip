@@ -1095,7 +1095,9 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
         // message (profiles/r06_one_rank_of_N.txt; step in ms, half / full): 8 ranks 0.132 / 0.141 at 0 us, 0.149 / 0.142 at 5,
         // 0.162 / 0.148 at 10, 0.208 / 0.173 at 25, 0.272 / 0.196 at 50; 4 ranks 0.200 / 0.219 at 0, 0.259 / 0.249 at 25; 2 ranks
         // 0.330 / 0.335 at 0, 0.395 / 0.365 at 25 - a microsecond of message time costs the half shell 2.4-3.0 us of step, the full
-        // shell 1.2-1.3: they cross at ~4 us per message (16 us on four ranks).  So a transport whose message time means something
+        // shell 1.2-1.3: they cross at ~4 us per message (16 us on four ranks) in that session and at ~10 us in a second one (the half
+        // shell's step varies more from box to box: 0.122-0.132 ms at 0 us, 0.184-0.208 at 25; the full shell's does not).  The crossing
+        // is taken at 8 us (16 on four ranks).  So a transport whose message time means something
         // is measured here, once (every rank takes the largest value any rank saw: the choice is part of the partition), and the
         // half shell stays only below that crossing.  Half shell needs Newton's third law across the rank boundary: the half-list
         // pair kernel.  MDX_HALF_SHELL=0 / 1 pins the choice; MDX_HALF_SHELL_WIRE_US moves the crossing.
@@ -1105,7 +1107,7 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
         else if (hs && tr->wire_time_decides()) {
             if (dd_measure_wire_us(tr, h->stream, &dd->wire_us) != MDX_OK) return bail(MDX_EDEVICE);
             const char* t = std::getenv("MDX_HALF_SHELL_WIRE_US");
-            const float crossing = t ? (float)std::atof(t) : (dd->world == 4 ? 16.f : 4.f);
+            const float crossing = t ? (float)std::atof(t) : (dd->world == 4 ? 16.f : 8.f);
             hs = dd->wire_us < crossing;
         }
         dd->half_shell = hs;

@@ -2,6 +2,7 @@
 README.md:236-240): rigid 4-site OPC water (SHAKE/RATTLE + M virtual site), dt = 2 fs, SPME, CSVR thermostat - on a
 1,048,576-site box (64^3 waters), next to the flexible cutoff box the headline metric is quoted on."""
 import os, sys, time
+if os.environ.get("DP_IMPORT_TORCH") == "1": import torch      # (A/B: bench.py's process has PyTorch's bundled HIP runtime loaded)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from molchanica_amd import systems, MdConfig
 from molchanica_amd.md_state import MdState
