@@ -1154,7 +1154,11 @@ int mdx_dd_attach(mdx_handle* h, MdxTransport* tr) {
     DD_HIP(hipMemcpyAsync(dd->g_vel, h->d.vel_orig, sizeof(float4) * N, hipMemcpyDeviceToDevice, h->stream));
     {   // the drift pass of a decomposed step carries the halo pack and the add of the returned ghost forces (MDX_HALO_FOLD=0: A/B)
         const char* f = std::getenv("MDX_HALO_FOLD");
-        dd->fold_ok = dd->world > 1 && dd->half_shell && dd->comm_stream == h->stream && !(f && f[0] == '0');
+        // (round 6: with the full shell the pass would only pack - no ghost forces come back; built, agrees (fuzz), measured SLOWER than the
+        // pack kernel it saves - rank 0 of 8: 0.140 against 0.135 ms at 0 us per message, 0.171 against 0.163 at 25 - so it stays behind
+        // MDX_HALO_FOLD_FULL_SHELL=1)
+        static const bool fold_full = [] { const char* x = std::getenv("MDX_HALO_FOLD_FULL_SHELL"); return x && x[0] == '1'; }();
+        dd->fold_ok = dd->world > 1 && (dd->half_shell || fold_full) && dd->comm_stream == h->stream && !(f && f[0] == '0');
     }
     h->want_tile_split = dd->world > 1 && (dd->overlap || dd->tune_phase < 2);
     if (h->pme_on) {   // the reciprocal-space chain of a decomposed handle runs on the handle's own stream (mesh all-reduce inside)
