@@ -146,7 +146,7 @@ static void free_device(mdx_handle* h) {
                     d.tile_col, d.scan_tmp, d.cl_lo, d.cl_hi, d.cl_kind, d.list_counts, d.entry_cnt, d.entry_off,
                     d.mchunk_cnt, d.mchunk_off, d.entries, d.entries_in, d.inner_nch, d.list_cursors, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
                     d.role_off_s, d.role_rec_s, d.role_prm, d.ctl, d.energy,
-                    d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.pme_force, d.wstep_s, d.cons_o, d.cons_s, d.cons_tmp, d.cons_mask, d.cons_cnt, d.cons_off, d.cons_vir, d.vsite_o, d.vsite_s, d.gsite_o, d.gsite_s, d.gsite_tmp, d.pme_q, d.pme_f,
+                    d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.pme_force, d.wstep_s, d.path, d.dprune, d.cons_o, d.cons_s, d.cons_tmp, d.cons_mask, d.cons_cnt, d.cons_off, d.cons_vir, d.vsite_o, d.vsite_s, d.gsite_o, d.gsite_s, d.gsite_tmp, d.pme_q, d.pme_f,
                     d.pme_theta, d.pme_q2, d.pme_f2, d.scratch4, d.tile_bnd, d.tile_scan, d.tile_order, d.tile_lpt, d.rb_ctl, d.scan_chain, d.grp, d.grp_mat, d.star_o, d.star_s, d.ewald_tab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = DeviceState{};
@@ -383,6 +383,11 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
     MDX_TRY(mdx_build_constraints(h, s));
     MDX_TRY(mdx_build_ewald_table(h));
     h->cons_dirty = mdx_has_constraints(h);
+    {   // path split (DeviceState): handles whose atoms only the drift passes (and, decomposed, the halo unpack) move - the
+        // constraint solvers and the one-pass water step keep the accumulator in ref[].w.  MDX_PATH_SPLIT=0: A/B
+        const char* e = std::getenv("MDX_PATH_SPLIT");
+        h->path_split = !mdx_has_constraints(h) && h->n_vsites == 0 && !(e && e[0] == '0');
+    }
     MDX_TRY(mdx_pme_setup(h));
     MDX_TRY(mdx_rebuild(h));
     return MDX_OK;
@@ -1469,7 +1474,7 @@ __global__ void unpack_pos_kernel(uint32_t n, const uint32_t* __restrict__ atom_
                                   float4* __restrict__ posq, const float4* __restrict__ in,
                                   const float4* __restrict__ shift, uint32_t* __restrict__ flag_word,
                                   float4* __restrict__ ref, uint32_t* __restrict__ prune_out, float path_thr,
-                                  float gx, float gy, float gz) {
+                                  float gx, float gy, float gz, float* __restrict__ path_arr) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t g = atom_idx[i];
@@ -1493,8 +1498,9 @@ __global__ void unpack_pos_kernel(uint32_t n, const uint32_t* __restrict__ atom_
     if (gz > 0.f) v.z -= gz * rintf((v.z - p.z) / gz);
     if (ref) {
         const float mx = v.x - p.x, my = v.y - p.y, mz = v.z - p.z;
-        const float w = ref[s].w + sqrtf(mx * mx + my * my + mz * mz);
-        ref[s].w = w;
+        const float mv = sqrtf(mx * mx + my * my + mz * mz);
+        float w;
+        if (path_arr) { w = path_arr[s] + mv; path_arr[s] = w; } else { w = ref[s].w + mv; ref[s].w = w; }
         if (!(w <= path_thr)) *prune_out = 1u;   // idempotent, rare
     }
     p.x = v.x; p.y = v.y; p.z = v.z;
@@ -1629,7 +1635,7 @@ extern "C" int mdx_unpack_positions(mdx_handle* h, const uint32_t* d_gid, uint32
                                                                                                       : &h->d.ctl->prune[h->chunk_s + 1]) : nullptr,
                               0.5f * h->inner_skin * (1.0f - 1.0e-4f),
                               h->dd ? h->box_hi[0] - h->box_lo[0] : 0.f, h->dd ? h->box_hi[1] - h->box_lo[1] : 0.f,
-                              h->dd ? h->box_hi[2] - h->box_lo[2] : 0.f);
+                              h->dd ? h->box_hi[2] - h->box_lo[2] : 0.f, (dual && h->path_split) ? h->d.path : nullptr);
     HIP_TRY(hipGetLastError());
     h->forces_valid = false;
     if (!dual) h->moved_outside = true;     // ghosts moved without feeding their path accumulators

@@ -461,7 +461,8 @@ __global__ void gather_slots_kernel(uint32_t S, const uint32_t* __restrict__ ori
                                     const float* __restrict__ o_qs, const float2* __restrict__ o_lj,
                                     const float* __restrict__ o_invm, float4* __restrict__ posq,
                                     float2* __restrict__ lj, float4* __restrict__ vel, float4* __restrict__ ref,
-                                    float4* __restrict__ force, uint8_t* __restrict__ slot_flags) {
+                                    float4* __restrict__ force, uint8_t* __restrict__ slot_flags, float* __restrict__ path,
+                                    float* __restrict__ dprune) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
     uint32_t o = orig_of[s];
@@ -485,6 +486,7 @@ __global__ void gather_slots_kernel(uint32_t S, const uint32_t* __restrict__ ori
         l = make_float2(0.f, 0.f);
     }
     posq[s] = p; vel[s] = v; lj[s] = l; ref[s] = make_float4(p.x, p.y, p.z, 0.f);   // .w: path length (dual list)
+    path[s] = 0.f; dprune[s] = 0.f;                                                  // (... or, path split, its own array)
     force[s] = make_float4(0.f, 0.f, 0.f, 0.f);
     slot_flags[s] = fl;
 }
@@ -1471,7 +1473,7 @@ static int setup_grid(mdx_handle* h) {
         if (h->in_slot_space && h->cap_tiles) MDX_TRY(mdx_unsort_state(h));
         h->cap_tiles = need_tiles;
         const size_t S = (size_t)need_tiles * MDX_TILE, NC = (size_t)need_tiles * MDX_CL_PER_TILE;
-        ALLOC(d.posq, S); ALLOC(d.lj, S); ALLOC(d.vel, S); ALLOC(d.force, S); ALLOC(d.ref, S); ALLOC(d.posq_alt, S);
+        ALLOC(d.posq, S); ALLOC(d.lj, S); ALLOC(d.vel, S); ALLOC(d.force, S); ALLOC(d.ref, S); ALLOC(d.posq_alt, S); ALLOC(d.path, S); ALLOC(d.dprune, S);
         ALLOC(d.orig_of, S); ALLOC(d.slot_flags, S); ALLOC(d.pme_force, S);
         ALLOC(d.role_cnt_s, S + 1); ALLOC(d.role_off_s, S + 1);
         ALLOC(d.tile_col, need_tiles);
@@ -1683,6 +1685,7 @@ struct AssignArgs {
     const float* o_qs; const float2* o_lj; const float* o_invm;
     uint32_t* orig_of; uint32_t* slot_of;
     float4* posq; float2* lj; float4* vel; float4* ref; float4* force; uint8_t* slot_flags;
+    float* path; float* dprune;      // path split (DeviceState): both start at zero with the new reference positions
     float4* cl_lo; float4* cl_hi;
     const uint32_t* role_off_o; uint32_t* role_cnt_s;     // null without bonded roles
     uint8_t* cl_kind; int kind_split;                     // interaction kinds per cluster; kind_split: clusters are formed per kind
@@ -1740,6 +1743,7 @@ __global__ __launch_bounds__(256) void rb_assign_kernel(AssignArgs a) {
         l = make_float2(0.f, 0.f);
     }
     a.posq[s] = p; a.vel[s] = v; a.lj[s] = l; a.ref[s] = make_float4(p.x, p.y, p.z, 0.f);
+    a.path[s] = 0.f; a.dprune[s] = 0.f;
     a.force[s] = make_float4(0.f, 0.f, 0.f, 0.f);
     a.slot_flags[s] = fl;
     if (a.role_cnt_s) {
@@ -1913,7 +1917,7 @@ static int rebuild_fast(mdx_handle* h, RebuildResult* res, bool* fell_back) {
         aa.sorted_orig = d.sorted_orig; aa.pos_orig = d.pos_orig; aa.vel_orig = d.vel_orig; aa.gid = d.gid; aa.lflag = d.lflag;
         aa.o_qs = d.o_qs; aa.o_lj = d.o_lj; aa.o_invm = d.o_invm; aa.orig_of = d.orig_of; aa.slot_of = d.slot_of;
         aa.cl_kind = d.cl_kind; aa.kind_split = h->kind_split ? 1 : 0;
-        aa.posq = d.posq; aa.lj = d.lj; aa.vel = d.vel; aa.ref = d.ref; aa.force = d.force; aa.slot_flags = d.slot_flags;
+        aa.posq = d.posq; aa.lj = d.lj; aa.vel = d.vel; aa.ref = d.ref; aa.force = d.force; aa.slot_flags = d.slot_flags; aa.path = d.path; aa.dprune = d.dprune;
         aa.cl_lo = d.cl_lo; aa.cl_hi = d.cl_hi;
         aa.role_off_o = h->n_roles ? d.role_off_o : nullptr; aa.role_cnt_s = h->n_roles ? d.role_cnt_s : nullptr;
         hipLaunchKernelGGL(rb_assign_kernel, dim3(div_up(T_bound + 1, 4)), dim3(256), 0, st, aa);
@@ -2108,7 +2112,7 @@ int mdx_rebuild(mdx_handle* h) {
                        d.lflag, d.o_qs, d.o_lj);
     hipLaunchKernelGGL(gather_slots_kernel, dim3(div_up(S, 256)), dim3(256), 0, st, S, d.orig_of, d.gid, d.lflag,
                        d.pos_orig, d.vel_orig, d.o_qs, d.o_lj, d.o_invm, d.posq, d.lj, d.vel, d.ref, d.force,
-                       d.slot_flags);
+                       d.slot_flags, d.path, d.dprune);
     hipLaunchKernelGGL(cluster_bbox_kernel, dim3(div_up(NC, 256)), dim3(256), 0, st, NC, d.orig_of, d.posq,
                        d.slot_flags, d.cl_lo, d.cl_hi, d.lj, d.cl_kind);
     h->in_slot_space = true;

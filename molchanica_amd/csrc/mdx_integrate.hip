@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void integrate_kernel(uint32_t S, float dt, fl
                                                         float4* __restrict__ vel, float4* __restrict__ force,
                                                         float4* __restrict__ ref, const uint32_t* gate_in,
                                                         uint32_t* disp_out, uint32_t thr_bits, LangevinArgs lg,
-                                                        uint32_t* prune_out, float path_thr, const uint8_t* __restrict__ skip) {
+                                                        uint32_t* prune_out, float path_thr, const uint8_t* __restrict__ skip,
+                                                        float* __restrict__ path_arr) {
     const uint32_t gate = gate_in ? *gate_in : 0u;
     if (gate > thr_bits) {  // list already stale: stay a no-op, keep the flag raised
         if (MODE != 2 && blockIdx.x == 0 && threadIdx.x == 0) atomicMax(disp_out, gate);
@@ -85,9 +86,9 @@ __global__ __launch_bounds__(256) void integrate_kernel(uint32_t S, float dt, fl
                 if (!(d2 < 1.0e30f)) d2 = 3.0e38f;  // NaN/inf -> huge, forces a stop
                 if (DUAL) {
                     const float mx = p.x - ox, my = p.y - oy, mz = p.z - oz;
-                    path = r.w + __builtin_sqrtf(mx * mx + my * my + mz * mz);
-                    r.w = path;
-                    ref[s] = r;
+                    const float mv = __builtin_sqrtf(mx * mx + my * my + mz * mz);
+                    if (path_arr) { path = path_arr[s] + mv; path_arr[s] = path; }      // path split: 8 B instead of the 16-B row written back
+                    else { path = r.w + mv; r.w = path; ref[s] = r; }
                 }
             }
             vel[s] = v;
@@ -173,15 +174,26 @@ __global__ __launch_bounds__(256) void bonded_integrate_kernel(FusedArgs a) {
             v.x += kdt * f.x; v.y += kdt * f.y; v.z += kdt * f.z;
             const float ox = p.x, oy = p.y, oz = p.z;
             p.x += a.dt * v.x; p.y += a.dt * v.y; p.z += a.dt * v.z;
-            float4 r = a.ref[s];
-            const float dx = p.x - r.x, dy = p.y - r.y, dz = p.z - r.z;
-            d2 = dx * dx + dy * dy + dz * dz;
-            if (!(d2 < 1.0e30f)) d2 = 3.0e38f;  // NaN/inf -> huge, forces a stop
-            if (DUAL) {
+            if (DUAL && a.path) {
+                // path split: |x - ref| <= |x(last pruning pass) - ref| + path since that pass (triangle inequality) - two floats instead
+                // of the ref row read and written; the bound is exact at every pruning pass and at most inner_skin / 2 above in between
                 const float mx = p.x - ox, my = p.y - oy, mz = p.z - oz;
-                path = r.w + __builtin_sqrtf(mx * mx + my * my + mz * mz);
-                r.w = path;
-                a.ref[s] = r;
+                path = a.path[s] + __builtin_sqrtf(mx * mx + my * my + mz * mz);
+                a.path[s] = path;
+                const float d = a.dprune[s] + path;
+                d2 = d * d;
+                if (!(d2 < 1.0e30f)) d2 = 3.0e38f;  // NaN/inf -> huge, forces a stop
+            } else {
+                float4 r = a.ref[s];
+                const float dx = p.x - r.x, dy = p.y - r.y, dz = p.z - r.z;
+                d2 = dx * dx + dy * dy + dz * dz;
+                if (!(d2 < 1.0e30f)) d2 = 3.0e38f;  // NaN/inf -> huge, forces a stop
+                if (DUAL) {
+                    const float mx = p.x - ox, my = p.y - oy, mz = p.z - oz;
+                    path = r.w + __builtin_sqrtf(mx * mx + my * my + mz * mz);
+                    r.w = path;
+                    a.ref[s] = r;
+                }
             }
             a.vel[s] = v;
         }
@@ -253,6 +265,7 @@ __global__ __launch_bounds__(256) void kinetic_kernel(uint32_t S, const float4* 
 int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_gate_in, uint32_t* d_disp_out,
                          uint32_t thr_bits, uint32_t* d_prune_out, bool skip_wstep) {
     const uint8_t* const skip = (skip_wstep && mode != 2) ? h->d.wstep_s : nullptr;
+    float* const path_arr = h->path_split ? h->d.path : nullptr;
     const dim3 g((h->S + 255) / 256), b(256);
     DeviceState& d = h->d;
     if (mode != 2) h->vsites_fresh = false;      // a drift: the virtual sites follow at the next position stage / construct launch
@@ -272,11 +285,11 @@ int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_ga
 #define INTEG(M)                                                                                                      \
     do {                                                                                                              \
         if (dual) hipLaunchKernelGGL((integrate_kernel<M, true, true>), g, b, 0, h->stream, h->S, dt, d.posq, d.vel, d.force, \
-                                     d.ref, d_gate_in, d_disp_out, thr_bits, lg, d_prune_out, path_thr, skip);        \
+                                     d.ref, d_gate_in, d_disp_out, thr_bits, lg, d_prune_out, path_thr, skip, path_arr); \
         else if (zero) hipLaunchKernelGGL((integrate_kernel<M, true, false>), g, b, 0, h->stream, h->S, dt, d.posq, d.vel, d.force, \
-                                     d.ref, d_gate_in, d_disp_out, thr_bits, lg, nullptr, 0.f, skip);                 \
+                                     d.ref, d_gate_in, d_disp_out, thr_bits, lg, nullptr, 0.f, skip, nullptr);        \
         else hipLaunchKernelGGL((integrate_kernel<M, false, false>), g, b, 0, h->stream, h->S, dt, d.posq, d.vel, d.force,  \
-                                d.ref, d_gate_in, d_disp_out, thr_bits, lg, nullptr, 0.f, skip);                      \
+                                d.ref, d_gate_in, d_disp_out, thr_bits, lg, nullptr, 0.f, skip, nullptr);             \
     } while (0)
     switch (mode) {
     case 0: INTEG(0); break;
@@ -311,6 +324,7 @@ int mdx_launch_bonded_integrate(mdx_handle* h, float dt, const uint32_t* d_gate_
     DeviceState& d = h->d;
     FusedArgs a{};
     a.S = h->S; a.dt = dt; a.posq_in = d.posq; a.posq_out = d.posq_alt; a.vel = d.vel; a.force = d.force; a.ref = d.ref;
+    a.path = h->path_split ? d.path : nullptr; a.dprune = h->path_split ? d.dprune : nullptr;
     a.role_off = d.role_off_s; a.roles = d.role_rec_s; a.prm = d.role_prm; a.R = h->n_roles;
     mdx_fill_bonded_params(h, a.p);
     a.gate_in = d_gate_in; a.disp_out = d_disp_out; a.thr_bits = thr_bits; a.prune_out = d_prune_out;

@@ -183,6 +183,11 @@ struct DeviceState {
     // slot space
     float4* posq = nullptr; float2* lj = nullptr; float4* vel = nullptr; float4* force = nullptr;
     float4* ref = nullptr;
+    // Path split (round 6; handles without constraints and virtual sites): the path accumulator of the dual pair list lives in its
+    // own array instead of ref[].w, and dprune[] holds |x - ref| at the atom's last pruning pass, so the fused bonded + kick + drift pass
+    // bounds the displacement since the rebuild by dprune + path (triangle inequality) and reads 8 B per slot where it read and wrote
+    // the 16-B ref row
+    float* path = nullptr; float* dprune = nullptr;
     float4* posq_alt = nullptr;   // second position buffer: the fused bonded + kick + drift pass reads t, writes t + dt, then the two swap
     uint32_t* orig_of = nullptr;  // [S]  slot -> local atom index (MDX_INVALID for dummies)
     uint32_t* slot_of = nullptr;  // [N]  GLOBAL atom id -> slot (MDX_INVALID when not simulated here)
@@ -330,6 +335,7 @@ struct mdx_handle {
     bool prune_pending = true;   // the next step-loop force call must prune (after a rebuild / at the start of mdx_step)
     uint32_t inner_rebuilds = 0;       // list rebuilds so far whose pruning pass wrote the inner list
     bool inner_from_rebuild = false;   // the last list rebuild produced the inner list itself (prune_list_kernel<true>): the force call behind it walks it
+    bool path_split = false;           // the dual list's path accumulators live in d.path / d.dprune (DeviceState)
     bool prune_latch = false;    // ... latched for the (up to two) launches of that force call
     bool moved_outside = true;   // something other than the step loop moved atoms in slot space (minimiser, constraint projection):
                                  // the path accumulators did not see it, the next mdx_step starts with a pruning pass
@@ -411,6 +417,7 @@ struct mdx_handle {
 struct FusedArgs {
     uint32_t S; float dt;
     const float4* posq_in; float4* posq_out; float4* vel; float4* force; float4* ref;
+    float* path; const float* dprune;      // path split (DeviceState): null -> the accumulator rides in ref[].w
     const uint32_t* role_off; const RoleRec* roles; const float4* prm; BondedParams p; uint32_t R;
     const uint32_t* gate_in; uint32_t* disp_out; uint32_t thr_bits; uint32_t* prune_out; float path_thr;
     // Decomposed handle, pipelined step (PIPE; mdx_decomp.hip).  The pass takes over what two kernels and two launch boundaries did:

@@ -152,6 +152,7 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
         const float rin = std::max(cut_on(c.lj_cutoff) ? c.lj_cutoff : 0.f, cut_on(c.coulomb_cutoff) ? c.coulomb_cutoff : 0.f) + h->inner_skin;
         a.rin2 = rin * rin;
         a.entries_in = h->d.entries_in; a.inner_nch = h->d.inner_nch; a.ref = h->d.ref; a.inner_count = h->d.inner_count;
+        a.path = h->path_split ? h->d.path : nullptr; a.dprune = h->path_split ? h->d.dprune : nullptr;
         // (a launch gated off behind a stale list is followed by a rebuild, which sets prune_pending again)
     }
     // small systems: the bonded gather rides along as extra workgroups of the merged dual-list launch (launch_variant

@@ -501,7 +501,14 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
     }
     if (prune) {
         // path lengths count from this pass (a boundary pass asked for by the ghosts alone restarts the ghosts only)
-        if (part == 0 && t_ok && (owned_prune || !(a.slot_flags[t * MDX_TILE + lane] & 2u))) a.ref[t * MDX_TILE + lane].w = 0.f;
+        if (part == 0 && t_ok && (owned_prune || !(a.slot_flags[t * MDX_TILE + lane] & 2u))) {
+            const uint32_t s = t * MDX_TILE + lane;
+            if (a.path) {      // path split: the accumulator restarts, and the displacement reached so far is kept for the drift pass's bound
+                const float4 x = a.posq[s], r = a.ref[s];
+                const float dx = x.x - r.x, dy = x.y - r.y, dz = x.z - r.z;
+                a.path[s] = 0.f; a.dprune[s] = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+            } else a.ref[s].w = 0.f;
+        }
         if (lane == 0 && kept) atomicAdd(a.inner_count + ((blk * BW + wave) & (MDX_EPART - 1)), (unsigned long long)kept);
         if (lane == 0 && blk == 0 && wave == 0) atomicAdd(a.inner_count + MDX_EPART, 1ull);
 #ifdef NB_HALF_STATS

@@ -32,6 +32,7 @@ struct NbArgs {
     uint2* entries_in;            // the inner list: same layout as `entries`, every wave's share of the plain run compacted
     uint32_t* inner_nch;          // [T * 8 + part] chunk-loop bound of wave `part` of a tile in the inner list
     float4* ref; unsigned long long* inner_count;
+    float* path; float* dprune;   // path split (mdx_internal.h): the pruning pass clears path[] and stores |x - ref| in dprune[]; null: ref[].w
     uint32_t xcd_interleave;      // 1: workgroup b takes tile group b (round-robin over the XCDs) instead of a contiguous eighth per XCD
     // decomposed handle, interior / boundary split: this launch covers tiles tile_order[t_first .. t_first + t_count)
     const uint32_t* tile_order; uint32_t t_first, t_count;
