@@ -12,6 +12,10 @@ i0 = starts[which]
 while i0 > 0 and short(rows[i0 - 1][0]) in ("unsort_kernel",): i0 -= 1
 t0 = rows[i0][1]; prev_end = rows[i0 - 1][2] if i0 else t0
 print(f"rebuild #{which} of {len(starts)}: gap in front of its first kernel {(t0 - prev_end) / 1e3:.1f} us (previous kernel: {short(rows[i0 - 1][0]) if i0 else '-'})")
+nb = int(os.environ.get("TIMELINE_BEFORE", "0"))      # kernels in front of the rebuild (the step loop noticing the stale list)
+for j in range(max(0, i0 - nb), i0):
+    name, a, b = rows[j]
+    print(f"  {(a - t0) / 1e3:9.1f} us  gap {(a - rows[j - 1][2]) / 1e3 if j else 0.0:6.1f}  dur {(b - a) / 1e3:7.1f}  {short(name)}")
 tot_k = 0.0; n = 0
 for name, a, b in rows[i0:i0 + 60]:
     k = short(name)
