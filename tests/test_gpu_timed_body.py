@@ -140,3 +140,63 @@ def test_every_waves_per_tile_instantiation_against_the_oracle(wpt, fused):
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     tail = "\n".join((p.stdout + p.stderr).splitlines()[-25:])
     assert p.returncode == 0 and "TIMED-BODY-OK" in p.stdout, tail
+
+
+def test_default_operating_point_step_loop_forces_against_the_oracle(mdx, orc):
+    """The body `bench.py`'s `default_operating_point` block times - what a user of the reference runs (/root/reference src/prefs/mod.rs:203,
+    src/ui/panels/md.rs:362-371, README.md:236-240): 64^3 rigid four-site OPC waters = 1,048,576 sites, SPME on the 200^3 mesh the
+    library chooses, dt 2 fs, rc 10 A, skin 2 A - at ITS size: one wave per tile with the Ewald force table, merged dual-list body,
+    one `water_step_kernel` pass per step, brick spread / 2-D transforms + own x pass / brick gather on the side stream.  20 steps from
+    the random-orientation lattice (it heats to ~1150 K on the way: seven list rebuilds and nineteen pruning passes in those 20 steps),
+    then the forces THE STEP LOOP LEFT BEHIND against the fp64 oracle's real-space sum + the numpy SPME of oracle/pme_ref.py on the same
+    mesh + the erf corrections of the excluded pairs, the M sites' share spread onto their parents as the library does."""
+    from molchanica_amd import _abi
+    from oracle import pme_ref as P
+    from tests.test_gpu_pme import excluded_pairs
+    s = systems.opc_water_box(64, seed=5)
+    beta = 0.3
+    cfg = MdConfig(coulomb_mode=_abi.COULOMB_EWALD, ewald_alpha=beta, overrides=0, skin=2.0)        # bench.py default_operating_point_rate
+    with mdx.MdState(s, cfg) as md:
+        md.initialize_velocities(300.0, True, seed=1)
+        md.step(0.002, None, 20)
+        info, st = md.pair_launch_info(), md.stats()
+        pos = md.positions()
+        f_step = md.forces().astype(np.float64)            # NOT re-evaluated
+        e = md.energy()                                     # plain list, energy flavour, the chain with its energy sums
+        f_plain = md.forces().astype(np.float64)
+    step = info["step"]
+    assert (step["waves_per_tile"], step["dual"], step["half"], step["coulomb"], step["energy"]) == (1, 3, 1, 4, 0), info      # 4: Ewald real space from the force table
+    assert step["tiles"] >= 12000 and info["water_step_launches"] >= 20 and info["water_step_mixed_launches"] == 0, info
+    assert st["rebuild_count"] >= 3 and st["prune_passes"] >= 3 and st["rebuild_fallbacks"] == 0, (st["rebuild_count"], st["prune_passes"])
+    x = pos.astype(np.float64)
+    L = float(s.box_hi[0])
+    box, q, K = np.full(3, L), s.charge.astype(np.float64), 200       # (198.6 A: the next 2-3-5-smooth size at ~1 A per mesh cell)
+    cfg_real = MdConfig(coulomb_mode=_abi.COULOMB_EWALD, ewald_alpha=beta, overrides=_abi.OVR_LONG_RANGE_RECIP_DISABLED, skin=2.0)
+    fo, eo = orc.forces(s, cfg_real, pos=x, use_cells=True)
+    e_rec, f_rec = P.spme_recip(x, q, (0, 0, 0), box, beta, (K, K, K), 4)
+    e_x, f_x = P.excluded_pair_correction(x, q, excluded_pairs(s), box, beta)
+    e_rec += e_x + P.ewald_self_energy(q, beta) + P.ewald_background_energy(q, box, beta)
+    f_rec += f_x
+    vi, w = s.vsite_idx.astype(np.int64), s.vsite_w.astype(np.float64)          # site = O + w0 (H1 - O) + w1 (H2 - O): its force goes the same way
+    fm = f_rec[vi[:, 0]].copy()
+    f_rec[vi[:, 1]] += (1.0 - w[:, 0] - w[:, 1])[:, None] * fm
+    f_rec[vi[:, 2]] += w[:, 0:1] * fm
+    f_rec[vi[:, 3]] += w[:, 1:2] * fm
+    f_rec[vi[:, 0]] = 0.0
+    f_ref = fo + f_rec
+    slack = orc.cutoff_slack(s, cfg_real, pos=pos, rel=4e-5)
+    rec_rms = _rms(f_rec)
+    # Bounds.  The real-space part carries SURVEY 8(c)'s per-atom bound (1e-4 max(|F|, 1) + the cutoff slack).  The mesh part is fp32 with
+    # fixed-point LDS canvases against an fp64 numpy SPME: tests/test_gpu_pme.py bounds its rms at 2e-4 of the reciprocal force's rms on
+    # small boxes - the same bound here; per atom 2e-3 of that rms on top.  Measured on the MI355X (tools/dbg/default_point_body.py):
+    # rms 3.7e-4 kcal/mol/A = 1.1e-4 of the reciprocal rms (2e-5 of the total force's rms), worst atom 2.8e-3 = 0.4 of its bound.
+    for name, f in (("step-loop", f_step), ("plain-list", f_plain)):
+        assert np.abs(f[vi[:, 0]]).max() == 0.0, "a virtual site must not keep a force"
+        err = np.linalg.norm(f - f_ref, axis=1)
+        tol = 1e-4 * np.maximum(np.linalg.norm(f_ref, axis=1), 1.0) + slack + 2e-3 * rec_rms
+        print(f"default operating point, {name} forces: rms {_rms(f - f_ref):.2e} = {_rms(f - f_ref) / rec_rms:.2e} of the reciprocal rms, worst atom {(err / tol).max():.2f} of its bound")
+        assert _rms(f - f_ref) < 2e-4 * rec_rms, (name, _rms(f - f_ref) / rec_rms)
+        assert (err <= tol).all(), (name, float((err / tol).max()))
+    assert e["lj"] == pytest.approx(eo["lj"], rel=2e-6, abs=2e-2)
+    assert e["coulomb"] == pytest.approx(eo["coulomb"], rel=5e-6)             # (measured 1.5e-6: fp32 pair terms, fp64 sums)
+    assert e["coulomb_recip"] == pytest.approx(e_rec, rel=2e-5)               # (measured 2.7e-6; tests/test_gpu_pme.py's bound)
