@@ -291,14 +291,16 @@ int mdx_get_stats(mdx_handle* h, mdx_stats* out);
 /* Diagnostics: which instantiation of the pair kernel the handle launched last - out[0..7] by the step loop over the dual pair
  * list, out[8..15] by any other force call (mdx_energy, the minimiser, single points); all zero until such a launch happened.
  * Per block: {waves per tile (0: the whole-tile kernel), dual-list body (0 plain list, 1 / 2 inner-walk / pruning twins, 3 one merged
- * launch - the device picks the body, 4 merged + the bonded gather in extra workgroups), half list, Coulomb flavour (0 shifted cutoff,
+ * launch - the device picks the body, 4 merged + the bonded gather in extra workgroups, 5 merged + the previous step's kick and drift
+ * and the bonded roles of the tile's atoms inside: one launch per step), half list, Coulomb flavour (0 shifted cutoff,
  * 1 reaction field, 2 Ewald closed form, 3 softened, 4 Ewald table), energy flavour, workgroups per tile, bonded workgroups behind
  * twin launches, tiles in the launch}.  out[16]: list rebuilds so far whose exact pruning pass also wrote the inner list (the force
  * call behind such a rebuild walks the inner list instead of being a pruning pass: one wave per tile, single device), out[17]: the
  * last rebuild was one of them, out[18]: steps so far that took the handle's rigid waters through the one-pass water_step_kernel, out[19]: ... of
- * which with other mobile atoms beside them (a solute in rigid water).  The parity tests use it to name the body they hold against the oracle; no call
+ * which with other mobile atoms beside them (a solute in rigid water), out[20]: pair launches so far that were the whole step (body 5),
+ * out[21]: steps taken back to a list rebuild because a kick exceeded what the gating words had granted it, out[22..23]: 0.  The parity tests use it to name the body they hold against the oracle; no call
  * of the reference corresponds to it. */
-int mdx_pair_launch_info(const mdx_handle* h, uint32_t out[20]);
+int mdx_pair_launch_info(const mdx_handle* h, uint32_t out[24]);
 /* The Verlet skin in force, and whether the library is still tuning it (mdx_config.skin == 0). */
 int mdx_get_skin(const mdx_handle* h, float* skin, int* tuning);
 

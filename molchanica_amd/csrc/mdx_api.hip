@@ -146,7 +146,7 @@ static void free_device(mdx_handle* h) {
                     d.tile_col, d.scan_tmp, d.cl_lo, d.cl_hi, d.cl_kind, d.list_counts, d.entry_cnt, d.entry_off,
                     d.mchunk_cnt, d.mchunk_off, d.entries, d.entries_in, d.inner_nch, d.list_cursors, d.masks, d.role_off_o, d.role_rec_o, d.role_cnt_s,
                     d.role_off_s, d.role_rec_s, d.role_prm, d.ctl, d.energy,
-                    d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.pme_force, d.wstep_s, d.path, d.dprune, d.cons_o, d.cons_s, d.cons_tmp, d.cons_mask, d.cons_cnt, d.cons_off, d.cons_vir, d.vsite_o, d.vsite_s, d.gsite_o, d.gsite_s, d.gsite_tmp, d.pme_q, d.pme_f,
+                    d.flags_dev, d.bbox_red, d.pair_count, d.inner_count, d.pme_force, d.wstep_s, d.path, d.dprune, d.force_b, d.force_c, d.cons_o, d.cons_s, d.cons_tmp, d.cons_mask, d.cons_cnt, d.cons_off, d.cons_vir, d.vsite_o, d.vsite_s, d.gsite_o, d.gsite_s, d.gsite_tmp, d.pme_q, d.pme_f,
                     d.pme_theta, d.pme_q2, d.pme_f2, d.scratch4, d.tile_bnd, d.tile_scan, d.tile_order, d.tile_lpt, d.rb_ctl, d.scan_chain, d.grp, d.grp_mat, d.star_o, d.star_s, d.ewald_tab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = DeviceState{};
@@ -754,9 +754,50 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         // boxes of rigid water (the reference's default operating point): site-force spread + kick + drift + SETTLE + site placement in ONE pass
         const bool water = fused && mdx_water_step_ok(h);
         const bool pipe_chunk = fuse_bi && mdx_dd_fold_eligible(h);      // decomposed handle: the fused pass also packs the halo and adds the returned ghost forces
+        // One launch per step (round 6; the one-wave-per-tile class): the pair launch of step s also finishes the drift of step s for its
+        // tile's atoms and evaluates their bonded roles (mdx_nonbonded_impl.h STEP).  Positions travel in the step form Y between two
+        // buffers, forces rotate through three (read / accumulate / zero); step s reads ybuf[s & 1] and fb3[s % 3].  A chunk that ends with
+        // an energy evaluation leaves the form one step early (the energy flavour is a kernel of its own).
+        const bool onepass = fused && !water && !pipe_chunk && chunk >= (want_e ? 2u : 1u) && mdx_onepass_ok(h);
+        float4* const ybuf[2] = {d.posq_alt, d.posq};
+        float4* const fb3[3] = {d.force, d.force_b, d.force_c};
+        auto onepass_point_at = [&](uint32_t n) {      // the plain arrays after n position stages of this chunk
+            d.posq = ybuf[n & 1]; d.posq_alt = ybuf[(n + 1) & 1];
+            d.force = fb3[n % 3]; d.force_b = fb3[(n + 1) % 3]; d.force_c = fb3[(n + 2) % 3];
+        };
         for (uint32_t s = 0; s < chunk; ++s) {
             h->prof_tag = (int)s;
             h->lang_step = h->step_count + s;
+            if (onepass) {
+                if (s == 0) MDX_TRY(mdx_launch_step_begin(h, dt, &d.ctl->disp2[0], &d.ctl->disp2[1], thr, &d.ctl->prune[1]));
+                pos_after[s] = ybuf[(s + 1) & 1];
+                if (!(want_e && s + 1 == chunk)) {
+                    OnePassNow& o = h->onepass;
+                    o.yin = ybuf[s & 1]; o.yout = ybuf[(s + 1) & 1];
+                    o.fprev = fb3[s % 3]; o.fcur = fb3[(s + 1) % 3]; o.fnext = fb3[(s + 2) % 3];
+                    o.dt = dt; o.last = s + 1 == chunk; o.first = s == 0;
+                    o.disp_out = &d.ctl->disp2[s + 2]; o.prune_out = o.last ? nullptr : &d.ctl->prune[s + 2]; o.viol = &d.ctl->viol[s];
+                    h->nb_step = (int)s;
+                    const int frc = mdx_launch_nonbonded(h, false, &d.ctl->disp2[s + 1], thr, 0);
+                    h->nb_step = -1; h->onepass = OnePassNow{};
+                    MDX_TRY(frc);
+                    if (h->onepass_refused) FAIL(MDX_EDEVICE, "internal: no one-launch-per-step instantiation for this handle's pair kernel");
+                    if (s + 1 == chunk) onepass_point_at(chunk);
+                    continue;
+                }
+                // the chunk's last step, energies wanted: its drift as a pass of its own (back into the plain form), then the energy flavour
+                onepass_point_at(chunk);
+                MDX_TRY(mdx_launch_step_materialise(h, dt, ybuf[s & 1], fb3[s % 3], ybuf[(s + 1) & 1], false, 1.0f, &d.ctl->disp2[s + 1], thr));
+                HIP_TRY(hipMemsetAsync(d.energy, 0, e_bytes, st));
+                h->nb_step = (int)s;
+                // (the buffer this evaluation accumulates into was zeroed by the launch before it; the fill the pair launch would enqueue
+                // is not gated - behind a stale step it would wipe force rows the way back out of the step form still reads)
+                h->force_zeroed = true;
+                const int frc = compute_forces(h, true, &d.ctl->disp2[s + 1], thr);
+                h->nb_step = -1;
+                MDX_TRY(frc);
+                continue;
+            }
             const int mode = !vv ? (integ == MDX_INTEGRATOR_LANGEVIN_MIDDLE ? 3 : 1) : ((s == 0 || !fused) ? 0 : 1);
             if (h->dd) h->dd->pipe_now = pipe_chunk && mode == 1 && !(want_e && s + 1 == chunk);
             const bool water_now = water && (mode == 0 || mode == 1);
@@ -802,7 +843,8 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         }
         h->prof_tag = (int)chunk;
         if (fused) {
-            MDX_TRY(mdx_launch_integrate(h, 2, dt, &d.ctl->disp2[chunk], nullptr, thr));
+            // (one launch per step, no energy step at the end: the last launch passes its own gate - or a kick beyond its grant - on in the next word)
+            MDX_TRY(mdx_launch_integrate(h, 2, dt, &d.ctl->disp2[(onepass && !want_e) ? chunk + 1 : chunk], nullptr, thr));
             MDX_TRY(mdx_launch_constrain_velocities(h, &d.ctl->disp2[chunk], thr));     // (no-op without constraints)
         }
         h->prof_tag = -1;
@@ -827,18 +869,26 @@ extern "C" int mdx_step(mdx_handle* h, float dt, const float* ext_forces, uint32
         bool stale_hit = false;
         int first_stale = 1 << 30;
         for (uint32_t s = 0; s < chunk; ++s)
-            if (h->h_ctl->disp2[s + 1] > thr) { first_stale = (int)s; break; }
+            if (h->h_ctl->disp2[s + 1] > thr || (onepass && h->h_ctl->viol[s])) { first_stale = (int)s; break; }
         if (h->profile) mdx_prof_collect(h, first_stale);
         static const bool dbg_stale = [] { const char* e = std::getenv("MDX_DEBUG_STALE"); return e && e[0] == '1'; }();
         if (dbg_stale && first_stale < (1 << 30))
             std::fprintf(stderr, "[mdx] list stale at step %d of a chunk of %u (step count %llu): word %.4g against (skin / 2)^2 = %.4g%s\n", first_stale, chunk,
                          (unsigned long long)h->step_count, (double)u2f(h->h_ctl->disp2[first_stale + 1]), (double)u2f(thr), h->dd ? " [decomposed]" : "");
         for (uint32_t s = 0; s < chunk; ++s) {
-            if (h->h_ctl->disp2[s + 1] > thr) {
+            const bool kick_beyond_grant = onepass && h->h_ctl->viol[s] != 0u;
+            if (h->h_ctl->disp2[s + 1] > thr || kick_beyond_grant) {
                 // (fused bonded + kick + drift passes swap the two position buffers at every enqueued step, the gated-off
                 // ones included: the state is in the buffer step s's drift wrote - also for a caller that downloads the
                 // coordinates to look at a runaway step)
-                if (fuse_bi && d.posq != pos_after[s]) std::swap(d.posq, d.posq_alt);
+                if (fuse_bi && !onepass && d.posq != pos_after[s]) std::swap(d.posq, d.posq_alt);
+                if (onepass) {
+                    // the launch of step s stayed a no-op (or its kick went beyond what the words had granted: its forces are not to be
+                    // trusted, its kick is done): the drift of step s out of the step form, into the buffer that launch would have written
+                    onepass_point_at(s + 1);
+                    MDX_TRY(mdx_launch_step_materialise(h, dt, ybuf[s & 1], fb3[s % 3], ybuf[(s + 1) & 1], kick_beyond_grant, s == 0 ? 0.5f : 1.0f, nullptr, 0));
+                    if (kick_beyond_grant) ++h->onepass_violations;
+                }
                 if (u2f(h->h_ctl->disp2[s + 1]) > 1.0e29f) {
                     h->forces_valid = false; h->list_valid = false;
                     h->step_count += s;
@@ -1420,10 +1470,11 @@ extern "C" int mdx_get_skin(const mdx_handle* h, float* skin, int* tuning) {
     return MDX_OK;
 }
 
-extern "C" int mdx_pair_launch_info(const mdx_handle* h, uint32_t out[20]) {
+extern "C" int mdx_pair_launch_info(const mdx_handle* h, uint32_t out[24]) {
     if (!h || !out) FAIL(MDX_EPARAM, "null argument");
     for (int k = 0; k < 8; ++k) { out[k] = h->pair_info_step[k]; out[8 + k] = h->pair_info_any[k]; }
     out[16] = h->inner_rebuilds; out[17] = h->inner_from_rebuild ? 1u : 0u; out[18] = h->water_step_launches; out[19] = h->water_step_mixed_launches;
+    out[20] = (uint32_t)h->onepass_launches; out[21] = (uint32_t)h->onepass_violations; out[22] = 0u; out[23] = 0u;
     return MDX_OK;
 }
 

@@ -18,6 +18,13 @@ __device__ __forceinline__ float3 cross3(float3 a, float3 b) {
 __device__ __forceinline__ float3 scale3(float3 a, float s) { return make_float3(a.x * s, a.y * s, a.z * s); }
 
 
+// One launch per step (round 6, mdx_nonbonded_impl.h "STEP"): between two chunk boundaries the position array holds Y = x + dt v (the drift
+// without the last kick) and the force array's .w holds dt^2 * 418.4 / m, so that EVERY reader of an atom reconstructs its position as
+// Y + w F from two rows - the owner, the pair kernel's j-side and the bonded partners alike, with this one expression (bitwise the same).
+__device__ __forceinline__ float4 step_pos(const float4 y, const float4 f) {
+    return make_float4(fmaf(f.w, f.x, y.x), fmaf(f.w, f.y, y.y), fmaf(f.w, f.z, y.z), y.w);
+}
+
 struct RoleEnergies { double bond = 0.0, angle = 0.0, dih = 0.0, lj14 = 0.0, c14 = 0.0, rec = 0.0, vir = 0.0; };
 
 // Adds to (fx, fy, fz) the force of role `r` on its own atom (position `self`).  ENERGY: the term's energy and
@@ -27,7 +34,8 @@ struct RoleEnergies { double bond = 0.0, angle = 0.0, dih = 0.0, lj14 = 0.0, c14
 template <bool ENERGY>
 __device__ __forceinline__ void role_compute(const RoleRec& r, const float4 prm4, const float4 self, const float4 q0, const float4 q1,
                                              const float4* __restrict__ posq,
-                                             const BondedParams& p, float& fx, float& fy, float& fz, RoleEnergies& en);
+                                             const BondedParams& p, float& fx, float& fy, float& fz, RoleEnergies& en,
+                                             const float4* __restrict__ fstep = nullptr);
 
 template <bool ENERGY>
 __device__ __forceinline__ void role_eval(const RoleRec& r, const float4* __restrict__ prm_tab, const float4 self,
@@ -39,10 +47,22 @@ __device__ __forceinline__ void role_eval(const RoleRec& r, const float4* __rest
     role_compute<ENERGY>(r, prm_tab[r.meta >> 8], self, q0, q1, posq, p, fx, fy, fz, en);
 }
 
+// (positions in the step form - posq = Y, fstep = the force rows beside it: role_eval_step)
+template <bool ENERGY>
+__device__ __forceinline__ void role_eval_step(const RoleRec& r, const float4* __restrict__ prm_tab, const float4 self,
+                                               const float4* __restrict__ y, const float4* __restrict__ fstep,
+                                               const BondedParams& p, float& fx, float& fy, float& fz, RoleEnergies& en) {
+    const uint32_t kind = r.meta & 0xFu;
+    const float4 q0 = step_pos(y[r.p[0]], fstep[r.p[0]]);
+    const float4 q1 = (kind == ROLE_ANGLE || kind == ROLE_DIHEDRAL) ? step_pos(y[r.p[1]], fstep[r.p[1]]) : q0;
+    role_compute<ENERGY>(r, prm_tab[r.meta >> 8], self, q0, q1, y, p, fx, fy, fz, en, fstep);
+}
+
 template <bool ENERGY>
 __device__ __forceinline__ void role_compute(const RoleRec& r, const float4 prm4, const float4 self, const float4 q0, const float4 q1,
                                              const float4* __restrict__ posq,
-                                             const BondedParams& p, float& fx, float& fy, float& fz, RoleEnergies& en) {
+                                             const BondedParams& p, float& fx, float& fy, float& fz, RoleEnergies& en,
+                                             const float4* __restrict__ fstep) {
     const float prm[3] = {prm4.x, prm4.y, prm4.z};
     double& e_bond = en.bond; double& e_angle = en.angle; double& e_dih = en.dih; double& e_lj14 = en.lj14;
     double& e_c14 = en.c14; double& e_rec = en.rec; double& e_vir = en.vir;
@@ -107,7 +127,8 @@ __device__ __forceinline__ void role_compute(const RoleRec& r, const float4 prm4
         else { fx -= fi.x + fk.x; fy -= fi.y + fk.y; fz -= fi.z + fk.z; }
         if (ENERGY && role == 0) e_angle += (double)prm[0] * dth * dth;
     } else {   // ROLE_DIHEDRAL: ordered atoms 0-1-2-3, this lane is atom `role`
-        const float4 q2 = posq[r.p[2]];
+        float4 q2 = posq[r.p[2]];
+        if (fstep) q2 = step_pos(q2, fstep[r.p[2]]);
         const float4 p0 = role == 0 ? self : q0;
         const float4 p1 = role == 1 ? self : (role == 0 ? q0 : q1);
         const float4 p2 = role == 2 ? self : (role < 2 ? q1 : q2);

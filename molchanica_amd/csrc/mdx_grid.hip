@@ -1474,6 +1474,7 @@ static int setup_grid(mdx_handle* h) {
         h->cap_tiles = need_tiles;
         const size_t S = (size_t)need_tiles * MDX_TILE, NC = (size_t)need_tiles * MDX_CL_PER_TILE;
         ALLOC(d.posq, S); ALLOC(d.lj, S); ALLOC(d.vel, S); ALLOC(d.force, S); ALLOC(d.ref, S); ALLOC(d.posq_alt, S); ALLOC(d.path, S); ALLOC(d.dprune, S);
+        ALLOC(d.force_b, S); ALLOC(d.force_c, S);
         ALLOC(d.orig_of, S); ALLOC(d.slot_flags, S); ALLOC(d.pme_force, S);
         ALLOC(d.role_cnt_s, S + 1); ALLOC(d.role_off_s, S + 1);
         ALLOC(d.tile_col, need_tiles);

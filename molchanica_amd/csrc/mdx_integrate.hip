@@ -262,6 +262,96 @@ __global__ __launch_bounds__(256) void kinetic_kernel(uint32_t S, const float4* 
     }
 }
 
+// ---- one launch per step (round 6; mdx_nonbonded_impl.h STEP, mdx_api.hip mdx_step "onepass") ---------------------------------------
+// A chunk of such steps opens with this pass: positions go into the step form for a step that opens with a HALF kick - Y = x + dt v,
+// the force rows the first launch reads keep the complete forces and get .w = dt^2 418.4/m / 2, so that Y + w F is x + dt (v + dt/2 a) -
+// the two other force buffers are zeroed with the full .w, and the words that gate the first launch are raised from that very position:
+// nothing is predicted here.
+__global__ __launch_bounds__(256) void step_begin_kernel(uint32_t S, float dt, const float4* __restrict__ x_in, float4* __restrict__ y_out,
+                                                         const float4* __restrict__ vel, float4* __restrict__ f0, float4* __restrict__ fb,
+                                                         float4* __restrict__ fc, const float* __restrict__ path, const float4* __restrict__ ref,
+                                                         const uint32_t* __restrict__ gate_in,
+                                                         uint32_t* __restrict__ disp_out, uint32_t thr_bits, uint32_t* __restrict__ prune_out,
+                                                         float path_thr) {
+    const uint32_t gate = gate_in ? *gate_in : 0u;
+    if (gate > thr_bits) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(disp_out, gate);
+        return;
+    }
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    float d2 = 0.f, pw = 0.f;
+    if (s < S) {
+        float4 p = x_in[s];
+        const float4 v = vel[s];
+        float w = 0.f;
+        if (v.w != 0.f) {
+            float4 f = f0[s];
+            w = dt * dt * v.w;
+            f.w = 0.5f * w;
+            const float kx = f.w * f.x, ky = f.w * f.y, kz = f.w * f.z;
+            const float mx = fmaf(dt, v.x, kx), my = fmaf(dt, v.y, ky), mz = fmaf(dt, v.z, kz);      // the step's displacement, as the first launch will find it
+            const float4 r = ref[s];
+            const float ex = p.x + mx - r.x, ey = p.y + my - r.y, ez = p.z + mz - r.z;      // the stage the first launch will reconstruct, against the list's reference
+            p.x = fmaf(dt, v.x, p.x); p.y = fmaf(dt, v.y, p.y); p.z = fmaf(dt, v.z, p.z);
+            pw = path[s] + __builtin_sqrtf(mx * mx + my * my + mz * mz);
+            d2 = ex * ex + ey * ey + ez * ez;
+            if (!(d2 < 1.0e30f)) d2 = 3.0e38f;
+            f0[s] = f;
+        } else f0[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        y_out[s] = p;
+        const float4 z = make_float4(0.f, 0.f, 0.f, w);
+        fb[s] = z; fc[s] = z;
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) { d2 = fmaxf(d2, __shfl_xor(d2, m)); pw = fmaxf(pw, __shfl_xor(pw, m)); }
+    if ((threadIdx.x & 63) == 0) {
+        if (__float_as_uint(d2) > thr_bits) atomicMax(disp_out, __float_as_uint(d2));
+        if (prune_out && !(pw <= path_thr)) *prune_out = 1u;
+    }
+}
+
+// ... and when a launch of the chunk found itself gated off (the list went stale at its position stage) or a kick exceeded what had been
+// granted, the host takes the state back into the plain form: x = Y + w F, v += dt 418.4/m F unless the launch that raised the flag had
+// already kicked (kick_done).
+__global__ __launch_bounds__(256) void step_materialise_kernel(uint32_t S, float dt, const float4* __restrict__ y, const float4* __restrict__ fprev,
+                                                               float4* __restrict__ vel, float4* __restrict__ x_out, float* __restrict__ path,
+                                                               uint32_t kick_done, float kick, const uint32_t* __restrict__ gate_in, uint32_t thr_bits) {
+    if (gate_in && *gate_in > thr_bits) return;
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const float4 Y = y[s], F = fprev[s];
+    float4 v = vel[s];
+    if (v.w != 0.f) {
+        x_out[s] = step_pos(Y, F);
+        if (!kick_done) {      // (else the launch that kicked also counted the path)
+            const float kdt = kick * dt * v.w;      // (kick: 0.5 for the chunk's first step, whose force rows carry w / 2)
+            const float sx = fmaf(dt, v.x, F.w * F.x), sy = fmaf(dt, v.y, F.w * F.y), sz = fmaf(dt, v.z, F.w * F.z);      // this drift, for the path length
+            path[s] += __builtin_sqrtf(sx * sx + sy * sy + sz * sz);
+            v.x = fmaf(kdt, F.x, v.x); v.y = fmaf(kdt, F.y, v.y); v.z = fmaf(kdt, F.z, v.z);
+            vel[s] = v;
+        }
+    } else x_out[s] = Y;
+}
+
+int mdx_launch_step_begin(mdx_handle* h, float dt, const uint32_t* d_gate_in, uint32_t* d_disp_out, uint32_t thr_bits, uint32_t* d_prune_out) {
+    DeviceState& d = h->d;
+    const dim3 g((h->S + 255) / 256), b(256);
+    mdx_prof_begin(h, 2);
+    hipLaunchKernelGGL(step_begin_kernel, g, b, 0, h->stream, h->S, dt, d.posq, d.posq_alt, d.vel, d.force, d.force_b, d.force_c, d.path, d.ref,
+                       d_gate_in, d_disp_out, thr_bits, d_prune_out, 0.5f * h->inner_skin * (1.0f - 1.0e-4f));
+    mdx_prof_end(h);
+    HIP_TRY(hipGetLastError());
+    return MDX_OK;
+}
+
+int mdx_launch_step_materialise(mdx_handle* h, float dt, const float4* y, const float4* fprev, float4* x_out, bool kick_done, float kick,
+                                const uint32_t* d_gate_in, uint32_t thr_bits) {
+    const dim3 g((h->S + 255) / 256), b(256);
+    hipLaunchKernelGGL(step_materialise_kernel, g, b, 0, h->stream, h->S, dt, y, fprev, h->d.vel, x_out, h->d.path, kick_done ? 1u : 0u, kick, d_gate_in, thr_bits);
+    HIP_TRY(hipGetLastError());
+    return MDX_OK;
+}
+
 int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_gate_in, uint32_t* d_disp_out,
                          uint32_t thr_bits, uint32_t* d_prune_out, bool skip_wstep) {
     const uint8_t* const skip = (skip_wstep && mode != 2) ? h->d.wstep_s : nullptr;

@@ -116,6 +116,14 @@ struct StepCtl {
     // decomposed handle with interior / boundary split: raised by the halo unpack when a GHOST's path length since the last
     // pruning pass of the boundary tiles exceeded inner_skin/2 (interior tiles never see a ghost and never read it)
     uint32_t prune_ghost[MDX_MAX_CHUNK + 2];
+    // one launch per step (mdx_pair_dev.h NbArgs::st_*): the kick of step s exceeded what the words of step s - 1 had granted it
+    uint32_t viol[MDX_MAX_CHUNK + 2];
+};
+
+// One launch per step (mdx_step "onepass"; mdx_pair_dev.h NbArgs::st_*)
+struct OnePassNow {      // what mdx_launch_nonbonded adds to the argument block of the launch being enqueued (null fprev: nothing)
+    const float4* yin = nullptr; const float4* fprev = nullptr; float4* fcur = nullptr; float4* yout = nullptr; float4* fnext = nullptr;
+    float dt = 0.f; bool last = false, first = false; uint32_t* disp_out = nullptr; uint32_t* prune_out = nullptr; uint32_t* viol = nullptr;
 };
 
 // Decomposed handle, steps of the fused bonded + kick + drift pass: the pass also packs the halo and adds the ghost forces the peers
@@ -188,6 +196,8 @@ struct DeviceState {
     // bounds the displacement since the rebuild by dprune + path (triangle inequality) and reads 8 B per slot where it read and wrote
     // the 16-B ref row
     float* path = nullptr; float* dprune = nullptr;
+    float4* force_b = nullptr;    // one launch per step (mdx_pair_dev.h NbArgs::st_*): the force array rotates through three buffers -
+    float4* force_c = nullptr;    // read (previous stage, complete), accumulate, zero for the next - and d.force is whichever holds the current one
     float4* posq_alt = nullptr;   // second position buffer: the fused bonded + kick + drift pass reads t, writes t + dt, then the two swap
     uint32_t* orig_of = nullptr;  // [S]  slot -> local atom index (MDX_INVALID for dummies)
     uint32_t* slot_of = nullptr;  // [N]  GLOBAL atom id -> slot (MDX_INVALID when not simulated here)
@@ -336,6 +346,9 @@ struct mdx_handle {
     uint32_t inner_rebuilds = 0;       // list rebuilds so far whose pruning pass wrote the inner list
     bool inner_from_rebuild = false;   // the last list rebuild produced the inner list itself (prune_list_kernel<true>): the force call behind it walks it
     bool path_split = false;           // the dual list's path accumulators live in d.path / d.dprune (DeviceState)
+    OnePassNow onepass;                // one launch per step: the launch mdx_step is enqueuing right now
+    bool onepass_refused = false;      // the pair kernel's flavour of this handle has no such instantiation (set by the first attempt)
+    uint64_t onepass_launches = 0, onepass_violations = 0;
     bool prune_latch = false;    // ... latched for the (up to two) launches of that force call
     bool moved_outside = true;   // something other than the step loop moved atoms in slot space (minimiser, constraint projection):
                                  // the path accumulators did not see it, the next mdx_step starts with a pruning pass
@@ -475,6 +488,13 @@ int mdx_launch_integrate(mdx_handle* h, int mode, float dt, const uint32_t* d_ga
 bool mdx_bonded_integrate_ok(const mdx_handle* h);
 int mdx_launch_bonded_integrate(mdx_handle* h, float dt, const uint32_t* d_gate_in, uint32_t* d_disp_out, uint32_t thr_bits,
                                 uint32_t* d_prune_out);
+// One launch per step (round 6): the pair launch of the one-wave-per-tile class also finishes the previous step for its tile's atoms and
+// evaluates their bonded roles (mdx_nonbonded_impl.h STEP); a chunk opens with mdx_launch_step_begin and, where a launch was gated off,
+// returns to the plain form through mdx_launch_step_materialise.  mdx_step (mdx_api.hip) owns the buffer rotation.
+bool mdx_onepass_ok(const mdx_handle* h);
+int mdx_launch_step_begin(mdx_handle* h, float dt, const uint32_t* d_gate_in, uint32_t* d_disp_out, uint32_t thr_bits, uint32_t* d_prune_out);
+int mdx_launch_step_materialise(mdx_handle* h, float dt, const float4* y, const float4* fprev, float4* x_out, bool kick_done, float kick,
+                                const uint32_t* d_gate_in, uint32_t thr_bits);
 int mdx_launch_kinetic(mdx_handle* h);  // energy[EN_KIN], energy[EN_COUNT] = max |F|^2
 int mdx_exclusive_scan_u32(mdx_handle* h, const uint32_t* in, uint32_t* out, uint32_t n);
 int mdx_exclusive_scan_u32_ex(mdx_handle* h, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums);   // caller's scratch: n / 2048 + 1 words

@@ -117,6 +117,29 @@ int mdx_build_ewald_table(mdx_handle* h) {
     return MDX_OK;
 }
 
+// Single-device handles with velocity Verlet and no constraints / virtual sites / SPME / external forces / alchemy, dual list with split
+// path arrays.  By default the eight-waves-per-tile class (below 2048 tiles: a step there is launch latency, and this is one launch
+// instead of two); MDX_ONEPASS=2 also takes the one-wave class (1 M atoms: measured slower - the pair launch grows by more than the
+// 35 us pass it absorbs); MDX_ONEPASS=0: off.  Read per chunk.
+bool mdx_onepass_ok(const mdx_handle* h) {
+    const char* e = std::getenv("MDX_ONEPASS");
+    if (e && e[0] == '0') return false;
+    const int wpt = mdx_nb_wpt_half(h, h->T);
+    if (!(wpt == 8 || (wpt == 1 && e && e[0] == '2'))) return false;
+    static const bool dbg = [] { const char* x = std::getenv("MDX_DEBUG_ONEPASS"); return x && x[0] == '1'; }();
+    if (dbg) std::fprintf(stderr, "[mdx onepass] refused %d dd %d dual %d path_split %d force_b %d fuse_ok %d variant %d wpt %d (T %u)\n", (int)h->onepass_refused, h->dd != nullptr,
+                          (int)h->dual_on, (int)h->path_split, h->d.force_b != nullptr, (int)mdx_bonded_integrate_ok(h), mdx_nb_variant(h), mdx_nb_wpt_half(h, h->T), h->T);
+    if (h->onepass_refused || h->dd || !h->dual_on || !h->path_split || !h->d.force_b) return false;
+    if (mdx_nb_variant(h) != 5 || h->integrator != MDX_INTEGRATOR_VERLET_VELOCITY || mdx_has_constraints(h) || h->n_vsites != 0 || h->pme_on ||
+        h->have_ext || h->n_local != h->N || h->alch_on || h->d.posq_alt == nullptr) return false;
+    if (wpt == 1 && !mdx_bonded_integrate_ok(h)) return false;
+    if (h->profile && h->profile_level < 2) return false;      // (event brackets around every kernel count launches per kind: they keep the separate passes)
+    // the pair kernel's flavours that exist in this form (mdx_nonbonded_impl.h NB_STEP): orthorhombic periodic cells, not the softened Coulomb
+    NbParams p; int mode = CM_SHIFTED; bool geom = false, samecut = false;
+    mdx_fill_nb_params(h, p, &mode, &geom, &samecut);
+    return !geom && mode != CM_SOFT;
+}
+
 int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uint32_t thr_bits, int part) {
     const mdx_config& c = h->cfg;
     NbArgs a{};
@@ -162,6 +185,25 @@ int mdx_launch_nonbonded(mdx_handle* h, bool energy, const uint32_t* d_gate, uin
     if (fuse_bonded && a.inner && part == 0 && mdx_bonded_wanted(h) && !h->bonded_deferred && (!h->profile || h->profile_level >= 2)) {
         a.b_S = h->S; a.b_role_off = h->d.role_off_s; a.b_roles = h->d.role_rec_s; a.b_prm = h->d.role_prm;
         mdx_fill_bonded_params(h, a.b_p);
+    }
+    if (h->onepass.fprev && a.inner && part == 0 && !energy) {      // one launch per step (mdx_step "onepass")
+        const OnePassNow& o = h->onepass;
+        a.posq = o.yin; a.force = o.fcur;
+        a.st_fprev = o.fprev; a.st_yout = o.yout; a.st_fnext = o.fnext; a.st_vel = h->d.vel; a.st_dt = o.dt; a.st_last = o.last ? 1u : 0u; a.st_kick = o.first ? 0.5f : 1.0f;
+        {   // MDX_ONEPASS_GRANT=x (tests): scales what the words grant the unknown kick; negative: the words under-estimate, launches contradict them
+            static const float grant = [] { const char* e = std::getenv("MDX_ONEPASS_GRANT"); return e ? (float)std::atof(e) : 1.0f; }();
+            a.st_grant = grant;
+        }
+        a.st_disp_out = o.disp_out; a.st_prune_out = o.prune_out; a.st_viol = o.viol;
+        a.st_path_thr = 0.5f * h->inner_skin * (1.0f - 1.0e-4f);
+        a.b_S = 0; a.b_role_off = nullptr;
+        if (mdx_bonded_wanted(h)) {      // one wave per tile: the tile's wave evaluates its atoms' roles itself; eight: extra workgroups (b_S)
+            a.b_role_off = h->d.role_off_s; a.b_roles = h->d.role_rec_s; a.b_prm = h->d.role_prm;
+            mdx_fill_bonded_params(h, a.b_p);
+            if (mdx_nb_wpt_half(h, a.T) != 1) a.b_S = h->S;
+        }
+        h->force_zeroed = true;          // (the launch before this one - or the chunk's opening pass - zeroed the buffer this one accumulates into)
+        ++h->onepass_launches;
     }
     int mode = CM_SHIFTED; bool geom = false, samecut = false;
     mdx_fill_nb_params(h, a.p, &mode, &geom, &samecut);

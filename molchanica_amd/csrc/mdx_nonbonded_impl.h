@@ -222,7 +222,11 @@ __device__ __forceinline__ float dpp_xadd(float v) {
 // The body of the cluster kernel.  DUAL here is 0, 1 or 2; the __global__ wrapper below owns the LDS arrays and, for the
 // merged dual-list launch (DUAL 3), picks the inner-walk or the pruning body at run time: one launch per step instead
 // of a pair of which the device runs one (the gated-off twin cost ~4 us per step - 5 % of a 23 k-atom step).
-template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF, bool ALCH, int DUAL, int BW>
+// STEP (round 6, "one launch per step": NbArgs::st_*): the tile's wave first FINISHES THE LAST STEP for its 64 atoms - position x = Y + w F
+// from the two rows every reader uses (mdx_bonded_dev.h step_pos), full kick, the next step's Y, path length, the words that gate the next
+// launch - then evaluates the pairs at x as below, j-atoms reconstructed from the same two rows, and its atoms' bonded roles.  The separate
+// bonded + kick + drift pass (35 us of a 513 us step at 1 M atoms, 112 B per atom) rides inside this compute-bound launch instead.
+template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF, bool ALCH, int DUAL, int BW, bool STEP = false>
 __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owned_prune, float4 (*s_xyzq)[64], float2 (*s_lj)[64],
                                                 float (*s_red)[3][64], float (*s_ownj)[64], float4 (*s_g)[64],
                                                 unsigned long long (*s_mask)[64], const float4* __restrict__ etab = nullptr) {
@@ -251,6 +255,93 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
     const int ii = lane & 7, jj = lane >> 3;
 
     float xi[8], yi[8], zi[8], qi[8], sgi[8], epi[8], fx[8], fy[8], fz[8];
+    if constexpr (STEP) {
+        static_assert(HALF && !ENERGY && !ALCH && DUAL != 0, "one launch per step: half list, dual list");
+        // lane = slot.  Every wave of the tile reconstructs the tile's positions (it needs them as i-atoms); the tile's FIRST wave also
+        // finishes the last step for them: kick, next Y, path length, the words of the next launch.
+        const uint32_t s = t * MDX_TILE + lane;
+        const float4 Y = a.posq[s], Fp = a.st_fprev[s];
+        const float4 x = step_pos(Y, Fp);        // (static and dummy slots carry w = 0)
+        if (part == 0 && t_ok) {
+            float4 v = a.st_vel[s];
+            float d2w = 0.f, pw = 0.f;       // what this lane contributes to the words of the NEXT launch
+            bool viol = false;
+            if (v.w != 0.f) {   // w = 418.4/m; 0 marks static and dummy slots
+                // (the chunk's first launch finishes a step that opens with a HALF kick: its force rows carry w / 2, st_kick is 0.5)
+                const float w = Fp.w, kdt = a.st_kick * a.st_dt * v.w;
+                const float4 Fm = a.st_fnext[s];                                // the forces of the stage before Fp's (the buffer this launch zeroes)
+                const float kx = w * Fp.x, ky = w * Fp.y, kz = w * Fp.z;       // the kick's share of this step's displacement
+                const float sx_ = fmaf(a.st_dt, v.x, kx), sy_ = fmaf(a.st_dt, v.y, ky), sz_ = fmaf(a.st_dt, v.z, kz);      // x - x(previous stage)
+                v.x = fmaf(kdt, Fp.x, v.x); v.y = fmaf(kdt, Fp.y, v.y); v.z = fmaf(kdt, Fp.z, v.z);
+                float path;
+                const float4 r = a.ref[s];
+                const float dpr = __builtin_sqrtf((x.x - r.x) * (x.x - r.x) + (x.y - r.y) * (x.y - r.y) + (x.z - r.z) * (x.z - r.z));      // |x - ref|, exactly
+                if (DUAL == 2) {   // this launch is a pruning pass: the inner list it writes is exact at x, paths count from here
+                    path = 0.f;
+                    a.dprune[s] = dpr;
+                } else path = a.path[s] + __builtin_sqrtf(sx_ * sx_ + sy_ * sy_ + sz_ * sz_);
+                a.path[s] = path;
+                // The words that let this launch run were raised by the launch before it from Y and a GRANT for the kick it could not know
+                // (below).  Now the stage is known exactly: had the words been raised from it, would this launch walk the inner list although
+                // the path budget is spent, or run at all although the list is stale?  Then its forces are not to be trusted - the host
+                // takes the step back to a list rebuild (rare: the atom that decides the word must also be the one that outran its grant).
+                {
+                    float dt2 = dpr * dpr;
+                    if (!(dt2 < 1.0e30f)) dt2 = 3.0e38f;
+                    viol = (DUAL != 2 && !(path <= a.st_path_thr)) || __float_as_uint(dt2) > a.thr_bits;
+                }
+                float4 yo = x;
+                if (!a.st_last) {
+                    yo.x = fmaf(a.st_dt, v.x, x.x); yo.y = fmaf(a.st_dt, v.y, x.y); yo.z = fmaf(a.st_dt, v.z, x.z);
+                    // The next stage is yo + w F(x), F not known before this launch ends: the words that gate the next launch grant the
+                    // kick w (|2 Fp - Fm| + |Fp - Fm| + 30 kcal/mol/A) - the force extrapolated from the last two stages and room for its
+                    // curvature; ~0.01 A for a water hydrogen at 0.5 fs - and the next launch checks the words against what the stage turned out to be.
+                    const float wf = a.st_dt * a.st_dt * v.w;
+                    const float ex = 2.f * Fp.x - Fm.x, ey = 2.f * Fp.y - Fm.y, ez = 2.f * Fp.z - Fm.z;
+                    const float gx = Fp.x - Fm.x, gy = Fp.y - Fm.y, gz = Fp.z - Fm.z;
+                    const float m = a.st_grant * wf * (__builtin_sqrtf(ex * ex + ey * ey + ez * ez) + __builtin_sqrtf(gx * gx + gy * gy + gz * gz) + 30.f);
+                    pw = path + a.st_dt * __builtin_sqrtf(v.x * v.x + v.y * v.y + v.z * v.z) + m;
+                    const float db = __builtin_sqrtf((yo.x - r.x) * (yo.x - r.x) + (yo.y - r.y) * (yo.y - r.y) + (yo.z - r.z) * (yo.z - r.z)) + m;
+                    d2w = db * db;
+                    if (!(d2w < 1.0e30f)) d2w = 3.0e38f;      // NaN / inf -> huge, forces a stop
+                }
+                a.st_vel[s] = v;
+                a.st_yout[s] = yo;
+            } else a.st_yout[s] = Y;
+            a.st_fnext[s] = make_float4(0.f, 0.f, 0.f, a.st_dt * a.st_dt * v.w);
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) { d2w = fmaxf(d2w, __shfl_xor(d2w, m)); pw = fmaxf(pw, __shfl_xor(pw, m)); }
+            const bool any_viol = __any(viol);
+            if (lane == 0) {
+                if (a.st_disp_out && __float_as_uint(d2w) > a.thr_bits) atomicMax(a.st_disp_out, __float_as_uint(d2w));
+                if (a.st_prune_out && !(pw <= a.st_path_thr)) *a.st_prune_out = 1u;
+                if (any_viol) { *a.st_viol = 1u; if (a.st_disp_out) atomicMax(a.st_disp_out, __float_as_uint(1.0e20f)); }      // (the launches behind this one stay no-ops)
+            }
+            // one wave per tile: the bonded roles of this tile's atoms at x as well, partners through the same two rows; the force leaves
+            // right away (three atomics per atom into the buffer this launch accumulates - nothing of this stays live across the chunk
+            // loop).  (Eight waves per tile: the roles ride in extra workgroups of the launch, bonded_workgroup.)
+            if (WPT == 1 && a.b_role_off) {
+                const uint32_t rb = a.b_role_off[s], re = a.b_role_off[s + 1];
+                if (re > rb) {
+                    float bx = 0.f, by = 0.f, bz = 0.f;
+                    RoleEnergies en;
+                    for (uint32_t k = rb; k < re; ++k) role_eval_step<false>(a.b_roles[k], a.b_prm, x, a.posq, a.st_fprev, a.b_p, bx, by, bz, en);
+                    float* const fb_ = reinterpret_cast<float*>(a.force) + (size_t)s * 4;
+                    unsafeAtomicAdd(fb_, bx); unsafeAtomicAdd(fb_ + 1, by); unsafeAtomicAdd(fb_ + 2, bz);
+                }
+            }
+        }
+        s_xyzq[wave][lane] = x;
+        WAVE_LDS_SYNC();
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) {
+            const float4 pi = s_xyzq[wave][ci * MDX_CLUSTER + ii];
+            const float2 li = a.lj[t * MDX_TILE + ci * MDX_CLUSTER + ii];
+            xi[ci] = pi.x; yi[ci] = pi.y; zi[ci] = pi.z; qi[ci] = pi.w; sgi[ci] = li.x; epi[ci] = li.y;
+            fx[ci] = 0.f; fy[ci] = 0.f; fz[ci] = 0.f;
+        }
+        WAVE_LDS_SYNC();
+    } else {
 #pragma unroll
     for (int ci = 0; ci < 8; ++ci) {
         const uint32_t s = t * MDX_TILE + ci * MDX_CLUSTER + ii;
@@ -258,6 +349,7 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
         const float2 li = a.lj[s];
         xi[ci] = pi.x; yi[ci] = pi.y; zi[ci] = pi.z; qi[ci] = pi.w; sgi[ci] = li.x; epi[ci] = li.y;
         fx[ci] = 0.f; fy[ci] = 0.f; fz[ci] = 0.f;
+    }
     }
     ListCounts cnt = a.counts[t_ok ? t : 0];
     if (!t_ok) { cnt.n_masked = 0; cnt.n_plain = 0; }
@@ -286,7 +378,7 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
     // s_waitcnt vmcnt(0) per chunk sits where the data is a whole chunk old and the entry loop has
     // no vector-memory instruction in it (a mask fetched at its point of use - or an atomic issued
     // per entry - drags a vmcnt(0) into the loop and serialises the wave on memory latency).
-    float4 nj = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 nj = make_float4(0.f, 0.f, 0.f, 0.f), nf = nj;      // (STEP: nf = the force row beside the j-atom's Y)
     float2 nl = make_float2(0.f, 0.f);
     uint32_t ny = 13, njc = 0;
     float nown = 0.f;
@@ -298,6 +390,7 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
         if ((uint32_t)part + WPT < nchunks) ent_n = entries[e0 + (part + WPT) * 8 + (lane >> 3)];
         const uint32_t js = ent.x * MDX_CLUSTER + (lane & 7);
         nj = a.posq[js]; nl = a.lj[js]; ny = ent.y; njc = ent.x;
+        if (STEP) nf = a.st_fprev[js];
         if (ENERGY && HALF) nown = a.energy_all ? 1.0f : (float)((a.slot_flags[js] >> 1) & 1u);
     }
     float* const fbase = reinterpret_cast<float*>(a.force);
@@ -342,6 +435,7 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
         {   // image shift, then park in LDS
             const uint32_t code = ny & 31u;
             const int kx = (int)(code % 3u) - 1, ky = (int)((code / 3u) % 3u) - 1, kz = (int)(code / 9u) - 1;
+            if (STEP) nj = step_pos(nj, nf);
             nj.x += (float)kx * a.p.shift[0];
             nj.y += (float)ky * a.p.shift[1];
             nj.z += (float)kz * a.p.shift[2];
@@ -353,6 +447,7 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
         if (c + WPT < nchunks) {
             const uint32_t js = ent_n.x * MDX_CLUSTER + (lane & 7);
             nj = a.posq[js]; nl = a.lj[js]; ny = ent_n.y; njc = ent_n.x;
+            if (STEP) nf = a.st_fprev[js];
             if (ENERGY && HALF) nown = a.energy_all ? 1.0f : (float)((a.slot_flags[js] >> 1) & 1u);
             if (c + 2 * WPT < nchunks) ent_n = entries[e0 + (c + 2 * WPT) * 8 + (lane >> 3)];
         }
@@ -501,7 +596,7 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
     }
     if (prune) {
         // path lengths count from this pass (a boundary pass asked for by the ghosts alone restarts the ghosts only)
-        if (part == 0 && t_ok && (owned_prune || !(a.slot_flags[t * MDX_TILE + lane] & 2u))) {
+        if (!STEP && part == 0 && t_ok && (owned_prune || !(a.slot_flags[t * MDX_TILE + lane] & 2u))) {      // (STEP: the tile's wave did this where it had x)
             const uint32_t s = t * MDX_TILE + lane;
             if (a.path) {      // path split: the accumulator restarts, and the displacement reached so far is kept for the drift pass's bound
                 const float4 x = a.posq[s], r = a.ref[s];
@@ -559,18 +654,21 @@ __device__ __forceinline__ void nb_cluster_body(const NbArgs& a, const bool owne
 // lanes per atom as in bonded_gather_kernel (mdx_bonded.hip); the force leaves through atomics, as the pair kernel's
 // does.  (At 1 M atoms the same arrangement costs more than it hides - the two compete for the memory-side atomic
 // path, DESIGN.md section 4 - so the large-system classes keep the separate launch.)
+template <bool STEP = false>
 __device__ __forceinline__ void bonded_workgroup(const NbArgs& a, uint32_t wg, uint32_t wg_threads) {
     const uint32_t tid = wg * wg_threads + threadIdx.x;
     const uint32_t s = tid >> 2, q4 = tid & 3u;
     if (s >= a.b_S) return;
     const uint32_t rb = a.b_role_off[s], re = a.b_role_off[s + 1];
     if (re <= rb) return;      // quad-uniform
-    const float4 self = a.posq[s];
+    // (one launch per step: positions in the step form, every atom reconstructed from its two rows - mdx_bonded_dev.h step_pos)
+    const float4 self = STEP ? step_pos(a.posq[s], a.st_fprev[s]) : a.posq[s];
     float fx = 0.f, fy = 0.f, fz = 0.f;
     RoleEnergies en;
     for (uint32_t k = rb + q4; k < re; k += 4) {
         const RoleRec r = a.b_roles[k];
-        role_eval<false>(r, a.b_prm, self, a.posq, a.b_p, fx, fy, fz, en);
+        if (STEP) role_eval_step<false>(r, a.b_prm, self, a.posq, a.st_fprev, a.b_p, fx, fy, fz, en);
+        else role_eval<false>(r, a.b_prm, self, a.posq, a.b_p, fx, fy, fz, en);
     }
     fx = dpp_xadd<0xB1>(fx); fy = dpp_xadd<0xB1>(fy); fz = dpp_xadd<0xB1>(fz);   // lane ^ 1
     fx = dpp_xadd<0x4E>(fx); fy = dpp_xadd<0x4E>(fy); fz = dpp_xadd<0x4E>(fz);   // lane ^ 2
@@ -580,6 +678,9 @@ __device__ __forceinline__ void bonded_workgroup(const NbArgs& a, uint32_t wg, u
     }
 }
 
+#ifndef NB_STEP_WAVES3
+#define NB_STEP_WAVES3 0      // one launch per step: 1 = three waves per SIMD (168 VGPRs) instead of four (128)
+#endif
 #ifndef NB_MERGED_NOINLINE
 #define NB_MERGED_NOINLINE 0
 #endif
@@ -591,18 +692,27 @@ __device__ __attribute__((noinline)) void nb_cluster_body_call(const NbArgs& a, 
 }
 
 template <bool ENERGY, int COUL, bool GEOM, bool SAMECUT, int WPT, bool HALF, bool ALCH = false, int DUAL = 0, bool FB = false, int SPLIT = 1>
-__global__ __launch_bounds__((SPLIT > 1 ? WPT / SPLIT : (WPT > NB_WAVES ? WPT : NB_WAVES)) * 64, ((HALF && NB_HALF_FLUSH) || ENERGY) ? 3 : 4) void nb_cluster_kernel(NbArgs a) {
-    if (a.gate && *a.gate > a.thr_bits) return;
+__global__ __launch_bounds__((SPLIT > 1 ? WPT / SPLIT : (WPT > NB_WAVES ? WPT : NB_WAVES)) * 64, ((HALF && NB_HALF_FLUSH) || ENERGY || (DUAL == 5 && NB_STEP_WAVES3)) ? 3 : 4) void nb_cluster_kernel(NbArgs a) {
+    if (a.gate && *a.gate > a.thr_bits) {
+        // (one launch per step: the stale word travels on, the launches behind this one stay no-ops too)
+        if ((DUAL == 5 || DUAL == 6) && a.st_disp_out && blockIdx.x == 0 && threadIdx.x == 0) atomicMax(a.st_disp_out, *a.gate);
+        return;
+    }
+    // one launch per step: DUAL 5 = the merged launch of the one-wave class, the tile's wave evaluates its atoms' roles; DUAL 6 = the merged
+    // launch of the eight-waves class with the bonded gather in extra workgroups (as DUAL 4)
+    static_assert(DUAL != 5 || (WPT == 1 && !FB && SPLIT == 1), "one launch per step: the one-wave-per-tile class");
+    static_assert(DUAL != 6 || (WPT == 8 && !FB), "one launch per step: the eight-waves-per-tile class");
+    constexpr bool STEP = DUAL == 5 || DUAL == 6;
     static_assert(DUAL == 0 || (HALF && !ENERGY), "the dual list exists for the half-list force kernel");
     static_assert(!FB || DUAL != 0, "the bonded workgroups ride with the dual-list launches");
     constexpr int BW = SPLIT > 1 ? WPT / SPLIT : (WPT > NB_WAVES ? WPT : NB_WAVES);       // waves per workgroup
-    if ((DUAL == 4 || FB) && blockIdx.x >= a.pair_grid) {
+    if ((DUAL == 4 || DUAL == 6 || FB) && blockIdx.x >= a.pair_grid) {
         // (a twin launch: the bonded workgroups run in whichever of the two the device executes)
         if (DUAL == 1 || DUAL == 2) {
             const bool want_prune = (a.force_prune | *a.prune_flag) != 0u || (a.prune_flag2 && *a.prune_flag2 != 0u);
             if (want_prune != (DUAL == 2)) return;
         }
-        bonded_workgroup(a, blockIdx.x - a.pair_grid, BW * 64);
+        bonded_workgroup<STEP>(a, blockIdx.x - a.pair_grid, BW * 64);
         return;
     }
     __shared__ float4 s_xyzq[BW][64];
@@ -631,8 +741,8 @@ __global__ __launch_bounds__((SPLIT > 1 ? WPT / SPLIT : (WPT > NB_WAVES ? WPT : 
             if (want_prune) nb_cluster_body_call<ENERGY, COUL, GEOM, SAMECUT, WPT, HALF, ALCH, 2, BW>(a, owned_prune, s_xyzq, s_lj, s_red, s_ownj, s_g, s_mask, etab);
             else nb_cluster_body_call<ENERGY, COUL, GEOM, SAMECUT, WPT, HALF, ALCH, 1, BW>(a, owned_prune, s_xyzq, s_lj, s_red, s_ownj, s_g, s_mask, etab);
 #else
-            if (want_prune) nb_cluster_body<ENERGY, COUL, GEOM, SAMECUT, WPT, HALF, ALCH, 2, BW>(a, owned_prune, s_xyzq, s_lj, s_red, s_ownj, s_g, s_mask, etab);
-            else nb_cluster_body<ENERGY, COUL, GEOM, SAMECUT, WPT, HALF, ALCH, 1, BW>(a, owned_prune, s_xyzq, s_lj, s_red, s_ownj, s_g, s_mask, etab);
+            if (want_prune) nb_cluster_body<ENERGY, COUL, GEOM, SAMECUT, WPT, HALF, ALCH, 2, BW, STEP>(a, owned_prune, s_xyzq, s_lj, s_red, s_ownj, s_g, s_mask, etab);
+            else nb_cluster_body<ENERGY, COUL, GEOM, SAMECUT, WPT, HALF, ALCH, 1, BW, STEP>(a, owned_prune, s_xyzq, s_lj, s_red, s_ownj, s_g, s_mask, etab);
 #endif
         } else {
             if (want_prune != (DUAL == 2)) return;
@@ -686,6 +796,27 @@ void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samecut) {
         o[5] = (uint32_t)split; o[6] = (uint32_t)fb; o[7] = a.tile_order ? a.t_count : a.T;
     };
     // dual list: the inner-walk kernel and the pruning kernel back to back, the device runs exactly one of them
+#define NB_STEP(G, S)                                                                                                 \
+    do {                                                                                                               \
+        if constexpr (!ENERGY && !G && COUL != CM_SOFT) {                                                              \
+            if (wpt == 1 && half && a.inner) {                                                                         \
+                hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, false, S, 1, true, false, 5>), g, b, lds_pad, h->stream, a); \
+                note(5, 1, 1, 0);                                                                                      \
+            } else if (wpt == 8 && half && a.inner && split2) {   /* a tile = two workgroups of four waves */          \
+                NbArgs af = a;                                                                                         \
+                const uint32_t nb2 = (a.tile_order ? a.t_count : a.T) * 2u;                                            \
+                af.pair_grid = ((nb2 + 7) / 8) * 8;                                                                    \
+                const dim3 gf(af.pair_grid + (a.b_S ? (uint32_t)(((size_t)a.b_S * 4 + 255) / 256) : 0u)), bf(256);     \
+                hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, false, S, 8, true, false, 6, false, 2>), gf, bf, lds_pad, h->stream, af); \
+                note(6, 8, 2, 0);                                                                                      \
+            } else if (wpt == 8 && half && a.inner) {                                                                  \
+                NbArgs af = a; af.pair_grid = grid;                                                                    \
+                const dim3 gf(grid + (a.b_S ? (uint32_t)(((size_t)a.b_S * 4 + bw * 64 - 1) / (bw * 64)) : 0u));        \
+                hipLaunchKernelGGL((nb_cluster_kernel<false, COUL, false, S, 8, true, false, 6>), gf, b, lds_pad, h->stream, af); \
+                note(6, 8, 1, 0);                                                                                      \
+            } else h->onepass_refused = true;                                                                          \
+        } else h->onepass_refused = true;                                                                              \
+    } while (0)
 #define NB_DUAL(G, S, D)                                                                                              \
     do {                                                                                                               \
         if (ENERGY) break;                                                                                             \
@@ -708,6 +839,7 @@ void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samecut) {
         note(0, var == 1 ? 0 : ((h->alch_on && wpt != 8) ? 4 : wpt), 1, 0);   /* (the dual-list branches below overwrite it) */ \
         if (h->alch_on && wpt == 8) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 8, true, COUL != CM_EWALD_TAB>), g, b, lds_pad, h->stream, a); \
         else if (h->alch_on) hipLaunchKernelGGL((nb_cluster_kernel<ENERGY, COUL, G, S, 4, true, COUL != CM_EWALD_TAB>), g, b, lds_pad, h->stream, a); \
+        else if (a.st_fprev) { NB_STEP(G, S); }                                                                    \
         else if (var == 1) hipLaunchKernelGGL((nb_tile_kernel<ENERGY, COUL, G, S>), g, b, lds_pad, h->stream, a);     \
         else if (half && a.inner && dual_merged && wpt == 8 && split2 && !ENERGY) {   /* a tile = two workgroups of four waves */ \
             NbArgs af = a;                                                                                         \
@@ -737,5 +869,6 @@ void launch_variant(mdx_handle* h, const NbArgs& a, bool geom, bool samecut) {
     else      { if (samecut) NB_LAUNCH(false, true); else NB_LAUNCH(false, false); }
 #undef NB_LAUNCH
 #undef NB_DUAL
+#undef NB_STEP
 }
 

@@ -43,6 +43,19 @@ struct NbArgs {
     uint32_t pair_grid, b_S;
     const uint32_t* b_role_off; const RoleRec* b_roles; const float4* b_prm;
     BondedParams b_p;
+    // One launch per step (round 6; DUAL 5, one wave per tile, single-device handles without constraints: mdx_step "onepass").  posq = Y
+    // (mdx_bonded_dev.h step_pos), st_fprev = the complete forces of the previous position stage with .w = dt^2 418.4/m, force = the buffer
+    // this launch accumulates into (zeroed by the launch before it).  The tile's wave first finishes the last step for its 64 atoms -
+    // x = Y + w F, full kick, next Y - then evaluates pairs and its atoms' bonded roles (b_role_off / b_roles / b_prm / b_p) at x;
+    // j-atoms and bonded partners are reconstructed from the same two rows.  null st_fprev: not this flavour.
+    const float4* st_fprev; float4* st_yout; float4* st_fnext; float4* st_vel;
+    float st_dt, st_path_thr;
+    uint32_t st_last;             // 1: the last launch of a chunk writes x itself (no pre-drift) and raises no words
+    float st_grant;               // scale of the kick the words grant (1; tests make it negative to drive the way back)
+    float st_kick;                // 0.5: the first launch of a chunk finishes a step that opens with a half kick (its force rows carry w / 2); else 1
+    uint32_t* st_disp_out;        // ctl.disp2[s + 2]: (bound of |x - ref| at the NEXT position stage)^2, raised only above thr_bits
+    uint32_t* st_prune_out;       // ctl.prune[s + 2]
+    uint32_t* st_viol;            // ctl.viol[s]: the stage this launch found contradicts the words that let it run - the host takes the step back to a list rebuild
 };
 
 enum { CM_SHIFTED = 0, CM_RF = 1, CM_EWALD = 2, CM_SOFT = 3,

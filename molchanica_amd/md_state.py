@@ -466,12 +466,13 @@ class MdState:
 
     def pair_launch_info(self) -> dict:
         """Which pair-kernel instantiation ran last: {"step": {...}, "any": {...}} (include/mdx.h: mdx_pair_launch_info)."""
-        out = (C.c_uint32 * 20)()
+        out = (C.c_uint32 * 24)()
         _check(load_library().mdx_pair_launch_info(self._h, out))
         keys = ("waves_per_tile", "dual", "half", "coulomb", "energy", "workgroups_per_tile", "bonded_workgroups", "tiles")
         return {"step": dict(zip(keys, (int(v) for v in out[0:8]))), "any": dict(zip(keys, (int(v) for v in out[8:16]))),
                 "inner_lists_from_rebuilds": int(out[16]), "last_rebuild_wrote_the_inner_list": bool(out[17]),
-                "water_step_launches": int(out[18]), "water_step_mixed_launches": int(out[19])}
+                "water_step_launches": int(out[18]), "water_step_mixed_launches": int(out[19]),
+                "one_launch_steps": int(out[20]), "kicks_beyond_grant": int(out[21])}
 
     def skin(self):
         """-> (Verlet skin in force, still tuning?)  (MdConfig.skin == 0 lets the library choose it)."""

@@ -65,7 +65,10 @@ def test_c5_water1m_step_loop_forces_against_the_oracle(mdx, orc):
         md.step(dt, None, 20)
         info = md.pair_launch_info()["step"]
         # the instantiation BENCH_r05.json names: one wave per tile, half list, merged dual-list body, shifted cutoff, force flavour
-        assert (info["waves_per_tile"], info["dual"], info["half"], info["coulomb"], info["energy"], info["workgroups_per_tile"]) == (1, 3, 1, 0, 0, 1), info
+        # (round 6: dual 5 = the same merged body with the previous step's kick + drift and the bonded roles inside - one launch per step)
+        dual = 5 if os.environ.get("MDX_ONEPASS", "1") == "2" else 3      # (the one-wave class takes one launch per step only under MDX_ONEPASS=2: measured slower)
+        assert (info["waves_per_tile"], info["dual"], info["half"], info["coulomb"], info["energy"], info["workgroups_per_tile"]) == (1, dual, 1, 0, 0, 1), info
+        assert (md.pair_launch_info()["one_launch_steps"] >= 15) == (dual == 5)
         assert info["tiles"] >= 12000
         xg, vg = md.positions().astype(np.float64), md.velocities().astype(np.float64)
         # (a) the oracle's own 20 steps from the same state (fp64 state, cell search)
@@ -126,7 +129,7 @@ def test_mid_size_classes_step_loop_forces_against_the_oracle(mdx, orc, n_side, 
         step_loop_forces_vs_oracle(md, orc, s, cfg, f"water_box({n_side}) after a rebuild", slack_rel=2e-5)
 
 
-@pytest.mark.parametrize("wpt,fused", [(1, False), (2, False), (4, False), (8, False), (1, True), (2, True), (1, "inner")])
+@pytest.mark.parametrize("wpt,fused", [(1, False), (2, False), (4, False), (8, False), (1, True), (2, True), (1, "inner"), (1, "onepass")])
 def test_every_waves_per_tile_instantiation_against_the_oracle(wpt, fused):
     """MDX_WPT is read once per process: each value in a child (tests/timed_body_child.py).  `fused`: MDX_WPT8_BELOW=32 also
     selects the large classes' fused bonded + kick + drift pass - with MDX_WPT=1 the complete water1M arrangement on 12 k atoms."""
@@ -134,6 +137,8 @@ def test_every_waves_per_tile_instantiation_against_the_oracle(wpt, fused):
     env["MDX_WPT"] = str(wpt)
     if fused:
         env["MDX_WPT8_BELOW"] = "32"
+    if fused == "onepass":    # ... and one launch per step in the one-wave class (body 5; off by default there: slower at 1 M atoms)
+        env["MDX_ONEPASS"] = "2"
     if fused == "inner":      # ... and the one-wave pruning pass of the list rebuild, which then writes the inner list itself (water1M's path)
         env["MDX_PRUNE_MW_BELOW"] = "0"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "timed_body_child.py"), str(wpt)] + ([str(fused).replace("True", "fused")] if fused else []),

@@ -9,7 +9,7 @@ for rep in 1 2; do
     python3 - "$L" gpurun_out/$TAG/ab_${L}_$rep.json <<'PY'
 import json, sys
 j = json.load(open(sys.argv[2]))
-print(sys.argv[1], round(j["steps_per_s"], 1), {k: round(v, 4) for k, v in j["kernel_ms"].items()})
+print(sys.argv[1], round(j["steps_per_s"], 1), {k: (round(v, 4) if v is not None else None) for k, v in j["kernel_ms"].items()})
 PY
   done
 done
