@@ -344,6 +344,8 @@ static int create_impl(const mdx_system* s, const mdx_config* c, int device, mdx
         h->n_roles = R;
         h->n_roles_excl = 0;
         for (const RoleRec& r : recs) h->n_roles_excl += (r.meta & 0xFu) == ROLE_EWALD_EXCL ? 1u : 0u;
+        h->n_roles_dih = 0;
+        for (const RoleRec& r : recs) h->n_roles_dih += ((r.meta & 0xFu) != ROLE_BOND && (r.meta & 0xFu) != ROLE_ANGLE) ? 1u : 0u;
         if (prm_overflow) FAIL(MDX_EPARAM, "more than 16.7 M distinct bonded parameter sets");
         MDX_TRY(upload_vec(&d.role_prm, prm_tab, st));
         MDX_TRY(upload_vec(&d.role_off_o, cnt, st)); MDX_TRY(upload_vec(&d.role_rec_o, recs, st));

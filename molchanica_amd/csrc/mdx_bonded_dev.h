@@ -31,20 +31,23 @@ struct RoleEnergies { double bond = 0.0, angle = 0.0, dih = 0.0, lj14 = 0.0, c14
 // virial are credited once, by the atom in role 0.
 // role_compute: the arithmetic, with the term's first two partners (q0 = posq[r.p[0]], q1 = posq[r.p[1]]) already loaded -
 // the fused bonded + kick + drift pass issues the partner loads of an atom's first roles together, ahead of the arithmetic.
-template <bool ENERGY>
+// NODIH: the caller knows the system has bond and angle roles only (a box of flexible water): the dihedral branch - a third of the
+// function's registers -, the 1-4 pairs and the Ewald exclusion corrections are compiled out (the fused bonded + kick + drift pass:
+// 93 -> 67 VGPRs, five -> seven waves per SIMD)
+template <bool ENERGY, bool NODIH = false>
 __device__ __forceinline__ void role_compute(const RoleRec& r, const float4 prm4, const float4 self, const float4 q0, const float4 q1,
                                              const float4* __restrict__ posq,
                                              const BondedParams& p, float& fx, float& fy, float& fz, RoleEnergies& en,
                                              const float4* __restrict__ fstep = nullptr);
 
-template <bool ENERGY>
+template <bool ENERGY, bool NODIH = false>
 __device__ __forceinline__ void role_eval(const RoleRec& r, const float4* __restrict__ prm_tab, const float4 self,
                                           const float4* __restrict__ posq,
                                           const BondedParams& p, float& fx, float& fy, float& fz, RoleEnergies& en) {
     const uint32_t kind = r.meta & 0xFu;
     const float4 q0 = posq[r.p[0]];
     const float4 q1 = (kind == ROLE_ANGLE || kind == ROLE_DIHEDRAL) ? posq[r.p[1]] : q0;
-    role_compute<ENERGY>(r, prm_tab[r.meta >> 8], self, q0, q1, posq, p, fx, fy, fz, en);
+    role_compute<ENERGY, NODIH>(r, prm_tab[r.meta >> 8], self, q0, q1, posq, p, fx, fy, fz, en);
 }
 
 // (positions in the step form - posq = Y, fstep = the force rows beside it: role_eval_step)
@@ -58,7 +61,7 @@ __device__ __forceinline__ void role_eval_step(const RoleRec& r, const float4* _
     role_compute<ENERGY>(r, prm_tab[r.meta >> 8], self, q0, q1, y, p, fx, fy, fz, en, fstep);
 }
 
-template <bool ENERGY>
+template <bool ENERGY, bool NODIH>
 __device__ __forceinline__ void role_compute(const RoleRec& r, const float4 prm4, const float4 self, const float4 q0, const float4 q1,
                                              const float4* __restrict__ posq,
                                              const BondedParams& p, float& fx, float& fy, float& fz, RoleEnergies& en,
@@ -67,7 +70,7 @@ __device__ __forceinline__ void role_compute(const RoleRec& r, const float4 prm4
     double& e_bond = en.bond; double& e_angle = en.angle; double& e_dih = en.dih; double& e_lj14 = en.lj14;
     double& e_c14 = en.c14; double& e_rec = en.rec; double& e_vir = en.vir;
     const uint32_t kind = r.meta & 0xFu, role = (r.meta >> 4) & 0xFu;
-    if (kind == ROLE_EWALD_EXCL) {
+    if (!NODIH && kind == ROLE_EWALD_EXCL) {
         // the reciprocal sum includes this excluded / 1-4 pair: take erf(beta r)/r out again
         const float3 d = mimg(sub3(self, q0), p);
         const float r2 = dot3(d, d), rinv = rsqrtf(r2), rr = r2 * rinv, br = p.ewald_beta * rr;
@@ -82,7 +85,7 @@ __device__ __forceinline__ void role_compute(const RoleRec& r, const float4 prm4
         const float3 d = mimg(sub3(self, q0), p);
         const float r2 = dot3(d, d);
         float fs;
-        if (kind == ROLE_BOND) {
+        if (NODIH || kind == ROLE_BOND) {
             const float rr = sqrtf(r2), dr = rr - prm[1];
             fs = -2.0f * prm[0] * dr / rr;
             if (ENERGY && role == 0) e_bond += (double)prm[0] * dr * dr;
@@ -126,7 +129,7 @@ __device__ __forceinline__ void role_compute(const RoleRec& r, const float4 prm4
         else if (role == 2) { fx += fk.x; fy += fk.y; fz += fk.z; }
         else { fx -= fi.x + fk.x; fy -= fi.y + fk.y; fz -= fi.z + fk.z; }
         if (ENERGY && role == 0) e_angle += (double)prm[0] * dth * dth;
-    } else {   // ROLE_DIHEDRAL: ordered atoms 0-1-2-3, this lane is atom `role`
+    } else if (!NODIH) {   // ROLE_DIHEDRAL: ordered atoms 0-1-2-3, this lane is atom `role`
         float4 q2 = posq[r.p[2]];
         if (fstep) q2 = step_pos(q2, fstep[r.p[2]]);
         const float4 p0 = role == 0 ? self : q0;

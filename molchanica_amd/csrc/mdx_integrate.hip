@@ -123,7 +123,7 @@ __device__ __forceinline__ void pipe_publish(const FusedArgs& a, uint32_t word) 
     for (uint32_t q = 0; q < a.n_flag; ++q) a.send_buf[a.flag_rows[q]] = make_float4(__uint_as_float(word), 0.f, 0.f, 0.f);
     for (int k = 0; k < 9; ++k) a.pc->m1_shard[k] = 0u;
 }
-template <bool DUAL, bool PIPE>
+template <bool DUAL, bool PIPE, bool NODIH = false>
 __global__ __launch_bounds__(256) void bonded_integrate_kernel(FusedArgs a) {
     uint32_t gate = a.gate_in ? *a.gate_in : 0u;
     if (PIPE && (a.pipe_flags & 1u))       // what the ranks below this one found during the last drift came back with their ghost forces
@@ -165,10 +165,10 @@ __global__ __launch_bounds__(256) void bonded_integrate_kernel(FusedArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < FUSED_PRE; ++i)
-                if (rb + (uint32_t)i < re) role_compute<false>(rr[i], prm[i], p, q0[i], q1[i], a.posq_in, a.p, f.x, f.y, f.z, en);
+                if (rb + (uint32_t)i < re) role_compute<false, NODIH>(rr[i], prm[i], p, q0[i], q1[i], a.posq_in, a.p, f.x, f.y, f.z, en);
             for (uint32_t k = rb + FUSED_PRE; k < re; ++k) {
                 const RoleRec r = a.roles[k];
-                role_eval<false>(r, a.prm, p, a.posq_in, a.p, f.x, f.y, f.z, en);
+                role_eval<false, NODIH>(r, a.prm, p, a.posq_in, a.p, f.x, f.y, f.z, en);
             }
             const float kdt = a.dt * v.w;
             v.x += kdt * f.x; v.y += kdt * f.y; v.z += kdt * f.z;
@@ -423,11 +423,15 @@ int mdx_launch_bonded_integrate(mdx_handle* h, float dt, const uint32_t* d_gate_
     const dim3 g((h->S + 255) / 256), b(256);
     const bool pipe = mdx_dd_pipe_fill(h, a, const_cast<uint32_t*>(d_gate_in));      // decomposed handle, pipelined arrangement: returned ghost forces in, halo pack out
     mdx_prof_begin(h, 5);
+    // no dihedral role in the system (a box of flexible water): the flavour without that branch - 67 VGPRs instead of 93, seven waves per
+    // SIMD instead of five for a pass that lives on loads in flight.  MDX_FUSED_NODIH=0: A/B (read per launch)
+    const char* nd_env = std::getenv("MDX_FUSED_NODIH");
+    const bool nodih = h->n_roles_dih == 0 && !(nd_env && nd_env[0] == '0');
     if (pipe) {
-        if (dual) hipLaunchKernelGGL((bonded_integrate_kernel<true, true>), g, b, 0, h->stream, a);
+        if (dual) { if (nodih) hipLaunchKernelGGL((bonded_integrate_kernel<true, true, true>), g, b, 0, h->stream, a); else hipLaunchKernelGGL((bonded_integrate_kernel<true, true>), g, b, 0, h->stream, a); }
         else hipLaunchKernelGGL((bonded_integrate_kernel<false, true>), g, b, 0, h->stream, a);
     } else {
-        if (dual) hipLaunchKernelGGL((bonded_integrate_kernel<true, false>), g, b, 0, h->stream, a);
+        if (dual) { if (nodih) hipLaunchKernelGGL((bonded_integrate_kernel<true, false, true>), g, b, 0, h->stream, a); else hipLaunchKernelGGL((bonded_integrate_kernel<true, false>), g, b, 0, h->stream, a); }
         else hipLaunchKernelGGL((bonded_integrate_kernel<false, false>), g, b, 0, h->stream, a);
     }
     mdx_prof_end(h);

@@ -294,6 +294,7 @@ struct mdx_handle {
     uint32_t n_bonds = 0, n_angles = 0, n_dih = 0, n_p14 = 0;
     uint32_t n_roles = 0;
     uint32_t n_roles_excl = 0;        // ... of which Ewald exclusion corrections (ROLE_EWALD_EXCL)
+    uint32_t n_roles_dih = 0;         // ... of which neither bond nor angle roles (none: the fused bonded + kick + drift pass runs a flavour without the other branches)
     bool excl_inside_rigid = false;   // every excluded pair lies inside ONE rigid three-site cluster (its virtual site included)
     uint32_t n_groups = 0, n_cons = 0, n_vsites = 0;   // constraint clusters of up to four atoms / constraints / virtual sites
     uint32_t n_star5 = 0; std::vector<ConsStar5> h_star5;   // X-H4 clusters (caller order)
