@@ -58,10 +58,15 @@ for case in range(n_cases):
             md.minimize_energy(150); md.initialize_velocities(300.0, True, seed=3)
             md.set_thermostat(1, 300.0, 0.02, 1); md.step(min(dt, 0.001), None, 150)
             s.pos = md.positions().astype(np.float32); s.vel = md.velocities().astype(np.float32)
+        # (the one-GPU arm keeps the separate kick + drift launch, as decomposed handles do: one launch per step - round 6, small flexible
+        # systems - rounds the drift differently, and under the shifted cutoff's force jump that alone parts two runs by 1e-4 ... 7e-4 A
+        # in 38 steps; this comparison is about the decomposition.  The arrangement itself meets the oracle in tests/fuzz_parity.py.)
+        os.environ["MDX_ONEPASS"] = "0"
         with MdState(s, cfg) as md:
             setup(md)
             e_ref = md.energy(); md.step(dt, None, n_steps)
             p_ref = md.positions().astype(np.float64); e1_ref = md.energy()
+        os.environ.pop("MDX_ONEPASS", None)
         res = run_ranks(s, cfg, world, n_steps, dt=dt, setup=setup)
         r0 = res[0]
         for k in ("lj", "coulomb", "kinetic", "bond", "angle", "coulomb_recip"):

@@ -13,6 +13,14 @@ from molchanica_amd import MdConfig, systems
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _same_arrangement_on_both_sides(monkeypatch):
+    """These tests hold decomposed handles against ONE GPU to tolerances that assume the same rounding on both sides.  Decomposed handles
+    keep the separate kick + drift launch; a small single-GPU handle would by default take one launch per step (round 6), which rounds the
+    drift differently - pinned off here; that arrangement meets the oracle in tests/test_gpu_onepass.py and the parity tests."""
+    monkeypatch.setenv("MDX_ONEPASS", "0")
+
 CFG = dict(lj_cutoff=9.0, coulomb_cutoff=9.0, skin=1.5, chunk_steps=8)
 
 
