@@ -129,7 +129,7 @@ def test_mid_size_classes_step_loop_forces_against_the_oracle(mdx, orc, n_side, 
         step_loop_forces_vs_oracle(md, orc, s, cfg, f"water_box({n_side}) after a rebuild", slack_rel=2e-5)
 
 
-@pytest.mark.parametrize("wpt,fused", [(1, False), (2, False), (4, False), (8, False), (1, True), (2, True), (1, "inner"), (1, "onepass")])
+@pytest.mark.parametrize("wpt,fused", [(1, False), (2, False), (4, False), (8, False), (1, True), (2, True), (1, "inner"), (1, "onepass"), (2, "generic")])
 def test_every_waves_per_tile_instantiation_against_the_oracle(wpt, fused):
     """MDX_WPT is read once per process: each value in a child (tests/timed_body_child.py).  `fused`: MDX_WPT8_BELOW=32 also
     selects the large classes' fused bonded + kick + drift pass - with MDX_WPT=1 the complete water1M arrangement on 12 k atoms."""
@@ -137,6 +137,8 @@ def test_every_waves_per_tile_instantiation_against_the_oracle(wpt, fused):
     env["MDX_WPT"] = str(wpt)
     if fused:
         env["MDX_WPT8_BELOW"] = "32"
+    if fused == "generic":    # ... the fused pass's flavour WITH the dihedral / 1-4 / exclusion branches (a box of water takes the one without by default)
+        env["MDX_FUSED_NODIH"] = "0"
     if fused == "onepass":    # ... and one launch per step in the one-wave class (body 5; off by default there: slower at 1 M atoms)
         env["MDX_ONEPASS"] = "2"
     if fused == "inner":      # ... and the one-wave pruning pass of the list rebuild, which then writes the inner list itself (water1M's path)

@@ -22,7 +22,7 @@ from tests.test_gpu_timed_body import step_loop_forces_vs_oracle  # noqa: E402
 
 def main():
     w = int(sys.argv[1])
-    fused = len(sys.argv) > 2 and sys.argv[2] in ("fused", "inner", "onepass")
+    fused = len(sys.argv) > 2 and sys.argv[2] in ("fused", "inner", "onepass", "generic")
     inner = len(sys.argv) > 2 and sys.argv[2] == "inner"
     assert os.environ.get("MDX_WPT") == str(w)
     assert md_state.device_count() >= 1
